@@ -1,0 +1,489 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by RUNNING THE REFERENCE in this container.
+
+Container-only tool: it puts /root/reference on sys.path (never writing bytecode
+there), applies the three-line CPU shim of SURVEY.md Appendix D (the reference
+hard-codes ``.cuda()`` and raises without CUDA, quant_layers/linear.py:111-121),
+drives the reference's own quantisers / layer searches on small seeded tensors
+and writes *numeric fixtures only* (inputs, seeds, expected outputs) as .npz
+files under tests/golden/.  No reference source, bytecode or pickled reference
+object is ever written into this repository.
+
+Every scoring call inside the reference ends in ``torch.topk`` (or ``argmax``
+for dead paths), so the full per-candidate score vectors are captured by
+wrapping ``torch.topk`` while a search runs: the fixture then pins the oracle at
+every FPCS step (scores, k, returned indices), not only at the final parameters.
+
+Usage:  python tools/make_golden.py            (needs /root/reference)
+"""
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("ADALOG_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+torch.Tensor.cuda = lambda self, *a, **k: self                      # reference hard-codes .cuda()
+torch.cuda.is_available = lambda: True                              # linear.py:113
+torch.cuda.get_device_properties = lambda i: types.SimpleNamespace(total_memory=8 * 2 ** 30)
+
+import quant_layers as RL                      # noqa: E402  (the reference's packages)
+import quantizers as RQ                        # noqa: E402
+from quantizers.adaround import AdaRoundQuantizer as RefAdaRound   # noqa: E402
+from utils.calibrator import QuantCalibrator as RefCalibrator      # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def npy(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy()
+    return np.asarray(t)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrays.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays)")
+
+
+class TopkTrace:
+    """Record (scores, k, dim, indices) of every torch.topk call while active."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __enter__(self):
+        self._orig = torch.topk
+
+        def traced(inp, k, dim=-1, **kw):
+            res = self._orig(inp, k=k, dim=dim, **kw)
+            self.calls.append((inp.detach().clone(), int(k), int(dim), res[1].detach().clone()))
+            return res
+
+        torch.topk = traced
+        return self
+
+    def __exit__(self, *exc):
+        torch.topk = self._orig
+
+    def arrays(self, prefix="trace"):
+        out = {f"{prefix}_n": np.int64(len(self.calls))}
+        for i, (s, k, d, idx) in enumerate(self.calls):
+            out[f"{prefix}_{i:03d}_scores"] = s
+            out[f"{prefix}_{i:03d}_k"] = np.int64(k)
+            out[f"{prefix}_{i:03d}_dim"] = np.int64(d)
+            out[f"{prefix}_{i:03d}_idx"] = idx
+        return out
+
+
+def state(module, prefix="out_"):
+    return {prefix + k.replace(".", "__"): v for k, v in module.state_dict().items()}
+
+
+# ----------------------------------------------------------------------------- quantisers
+def gen_quantizers():
+    g = torch.Generator().manual_seed(1234)
+    arrays = {}
+    for bits in (3, 4, 6, 8):
+        L = 2 ** (bits - 1)
+        # per-tensor asym
+        x = torch.randn(5, 7, 24, generator=g) * 1.7
+        uq = RQ.UniformQuantizer(n_bits=bits, symmetric=False, channel_wise=False)
+        uq.scale = torch.nn.Parameter(torch.tensor([x.abs().max().item() * 2 / (2 * L - 1)]))
+        uq.zero_point = torch.nn.Parameter(torch.tensor([L - 0.3]))           # non-integer zp -> round()
+        uq.inited = True
+        arrays[f"u{bits}_pt_x"] = x
+        arrays[f"u{bits}_pt_scale"] = uq.scale
+        arrays[f"u{bits}_pt_zp"] = uq.zero_point
+        arrays[f"u{bits}_pt_y"] = uq(x)
+        # per-channel (last dim) asym
+        uq = RQ.UniformQuantizer(n_bits=bits, symmetric=False, channel_wise=True)
+        uq.scale = torch.nn.Parameter(torch.rand(24, generator=g) * 0.3 + 0.05)
+        uq.zero_point = torch.nn.Parameter(torch.randint(0, 2 * L, (24,), generator=g).float())
+        uq.inited = True
+        arrays[f"u{bits}_pc_scale"] = uq.scale
+        arrays[f"u{bits}_pc_zp"] = uq.zero_point
+        arrays[f"u{bits}_pc_y"] = uq(x)
+        # per-row weight layout [n_V, rows, 1] on [n_V, rows, I]
+        w = torch.randn(3, 16, 32, generator=g) * 0.2
+        uq = RQ.UniformQuantizer(n_bits=bits, symmetric=False, channel_wise=True)
+        uq.scale = torch.nn.Parameter(torch.rand(3, 16, 1, generator=g) * 0.05 + 0.01)
+        uq.zero_point = torch.nn.Parameter(torch.randint(0, 2 * L, (3, 16, 1), generator=g).float())
+        uq.inited = True
+        arrays[f"u{bits}_row_w"] = w
+        arrays[f"u{bits}_row_scale"] = uq.scale
+        arrays[f"u{bits}_row_zp"] = uq.zero_point
+        arrays[f"u{bits}_row_y"] = uq(w)
+        # per-head [1,H,1,1] on [N,H,S,C]
+        a = torch.randn(3, 2, 7, 8, generator=g)
+        uq = RQ.UniformQuantizer(n_bits=bits, symmetric=False, channel_wise=True)
+        uq.scale = torch.nn.Parameter(torch.rand(1, 2, 1, 1, generator=g) * 0.3 + 0.05)
+        uq.zero_point = torch.nn.Parameter(torch.randint(0, 2 * L, (1, 2, 1, 1), generator=g).float())
+        uq.inited = True
+        arrays[f"u{bits}_head_a"] = a
+        arrays[f"u{bits}_head_scale"] = uq.scale
+        arrays[f"u{bits}_head_zp"] = uq.zero_point
+        arrays[f"u{bits}_head_y"] = uq(a)
+        # symmetric per-tensor
+        uq = RQ.UniformQuantizer(n_bits=bits, symmetric=True, channel_wise=False)
+        uq.scale = torch.nn.Parameter(torch.tensor([x.abs().max().item() / (L - 0.5)]))
+        uq.inited = True
+        arrays[f"u{bits}_sym_scale"] = uq.scale
+        arrays[f"u{bits}_sym_y"] = uq(x)
+        # training (STE) form: forward value identical, gradient is straight-through
+        uq.init_training()
+        xt = x.clone().requires_grad_(True)
+        yt = uq(xt)
+        yt.sum().backward()
+        arrays[f"u{bits}_sym_train_y"] = yt
+        arrays[f"u{bits}_sym_train_gx"] = xt.grad
+    # n_bits == 32 passthrough
+    uq = RQ.UniformQuantizer(n_bits=32)
+    arrays["u32_y"] = uq(x)
+    arrays["u32_x"] = x
+    save("quantizers_uniform", **arrays)
+
+    arrays = {}
+    for bits in (3, 4, 6):
+        L = 2 ** (bits - 1)
+        # post-softmax-like and post-GELU-like inputs exercising all bins
+        sm = torch.softmax(4 * torch.randn(3, 2, 9, 9, generator=g), dim=-1)
+        ge = torch.nn.functional.gelu(2 * torch.randn(4, 7, 40, generator=g))
+        arrays[f"a{bits}_sm_x"] = sm
+        arrays[f"a{bits}_ge_x"] = ge
+        for q in (10, 23, 37, 53, 90, 137):
+            aq = RQ.AdaLogQuantizer(n_bits=bits)
+            aq.scale = torch.nn.Parameter(torch.ones(1, 1, 1, 1))
+            aq.q.data.copy_(torch.tensor([q]))
+            aq.update_table()
+            aq.inited = True
+            arrays[f"a{bits}_q{q}_t1"] = aq.table1
+            arrays[f"a{bits}_q{q}_t2"] = aq.table2
+            arrays[f"a{bits}_q{q}_sm_y"] = aq(sm)
+            aq.scale = torch.nn.Parameter(torch.tensor([0.83]))
+            arrays[f"a{bits}_q{q}_sm_y_s083"] = aq(sm)
+            # training form (no LUT rounding, logarithm.py:88-92)
+            aq.init_training()
+            arrays[f"a{bits}_q{q}_sm_ytrain_s083"] = aq(sm)
+            aq.end_training()
+            sq = RQ.ShiftAdaLogQuantizer(n_bits=bits)
+            sq.scale = torch.nn.Parameter(torch.tensor([ge.max().item() * 0.9 + 0.17]))
+            sq.shift.data.copy_(torch.tensor(0.16997124254703522))
+            sq.q.data.copy_(torch.tensor([q]))
+            sq.update_table()
+            sq.inited = True
+            arrays[f"a{bits}_q{q}_ge_scale"] = sq.scale
+            arrays[f"a{bits}_q{q}_ge_y"] = sq(ge)
+            sq.bias_reparamed.data.copy_(torch.tensor(True))
+            arrays[f"a{bits}_q{q}_ge_y_reparamed"] = sq(ge)
+    save("quantizers_adalog", **arrays)
+
+    # AdaRound
+    arrays = {}
+    for bits in (3, 4):
+        L = 2 ** (bits - 1)
+        w = torch.randn(3, 16, 32, generator=g) * 0.2
+        uq = RQ.UniformQuantizer(n_bits=bits, symmetric=False, channel_wise=True)
+        uq.scale = torch.nn.Parameter((w.amax(2, keepdim=True) - w.amin(2, keepdim=True)) / (2 * L - 1))
+        uq.zero_point = torch.nn.Parameter(torch.round(-w.amin(2, keepdim=True) / uq.scale.data))
+        uq.inited = True
+        ar = RefAdaRound(uq=uq, weight_tensor=w, round_mode="learned_hard_sigmoid")
+        arrays[f"r{bits}_w"] = w
+        arrays[f"r{bits}_scale"] = uq.scale
+        arrays[f"r{bits}_zp"] = uq.zero_point
+        arrays[f"r{bits}_alpha0"] = ar.alpha.detach().clone()
+        arrays[f"r{bits}_uq_y"] = uq(w)
+        arrays[f"r{bits}_hard_y"] = ar(w)
+        ar.soft_targets = True
+        arrays[f"r{bits}_soft_y"] = ar(w)
+        arrays[f"r{bits}_soft_targets"] = ar.get_soft_targets()
+        # perturbed alpha + gradient through the soft path
+        ar.alpha.data.add_(torch.randn(ar.alpha.shape, generator=g) * 2)
+        arrays[f"r{bits}_alpha1"] = ar.alpha
+        y = ar(w)
+        (y * y).sum().backward()
+        arrays[f"r{bits}_soft_y1"] = y
+        arrays[f"r{bits}_galpha1"] = ar.alpha.grad
+        arrays[f"r{bits}_hardval1"] = ar.get_hard_value(w.view(48, 32))
+    save("quantizers_adaround", **arrays)
+
+
+# ----------------------------------------------------------------------------- layers
+def gen_linear(bits, seed, N=4, T=7, I=32, O=48, n_V=3, cbs=2):
+    torch.manual_seed(seed)
+    lay = RL.AsymmetricallyBatchingQuantLinear(I, O, True, "raw", bits, bits, calib_batch_size=cbs,
+                                               search_round=3, eq_n=128, n_V=n_V, fpcs=True, steps=6)
+    lay.weight.data.normal_(0, 0.15)
+    lay.bias.data.normal_(0, 0.1)
+    x = torch.randn(N, T, I) * 1.3 + 0.2
+    arrays = dict(weight=lay.weight.data.clone(), bias=lay.bias.data.clone(), x=x,
+                  cfg=np.array([bits, bits, N, T, I, O, n_V, cbs], dtype=np.int64))
+    with torch.no_grad():
+        lay.raw_input = x
+        lay.raw_out = lay(x)
+        arrays["raw_out"] = lay.raw_out.clone()
+        lay._initialize_calib_parameters()
+        ws, wz = lay.calculate_percentile_weight_candidates()
+        as_, az = lay.calculate_percentile_activation_candidates()
+        arrays.update(cand_w_scale=ws, cand_w_zp=wz, cand_a_scale=as_, cand_a_zp=az)
+        with TopkTrace() as tr:
+            lay.hyperparameter_searching()
+    arrays.update(tr.arrays())
+    arrays.update(state(lay))
+    lay.mode = "quant_forward"
+    arrays["qf_out"] = lay(x)
+    save(f"linear_w{bits}a{bits}", **arrays)
+
+
+def gen_linear_channelwise(bits, seed, N=4, T=7, I=32, O=48, n_V=3, cbs=2):
+    torch.manual_seed(seed)
+    lay = RL.AsymmetricallyChannelWiseBatchingQuantLinear(I, O, True, "raw", bits, bits, calib_batch_size=cbs,
+                                                          search_round=3, eq_n=128, n_V=n_V, fpcs=True, steps=6)
+    lay.weight.data.normal_(0, 0.15)
+    lay.bias.data.normal_(0, 0.1)
+    ln = torch.nn.LayerNorm(I)
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.normal_(0, 0.2)
+    lay.prev_layer = ln
+    h = torch.randn(N, T, I) * torch.linspace(0.3, 3.0, I)          # strong per-channel range spread
+    arrays = dict(weight=lay.weight.data.clone(), bias=lay.bias.data.clone(), h=h,
+                  ln_weight=ln.weight.data.clone(), ln_bias=ln.bias.data.clone(),
+                  cfg=np.array([bits, bits, N, T, I, O, n_V, cbs], dtype=np.int64))
+    with torch.no_grad():
+        x = ln(h)
+        arrays["x"] = x.clone()
+        lay.raw_input = x
+        lay.raw_out = lay(x)
+        arrays["raw_out"] = lay.raw_out.clone()
+        lay._initialize_calib_parameters()
+        as_, az = lay.calculate_percentile_activation_candidates()
+        arrays.update(cand_a_scale=as_, cand_a_zp=az)
+        with TopkTrace() as tr:
+            lay.hyperparameter_searching()
+        arrays.update(tr.arrays("cwtrace"))
+        arrays["cw_a_scale"] = lay.a_quantizer.scale.data.clone()
+        arrays["cw_a_zp"] = lay.a_quantizer.zero_point.data.clone()
+        with TopkTrace() as tr2:
+            lay.reparam()
+        arrays.update(tr2.arrays("trace"))
+        # function preservation of the LayerNorm fold (linear.py:604-611)
+        arrays["reparam_ln_weight"] = ln.weight.data.clone()
+        arrays["reparam_ln_bias"] = ln.bias.data.clone()
+        arrays["reparam_out_fp"] = torch.nn.functional.linear(ln(h), lay.weight, lay.bias)
+    arrays.update(state(lay))
+    lay.mode = "quant_forward"
+    arrays["qf_out"] = lay(ln(h))
+    save(f"linear_cw_w{bits}a{bits}", **arrays)
+
+
+def gen_postgelu(bits, seed, N=4, T=7, I=40, O=24, cbs=2):
+    torch.manual_seed(seed)
+    lay = RL.PostGeluLogBasedBatchingQuantLinear(I, O, True, "raw", bits, bits, calib_batch_size=cbs,
+                                                 search_round=3, eq_n=128, n_V=1, quantizer="adalog",
+                                                 fpcs=True, steps=6)
+    lay.weight.data.normal_(0, 0.15)
+    lay.bias.data.normal_(0, 0.1)
+    x = torch.nn.functional.gelu(2 * torch.randn(N, T, I))
+    arrays = dict(weight=lay.weight.data.clone(), bias=lay.bias.data.clone(), x=x,
+                  cfg=np.array([bits, bits, N, T, I, O, 1, cbs], dtype=np.int64),
+                  search_table=lay.table.clone())
+    with torch.no_grad():
+        lay.raw_input = x
+        lay.raw_out = lay(x)
+        arrays["raw_out"] = lay.raw_out.clone()
+        ud, sc = lay.calculate_percentile_activation_candidates()
+        arrays.update(cand_ud=ud, cand_a_scale=sc)
+        arrays["pospct"] = RL.PostGeluLogBasedBatchingQuantLinear.positive_percentile(
+            x.view(-1), torch.tensor([0.9, 1.0, 0.5, 0.013]))
+        with TopkTrace() as tr:
+            lay.hyperparameter_searching()
+    arrays.update(tr.arrays())
+    arrays.update(state(lay))
+    lay.mode = "quant_forward"
+    arrays["qf_out"] = lay(x)
+    with torch.no_grad():
+        lay.reparam_bias()
+    arrays["reparamed_bias"] = lay.bias.data.clone()
+    arrays["qf_out_reparamed"] = lay(x)
+    save(f"postgelu_w{bits}a{bits}", **arrays)
+
+
+def gen_matmul(bits, seed, N=4, H=2, S=7, C=8, cbs=2):
+    torch.manual_seed(seed)
+    lay = RL.AsymmetricallyBatchingQuantMatMul(A_bit=bits, B_bit=bits, mode="raw", calib_batch_size=cbs,
+                                               search_round=3, eq_n=128, head_channel_wise=True,
+                                               num_heads=H, fpcs=True, steps=6)
+    A = torch.randn(N, H, S, C) * torch.tensor([0.7, 1.9]).view(1, H, 1, 1)
+    Bk = torch.randn(N, H, S, C) * 1.1 + 0.1
+    B = Bk.transpose(-2, -1)                  # qk^T passes a transposed view (wrap_net.py:25)
+    arrays = dict(A=A, B=B.contiguous(), cfg=np.array([bits, bits, N, H, S, C, cbs], dtype=np.int64))
+    with torch.no_grad():
+        lay.raw_input = [A, B.contiguous()]
+        lay.raw_out = lay(A, B)
+        arrays["raw_out"] = lay.raw_out.clone()
+        sA, zA = lay.calculate_percentile_candidates(A)
+        sB, zB = lay.calculate_percentile_candidates(B.contiguous())
+        arrays.update(cand_A_scale=sA, cand_A_zp=zA, cand_B_scale=sB, cand_B_zp=zB)
+        with TopkTrace() as tr:
+            lay.hyperparameter_searching()
+    arrays.update(tr.arrays())
+    arrays.update(state(lay))
+    lay.mode = "quant_forward"
+    arrays["qf_out"] = lay(A, B)
+    save(f"matmul_a{bits}b{bits}", **arrays)
+
+
+def gen_postsoftmax(bits, seed, N=4, H=2, S=9, C=8, cbs=2):
+    torch.manual_seed(seed)
+    lay = RL.PostSoftmaxAsymmetricallyBatchingQuantMatMul(A_bit=bits, B_bit=bits, mode="raw", calib_batch_size=cbs,
+                                                          search_round=3, eq_n=128, head_channel_wise=True,
+                                                          num_heads=H, fpcs=True, steps=6, quantizer="adalog")
+    A = torch.softmax(3 * torch.randn(N, H, S, S), dim=-1)
+    B = torch.randn(N, H, S, C) * torch.tensor([0.6, 1.4]).view(1, H, 1, 1)
+    arrays = dict(A=A, B=B, cfg=np.array([bits, bits, N, H, S, C, cbs], dtype=np.int64),
+                  search_table=lay.table.clone())
+    with torch.no_grad():
+        lay.raw_input = [A, B]
+        lay.raw_out = lay(A, B)
+        arrays["raw_out"] = lay.raw_out.clone()
+        with TopkTrace() as tr:
+            lay.hyperparameter_searching()
+    arrays.update(tr.arrays())
+    arrays.update(state(lay))
+    lay.mode = "quant_forward"
+    arrays["qf_out"] = lay(A, B)
+    save(f"postsoftmax_a{bits}b{bits}", **arrays)
+
+
+def gen_conv(bits, seed, N=4, ic=3, oc=12, k=4, hw=16, cbs=2):
+    torch.manual_seed(seed)
+    lay = RL.AsymmetricallyBatchingQuantConv2d(in_channels=ic, out_channels=oc, kernel_size=(k, k), stride=(k, k),
+                                               mode="raw", w_bit=bits, a_bit=8, calib_batch_size=cbs,
+                                               search_round=3, eq_n=128, fpcs=True, steps=6)
+    lay.weight.data.normal_(0, 0.2)
+    lay.bias.data.normal_(0, 0.1)
+    x = torch.randn(N, ic, hw, hw)
+    arrays = dict(weight=lay.weight.data.clone(), bias=lay.bias.data.clone(), x=x,
+                  cfg=np.array([bits, 8, N, ic, oc, k, hw, cbs], dtype=np.int64))
+    with torch.no_grad():
+        lay.raw_input = x
+        lay.raw_out = lay(x)
+        arrays["raw_out"] = lay.raw_out.clone()
+        ws, wz = lay.calculate_percentile_weight_candidates()
+        arrays.update(cand_w_scale=ws, cand_w_zp=wz)
+        with TopkTrace() as tr:
+            lay.hyperparameter_searching()
+    arrays.update(tr.arrays())
+    arrays.update(state(lay))
+    lay.mode = "quant_forward"
+    arrays["qf_out"] = lay(x)
+    save(f"conv_w{bits}", **arrays)
+
+
+def gen_quantile_large():
+    """Per-tensor activation candidates above the 2**24 quantile limit (linear.py:465-471)."""
+    torch.manual_seed(77)
+    N, T, I = 3, 2797, 2000            # 16 782 000 elements > 2**24 -> mini_batch_size doubles until it fits
+    lay = RL.AsymmetricallyBatchingQuantLinear(I, 8, True, "raw", 4, 4, calib_batch_size=1,
+                                               search_round=1, eq_n=128, n_V=1, fpcs=True, steps=6)
+    x = torch.randn(N, T, I, generator=torch.Generator().manual_seed(77))
+    lay.raw_input = x
+    with torch.no_grad():
+        as_, az = lay.calculate_percentile_activation_candidates()
+    # the tensor itself is too big for a fixture: regenerate from the seed in the test
+    save("quantile_large", seed=np.int64(77), shape=np.array([N, T, I]), cand_a_scale=as_, cand_a_zp=az,
+         x_head=x.view(-1)[:64], x_sum=x.double().sum())
+
+
+def gen_calibrator():
+    """Visiting order + captured shapes of QuantCalibrator on a toy tree of the reference's own layers."""
+    torch.manual_seed(5)
+    I, H = 16, 2
+
+    class Attn(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            kw = dict(mode="raw", w_bit=4, a_bit=4, calib_batch_size=2, search_round=1, eq_n=128, fpcs=True, steps=2)
+            self.qkv = RL.AsymmetricallyBatchingQuantLinear(I, 3 * I, True, n_V=3, **kw)
+            self.proj = RL.AsymmetricallyBatchingQuantLinear(I, I, True, n_V=1, **kw)
+            mk = dict(B_bit=4, mode="raw", calib_batch_size=2, search_round=1, eq_n=128, head_channel_wise=True,
+                      num_heads=H, fpcs=True, steps=2)
+            setattr(self, "matmul1", RL.AsymmetricallyBatchingQuantMatMul(A_bit=4, **mk))
+            setattr(self, "matmul2", RL.PostSoftmaxAsymmetricallyBatchingQuantMatMul(A_bit=4, quantizer="adalog", **mk))
+
+        def forward(self, x):
+            B, N, C = x.shape
+            qkv = self.qkv(x).reshape(B, N, 3, H, C // H).permute(2, 0, 3, 1, 4)
+            q, k, v = qkv[0], qkv[1], qkv[2]
+            attn = self.matmul1(q, k.transpose(-2, -1)) * (C // H) ** -0.5
+            attn = attn.softmax(dim=-1)
+            x = self.matmul2(attn, v).transpose(1, 2).reshape(B, N, C)
+            return self.proj(x)
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.attn = Attn()
+            kw = dict(mode="raw", w_bit=4, a_bit=4, calib_batch_size=2, search_round=1, eq_n=128, fpcs=True, steps=2)
+            self.fc1 = RL.AsymmetricallyBatchingQuantLinear(I, 2 * I, True, n_V=1, **kw)
+            self.fc2 = RL.PostGeluLogBasedBatchingQuantLinear(2 * I, I, True, n_V=1, quantizer="adalog", **kw)
+
+        def forward(self, x):
+            x = x + self.attn(x)
+            return x + self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+    model = Toy().eval()
+    xs = [torch.randn(2, 5, I) for _ in range(2)]
+    loader = [(x, None) for x in xs]
+    order, shapes = [], {}
+    for name, m in model.named_modules():
+        if hasattr(m, "hyperparameter_searching"):
+            orig = m.hyperparameter_searching
+
+            def wrapped(orig=orig, name=name, m=m):
+                order.append(name)
+                ri = m.raw_input
+                shapes[name] = ([list(t.shape) for t in ri] if isinstance(ri, list) else [list(ri.shape)],
+                                list(m.raw_out.shape))
+                return orig()
+
+            m.hyperparameter_searching = wrapped
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    RefCalibrator(model, loader).batching_quant_calib()
+    arrays = {"in_" + k.replace(".", "__"): v for k, v in sd0.items()}
+    arrays.update({"out_" + k.replace(".", "__"): v for k, v in model.state_dict().items()})
+    arrays["x0"], arrays["x1"] = xs
+    arrays["order"] = np.array(order)
+    for n in order:
+        arrays["shape_in_" + n.replace(".", "__")] = np.array(shapes[n][0][0])
+        arrays["shape_out_" + n.replace(".", "__")] = np.array(shapes[n][1])
+    with torch.no_grad():
+        arrays["qf_out"] = model(xs[0])
+    save("calibrator_toy", **arrays)
+
+
+if __name__ == "__main__":
+    gen_quantizers()
+    for bits, seed in ((3, 11), (4, 12), (6, 13)):
+        gen_linear(bits, seed)
+    gen_linear(4, 112, N=6, T=5, I=24, O=16, n_V=1, cbs=4)          # ragged last calib batch (6 = 4 + 2)
+    os.replace(os.path.join(OUT, "linear_w4a4.npz"), os.path.join(OUT, "linear_w4a4_ragged.npz"))
+    gen_linear(4, 12)
+    for bits, seed in ((3, 21), (4, 22), (6, 23)):
+        gen_linear_channelwise(bits, seed)
+    for bits, seed in ((3, 31), (4, 32), (6, 33)):
+        gen_postgelu(bits, seed)
+    for bits, seed in ((3, 41), (4, 42), (6, 43)):
+        gen_matmul(bits, seed)
+    for bits, seed in ((3, 51), (4, 52), (6, 53)):
+        gen_postsoftmax(bits, seed)
+    for bits, seed in ((3, 61), (4, 62), (6, 63)):
+        gen_conv(bits, seed)
+    gen_quantile_large()
+    gen_calibrator()
