@@ -1,0 +1,69 @@
+"""ctypes binding of libadalog_hip.so (the C ABI declared in include/adalog_hip.h).
+
+The library is built in-tree (adalog_amd/csrc, `make` or __graft_entry__.build()) so that it travels to the GPU box
+and is visible as a loaded native extension.  There is NO fallback: if the library is missing, import of the product
+path raises, and every call needs a HIP device.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libadalog_hip.so")
+
+p, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
+
+# name -> (restype, argtypes); must list every function of include/adalog_hip.h (tests/test_abi.py checks that)
+SIGNATURES = {
+    "adalog_abi_version": (i32, []),
+    "adalog_last_error": (C.c_char_p, []),
+    "adalog_uniform_fake_quant_f32": (i32, [p, p, p, i64, p, p, i64, i64, i32, i32, p]),
+    "adalog_log_fake_quant_f32": (i32, [p, p, p, i64, p, p, p, p, i32, p, i32, i32, p]),
+    "adalog_pack_uniform": (i32, [p, i64, i64, i64, i64, i64, i64, p, p, i64, i64, i64, i64, i64, i32, i32, p, i64, p, p]),
+    "adalog_pack_adalog_bf16": (i32, [p, i64, i64, i64, i64, i64, i64, p, p, i64, i64, i64, i64, i32, p, p, i32, p, i64, p]),
+    "adalog_pack_raw_f32": (i32, [p, i64, i64, i64, i64, i64, i64, p, i64, p]),
+    "adalog_gemm_score": (i32, [i32, p, p, i64, i64, i64, i64, i32, i32, i64, i32, i32, i32, p, i64, i64, i32,
+                                p, i64, i64, f32, p, i64, i64, i64, p, i64, i64, i64, p, i64, p, i64, i64, i64, p]),
+    "adalog_gemm_score_partial_elems": (i64, [i32, i32, i32, i32]),
+    "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, f64, p]),
+    "adalog_topk": (i32, [p, i32, i32, i32, p, p]),
+    "adalog_fpcs_next": (i32, [p, p, p, i32, p, i32, i32, p, p, i32, f32, p, p, p, p]),
+    "adalog_candidate_grid": (i32, [p, i32, i32, i32, i32, i32, p, i32, f32, p, p, p, p]),
+    "adalog_score_w_self": (i32, [p, i32, i32, p, p, i32, i32, p, p]),
+    "adalog_score_a_self": (i32, [p, i64, i32, p, p, i32, i32, i32, f64, p, i64, p, p]),
+    "adalog_score_a_self_partial_elems": (i64, [i64, i32, i32]),
+    "adalog_quantile_rows": (i32, [p, i64, i64, i32, p, p, i32, p, p, i64, p]),
+    "adalog_positive_percentile_rows": (i32, [p, i64, i64, i32, p, p, p, i64, p]),
+    "adalog_select_workspace_bytes": (i64, [i64, i32]),
+    "adalog_shift_fold": (i32, [p, p, p, p, i32, i32, p, p]),
+    "adalog_minmax_rows": (i32, [p, i32, i32, i32, p, p, p]),
+    "adalog_absminmax_cols": (i32, [p, i64, i32, i32, p, p, p]),
+}
+
+_lib = None
+
+
+class AdalogHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AdalogHipError(
+                f"{LIB_PATH} not found: build the HIP kernels first (python -c 'import __graft_entry__ as g; g.build()' "
+                "or `make -C adalog_amd/csrc`).  The AdaLog MI355X path has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().adalog_last_error().decode("utf-8", "replace")
+        raise AdalogHipError(f"{what} failed (rc={rc}): {msg}")

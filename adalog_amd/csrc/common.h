@@ -1,0 +1,48 @@
+// Shared device/host helpers for the AdaLog MI355X (gfx950) kernels.
+// Compiled with hipcc --offload-arch=gfx950 -ffp-contract=off: every fp32 step below must round exactly
+// like the reference's ATen CPU op (IEEE divide, round-half-even, no FMA contraction).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define ADALOG_R 37            // AdaLog fixed denominator r (reference quantizers/logarithm.py:71)
+
+extern "C" void adalog_set_error(const char* where, hipError_t e);
+extern "C" void adalog_set_error_msg(const char* msg);
+
+#define ADALOG_LAUNCH_CHECK(name)                                   \
+    do {                                                            \
+        hipError_t e__ = hipGetLastError();                         \
+        if (e__ != hipSuccess) { adalog_set_error(name, e__); return (int)e__; } \
+    } while (0)
+
+#define ADALOG_ARG_CHECK(cond, msg)                                 \
+    do { if (!(cond)) { adalog_set_error_msg(msg); return -1; } } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------- device math
+// asymmetric uniform bin: clamp(rne(x / s) + z, 0, qmax)       (uniform.py:29-35; z already rounded)
+__device__ __forceinline__ float uni_bin(float x, float s, float z, float qmax) {
+    float xi = rintf(x / s);
+    return fminf(fmaxf(xi + z, 0.0f), qmax);
+}
+
+// k = rne( (-log2(u)) * 37 / q ) with u a positive float, evaluated so that it equals the fp32 pipeline
+//   L = fl32(log2 u) correctly rounded;  t = fl32(fl32(-L * 37) / q);  k = rne(t)
+// (logarithm.py:94 with a correctly-rounded log2; torch's SLEEF log2 differs from correct rounding on <1e-3 of
+// inputs by one ulp, which moves k only for t within one ulp of a tie: ~1e-9 of elements).
+// Fast path: hardware v_log_f32 (1 ulp) unless t lands within 1e-3 of a tie; then the exact path in fp64.
+__device__ __forceinline__ float adalog_k(float u, float qf) {
+    float lf = __log2f(u);
+    float t = (-lf) * 37.0f / qf;
+    float k = rintf(t);
+    float fr = fabsf(t - k);
+    if (__builtin_expect(fr > 0.499f || !(t < 3.0e38f), 0)) {
+        float le = (float)log2((double)u);
+        t = (-le) * 37.0f / qf;
+        k = rintf(t);
+    }
+    return k;
+}

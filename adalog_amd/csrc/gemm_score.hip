@@ -1,0 +1,279 @@
+// K7/K8/K11-K15 -- candidate-scoring GEMM with a fused squared-error epilogue, on the CDNA4 matrix cores.
+//
+// Replaces, for every scoring call of the reference's searches
+//   quant_layers/linear.py:355-384 (_search_best_w_scale), :394-423 (_search_best_a_scale),
+//   :816-848/:856-890/:898-931 (post-GELU AdaLog searches), matmul.py:135-163/:173-201/:321-351, conv.py:226-255,
+// the sequence  F.linear / @ / F.conv2d  ->  out_sim[.., P, ..] in HBM  ->  (raw_out - out_sim)**2  ->  mean/sum,
+// by ONE kernel per call: D = A.B^T on MFMA from packed operands (operand.hip), then in registers
+//   out = D * (sa * sb[col]) + bias[col];   e = ref - out;   column sums of e*e over the tile's rows,
+// so only per-tile score partials ever reach HBM (the reference materialises out_sim: 3.7 GB for deit_small qkv).
+// A second tiny kernel adds the partials in fp64 in a fixed order (deterministic, SURVEY "hard parts").
+//
+// Data types:  0 = int8  (v_mfma_i32_32x32x32_i8,  exact integer dot products)
+//              1 = bf16  (v_mfma_f32_32x32x16_bf16, AdaLog operand m*2^-t and integer operand exact in bf16)
+//              2 = fp32  (v_mfma_f32_32x32x2_f32,   conv patch-embed with unquantised 8-bit input)
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32 tiles),
+// K-step 64 bytes, LDS double-buffered with a 16-byte-slot XOR swizzle (conflict-free ds_read_b128),
+// XCD-aware block order so the workgroups sharing an A tile sit on one XCD's L2.
+#include "common.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128, BKB = 64;   // BKB: K-step in bytes
+
+struct GemmArgs {
+    const uint8_t* A; const uint8_t* B;
+    int64_t sAc, sAg, sBc, sBg;      // byte strides between candidates / groups (0 = shared operand)
+    int M, N; int64_t Kb;            // Kb = padded K in bytes (multiple of 64)
+    int C, G, gmod;
+    const float* ref; int64_t ldr, sRg; int ref_div;
+    const float* sa; int64_t sa_c, sa_g;
+    const float* sb; int64_t sb_c, sb_g, sb_n;
+    const float* bias; int64_t bi_c, bi_g, bi_n;
+    float* partial; int MT, NT, Npad;
+    float* out; int64_t ldo, sOc, sOg;
+    float sa_mul;                    // constant folded into sa (e.g. 1/(4L-2) for AdaLog numerators)
+};
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * BKB + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int DT> struct Acc { typedef v16f type; };
+template <> struct Acc<0> { typedef v16i type; };
+
+template <int DT>
+__device__ __forceinline__ void mma(const uint4& a, const uint4& b, typename Acc<DT>::type& c) {
+    if constexpr (DT == 0) {
+        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const v4i*>(&a), *reinterpret_cast<const v4i*>(&b), c, 0, 0, 0);
+    } else if constexpr (DT == 1) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const v8bf*>(&a), *reinterpret_cast<const v8bf*>(&b), c, 0, 0, 0);
+    } else {
+        const float* af = reinterpret_cast<const float*>(&a);
+        const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], c, 0, 0, 0);
+    }
+}
+
+template <int DT, bool STORE>
+__global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[2 * (BM + BN) * BKB];
+    __shared__ float red[2][2][2][32];
+    uint8_t* As = lds;
+    uint8_t* Bs = lds + 2 * BM * BKB;
+
+    // ---- XCD-aware bijective block remap: consecutive logical tiles (same A tile, neighbouring n) share an XCD/L2
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const unsigned lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    unsigned t = lid;
+    const int nt = t % p.NT; t /= p.NT;
+    const int mt = t % p.MT; t /= p.MT;
+    const int g = t % p.G;
+    const int c = t / p.G;
+    const int gh = g % p.gmod;
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const uint8_t* Ag = p.A + c * p.sAc + g * p.sAg;
+    const uint8_t* Bg = p.B + c * p.sBc + g * p.sBg;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    // global->LDS staging: thread loads rows (tid>>2) and (tid>>2)+64, 16-byte slot tid&3
+    const int lrow = tid >> 2, lslot = tid & 3;
+    int ar0 = m0 + lrow, ar1 = m0 + lrow + 64, br0 = n0 + lrow, br1 = n0 + lrow + 64;
+    ar0 = ar0 < p.M ? ar0 : p.M - 1; ar1 = ar1 < p.M ? ar1 : p.M - 1;      // edge rows: clamp, masked in epilogue
+    br0 = br0 < p.N ? br0 : p.N - 1; br1 = br1 < p.N ? br1 : p.N - 1;
+    const uint4* ga0 = reinterpret_cast<const uint4*>(Ag + (int64_t)ar0 * p.Kb) + lslot;
+    const uint4* ga1 = reinterpret_cast<const uint4*>(Ag + (int64_t)ar1 * p.Kb) + lslot;
+    const uint4* gb0 = reinterpret_cast<const uint4*>(Bg + (int64_t)br0 * p.Kb) + lslot;
+    const uint4* gb1 = reinterpret_cast<const uint4*>(Bg + (int64_t)br1 * p.Kb) + lslot;
+    const int so0 = swz(lrow, lslot), so1 = swz(lrow + 64, lslot);
+
+    typename Acc<DT>::type acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int nk = (int)(p.Kb / BKB);
+    uint4 ra0 = ga0[0], ra1 = ga1[0], rb0 = gb0[0], rb1 = gb1[0];
+    *reinterpret_cast<uint4*>(As + so0) = ra0; *reinterpret_cast<uint4*>(As + so1) = ra1;
+    *reinterpret_cast<uint4*>(Bs + so0) = rb0; *reinterpret_cast<uint4*>(Bs + so1) = rb1;
+    __syncthreads();
+
+    const int frow = lane & 31, fkg = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            const int o = (kt + 1) * (BKB / 16);
+            ra0 = ga0[o]; ra1 = ga1[o]; rb0 = gb0[o]; rb1 = gb1[o];
+        }
+        const uint8_t* Ac = As + cur * BM * BKB;
+        const uint8_t* Bc = Bs + cur * BN * BKB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const uint4*>(Ac + swz(wr * 64 + i * 32 + frow, ks * 2 + fkg));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bc + swz(wc * 64 + j * 32 + frow, ks * 2 + fkg));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) mma<DT>(af[i], bf[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) {
+            uint8_t* An = As + (cur ^ 1) * BM * BKB;
+            uint8_t* Bn = Bs + (cur ^ 1) * BN * BKB;
+            *reinterpret_cast<uint4*>(An + so0) = ra0; *reinterpret_cast<uint4*>(An + so1) = ra1;
+            *reinterpret_cast<uint4*>(Bn + so0) = rb0; *reinterpret_cast<uint4*>(Bn + so1) = rb1;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: out = acc * (sa*sb[col]) + bias[col]; squared error against ref; column sums
+    const float sa = p.sa[c * p.sa_c + gh * p.sa_g] * p.sa_mul;
+    const float* refg = p.ref ? p.ref + (int64_t)g * p.sRg : nullptr;
+    float* outg = STORE ? p.out + (int64_t)c * p.sOc + (int64_t)g * p.sOg : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + frow;
+        const bool cv = col < p.N;
+        const int colc = cv ? col : p.N - 1;
+        const float alpha = sa * p.sb[c * p.sb_c + gh * p.sb_g + colc * p.sb_n];
+        const float beta = p.bias ? p.bias[c * p.bi_c + gh * p.bi_g + colc * p.bi_n] : 0.0f;
+        const int rcol = colc / p.ref_div;
+        float csum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fkg;
+                if (cv && row < p.M) {
+                    float o = (float)acc[i][j][r] * alpha;
+                    o = p.bias ? o + beta : o;
+                    if (STORE) outg[(int64_t)row * p.ldo + col] = o;
+                    if (refg) {
+                        const float e = refg[(int64_t)row * p.ldr + rcol] - o;
+                        csum += e * e;
+                    }
+                }
+            }
+        }
+        csum += __shfl_xor(csum, 32);
+        if (fkg == 0) red[wr][wc][j][frow] = csum;
+    }
+    if (p.partial) {
+        __syncthreads();
+        if (tid < 128) {
+            const int cwc = tid >> 6, cj = (tid >> 5) & 1, cl = tid & 31;
+            const int col = n0 + cwc * 64 + cj * 32 + cl;
+            if (col < p.Npad)
+                p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + col] = red[0][cwc][cj][cl] + red[1][cwc][cj][cl];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ finish
+// scores[c][h?][n?] = -norm * sum over (image = g / gmod, [h], m-tile, [n]) of partial[c][g][mt][n]   in fp64,
+// fixed summation order: each thread takes a strided subset, then a fixed LDS tree.
+struct FinishArgs {
+    const float* partial; float* scores;
+    int C, G, gmod, MT, N, Npad;
+    int keep_h, keep_n;
+    double norm;
+};
+
+__global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
+    __shared__ double sm[256];
+    const int nh = p.keep_h ? p.gmod : 1, nn = p.keep_n ? p.N : 1;
+    int o = blockIdx.x;
+    const int n = o % nn; o /= nn;
+    const int h = o % nh;
+    const int c = o / nh;
+    const int n_lo = p.keep_n ? n : 0, n_cnt = p.keep_n ? 1 : p.N;
+    const int imgs = p.G / p.gmod;
+    const int h_lo = p.keep_h ? h : 0, h_cnt = p.keep_h ? 1 : p.gmod;
+    const int64_t total = (int64_t)imgs * h_cnt * p.MT * n_cnt;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
+        int64_t t = i;
+        const int nn_i = (int)(t % n_cnt); t /= n_cnt;
+        const int mt = (int)(t % p.MT); t /= p.MT;
+        const int hh = (int)(t % h_cnt); t /= h_cnt;
+        const int img = (int)t;
+        const int g = img * p.gmod + h_lo + hh;
+        acc += (double)p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + n_lo + nn_i];
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.scores[blockIdx.x] = (float)(-p.norm * sm[0]);
+}
+
+}  // namespace
+
+extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
+                                 int64_t sBg, int M, int N, int64_t Kp, int C, int G, int gmod, const float* ref,
+                                 int64_t ldr, int64_t sRg, int ref_div, const float* sa, int64_t sa_c, int64_t sa_g,
+                                 float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
+                                 const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, float* partial,
+                                 int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, void* stream) {
+    ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
+    ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 2, "gemm_score: dtype must be 0 (i8), 1 (bf16) or 2 (f32)");
+    ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
+    const int esz = dtype == 0 ? 1 : dtype == 1 ? 2 : 4;
+    ADALOG_ARG_CHECK((Kp * esz) % BKB == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 64 bytes");
+    ADALOG_ARG_CHECK((partial != nullptr) == (ref != nullptr), "gemm_score: partial and ref go together");
+    ADALOG_ARG_CHECK(partial || out, "gemm_score: nothing to produce");
+    GemmArgs p{};
+    p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
+    p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;
+    p.M = M; p.N = N; p.Kb = Kp * esz; p.C = C; p.G = G; p.gmod = gmod;
+    p.ref = ref; p.ldr = ldr; p.sRg = sRg; p.ref_div = ref_div;
+    p.sa = sa; p.sa_c = sa_c; p.sa_g = sa_g; p.sa_mul = sa_mul;
+    p.sb = sb; p.sb_c = sb_c; p.sb_g = sb_g; p.sb_n = sb_n;
+    p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;
+    p.MT = cdiv(M, BM); p.NT = cdiv(N, BN); p.Npad = p.NT * BN;
+    p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
+    if (partial) ADALOG_ARG_CHECK(partial_elems >= (int64_t)C * G * p.MT * p.Npad, "gemm_score: partial buffer too small");
+    const int64_t nwg = (int64_t)p.MT * p.NT * G * C;
+    ADALOG_ARG_CHECK(nwg < (int64_t)1 << 31, "gemm_score: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)nwg), block(256);
+#define LAUNCH(DT)                                                                                   \
+    do {                                                                                             \
+        if (out) hipLaunchKernelGGL((k_gemm_score<DT, true>), grid, block, 0, st, p);                \
+        else hipLaunchKernelGGL((k_gemm_score<DT, false>), grid, block, 0, st, p);                   \
+    } while (0)
+    if (dtype == 0) LAUNCH(0); else if (dtype == 1) LAUNCH(1); else LAUNCH(2);
+#undef LAUNCH
+    ADALOG_LAUNCH_CHECK("adalog_gemm_score");
+    return 0;
+}
+
+extern "C" int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G) {
+    return (int64_t)C * G * cdiv(M, BM) * (cdiv(N, BN) * BN);
+}
+
+extern "C" int adalog_finish_scores(const float* partial, float* scores, int M, int N, int C, int G, int gmod,
+                                    int keep_h, int keep_n, double norm, void* stream) {
+    ADALOG_ARG_CHECK(partial && scores && M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0,
+                     "finish_scores: bad arguments");
+    FinishArgs p{};
+    p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = cdiv(M, BM); p.N = N;
+    p.Npad = cdiv(N, BN) * BN; p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm;
+    const int64_t nout = (int64_t)C * (keep_h ? gmod : 1) * (keep_n ? N : 1);
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)nout), dim3(256), 0, (hipStream_t)stream, p);
+    ADALOG_LAUNCH_CHECK("adalog_finish_scores");
+    return 0;
+}

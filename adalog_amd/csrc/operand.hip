@@ -1,0 +1,183 @@
+// Operand packing for the candidate-scoring GEMMs (K7/K8/K11-K14 prologue).
+//
+// The reference re-materialises an fp32 fake-quantised copy of the searched operand for every candidate
+// (quant_layers/linear.py:369-371,409-411,830-837; matmul.py:150-151,188-189,337-342; conv.py:240-242).  Here each
+// operand is packed ONCE per scoring call into an MFMA-ready, K-contiguous compact image:
+//   * uniformly quantised operands  -> int8   (q - z)                exact small integers  
+//   * AdaLog operands               -> bf16   m * 2^-t               m = LUT numerator <= 4L-2, exact in bf16
+//   * unquantised conv input        -> fp32   zero-padded copy
+// so a candidate costs 1 B (2 B) per element instead of 4 B x ~8 temporaries, and the de-quantisation scales are
+// applied once per output in the GEMM epilogue.  Output layout: out[c][g][r][Kp], Kp = K rounded up to 64 bytes,
+// zero padded (zeros contribute nothing to the integer dot product).
+#include "common.h"
+#include <hip/hip_bf16.h>
+
+namespace {
+
+enum { KIND_UNIFORM = 0, KIND_ADALOG = 1, KIND_RAW = 2 };
+
+struct PackArgs {
+    const float* x;
+    int64_t G, R, K, sxg, sxr, sxk;
+    // parameter addressing: idx = c*pc + (g % gmod)*pg + r*pr
+    const float* scale;
+    const float* zp;      // uniform: zero point (rounded in-kernel); adalog: unused
+    const float* qv;      // adalog: log-base numerator q per candidate (same addressing, pr ignored)
+    int64_t C, pc, gmod, pg, pr;
+    float qmax;           // 2L-1
+    int levels2;          // 2L
+    const float* mant;    // adalog: 37 integer numerators of the search table (linear.py:750-752)
+    const float* shift;   // adalog: optional input shift (post-GELU), device scalar
+    int clamp_u;          // adalog: clamp((x+shift)/s, 1e-15, 1) (linear.py:830) or raw log2 (matmul.py:337)
+    void* out;
+    int64_t Kp;
+    int32_t* rowsum;      // optional [C][G][R] sum_k (q - z)
+};
+
+template <typename T> struct Out;
+template <> struct Out<int8_t> { static constexpr int EPT = 16; };
+template <> struct Out<__hip_bfloat16> { static constexpr int EPT = 8; };
+template <> struct Out<float> { static constexpr int EPT = 4; };
+
+template <typename T> __device__ __forceinline__ T cvt(float v);
+template <> __device__ __forceinline__ int8_t cvt<int8_t>(float v) { return (int8_t)(int)v; }
+template <> __device__ __forceinline__ __hip_bfloat16 cvt<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
+
+template <typename T, int KIND, bool RFAST>
+__global__ __launch_bounds__(256) void k_pack(PackArgs a) {
+    constexpr int EPT = Out<T>::EPT;
+    const int64_t nchunk = a.Kp / EPT;
+    const int64_t per_c = a.G * a.R * nchunk;
+    const int64_t c = blockIdx.y;
+    __shared__ float s_mant[ADALOG_R];
+    if (KIND == KIND_ADALOG) {
+        if (threadIdx.x < ADALOG_R) s_mant[threadIdx.x] = a.mant[threadIdx.x];
+        __syncthreads();
+    }
+    const float sh = (KIND == KIND_ADALOG && a.shift) ? a.shift[0] : 0.0f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per_c; idx += (int64_t)gridDim.x * blockDim.x) {
+        int64_t g, r, ch;
+        if (RFAST) {
+            r = idx % a.R;
+            int64_t t = idx / a.R;
+            ch = t % nchunk;
+            g = t / nchunk;
+        } else {
+            ch = idx % nchunk;
+            int64_t t = idx / nchunk;
+            r = t % a.R;
+            g = t / a.R;
+        }
+        const int64_t pidx = c * a.pc + (g % a.gmod) * a.pg + r * a.pr;
+        float s = 1.0f, z = 0.0f, qf = 37.0f;
+        if (KIND != KIND_RAW) s = a.scale[pidx];
+        if (KIND == KIND_UNIFORM) z = rintf(a.zp[pidx]);
+        if (KIND == KIND_ADALOG) qf = a.qv[c * a.pc + (g % a.gmod) * a.pg];
+        const float* xp = a.x + g * a.sxg + r * a.sxr;
+        alignas(16) T vals[EPT];
+        int isum = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int64_t k = ch * EPT + e;
+            float v = 0.0f;
+            if (k < a.K) {
+                const float xv = xp[k * a.sxk];
+                if (KIND == KIND_UNIFORM) {
+                    v = fminf(fmaxf(rintf(xv / s) + z, 0.0f), a.qmax) - z;
+                    isum += (int)v;
+                } else if (KIND == KIND_ADALOG) {
+                    float u = (a.shift ? xv + sh : xv) / s;
+                    if (a.clamp_u) u = fminf(fmaxf(u, 1e-15f), 1.0f);
+                    float kk = adalog_k(u, qf);
+                    if (kk < (float)a.levels2 && kk == kk) {        // masked bins (and NaN) -> 0
+                        kk = fmaxf(kk, 0.0f);
+                        const int kq = (int)kk * (int)qf;             // exact: k <= 255, q <= 137
+                        const int t = kq / ADALOG_R, j = kq - t * ADALOG_R;
+                        v = (t > 100) ? 0.0f : ldexpf(s_mant[j], -t);  // < 2^-100: below fp32 resolution of the sums
+                    }
+                } else {
+                    v = xv;
+                }
+            }
+            vals[e] = cvt<T>(v);
+        }
+        T* op = reinterpret_cast<T*>(a.out) + ((c * a.G + g) * a.R + r) * a.Kp + ch * EPT;
+        *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(vals);
+        if (KIND == KIND_UNIFORM && a.rowsum) atomicAdd(a.rowsum + (c * a.G + g) * a.R + r, isum);
+    }
+}
+
+template <typename T, int KIND>
+int launch_pack(const PackArgs& a, hipStream_t st) {
+    constexpr int EPT = Out<T>::EPT;
+    const int64_t per_c = a.G * a.R * (a.Kp / EPT);
+    int64_t gx = (per_c + 255) / 256;
+    if (gx > 4096) gx = 4096;
+    if (gx < 1) gx = 1;
+    dim3 grid((unsigned)gx, (unsigned)a.C);
+    const bool rfast = (a.sxr == 1 && a.sxk != 1);
+    if (rfast)
+        hipLaunchKernelGGL((k_pack<T, KIND, true>), grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((k_pack<T, KIND, false>), grid, dim3(256), 0, st, a);
+    return 0;
+}
+
+}  // namespace
+
+// out dtype codes shared with gemm_score: 0 = int8, 1 = bf16, 2 = fp32
+extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
+                                   const float* scale, const float* zero_point, int64_t C, int64_t pc, int64_t gmod,
+                                   int64_t pg, int64_t pr, int n_bits, int out_dtype, void* out, int64_t Kp,
+                                   int32_t* rowsum, void* stream) {
+    ADALOG_ARG_CHECK(x && scale && zero_point && out, "pack_uniform: null pointer");
+    ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_uniform: bad sizes");
+    ADALOG_ARG_CHECK(Kp >= K && (Kp * (out_dtype == 0 ? 1 : out_dtype == 1 ? 2 : 4)) % 64 == 0,
+                     "pack_uniform: Kp must cover K and be a multiple of 64 bytes");
+    ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_uniform: n_bits must be in [2,7] (q - z must fit int8)");
+    hipStream_t st = (hipStream_t)stream;
+    PackArgs a{};
+    a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk;
+    a.scale = scale; a.zp = zero_point; a.C = C; a.pc = pc; a.gmod = gmod; a.pg = pg; a.pr = pr;
+    a.qmax = (float)((1 << n_bits) - 1); a.levels2 = 1 << n_bits; a.out = out; a.Kp = Kp; a.rowsum = rowsum;
+    if (rowsum) {
+        hipError_t e = hipMemsetAsync(rowsum, 0, sizeof(int32_t) * C * G * R, st);
+        if (e != hipSuccess) { adalog_set_error("pack_uniform/memset", e); return (int)e; }
+    }
+    if (out_dtype == 0) launch_pack<int8_t, KIND_UNIFORM>(a, st);
+    else if (out_dtype == 1) launch_pack<__hip_bfloat16, KIND_UNIFORM>(a, st);
+    else if (out_dtype == 2) launch_pack<float, KIND_UNIFORM>(a, st);
+    else { adalog_set_error_msg("pack_uniform: unknown out_dtype"); return -1; }
+    ADALOG_LAUNCH_CHECK("adalog_pack_uniform");
+    return 0;
+}
+
+extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr,
+                                       int64_t sxk, const float* scale, const float* qv, int64_t C, int64_t pc,
+                                       int64_t gmod, int64_t pg, int n_bits, const float* mant37, const float* shift,
+                                       int clamp_u, void* out, int64_t Kp, void* stream) {
+    ADALOG_ARG_CHECK(x && scale && qv && mant37 && out, "pack_adalog: null pointer");
+    ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_adalog: bad sizes");
+    ADALOG_ARG_CHECK(Kp >= K && (Kp * 2) % 64 == 0, "pack_adalog: Kp must cover K and be a multiple of 32 elements");
+    ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_adalog: n_bits must be in [2,7] (numerators must fit bf16)");
+    PackArgs a{};
+    a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk;
+    a.scale = scale; a.qv = qv; a.C = C; a.pc = pc; a.gmod = gmod; a.pg = pg; a.pr = 0;
+    a.levels2 = 1 << n_bits; a.mant = mant37; a.shift = shift; a.clamp_u = clamp_u; a.out = out; a.Kp = Kp;
+    launch_pack<__hip_bfloat16, KIND_ADALOG>(a, (hipStream_t)stream);
+    ADALOG_LAUNCH_CHECK("adalog_pack_adalog_bf16");
+    return 0;
+}
+
+extern "C" int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
+                                   void* out, int64_t Kp, void* stream) {
+    ADALOG_ARG_CHECK(x && out && G >= 1 && R >= 1 && K >= 1, "pack_raw: bad arguments");
+    ADALOG_ARG_CHECK(Kp >= K && Kp % 16 == 0, "pack_raw: Kp must cover K and be a multiple of 16 elements");
+    PackArgs a{};
+    a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk; a.C = 1; a.gmod = 1;
+    a.out = out; a.Kp = Kp;
+    launch_pack<float, KIND_RAW>(a, (hipStream_t)stream);
+    ADALOG_LAUNCH_CHECK("adalog_pack_raw_f32");
+    return 0;
+}

@@ -1,0 +1,353 @@
+"""Tensor-level wrappers over the C ABI (include/adalog_hip.h): torch is used for device memory and streams only.
+
+Every function takes CUDA(HIP) fp32 tensors, validates them, and enqueues the hand-written kernels on torch's current
+stream.  No function here computes anything with torch ops, and none synchronises the host.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+I8, BF16, F32 = 0, 1, 2
+_ESZ = {I8: 1, BF16: 2, F32: 4}
+_TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.AdalogHipError(f"{name}: expected a tensor on the HIP device, got {t.device} (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def pad_k(K: int, dtype: int) -> int:
+    per = 64 // _ESZ[dtype]
+    return ((K + per - 1) // per) * per
+
+
+def broadcast_layout(x_shape, p_shape) -> Tuple[int, int]:
+    """(n_channels, inner) such that channel(i) = (i // inner) % n_channels reproduces torch broadcasting of a
+    parameter of shape ``p_shape`` against ``x_shape`` (uniform.py:29-36 relies on plain broadcasting)."""
+    xs = list(x_shape)
+    ps = [1] * (len(xs) - len(p_shape)) + list(p_shape)
+    if len(ps) != len(xs):
+        raise ValueError(f"parameter shape {tuple(p_shape)} has more dims than input {tuple(x_shape)}")
+    nz = [i for i, s in enumerate(ps) if s != 1]
+    if not nz:
+        return 1, int(math.prod(xs)) if xs else 1
+    a, b = nz[0], nz[-1]
+    for i in range(a, b + 1):
+        if ps[i] != xs[i]:
+            raise ValueError(f"unsupported broadcast of {tuple(p_shape)} against {tuple(x_shape)}")
+    return int(math.prod(ps[a:b + 1])), int(math.prod(xs[b + 1:]))
+
+
+# ------------------------------------------------------------------------------------------------ K1-K3
+def uniform_fake_quant(x, scale, zero_point, n_bits: int, sym: bool = False, want_bins: bool = False,
+                       want_y: bool = True):
+    x = _f32c(x, "x")
+    scale = _f32c(scale, "scale")
+    zp = None if sym else _f32c(zero_point, "zero_point")
+    n_ch, inner = broadcast_layout(x.shape, scale.shape)
+    y = torch.empty_like(x) if want_y else None
+    bins = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_bins else None
+    lib = _lib.load()
+    rc = lib.adalog_uniform_fake_quant_f32(_ptr(x), _ptr(y), _ptr(bins), x.numel(), _ptr(scale), _ptr(zp), n_ch, inner,
+                                           int(n_bits), int(bool(sym)), _stream())
+    _lib.check(rc, "adalog_uniform_fake_quant_f32")
+    return (y, bins) if want_bins else y
+
+
+def log_fake_quant(x, scale, q, table1, table2, n_bits: int, shift=None, sub_shift: bool = False,
+                   train_form: bool = False, want_bins: bool = False, want_y: bool = True):
+    x = _f32c(x, "x")
+    scale = _f32c(scale, "scale")
+    if scale.numel() != 1:
+        raise ValueError("AdaLog quantisers are per-tensor (scale must have one element)")
+    if q.dtype != torch.int64 or not q.is_cuda:
+        raise TypeError("q must be an int64 tensor on the device (the quantiser's buffer)")
+    y = torch.empty_like(x) if want_y else None
+    bins = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_bins else None
+    lib = _lib.load()
+    rc = lib.adalog_log_fake_quant_f32(_ptr(x), _ptr(y), _ptr(bins), x.numel(), _ptr(scale), _ptr(q),
+                                       _ptr(None if train_form else _f32c(table1, "table1")),
+                                       _ptr(None if train_form else _f32c(table2, "table2")), int(n_bits),
+                                       _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(sub_shift)),
+                                       int(bool(train_form)), _stream())
+    _lib.check(rc, "adalog_log_fake_quant_f32")
+    return (y, bins) if want_bins else y
+
+
+# ------------------------------------------------------------------------------------------------ operand packing
+def _view3(x3: torch.Tensor):
+    if x3.dim() != 3 or x3.dtype != torch.float32 or not x3.is_cuda:
+        raise ValueError("operand must be a 3-D float32 device view [G, R, K] (any strides)")
+    return x3.shape[0], x3.shape[1], x3.shape[2], x3.stride(0), x3.stride(1), x3.stride(2)
+
+
+def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr: int, n_bits: int, dtype: int = I8,
+                 want_rowsum: bool = False):
+    """-> packed [C, G, R, Kp] (int8 / bf16 / fp32) [+ int32 rowsum [C, G, R]]."""
+    G, R, K, sg, sr, sk = _view3(x3)
+    scale, zero_point = _f32c(scale, "scale"), _f32c(zero_point, "zero_point")
+    Kp = pad_k(K, dtype)
+    out = torch.empty((C, G, R, Kp), dtype=_TORCH_DT[dtype], device=x3.device)
+    rowsum = torch.empty((C, G, R), dtype=torch.int32, device=x3.device) if want_rowsum else None
+    rc = _lib.load().adalog_pack_uniform(x3.data_ptr(), G, R, K, sg, sr, sk, _ptr(scale), _ptr(zero_point), C, pc, gmod,
+                                        pg, pr, int(n_bits), dtype, out.data_ptr(), Kp, _ptr(rowsum), _stream())
+    _lib.check(rc, "adalog_pack_uniform")
+    return (out, rowsum) if want_rowsum else out
+
+
+def pack_adalog(x3, scale, qv, C: int, pc: int, gmod: int, pg: int, n_bits: int, mant37, shift=None,
+                clamp_u: bool = True):
+    G, R, K, sg, sr, sk = _view3(x3)
+    Kp = pad_k(K, BF16)
+    out = torch.empty((C, G, R, Kp), dtype=torch.bfloat16, device=x3.device)
+    rc = _lib.load().adalog_pack_adalog_bf16(x3.data_ptr(), G, R, K, sg, sr, sk, _ptr(_f32c(scale, "scale")),
+                                            _ptr(_f32c(qv, "qv")), C, pc, gmod, pg, int(n_bits),
+                                            _ptr(_f32c(mant37, "mant37")),
+                                            _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(clamp_u)),
+                                            out.data_ptr(), Kp, _stream())
+    _lib.check(rc, "adalog_pack_adalog_bf16")
+    return out
+
+
+def pack_raw(x3):
+    G, R, K, sg, sr, sk = _view3(x3)
+    Kp = pad_k(K, F32)
+    out = torch.empty((1, G, R, Kp), dtype=torch.float32, device=x3.device)
+    rc = _lib.load().adalog_pack_raw_f32(x3.data_ptr(), G, R, K, sg, sr, sk, out.data_ptr(), Kp, _stream())
+    _lib.check(rc, "adalog_pack_raw_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ scoring GEMM
+class Strided:
+    """A device fp32 parameter with (candidate, head, column) element strides for the GEMM epilogue."""
+    __slots__ = ("t", "c", "g", "n")
+
+    def __init__(self, t, c=0, g=0, n=0):
+        self.t, self.c, self.g, self.n = t, int(c), int(g), int(n)
+
+    def checked(self):
+        self.t = _f32c(self.t, "epilogue parameter")
+        return self
+
+
+def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
+               bias: Optional[Strided], keep_h: bool, keep_n: bool, norm: float, sa_mul: float = 1.0,
+               ref_div: int = 1, a_shared: bool = False, b_shared: bool = False):
+    """scores = finish(gemm_score(...)).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N, Kp]; ref: [G, M, N/ref_div] fp32.
+
+    Returns fp32 scores of shape [C, (gmod if keep_h), (N if keep_n)] (trailing singleton dims dropped to [C, 1]).
+    """
+    lib = _lib.load()
+    sa, sb = sa.checked(), sb.checked()
+    bias = None if bias is None else bias.checked()
+    Kp = A.shape[-1]
+    assert B.shape[-1] == Kp and A.shape[-2] == M and B.shape[-2] == N
+    assert A.dtype == _TORCH_DT[dtype] and B.dtype == _TORCH_DT[dtype] and A.is_contiguous() and B.is_contiguous()
+    sAc = 0 if A.shape[0] == 1 and C > 1 or a_shared else A.stride(0)
+    sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
+    sBc = 0 if B.shape[0] == 1 and C > 1 or b_shared else B.stride(0)
+    sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
+    ref = _f32c(ref, "ref")
+    ldr = ref.shape[-1]
+    sRg = 0 if G == 1 else M * ldr
+    n_part = lib.adalog_gemm_score_partial_elems(M, N, C, G)
+    partial = torch.empty(n_part, dtype=torch.float32, device=A.device)
+    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, N, Kp, C, G, gmod,
+                               ref.data_ptr(), ldr, sRg, ref_div, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul),
+                               sb.t.data_ptr(), sb.c, sb.g, sb.n,
+                               None if bias is None else bias.t.data_ptr(),
+                               0 if bias is None else bias.c, 0 if bias is None else bias.g,
+                               0 if bias is None else bias.n,
+                               partial.data_ptr(), n_part, None, 0, 0, 0, _stream())
+    _lib.check(rc, "adalog_gemm_score")
+    cols = (gmod if keep_h else 1) * (N if keep_n else 1)
+    scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
+    rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), M, N, C, G, gmod, int(keep_h), int(keep_n),
+                                  float(norm), _stream())
+    _lib.check(rc, "adalog_finish_scores")
+    return scores
+
+
+def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, sb: Strided, bias: Optional[Strided],
+             sa_mul: float = 1.0):
+    """Quantised forward: out[g] = (A[g] . B[g]^T) * sa * sb[n] + bias[n]   -> fp32 [G, M, N]."""
+    lib = _lib.load()
+    sa, sb = sa.checked(), sb.checked()
+    bias = None if bias is None else bias.checked()
+    Kp = A.shape[-1]
+    assert B.shape[-1] == Kp and A.dtype == _TORCH_DT[dtype] and B.dtype == _TORCH_DT[dtype]
+    sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
+    sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
+    out = torch.empty((G, M, N), dtype=torch.float32, device=A.device)
+    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), 0, sAg, 0, sBg, M, N, Kp, 1, G, gmod, None, 0, 0, 1,
+                               sa.t.data_ptr(), sa.c, sa.g, float(sa_mul), sb.t.data_ptr(), sb.c, sb.g, sb.n,
+                               None if bias is None else bias.t.data_ptr(),
+                               0 if bias is None else bias.c, 0 if bias is None else bias.g,
+                               0 if bias is None else bias.n,
+                               None, 0, out.data_ptr(), N, 0, M * N, _stream())
+    _lib.check(rc, "adalog_gemm_score(out)")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ FPCS pieces
+def topk(scores, k: int):
+    scores = _f32c(scores, "scores")
+    P, cols = scores.shape
+    idx = torch.empty((k, cols), dtype=torch.int32, device=scores.device)
+    rc = _lib.load().adalog_topk(scores.data_ptr(), P, cols, int(k), idx.data_ptr(), _stream())
+    _lib.check(rc, "adalog_topk")
+    return idx
+
+
+def fpcs_next(scale, zp, third, idx, k: int, new_cnt: int, lin, delta, clamp_min: Optional[float]):
+    """new_cnt > 0: returns the next grid (scale, zp, third) of k*new_cnt candidates and updates ``delta`` in place;
+    new_cnt == 0: returns the committed winner, each of shape [cols]."""
+    scale = _f32c(scale, "scale")
+    cols = scale.shape[1]
+    rows = k * new_cnt if new_cnt > 0 else 1
+    mk = lambda src: None if src is None else torch.empty((rows, cols), dtype=torch.float32, device=scale.device)
+    o_s, o_z, o_t = mk(scale), mk(zp), mk(third)
+    rc = _lib.load().adalog_fpcs_next(scale.data_ptr(), _ptr(zp), _ptr(third), cols, idx.data_ptr(), int(k), int(new_cnt),
+                                     _ptr(lin), _ptr(delta), int(clamp_min is not None),
+                                     float(clamp_min if clamp_min is not None else 0.0), o_s.data_ptr(), _ptr(o_z),
+                                     _ptr(o_t), _stream())
+    _lib.check(rc, "adalog_fpcs_next")
+    if new_cnt == 0:
+        return o_s[0], (None if o_z is None else o_z[0]), (None if o_t is None else o_t[0])
+    return o_s, o_z, o_t
+
+
+def candidate_grid(quant4, num_scale: int, num_zp: int, zp_min: int, n_bits: int, lin, clamp_min: Optional[float]):
+    quant4 = _f32c(quant4, "quant4")
+    cols = quant4.shape[1]
+    P = num_scale * num_zp
+    scale = torch.empty((P, cols), dtype=torch.float32, device=quant4.device)
+    zp = torch.empty_like(scale)
+    delta = torch.empty(cols, dtype=torch.float32, device=quant4.device)
+    rc = _lib.load().adalog_candidate_grid(quant4.data_ptr(), cols, num_scale, num_zp, zp_min, int(n_bits), lin.data_ptr(),
+                                          int(clamp_min is not None), float(clamp_min or 0.0), scale.data_ptr(),
+                                          zp.data_ptr(), delta.data_ptr(), _stream())
+    _lib.check(rc, "adalog_candidate_grid")
+    return scale, zp, delta
+
+
+def score_w_self(w2, scale, zp, n_bits: int):
+    w2 = _f32c(w2, "weight")
+    rows, I = w2.shape
+    P = scale.shape[0]
+    scores = torch.empty((P, rows), dtype=torch.float32, device=w2.device)
+    rc = _lib.load().adalog_score_w_self(w2.data_ptr(), rows, I, _f32c(scale, "scale").data_ptr(),
+                                        _f32c(zp, "zp").data_ptr(), P, int(n_bits), scores.data_ptr(), _stream())
+    _lib.check(rc, "adalog_score_w_self")
+    return scores
+
+
+def score_a_self(x2, scale, zp, channel_wise: bool, n_bits: int, norm: float):
+    x2 = _f32c(x2, "x")
+    rows, I = x2.shape
+    P = scale.shape[0]
+    lib = _lib.load()
+    n_part = lib.adalog_score_a_self_partial_elems(rows, I, P)
+    partial = torch.empty(n_part, dtype=torch.float32, device=x2.device)
+    scores = torch.empty((P, I if channel_wise else 1), dtype=torch.float32, device=x2.device)
+    rc = lib.adalog_score_a_self(x2.data_ptr(), rows, I, _f32c(scale, "scale").data_ptr(), _f32c(zp, "zp").data_ptr(), P,
+                                 int(bool(channel_wise)), int(n_bits), float(norm), partial.data_ptr(), n_part,
+                                 scores.data_ptr(), _stream())
+    _lib.check(rc, "adalog_score_a_self")
+    return scores
+
+
+# ------------------------------------------------------------------------------------------------ order statistics
+def quantile_ranks(qs, n: int):
+    """Host-side rank arithmetic exactly as ATen's quantile does it: pos = q * (n - 1) in fp32."""
+    pos = torch.tensor(qs, dtype=torch.float32) * (n - 1)
+    lo = pos.floor()
+    hi = pos.ceil()
+    lohi = torch.stack([lo, hi], dim=1).reshape(-1).to(torch.int64)
+    return lohi, (pos - lo)
+
+
+def quantile_rows(x2, qs, mbs: int = 1):
+    """torch.quantile(x2, qs, dim=-1) followed by the mean over groups of ``mbs`` rows -> [len(qs), S/mbs]."""
+    x2 = _f32c(x2, "x")
+    S, n = x2.shape
+    nq = len(qs)
+    lohi, w = quantile_ranks(qs, n)
+    lohi, w = lohi.to(x2.device), w.to(x2.device)
+    lib = _lib.load()
+    ws_bytes = lib.adalog_select_workspace_bytes(S, 2 * nq)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device)
+    out = torch.empty((nq, S // mbs), dtype=torch.float32, device=x2.device)
+    rc = lib.adalog_quantile_rows(x2.data_ptr(), S, n, nq, lohi.data_ptr(), w.data_ptr(), int(mbs), out.data_ptr(),
+                                  ws.data_ptr(), ws_bytes, _stream())
+    _lib.check(rc, "adalog_quantile_rows")
+    return out
+
+
+def positive_percentile_rows(x2, qs):
+    x2 = _f32c(x2, "x")
+    S, n = x2.shape
+    nq = len(qs)
+    qf = torch.tensor(qs, dtype=torch.float32).to(x2.device)
+    lib = _lib.load()
+    ws_bytes = lib.adalog_select_workspace_bytes(S, nq)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device)
+    out = torch.empty((nq, S), dtype=torch.float32, device=x2.device)
+    rc = lib.adalog_positive_percentile_rows(x2.data_ptr(), S, n, nq, qf.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                             ws_bytes, _stream())
+    _lib.check(rc, "adalog_positive_percentile_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ small vector ops
+def shift_fold(rowsum, w_scale, shift, bias):
+    """fold[c][o] = bias[o] - shift * (w_scale[c][o] * rowsum[c][o])   (post-GELU shift folded into the bias)."""
+    C, O = rowsum.shape
+    w_scale = _f32c(w_scale, "w_scale")
+    out = torch.empty((C, O), dtype=torch.float32, device=rowsum.device)
+    rc = _lib.load().adalog_shift_fold(rowsum.data_ptr(), w_scale.data_ptr(), _f32c(shift, "shift").data_ptr(),
+                                      _ptr(None if bias is None else _f32c(bias, "bias")), C, O, out.data_ptr(), _stream())
+    _lib.check(rc, "adalog_shift_fold")
+    return out
+
+
+def minmax_rows(w2):
+    """Per-row (min, max) of a [rows, I] matrix (K4; linear.py:267-273)."""
+    w2 = _f32c(w2, "w")
+    rows, I = w2.shape
+    mn = torch.empty(rows, dtype=torch.float32, device=w2.device)
+    mx = torch.empty_like(mn)
+    rc = _lib.load().adalog_minmax_rows(w2.data_ptr(), rows, I, 0, mn.data_ptr(), mx.data_ptr(), _stream())
+    _lib.check(rc, "adalog_minmax_rows")
+    return mn, mx
+
+
+def absminmax(x2, per_channel: bool):
+    """(min |x|, max |x|) per tensor ([1]) or per column ([I]) of a [rows, I] matrix (K4; linear.py:282-287)."""
+    x2 = _f32c(x2, "x")
+    rows, I = x2.shape
+    n = I if per_channel else 1
+    mn = torch.empty(n, dtype=torch.float32, device=x2.device)
+    mx = torch.empty_like(mn)
+    rc = _lib.load().adalog_absminmax_cols(x2.data_ptr(), rows, I, int(bool(per_channel)), mn.data_ptr(), mx.data_ptr(),
+                                          _stream())
+    _lib.check(rc, "adalog_absminmax_cols")
+    return mn, mx

@@ -1,0 +1,525 @@
+"""Quantised nn.Linear family -- module API of reference quant_layers/linear.py (class names, constructor signatures,
+attributes, state_dict keys, mode strings), with every search and forward pass running as HIP kernels on the MI355X.
+
+Class chain kept for isinstance dispatch by the calibrator / block reconstructor (calibrator.py:40-53):
+  MinMaxQuantLinear -> PTQSLQuantLinear -> PTQSLBatchingQuantLinear -> AsymmetricallyBatchingQuantLinear
+      -> AsymmetricallyChannelWiseBatchingQuantLinear   (qkv / fc1 / reduction: per-channel search + LayerNorm fold)
+      -> PostGeluLogBasedBatchingQuantLinear            (fc2: shifted AdaLog activation, joint (scale, base) search)
+
+What differs from the reference, by design:
+  * captured calibration tensors (raw_input / raw_out) stay in HBM for the whole search (no .cpu()/.cuda() round
+    trips, no memory-derived candidate chunking: linear.py:111-121 has no counterpart);
+  * a scoring call = pack operands once (int8 / bf16) + ONE MFMA GEMM with a fused squared-error epilogue;
+  * the FPCS loop is sync-free; winners are committed on the device;
+  * images may be sharded over ranks (adalog_amd.parallel): raw_input/raw_out then hold the local shard.
+Out of scope: the symmetric PTQSL search (dead code in the reference, linear.py:171) and
+PostGeluTwinUniformBatchingQuantLinear (ptq4vit ablation).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import backend, search
+from ..ops import BF16, I8, Strided, pad_k  # noqa: F401  (dtype codes / epilogue parameter helper; pure metadata)
+from ..quantizers.logarithm import ShiftAdaLogQuantizer
+from ..quantizers.uniform import UniformQuantizer
+
+GELU_SHIFT = 0.16997124254703522      # -min(gelu(x)), reference linear.py:749
+MAX_PACK_BYTES = 6 << 30              # candidates are scored in chunks when a packed operand would exceed this
+
+
+class MinMaxQuantLinear(nn.Linear):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, mode="raw", w_bit=8, a_bit=8):
+        super().__init__(in_features, out_features, bias)
+        self.mode = mode
+        self.w_quantizer = UniformQuantizer(n_bits=w_bit, symmetric=True, channel_wise=False)
+        self.a_quantizer = UniformQuantizer(n_bits=a_bit, symmetric=True, channel_wise=False)
+        self.raw_input = None
+        self.raw_out = None
+        self.tmp_input = None
+        self.tmp_out = None
+        self.calibrated = False
+
+    def forward(self, x):
+        if self.mode == 'raw':
+            return F.linear(x, self.weight, self.bias)
+        if self.mode == "quant_forward":
+            return self.quant_forward(x)
+        if self.mode == 'debug_only_quant_weight':
+            return self.debug_only_quant_weight(x)
+        if self.mode == 'debug_only_quant_act':
+            return self.debug_only_quant_act(x)
+        raise NotImplementedError
+
+    def quant_weight_bias(self):
+        return self.w_quantizer(self.weight), self.bias
+
+    def quant_input(self, x):
+        return self.a_quantizer(x)
+
+    def quant_forward(self, x):
+        assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
+        w_sim, bias_sim = self.quant_weight_bias()
+        return F.linear(self.quant_input(x), w_sim, bias_sim)
+
+    def debug_only_quant_weight(self, x):
+        w_sim, bias_sim = self.quant_weight_bias()
+        return F.linear(x, w_sim, bias_sim)
+
+    def debug_only_quant_act(self, x):
+        return F.linear(self.quant_input(x), self.weight, self.bias)
+
+
+class PTQSLQuantLinear(MinMaxQuantLinear):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, mode="raw", w_bit=8, a_bit=8,
+                 search_round=1, eq_n=100, n_V=1):
+        super().__init__(in_features, out_features, bias=bias, mode=mode, w_bit=w_bit, a_bit=a_bit)
+        self.w_quantizer = UniformQuantizer(n_bits=w_bit, symmetric=True, channel_wise=True)
+        self.a_quantizer = UniformQuantizer(n_bits=a_bit, symmetric=True, channel_wise=False)
+        self.search_round = search_round
+        self.eq_n = eq_n
+        self.parallel_eq_n = eq_n
+        self.n_V = n_V
+        self.crb_rows = out_features // n_V
+        self.w_quantizer.scale = nn.Parameter(torch.zeros((n_V, self.crb_rows, 1)))
+        self.a_quantizer.scale = nn.Parameter(torch.zeros((1)))
+
+    def quant_weight_bias(self):
+        w_sim = self.w_quantizer(self.weight.view(self.n_V, self.crb_rows, self.in_features)).view(
+            self.out_features, self.in_features)
+        return w_sim, self.bias
+
+
+class PTQSLBatchingQuantLinear(PTQSLQuantLinear):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, mode="raw", w_bit=8, a_bit=8,
+                 calib_batch_size=32, search_round=1, eq_n=100, n_V=1):
+        super().__init__(in_features, out_features, bias=bias, mode=mode, w_bit=w_bit, a_bit=a_bit,
+                         search_round=search_round, eq_n=eq_n, n_V=n_V)
+        self.calib_batch_size = calib_batch_size
+
+    def _initialize_calib_parameters(self):
+        """The reference sizes candidate chunks from free GPU memory (linear.py:111-121); with the operands packed to
+        int8/bf16 and the error reduced in registers there is nothing to size -- only the shard's image count."""
+        self.calib_size = self.raw_input.shape[0]
+        self.parallel_eq_n = self.eq_n
+
+
+class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, mode="raw", w_bit=8, a_bit=8,
+                 calib_batch_size=32, search_round=1, eq_n=100, n_V=1, fpcs=False, steps=4):
+        super().__init__(in_features, out_features, bias=bias, mode=mode, w_bit=w_bit, a_bit=a_bit,
+                         calib_batch_size=calib_batch_size, search_round=search_round, eq_n=eq_n, n_V=n_V)
+        self.fpcs = fpcs
+        self.steps = steps
+        del self.a_quantizer, self.w_quantizer
+        self.w_quantizer = UniformQuantizer(n_bits=w_bit, symmetric=False, channel_wise=True)
+        self.a_quantizer = UniformQuantizer(n_bits=a_bit, symmetric=False, channel_wise=False)
+        self.a_quantizer.scale = nn.Parameter(torch.zeros((1)))
+        self.a_quantizer.zero_point = nn.Parameter(torch.zeros((1)))
+        self.w_quantizer.scale = nn.Parameter(torch.zeros((n_V, self.crb_rows, 1)))
+        self.w_quantizer.zero_point = nn.Parameter(torch.zeros((n_V, self.crb_rows, 1)))
+
+    # ------------------------------------------------------------------ min/max initialisation (linear.py:265-294)
+    def _initialize_weight_scale(self):
+        be = backend.get()
+        mn, mx = be.minmax_rows(self.weight.data.view(self.out_features, self.in_features))
+        L2 = 2 * self.w_quantizer.n_levels - 1
+        scale = ((mx - mn) / L2).view(self.n_V, self.crb_rows, 1)
+        self.w_quantizer.scale.data.copy_(scale)
+        self.w_quantizer.zero_point.data.copy_(-mn.view(self.n_V, self.crb_rows, 1) / scale)
+        self.w_quantizer.inited = True
+
+    def _initialize_activation_scale(self):
+        from .. import parallel
+        be = backend.get()
+        x2 = self.raw_input.reshape(-1, self.in_features)
+        amn, amx = be.absminmax(x2, per_channel=self.a_quantizer.channel_wise)     # note: of |x| (linear.py:283-287)
+        amx, amn = parallel.all_reduce_max(amx), parallel.all_reduce_min(amn)
+        scale = (amx - amn) / (2 * self.a_quantizer.n_levels - 1)
+        self.a_quantizer.scale.data.copy_(scale.view(self.a_quantizer.scale.shape))
+        self.a_quantizer.zero_point.data.copy_((-amn / scale).view(self.a_quantizer.zero_point.shape))
+        self.a_quantizer.inited = True
+
+    # ------------------------------------------------------------------ helpers
+    def _tokens_per_image(self):
+        x = self.raw_input
+        return x.numel() // (x.shape[0] * x.shape[-1])
+
+    def _x2(self):
+        return self.raw_input.reshape(-1, self.in_features)
+
+    def _ref2(self):
+        return self.raw_out.reshape(1, -1, self.out_features)
+
+    def _w2(self):
+        return self.weight.data.view(self.out_features, self.in_features)
+
+    def _commit_w(self, scale, zp):
+        self.w_quantizer.scale.data.copy_(scale.view(self.n_V, self.crb_rows, 1))
+        self.w_quantizer.zero_point.data.copy_(zp.view(self.n_V, self.crb_rows, 1))
+        self.w_quantizer.inited = True
+
+    def _commit_a(self, scale, zp):
+        self.a_quantizer.scale.data.copy_(scale.view(self.a_quantizer.scale.shape))
+        self.a_quantizer.zero_point.data.copy_(zp.view(self.a_quantizer.zero_point.shape))
+        self.a_quantizer.inited = True
+
+    def _cand_chunk(self, rows, kp_bytes):
+        return max(1, min(self.eq_n, MAX_PACK_BYTES // max(1, rows * kp_bytes)))
+
+    # ------------------------------------------------------------------ scoring calls (one = eq_n candidates)
+    def _pack_x_fixed(self):
+        """Activation operand quantised with the current a_quantizer -> (dtype, packed [1,1,M,Kp], sa, sa_mul, extra)."""
+        be = backend.get()
+        aq = self.a_quantizer
+        x3 = self._x2().unsqueeze(0)
+        xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
+        return I8, xp, Strided(aq.scale.data.view(-1)), 1.0, None
+
+    def _score_w(self, fixed, scale, zp):
+        """linear.py:355-384 -> scores [P, O] = -sum_images mean_tokens (raw_out - q_a(x) . fq_p(W)^T - b)^2."""
+        be = backend.get()
+        dt, xp, sa, sa_mul, shift = fixed
+        M = xp.shape[2]
+        P = scale.shape[0]
+        wq = self.w_quantizer
+        out = []
+        chunk = self._cand_chunk(self.out_features, pad_k(self.in_features, dt) * (1 if dt == I8 else 2))
+        for s in range(0, P, chunk):
+            e = min(P, s + chunk)
+            sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
+            bias = None if self.bias is None else Strided(self.bias.data, n=1)
+            if shift is None:
+                wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1, wq.n_bits, dt)
+            else:
+                # post-GELU operand is y*s - shift: the -shift term is a per-(candidate, row) constant
+                #   -shift * s_w[p,o] * sum_i (q_w - z_w)  folded into the bias (cf. reparam_bias, linear.py:999-1006)
+                wp, rowsum = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1,
+                                             wq.n_bits, dt, want_rowsum=True)
+                fold = be.shift_fold(rowsum.view(e - s, -1), sc, shift, None if self.bias is None else self.bias.data)
+                bias = Strided(fold, c=self.out_features, n=1)
+            out.append(be.gemm_score(dt, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2(), sa,
+                                     Strided(sc, c=self.out_features, n=1), bias, False, True,
+                                     1.0 / self._tokens_per_image(), sa_mul=sa_mul))
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+    def _pack_w_fixed(self, dt=I8, want_rowsum=False):
+        be = backend.get()
+        wq = self.w_quantizer
+        return be.pack_uniform(self._w2().unsqueeze(0), wq.scale.data.view(-1), wq.zero_point.data.view(-1), 1, 0, 1, 0, 1,
+                               wq.n_bits, dt, want_rowsum=want_rowsum)
+
+    def _score_a(self, wp, scale, zp):
+        """linear.py:394-423 -> scores [P, 1] = -sum_images mean_{tokens,out} (raw_out - fq_p(x) . q_w(W)^T - b)^2."""
+        be = backend.get()
+        aq = self.a_quantizer
+        x3 = self._x2().unsqueeze(0)
+        M = x3.shape[1]
+        P = scale.shape[0]
+        out = []
+        chunk = self._cand_chunk(M, pad_k(self.in_features, I8))
+        bias = None if self.bias is None else Strided(self.bias.data, n=1)
+        for s in range(0, P, chunk):
+            e = min(P, s + chunk)
+            sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
+            xp = be.pack_uniform(x3, sc, zc, e - s, 1, 1, 0, 0, aq.n_bits, I8)
+            out.append(be.gemm_score(I8, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2(),
+                                     Strided(sc, c=1), Strided(self.w_quantizer.scale.data.view(-1), n=1), bias,
+                                     False, False, 1.0 / (self._tokens_per_image() * self.out_features)))
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+    def _score_w_self(self, scale, zp):
+        return backend.get().score_w_self(self._w2(), scale, zp, self.w_quantizer.n_bits)
+
+    def _score_a_self(self, scale, zp):
+        cw = self.a_quantizer.channel_wise
+        T = self._tokens_per_image()
+        norm = 1.0 / T if cw else 1.0 / (T * self.in_features)
+        return backend.get().score_a_self(self._x2(), scale, zp, cw, self.a_quantizer.n_bits, norm)
+
+    # ------------------------------------------------------------------ FPCS (linear.py:483-523)
+    def weight_fpcs(self, fpcs_width=16, steps=6, search_strategy="output"):
+        scale, zp, delta = search.weight_grid(self._w2(), self.w_quantizer.n_bits, self.eq_n)
+        if search_strategy == "self":
+            fn = lambda s, z, t: self._score_w_self(s, z)
+        else:
+            fixed = self._pack_x_fixed()
+            fn = lambda s, z, t: self._score_w(fixed, s, z)
+        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
+        if res is not None:
+            self._commit_w(res[0], res[1])
+
+    def activation_fpcs(self, fpcs_width=16, steps=6, search_strategy="output"):
+        aq = self.a_quantizer
+        scale, zp, delta = search.activation_grid(self.raw_input, aq.n_bits, self.eq_n, aq.channel_wise)
+        if search_strategy == "self":
+            fn = lambda s, z, t: self._score_a_self(s, z)
+        else:
+            wp = self._pack_w_fixed()
+            fn = lambda s, z, t: self._score_a(wp, s, z)
+        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, 1e-4)
+        if res is not None:
+            self._commit_a(res[0], res[1])
+
+    def hyperparameter_searching(self):
+        """linear.py:525-545 with fpcs=True (the only mode the shipped configs use, configs/*.py:20)."""
+        if not self.fpcs:
+            raise NotImplementedError("non-FPCS single-pass search is not part of the accelerated path (configs use fpcs=True)")
+        self._initialize_calib_parameters()
+        self.weight_fpcs(steps=self.steps, search_strategy="self")
+        self.activation_fpcs(steps=self.steps, search_strategy="self")
+        for _ in range(self.search_round):
+            self.weight_fpcs(steps=self.steps, search_strategy="output")
+            self.activation_fpcs(steps=self.steps, search_strategy="output")
+        self.calibrated = True
+        del self.raw_input, self.raw_out
+        return None
+
+    # ------------------------------------------------------------------ quantised forward (linear.py:46-51), fused
+    def quant_forward(self, x):
+        assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
+        if torch.is_grad_enabled() and (self.w_quantizer.training_mode or self.a_quantizer.training_mode
+                                        or not isinstance(self.w_quantizer, UniformQuantizer)):
+            return super().quant_forward(x)                    # BRECQ: differentiable fake-quant + GEMM
+        be = backend.get()
+        aq = self.a_quantizer
+        if not isinstance(self.w_quantizer, UniformQuantizer) or aq.n_bits > 7 or self.w_quantizer.n_bits > 7:
+            return super().quant_forward(x)
+        lead = x.shape[:-1]
+        x3 = x.reshape(1, -1, self.in_features)
+        xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
+        wp = self._pack_w_fixed()
+        out = be.gemm_out(I8, xp, wp, x3.shape[1], self.out_features, 1, 1, Strided(aq.scale.data.view(-1)),
+                          Strided(self.w_quantizer.scale.data.view(-1), n=1),
+                          None if self.bias is None else Strided(self.bias.data, n=1))
+        return out.view(*lead, self.out_features)
+
+
+class AsymmetricallyChannelWiseBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, mode="raw", w_bit=8, a_bit=8,
+                 calib_batch_size=None, search_round=1, eq_n=100, n_V=1, fpcs=False, steps=4):
+        super().__init__(in_features, out_features, bias=bias, mode=mode, w_bit=w_bit, a_bit=a_bit,
+                         calib_batch_size=calib_batch_size, search_round=search_round, eq_n=eq_n, n_V=n_V,
+                         fpcs=fpcs, steps=steps)
+        del self.a_quantizer
+        self.a_quantizer = UniformQuantizer(n_bits=a_bit, symmetric=False, channel_wise=True)
+        self.a_quantizer.scale = nn.Parameter(torch.zeros((in_features)))
+        self.a_quantizer.zero_point = nn.Parameter(torch.zeros((in_features)))
+        self._prev_layer = None
+
+    def __setattr__(self, name, value):
+        if name == "prev_layer":                     # keep the LayerNorm out of _modules (linear.py:571-575)
+            self.__dict__['_prev_layer'] = value
+        else:
+            super().__setattr__(name, value)
+
+    @property
+    def prev_layer(self):
+        return self._prev_layer
+
+    def quant_forward(self, x):
+        if self.a_quantizer.channel_wise:            # only between search and reparam; plain composition
+            return MinMaxQuantLinear.quant_forward(self, x)
+        return super().quant_forward(x)
+
+    def hyperparameter_searching(self):
+        """linear.py:585-594: per-channel activation FPCS against the activation's own MSE."""
+        assert self.a_quantizer.channel_wise and self.w_quantizer.channel_wise
+        if not self.fpcs:
+            raise NotImplementedError("non-FPCS search is not part of the accelerated path")
+        self._initialize_calib_parameters()
+        self.activation_fpcs(steps=self.steps, search_strategy="self")
+        self.calibrated = True
+
+    def reparam_step1(self):
+        """linear.py:596-612: fold the per-channel (scale, zero point) into the preceding LayerNorm and this weight."""
+        self.calibrated = False
+        aq = self.a_quantizer
+        channel_min = -aq.zero_point * aq.scale
+        target_channel_scale = torch.mean(aq.scale).view(1)
+        target_channel_zero_point = torch.mean(aq.zero_point).round().view(1)
+        target_channel_min = -target_channel_zero_point * target_channel_scale
+        r = (aq.scale / target_channel_scale)
+        b = channel_min / r - target_channel_min
+        self.prev_layer.weight.data = self.prev_layer.weight.data / r
+        self.prev_layer.bias.data = self.prev_layer.bias.data / r.view(-1) - b
+        self.weight.data = self.weight.data * r.view(1, -1)
+        extra = torch.mm(self.weight.data, b.reshape(-1, 1)).reshape(-1)
+        if self.bias is not None:
+            self.bias.data = self.bias.data + extra
+        else:
+            self.bias = nn.Parameter(torch.zeros(self.out_features, device=self.weight.device))
+            self.bias.data = extra
+        return r, b, target_channel_scale, target_channel_zero_point
+
+    def reparam(self):
+        """linear.py:614-621."""
+        with torch.no_grad():
+            r, b, t_scale, t_zp = self.reparam_step1()
+            self.raw_input = self.raw_input / r - b
+            del self.a_quantizer.scale, self.a_quantizer.zero_point
+            self.a_quantizer.channel_wise = False
+            self.a_quantizer.scale = nn.Parameter(t_scale.detach().clone())
+            self.a_quantizer.zero_point = nn.Parameter(t_zp.detach().clone())
+            AsymmetricallyBatchingQuantLinear.hyperparameter_searching(self)
+
+
+class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
+    """fc2: activation = ShiftAdaLog (log base 2^(-q/37), q searched), bias re-parameterised after the search."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, mode="raw", w_bit=8, a_bit=8,
+                 calib_batch_size=None, search_round=1, eq_n=100, n_V=1, quantizer='adalog', fpcs=False, steps=4):
+        super().__init__(in_features, out_features, bias=bias, mode=mode, w_bit=w_bit, a_bit=a_bit,
+                         calib_batch_size=calib_batch_size, search_round=search_round, eq_n=eq_n, n_V=n_V,
+                         fpcs=fpcs, steps=steps)
+        if quantizer != 'adalog':
+            raise NotImplementedError("only the 'adalog' post-GELU quantiser is accelerated (log2/logsqrt2 are ablations)")
+        del self.a_quantizer
+        self.a_quantizer = ShiftAdaLogQuantizer(n_bits=a_bit, symmetric=False, channel_wise=False)
+        self.a_quantizer.scale = nn.Parameter(torch.zeros((1)))
+        self.a_quantizer.shift.data.copy_(torch.tensor(GELU_SHIFT))
+        # search-time mantissa table (linear.py:750-752), fp32 ops as in the reference
+        self.table = torch.tensor([2 ** (-j / self.a_quantizer.r) for j in range(120)])
+        self.table_scale = 1. / (4 * self.a_quantizer.n_levels - 2)
+        self.table = torch.round(self.table / self.table_scale) * self.table_scale
+        self._q_host = 37
+
+    def _mant37(self, device):
+        """Integer numerators of the table (15..30 for 4 bit), the bf16-exact MFMA operand."""
+        num = torch.round(self.table[:37] / self.table_scale)
+        return search.const_tensor(num.tolist(), device)
+
+    def _ts32(self):
+        return float(torch.tensor(self.table_scale, dtype=torch.float32))
+
+    # ---- percentile candidates (linear.py:763-814)
+    def calculate_percentile_activation_candidates(self, l=0.9, r=1.0):
+        from .. import parallel
+        be = backend.get()
+        xg = parallel.gather_images(self.raw_input)
+        pp = be.positive_percentile_rows(xg.reshape(1, -1), torch.tensor([l, r]).tolist())     # [2, 1]
+        cand = (pp.view(1, 2) + self.a_quantizer.shift.data.view(1, 1))
+        frac = search.const_tensor([i / (self.eq_n - 1) for i in range(self.eq_n)], cand.device).view(1, -1)
+        scales = cand[:, 0:1] + (cand[:, 1:] - cand[:, 0:1]) * frac
+        return cand, scales
+
+    # ---- fixed operands
+    def _pack_x_fixed(self):
+        be = backend.get()
+        aq = self.a_quantizer
+        dev = self.weight.device
+        x3 = self._x2().unsqueeze(0)
+        qv = search.const_tensor([float(self._q_host)], dev)
+        xp = be.pack_adalog(x3, aq.scale.data.view(-1), qv, 1, 0, 1, 0, aq.n_bits, self._mant37(dev),
+                            shift=aq.shift.data, clamp_u=True)
+        return BF16, xp, Strided(aq.scale.data.view(-1)), self._ts32(), aq.shift.data
+
+    def _score_scale_logbase(self, wp, bias_fold, scale, qv):
+        """linear.py:816-848 / 856-890 / 898-931 -> scores [P, 1] for per-candidate (scale_p, q_p)."""
+        be = backend.get()
+        aq = self.a_quantizer
+        dev = self.weight.device
+        x3 = self._x2().unsqueeze(0)
+        M = x3.shape[1]
+        P = scale.shape[0]
+        out = []
+        chunk = self._cand_chunk(M, pad_k(self.in_features, BF16) * 2)
+        for s in range(0, P, chunk):
+            e = min(P, s + chunk)
+            sc, qc = scale[s:e].contiguous(), qv[s:e].contiguous()
+            xp = be.pack_adalog(x3, sc, qc, e - s, 1, 1, 0, aq.n_bits, self._mant37(dev), shift=aq.shift.data, clamp_u=True)
+            out.append(be.gemm_score(BF16, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2(),
+                                     Strided(sc, c=1), Strided(self.w_quantizer.scale.data.view(-1), n=1),
+                                     Strided(bias_fold, n=1), False, False,
+                                     1.0 / (self._tokens_per_image() * self.out_features), sa_mul=self._ts32()))
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+    def activation_fpcs(self, ud_candidates, base_num=8, scale_num=16, fpcs_width=32, steps=6):
+        """linear.py:941-967: 128 log bases -> top-8 bases x 16 scales -> width-32 FPCS with 4 neighbours."""
+        be = backend.get()
+        aq = self.a_quantizer
+        dev = self.weight.device
+        wp, rowsum = self._pack_w_fixed(BF16, want_rowsum=True)
+        bias_fold = be.shift_fold(rowsum.view(1, -1), self.w_quantizer.scale.data.view(1, -1), aq.shift.data,
+                                  None if self.bias is None else self.bias.data).view(-1)
+        q_all = search.const_tensor([float(i) for i in range(10, 11 + self.eq_n)], dev)[:self.eq_n].view(-1, 1)
+        cur_scale = aq.scale.data.view(1, 1).expand(self.eq_n, 1).contiguous()
+        s0 = self._score_scale_logbase(wp, bias_fold, cur_scale, q_all)
+        q_idx = search.argbest(s0, base_num)                                       # [8, 1]
+        top_q = be.fpcs_next(q_all, None, None, q_idx, base_num, 1, search.const_tensor([0.5], dev),
+                             torch.zeros(1, device=dev), None)[0]                  # gather: [8, 1]
+        frac = search.const_tensor([i / (scale_num - 1) for i in range(scale_num)], dev).view(-1, 1)
+        ud = ud_candidates.view(-1)
+        scales16 = ud[0:1].view(1, 1) + (ud[1:2] - ud[0:1]).view(1, 1) * frac       # [16, 1]
+        delta = (scales16[1:2] - scales16[0:1]).view(1).contiguous()
+        scale = scales16.repeat(base_num, 1).contiguous()                           # a.repeat(1, base_num) layout
+        qv = top_q.repeat_interleave(scale_num, dim=0).contiguous()
+        fn = lambda s, z, t: self._score_scale_logbase(wp, bias_fold, s, t)
+        res = search.fpcs(scale, None, qv, delta, fn, steps, fpcs_width, self.eq_n, None)
+        if res is not None:
+            aq.scale.data.copy_(res[0].view(aq.scale.shape))
+            aq.q.data.copy_(res[2].view(aq.q.shape).to(aq.q.dtype))
+            self._q_host = int(aq.q.item())                     # one host read per activation_fpcs (LUT rebuild)
+            aq.update_table(self._q_host)
+
+    def hyperparameter_searching(self):
+        """linear.py:969-997 with fpcs=True."""
+        if not self.fpcs:
+            raise NotImplementedError("non-FPCS search is not part of the accelerated path")
+        self._initialize_calib_parameters()
+        self.weight_fpcs(steps=self.steps, search_strategy="self")
+        ud_candidates, input_scale_candidates = self.calculate_percentile_activation_candidates()
+        self.a_quantizer.scale.data.copy_(input_scale_candidates[:, -2])
+        self.a_quantizer.inited = True
+        self._q_host = int(self.a_quantizer.q.item())
+        for _ in range(self.search_round):
+            self.activation_fpcs(ud_candidates=ud_candidates, steps=self.steps)
+            self.weight_fpcs(steps=self.steps, search_strategy="output")
+        self.calibrated = True
+        del self.raw_input, self.raw_out
+
+    def reparam_bias(self):
+        """linear.py:999-1006: bias += (-shift * 1^T) . q_w(W)^T, then the quantiser stops subtracting the shift."""
+        aq = self.a_quantizer
+        if aq._shift_args()[1] is False:
+            return
+        be = backend.get()
+        _, rowsum = self._pack_w_fixed(BF16, want_rowsum=True)
+        fold = be.shift_fold(rowsum.view(1, -1), self.w_quantizer.scale.data.view(1, -1), aq.shift.data,
+                             None if self.bias is None else self.bias.data).view(-1)
+        if self.bias is None:
+            self.bias = nn.Parameter(torch.zeros(self.out_features, device=self.weight.device))
+        self.bias.data.copy_(fold)
+        aq.mark_bias_reparamed()
+
+    def quant_forward(self, x):
+        assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
+        aq = self.a_quantizer
+        if (torch.is_grad_enabled() and (self.w_quantizer.training_mode or aq.training_mode)) \
+                or not isinstance(self.w_quantizer, UniformQuantizer) or aq.training_mode:
+            return MinMaxQuantLinear.quant_forward(self, x)
+        be = backend.get()
+        dev = x.device
+        lead = x.shape[:-1]
+        x3 = x.reshape(1, -1, self.in_features)
+        if self._q_host is None:
+            self._q_host = int(aq.q.item())
+        qv = search.const_tensor([float(self._q_host)], dev)
+        xp = be.pack_adalog(x3, aq.scale.data.view(-1), qv, 1, 0, 1, 0, aq.n_bits, self._mant37(dev),
+                            shift=aq.shift.data, clamp_u=True)
+        _, sub = aq._shift_args()
+        if sub:
+            wp, rowsum = self._pack_w_fixed(BF16, want_rowsum=True)
+            bias = be.shift_fold(rowsum.view(1, -1), self.w_quantizer.scale.data.view(1, -1), aq.shift.data,
+                                 None if self.bias is None else self.bias.data).view(-1)
+        else:
+            wp = self._pack_w_fixed(BF16)
+            bias = None if self.bias is None else self.bias.data
+        out = be.gemm_out(BF16, xp, wp, x3.shape[1], self.out_features, 1, 1, Strided(aq.scale.data.view(-1)),
+                          Strided(self.w_quantizer.scale.data.view(-1), n=1),
+                          None if bias is None else Strided(bias, n=1), sa_mul=self._ts32())
+        return out.view(*lead, self.out_features)
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._q_host = None

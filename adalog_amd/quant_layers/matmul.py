@@ -1,0 +1,327 @@
+"""Quantised A @ B for the attention products -- module API of reference quant_layers/matmul.py
+(MinMaxQuantMatMul -> PTQSLQuantMatMul -> PTQSLBatchingQuantMatMul -> AsymmetricallyBatchingQuantMatMul
+ -> PostSoftmaxAsymmetricallyBatchingQuantMatMul), searches and forward on HIP kernels.
+
+Shapes (matmul.py:49-56):  q@k^T: A [N,H,S,C], B [N,H,C,S];  softmax@v: A [N,H,S,S], B [N,H,S,C].
+Every (image, head) pair is one GEMM group g = n*H + h; per-head parameters are addressed by g % H inside the
+kernels, so a scoring call for 128 candidates is one batched MFMA launch over [P, N*H] groups.
+B enters the GEMM K-contiguous, i.e. as B^T -- taken as a strided *view*, packed by the operand kernel (no copy).
+"""
+import torch
+import torch.nn as nn
+
+from .. import backend, search
+from ..ops import BF16, I8, Strided, pad_k
+from ..quantizers.logarithm import AdaLogQuantizer
+from ..quantizers.uniform import UniformQuantizer
+
+MAX_PACK_BYTES = 6 << 30
+
+
+class MinMaxQuantMatMul(nn.Module):
+    def __init__(self, A_bit=8, B_bit=8, mode="raw"):
+        super().__init__()
+        self.mode = mode
+        self.A_quantizer = UniformQuantizer(n_bits=A_bit, symmetric=True, channel_wise=False)
+        self.B_quantizer = UniformQuantizer(n_bits=B_bit, symmetric=True, channel_wise=False)
+        self.raw_input = None
+        self.raw_out = None
+        self.tmp_input = None
+        self.tmp_out = None
+        self.calibrated = False
+
+    def forward(self, A, B):
+        if self.mode == 'raw':
+            return A @ B
+        if self.mode == "quant_forward":
+            return self.quant_forward(A, B)
+        raise NotImplementedError
+
+    def quant_input_A(self, x):
+        return self.A_quantizer(x)
+
+    def quant_input_B(self, x):
+        return self.B_quantizer(x)
+
+    def quant_forward(self, A, B):
+        assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
+        return self.quant_input_A(A) @ self.quant_input_B(B)
+
+
+class PTQSLQuantMatMul(MinMaxQuantMatMul):
+    def __init__(self, A_bit=8, B_bit=8, mode="raw", search_round=1, eq_n=100, head_channel_wise=True, num_heads=12):
+        super().__init__(A_bit, B_bit, mode)
+        self.A_quantizer = UniformQuantizer(n_bits=A_bit, symmetric=True, channel_wise=head_channel_wise)
+        self.B_quantizer = UniformQuantizer(n_bits=B_bit, symmetric=True, channel_wise=head_channel_wise)
+        self.search_round = search_round
+        self.eq_n = eq_n
+        self.head_channel_wise = head_channel_wise
+        self.num_heads = num_heads
+        target_shape = [1, self.num_heads, 1, 1] if self.head_channel_wise else [1, 1, 1, 1]
+        self.A_quantizer.scale = nn.Parameter(torch.zeros(*target_shape))
+        self.B_quantizer.scale = nn.Parameter(torch.zeros(*target_shape))
+
+
+class PTQSLBatchingQuantMatMul(PTQSLQuantMatMul):
+    def __init__(self, A_bit=8, B_bit=8, mode="raw", calib_batch_size=32, search_round=1, eq_n=100,
+                 head_channel_wise=True, num_heads=12):
+        super().__init__(A_bit, B_bit, mode, search_round, eq_n, head_channel_wise, num_heads)
+        self.calib_batch_size = calib_batch_size
+
+    def _initialize_calib_parameters(self):
+        self.calib_size = self.raw_input[0].shape[0]
+        self.parallel_eq_n = self.eq_n            # no memory-derived chunking (matmul.py:95-106 has no counterpart)
+
+
+class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
+    def __init__(self, A_bit=8, B_bit=8, mode="raw", calib_batch_size=32, search_round=1, eq_n=128,
+                 head_channel_wise=True, num_heads=12, fpcs=False, steps=4):
+        super().__init__(A_bit, B_bit, mode, calib_batch_size, search_round, eq_n, head_channel_wise, num_heads)
+        self.fpcs = fpcs
+        self.steps = steps
+        del self.A_quantizer, self.B_quantizer
+        self.A_quantizer = UniformQuantizer(n_bits=A_bit, symmetric=False, channel_wise=head_channel_wise)
+        self.B_quantizer = UniformQuantizer(n_bits=B_bit, symmetric=False, channel_wise=head_channel_wise)
+        target_shape = [1, self.num_heads, 1, 1] if self.head_channel_wise else [1, 1, 1, 1]
+        self.A_quantizer.scale = nn.Parameter(torch.zeros(*target_shape))
+        self.B_quantizer.scale = nn.Parameter(torch.zeros(*target_shape))
+        self.A_quantizer.zero_point = nn.Parameter(torch.zeros(*target_shape))
+        self.B_quantizer.zero_point = nn.Parameter(torch.zeros(*target_shape))
+
+    # ------------------------------------------------------------------ views
+    def _heads(self):
+        return self.num_heads if self.head_channel_wise else 1
+
+    def _norm(self, A, S, Sp):
+        """mean over (S, S') per head (matmul.py:154-155) or over (H, S, S') per tensor (:156-157), summed over images."""
+        return 1.0 / (S * Sp) if self.head_channel_wise else 1.0 / (A.shape[1] * S * Sp)
+
+    @staticmethod
+    def _a3(A):
+        """[N,H,S,K] -> [G, S, K] view (rows = output rows, K contiguous)."""
+        return A.reshape(-1, A.shape[-2], A.shape[-1])
+
+    @staticmethod
+    def _bt3(B):
+        """[N,H,K,S'] -> B^T as a [G, S', K] view: K-contiguous when B itself was a transposed view (q@k^T), otherwise
+        row-contiguous (softmax@v) -- the operand kernel coalesces along whichever stride is 1.  Copies only if the
+        layout cannot be expressed as a 3-D strided view."""
+        Bt = B.transpose(-2, -1)
+        return Bt.reshape(-1, Bt.shape[-2], Bt.shape[-1])
+
+    def _dims(self):
+        A, B = self.raw_input
+        S, K, Sp = A.shape[-2], A.shape[-1], B.shape[-1]
+        G = A.numel() // (S * K)
+        return G, S, K, Sp
+
+    def _ref3(self):
+        G, S, K, Sp = self._dims()
+        return self.raw_out.reshape(G, S, Sp)
+
+    def _cand_chunk(self, bytes_per_cand):
+        return max(1, min(self.eq_n, MAX_PACK_BYTES // max(1, bytes_per_cand)))
+
+    def _q_params(self, quantizer):
+        return quantizer.scale.data.view(-1), quantizer.zero_point.data.view(-1)
+
+    # ------------------------------------------------------------------ scoring calls
+    def _pack_fixed(self, which, dt=I8):
+        be = backend.get()
+        H = self._heads()
+        A, B = self.raw_input
+        if which == "A":
+            s, z = self._q_params(self.A_quantizer)
+            return be.pack_uniform(self._a3(A), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.A_quantizer.n_bits, dt)
+        s, z = self._q_params(self.B_quantizer)
+        return be.pack_uniform(self._bt3(B), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.B_quantizer.n_bits, dt)
+
+    def _score(self, which, fixed, scale, zp, dt=I8, fixed_sa=None, sa_mul=1.0):
+        """matmul.py:135-163 (which='A') / :173-201 (which='B') -> scores [P, H]."""
+        be = backend.get()
+        H = self._heads()
+        G, S, K, Sp = self._dims()
+        A, B = self.raw_input
+        P = scale.shape[0]
+        src = self._a3(A) if which == "A" else self._bt3(B)
+        bits = self.A_quantizer.n_bits if which == "A" else self.B_quantizer.n_bits
+        rows = S if which == "A" else Sp
+        esz = 1 if dt == I8 else 2
+        chunk = self._cand_chunk(G * rows * pad_k(K, dt) * esz)
+        pg = 1 if H > 1 else 0
+        out = []
+        for s0 in range(0, P, chunk):
+            e = min(P, s0 + chunk)
+            sc, zc = scale[s0:e].contiguous(), zp[s0:e].contiguous()
+            cand = be.pack_uniform(src, sc, zc, e - s0, H, H, pg, 0, bits, dt)
+            if which == "A":
+                sa = Strided(sc, c=H, g=pg)
+                sb = Strided(self.B_quantizer.scale.data.view(-1), g=pg)
+                a_op, b_op = cand, fixed
+            else:
+                sa = fixed_sa if fixed_sa is not None else Strided(self.A_quantizer.scale.data.view(-1), g=pg)
+                sb = Strided(sc, c=H, g=pg)
+                a_op, b_op = fixed, cand
+            out.append(be.gemm_score(dt, a_op, b_op, S, Sp, e - s0, G, H, self._ref3(), sa, sb, None,
+                                     self.head_channel_wise, False, self._norm(A, S, Sp), sa_mul=sa_mul))
+        return out[0] if len(out) == 1 else torch.cat(out, 0)
+
+    def _commit(self, quantizer, scale, zp):
+        quantizer.scale.data.copy_(scale.view(quantizer.scale.shape))
+        quantizer.zero_point.data.copy_(zp.view(quantizer.zero_point.shape))
+
+    def _fpcs(self, which, fpcs_width=16, steps=6, fixed=None, dt=I8, fixed_sa=None, sa_mul=1.0):
+        """matmul.py:243-262."""
+        x = self.raw_input[0] if which == "A" else self.raw_input[1]
+        scale, zp, delta = search.matmul_grid(x, self.B_quantizer.n_bits, self.eq_n, self.head_channel_wise)
+        if fixed is None:
+            fixed = self._pack_fixed("B" if which == "A" else "A", dt)
+        fn = lambda s, z, t: self._score(which, fixed, s, z, dt, fixed_sa, sa_mul)
+        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
+        if res is not None:
+            self._commit(self.A_quantizer if which == "A" else self.B_quantizer, res[0], res[1])
+
+    def _init_from_grid(self, which):
+        """matmul.py:266-271: parameters start at candidate [-2] of the percentile grid."""
+        x = self.raw_input[0] if which == "A" else self.raw_input[1]
+        scale, zp, _ = search.matmul_grid(x, self.B_quantizer.n_bits, self.eq_n, self.head_channel_wise)
+        q = self.A_quantizer if which == "A" else self.B_quantizer
+        self._commit(q, scale[-2], zp[-2])
+        q.inited = True
+
+    def hyperparameter_searching(self):
+        """matmul.py:264-283 with fpcs=True."""
+        if not self.fpcs:
+            raise NotImplementedError("non-FPCS search is not part of the accelerated path")
+        self._initialize_calib_parameters()
+        self._init_from_grid("A")
+        self._init_from_grid("B")
+        for _ in range(self.search_round):
+            self._fpcs("A", steps=self.steps)
+            self._fpcs("B", steps=self.steps)
+        self.calibrated = True
+        del self.raw_input, self.raw_out
+        return None
+
+    # ------------------------------------------------------------------ fused quantised forward (matmul.py:43-45)
+    def _training(self):
+        return torch.is_grad_enabled() and (self.A_quantizer.training_mode or self.B_quantizer.training_mode)
+
+    def quant_forward(self, A, B):
+        assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
+        if self._training() or self.A_quantizer.n_bits > 7 or self.B_quantizer.n_bits > 7:
+            return super().quant_forward(A, B)
+        be = backend.get()
+        H = self._heads()
+        pg = 1 if H > 1 else 0
+        lead = A.shape[:-2]
+        S, Sp = A.shape[-2], B.shape[-1]
+        sA, zA = self._q_params(self.A_quantizer)
+        sB, zB = self._q_params(self.B_quantizer)
+        a3, bt3 = self._a3(A), self._bt3(B)
+        ap = be.pack_uniform(a3, sA, zA, 1, 0, H, pg, 0, self.A_quantizer.n_bits, I8)
+        bp = be.pack_uniform(bt3, sB, zB, 1, 0, H, pg, 0, self.B_quantizer.n_bits, I8)
+        out = be.gemm_out(I8, ap, bp, S, Sp, a3.shape[0], H, Strided(sA, g=pg), Strided(sB, g=pg), None)
+        return out.view(*lead, S, Sp)
+
+
+class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMatMul):
+    """softmax @ v: A is quantised with AdaLog (scale fixed to 1, log base 2^(-q/37) searched), B uniformly."""
+
+    def __init__(self, A_bit=8, B_bit=8, mode="raw", calib_batch_size=32, search_round=1, eq_n=100,
+                 head_channel_wise=True, num_heads=12, fpcs=False, steps=4, quantizer='adalog'):
+        super().__init__(A_bit, B_bit, mode, calib_batch_size, search_round, eq_n, head_channel_wise, num_heads,
+                         fpcs, steps)
+        if quantizer != 'adalog':
+            raise NotImplementedError(f"quantizer {quantizer} not implemented on the accelerated path "
+                                      "(log2/logsqrt2 are ablation baselines)")
+        del self.A_quantizer
+        self.A_quantizer = AdaLogQuantizer(n_bits=A_bit, symmetric=False, channel_wise=False)
+        self.table = torch.tensor([2 ** (-j / self.A_quantizer.r) for j in range(120)])
+        self.table_scale = 1. / (4 * self.A_quantizer.n_levels - 2)
+        self.table = torch.round(self.table / self.table_scale) * self.table_scale
+        self.A_quantizer.scale = nn.Parameter(torch.ones([1, 1, 1, 1]))
+        self.A_quantizer.inited = True
+        self._q_host = 37
+
+    def _mant37(self, device):
+        return search.const_tensor(torch.round(self.table[:37] / self.table_scale).tolist(), device)
+
+    def _ts32(self):
+        return float(torch.tensor(self.table_scale, dtype=torch.float32))
+
+    def _pack_A_adalog(self, A3, qv, scale, C, clamp_u):
+        be = backend.get()
+        return be.pack_adalog(A3, scale, qv, C, 1 if C > 1 else 0, 1, 0, self.A_quantizer.n_bits,
+                              self._mant37(A3.device), shift=None, clamp_u=clamp_u)
+
+    def _search_best_A_log_base(self):
+        """matmul.py:321-358: 128 bases q = 10..137, per-tensor score, commit the best."""
+        be = backend.get()
+        aq = self.A_quantizer
+        H = self._heads()
+        pg = 1 if H > 1 else 0
+        G, S, K, Sp = self._dims()
+        A, B = self.raw_input
+        dev = A.device
+        bp = self._pack_fixed("B", BF16)
+        q_all = search.const_tensor([float(i) for i in range(10, 11 + self.eq_n)], dev)[:self.eq_n]
+        P = self.eq_n
+        ones = search.const_tensor([1.0] * P, dev)
+        chunk = self._cand_chunk(G * S * pad_k(K, BF16) * 2)
+        out = []
+        for s0 in range(0, P, chunk):
+            e = min(P, s0 + chunk)
+            ap = self._pack_A_adalog(self._a3(A), q_all[s0:e].contiguous(), ones[s0:e].contiguous(), e - s0, False)
+            out.append(be.gemm_score(BF16, ap, bp, S, Sp, e - s0, G, H, self._ref3(), Strided(ones),
+                                     Strided(self.B_quantizer.scale.data.view(-1), g=pg), None, False, False,
+                                     1.0 / (A.shape[1] * S * Sp), sa_mul=self._ts32()))
+        scores = out[0] if len(out) == 1 else torch.cat(out, 0)
+        idx = search.argbest(scores, 1)
+        best_q = be.fpcs_next(q_all.view(-1, 1), None, None, idx, 1, 0, None, None, None)[0]
+        aq.q.data.copy_(best_q.view(aq.q.shape).to(aq.q.dtype))
+        self._q_host = int(aq.q.item())                           # one host read per round (LUT rebuild)
+        aq.update_table(self._q_host)
+
+    def hyperparameter_searching(self):
+        """matmul.py:360-378."""
+        if not self.fpcs:
+            raise NotImplementedError("non-FPCS search is not part of the accelerated path")
+        self._initialize_calib_parameters()
+        self._init_from_grid("B")
+        A = self.raw_input[0]
+        dev = A.device
+        for _ in range(self.search_round):
+            self._search_best_A_log_base()
+            # B search against q_A(A): eval-form AdaLog of A (clamped, scale 1) is the fixed bf16 operand
+            qv = search.const_tensor([float(self._q_host)], dev)
+            ap = self._pack_A_adalog(self._a3(A), qv, self.A_quantizer.scale.data.view(-1), 1, True)
+            self._fpcs("B", steps=self.steps, fixed=ap, dt=BF16, fixed_sa=Strided(self.A_quantizer.scale.data.view(-1)),
+                       sa_mul=self._ts32())
+        self.calibrated = True
+        del self.raw_input, self.raw_out
+        return None
+
+    def quant_forward(self, A, B):
+        assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
+        if self._training() or self.A_quantizer.training_mode:
+            return MinMaxQuantMatMul.quant_forward(self, A, B)
+        be = backend.get()
+        H = self._heads()
+        pg = 1 if H > 1 else 0
+        lead = A.shape[:-2]
+        S, Sp = A.shape[-2], B.shape[-1]
+        if self._q_host is None:
+            self._q_host = int(self.A_quantizer.q.item())
+        qv = search.const_tensor([float(self._q_host)], A.device)
+        a3, bt3 = self._a3(A), self._bt3(B)
+        ap = self._pack_A_adalog(a3, qv, self.A_quantizer.scale.data.view(-1), 1, True)
+        sB, zB = self._q_params(self.B_quantizer)
+        bp = be.pack_uniform(bt3, sB, zB, 1, 0, H, pg, 0, self.B_quantizer.n_bits, BF16)
+        out = be.gemm_out(BF16, ap, bp, S, Sp, a3.shape[0], H, Strided(self.A_quantizer.scale.data.view(-1)),
+                          Strided(sB, g=pg), None, sa_mul=self._ts32())
+        return out.view(*lead, S, Sp)
+
+    def _load_from_state_dict(self, *a, **k):
+        super()._load_from_state_dict(*a, **k)
+        self._q_host = None

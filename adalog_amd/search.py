@@ -1,0 +1,133 @@
+"""Device-resident Fast Progressive Combining Search (FPCS) engine.
+
+Host-side driver for the searches of reference quant_layers/linear.py:483-523, matmul.py:243-262, conv.py:292-311
+(coarse 128-candidate grid -> top-16 -> (16 survivors x 8 neighbours -> top-16) x 4 -> top-1, spacing /= 7.5 each step).
+It only sequences kernels: candidate grids, scores, top-k and the committed winner all stay on the GPU, and nothing
+in a search synchronises the host.  Candidate tensors are fp32 [P, cols] (candidate-major).
+
+Multi-GPU: calibration images are sharded across ranks; every scoring call's score tensor is the sum over images of
+per-image terms (linear.py:345,384,423; matmul.py:163,201,351; conv.py:255), so ranks all-reduce(SUM) the [P, cols]
+scores (RCCL over xGMI) and then run the identical deterministic top-k -- no broadcast needed.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import torch
+
+from . import backend, parallel
+
+_LIN_CACHE = {}
+
+
+def linspace01(n: int, device) -> torch.Tensor:
+    """torch.linspace(0, 1, n) evaluated on the host exactly as the reference does, cached on the device."""
+    key = (n, str(device))
+    if key not in _LIN_CACHE:
+        _LIN_CACHE[key] = torch.linspace(0, 1, steps=n).to(device)
+    return _LIN_CACHE[key]
+
+
+def const_tensor(values, device, dtype=torch.float32) -> torch.Tensor:
+    key = (tuple(values), str(device), dtype)
+    if key not in _LIN_CACHE:
+        _LIN_CACHE[key] = torch.tensor(values, dtype=dtype).to(device)
+    return _LIN_CACHE[key]
+
+
+def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 16, eq_n: int = 128,
+         clamp_min: Optional[float] = None):
+    """Run the progressive search.  ``score_fn(scale, zp, third) -> scores [P, cols]`` (rank-local partial sums).
+
+    Returns the committed (scale [cols], zp [cols] | None, third [cols] | None); with steps == 1 nothing is committed
+    (the reference's loop never reaches its top-1 branch then) and None is returned.
+    """
+    be = backend.get()
+    new_cnt = int(eq_n / width)
+    lin = linspace01(new_cnt, scale.device)
+    remain = steps
+    first = True
+    while remain > 0:
+        scores = parallel.all_reduce_sum(score_fn(scale, zp, third))
+        last = (remain == 1) and not first
+        k = 1 if last else width
+        idx = be.topk(scores, k)
+        if last:
+            return be.fpcs_next(scale, zp, third, idx, 1, 0, None, None, None)
+        if remain == 1:          # steps == 1: survivors are selected but never committed (linear.py:490-491)
+            return None
+        scale, zp, third = be.fpcs_next(scale, zp, third, idx, k, new_cnt, lin, delta, clamp_min)
+        remain -= 1
+        first = False
+    return None
+
+
+def argbest(scores, k: int = 1):
+    """top-k candidate indices [k, cols] of an (all-reduced) score tensor."""
+    return backend.get().topk(parallel.all_reduce_sum(scores), k)
+
+
+# ------------------------------------------------------------------------------------------------ percentile grids
+QS_HI = (0.9, 1.0)
+
+
+def _pct_lists(lo=0.9, hi=1.0):
+    pct = torch.tensor([lo, hi])
+    return pct.tolist() + (1 - pct).tolist()            # fp32 arithmetic for 1 - pct, as in linear.py:439-441
+
+
+def _chunk_rows(numel: int) -> int:
+    """Rows ``mbs`` of the reference's chunked per-tensor quantile: the smallest power of two for which
+    x.view(mbs, -1) is legal and the reduced dim fits torch.quantile's 2**24 limit (linear.py:465-471)."""
+    mbs = 1
+    while numel % mbs != 0 or numel // mbs > 16777216:
+        mbs *= 2
+        if mbs > numel:
+            raise ValueError("cannot chunk tensor for quantile")
+    return mbs
+
+
+def weight_grid(w2, n_bits: int, eq_n: int, conv: bool = False):
+    """linear.py:432-451 / conv.py:271-290 -> (scale [P, rows], zp [P, rows], delta [rows])."""
+    be = backend.get()
+    L = 2 ** (n_bits - 1)
+    num_zp = L if conv else min(16, L)
+    num_scale = int(eq_n / num_zp)
+    quant4 = be.quantile_rows(w2, _pct_lists(), 1)           # weights are replicated on every rank
+    return be.candidate_grid(quant4, num_scale, num_zp, int(L - num_zp / 2), n_bits, linspace01(num_scale, w2.device), None)
+
+
+def activation_grid(x, n_bits: int, eq_n: int, channel_wise: bool):
+    """linear.py:453-481 -> (scale [P, C], zp [P, C], delta [C]), C = in_features or 1.  ``x`` is the rank-local shard;
+    quantiles are global order statistics, so the shards are gathered for this one-off HBM-bound step."""
+    be = backend.get()
+    L = 2 ** (n_bits - 1)
+    num_zp = min(16, 2 * L)
+    num_scale = int(eq_n / num_zp)
+    xg = parallel.gather_images(x)
+    if channel_wise:
+        x2 = xg.reshape(-1, xg.shape[-1]).t().contiguous()
+        quant4 = be.quantile_rows(x2, _pct_lists(), 1)
+    else:
+        mbs = _chunk_rows(xg.numel())
+        quant4 = be.quantile_rows(xg.reshape(mbs, -1), _pct_lists(), mbs)
+    return be.candidate_grid(quant4, num_scale, num_zp, int(L - num_zp / 2), n_bits, linspace01(num_scale, x.device), 1e-4)
+
+
+def matmul_grid(x, n_bits_B: int, eq_n: int, head_wise: bool = True):
+    """matmul.py:211-240 -> (scale [P, H], zp [P, H], delta [H]); both operands use B's level count."""
+    be = backend.get()
+    L = 2 ** (n_bits_B - 1)
+    num_zp = min(16, L)
+    num_scale = int(eq_n / num_zp)
+    xg = parallel.gather_images(x)
+    if head_wise:
+        H = xg.shape[1]
+        xt = xg.transpose(0, 1).contiguous()
+        mbs = _chunk_rows(xt.numel() // H)
+        x2 = xt.view(H * mbs, -1)
+    else:
+        mbs = _chunk_rows(xg.numel())
+        x2 = xg.reshape(mbs, -1)
+    quant4 = be.quantile_rows(x2, _pct_lists(), mbs)
+    return be.candidate_grid(quant4, num_scale, num_zp, int(L - num_zp / 2), n_bits_B, linspace01(num_scale, x.device), None)

@@ -1,0 +1,155 @@
+/* adalog_hip.h -- C ABI of the MI355X (gfx950) AdaLog calibration kernels  (libadalog_hip.so)
+ *
+ * The reference (GoatWu/AdaLog) has no FFI: its hot path is Python calling ATen ops.  The drop-in boundary is
+ * therefore the Python module API (quantizers / quant_layers / utils.calibrator, mirrored in adalog_amd/); THIS header
+ * is the layer directly beneath it -- what a maintainer of the reference would bind with ctypes to replace the bodies
+ * of the functions cited below (INTEGRATION.md shows the stubs).  Plain pointers and sizes only, no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, same GPU as `stream`) unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises the host;
+ *   - return value: 0 = enqueued; -1 = rejected arguments; otherwise the hipError_t of the failed call.
+ *     adalog_last_error() returns a thread-local description;
+ *   - candidate tensors are fp32 [P][cols], candidate-major (P = eq_n = 128 in the shipped configs);
+ *   - "n_bits" is the quantiser bit-width b; L = 2^(b-1) levels per sign, the integer grid is [0, 2L-1].
+ */
+#ifndef ADALOG_HIP_H
+#define ADALOG_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int adalog_abi_version(void);
+const char* adalog_last_error(void);
+
+/* ---- K1  UniformQuantizer.forward, eval form                      reference quantizers/uniform.py:25-36
+ * y = (clamp(rne(x/s) + rne(zp), 0, 2L-1) - rne(zp)) * s   (asymmetric), or clamp(rne(x/s), -L, L-1) * s (symmetric).
+ * Broadcast of scale/zero_point: channel(i) = (i / inner) % n_channels
+ *   per-tensor            n_channels = 1
+ *   per-row weights       x = W.view(rows, I):      n_channels = rows, inner = I      (linear.py:90-92, conv.py:115-120)
+ *   per-head [N,H,S,C]    n_channels = H, inner = S*C                                 (matmul.py:129-133)
+ *   per-channel [.., I]   n_channels = I, inner = 1                                   (linear.py:566-568)
+ * y and bins (uint8 integer bin index, asymmetric only) are each optional (NULL). */
+int adalog_uniform_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale,
+                                  const float* zero_point, int64_t n_channels, int64_t inner, int n_bits, int symmetric,
+                                  void* stream);
+
+/* ---- K2/K3  AdaLogQuantizer.forward / ShiftAdaLogQuantizer.forward   reference quantizers/logarithm.py:83-99,127-135
+ * k = rne(-log2(clamp((x+shift)/s, 1e-15, 1)) * 37 / q);  y = 2^-table1[k] * table2[k] * s * [k < 2L]  [- shift]
+ * scale: [1]; q: int64 [1] (the quantiser's buffer); table1/table2: fp32 [2L] (update_table, logarithm.py:77-81);
+ * shift: [1] or NULL; sub_shift: subtract the shift again (bias not yet re-parameterised);
+ * train_form: y = 2^(-k*q/37) * s (logarithm.py:88-92, no LUT).  bins: k, or 255 where masked. */
+int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale, const int64_t* q,
+                              const float* table1, const float* table2, int n_bits, const float* shift, int sub_shift,
+                              int train_form, void* stream);
+
+/* ---- operand packing for the scoring GEMMs (prologue of K7/K8/K11-K15)
+ * Input: fp32 view x[g][r][k] with element strides (sxg, sxr, sxk), g < G, r < R, k < K.
+ * Output: out[c][g][r][Kp], K-contiguous, zero padded to Kp (Kp * sizeof(elem) a multiple of 64 bytes).
+ * Parameter addressing for candidate c: idx = c*pc + (g % gmod)*pg + r*pr.
+ * out_dtype: 0 = int8, 1 = bf16, 2 = fp32.
+ *
+ * adalog_pack_uniform: value = clamp(rne(x/s)+rne(zp), 0, 2L-1) - rne(zp)  (an exact small integer)
+ *   replaces the per-candidate fp32 copies at linear.py:369-371,409-411; matmul.py:150-151,188-189; conv.py:240-242
+ *   rowsum (optional int32 [C][G][R]) = sum_k value, used to fold the post-GELU shift into the bias (linear.py:1002-1005).
+ * adalog_pack_adalog_bf16: value = m * 2^-t with k = rne(-log2(u)*37/q_c), t = floor(k*q_c/37), m = mant37[(k*q_c) % 37],
+ *   u = (x + shift)/s_c [clamped to [1e-15,1] when clamp_u];  masked bins (k >= 2L) -> 0
+ *   replaces linear.py:830-836,872-878,913-919 and matmul.py:337-342.  mant37: fp32 [37] integer numerators
+ *   round(2^(-j/37) * (4L-2))  (linear.py:750-752).
+ * adalog_pack_raw_f32: zero-padded fp32 copy (conv input with qconv_a_bit = 8, conv.py:55-58). */
+int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
+                        const float* scale, const float* zero_point, int64_t C, int64_t pc, int64_t gmod, int64_t pg,
+                        int64_t pr, int n_bits, int out_dtype, void* out, int64_t Kp, int32_t* rowsum, void* stream);
+int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
+                            const float* scale, const float* qv, int64_t C, int64_t pc, int64_t gmod, int64_t pg,
+                            int n_bits, const float* mant37, const float* shift, int clamp_u, void* out, int64_t Kp,
+                            void* stream);
+int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk, void* out,
+                        int64_t Kp, void* stream);
+
+/* ---- K7/K8/K11-K15  scoring GEMM with fused squared-error epilogue (MFMA)
+ * For candidate c < C and group g < G (gh = g % gmod):
+ *     D = A[c][g] (M x Kp) . B[c][g]^T (N x Kp)          A/B strides sAc,sAg,sBc,sBg in elements, 0 = shared
+ *     out[m][n] = D[m][n] * (sa[c*sa_c + gh*sa_g] * sa_mul * sb[c*sb_c + gh*sb_g + n*sb_n]) + bias[c*bi_c + gh*bi_g + n*bi_n]
+ *     partial[c][g][m_tile][n] = sum over the tile's rows of (ref[g*sRg + m*ldr + n/ref_div] - out[m][n])^2
+ * and/or `out` is stored (quant_forward, linear.py:46-51 / matmul.py:43-45 / conv.py:60-65).
+ * Replaces F.linear / @ / F.conv2d + _get_similarity + mean/sum in
+ *   linear.py:355-384, 394-423, 816-848, 856-890, 898-931; matmul.py:135-163, 173-201, 321-351; conv.py:226-255.
+ * dtype: 0 = int8 (exact integer dot products), 1 = bf16, 2 = fp32.  bias may be NULL.  partial and ref go together.
+ * partial must hold adalog_gemm_score_partial_elems(M, N, C, G) floats. */
+int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc, int64_t sBg, int M,
+                      int N, int64_t Kp, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int ref_div,
+                      const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
+                      int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n,
+                      float* partial, int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg,
+                      void* stream);
+int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G);
+
+/* scores[c][h?][n?] = -norm * sum_{image = g/gmod, (h), m_tile, (n)} partial[c][g][m_tile][n], accumulated in fp64 in a
+ * fixed order (deterministic).  keep_h / keep_n select which axes survive:
+ *   Linear weight search  keep_n=1 -> [P][O]   (linear.py:378-385, norm = 1/T)
+ *   Linear act. search    keep_n=0 -> [P]      (linear.py:415-424, norm = 1/(T*O))
+ *   MatMul per head       keep_h=1 -> [P][H]   (matmul.py:154-164, norm = 1/(S*S'))
+ *   post-softmax base     none     -> [P]      (matmul.py:345-352, norm = 1/(H*S*S')) */
+int adalog_finish_scores(const float* partial, float* scores, int M, int N, int C, int G, int gmod, int keep_h, int keep_n,
+                         double norm, void* stream);
+
+/* ---- K16  FPCS driver pieces                 reference linear.py:483-523, matmul.py:243-262, conv.py:292-311
+ * adalog_topk: idx[j][col] = candidate with the j-th best score of column col, j < k; order (score desc, index asc),
+ *   i.e. torch.topk(sorted=True) with ties made deterministic.  scores: [P][cols], P <= 256.
+ * adalog_fpcs_next: gathers the survivors and
+ *   new_cnt > 0: writes the next survivor-major grid  out[(j*new_cnt+i)][col] = top_scale[j][col] + (lin[i]-0.5)*delta[col]
+ *                (clamped below when has_clamp), copies zero points / third plane, then delta[col] /= (new_cnt - 0.5);
+ *   new_cnt = 0: commits the winner (k = 1) to out_scale/out_zp/out_third [cols]          (linear.py:387-391).
+ * adalog_candidate_grid: the initial percentile grid                    (linear.py:442-451,472-481; matmul.py:231-240)
+ *   quant4 = [4][cols] {Q_hi0, Q_hi1, Q_lo0, Q_lo1};  scale[(zi*num_scale+si)][col] = (dmin + lin[si]*(dmax-dmin))/(2L-1),
+ *   zp = zp_min + zi, delta[col] = scale[1][col] - scale[0][col]. */
+int adalog_topk(const float* scores, int P, int cols, int k, int* idx, void* stream);
+int adalog_fpcs_next(const float* scale, const float* zp, const float* third, int cols, const int* idx, int k, int new_cnt,
+                     const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale, float* out_zp,
+                     float* out_third, void* stream);
+int adalog_candidate_grid(const float* quant4, int cols, int num_scale, int num_zp, int zp_min, int n_bits, const float* lin,
+                          int has_clamp, float clamp_min, float* scale, float* zp, float* delta, void* stream);
+
+/* ---- K9   _search_best_w_scale_self                                   reference linear.py:296-309
+ * scores[p][row] = -mean_i (w[row][i] - fq_p(w[row][i]))^2,  w: [rows][I], scale/zp: [P][rows]. */
+int adalog_score_w_self(const float* w, int rows, int I, const float* scale, const float* zp, int P, int n_bits,
+                        float* scores, void* stream);
+
+/* ---- K10  _search_best_a_scale_self                                   reference linear.py:320-345
+ * x: [rows][I] read ONCE for all P candidates.  channel_wise: scale/zp [P][I] -> scores [P][I], norm = 1/T;
+ * else scale/zp [P][1] -> scores [P][1], norm = 1/(T*I).  partial: scratch of adalog_score_a_self_partial_elems floats. */
+int adalog_score_a_self(const float* x, int64_t rows, int I, const float* scale, const float* zp, int P, int channel_wise,
+                        int n_bits, double norm, float* partial, int64_t partial_elems, float* scores, void* stream);
+int64_t adalog_score_a_self_partial_elems(int64_t rows, int I, int P);
+
+/* ---- K5/K6  exact order statistics by radix select
+ * adalog_quantile_rows: torch.quantile(x.view(S, n), q, dim=-1, interpolation='linear') for nq <= 4 quantiles, then the mean
+ *   over each group of `mbs` consecutive rows (the reference's chunked quantile, linear.py:465-471, matmul.py:219-230).
+ *   ranks_lo_hi: int64 [2*nq] = {floor(pos_j), ceil(pos_j)}, weights: fp32 [nq] = pos_j - floor(pos_j), pos_j = q_j*(n-1)
+ *   (computed by the host exactly as ATen does).  out: [nq][S/mbs].
+ * adalog_positive_percentile_rows: linear.py:763-798 -- value of rank ceil(count*q)-1 among the entries > 0 (0 if none).
+ *   qfrac: fp32 [nq].  out: [nq][S].
+ * workspace: adalog_select_workspace_bytes(S, R) bytes, R = 2*nq resp. nq. */
+int adalog_quantile_rows(const float* x, int64_t S, int64_t n, int nq, const int64_t* ranks_lo_hi, const float* weights,
+                         int mbs, float* out, void* workspace, int64_t workspace_bytes, void* stream);
+int adalog_positive_percentile_rows(const float* x, int64_t S, int64_t n, int nq, const float* qfrac, float* out,
+                                    void* workspace, int64_t workspace_bytes, void* stream);
+int64_t adalog_select_workspace_bytes(int64_t S, int R);
+
+/* ---- small vector kernels
+ * adalog_shift_fold: out[c][o] = bias[o] - shift[0] * (w_scale[c][o] * rowsum[c][o])      reference linear.py:999-1006
+ *   (rowsum from adalog_pack_uniform): folds the post-GELU "- shift" operand term into the bias, for reparam_bias and
+ *   for every post-GELU scoring call (linear.py:837,879,920).  bias may be NULL.
+ * adalog_minmax_rows: K4, per-row (min, max) [of |w| when use_abs] of w[rows][I]             reference linear.py:265-274
+ * adalog_absminmax_cols: K4, (min |x|, max |x|) per tensor ([1]) or per column ([I])          reference linear.py:276-294 */
+int adalog_shift_fold(const int32_t* rowsum, const float* w_scale, const float* shift, const float* bias, int C, int O,
+                      float* out, void* stream);
+int adalog_minmax_rows(const float* w, int rows, int I, int use_abs, float* mn, float* mx, void* stream);
+int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, float* mn, float* mx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADALOG_HIP_H */

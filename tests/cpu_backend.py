@@ -1,0 +1,223 @@
+"""CPU stand-in for the HIP kernel backend -- TEST INFRASTRUCTURE ONLY (lives under tests/, never imported by the package).
+
+Each function is an executable specification of one C-ABI entry point (include/adalog_hip.h) written with torch CPU
+ops, with the same Python signature as adalog_amd/ops.py.  Two uses:
+  * `-m "not gpu"` tests inject it with adalog_amd.backend.set_backend() to exercise the HOST logic (FPCS driver,
+    layer searches, calibrator, image sharding over gloo) against the golden fixtures without a GPU;
+  * `-m gpu` tests compare every HIP kernel against it one to one on seeded inputs.
+"""
+import math
+
+import torch
+
+from oracle import adalog_oracle as O
+
+I8, BF16, F32 = 0, 1, 2
+_ESZ = {I8: 1, BF16: 2, F32: 4}
+_TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32}
+
+
+def pad_k(K, dtype):
+    per = 64 // _ESZ[dtype]
+    return ((K + per - 1) // per) * per
+
+
+class Strided:
+    def __init__(self, t, c=0, g=0, n=0):
+        self.t, self.c, self.g, self.n = t, int(c), int(g), int(n)
+
+
+def uniform_fake_quant(x, scale, zero_point, n_bits, sym=False, want_bins=False, want_y=True):
+    y, q = O.uniform_fake_quant(x, scale, zero_point, n_bits, sym)
+    if want_bins:
+        return (y if want_y else None), q.to(torch.uint8)
+    return y
+
+
+def log_fake_quant(x, scale, q, table1, table2, n_bits, shift=None, sub_shift=False, train_form=False,
+                   want_bins=False, want_y=True):
+    xs = x if shift is None else x + shift
+    if train_form:
+        y, k, mask = O.adalog_fake_quant_train(xs, scale, int(q.item()), n_bits)
+    else:
+        y, k, mask = O.adalog_fake_quant(xs, scale, int(q.item()), n_bits, (table1, table2))
+    if sub_shift:
+        y = y - shift
+    if want_bins:
+        b = torch.where(mask, k, torch.full_like(k, 255.0)).to(torch.uint8)
+        return (y if want_y else None), b
+    return y
+
+
+def _params(t, C, G, R, pc, gmod, pg, pr):
+    c = torch.arange(C).view(C, 1, 1)
+    g = (torch.arange(G) % gmod).view(1, G, 1)
+    r = torch.arange(R).view(1, 1, R)
+    return t.reshape(-1)[(c * pc + g * pg + r * pr)]            # [C, G, R]
+
+
+def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, want_rowsum=False):
+    G, R, K = x3.shape
+    s = _params(scale, C, G, R, pc, gmod, pg, pr).unsqueeze(-1)
+    z = torch.round(_params(zero_point, C, G, R, pc, gmod, pg, pr)).unsqueeze(-1)
+    q = (torch.round(x3.unsqueeze(0) / s) + z).clamp(0, 2 ** n_bits - 1) - z
+    Kp = pad_k(K, dtype)
+    out = torch.zeros((C, G, R, Kp), dtype=_TORCH_DT[dtype])
+    out[..., :K] = q.to(_TORCH_DT[dtype])
+    if want_rowsum:
+        return out, q.sum(-1).to(torch.int32)
+    return out
+
+
+def pack_adalog(x3, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift=None, clamp_u=True):
+    G, R, K = x3.shape
+    s = _params(scale, C, G, R, pc, gmod, pg, 0).unsqueeze(-1)
+    qf = _params(qv, C, G, R, pc, gmod, pg, 0).unsqueeze(-1)
+    xs = x3 if shift is None else x3 + shift
+    u = xs.unsqueeze(0) / s
+    if clamp_u:
+        u = u.clamp(min=1e-15, max=1.0)
+    k = torch.round(-u.log2() * 37.0 / qf)
+    mask = ~(k < 2 ** n_bits)
+    k = k.clamp(0, 2 ** n_bits - 1)
+    k = torch.nan_to_num(k, nan=0.0)
+    kq = (k * qf).long()
+    t, j = kq // 37, kq % 37
+    v = torch.ldexp(mant37[j], -t.to(torch.int32))
+    v[t > 100] = 0
+    v[mask] = 0
+    Kp = pad_k(K, BF16)
+    out = torch.zeros((C, G, R, Kp), dtype=torch.bfloat16)
+    vb = v.to(torch.bfloat16)
+    assert torch.equal(vb.float(), v.float()), "AdaLog operand must be exact in bf16"
+    out[..., :K] = vb
+    return out
+
+
+def pack_raw(x3):
+    G, R, K = x3.shape
+    out = torch.zeros((1, G, R, pad_k(K, F32)), dtype=torch.float32)
+    out[0, :, :, :K] = x3
+    return out
+
+
+def _epi(t: Strided, C, G, gmod, N):
+    c = torch.arange(C).view(C, 1, 1)
+    gh = (torch.arange(G) % gmod).view(1, G, 1)
+    n = torch.arange(N).view(1, 1, N)
+    return t.t.reshape(-1)[c * t.c + gh * t.g + n * t.n].double()          # [C, G, N]
+
+
+def _gemm(dtype, A, B, C, G):
+    Ad = A.double().expand(C if A.shape[0] == 1 else A.shape[0], G if A.shape[1] == 1 else A.shape[1], -1, -1)
+    Bd = B.double().expand(C if B.shape[0] == 1 else B.shape[0], G if B.shape[1] == 1 else B.shape[1], -1, -1)
+    return torch.einsum("cgmk,cgnk->cgmn", Ad, Bd)
+
+
+def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1,
+               a_shared=False, b_shared=False):
+    D = _gemm(dtype, A, B, C, G)                                            # [C, G, M, N]
+    alpha = (_epi(sa, C, G, gmod, 1) * float(torch.tensor(sa_mul, dtype=torch.float32))) * _epi(sb, C, G, gmod, N)
+    out = D * alpha.unsqueeze(2)
+    if bias is not None:
+        out = out + _epi(bias, C, G, gmod, N).unsqueeze(2)
+    r = ref.reshape(G, M, -1).double()
+    if ref_div != 1:
+        r = r[..., torch.arange(N) // ref_div]
+    e2 = (r.unsqueeze(0) - out) ** 2                                        # [C, G, M, N]
+    e2 = e2.view(C, G // gmod, gmod, M, N)
+    dims = [1, 3]
+    if not keep_h:
+        dims.append(2)
+    if not keep_n:
+        dims.append(4)
+    s = -norm * e2.sum(dim=dims)
+    return s.reshape(C, -1).float()
+
+
+def gemm_out(dtype, A, B, M, N, G, gmod, sa, sb, bias, sa_mul=1.0):
+    D = _gemm(dtype, A, B, 1, G)
+    alpha = (_epi(sa, 1, G, gmod, 1) * float(torch.tensor(sa_mul, dtype=torch.float32))) * _epi(sb, 1, G, gmod, N)
+    out = D * alpha.unsqueeze(2)
+    if bias is not None:
+        out = out + _epi(bias, 1, G, gmod, N).unsqueeze(2)
+    return out[0].float()
+
+
+def topk(scores, k):
+    """(score desc, index asc); NaN first -- the deterministic tie rule of adalog_topk."""
+    s = torch.nan_to_num(scores, nan=float("inf"))
+    order = torch.sort(-s.double(), dim=0, stable=True)[1]
+    return order[:k].to(torch.int32)
+
+
+def fpcs_next(scale, zp, third, idx, k, new_cnt, lin, delta, clamp_min):
+    idx = idx.long()
+    g = lambda t: None if t is None else torch.gather(t, 0, idx)
+    ts, tz, tt = g(scale), g(zp), g(third)
+    if new_cnt == 0:
+        return ts[0], (None if tz is None else tz[0]), (None if tt is None else tt[0])
+    d = (lin.view(1, -1, 1) - 0.5) * delta.view(1, 1, -1)
+    ns = (ts.unsqueeze(1) + d).reshape(k * new_cnt, -1)
+    if clamp_min is not None:
+        ns = ns.clamp(min=clamp_min)
+    rep = lambda t: None if t is None else t.repeat_interleave(new_cnt, dim=0)
+    delta.copy_(delta / (new_cnt - 0.5))
+    return ns, rep(tz), rep(tt)
+
+
+def candidate_grid(quant4, num_scale, num_zp, zp_min, n_bits, lin, clamp_min):
+    dmin = quant4[0] - quant4[2]
+    dmax = quant4[1] - quant4[3]
+    sc = (dmin.unsqueeze(0) + lin.view(-1, 1) * (dmax - dmin).unsqueeze(0)) / (2 ** n_bits - 1)
+    if clamp_min is not None:
+        sc = sc.clamp(min=clamp_min)
+    scale = sc.repeat(num_zp, 1)
+    zp = torch.arange(zp_min, zp_min + num_zp).repeat_interleave(num_scale).float().view(-1, 1).repeat(1, quant4.shape[1])
+    return scale.contiguous(), zp.contiguous(), (scale[1] - scale[0]).contiguous()
+
+
+def score_w_self(w2, scale, zp, n_bits):
+    q = (torch.round(w2.unsqueeze(0) / scale.unsqueeze(-1)) + zp.unsqueeze(-1)).clamp(0, 2 ** n_bits - 1)
+    dq = (q - zp.unsqueeze(-1)) * scale.unsqueeze(-1)
+    return -((w2.unsqueeze(0) - dq) ** 2).mean(-1)
+
+
+def score_a_self(x2, scale, zp, channel_wise, n_bits, norm):
+    s, z = scale.unsqueeze(1), zp.unsqueeze(1)                               # [P, 1, C]
+    q = (torch.round(x2.unsqueeze(0) / s) + z).clamp(0, 2 ** n_bits - 1)
+    e2 = ((x2.unsqueeze(0) - (q - z) * s).double()) ** 2                     # [P, rows, I]
+    tot = e2.sum(1) if channel_wise else e2.sum((1, 2)).unsqueeze(-1)
+    return (-norm * tot).float()
+
+
+def quantile_ranks(qs, n):
+    pos = torch.tensor(qs, dtype=torch.float32) * (n - 1)
+    lo = pos.floor()
+    return torch.stack([lo, pos.ceil()], 1).reshape(-1).long(), pos - lo
+
+
+def quantile_rows(x2, qs, mbs=1):
+    S, n = x2.shape
+    v = torch.quantile(x2, torch.tensor(qs, dtype=torch.float32), dim=-1)       # [nq, S]
+    return v.view(len(qs), S // mbs, mbs).mean(-1) if mbs > 1 else v
+
+
+def positive_percentile_rows(x2, qs):
+    return torch.stack([O.positive_percentile(row, torch.tensor(qs, dtype=torch.float32)) for row in x2], dim=1)
+
+
+def shift_fold(rowsum, w_scale, shift, bias):
+    f = shift * (w_scale * rowsum.float())
+    return (bias.view(1, -1) if bias is not None else 0.0) - f
+
+
+def minmax_rows(w2):
+    return w2.amin(1), w2.amax(1)
+
+
+def absminmax(x2, per_channel):
+    a = x2.abs()
+    if per_channel:
+        return a.amin(0), a.amax(0)
+    return a.min().view(1), a.max().view(1)

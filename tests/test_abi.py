@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports every symbol include/adalog_hip.h declares (no compute: CPU tier)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "adalog_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(adalog_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_lists_functions():
+    names = header_functions()
+    assert "adalog_gemm_score" in names and "adalog_uniform_fake_quant_f32" in names and len(names) >= 18
+
+
+def test_library_exports_every_declared_symbol():
+    from adalog_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = _lib.load()
+    for name in header_functions():
+        assert hasattr(lib, name), f"{name} declared in include/adalog_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(header_functions())
+    assert lib.adalog_abi_version() == 1
+
+
+def test_argument_rejection_without_gpu():
+    """Entry points validate arguments before touching the device (returns -1 + message)."""
+    from adalog_amd import _lib
+    lib = _lib.load()
+    rc = lib.adalog_topk(None, 128, 4, 1, None, None)
+    assert rc == -1 and b"topk" in lib.adalog_last_error()
+    rc = lib.adalog_gemm_score(7, None, None, 0, 0, 0, 0, 1, 1, 64, 1, 1, 1, None, 0, 0, 1, None, 0, 0, 1.0,
+                               None, 0, 0, 0, None, 0, 0, 0, None, 0, None, 0, 0, 0, None)
+    assert rc == -1
+
+
+def test_product_package_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under adalog_amd/ may reference it."""
+    out = subprocess.run(["grep", "-rIl", "-E", r"(^|[^_a-zA-Z])oracle", os.path.join(ROOT, "adalog_amd"),
+                          "--include=*.py", "--include=*.hip", "--include=*.h"], capture_output=True, text=True).stdout
+    assert out.strip() == "", f"product files mention the oracle: {out}"
