@@ -1,0 +1,347 @@
+"""`-m gpu` parity tests: every HIP kernel, called through the C ABI, against its CPU specification / the oracle.
+
+Bars (north star): integer bin indices and packed integer operands bit-exact; fp32 fake-quant tensors and scores within
+1e-3 relative (observed: bit-exact for the elementwise kernels, ~1e-6 for scores).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adalog_oracle as O
+from tests import cpu_backend as CB
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from adalog_amd import backend
+    backend.set_backend(None)
+    return backend.get()          # raises loudly if the HIP library or the device is missing
+
+
+DEV = "cuda"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp(min=1e-30)).item()
+
+
+# ------------------------------------------------------------------------------------------------ K1
+@pytest.mark.parametrize("bits", [3, 4, 6, 8])
+@pytest.mark.parametrize("layout", ["tensor", "channel", "rows", "heads", "ragged"])
+def test_uniform_fake_quant(ops, bits, layout):
+    L = 2 ** (bits - 1)
+    gen = g(100 + bits)
+    if layout == "tensor":
+        x = torch.randn(7, 197, 96, generator=gen) * 2
+        s = torch.tensor([0.11]); z = torch.tensor([L - 0.3])
+    elif layout == "channel":
+        x = torch.randn(5, 33, 96, generator=gen) * torch.linspace(0.2, 3, 96)
+        s = torch.rand(96, generator=gen) * 0.3 + 0.02; z = torch.randint(0, 2 * L, (96,), generator=gen).float()
+    elif layout == "rows":
+        x = torch.randn(3, 64, 384, generator=gen) * 0.2
+        s = torch.rand(3, 64, 1, generator=gen) * 0.05 + 0.005; z = torch.randint(0, 2 * L, (3, 64, 1), generator=gen).float()
+    elif layout == "heads":
+        x = torch.randn(4, 6, 50, 64, generator=gen)
+        s = torch.rand(1, 6, 1, 1, generator=gen) * 0.3 + 0.05; z = torch.randint(0, 2 * L, (1, 6, 1, 1), generator=gen).float()
+    else:   # odd sizes: scalar (non-vectorised) path, empty tail handling
+        x = torch.randn(3, 7, 13, generator=gen)
+        s = torch.rand(3, 7, 1, generator=gen) * 0.3 + 0.05; z = torch.randint(0, 2 * L, (3, 7, 1), generator=gen).float()
+    y_ref, q_ref = O.uniform_fake_quant(x, s, z, bits)
+    y, bins = ops.uniform_fake_quant(x.to(DEV), s.to(DEV), z.to(DEV), bits, want_bins=True)
+    assert torch.equal(bins.cpu(), q_ref.to(torch.uint8)), "integer bins must be exact"
+    assert torch.equal(y.cpu(), y_ref), "fp32 fake-quant is the same IEEE op sequence: expected bit-exact"
+    ys = ops.uniform_fake_quant(x.to(DEV), s.abs().to(DEV) * 4, None, bits, sym=True)
+    assert torch.equal(ys.cpu(), O.uniform_fake_quant(x, s.abs() * 4, None, bits, sym=True)[0])
+
+
+def test_uniform_empty_and_errors(ops):
+    from adalog_amd._lib import AdalogHipError
+    x = torch.empty(0, 8, device=DEV)
+    assert ops.uniform_fake_quant(x, torch.ones(1, device=DEV), torch.zeros(1, device=DEV), 4).numel() == 0
+    with pytest.raises(AdalogHipError):
+        ops.uniform_fake_quant(torch.randn(4, 4), torch.ones(1), torch.zeros(1), 4)      # CPU tensors: no fallback
+    with pytest.raises(AdalogHipError):
+        ops.uniform_fake_quant(torch.randn(4, 4, device=DEV), torch.ones(1, device=DEV), torch.zeros(1, device=DEV), 9)
+
+
+# ------------------------------------------------------------------------------------------------ K2/K3
+@pytest.mark.parametrize("bits", [3, 4, 6])
+@pytest.mark.parametrize("q", [10, 37, 53, 137])
+def test_adalog_fake_quant(ops, bits, q):
+    gen = g(200 + bits + q)
+    sm = torch.softmax(4 * torch.randn(8, 6, 197, 197, generator=gen), dim=-1)          # 1.86 M elements
+    t1, t2 = O.adalog_tables(q, bits)
+    qd = torch.tensor([q]).to(DEV)
+    for scale in (torch.ones(1, 1, 1, 1), torch.tensor([0.83])):
+        y_ref, k_ref, m_ref = O.adalog_fake_quant(sm, scale, q, bits, (t1, t2))
+        y, bins = ops.log_fake_quant(sm.to(DEV), scale.to(DEV), qd, t1.to(DEV), t2.to(DEV), bits, want_bins=True)
+        b_ref = torch.where(m_ref, k_ref, torch.full_like(k_ref, 255.0)).to(torch.uint8)
+        flips = (bins.cpu() != b_ref).sum().item()
+        assert flips == 0, f"{flips} bin flips of {sm.numel()} (expected ~1e-9 per element, see DESIGN.md)"
+        assert rel_err(y.cpu(), y_ref) <= 1e-6
+    # shifted post-GELU form, both re-parameterisation states, and the training (no-LUT) form
+    ge = torch.nn.functional.gelu(2 * torch.randn(16, 197, 384, generator=gen))
+    sc = torch.tensor([ge.max().item() * 0.9 + 0.17]); sh = torch.tensor([O.GELU_SHIFT])
+    for reparamed in (False, True):
+        y_ref, k_ref, m_ref = O.shift_adalog_fake_quant(ge, sc, q, bits, sh, reparamed, (t1, t2))
+        y, bins = ops.log_fake_quant(ge.to(DEV), sc.to(DEV), qd, t1.to(DEV), t2.to(DEV), bits, shift=sh.to(DEV),
+                                     sub_shift=not reparamed, want_bins=True)
+        b_ref = torch.where(m_ref, k_ref, torch.full_like(k_ref, 255.0)).to(torch.uint8)
+        assert (bins.cpu() != b_ref).sum().item() == 0
+        assert (y.cpu() - y_ref).abs().max().item() <= 1e-6 * sc.item()
+    y_ref, _, _ = O.adalog_fake_quant_train(sm, torch.tensor([0.83]), q, bits)
+    y = ops.log_fake_quant(sm.to(DEV), torch.tensor([0.83]).to(DEV), qd, None, None, bits, train_form=True)
+    assert rel_err(y.cpu(), y_ref) <= 1e-5
+
+
+def test_adalog_zero_and_tiny_inputs(ops):
+    """x = 0 / denormal / above the scale: clamp to [1e-15, 1] then mask, exactly as logarithm.py:87-98."""
+    x = torch.tensor([0.0, 1e-45, 1e-30, 1e-16, 1e-15, 0.5, 1.0, 2.0, -1.0, 0.999999, 2 ** -15.5])
+    for bits in (3, 4, 6):
+        t1, t2 = O.adalog_tables(37, bits)
+        y_ref, k_ref, m_ref = O.adalog_fake_quant(x, torch.ones(1), 37, bits, (t1, t2))
+        y, bins = ops.log_fake_quant(x.to(DEV), torch.ones(1, device=DEV), torch.tensor([37]).to(DEV), t1.to(DEV),
+                                     t2.to(DEV), bits, want_bins=True)
+        assert torch.equal(y.cpu(), y_ref)
+        assert torch.equal(bins.cpu(), torch.where(m_ref, k_ref, torch.full_like(k_ref, 255.0)).to(torch.uint8))
+
+
+# ------------------------------------------------------------------------------------------------ operand packing
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_pack_uniform(ops, bits):
+    gen = g(300 + bits)
+    L = 2 ** (bits - 1)
+    # activation candidates (per-tensor, C = 16), K not a multiple of 64
+    x3 = torch.randn(1, 500, 197, generator=gen)
+    sc = torch.rand(16, 1, generator=gen) * 0.2 + 0.05; zp = torch.randint(L - 4, L + 4, (16, 1), generator=gen).float()
+    ref = CB.pack_uniform(x3, sc, zp, 16, 1, 1, 0, 0, bits, CB.I8)
+    out = ops.pack_uniform(x3.to(DEV), sc.to(DEV), zp.to(DEV), 16, 1, 1, 0, 0, bits, ops.I8)
+    assert torch.equal(out.cpu(), ref)
+    # per-row weight candidates with rowsum, bf16 and fp32 outputs
+    w3 = torch.randn(1, 96, 384, generator=gen) * 0.1
+    sc = torch.rand(8, 96, generator=gen) * 0.02 + 0.005; zp = torch.randint(0, 2 * L, (8, 96), generator=gen).float()
+    for dt_c, dt_o in ((CB.I8, ops.I8), (CB.BF16, ops.BF16), (CB.F32, ops.F32)):
+        ref, rs = CB.pack_uniform(w3, sc, zp, 8, 96, 1, 0, 1, bits, dt_c, want_rowsum=True)
+        out, rso = ops.pack_uniform(w3.to(DEV), sc.to(DEV), zp.to(DEV), 8, 96, 1, 0, 1, bits, dt_o, want_rowsum=True)
+        assert torch.equal(out.cpu().float(), ref.float()) and torch.equal(rso.cpu(), rs)
+    # per-head candidates on a transposed view (B^T of softmax@v: row stride 1)
+    B = torch.randn(3, 4, 49, 32, generator=gen)                               # [N,H,S,C]
+    bt3 = B.transpose(-2, -1).reshape(-1, 32, 49)
+    sc = torch.rand(8, 4, generator=gen) * 0.2 + 0.05; zp = torch.randint(L - 3, L + 3, (8, 4), generator=gen).float()
+    ref = CB.pack_uniform(bt3, sc, zp, 8, 4, 4, 1, 0, bits, CB.I8)
+    Bd = B.to(DEV)
+    out = ops.pack_uniform(Bd.transpose(-2, -1).reshape(-1, 32, 49), sc.to(DEV), zp.to(DEV), 8, 4, 4, 1, 0, bits, ops.I8)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_pack_adalog(ops, bits):
+    gen = g(400 + bits)
+    L = 2 ** (bits - 1)
+    table = O.search_table(bits)
+    mant = torch.round(table[:37] * (4 * L - 2))
+    # post-softmax: no clamp, scale 1, 16 candidate bases
+    A3 = torch.softmax(4 * torch.randn(6, 50, 50, generator=gen), -1)
+    A3[0, 0, :5] = torch.tensor([0.0, 1e-40, 1e-20, 1.0, 0.5])
+    qv = torch.tensor([10., 11, 23, 36, 37, 38, 53, 64, 77, 90, 100, 111, 120, 130, 136, 137])
+    ones = torch.ones(16)
+    ref = CB.pack_adalog(A3, ones, qv, 16, 1, 1, 0, bits, mant, None, False)
+    out = ops.pack_adalog(A3.to(DEV), ones.to(DEV), qv.to(DEV), 16, 1, 1, 0, bits, mant.to(DEV), None, False)
+    bad = (out.cpu().float() != ref.float()).sum().item()
+    assert bad == 0, f"{bad} of {ref.numel()} AdaLog operands differ"
+    # post-GELU: shift + clamp, per-candidate (scale, base)
+    x3 = torch.nn.functional.gelu(2 * torch.randn(1, 300, 200, generator=gen))
+    sc = torch.rand(16, generator=gen) * 2 + 1.0
+    sh = torch.tensor([O.GELU_SHIFT])
+    ref = CB.pack_adalog(x3, sc, qv, 16, 1, 1, 0, bits, mant, sh, True)
+    out = ops.pack_adalog(x3.to(DEV), sc.to(DEV), qv.to(DEV), 16, 1, 1, 0, bits, mant.to(DEV), sh.to(DEV), True)
+    assert (out.cpu().float() != ref.float()).sum().item() == 0
+    # the packed operand times s/(4L-2) reproduces the reference's search-time value (linear.py:830-837)
+    v_ref = O.adalog_search_value(-((x3.unsqueeze(-1) + sh) / sc).clamp(1e-15, 1.0).log2(), qv, bits, table)
+    got = out.cpu().float()[..., :200].permute(1, 2, 3, 0) / (4 * L - 2)        # [G,R,K,C]
+    torch.testing.assert_close(got, v_ref, rtol=1e-6, atol=0)
+
+
+def test_pack_raw(ops):
+    x3 = torch.randn(1, 77, 48 * 3, generator=g(5))
+    assert torch.equal(ops.pack_raw(x3.to(DEV)).cpu(), CB.pack_raw(x3))
+
+
+# ------------------------------------------------------------------------------------------------ scoring GEMM
+def _strided(mod, t, **kw):
+    return mod.Strided(t, **kw)
+
+
+@pytest.mark.parametrize("dtype", ["i8", "bf16", "f32"])
+@pytest.mark.parametrize("shape", [(300, 200, 197, 1, 1, 5), (197, 197, 64, 12, 6, 4), (130, 129, 65, 2, 2, 3)])
+def test_gemm_score_vs_spec(ops, dtype, shape):
+    """M, N, K, G, gmod, C with ragged edges in every dimension; all three epilogue reductions."""
+    M, N, K, G, gmod, C = shape
+    gen = g(500 + M)
+    dt_c = {"i8": CB.I8, "bf16": CB.BF16, "f32": CB.F32}[dtype]
+    dt_o = {"i8": ops.I8, "bf16": ops.BF16, "f32": ops.F32}[dtype]
+    Kp = CB.pad_k(K, dt_c)
+    tdt = {"i8": torch.int8, "bf16": torch.bfloat16, "f32": torch.float32}[dtype]
+    A = torch.zeros(C, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, N, Kp, dtype=tdt)
+    A[..., :K] = torch.randint(-15, 16, (C, G, M, K), generator=gen).to(tdt)
+    B[..., :K] = torch.randint(-15, 16, (1, G, N, K), generator=gen).to(tdt)
+    if dtype != "i8":
+        A[..., :K] = (A[..., :K].float() * 0.25).to(tdt)
+    ref = torch.randn(G, M, N, generator=gen) * 3
+    sa = torch.rand(C, gmod, generator=gen) * 0.02 + 0.01
+    sb = torch.rand(gmod, N, generator=gen) * 0.5 + 0.5
+    bias = torch.randn(N, generator=gen)
+    for keep_h, keep_n in ((False, True), (True, False), (False, False)):
+        want = CB.gemm_score(dt_c, A, B, M, N, C, G, gmod, ref, CB.Strided(sa, c=gmod, g=1), CB.Strided(sb, g=N, n=1),
+                             CB.Strided(bias, n=1), keep_h, keep_n, 1.0 / M, sa_mul=0.5)
+        got = ops.gemm_score(dt_o, A.to(DEV), B.to(DEV), M, N, C, G, gmod, ref.to(DEV),
+                             ops.Strided(sa.to(DEV), c=gmod, g=1), ops.Strided(sb.to(DEV), g=N, n=1),
+                             ops.Strided(bias.to(DEV), n=1), keep_h, keep_n, 1.0 / M, sa_mul=0.5)
+        assert got.shape == want.shape
+        assert rel_err(got.cpu(), want) <= 2e-6, (keep_h, keep_n, rel_err(got.cpu(), want))
+    out = ops.gemm_out(dt_o, A[:1].to(DEV), B.to(DEV), M, N, G, gmod, ops.Strided(sa[:1].to(DEV), g=1),
+                       ops.Strided(sb.to(DEV), g=N, n=1), ops.Strided(bias.to(DEV), n=1), sa_mul=0.5)
+    want = CB.gemm_out(dt_c, A[:1], B, M, N, G, gmod, CB.Strided(sa[:1], g=1), CB.Strided(sb, g=N, n=1),
+                       CB.Strided(bias, n=1), sa_mul=0.5)
+    assert rel_err(out.cpu(), want) <= 2e-6
+
+
+def test_gemm_score_transpose_detecting(ops):
+    """A = I with an ASYMMETRIC B: catches a swapped C/D fragment layout (cdna guide, G9)."""
+    M = N = 128; K = 128
+    A = torch.zeros(1, 1, M, K, dtype=torch.int8); A[0, 0, torch.arange(M), torch.arange(M)] = 1
+    B = torch.zeros(1, 1, N, K, dtype=torch.int8)
+    B[0, 0] = (torch.arange(N).view(-1, 1) * 3 + torch.arange(K).view(1, -1) * 5) % 23 - 11
+    one = torch.ones(1)
+    out = ops.gemm_out(ops.I8, A.to(DEV), B.to(DEV), M, N, 1, 1, ops.Strided(one.to(DEV)), ops.Strided(one.to(DEV)), None)
+    assert torch.equal(out.cpu()[0], B[0, 0].float().t())
+
+
+def test_gemm_score_deterministic(ops):
+    gen = g(7)
+    A = torch.randint(-8, 8, (8, 1, 1000, 192), generator=gen).to(torch.int8).to(DEV)
+    B = torch.randint(-8, 8, (1, 1, 300, 192), generator=gen).to(torch.int8).to(DEV)
+    ref = torch.randn(1, 1000, 300, generator=gen).to(DEV)
+    s = torch.rand(8, generator=gen).to(DEV) * 0.01; sb = torch.rand(300, generator=gen).to(DEV)
+    run = lambda: ops.gemm_score(ops.I8, A, B, 1000, 300, 8, 1, 1, ref, ops.Strided(s, c=1), ops.Strided(sb, n=1), None,
+                                 False, False, 1e-3)
+    a = run()
+    for _ in range(3):
+        assert torch.equal(a, run()), "scores must be bit-reproducible (fixed-order fp64 finish)"
+
+
+# ------------------------------------------------------------------------------------------------ FPCS pieces
+def test_topk_ties_and_nan(ops):
+    gen = g(11)
+    s = torch.randn(128, 300, generator=gen)
+    s[5, :] = s[9, :]                          # exact ties -> lower index first
+    s[100, 7] = float("nan")
+    for k in (1, 8, 16, 32):
+        assert torch.equal(ops.topk(s.to(DEV), k).cpu(), CB.topk(s, k))
+    vals, _ = torch.topk(torch.nan_to_num(s, nan=float("inf")), 16, dim=0)
+    got = torch.gather(torch.nan_to_num(s, nan=float("inf")), 0, ops.topk(s.to(DEV), 16).cpu().long())
+    assert torch.equal(got, vals)
+
+
+def test_candidate_grid_and_fpcs_next(ops):
+    gen = g(12)
+    cols = 70
+    q4 = torch.stack([torch.rand(cols, generator=gen) + 1, torch.rand(cols, generator=gen) + 2,
+                      -torch.rand(cols, generator=gen) - 1, -torch.rand(cols, generator=gen) - 2])
+    for bits, num_zp, clamp in ((4, 8, None), (6, 16, 1e-4), (3, 4, None)):
+        L = 2 ** (bits - 1)
+        ns = 128 // num_zp
+        lin = torch.linspace(0, 1, ns)
+        want = CB.candidate_grid(q4, ns, num_zp, int(L - num_zp / 2), bits, lin, clamp)
+        got = ops.candidate_grid(q4.to(DEV), ns, num_zp, int(L - num_zp / 2), bits, lin.to(DEV), clamp)
+        for a, b in zip(got, want):
+            torch.testing.assert_close(a.cpu(), b, rtol=2e-7, atol=0)
+    scale, zp, delta = want
+    scores = torch.randn(128, cols, generator=gen)
+    idx = CB.topk(scores, 16)
+    lin8 = torch.linspace(0, 1, 8)
+    d_ref = delta.clone()
+    w = CB.fpcs_next(scale, zp, zp * 2, idx, 16, 8, lin8, d_ref, 1e-4)
+    d_dev = delta.clone().to(DEV)
+    o = ops.fpcs_next(scale.to(DEV), zp.to(DEV), (zp * 2).to(DEV), idx.to(DEV), 16, 8, lin8.to(DEV), d_dev, 1e-4)
+    for a, b in zip(o, w):
+        assert torch.equal(a.cpu(), b)
+    assert torch.equal(d_dev.cpu(), d_ref)
+    idx1 = CB.topk(scores, 1)
+    w = CB.fpcs_next(scale, zp, None, idx1, 1, 0, None, None, None)
+    o = ops.fpcs_next(scale.to(DEV), zp.to(DEV), None, idx1.to(DEV), 1, 0, None, None, None)
+    assert torch.equal(o[0].cpu(), w[0]) and torch.equal(o[1].cpu(), w[1]) and o[2] is None
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_self_mse_scores(ops, bits):
+    gen = g(600 + bits)
+    L = 2 ** (bits - 1)
+    W = torch.randn(3, 64, 192, generator=gen) * 0.1
+    sc, zp = O.weight_candidates(W, bits)
+    want = O.score_w_self(W, sc, zp, bits).reshape(128, -1)
+    got = ops.score_w_self(W.view(-1, 192).to(DEV), sc.reshape(128, -1).to(DEV), zp.reshape(128, -1).float().to(DEV), bits)
+    assert rel_err(got.cpu(), want) <= 1e-5
+    x = torch.randn(6, 197, 96, generator=gen) * torch.linspace(0.3, 2, 96)
+    for cw in (True, False):
+        s2, z2 = O.activation_candidates(x, bits, cw)
+        want = O.score_a_self(x, s2, z2, bits, cw).t()                       # [P, C]
+        T = 197
+        norm = 1.0 / T if cw else 1.0 / (T * 96)
+        got = ops.score_a_self(x.view(-1, 96).to(DEV), s2.t().contiguous().to(DEV), z2.t().contiguous().float().to(DEV),
+                               cw, bits, norm)
+        assert rel_err(got.cpu(), want) <= 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ order statistics
+@pytest.mark.parametrize("S,n", [(1, 1000003), (96, 384), (7, 6304), (4, 65536)])
+def test_quantile_rows(ops, S, n):
+    gen = g(700 + S)
+    x = torch.randn(S, n, generator=gen)
+    x[0, :10] = x[0, 10:20]                                                 # duplicates
+    qs = torch.tensor([0.9, 1.0]).tolist() + (1 - torch.tensor([0.9, 1.0])).tolist()
+    want = torch.quantile(x, torch.tensor(qs), dim=-1)
+    got = ops.quantile_rows(x.to(DEV), qs, 1)
+    torch.testing.assert_close(got.cpu(), want, rtol=1e-6, atol=1e-7)
+    if S % 2 == 0:
+        got = ops.quantile_rows(x.to(DEV), qs, 2)
+        torch.testing.assert_close(got.cpu(), want.view(4, S // 2, 2).mean(-1), rtol=1e-6, atol=1e-7)
+
+
+def test_quantile_negative_zero_and_constant(ops):
+    x = torch.tensor([[0.0, -0.0, 1.0, -1.0, 0.0, 2.0, -2.0, 0.0], [3.0] * 8])
+    qs = [0.5, 0.0, 1.0, 0.25]
+    torch.testing.assert_close(ops.quantile_rows(x.to(DEV), qs, 1).cpu(), torch.quantile(x, torch.tensor(qs), dim=-1),
+                               rtol=0, atol=0)
+
+
+def test_positive_percentile(ops):
+    gen = g(800)
+    x = torch.nn.functional.gelu(2 * torch.randn(1, 500000, generator=gen))
+    qs = [0.9, 1.0, 0.5, 0.013]
+    want = O.positive_percentile(x.view(-1), torch.tensor(qs)).view(-1, 1)
+    assert torch.equal(ops.positive_percentile_rows(x.to(DEV), qs).cpu(), want)
+    neg = -torch.rand(1, 1000, generator=gen)                               # no positive entry -> 0 (linear.py:796-797)
+    assert torch.equal(ops.positive_percentile_rows(neg.to(DEV), [0.9, 1.0]).cpu(), torch.zeros(2, 1))
+
+
+def test_misc_kernels(ops):
+    gen = g(900)
+    W = torch.randn(100, 333, generator=gen)
+    mn, mx = ops.minmax_rows(W.to(DEV))
+    assert torch.equal(mn.cpu(), W.amin(1)) and torch.equal(mx.cpu(), W.amax(1))
+    x = torch.randn(5000, 96, generator=gen)
+    for pc in (True, False):
+        a, b = ops.absminmax(x.to(DEV), pc)
+        wa, wb = CB.absminmax(x, pc)
+        assert torch.equal(a.cpu(), wa) and torch.equal(b.cpu(), wb)
+    rs = torch.randint(-500, 500, (4, 50), generator=gen).to(torch.int32)
+    ws = torch.rand(4, 50, generator=gen); sh = torch.tensor([0.17]); bias = torch.randn(50, generator=gen)
+    torch.testing.assert_close(ops.shift_fold(rs.to(DEV), ws.to(DEV), sh.to(DEV), bias.to(DEV)).cpu(),
+                               CB.shift_fold(rs, ws, sh, bias), rtol=1e-6, atol=1e-6)

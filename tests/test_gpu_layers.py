@@ -1,0 +1,95 @@
+"""`-m gpu`: the product layers' full searches on the HIP backend against the reference's golden results
+(same cases as tests/test_host_logic_cpu.py, now with the real kernels), plus score-vector parity on identical
+candidates against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adalog_oracle as O
+from tests import layer_cases as LC
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _hip_backend():
+    from adalog_amd import backend
+    backend.set_backend(None)
+    backend.get()
+    yield
+
+
+@pytest.mark.parametrize("name", ["linear_w3a3", "linear_w4a4", "linear_w6a6", "linear_w4a4_ragged"])
+def test_linear_search(golden, name):
+    LC.case_linear_search(golden, name, DEV)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_channelwise_reparam(golden, bits):
+    LC.case_channelwise_reparam(golden, bits, DEV)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_postgelu_search(golden, bits):
+    LC.case_postgelu_search(golden, bits, DEV)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_matmul_search(golden, bits):
+    LC.case_matmul_search(golden, bits, DEV)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_postsoftmax_search(golden, bits):
+    LC.case_postsoftmax_search(golden, bits, DEV)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_conv_search(golden, bits):
+    LC.case_conv_search(golden, bits, DEV)
+
+
+def test_modes_and_errors():
+    LC.case_modes_and_errors(DEV)
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_linear_scores_on_reference_candidates(golden, bits):
+    """Score vectors of the output-MSE searches (K7/K8) on the reference's own first-round candidates:
+    the golden trace call 12 (weights) and 18 (activations) are reproduced to 1e-4 (observed ~5e-6)."""
+    from adalog_amd import quant_layers as Q, search
+    g = golden(f"linear_w{bits}a{bits}")
+    wb, ab, N, Tn, I, Oc, n_V, cbs = [int(v) for v in g["cfg"]]
+    W, b, x, ro = t(g["weight"]), t(g["bias"]), t(g["x"]), t(g["raw_out"])
+    p = O.search_linear(W, b, x, ro, wb, ab, n_V=n_V, batch=cbs, rounds=0)        # state after the two self-searches
+    lay = Q.AsymmetricallyBatchingQuantLinear(I, Oc, True, "raw", wb, ab, calib_batch_size=cbs, search_round=3,
+                                              eq_n=128, n_V=n_V, fpcs=True, steps=6).to(DEV)
+    lay.weight.data.copy_(W); lay.bias.data.copy_(b)
+    lay.raw_input, lay.raw_out = x.to(DEV), ro.to(DEV)
+    lay.a_quantizer.scale.data.copy_(p.a_scale); lay.a_quantizer.zero_point.data.copy_(p.a_zp)
+    lay.w_quantizer.scale.data.copy_(p.w_scale); lay.w_quantizer.zero_point.data.copy_(p.w_zp)
+    sc = t(g["cand_w_scale"]).reshape(128, -1).to(DEV); zp = t(g["cand_w_zp"]).reshape(128, -1).float().to(DEV)
+    s = lay._score_w(lay._pack_x_fixed(), sc, zp).cpu()
+    ref = t(g["trace_012_scores"]).reshape(128, -1)
+    assert ((s - ref).abs() / ref.abs()).max().item() <= 1e-4
+    # activation search of round 0 uses the weights committed by trace call 17
+    tr = O.Trace()
+    p1 = O.search_linear(W, b, x, ro, wb, ab, n_V=n_V, batch=cbs, rounds=1, trace=tr)
+    wsel = torch.gather(t(g["cand_w_scale"]), 0, torch.zeros(1, dtype=torch.long).view(1, 1, 1, 1).expand(1, n_V, Oc // n_V, 1))
+    del wsel
+    # recover the weights in force during call 18 by replaying only the weight FPCS of round 0
+    xq = O.uniform_fake_quant(x, p.a_scale, p.a_zp, ab)[0]
+    w3 = W.view(n_V, Oc // n_V, I)
+    scw, zpw = O.weight_candidates(w3, wb)
+    s_w, z_w = O.fpcs(scw, zpw, lambda a, c: O.score_w(xq, w3, b, ro, a, c, wb, cbs), 0, 6, 16, 128, None, None,
+                      lambda idx, k: idx.reshape(k, n_V, -1, 1))
+    lay.w_quantizer.scale.data.copy_(s_w.squeeze(0)); lay.w_quantizer.zero_point.data.copy_(z_w.squeeze(0).float())
+    sa = t(g["cand_a_scale"]).t().contiguous().to(DEV); za = t(g["cand_a_zp"]).t().contiguous().float().to(DEV)
+    s = lay._score_a(lay._pack_w_fixed(), sa, za).cpu()
+    ref = t(g["trace_018_scores"]).reshape(-1, 128).t()
+    assert ((s - ref).abs() / ref.abs()).max().item() <= 1e-4
