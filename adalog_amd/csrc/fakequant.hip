@@ -125,6 +125,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" int adalog_uniform_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale,
                                              const float* zero_point, int64_t n_channels, int64_t inner, int n_bits,
                                              int symmetric, void* stream) {
+    if (n == 0) return 0;
     ADALOG_ARG_CHECK(x && scale && n >= 0 && n_channels >= 1 && inner >= 1, "uniform_fake_quant: bad arguments");
     ADALOG_ARG_CHECK(symmetric || zero_point, "uniform_fake_quant: asymmetric needs zero_point");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 8, "uniform_fake_quant: n_bits must be in [2,8]");
@@ -161,6 +162,7 @@ extern "C" int adalog_uniform_fake_quant_f32(const float* x, float* y, uint8_t* 
 extern "C" int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale,
                                          const int64_t* q, const float* table1, const float* table2, int n_bits,
                                          const float* shift, int sub_shift, int train_form, void* stream) {
+    if (n == 0) return 0;
     ADALOG_ARG_CHECK(x && scale && q && n >= 0, "log_fake_quant: bad arguments");
     ADALOG_ARG_CHECK(train_form || (table1 && table2), "log_fake_quant: eval form needs table1/table2");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 8, "log_fake_quant: n_bits must be in [2,8]");

@@ -97,9 +97,9 @@ def case_channelwise_reparam(golden, bits, device="cpu"):
         lay.a_quantizer.zero_point.data.copy_(t(g["cw_a_zp"]))
         lay.reparam()
     close(ln.weight.data, t(g["reparam_ln_weight"]), 1e-6, 0)
-    close(ln.bias.data, t(g["reparam_ln_bias"]), 1e-6, 1e-7)
+    close(ln.bias.data, t(g["reparam_ln_bias"]), 1e-5, 1e-6)
     close(lay.weight.data, t(g["out_weight"]), 1e-6, 0)
-    close(lay.bias.data, t(g["out_bias"]), 1e-5, 1e-6)
+    close(lay.bias.data, t(g["out_bias"]), 1e-4, 1e-5)
     assert lay.a_quantizer.scale.shape == (1,) and not lay.a_quantizer.channel_wise
     lay.mode = "quant_forward"
     with torch.no_grad():
