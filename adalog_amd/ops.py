@@ -13,6 +13,9 @@ import torch
 from . import _lib
 
 I8, BF16, F32 = 0, 1, 2
+# bench.py sets this to a list to time the scoring GEMM launches: (dtype, M, N, Kp, C, G, A.data_ptr(), start, end) with
+# the two events recorded on the launch stream immediately around the adalog_gemm_score kernel (not the finish kernel)
+GEMM_EVENTS = None
 _ESZ = {I8: 1, BF16: 2, F32: 4}
 _TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32}
 
@@ -170,6 +173,9 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     sRg = 0 if G == 1 else M * ldr
     n_part = lib.adalog_gemm_score_partial_elems(M, N, C, G)
     partial = torch.empty(n_part, dtype=torch.float32, device=A.device)
+    if GEMM_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, N, Kp, C, G, gmod,
                                ref.data_ptr(), ldr, sRg, ref_div, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul),
                                sb.t.data_ptr(), sb.c, sb.g, sb.n,
@@ -177,6 +183,9 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
                                0 if bias is None else bias.n,
                                partial.data_ptr(), n_part, None, 0, 0, 0, _stream())
+    if GEMM_EVENTS is not None:
+        ev1.record()
+        GEMM_EVENTS.append((dtype, M, N, Kp, C, G, A.data_ptr(), B.data_ptr(), ev0, ev1))
     _lib.check(rc, "adalog_gemm_score")
     cols = (gmod if keep_h else 1) * (N if keep_n else 1)
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)

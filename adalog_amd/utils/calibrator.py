@@ -1,0 +1,122 @@
+"""QuantCalibrator -- the outer calibration loop of reference utils/calibrator.py:9-67, device-resident.
+
+Same contract: for every module that has ``calibrated == False`` (visited in ``named_modules()`` order) capture its
+input(s) and output over the whole calibration set with all modules in 'raw' mode, attach them as ``raw_input`` /
+``raw_out``, call ``hyperparameter_searching()`` and, for layers with a ``prev_layer``, ``reparam()``; finally switch
+every module to 'quant_forward'.
+
+What is different, by design:
+  * captures stay on the GPU (the reference moves every activation to the host and back, calibrator.py:17-28 and
+    linear.py:134,145,...); 288 GB of HBM holds a whole block's captures for 1024 images;
+  * ``capture='block'`` (default) records all un-calibrated modules that share a transformer block in ONE forward
+    pass instead of one full-model pass per module (74 passes for ViT, 149 for Swin).  This is legal because every
+    module stays 'raw' until the end (calibrator.py:65-67) and the LayerNorm fold of reparam() is function preserving
+    (linear.py:604-611), so later captures are unchanged up to fp32 rounding.  ``capture='module'`` reproduces the
+    reference's pass structure exactly;
+  * the forward pass stops right after the last hooked module of the group has run;
+  * with torch.distributed initialised the loader is expected to yield this rank's image shard; searches all-reduce
+    their scores (adalog_amd.parallel).
+"""
+import re
+import time
+
+import torch
+
+from ..quant_layers import MinMaxQuantConv2d, MinMaxQuantLinear, MinMaxQuantMatMul
+
+
+class _StopForward(Exception):
+    pass
+
+
+class QuantCalibrator:
+    def __init__(self, model, calib_loader, capture: str = "block", verbose: bool = False):
+        assert capture in ("block", "module")
+        self.model = model
+        self.calib_loader = calib_loader
+        self.capture = capture
+        self.verbose = verbose
+        self.timings = {}                    # module name -> seconds spent in hyperparameter_searching (+ reparam)
+        self.capture_seconds = 0.0
+
+    # hooks keep the reference's names (calibrator.py:14-28); tensors stay on the device
+    def single_input_forward_hook(self, module, inp, outp):
+        if module.tmp_input is None:
+            module.tmp_input = []
+        module.tmp_input.append(inp[0].detach())
+
+    def double_input_forward_hook(self, module, inp, outp):
+        if module.tmp_input is None:
+            module.tmp_input = [[], []]
+        module.tmp_input[0].append(inp[0].detach())
+        module.tmp_input[1].append(inp[1].detach())
+
+    def outp_forward_hook(self, module, inp, outp):
+        if module.tmp_out is None:
+            module.tmp_out = []
+        module.tmp_out.append(outp.detach())
+
+    @staticmethod
+    def _group_key(name: str) -> str:
+        m = re.match(r"^(.*?blocks\.\d+)\.", name)
+        return m.group(1) if m else name
+
+    def _pending(self):
+        return [(n, m) for n, m in self.model.named_modules() if hasattr(m, 'calibrated') and not m.calibrated]
+
+    def _capture(self, group):
+        """One pass over the calibration set recording inputs/outputs of every module in ``group``."""
+        t0 = time.perf_counter()
+        device = next(self.model.parameters()).device
+        hooks = []
+        last = group[-1][1]
+        for _, module in group:
+            hooks.append(module.register_forward_hook(self.outp_forward_hook))
+            if isinstance(module, (MinMaxQuantLinear, MinMaxQuantConv2d)):
+                hooks.append(module.register_forward_hook(self.single_input_forward_hook))
+            if isinstance(module, MinMaxQuantMatMul):
+                hooks.append(module.register_forward_hook(self.double_input_forward_hook))
+
+        def stop(module, inp, outp):
+            raise _StopForward()
+        hooks.append(last.register_forward_hook(stop))
+        with torch.no_grad():
+            for inp, _ in self.calib_loader:
+                try:
+                    self.model(inp.to(device, non_blocking=True))
+                except _StopForward:
+                    pass
+        for h in hooks:
+            h.remove()
+        for _, module in group:
+            module.raw_out = torch.cat(module.tmp_out, dim=0)
+            if isinstance(module, (MinMaxQuantLinear, MinMaxQuantConv2d)):
+                module.raw_input = torch.cat(module.tmp_input, dim=0)
+            if isinstance(module, MinMaxQuantMatMul):
+                module.raw_input = [torch.cat(t, dim=0) for t in module.tmp_input]
+            module.tmp_input = module.tmp_out = None
+        self.capture_seconds += time.perf_counter() - t0
+
+    def batching_quant_calib(self):
+        pending = self._pending()
+        groups = []
+        for name, module in pending:
+            key = self._group_key(name) if self.capture == "block" else name
+            if groups and groups[-1][0] == key:
+                groups[-1][1].append((name, module))
+            else:
+                groups.append((key, [(name, module)]))
+        for key, group in groups:
+            self._capture(group)
+            for name, module in group:
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    module.hyperparameter_searching()
+                    if hasattr(module, 'prev_layer') and module.prev_layer is not None:
+                        module.reparam()
+                self.timings[name] = time.perf_counter() - t0      # host-side enqueue time; the stream runs behind
+                if self.verbose:
+                    print(f"calibrated {name}")
+        for _, module in self.model.named_modules():
+            if hasattr(module, 'mode'):
+                module.mode = "quant_forward"

@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Benchmark of the AdaLog calibration hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One *step* = one complete calibration (QuantCalibrator.batching_quant_calib: capture + every module's FPCS search) of
+BASELINE.json configs[1]: deit_small, W4A4 (configs/4bit.py), 32 synthetic 224x224 calibration images PER GPU
+(weak scaling: the global calibration set is 32*N images sharded by rank, scores all-reduced over RCCL).
+Inputs (images, random-init weights) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
+  value      = calibration images per second, whole job  (= 32*N*K / wall, wall = max over ranks)
+  roofline   = the dominant kernel (k_gemm_score, int8 MFMA): algorithmic ops of its launches / their summed duration,
+               measured live with events on the launch stream during the timed steps
+  cpu_baseline = the CPU oracle (a port of the reference's algorithm, oracle/) timed on the host cores on a bounded
+               sample of the same workload and scaled to images/s with the work model of BASELINE.md section 2
+"""
+import argparse
+import copy
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TOPS = {0: 5000.0, 1: 2500.0, 2: 157.3}      # dense MFMA peaks, TFLOP/s (MI355X_MICROARCH.md): i8 = 2x bf16
+DT_NAME = {0: "i8", 1: "bf16", 2: "f32"}
+
+
+def load_cfg(bits):
+    spec = importlib.util.spec_from_file_location(f"cfg{bits}", os.path.join(ROOT, "configs", f"{bits}bit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.Config()
+
+
+class GemmProfiler:
+    """Collects the event pairs adalog_amd.ops records around every scoring-GEMM launch (on the launch stream) and the
+    true (un-padded) K of each packed operand, so that ALGORITHMIC flops = 2*M*N*K*C*G are divided by kernel time."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.true_k = {}
+
+    def install(self):
+        ops, prof = self.ops, self
+        orig_pu, orig_pa, orig_pr = ops.pack_uniform, ops.pack_adalog, ops.pack_raw
+
+        def note(out, x3):
+            t = out[0] if isinstance(out, tuple) else out
+            prof.true_k[t.data_ptr()] = x3.shape[-1]
+            return out
+        ops.pack_uniform = lambda x3, *a, **k: note(orig_pu(x3, *a, **k), x3)
+        ops.pack_adalog = lambda x3, *a, **k: note(orig_pa(x3, *a, **k), x3)
+        ops.pack_raw = lambda x3, *a, **k: note(orig_pr(x3, *a, **k), x3)
+
+    def start(self):
+        self.ops.GEMM_EVENTS = []
+
+    def stop(self):
+        ev, self.ops.GEMM_EVENTS = self.ops.GEMM_EVENTS, None
+        torch.cuda.synchronize()
+        by = {}
+        for dt, M, N, Kp, C, G, pa, pb, s, e in ev:
+            K = min(self.true_k.get(pa, Kp), self.true_k.get(pb, Kp))
+            b = by.setdefault(dt, [0.0, 0.0, 0])
+            b[0] += 2.0 * M * N * K * C * G
+            b[1] += s.elapsed_time(e)
+            b[2] += 1
+        return by
+
+
+def cpu_baseline(threads):
+    """Oracle (CPU port) on a bounded sample: one weight-scoring call + one activation-scoring call (128 candidates
+    each) of deit_small attn.proj (32 images x 197 tokens, 384 -> 384, W4A4).  Scaled to images/s with the candidate-GEMM
+    work of the whole model (1354 TFLOP for deit_small at 32 images)."""
+    from oracle import adalog_oracle as O
+    torch.set_num_threads(threads)
+    O.PCHUNK = 16
+    g = torch.Generator().manual_seed(5)
+    N, T, I, Oc, bits = 32, 197, 384, 384, 4
+    x = torch.randn(N, T, I, generator=g)
+    W = torch.randn(Oc, I, generator=g) * 0.05
+    b = torch.zeros(Oc)
+    ro = torch.nn.functional.linear(x, W, b)
+    w3 = W.view(1, Oc, I)
+    scw, zpw = O.weight_candidates(w3, bits)
+    sca, zpa = O.activation_candidates(x, bits, False)
+    xq = O.uniform_fake_quant(x, sca[:, 60], zpa[:, 60].float(), bits)[0]
+    wq = O.uniform_fake_quant(w3, scw[60], zpw[60].float(), bits)[0].view(Oc, I)
+    t0 = time.perf_counter()
+    O.score_w(xq, w3, b, ro, scw, zpw, bits, 32)
+    O.score_a(x, wq, b, ro, sca, zpa, bits, 32)
+    dt = time.perf_counter() - t0
+    flops = 2 * 2.0 * N * T * I * Oc * 128
+    rate = flops / dt                                   # candidate-GEMM flop/s of the CPU path
+    total = 1354e12                                     # deit_small, 32 images
+    return {"value": 32.0 / (total / rate), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"oracle score_w + score_a, 128 candidates each, deit_small attn.proj 32x197x384->384 W4A4: "
+                      f"{dt:.1f} s = {rate / 1e9:.1f} GFLOP/s candidate-GEMM rate; scaled by 1354 TFLOP per 32-image "
+                      f"calibration",
+            "sample_seconds": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="deit_small")
+    ap.add_argument("--bits", type=int, default=4)
+    ap.add_argument("--images-per-gpu", type=int, default=32)
+    ap.add_argument("--depth", type=int, default=None, help="truncate the block count (debug only; invalidates the metric)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from adalog_amd import backend, parallel
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import create_model
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net
+    ops = backend.get()
+
+    cfg = load_cfg(args.bits)
+    cfg.calib_size = args.images_per_gpu * world
+    torch.manual_seed(5)                                           # reference default seed (test_quant.py:77)
+    base = create_model(args.model, depth=args.depth).eval()
+    base = wrap_modules_in_net(base, cfg, reparam=True).to(dev)
+    images = torch.randn(cfg.calib_size, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    lo, hi = rank * args.images_per_gpu, (rank + 1) * args.images_per_gpu
+    local = images[lo:hi].to(dev)
+    loader = [(local[i:i + cfg.calib_batch_size], None) for i in range(0, local.shape[0], cfg.calib_batch_size)]
+
+    prof = GemmProfiler(ops)
+    prof.install()
+
+    def one_step(model):
+        QuantCalibrator(model, loader, capture="block").batching_quant_calib()
+
+    models = [copy.deepcopy(base) for _ in range(args.warmup + args.steps)]
+    for i in range(args.warmup):
+        one_step(models[i])
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    prof.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(models[args.warmup + i])
+    torch.cuda.synchronize()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    by = prof.stop()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([wall], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        value = cfg.calib_size * args.steps / wall
+        dom = max(by, key=lambda d: by[d][1]) if by else 0
+        fl, ms, n = by.get(dom, (0.0, 1.0, 1))
+        achieved = fl / (ms * 1e-3) / 1e12
+        gemm_ms_total = sum(v[1] for v in by.values())
+        result = {
+            "metric": "calib_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i8" if dom == 0 else DT_NAME[dom], "data": "synthetic",
+            "config": {"workload": f"{args.model} W{cfg.w_bit}A{cfg.a_bit} --calibrate, {args.images_per_gpu} calib images "
+                                   f"per GPU ({cfg.calib_size} total), eq_n=128, 3 rounds, FPCS 6 steps",
+                       "calib_wall_s_per_step": wall / args.steps,
+                       "scoring_gemm_ms_per_step": gemm_ms_total / args.steps,
+                       "scoring_gemm_by_dtype": {DT_NAME[d]: {"launches_per_step": v[2] / args.steps,
+                                                              "ms_per_step": v[1] / args.steps,
+                                                              "tflops": v[0] / (v[1] * 1e-3) / 1e12} for d, v in by.items()},
+                       "depth_override": args.depth},
+            "roofline": {"bound": "mfma", "kernel": f"k_gemm_score<{DT_NAME[dom]}>", "achieved": achieved,
+                         "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom], "traffic": None,
+                         "launches": n, "avg_launch_ms": ms / max(n, 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            result["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
