@@ -38,6 +38,7 @@ struct GemmArgs {
     float* partial; int MT, NT, Npad;
     float* out; int64_t ldo, sOc, sOg;
     float sa_mul;                    // constant folded into sa (e.g. 1/(4L-2) for AdaLog numerators)
+    int order;                       // tile order (fastest index first): 0 = nt,mt,g,c  1 = nt,c,mt,g  2 = mt,nt,c,g
 };
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * BKB + ((slot ^ ((row >> 2) & 3)) << 4); }
@@ -70,11 +71,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const unsigned lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    // Tile order = which operand stays hot in the XCD's 4 MiB L2 while its neighbours run:
+    //   1 (activation / matmul searches): the n-tiles of one (candidate, m-tile) share the candidate's A tile, and all
+    //     candidates of one m-tile share the fp32 reference rows and the fixed operand;
+    //   2 (weight searches, columns = (out-channel, candidate)): all m-tiles of one column tile share its packed weights.
     unsigned t = lid;
-    const int nt = t % p.NT; t /= p.NT;
-    const int mt = t % p.MT; t /= p.MT;
-    const int g = t % p.G;
-    const int c = t / p.G;
+    int nt, mt, g, c;
+    if (p.order == 1) { nt = t % p.NT; t /= p.NT; c = t % p.C; t /= p.C; mt = t % p.MT; g = t / p.MT; }
+    else if (p.order == 2) { mt = t % p.MT; t /= p.MT; nt = t % p.NT; t /= p.NT; c = t % p.C; g = t / p.C; }
+    else { nt = t % p.NT; t /= p.NT; mt = t % p.MT; t /= p.MT; g = t % p.G; c = t / p.G; }
     const int gh = g % p.gmod;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -137,8 +142,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: out = acc * (sa*sb[col]) + bias[col]; squared error against ref; column sums
-    const float sa = p.sa[c * p.sa_c + gh * p.sa_g] * p.sa_mul;
+    // ---- epilogue: out = acc * (sa*sb) + bias; squared error against ref; column sums over the tile's rows.
+    // With ref_div > 1 a GEMM column encodes (output channel n = col / ref_div, candidate = col % ref_div): the 128
+    // candidates of one channel sit in one tile and share ONE reference column (weight searches).
     const float* refg = p.ref ? p.ref + (int64_t)g * p.sRg : nullptr;
     float* outg = STORE ? p.out + (int64_t)c * p.sOc + (int64_t)g * p.sOg : nullptr;
 #pragma unroll
@@ -146,9 +152,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
         const int col = n0 + wc * 64 + j * 32 + frow;
         const bool cv = col < p.N;
         const int colc = cv ? col : p.N - 1;
-        const float alpha = sa * p.sb[c * p.sb_c + gh * p.sb_g + colc * p.sb_n];
-        const float beta = p.bias ? p.bias[c * p.bi_c + gh * p.bi_g + colc * p.bi_n] : 0.0f;
-        const int rcol = colc / p.ref_div;
+        const int ci = p.ref_div > 1 ? colc % p.ref_div : c;
+        const int ni = p.ref_div > 1 ? colc / p.ref_div : colc;
+        const float alpha = p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g + ni * p.sb_n];
+        const float beta = p.bias ? p.bias[ci * p.bi_c + gh * p.bi_g + ni * p.bi_n] : 0.0f;
         float csum = 0.0f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
                     o = p.bias ? o + beta : o;
                     if (STORE) outg[(int64_t)row * p.ldo + col] = o;
                     if (refg) {
-                        const float e = refg[(int64_t)row * p.ldr + rcol] - o;
+                        const float e = refg[(int64_t)row * p.ldr + ni] - o;
                         csum += e * e;
                     }
                 }
@@ -174,8 +181,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
         if (tid < 128) {
             const int cwc = tid >> 6, cj = (tid >> 5) & 1, cl = tid & 31;
             const int col = n0 + cwc * 64 + cj * 32 + cl;
-            if (col < p.Npad)
-                p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + col] = red[0][cwc][cj][cl] + red[1][cwc][cj][cl];
+            const float v = red[0][cwc][cj][cl] + red[1][cwc][cj][cl];
+            if (p.ref_div > 1) {
+                if (col < p.N)
+                    p.partial[(((int64_t)(col % p.ref_div) * p.G + g) * p.MT + mt) * p.Npad + col / p.ref_div] = v;
+            } else if (col < p.Npad) {
+                p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + col] = v;
+            }
         }
     }
 }
@@ -227,7 +239,8 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                  int64_t ldr, int64_t sRg, int ref_div, const float* sa, int64_t sa_c, int64_t sa_g,
                                  float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
                                  const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, float* partial,
-                                 int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, void* stream) {
+                                 int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, int order,
+                                 void* stream) {
     ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 2, "gemm_score: dtype must be 0 (i8), 1 (bf16) or 2 (f32)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
@@ -243,9 +256,16 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     p.sa = sa; p.sa_c = sa_c; p.sa_g = sa_g; p.sa_mul = sa_mul;
     p.sb = sb; p.sb_c = sb_c; p.sb_g = sb_g; p.sb_n = sb_n;
     p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;
-    p.MT = cdiv(M, BM); p.NT = cdiv(N, BN); p.Npad = p.NT * BN;
+    p.MT = cdiv(M, BM); p.NT = cdiv(N, BN);
+    p.order = order;
+    // partial layout [C_eff][G][MT][Npad] with C_eff = ref_div, N_eff = N / ref_div when columns carry the candidates
+    const int n_eff = ref_div > 1 ? N / ref_div : N;
+    const int c_eff = ref_div > 1 ? ref_div : C;
+    p.Npad = cdiv(n_eff, BN) * BN;
+    ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
+    ADALOG_ARG_CHECK(ref_div == 1 || (C == 1 && N % ref_div == 0 && !out), "gemm_score: ref_div > 1 needs C == 1, N % ref_div == 0, no out");
     p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
-    if (partial) ADALOG_ARG_CHECK(partial_elems >= (int64_t)C * G * p.MT * p.Npad, "gemm_score: partial buffer too small");
+    if (partial) ADALOG_ARG_CHECK(partial_elems >= (int64_t)c_eff * G * p.MT * p.Npad, "gemm_score: partial buffer too small");
     const int64_t nwg = (int64_t)p.MT * p.NT * G * C;
     ADALOG_ARG_CHECK(nwg < (int64_t)1 << 31, "gemm_score: grid too large");
     hipStream_t st = (hipStream_t)stream;

@@ -32,6 +32,7 @@ struct PackArgs {
     void* out;
     int64_t Kp;
     int32_t* rowsum;      // optional [C][G][R] sum_k (q - z)
+    int c_inner;          // 0: out[c][g][r][Kp]   1: out[g][r][c][Kp] (candidates innermost: GEMM columns = (row, candidate))
 };
 
 template <typename T> struct Out;
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
             }
             vals[e] = cvt<T>(v);
         }
-        T* op = reinterpret_cast<T*>(a.out) + ((c * a.G + g) * a.R + r) * a.Kp + ch * EPT;
+        const int64_t orow = a.c_inner ? (g * a.R + r) * a.C + c : (c * a.G + g) * a.R + r;
+        T* op = reinterpret_cast<T*>(a.out) + orow * a.Kp + ch * EPT;
         *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(vals);
         if (KIND == KIND_UNIFORM && a.rowsum) atomicAdd(a.rowsum + (c * a.G + g) * a.R + r, isum);
     }
@@ -130,7 +132,7 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
 extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
                                    const float* scale, const float* zero_point, int64_t C, int64_t pc, int64_t gmod,
                                    int64_t pg, int64_t pr, int n_bits, int out_dtype, void* out, int64_t Kp,
-                                   int32_t* rowsum, void* stream) {
+                                   int32_t* rowsum, int c_inner, void* stream) {
     ADALOG_ARG_CHECK(x && scale && zero_point && out, "pack_uniform: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_uniform: bad sizes");
     ADALOG_ARG_CHECK(Kp >= K && (Kp * (out_dtype == 0 ? 1 : out_dtype == 1 ? 2 : 4)) % 64 == 0,
@@ -140,7 +142,7 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
     PackArgs a{};
     a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk;
     a.scale = scale; a.zp = zero_point; a.C = C; a.pc = pc; a.gmod = gmod; a.pg = pg; a.pr = pr;
-    a.qmax = (float)((1 << n_bits) - 1); a.levels2 = 1 << n_bits; a.out = out; a.Kp = Kp; a.rowsum = rowsum;
+    a.qmax = (float)((1 << n_bits) - 1); a.levels2 = 1 << n_bits; a.out = out; a.Kp = Kp; a.rowsum = rowsum; a.c_inner = c_inner;
     if (rowsum) {
         hipError_t e = hipMemsetAsync(rowsum, 0, sizeof(int32_t) * C * G * R, st);
         if (e != hipSuccess) { adalog_set_error("pack_uniform/memset", e); return (int)e; }

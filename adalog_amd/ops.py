@@ -102,15 +102,18 @@ def _view3(x3: torch.Tensor):
 
 
 def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr: int, n_bits: int, dtype: int = I8,
-                 want_rowsum: bool = False):
-    """-> packed [C, G, R, Kp] (int8 / bf16 / fp32) [+ int32 rowsum [C, G, R]]."""
+                 want_rowsum: bool = False, c_inner: bool = False):
+    """-> packed [C, G, R, Kp] (int8 / bf16 / fp32), or [1, G, R*C, Kp] with candidates innermost when ``c_inner``
+    [+ int32 rowsum [C, G, R]]."""
     G, R, K, sg, sr, sk = _view3(x3)
     scale, zero_point = _f32c(scale, "scale"), _f32c(zero_point, "zero_point")
     Kp = pad_k(K, dtype)
-    out = torch.empty((C, G, R, Kp), dtype=_TORCH_DT[dtype], device=x3.device)
+    shape = (1, G, R * C, Kp) if c_inner else (C, G, R, Kp)
+    out = torch.empty(shape, dtype=_TORCH_DT[dtype], device=x3.device)
     rowsum = torch.empty((C, G, R), dtype=torch.int32, device=x3.device) if want_rowsum else None
     rc = _lib.load().adalog_pack_uniform(x3.data_ptr(), G, R, K, sg, sr, sk, _ptr(scale), _ptr(zero_point), C, pc, gmod,
-                                        pg, pr, int(n_bits), dtype, out.data_ptr(), Kp, _ptr(rowsum), _stream())
+                                        pg, pr, int(n_bits), dtype, out.data_ptr(), Kp, _ptr(rowsum), int(bool(c_inner)),
+                                        _stream())
     _lib.check(rc, "adalog_pack_uniform")
     return (out, rowsum) if want_rowsum else out
 
@@ -153,20 +156,24 @@ class Strided:
 
 def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
                bias: Optional[Strided], keep_h: bool, keep_n: bool, norm: float, sa_mul: float = 1.0,
-               ref_div: int = 1, a_shared: bool = False, b_shared: bool = False):
+               ref_div: int = 1, order: int = 1):
     """scores = finish(gemm_score(...)).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N, Kp]; ref: [G, M, N/ref_div] fp32.
 
-    Returns fp32 scores of shape [C, (gmod if keep_h), (N if keep_n)] (trailing singleton dims dropped to [C, 1]).
+    With ``ref_div`` = P > 1 (weight searches) B is packed candidates-innermost ([1, G, N*P, Kp]), C must be 1 and the
+    GEMM runs over N*P columns; scores come back as [P, N] all the same.
+    Returns fp32 scores of shape [C, (gmod if keep_h) * (N if keep_n)].
     """
     lib = _lib.load()
     sa, sb = sa.checked(), sb.checked()
     bias = None if bias is None else bias.checked()
     Kp = A.shape[-1]
-    assert B.shape[-1] == Kp and A.shape[-2] == M and B.shape[-2] == N
+    n_cols = N * ref_div                      # GEMM columns
+    c_grid = 1 if ref_div > 1 else C
+    assert B.shape[-1] == Kp and A.shape[-2] == M and B.shape[-2] == n_cols
     assert A.dtype == _TORCH_DT[dtype] and B.dtype == _TORCH_DT[dtype] and A.is_contiguous() and B.is_contiguous()
-    sAc = 0 if A.shape[0] == 1 and C > 1 or a_shared else A.stride(0)
+    sAc = 0 if A.shape[0] == 1 else A.stride(0)
     sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
-    sBc = 0 if B.shape[0] == 1 and C > 1 or b_shared else B.stride(0)
+    sBc = 0 if B.shape[0] == 1 else B.stride(0)
     sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
     ref = _f32c(ref, "ref")
     ldr = ref.shape[-1]
@@ -176,13 +183,13 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, N, Kp, C, G, gmod,
+    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, n_cols, Kp, c_grid, G, gmod,
                                ref.data_ptr(), ldr, sRg, ref_div, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul),
                                sb.t.data_ptr(), sb.c, sb.g, sb.n,
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
                                0 if bias is None else bias.n,
-                               partial.data_ptr(), n_part, None, 0, 0, 0, _stream())
+                               partial.data_ptr(), n_part, None, 0, 0, 0, int(order), _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
         GEMM_EVENTS.append((dtype, M, N, Kp, C, G, A.data_ptr(), B.data_ptr(), ev0, ev1))
@@ -211,7 +218,7 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
                                0 if bias is None else bias.n,
-                               None, 0, out.data_ptr(), N, 0, M * N, _stream())
+                               None, 0, out.data_ptr(), N, 0, M * N, 0, _stream())
     _lib.check(rc, "adalog_gemm_score(out)")
     return out
 

@@ -142,9 +142,10 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
-            wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, oc, 1, 0, 1, self.w_quantizer.n_bits, F32)
+            wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, oc, 1, 0, 1, self.w_quantizer.n_bits, F32,
+                                 c_inner=True)
             out.append(be.gemm_score(F32, xp, wp, M, oc, e - s, 1, 1, ref, Strided(ones), Strided(sc, c=oc, n=1), bias,
-                                     False, True, 1.0 / fmap))
+                                     False, True, 1.0 / fmap, ref_div=e - s, order=2))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def weight_fpcs(self, fpcs_width=16, steps=4):

@@ -189,18 +189,20 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
             bias = None if self.bias is None else Strided(self.bias.data, n=1)
+            # columns = (out channel, candidate): the e-s candidates of a channel share one reference column
             if shift is None:
-                wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1, wq.n_bits, dt)
+                wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1, wq.n_bits, dt,
+                                     c_inner=True)
             else:
                 # post-GELU operand is y*s - shift: the -shift term is a per-(candidate, row) constant
                 #   -shift * s_w[p,o] * sum_i (q_w - z_w)  folded into the bias (cf. reparam_bias, linear.py:999-1006)
                 wp, rowsum = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1,
-                                             wq.n_bits, dt, want_rowsum=True)
+                                             wq.n_bits, dt, want_rowsum=True, c_inner=True)
                 fold = be.shift_fold(rowsum.view(e - s, -1), sc, shift, None if self.bias is None else self.bias.data)
                 bias = Strided(fold, c=self.out_features, n=1)
             out.append(be.gemm_score(dt, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2(), sa,
                                      Strided(sc, c=self.out_features, n=1), bias, False, True,
-                                     1.0 / self._tokens_per_image(), sa_mul=sa_mul))
+                                     1.0 / self._tokens_per_image(), sa_mul=sa_mul, ref_div=e - s, order=2))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _pack_w_fixed(self, dt=I8, want_rowsum=False):

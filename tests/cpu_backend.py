@@ -56,7 +56,7 @@ def _params(t, C, G, R, pc, gmod, pg, pr):
     return t.reshape(-1)[(c * pc + g * pg + r * pr)]            # [C, G, R]
 
 
-def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, want_rowsum=False):
+def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, want_rowsum=False, c_inner=False):
     G, R, K = x3.shape
     s = _params(scale, C, G, R, pc, gmod, pg, pr).unsqueeze(-1)
     z = torch.round(_params(zero_point, C, G, R, pc, gmod, pg, pr)).unsqueeze(-1)
@@ -64,8 +64,11 @@ def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, w
     Kp = pad_k(K, dtype)
     out = torch.zeros((C, G, R, Kp), dtype=_TORCH_DT[dtype])
     out[..., :K] = q.to(_TORCH_DT[dtype])
+    rs = q.sum(-1).to(torch.int32)
+    if c_inner:                                   # [C,G,R,Kp] -> [1,G,R*C,Kp], candidates innermost
+        out = out.permute(1, 2, 0, 3).reshape(1, G, R * C, Kp).contiguous()
     if want_rowsum:
-        return out, q.sum(-1).to(torch.int32)
+        return out, rs
     return out
 
 
@@ -114,16 +117,15 @@ def _gemm(dtype, A, B, C, G):
     return torch.einsum("cgmk,cgnk->cgmn", Ad, Bd)
 
 
-def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1,
-               a_shared=False, b_shared=False):
+def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1, order=1):
+    if ref_div > 1:                               # columns = (n, candidate): un-interleave back to [C, G, N, Kp]
+        B = B.view(G, N, ref_div, -1).permute(2, 0, 1, 3)
     D = _gemm(dtype, A, B, C, G)                                            # [C, G, M, N]
     alpha = (_epi(sa, C, G, gmod, 1) * float(torch.tensor(sa_mul, dtype=torch.float32))) * _epi(sb, C, G, gmod, N)
     out = D * alpha.unsqueeze(2)
     if bias is not None:
         out = out + _epi(bias, C, G, gmod, N).unsqueeze(2)
     r = ref.reshape(G, M, -1).double()
-    if ref_div != 1:
-        r = r[..., torch.arange(N) // ref_div]
     e2 = (r.unsqueeze(0) - out) ** 2                                        # [C, G, M, N]
     e2 = e2.view(C, G // gmod, gmod, M, N)
     dims = [1, 3]

@@ -345,3 +345,41 @@ def test_misc_kernels(ops):
     ws = torch.rand(4, 50, generator=gen); sh = torch.tensor([0.17]); bias = torch.randn(50, generator=gen)
     torch.testing.assert_close(ops.shift_fold(rs.to(DEV), ws.to(DEV), sh.to(DEV), bias.to(DEV)).cpu(),
                                CB.shift_fold(rs, ws, sh, bias), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["i8", "f32"])
+def test_gemm_score_candidates_in_columns(ops, dtype):
+    """Weight-search layout: B packed candidates-innermost (c_inner), ref_div = P, every tile order -> same scores as
+    the candidate-batched layout and as the CPU specification."""
+    gen = g(31)
+    bits, P, O_, I_, M = 4, 128, 40, 100, 300
+    dt_c, dt_o = (CB.I8, ops.I8) if dtype == "i8" else (CB.F32, ops.F32)
+    W = torch.randn(1, O_, I_, generator=gen) * 0.1
+    sc = torch.rand(P, O_, generator=gen) * 0.02 + 0.005
+    zp = torch.randint(4, 12, (P, O_), generator=gen).float()
+    x3 = torch.randn(1, M, I_, generator=gen)
+    xs, xz = torch.tensor([0.2]), torch.tensor([8.0])
+    ref = torch.randn(1, M, O_, generator=gen)
+    bias = torch.randn(O_, generator=gen)
+    if dtype == "i8":
+        xa_c = CB.pack_uniform(x3, xs, xz, 1, 0, 1, 0, 0, bits, dt_c)
+        xa = ops.pack_uniform(x3.to(DEV), xs.to(DEV), xz.to(DEV), 1, 0, 1, 0, 0, bits, dt_o)
+    else:
+        xa_c, xa = CB.pack_raw(x3), ops.pack_raw(x3.to(DEV))
+    wb_c = CB.pack_uniform(W, sc, zp, P, O_, 1, 0, 1, bits, dt_c, c_inner=True)
+    wb = ops.pack_uniform(W.to(DEV), sc.to(DEV), zp.to(DEV), P, O_, 1, 0, 1, bits, dt_o, c_inner=True)
+    assert torch.equal(wb.cpu().float(), wb_c.float())
+    want = CB.gemm_score(dt_c, xa_c, wb_c, M, O_, P, 1, 1, ref, CB.Strided(xs), CB.Strided(sc, c=O_, n=1),
+                         CB.Strided(bias, n=1), False, True, 1.0 / 7, ref_div=P)
+    for order in (0, 1, 2):
+        got = ops.gemm_score(dt_o, xa, wb, M, O_, P, 1, 1, ref.to(DEV), ops.Strided(xs.to(DEV)),
+                             ops.Strided(sc.to(DEV), c=O_, n=1), ops.Strided(bias.to(DEV), n=1), False, True, 1.0 / 7,
+                             ref_div=P, order=order)
+        assert got.shape == (P, O_) and rel_err(got.cpu(), want) <= 2e-6, order
+    # candidate-batched layout gives the same numbers
+    wb2 = ops.pack_uniform(W.to(DEV), sc.to(DEV), zp.to(DEV), P, O_, 1, 0, 1, bits, dt_o)
+    for order in (0, 1, 2):
+        got2 = ops.gemm_score(dt_o, xa, wb2, M, O_, P, 1, 1, ref.to(DEV), ops.Strided(xs.to(DEV)),
+                              ops.Strided(sc.to(DEV), c=O_, n=1), ops.Strided(bias.to(DEV), n=1), False, True, 1.0 / 7,
+                              order=order)
+        assert rel_err(got2.cpu(), want) <= 2e-6
