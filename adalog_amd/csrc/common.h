@@ -46,3 +46,30 @@ __device__ __forceinline__ float adalog_k(float u, float qf) {
     }
     return k;
 }
+
+// ---- fast forms used by the operand-packing kernels (hundreds of millions of elements per scoring call).
+// Both evaluate with a reciprocal multiply first and fall back to the exact IEEE sequence above only when the result
+// lands within 1e-3 of a rounding tie, so they return EXACTLY the same integer as the exact forms (the reciprocal path
+// is accurate to ~3 ulp, i.e. < 1e-4 absolute at the magnitudes that survive the clamp).
+__device__ __forceinline__ float uni_bin_fast(float x, float s, float inv_s, float z, float qmax) {
+    float t = x * inv_s;
+    float k = rintf(t);
+    if (__builtin_expect(fabsf(t - k) > 0.499f && fabsf(t) < 4096.0f, 0)) k = rintf(x / s);
+    return fminf(fmaxf(k + z, 0.0f), qmax);
+}
+
+// xs = x (+ shift); returns k = rne(-log2(clamp(xs/s)) * 37 / q) exactly as adalog_k(clamp(xs / s), q)
+__device__ __forceinline__ float adalog_k_fast(float xs, float s, float inv_s, float qf, float rq37, bool clamp_u) {
+    float u = xs * inv_s;
+    if (clamp_u) u = fminf(fmaxf(u, 1e-15f), 1.0f);
+    float t = -__log2f(u) * rq37;
+    float k = rintf(t);
+    if (__builtin_expect(fabsf(t - k) > 0.499f || !(t < 3.0e38f), 0)) {
+        float ue = xs / s;
+        if (clamp_u) ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
+        float le = (float)log2((double)ue);
+        t = (-le) * 37.0f / qf;
+        k = rintf(t);
+    }
+    return k;
+}

@@ -38,6 +38,7 @@ struct GemmArgs {
     float* partial; int MT, NT, Npad;
     float* out; int64_t ldo, sOc, sOg;
     float sa_mul;                    // constant folded into sa (e.g. 1/(4L-2) for AdaLog numerators)
+    int reduce_cols;                 // 1: one partial per tile (sum over its columns) instead of one per column
     int order;                       // tile order (fastest index first): 0 = nt,mt,g,c  1 = nt,c,mt,g  2 = mt,nt,c,g
 };
 
@@ -64,6 +65,7 @@ template <int DT, bool STORE>
 __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[2 * (BM + BN) * BKB];
     __shared__ float red[2][2][2][32];
+    __shared__ float colv[128];
     uint8_t* As = lds;
     uint8_t* Bs = lds + 2 * BM * BKB;
 
@@ -178,10 +180,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
     }
     if (p.partial) {
         __syncthreads();
+        float v = 0.0f;
+        int col = 0;
         if (tid < 128) {
             const int cwc = tid >> 6, cj = (tid >> 5) & 1, cl = tid & 31;
-            const int col = n0 + cwc * 64 + cj * 32 + cl;
-            const float v = red[0][cwc][cj][cl] + red[1][cwc][cj][cl];
+            col = n0 + cwc * 64 + cj * 32 + cl;
+            v = red[0][cwc][cj][cl] + red[1][cwc][cj][cl];
+        }
+        if (p.reduce_cols) {                       // fixed-order tile total: LDS, then one wave's xor tree
+            if (tid < 128) colv[tid] = v;
+            __syncthreads();
+            if (tid < 64) {
+                float t2 = colv[tid] + colv[tid + 64];
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) t2 += __shfl_xor(t2, sft);
+                if (tid == 0) p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + nt] = t2;
+            }
+        } else if (tid < 128) {
             if (p.ref_div > 1) {
                 if (col < p.N)
                     p.partial[(((int64_t)(col % p.ref_div) * p.G + g) * p.MT + mt) * p.Npad + col / p.ref_div] = v;
@@ -202,19 +217,23 @@ struct FinishArgs {
     double norm;
 };
 
+// One wavefront per output (4 per block): lanes take a fixed strided subset, then a fixed xor-shuffle tree in fp64.
 __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
-    __shared__ double sm[256];
     const int nh = p.keep_h ? p.gmod : 1, nn = p.keep_n ? p.N : 1;
-    int o = blockIdx.x;
-    const int n = o % nn; o /= nn;
-    const int h = o % nh;
-    const int c = o / nh;
+    const int64_t nout = (int64_t)p.C * nh * nn;
+    const int64_t oid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (oid >= nout) return;
+    int64_t o = oid;
+    const int n = (int)(o % nn); o /= nn;
+    const int h = (int)(o % nh);
+    const int c = (int)(o / nh);
     const int n_lo = p.keep_n ? n : 0, n_cnt = p.keep_n ? 1 : p.N;
     const int imgs = p.G / p.gmod;
     const int h_lo = p.keep_h ? h : 0, h_cnt = p.keep_h ? 1 : p.gmod;
     const int64_t total = (int64_t)imgs * h_cnt * p.MT * n_cnt;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < total; i += 256) {
+    for (int64_t i = lane; i < total; i += 64) {
         int64_t t = i;
         const int nn_i = (int)(t % n_cnt); t /= n_cnt;
         const int mt = (int)(t % p.MT); t /= p.MT;
@@ -223,13 +242,9 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
         const int g = img * p.gmod + h_lo + hh;
         acc += (double)p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + n_lo + nn_i];
     }
-    sm[threadIdx.x] = acc;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) p.scores[blockIdx.x] = (float)(-p.norm * sm[0]);
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+    if (lane == 0) p.scores[oid] = (float)(-p.norm * acc);
 }
 
 }  // namespace
@@ -240,7 +255,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                  float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
                                  const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, float* partial,
                                  int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, int order,
-                                 void* stream) {
+                                 int reduce_cols, void* stream) {
     ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 2, "gemm_score: dtype must be 0 (i8), 1 (bf16) or 2 (f32)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
@@ -258,10 +273,12 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;
     p.MT = cdiv(M, BM); p.NT = cdiv(N, BN);
     p.order = order;
+    p.reduce_cols = reduce_cols;
+    ADALOG_ARG_CHECK(!(reduce_cols && ref_div > 1), "gemm_score: reduce_cols and ref_div > 1 are exclusive");
     // partial layout [C_eff][G][MT][Npad] with C_eff = ref_div, N_eff = N / ref_div when columns carry the candidates
     const int n_eff = ref_div > 1 ? N / ref_div : N;
     const int c_eff = ref_div > 1 ? ref_div : C;
-    p.Npad = cdiv(n_eff, BN) * BN;
+    p.Npad = reduce_cols ? p.NT : cdiv(n_eff, BN) * BN;
     ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
     ADALOG_ARG_CHECK(ref_div == 1 || (C == 1 && N % ref_div == 0 && !out), "gemm_score: ref_div > 1 needs C == 1, N % ref_div == 0, no out");
     p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
@@ -281,19 +298,21 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     return 0;
 }
 
-extern "C" int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G) {
-    return (int64_t)C * G * cdiv(M, BM) * (cdiv(N, BN) * BN);
+extern "C" int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G, int reduce_cols) {
+    return (int64_t)C * G * cdiv(M, BM) * (reduce_cols ? cdiv(N, BN) : cdiv(N, BN) * BN);
 }
 
 extern "C" int adalog_finish_scores(const float* partial, float* scores, int M, int N, int C, int G, int gmod,
-                                    int keep_h, int keep_n, double norm, void* stream) {
+                                    int keep_h, int keep_n, int reduced_cols, double norm, void* stream) {
     ADALOG_ARG_CHECK(partial && scores && M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0,
                      "finish_scores: bad arguments");
     FinishArgs p{};
-    p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = cdiv(M, BM); p.N = N;
-    p.Npad = cdiv(N, BN) * BN; p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm;
+    ADALOG_ARG_CHECK(!(reduced_cols && keep_n), "finish_scores: per-tile partials cannot keep the column axis");
+    p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = cdiv(M, BM);
+    p.N = reduced_cols ? cdiv(N, BN) : N;
+    p.Npad = reduced_cols ? cdiv(N, BN) : cdiv(N, BN) * BN; p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm;
     const int64_t nout = (int64_t)C * (keep_h ? gmod : 1) * (keep_n ? N : 1);
-    hipLaunchKernelGGL(k_finish, dim3((unsigned)nout), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(k_finish, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     ADALOG_LAUNCH_CHECK("adalog_finish_scores");
     return 0;
 }

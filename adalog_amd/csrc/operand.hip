@@ -110,9 +110,98 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
     }
 }
 
+// K-contiguous sources (activations, weights, q@k^T operands): one thread owns 4 consecutive k of one row and loops over
+// ALL candidates, so the fp32 source is read once (coalesced float4) instead of once per candidate, and every store
+// instruction of a wave writes one contiguous 256 B / 512 B / 1 KiB run.
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
+    const int64_t nq = a.Kp >> 2;
+    const int64_t total = a.G * a.R * nq;
+    __shared__ float s_mant[ADALOG_R];
+    if (KIND == KIND_ADALOG) {
+        if (threadIdx.x < ADALOG_R) s_mant[threadIdx.x] = a.mant[threadIdx.x];
+        __syncthreads();
+    }
+    const float sh = (KIND == KIND_ADALOG && a.shift) ? a.shift[0] : 0.0f;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t kq = idx % nq;
+        const int64_t t0 = idx / nq;
+        const int64_t r = t0 % a.R, g = t0 / a.R;
+        const int64_t k0 = kq << 2;
+        const float* xp = a.x + g * a.sxg + r * a.sxr + k0;
+        float xv[4];
+        if (k0 + 3 < a.K && ((uintptr_t)xp & 15) == 0) {
+            const float4 v = *reinterpret_cast<const float4*>(xp);
+            xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] = (k0 + e < a.K) ? xp[e] : 0.0f;
+        }
+        if (KIND == KIND_ADALOG && a.shift) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xv[e] += sh;
+        }
+        const int64_t pbase = (g % a.gmod) * a.pg + r * a.pr;
+        for (int64_t c = blockIdx.y; c < a.C; c += gridDim.y) {
+            alignas(16) T vals[4];
+            int isum = 0;
+            if (KIND == KIND_RAW) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vals[e] = cvt<T>(xv[e]);
+            } else if (KIND == KIND_UNIFORM) {
+                const float s = a.scale[c * a.pc + pbase], z = rintf(a.zp[c * a.pc + pbase]);
+                const float inv_s = 1.0f / s;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.0f;
+                    if (k0 + e < a.K) v = uni_bin_fast(xv[e], s, inv_s, z, a.qmax) - z;
+                    isum += (int)v;
+                    vals[e] = cvt<T>(v);
+                }
+            } else {
+                const float s = a.scale[c * a.pc + pbase];
+                const float qf = a.qv[c * a.pc + (g % a.gmod) * a.pg];
+                const float inv_s = 1.0f / s, rq37 = 37.0f / qf;
+                const int qi = (int)qf;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = 0.0f;
+                    if (k0 + e < a.K) {
+                        float kk = adalog_k_fast(xv[e], s, inv_s, qf, rq37, a.clamp_u != 0);
+                        if (kk < (float)a.levels2 && kk == kk) {
+                            kk = fmaxf(kk, 0.0f);
+                            const int kqv = (int)kk * qi;
+                            const int t = kqv / ADALOG_R, j = kqv - t * ADALOG_R;
+                            v = (t > 100) ? 0.0f : ldexpf(s_mant[j], -t);
+                        }
+                    }
+                    vals[e] = cvt<T>(v);
+                }
+            }
+            const int64_t orow = a.c_inner ? (g * a.R + r) * a.C + c : (c * a.G + g) * a.R + r;
+            T* op = reinterpret_cast<T*>(a.out) + orow * a.Kp + k0;
+            if (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(op) = *reinterpret_cast<const uint32_t*>(vals);
+            else if (sizeof(T) == 2) *reinterpret_cast<uint2*>(op) = *reinterpret_cast<const uint2*>(vals);
+            else *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(vals);
+            if (KIND == KIND_UNIFORM && a.rowsum && isum != 0) atomicAdd(a.rowsum + (c * a.G + g) * a.R + r, isum);
+        }
+    }
+}
+
 template <typename T, int KIND>
 int launch_pack(const PackArgs& a, hipStream_t st) {
     constexpr int EPT = Out<T>::EPT;
+    if (a.sxk == 1) {
+        const int64_t total = a.G * a.R * (a.Kp >> 2);
+        int64_t gx = (total + 255) / 256;
+        if (gx > 16384) gx = 16384;
+        if (gx < 1) gx = 1;
+        // enough candidate groups to fill the chip when the source is small (weights), all candidates per thread otherwise
+        int64_t gy = 1;
+        while (gx * gy < 2048 && gy < a.C) gy *= 2;
+        hipLaunchKernelGGL((k_pack_kfast<T, KIND>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, a);
+        return 0;
+    }
     const int64_t per_c = a.G * a.R * (a.Kp / EPT);
     int64_t gx = (per_c + 255) / 256;
     if (gx > 4096) gx = 4096;

@@ -178,7 +178,8 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     ref = _f32c(ref, "ref")
     ldr = ref.shape[-1]
     sRg = 0 if G == 1 else M * ldr
-    n_part = lib.adalog_gemm_score_partial_elems(M, N, C, G)
+    reduce_cols = 0 if (keep_n or ref_div > 1) else 1
+    n_part = lib.adalog_gemm_score_partial_elems(M, N, C, G, reduce_cols)
     partial = torch.empty(n_part, dtype=torch.float32, device=A.device)
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -189,7 +190,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
                                0 if bias is None else bias.n,
-                               partial.data_ptr(), n_part, None, 0, 0, 0, int(order), _stream())
+                               partial.data_ptr(), n_part, None, 0, 0, 0, int(order), reduce_cols, _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
         GEMM_EVENTS.append((dtype, M, N, Kp, C, G, A.data_ptr(), B.data_ptr(), ev0, ev1))
@@ -197,7 +198,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     cols = (gmod if keep_h else 1) * (N if keep_n else 1)
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
     rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), M, N, C, G, gmod, int(keep_h), int(keep_n),
-                                  float(norm), _stream())
+                                  reduce_cols, float(norm), _stream())
     _lib.check(rc, "adalog_finish_scores")
     return scores
 
@@ -218,7 +219,7 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
                                0 if bias is None else bias.n,
-                               None, 0, out.data_ptr(), N, 0, M * N, 0, _stream())
+                               None, 0, out.data_ptr(), N, 0, M * N, 0, 0, _stream())
     _lib.check(rc, "adalog_gemm_score(out)")
     return out
 

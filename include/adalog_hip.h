@@ -81,6 +81,8 @@ int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t
  * ref_div > 1 (weight searches; needs C = 1): GEMM column j encodes (output channel n = j / ref_div, candidate
  *   c = j % ref_div) -- B packed with c_inner = 1 -- so the 128 candidates of a channel share one reference column;
  *   sa/sb/bias are then addressed with (c, n) and partial is laid out [ref_div][G][m_tile][N/ref_div padded].
+ * reduce_cols = 1: the tile's column sums are added up in-kernel (fixed order) and partial holds one value per tile,
+ *   [C][G][m_tile][n_tile] -- for searches whose score does not keep the column axis.
  * order: workgroup -> tile order, fastest index first (L2 reuse): 0 = n,m,g,c   1 = n,c,m,g   2 = m,n,c,g.
  * dtype: 0 = int8 (exact integer dot products), 1 = bf16, 2 = fp32.  bias may be NULL.  partial and ref go together.
  * partial must hold adalog_gemm_score_partial_elems(M, N, C, G) floats. */
@@ -89,8 +91,8 @@ int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int6
                       const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
                       int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n,
                       float* partial, int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, int order,
-                      void* stream);
-int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G);
+                      int reduce_cols, void* stream);
+int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G, int reduce_cols);
 
 /* scores[c][h?][n?] = -norm * sum_{image = g/gmod, (h), m_tile, (n)} partial[c][g][m_tile][n], accumulated in fp64 in a
  * fixed order (deterministic).  keep_h / keep_n select which axes survive:
@@ -99,7 +101,7 @@ int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G);
  *   MatMul per head       keep_h=1 -> [P][H]   (matmul.py:154-164, norm = 1/(S*S'))
  *   post-softmax base     none     -> [P]      (matmul.py:345-352, norm = 1/(H*S*S')) */
 int adalog_finish_scores(const float* partial, float* scores, int M, int N, int C, int G, int gmod, int keep_h, int keep_n,
-                         double norm, void* stream);
+                         int reduced_cols, double norm, void* stream);
 
 /* ---- K16  FPCS driver pieces                 reference linear.py:483-523, matmul.py:243-262, conv.py:292-311
  * adalog_topk: idx[j][col] = candidate with the j-th best score of column col, j < k; order (score desc, index asc),
