@@ -368,3 +368,62 @@ def absminmax(x2, per_channel: bool):
                                           _stream())
     _lib.check(rc, "adalog_absminmax_cols")
     return mn, mx
+
+
+# ------------------------------------------------------------------------------------------------ BRECQ (K17)
+def uniform_fake_quant_backward(gy, x, scale, zero_point, n_bits: int, sym: bool, want_gscale: bool, want_gzp: bool):
+    """-> (gx, gscale | None, gzp | None) of the straight-through training form."""
+    gy, x, scale = _f32c(gy, "gy"), _f32c(x, "x"), _f32c(scale, "scale")
+    zp = None if sym else _f32c(zero_point, "zero_point")
+    n_ch, inner = broadcast_layout(x.shape, scale.shape)
+    if inner == 1 and n_ch > 1:
+        raise NotImplementedError("training gradients for per-last-dim-channel activations are not needed by BRECQ "
+                                  "(channel-wise layers are re-parameterised to per-tensor before block reconstruction)")
+    lib = _lib.load()
+    gx = torch.empty_like(x)
+    gs = torch.empty_like(scale) if want_gscale else None
+    gz = torch.empty_like(zp) if (want_gzp and zp is not None) else None
+    ws = None
+    if gs is not None or gz is not None:
+        nb = lib.adalog_uniform_fq_backward_blocks(x.numel(), n_ch, inner)
+        ws = torch.empty(2 * (x.numel() // inner) * nb, dtype=torch.float32, device=x.device)
+    rc = lib.adalog_uniform_fq_backward(gy.data_ptr(), x.data_ptr(), gx.data_ptr(), x.numel(), scale.data_ptr(), _ptr(zp),
+                                        n_ch, inner, int(n_bits), int(bool(sym)), _ptr(gs), _ptr(gz), _ptr(ws), _stream())
+    _lib.check(rc, "adalog_uniform_fq_backward")
+    return gx, gs, gz
+
+
+def log_fake_quant_backward(gy, x, y, scale, q, n_bits: int, shift, sub_shift: bool):
+    gy, x, y, scale = _f32c(gy, "gy"), _f32c(x, "x"), _f32c(y, "y"), _f32c(scale, "scale")
+    gx = torch.empty_like(x)
+    gs = torch.empty_like(scale)
+    ws = torch.empty(1024, dtype=torch.float32, device=x.device)
+    rc = _lib.load().adalog_log_fq_backward(gy.data_ptr(), x.data_ptr(), y.data_ptr(), gx.data_ptr(), x.numel(),
+                                           scale.data_ptr(), q.data_ptr(), int(n_bits),
+                                           _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(sub_shift)),
+                                           gs.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "adalog_log_fq_backward")
+    return gx, gs
+
+
+def adaround(w2, alpha2, scale, zero_point, n_bits: int, soft: bool, gy=None):
+    """Forward value (gy is None) or d/d alpha (gy given) of the AdaRound weight quantiser; w2/alpha2: [rows, inner]."""
+    w2, alpha2 = _f32c(w2, "w"), _f32c(alpha2, "alpha")
+    rows, inner = w2.shape
+    out = torch.empty_like(w2)
+    rc = _lib.load().adalog_adaround(w2.data_ptr(), alpha2.data_ptr(), _ptr(None if gy is None else _f32c(gy, "gy")),
+                                    out.data_ptr(), rows, inner, _f32c(scale, "scale").data_ptr(),
+                                    _f32c(zero_point, "zero_point").data_ptr(), int(n_bits), int(bool(soft)),
+                                    int(gy is not None), _stream())
+    _lib.check(rc, "adalog_adaround")
+    return out
+
+
+def round_loss(alpha, b: float, galpha=None, gscale: float = 1.0, want_loss: bool = True):
+    alpha = _f32c(alpha, "alpha")
+    loss = torch.empty(1, dtype=torch.float32, device=alpha.device) if want_loss else None
+    ws = torch.empty(1024, dtype=torch.float32, device=alpha.device)
+    rc = _lib.load().adalog_round_loss(alpha.data_ptr(), alpha.numel(), float(b), _ptr(loss), _ptr(galpha), float(gscale),
+                                      ws.data_ptr(), _stream())
+    _lib.check(rc, "adalog_round_loss")
+    return loss

@@ -1,0 +1,111 @@
+"""AdaRoundQuantizer -- API of reference quantizers/adaround.py:7-76 (learned hard-sigmoid rounding, arXiv 2004.10568),
+used by BRECQ block reconstruction.  Forward, d/d alpha and the rounding regulariser run as HIP kernels
+(csrc/brecq.hip); alpha is the only trained tensor (block_recon.py:97-108 optimises alpha and activation scales).
+"""
+import torch
+from torch import nn
+
+from .. import backend
+from .uniform import UniformQuantizer
+
+
+class _AdaRoundFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w2, alpha2, scale, zero_point, n_bits, soft):
+        ctx.save_for_backward(w2, alpha2, scale, zero_point)
+        ctx.n_bits, ctx.soft = n_bits, soft
+        return backend.get().adaround(w2, alpha2, scale, zero_point, n_bits, soft)
+
+    @staticmethod
+    def backward(ctx, gy):
+        w2, alpha2, scale, zero_point = ctx.saved_tensors
+        ga = backend.get().adaround(w2, alpha2, scale, zero_point, ctx.n_bits, ctx.soft, gy=gy.contiguous())
+        return None, ga, None, None, None, None
+
+
+class _RoundLossFn(torch.autograd.Function):
+    """sum(1 - |2h(alpha)-1|^b), block_recon.py:209-210; value and gradient in one fused kernel each."""
+
+    @staticmethod
+    def forward(ctx, alpha, b):
+        ctx.save_for_backward(alpha)
+        ctx.b = b
+        return backend.get().round_loss(alpha, b).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (alpha,) = ctx.saved_tensors
+        ga = torch.zeros_like(alpha)
+        backend.get().round_loss(alpha, ctx.b, galpha=ga, gscale=1.0, want_loss=False)
+        return ga * g, None
+
+
+class AdaRoundQuantizer(nn.Module):
+    def __init__(self, uq: UniformQuantizer, weight_tensor: torch.Tensor, round_mode='learned_hard_sigmoid'):
+        super().__init__()
+        self.n_bits = uq.n_bits
+        self.n_levels = uq.n_levels
+        self.channel_wise = uq.channel_wise
+        self.sym = uq.sym
+        self.scale = nn.Parameter(uq.scale)
+        self.zero_point = nn.Parameter(uq.zero_point)
+        self.round_mode = round_mode
+        self.alpha = None
+        self.soft_targets = False
+        self.inited = True
+        self.training_mode = False
+        # params for sigmoid function
+        self.gamma, self.zeta = -0.1, 1.1
+        self.beta = 2 / 3
+        self.init_alpha(x=weight_tensor.clone())
+
+    def init_training(self):
+        self.training_mode = True
+
+    def end_training(self):
+        self.training_mode = False
+
+    def _rows(self, x):
+        """View x as [rows, inner] matching the per-row scale ([n_V, rows, 1] or [oc, 1])."""
+        rows = self.scale.numel()
+        return x.reshape(rows, -1)
+
+    def forward(self, x):
+        if self.sym:
+            raise NotImplementedError("symmetric AdaRound is not used by the shipped configs")
+        if self.round_mode in ('nearest', 'nearest_ste'):
+            # after reconstruct_model(): weights already hold the hard values; plain round-to-nearest (adaround.py:39-42)
+            y = backend.get().uniform_fake_quant(x, self.scale.data, self.zero_point.data, self.n_bits, sym=False)
+            return y
+        if self.round_mode != 'learned_hard_sigmoid':
+            raise ValueError('Wrong rounding mode')
+        shp = x.shape
+        y = _AdaRoundFn.apply(self._rows(x), self._rows(self.alpha), self.scale.view(-1), self.zero_point.view(-1),
+                              self.n_bits, bool(self.soft_targets))
+        return y.view(shp)
+
+    def get_soft_targets(self):
+        return torch.clamp(torch.sigmoid(self.alpha) * (self.zeta - self.gamma) + self.gamma, 0, 1)
+
+    def round_loss(self, b: float):
+        """sum(1 - |2h-1|^b) over this quantiser's weights (block_recon.py:209-210), fused."""
+        return _RoundLossFn.apply(self.alpha, float(b))
+
+    def init_alpha(self, x: torch.Tensor):
+        """adaround.py:62-69: alpha such that h(alpha) equals the fractional part of w/s."""
+        x_floor = torch.floor(x / self.scale)
+        if self.round_mode == 'learned_hard_sigmoid':
+            rest = (x / self.scale) - x_floor
+            alpha = -torch.log((self.zeta - self.gamma) / (rest - self.gamma) - 1)
+            self.alpha = nn.Parameter(alpha)
+        else:
+            raise NotImplementedError
+
+    def get_hard_value(self, x):
+        init_shape = x.shape
+        return ((torch.floor(x.reshape_as(self.alpha) / self.scale) + (self.alpha >= 0).float()) * self.scale).reshape(
+            *init_shape)
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}(n_bits={self.n_bits}, sym={self.sym}, channel_wise={self.channel_wise}, '
+                f'round_mode={self.round_mode})')

@@ -157,6 +157,32 @@ int adalog_shift_fold(const int32_t* rowsum, const float* w_scale, const float* 
 int adalog_minmax_rows(const float* w, int rows, int I, int use_abs, float* mn, float* mx, void* stream);
 int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, float* mn, float* mx, void* stream);
 
+/* ---- K17  BRECQ / AdaRound block reconstruction: fused straight-through backward passes and AdaRound kernels
+ * adalog_uniform_fq_backward: gradients of the training form y = (clamp(round_ste(x/s) + round_ste(zp), 0, 2L-1) - round_ste(zp)) * s
+ *   (reference quantizers/uniform.py:29-35 + _ste.py:5-6):  gx = gy*[inside];  gscale[ch] = sum gy*((q - z) - [inside]*x/s);
+ *   gzp[ch] = sum gy*([inside] ? 0 : -s).  Broadcast layout as adalog_uniform_fake_quant_f32 with inner >= 1 rows
+ *   (per-tensor / per-row / per-head).  gx, gscale, gzp are each optional.  workspace: 2*(n/inner)*blocks floats with
+ *   blocks = adalog_uniform_fq_backward_blocks(n, n_channels, inner).
+ * adalog_log_fq_backward: gradients of AdaLog's training form (reference quantizers/logarithm.py:88-92,133-135):
+ *   gx = gy * y'/(u*s) inside both clamps, gscale = sum gy*(y'/s - dy/dx * (x+shift)/s), y' = y before the shift
+ *   subtraction.  workspace: 1024 floats.
+ * adalog_adaround: forward (backward = 0): out = (clamp(floor(w/s) + h + zp, 0, 2L-1) - zp) * s with
+ *   h = clamp(sigmoid(alpha)*1.2 - 0.1, 0, 1) (soft) or [alpha >= 0] (hard)   (reference quantizers/adaround.py:43-60);
+ *   backward = 1: out = d loss / d alpha = gy * s * h'(alpha) * [inside clamp].  w/alpha: [rows][inner], scale/zp: [rows].
+ * adalog_round_loss: loss[0] = sum (1 - |2h(alpha)-1|^b)  and, if galpha, galpha += gscale * d/d alpha
+ *   (reference utils/block_recon.py:205-210).  workspace: 1024 floats. */
+int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, int64_t inner);
+int adalog_uniform_fq_backward(const float* gy, const float* x, float* gx, int64_t n, const float* scale,
+                               const float* zero_point, int64_t n_channels, int64_t inner, int n_bits, int symmetric,
+                               float* gscale, float* gzp, float* workspace, void* stream);
+int adalog_log_fq_backward(const float* gy, const float* x, const float* y, float* gx, int64_t n, const float* scale,
+                           const int64_t* q, int n_bits, const float* shift, int sub_shift, float* gscale, float* workspace,
+                           void* stream);
+int adalog_adaround(const float* w, const float* alpha, const float* gy, float* out, int64_t rows, int64_t inner,
+                    const float* scale, const float* zero_point, int n_bits, int soft, int backward, void* stream);
+int adalog_round_loss(const float* alpha, int64_t n, float b, float* loss, float* galpha, float gscale, float* workspace,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,3 +223,62 @@ def absminmax(x2, per_channel):
     if per_channel:
         return a.amin(0), a.amax(0)
     return a.min().view(1), a.max().view(1)
+
+
+# ------------------------------------------------------------------------------------------------ BRECQ specs (autograd of the
+# reference's own formulas: uniform.py:29-35 / logarithm.py:88-92 with round_ste, adaround.py:43-60, block_recon.py:209)
+def _ste(x):
+    return (x.round() - x).detach() + x
+
+
+@torch.enable_grad()
+def uniform_fake_quant_backward(gy, x, scale, zero_point, n_bits, sym, want_gscale, want_gzp):
+    L = 2 ** (n_bits - 1)
+    x = x.detach().clone().requires_grad_(True)
+    s = scale.detach().clone().requires_grad_(True)
+    if sym:
+        y = _ste(x / s).clamp(-L, L - 1) * s
+        gx, gs = torch.autograd.grad(y, (x, s), gy)
+        return gx, (gs if want_gscale else None), None
+    z = zero_point.detach().clone().requires_grad_(True)
+    y = ((_ste(x / s) + _ste(z)).clamp(0, 2 * L - 1) - _ste(z)) * s
+    gx, gs, gz = torch.autograd.grad(y, (x, s, z), gy)
+    return gx, (gs if want_gscale else None), (gz if want_gzp else None)
+
+
+@torch.enable_grad()
+def log_fake_quant_backward(gy, x, y, scale, q, n_bits, shift, sub_shift):
+    L = 2 ** (n_bits - 1)
+    x = x.detach().clone().requires_grad_(True)
+    s = scale.detach().clone().requires_grad_(True)
+    xs = x if shift is None else x + shift.detach()
+    u = (xs / s).clamp(min=1e-15, max=1.0)
+    k = _ste(-u.log2() * 37.0 / q)
+    mask = k < 2 * L
+    k = torch.clamp(k, 0, 2 * L - 1)
+    out = 2 ** (-1 * k * q / 37.0) * s * mask
+    if sub_shift:
+        out = out - shift.detach()
+    gx, gs = torch.autograd.grad(out, (x, s), gy)
+    return gx, gs
+
+
+@torch.enable_grad()
+def adaround(w2, alpha2, scale, zero_point, n_bits, soft, gy=None):
+    s, z = scale.view(-1, 1), zero_point.view(-1, 1)
+    a = alpha2.detach().clone().requires_grad_(True)
+    h = torch.clamp(torch.sigmoid(a) * 1.2 - 0.1, 0, 1) if soft else (a >= 0).float()
+    y = (torch.clamp(torch.floor(w2 / s) + h + z, 0, 2 ** n_bits - 1) - z) * s
+    if gy is None:
+        return y.detach()
+    return torch.autograd.grad(y, a, gy)[0] if soft else torch.zeros_like(a)
+
+
+@torch.enable_grad()
+def round_loss(alpha, b, galpha=None, gscale=1.0, want_loss=True):
+    a = alpha.detach().clone().requires_grad_(True)
+    h = torch.clamp(torch.sigmoid(a) * 1.2 - 0.1, 0, 1)
+    loss = (1 - ((h - .5).abs() * 2).pow(b)).sum()
+    if galpha is not None:
+        galpha += gscale * torch.autograd.grad(loss, a)[0]
+    return loss.detach().view(1) if want_loss else None

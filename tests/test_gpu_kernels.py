@@ -383,3 +383,67 @@ def test_gemm_score_candidates_in_columns(ops, dtype):
                               ops.Strided(sc.to(DEV), c=O_, n=1), ops.Strided(bias.to(DEV), n=1), False, True, 1.0 / 7,
                               order=order)
         assert rel_err(got2.cpu(), want) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------------ K17 (BRECQ)
+@pytest.mark.parametrize("layout", ["tensor", "heads", "rows"])
+def test_uniform_backward(ops, layout):
+    gen = g(41)
+    bits = 4
+    if layout == "tensor":
+        x = torch.randn(6, 50, 96, generator=gen) * 2; s = torch.tensor([0.21]); z = torch.tensor([7.0])
+    elif layout == "heads":
+        x = torch.randn(4, 6, 20, 16, generator=gen); s = torch.rand(1, 6, 1, 1, generator=gen) * 0.3 + 0.1
+        z = torch.randint(4, 12, (1, 6, 1, 1), generator=gen).float()
+    else:
+        x = torch.randn(3, 16, 64, generator=gen) * 0.2; s = torch.rand(3, 16, 1, generator=gen) * 0.03 + 0.01
+        z = torch.randint(4, 12, (3, 16, 1), generator=gen).float()
+    gy = torch.randn(x.shape, generator=gen)
+    want = CB.uniform_fake_quant_backward(gy, x, s, z, bits, False, True, True)
+    got = ops.uniform_fake_quant_backward(gy.to(DEV), x.to(DEV), s.to(DEV), z.to(DEV), bits, False, True, True)
+    assert torch.equal(got[0].cpu(), want[0])
+    torch.testing.assert_close(got[1].cpu(), want[1], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got[2].cpu(), want[2], rtol=1e-4, atol=1e-5)
+    want = CB.uniform_fake_quant_backward(gy, x, s.abs() * 3, None, bits, True, True, False)
+    got = ops.uniform_fake_quant_backward(gy.to(DEV), x.to(DEV), (s.abs() * 3).to(DEV), None, bits, True, True, False)
+    assert torch.equal(got[0].cpu(), want[0])
+    torch.testing.assert_close(got[1].cpu(), want[1], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("q", [23, 37, 90])
+def test_adalog_backward(ops, q):
+    gen = g(42 + q)
+    bits = 4
+    x = torch.nn.functional.gelu(2 * torch.randn(8, 50, 64, generator=gen))
+    s = torch.tensor([x.max().item() * 0.8]); sh = torch.tensor([O.GELU_SHIFT]); qd = torch.tensor([q])
+    gy = torch.randn(x.shape, generator=gen)
+    for sub in (True, False):
+        y = ops.log_fake_quant(x.to(DEV), s.to(DEV), qd.to(DEV), None, None, bits, shift=sh.to(DEV), sub_shift=sub,
+                               train_form=True)
+        want = CB.log_fake_quant_backward(gy, x, y.cpu(), s, qd, bits, sh, sub)
+        got = ops.log_fake_quant_backward(gy.to(DEV), x.to(DEV), y, s.to(DEV), qd.to(DEV), bits, sh.to(DEV), sub)
+        torch.testing.assert_close(got[0].cpu(), want[0], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(got[1].cpu(), want[1], rtol=1e-3, atol=1e-3)
+
+
+def test_adaround_and_round_loss(ops):
+    gen = g(43)
+    bits = 4
+    w = torch.randn(48, 96, generator=gen) * 0.2
+    s = (w.amax(1) - w.amin(1)) / 15; z = torch.round(-w.amin(1) / s)
+    alpha = torch.randn(48, 96, generator=gen) * 2
+    gy = torch.randn(48, 96, generator=gen)
+    for soft in (True, False):
+        want = CB.adaround(w, alpha, s, z, bits, soft)
+        got = ops.adaround(w.to(DEV), alpha.to(DEV), s.to(DEV), z.to(DEV), bits, soft)
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=1e-6)
+        wantg = CB.adaround(w, alpha, s, z, bits, soft, gy=gy)
+        gotg = ops.adaround(w.to(DEV), alpha.to(DEV), s.to(DEV), z.to(DEV), bits, soft, gy=gy.to(DEV))
+        torch.testing.assert_close(gotg.cpu(), wantg, rtol=1e-4, atol=1e-6)
+    for b in (20.0, 11.0, 2.0):
+        ga_ref = torch.zeros_like(alpha)
+        l_ref = CB.round_loss(alpha, b, galpha=ga_ref, gscale=0.5)
+        ga = torch.zeros_like(alpha).to(DEV)
+        l = ops.round_loss(alpha.to(DEV), b, galpha=ga, gscale=0.5)
+        torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-4, atol=1e-3)
+        torch.testing.assert_close(ga.cpu(), ga_ref, rtol=1e-3, atol=1e-5)

@@ -93,3 +93,11 @@ def test_linear_scores_on_reference_candidates(golden, bits):
     s = lay._score_a(lay._pack_w_fixed(), sa, za).cpu()
     ref = t(g["trace_018_scores"]).reshape(-1, 128).t()
     assert ((s - ref).abs() / ref.abs()).max().item() <= 1e-4
+
+
+def test_brecq_toy_forward_backward(golden):
+    LC.case_brecq_toy(golden, DEV)
+
+
+def test_brecq_reconstruct_model():
+    LC.case_brecq_reconstruct(DEV, iters=200)

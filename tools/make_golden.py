@@ -468,6 +468,91 @@ def gen_calibrator():
     save("calibrator_toy", **arrays)
 
 
+def gen_brecq():
+    """BRECQ pieces (utils/block_recon.py needs timm at import: a container-only attribute stub satisfies it).
+    One forward/backward of a toy block of the reference's own layers in training mode pins the STE gradients of the
+    uniform / AdaLog quantisers, the AdaRound gradient, the reconstruction loss and the rounding regulariser."""
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            m = _Stub(self.__name__ + "." + k)
+            setattr(self, k, m)
+            return m
+    for name in ("timm", "timm.models", "timm.models.swin_transformer", "timm.models.vision_transformer", "timm.layers",
+                 "timm.layers.patch_embed"):
+        sys.modules.setdefault(name, _Stub(name))
+    sys.modules["timm.models.swin_transformer"].window_partition = None
+    sys.modules["timm.models.swin_transformer"].window_reverse = None
+    from utils.block_recon import LossFunction, LinearTempDecay, BlockReconstructor
+    arrays = {}
+    arrays["lp_ones"] = LossFunction.lp_loss(torch.ones(2, 3, 4), torch.zeros(2, 3, 4))
+    td = LinearTempDecay(1000, rel_start_decay=0.2, start_b=20, end_b=2)
+    arrays["temp_decay_t"] = np.array([1, 100, 199, 200, 201, 600, 999, 1000])
+    arrays["temp_decay_b"] = np.array([td(int(t)) for t in arrays["temp_decay_t"]], dtype=np.float64)
+
+    torch.manual_seed(91)
+    I, Hd, H = 16, 32, 2
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            kw = dict(mode="raw", w_bit=4, a_bit=4, calib_batch_size=4, search_round=1, eq_n=128, fpcs=True, steps=2)
+            self.fc1 = RL.AsymmetricallyBatchingQuantLinear(I, Hd, True, n_V=1, **kw)
+            self.fc2 = RL.PostGeluLogBasedBatchingQuantLinear(Hd, I, True, n_V=1, quantizer="adalog", **kw)
+            mk = dict(B_bit=4, mode="raw", calib_batch_size=4, search_round=1, eq_n=128, head_channel_wise=True,
+                      num_heads=H, fpcs=True, steps=2)
+            self.matmul1 = RL.AsymmetricallyBatchingQuantMatMul(A_bit=4, **mk)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            h = x.reshape(B, N, H, C // H).permute(0, 2, 1, 3)
+            a = self.matmul1(h, h.transpose(-2, -1)).softmax(-1) @ h
+            x = x + a.permute(0, 2, 1, 3).reshape(B, N, C)
+            return x + self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+    blk = Blk().eval()
+    for m in (blk.fc1, blk.fc2):
+        m.weight.data.normal_(0, 0.2)
+        m.bias.data.normal_(0, 0.1)
+    xs = torch.randn(4, 5, I)
+    sd0 = {k: v.clone() for k, v in blk.state_dict().items()}
+    RefCalibrator(blk, [(xs, None)]).batching_quant_calib()
+    arrays.update({"cal_" + k.replace(".", "__"): v.clone() for k, v in blk.state_dict().items()})
+    arrays.update({"in_" + k.replace(".", "__"): v for k, v in sd0.items()})
+    arrays["x"] = xs
+    tgt = torch.randn(4, 5, I)
+    arrays["tgt"] = tgt
+    rec = object.__new__(BlockReconstructor)
+    rec.wrap_quantizers_in_net(blk, "blk")
+    for m in blk.modules():
+        if hasattr(m, "training_mode"):
+            m.init_training()
+    for m in blk.modules():
+        if hasattr(m, "mode"):
+            m.mode = "quant_forward"
+    lf = LossFunction(blk, round_loss="relaxation", weight=0.01, max_count=10, rec_loss="mse", b_range=(20, 2),
+                      decay_start=0, warmup=0.2, p=2.0)
+    lf.count = 4                                          # past the warm-up: regulariser active, b decaying
+    blk.fc1.w_quantizer.alpha.data.add_(torch.randn(blk.fc1.w_quantizer.alpha.shape) * 1.5)
+    arrays["alpha_fc1"] = blk.fc1.w_quantizer.alpha.data.clone()
+    arrays["alpha_fc2"] = blk.fc2.w_quantizer.alpha.data.clone()
+    out = blk(xs)
+    loss = lf(out, tgt)
+    loss.backward()
+    arrays["train_out"] = out
+    arrays["loss"] = loss
+    arrays["b"] = np.float64(lf.temp_decay(lf.count))
+    arrays["g_alpha_fc1"] = blk.fc1.w_quantizer.alpha.grad
+    arrays["g_alpha_fc2"] = blk.fc2.w_quantizer.alpha.grad
+    arrays["g_a_scale_fc1"] = blk.fc1.a_quantizer.scale.grad
+    arrays["g_a_scale_fc2"] = blk.fc2.a_quantizer.scale.grad
+    arrays["g_A_scale_mm"] = blk.matmul1.A_quantizer.scale.grad
+    arrays["g_B_scale_mm"] = blk.matmul1.B_quantizer.scale.grad
+    arrays["hard_fc1"] = blk.fc1.w_quantizer.get_hard_value(blk.fc1.weight.data)
+    save("brecq_toy", **arrays)
+
+
 if __name__ == "__main__":
     gen_quantizers()
     for bits, seed in ((3, 11), (4, 12), (6, 13)):
@@ -487,3 +572,4 @@ if __name__ == "__main__":
         gen_conv(bits, seed)
     gen_quantile_large()
     gen_calibrator()
+    gen_brecq()
