@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
         const float u = fminf(fmaxf(ur, 1e-15f), 1.0f);
         const float k = adalog_k(u, qf);
         const bool ik = (k >= 0.0f) && (k <= (float)(levels2 - 1));
-        const float yv = sub_shift ? y[i] + sh : y[i];                 // y before the "- shift"
+        // y before the "- shift", recomputed from k (adding the shift back to the stored output would cancel small y)
+        const float yv = (k < (float)levels2) ? exp2f(-1.0f * fminf(fmaxf(k, 0.0f), (float)(levels2 - 1)) * qf / 37.0f) * s : 0.0f;
         const float g = gy[i];
         const float dydx = (iu && ik) ? yv / (u * s) : 0.0f;
         if (gx) gx[i] = g * dydx;

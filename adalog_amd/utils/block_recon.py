@@ -205,7 +205,8 @@ class LossFunction:
             raise NotImplementedError
         total_loss = rec_loss + round_loss
         if self.count == 1 or self.count % 500 == 0:
-            self.last = (float(total_loss), float(rec_loss), float(round_loss))
+            self.last = (float(total_loss.detach()), float(rec_loss.detach()),
+                         float(round_loss.detach()) if torch.is_tensor(round_loss) else float(round_loss))
             logging.info('Total loss:\t{:.3f} (rec:{:.3f}, round:{:.3f})\tb={:.2f}\tcount={}'.format(
                 self.last[0], self.last[1], self.last[2], b, self.count))
         return total_loss
