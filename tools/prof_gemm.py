@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Launch a handful of scoring-GEMM calls at deit_small shapes (for rocprofv3 --pmc / --kernel-trace runs)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from adalog_amd import backend  # noqa: E402
+
+ops = backend.get()
+dev = "cuda"
+torch.manual_seed(0)
+N, T, P = 32, 197, 128
+M = N * T
+S = ops.Strided
+which = sys.argv[1] if len(sys.argv) > 1 else "qkv"
+I, O = {"qkv": (384, 1152), "fc2": (1536, 384), "proj": (384, 384)}[which]
+x = torch.randn(1, M, I, device=dev)
+W = torch.randn(1, O, I, device=dev) * 0.05
+ref = torch.randn(1, M, O, device=dev)
+bias = torch.zeros(O, device=dev)
+xs, xz = torch.tensor([0.3], device=dev), torch.tensor([8.0], device=dev)
+ws, wz = torch.full((O,), 0.01, device=dev), torch.full((O,), 8.0, device=dev)
+csw = torch.rand(P, O, device=dev) * 0.01 + 0.005; czw = torch.randint(4, 12, (P, O), device=dev).float()
+csa = torch.rand(P, 1, device=dev) * 0.2 + 0.2; cza = torch.randint(4, 12, (P, 1), device=dev).float()
+xp = ops.pack_uniform(x, xs, xz, 1, 0, 1, 0, 0, 4, ops.I8)
+wp = ops.pack_uniform(W, csw, czw, P, O, 1, 0, 1, 4, ops.I8, c_inner=True)
+wfix = ops.pack_uniform(W, ws, wz, 1, 0, 1, 0, 1, 4, ops.I8)
+xP = ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8)
+for _ in range(3):
+    ops.gemm_score(ops.I8, xp, wp, M, O, P, 1, 1, ref, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True, 1.0 / T, ref_div=P, order=2)
+    ops.gemm_score(ops.I8, xP, wfix, M, O, P, 1, 1, ref, S(csa, c=1), S(ws, n=1), S(bias, n=1), False, False, 1.0 / (T * O), order=1)
+torch.cuda.synchronize()
+print("done")
