@@ -31,7 +31,7 @@ struct GemmArgs {
     int64_t sAc, sAg, sBc, sBg;      // byte strides between candidates / groups (0 = shared operand)
     int M, N; int64_t Kb;            // Kb = padded K in bytes (multiple of 64)
     int C, G, gmod;
-    const float* ref; int64_t ldr, sRg; int ref_div;
+    const float* ref; int64_t ldr, sRg, ref_cs; int ref_div;
     const float* sa; int64_t sa_c, sa_g;
     const float* sb; int64_t sb_c, sb_g, sb_n;
     const float* bias; int64_t bi_c, bi_g, bi_n;
@@ -147,8 +147,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
     // ---- epilogue: out = acc * (sa*sb) + bias; squared error against ref; column sums over the tile's rows.
     // With ref_div > 1 a GEMM column encodes (output channel n = col / ref_div, candidate = col % ref_div): the 128
     // candidates of one channel sit in one tile and share ONE reference column (weight searches).
+    // Branch-free: edge rows/columns are clamped for addressing and weighted 0; 32-bit offsets inside a group.
     const float* refg = p.ref ? p.ref + (int64_t)g * p.sRg : nullptr;
     float* outg = STORE ? p.out + (int64_t)c * p.sOc + (int64_t)g * p.sOg : nullptr;
+    const int ldr = (int)p.ldr, rcs = (int)p.ref_cs, ldo = (int)p.ldo;
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wc * 64 + j * 32 + frow;
@@ -158,19 +161,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
         const int ni = p.ref_div > 1 ? colc / p.ref_div : colc;
         const float alpha = p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g + ni * p.sb_n];
         const float beta = p.bias ? p.bias[ci * p.bi_c + gh * p.bi_g + ni * p.bi_n] : 0.0f;
+        const int rc0 = ni * rcs;
         float csum = 0.0f;
+        if (interior) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 2; ++i) {
+                const int rb = m0 + wr * 64 + i * 32 + 4 * fkg;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fkg;
-                if (cv && row < p.M) {
-                    float o = (float)acc[i][j][r] * alpha;
-                    o = p.bias ? o + beta : o;
-                    if (STORE) outg[(int64_t)row * p.ldo + col] = o;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + (r & 3) + 8 * (r >> 2);
+                    const float o = (float)acc[i][j][r] * alpha + beta;
+                    if (STORE) outg[row * ldo + col] = o;
                     if (refg) {
-                        const float e = refg[(int64_t)row * p.ldr + ni] - o;
+                        const float e = refg[row * ldr + rc0] - o;
                         csum += e * e;
+                    }
+                }
+            }
+        } else {
+            const float cm = cv ? 1.0f : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rb = m0 + wr * 64 + i * 32 + 4 * fkg;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rb + (r & 3) + 8 * (r >> 2);
+                    const bool rv = row < p.M;
+                    const int rowc = rv ? row : p.M - 1;
+                    const float o = (float)acc[i][j][r] * alpha + beta;
+                    if (STORE) { if (rv && cv) outg[rowc * ldo + col] = o; }
+                    if (refg) {
+                        const float e = refg[rowc * ldr + rc0] - o;
+                        csum += (e * e) * (rv ? cm : 0.0f);
                     }
                 }
             }
@@ -251,7 +273,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
 
 extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
                                  int64_t sBg, int M, int N, int64_t Kp, int C, int G, int gmod, const float* ref,
-                                 int64_t ldr, int64_t sRg, int ref_div, const float* sa, int64_t sa_c, int64_t sa_g,
+                                 int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c, int64_t sa_g,
                                  float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
                                  const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, float* partial,
                                  int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, int order,
@@ -267,7 +289,9 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
     p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;
     p.M = M; p.N = N; p.Kb = Kp * esz; p.C = C; p.G = G; p.gmod = gmod;
-    p.ref = ref; p.ldr = ldr; p.sRg = sRg; p.ref_div = ref_div;
+    p.ref = ref; p.ldr = ldr; p.sRg = sRg; p.ref_cs = ref_cs; p.ref_div = ref_div;
+    ADALOG_ARG_CHECK(!ref || ((int64_t)(M - 1) * ldr + (int64_t)(N - 1) * (ref_cs > 0 ? ref_cs : 1) < ((int64_t)1 << 31)),
+                     "gemm_score: reference group exceeds 32-bit addressing");
     p.sa = sa; p.sa_c = sa_c; p.sa_g = sa_g; p.sa_mul = sa_mul;
     p.sb = sb; p.sb_c = sb_c; p.sb_g = sb_g; p.sb_n = sb_n;
     p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;

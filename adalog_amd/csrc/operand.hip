@@ -247,7 +247,7 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
 extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr,
                                        int64_t sxk, const float* scale, const float* qv, int64_t C, int64_t pc,
                                        int64_t gmod, int64_t pg, int n_bits, const float* mant37, const float* shift,
-                                       int clamp_u, void* out, int64_t Kp, void* stream) {
+                                       int clamp_u, void* out, int64_t Kp, int c_inner, void* stream) {
     ADALOG_ARG_CHECK(x && scale && qv && mant37 && out, "pack_adalog: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_adalog: bad sizes");
     ADALOG_ARG_CHECK(Kp >= K && (Kp * 2) % 64 == 0, "pack_adalog: Kp must cover K and be a multiple of 32 elements");
@@ -256,6 +256,7 @@ extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int
     a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk;
     a.scale = scale; a.qv = qv; a.C = C; a.pc = pc; a.gmod = gmod; a.pg = pg; a.pr = 0;
     a.levels2 = 1 << n_bits; a.mant = mant37; a.shift = shift; a.clamp_u = clamp_u; a.out = out; a.Kp = Kp;
+    a.c_inner = c_inner;
     launch_pack<__hip_bfloat16, KIND_ADALOG>(a, (hipStream_t)stream);
     ADALOG_LAUNCH_CHECK("adalog_pack_adalog_bf16");
     return 0;

@@ -119,15 +119,15 @@ def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr:
 
 
 def pack_adalog(x3, scale, qv, C: int, pc: int, gmod: int, pg: int, n_bits: int, mant37, shift=None,
-                clamp_u: bool = True):
+                clamp_u: bool = True, c_inner: bool = False):
     G, R, K, sg, sr, sk = _view3(x3)
     Kp = pad_k(K, BF16)
-    out = torch.empty((C, G, R, Kp), dtype=torch.bfloat16, device=x3.device)
+    out = torch.empty((1, G, R * C, Kp) if c_inner else (C, G, R, Kp), dtype=torch.bfloat16, device=x3.device)
     rc = _lib.load().adalog_pack_adalog_bf16(x3.data_ptr(), G, R, K, sg, sr, sk, _ptr(_f32c(scale, "scale")),
                                             _ptr(_f32c(qv, "qv")), C, pc, gmod, pg, int(n_bits),
                                             _ptr(_f32c(mant37, "mant37")),
                                             _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(clamp_u)),
-                                            out.data_ptr(), Kp, _stream())
+                                            out.data_ptr(), Kp, int(bool(c_inner)), _stream())
     _lib.check(rc, "adalog_pack_adalog_bf16")
     return out
 
@@ -156,7 +156,7 @@ class Strided:
 
 def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
                bias: Optional[Strided], keep_h: bool, keep_n: bool, norm: float, sa_mul: float = 1.0,
-               ref_div: int = 1, order: int = 1):
+               ref_div: int = 1, order: int = 1, ref_transposed: bool = False):
     """scores = finish(gemm_score(...)).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N, Kp]; ref: [G, M, N/ref_div] fp32.
 
     With ``ref_div`` = P > 1 (weight searches) B is packed candidates-innermost ([1, G, N*P, Kp]), C must be 1 and the
@@ -176,8 +176,12 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     sBc = 0 if B.shape[0] == 1 else B.stride(0)
     sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
     ref = _f32c(ref, "ref")
-    ldr = ref.shape[-1]
-    sRg = 0 if G == 1 else M * ldr
+    if ref_transposed:                         # ref stored [G, N, M]: element (m, n) at n*M + m
+        assert ref.shape[-1] == M and ref.shape[-2] == N
+        ldr, ref_cs = 1, M
+    else:
+        ldr, ref_cs = ref.shape[-1], 1
+    sRg = 0 if G == 1 else ref.shape[-1] * ref.shape[-2]
     reduce_cols = 0 if (keep_n or ref_div > 1) else 1
     n_part = lib.adalog_gemm_score_partial_elems(M, N, C, G, reduce_cols)
     partial = torch.empty(n_part, dtype=torch.float32, device=A.device)
@@ -185,7 +189,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, n_cols, Kp, c_grid, G, gmod,
-                               ref.data_ptr(), ldr, sRg, ref_div, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul),
+                               ref.data_ptr(), ldr, sRg, ref_cs, ref_div, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul),
                                sb.t.data_ptr(), sb.c, sb.g, sb.n,
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
@@ -214,7 +218,7 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
     sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
     sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
     out = torch.empty((G, M, N), dtype=torch.float32, device=A.device)
-    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), 0, sAg, 0, sBg, M, N, Kp, 1, G, gmod, None, 0, 0, 1,
+    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), 0, sAg, 0, sBg, M, N, Kp, 1, G, gmod, None, 0, 0, 1, 1,
                                sa.t.data_ptr(), sa.c, sa.g, float(sa_mul), sb.t.data_ptr(), sb.c, sb.g, sb.n,
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,

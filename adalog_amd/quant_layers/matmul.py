@@ -137,7 +137,12 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         return be.pack_uniform(self._bt3(B), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.B_quantizer.n_bits, dt)
 
     def _score(self, which, fixed, scale, zp, dt=I8, fixed_sa=None, sa_mul=1.0):
-        """matmul.py:135-163 (which='A') / :173-201 (which='B') -> scores [P, H]."""
+        """matmul.py:135-163 (which='A') / :173-201 (which='B') -> scores [P, H].
+
+        The candidates go into the GEMM's COLUMN axis (packed candidates-innermost): the 128 candidates of one output
+        row/column share one reference element per accumulator row, and tiles are full along that axis.  For the
+        A-operand search the product is evaluated transposed (D^T = B . A_p^T), reading raw_out transposed in place.
+        """
         be = backend.get()
         H = self._heads()
         G, S, K, Sp = self._dims()
@@ -153,17 +158,18 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         for s0 in range(0, P, chunk):
             e = min(P, s0 + chunk)
             sc, zc = scale[s0:e].contiguous(), zp[s0:e].contiguous()
-            cand = be.pack_uniform(src, sc, zc, e - s0, H, H, pg, 0, bits, dt)
+            cand = be.pack_uniform(src, sc, zc, e - s0, H, H, pg, 0, bits, dt, c_inner=True)
+            sb = Strided(sc, c=H, g=pg)
             if which == "A":
-                sa = Strided(sc, c=H, g=pg)
-                sb = Strided(self.B_quantizer.scale.data.view(-1), g=pg)
-                a_op, b_op = cand, fixed
+                sa = Strided(self.B_quantizer.scale.data.view(-1), g=pg)
+                out.append(be.gemm_score(dt, fixed, cand, Sp, S, e - s0, G, H, self._ref3(), sa, sb, None,
+                                         self.head_channel_wise, False, self._norm(A, S, Sp), sa_mul=sa_mul,
+                                         ref_div=e - s0, order=2, ref_transposed=True))
             else:
                 sa = fixed_sa if fixed_sa is not None else Strided(self.A_quantizer.scale.data.view(-1), g=pg)
-                sb = Strided(sc, c=H, g=pg)
-                a_op, b_op = fixed, cand
-            out.append(be.gemm_score(dt, a_op, b_op, S, Sp, e - s0, G, H, self._ref3(), sa, sb, None,
-                                     self.head_channel_wise, False, self._norm(A, S, Sp), sa_mul=sa_mul))
+                out.append(be.gemm_score(dt, fixed, cand, S, Sp, e - s0, G, H, self._ref3(), sa, sb, None,
+                                         self.head_channel_wise, False, self._norm(A, S, Sp), sa_mul=sa_mul,
+                                         ref_div=e - s0, order=2))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _commit(self, quantizer, scale, zp):
@@ -250,10 +256,10 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
     def _ts32(self):
         return float(torch.tensor(self.table_scale, dtype=torch.float32))
 
-    def _pack_A_adalog(self, A3, qv, scale, C, clamp_u):
+    def _pack_A_adalog(self, A3, qv, scale, C, clamp_u, c_inner=False):
         be = backend.get()
         return be.pack_adalog(A3, scale, qv, C, 1 if C > 1 else 0, 1, 0, self.A_quantizer.n_bits,
-                              self._mant37(A3.device), shift=None, clamp_u=clamp_u)
+                              self._mant37(A3.device), shift=None, clamp_u=clamp_u, c_inner=c_inner)
 
     def _search_best_A_log_base(self):
         """matmul.py:321-358: 128 bases q = 10..137, per-tensor score, commit the best."""
@@ -272,10 +278,13 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         out = []
         for s0 in range(0, P, chunk):
             e = min(P, s0 + chunk)
-            ap = self._pack_A_adalog(self._a3(A), q_all[s0:e].contiguous(), ones[s0:e].contiguous(), e - s0, False)
-            out.append(be.gemm_score(BF16, ap, bp, S, Sp, e - s0, G, H, self._ref3(), Strided(ones),
-                                     Strided(self.B_quantizer.scale.data.view(-1), g=pg), None, False, False,
-                                     1.0 / (A.shape[1] * S * Sp), sa_mul=self._ts32()))
+            # transposed product: rows = head-dim columns of v, GEMM columns = (attention row, candidate base)
+            ap = self._pack_A_adalog(self._a3(A), q_all[s0:e].contiguous(), ones[s0:e].contiguous(), e - s0, False,
+                                     c_inner=True)
+            out.append(be.gemm_score(BF16, bp, ap, Sp, S, e - s0, G, H, self._ref3(),
+                                     Strided(self.B_quantizer.scale.data.view(-1), g=pg), Strided(ones[s0:e].contiguous(), c=1),
+                                     None, False, False, 1.0 / (A.shape[1] * S * Sp), sa_mul=self._ts32(),
+                                     ref_div=e - s0, order=2, ref_transposed=True))
         scores = out[0] if len(out) == 1 else torch.cat(out, 0)
         idx = search.argbest(scores, 1)
         best_q = be.fpcs_next(q_all.view(-1, 1), None, None, idx, 1, 0, None, None, None)[0]

@@ -47,7 +47,7 @@ int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n
 /* ---- operand packing for the scoring GEMMs (prologue of K7/K8/K11-K15)
  * Input: fp32 view x[g][r][k] with element strides (sxg, sxr, sxk), g < G, r < R, k < K.
  * Output: out[c][g][r][Kp], K-contiguous, zero padded to Kp (Kp * sizeof(elem) a multiple of 64 bytes);
- *   adalog_pack_uniform with c_inner = 1 writes out[g][r][c][Kp] instead (candidates innermost, see ref_div below).
+ *   adalog_pack_uniform / adalog_pack_adalog_bf16 with c_inner = 1 write out[g][r][c][Kp] instead (candidates innermost, see ref_div below).
  * Parameter addressing for candidate c: idx = c*pc + (g % gmod)*pg + r*pr.
  * out_dtype: 0 = int8, 1 = bf16, 2 = fp32.
  *
@@ -66,7 +66,7 @@ int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t K, int64_t
 int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
                             const float* scale, const float* qv, int64_t C, int64_t pc, int64_t gmod, int64_t pg,
                             int n_bits, const float* mant37, const float* shift, int clamp_u, void* out, int64_t Kp,
-                            void* stream);
+                            int c_inner, void* stream);
 int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk, void* out,
                         int64_t Kp, void* stream);
 
@@ -74,7 +74,8 @@ int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t
  * For candidate c < C and group g < G (gh = g % gmod):
  *     D = A[c][g] (M x Kp) . B[c][g]^T (N x Kp)          A/B strides sAc,sAg,sBc,sBg in elements, 0 = shared
  *     out[m][n] = D[m][n] * (sa[c*sa_c + gh*sa_g] * sa_mul * sb[c*sb_c + gh*sb_g + n*sb_n]) + bias[c*bi_c + gh*bi_g + n*bi_n]
- *     partial[c][g][m_tile][n] = sum over the tile's rows of (ref[g*sRg + m*ldr + n/ref_div] - out[m][n])^2
+ *     partial[c][g][m_tile][n] = sum over the tile's rows of (ref[g*sRg + m*ldr + (n/ref_div)*ref_cs] - out[m][n])^2
+ *       (ldr = N, ref_cs = 1 for a row-major reference; ldr = 1, ref_cs = M' reads it transposed)
  * and/or `out` is stored (quant_forward, linear.py:46-51 / matmul.py:43-45 / conv.py:60-65).
  * Replaces F.linear / @ / F.conv2d + _get_similarity + mean/sum in
  *   linear.py:355-384, 394-423, 816-848, 856-890, 898-931; matmul.py:135-163, 173-201, 321-351; conv.py:226-255.
@@ -87,7 +88,8 @@ int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t
  * dtype: 0 = int8 (exact integer dot products), 1 = bf16, 2 = fp32.  bias may be NULL.  partial and ref go together.
  * partial must hold adalog_gemm_score_partial_elems(M, N, C, G) floats. */
 int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc, int64_t sBg, int M,
-                      int N, int64_t Kp, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int ref_div,
+                      int N, int64_t Kp, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int64_t ref_cs,
+                      int ref_div,
                       const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
                       int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n,
                       float* partial, int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, int order,

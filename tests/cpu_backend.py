@@ -72,7 +72,7 @@ def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, w
     return out
 
 
-def pack_adalog(x3, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift=None, clamp_u=True):
+def pack_adalog(x3, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift=None, clamp_u=True, c_inner=False):
     G, R, K = x3.shape
     s = _params(scale, C, G, R, pc, gmod, pg, 0).unsqueeze(-1)
     qf = _params(qv, C, G, R, pc, gmod, pg, 0).unsqueeze(-1)
@@ -94,6 +94,8 @@ def pack_adalog(x3, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift=None, clam
     vb = v.to(torch.bfloat16)
     assert torch.equal(vb.float(), v.float()), "AdaLog operand must be exact in bf16"
     out[..., :K] = vb
+    if c_inner:
+        out = out.permute(1, 2, 0, 3).reshape(1, G, R * C, Kp).contiguous()
     return out
 
 
@@ -117,7 +119,8 @@ def _gemm(dtype, A, B, C, G):
     return torch.einsum("cgmk,cgnk->cgmn", Ad, Bd)
 
 
-def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1, order=1):
+def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1, order=1,
+               ref_transposed=False):
     if ref_div > 1:                               # columns = (n, candidate): un-interleave back to [C, G, N, Kp]
         B = B.view(G, N, ref_div, -1).permute(2, 0, 1, 3)
     D = _gemm(dtype, A, B, C, G)                                            # [C, G, M, N]
@@ -125,7 +128,7 @@ def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n,
     out = D * alpha.unsqueeze(2)
     if bias is not None:
         out = out + _epi(bias, C, G, gmod, N).unsqueeze(2)
-    r = ref.reshape(G, M, -1).double()
+    r = (ref.reshape(G, N, M).transpose(1, 2) if ref_transposed else ref.reshape(G, M, -1)).double()
     e2 = (r.unsqueeze(0) - out) ** 2                                        # [C, G, M, N]
     e2 = e2.view(C, G // gmod, gmod, M, N)
     dims = [1, 3]

@@ -83,10 +83,10 @@ if not args.only or "matmul" in args.only:
     fs, fz = torch.full((H,), 0.3, device=dev), torch.full((H,), 8.0, device=dev)
     a3 = A.reshape(G, T, C); bt3 = Bk.reshape(G, T, C)
     bfix = ops.pack_uniform(bt3, fs, fz, 1, 0, H, 1, 0, 4, ops.I8)
-    t_p = timeit(lambda: ops.pack_uniform(a3, cs, cz, P, H, H, 1, 0, 4, ops.I8))
-    aP = ops.pack_uniform(a3, cs, cz, P, H, H, 1, 0, 4, ops.I8)
-    t_g = timeit(lambda: ops.gemm_score(ops.I8, aP, bfix, T, T, P, G, H, ref, S(cs, c=H, g=1), S(fs, g=1), None, True, False,
-                                        1.0 / (T * T), order=1))
+    t_p = timeit(lambda: ops.pack_uniform(a3, cs, cz, P, H, H, 1, 0, 4, ops.I8, c_inner=True))
+    aP = ops.pack_uniform(a3, cs, cz, P, H, H, 1, 0, 4, ops.I8, c_inner=True)
+    t_g = timeit(lambda: ops.gemm_score(ops.I8, bfix, aP, T, T, P, G, H, ref, S(fs, g=1), S(cs, c=H, g=1), None, True, False,
+                                        1.0 / (T * T), ref_div=P, order=2, ref_transposed=True))
     fl = 2.0 * G * T * T * C * P
     print(f"qk^T  i8  A-search: pack {t_p*1e3:7.0f} us  gemm {t_g*1e3:7.0f} us = {fl/t_g/1e9:7.1f} TOPS", flush=True)
     Asm = torch.softmax(torch.randn(N, H, T, T, device=dev), -1); V = torch.randn(N, H, T, C, device=dev)
@@ -95,10 +95,10 @@ if not args.only or "matmul" in args.only:
     qv = torch.arange(10, 10 + P, device=dev).float(); ones = torch.ones(P, device=dev)
     vt3 = V.reshape(G, T, C).transpose(1, 2)
     vfix = ops.pack_uniform(vt3, fs, fz, 1, 0, H, 1, 0, 4, ops.BF16)
-    t_p = timeit(lambda: ops.pack_adalog(Asm.reshape(G, T, T), ones, qv, P, 1, 1, 0, 4, mant, None, False))
-    aL = ops.pack_adalog(Asm.reshape(G, T, T), ones, qv, P, 1, 1, 0, 4, mant, None, False)
-    t_g = timeit(lambda: ops.gemm_score(ops.BF16, aL, vfix, T, C, P, G, H, ref2, S(ones), S(fs, g=1), None, False, False,
-                                        1.0 / (H * T * C), sa_mul=1 / 30.0, order=1))
+    t_p = timeit(lambda: ops.pack_adalog(Asm.reshape(G, T, T), ones, qv, P, 1, 1, 0, 4, mant, None, False, c_inner=True))
+    aL = ops.pack_adalog(Asm.reshape(G, T, T), ones, qv, P, 1, 1, 0, 4, mant, None, False, c_inner=True)
+    t_g = timeit(lambda: ops.gemm_score(ops.BF16, vfix, aL, C, T, P, G, H, ref2, S(fs, g=1), S(ones, c=1), None, False, False,
+                                        1.0 / (H * T * C), sa_mul=1 / 30.0, ref_div=P, order=2, ref_transposed=True))
     fl = 2.0 * G * T * T * C * P
     print(f"sm@v  bf16 log-base: pack {t_p*1e3:7.0f} us  gemm {t_g*1e3:7.0f} us = {fl/t_g/1e9:7.1f} TFLOPS", flush=True)
     t_p = timeit(lambda: ops.pack_uniform(vt3, cs, cz, P, H, H, 1, 0, 4, ops.BF16))
