@@ -35,6 +35,7 @@ struct GemmArgs {
     const float* sa; int64_t sa_c, sa_g;
     const float* sb; int64_t sb_c, sb_g, sb_n;
     const float* bias; int64_t bi_c, bi_g, bi_n;
+    const float* row_scale; const float* row_bias;   // optional per-ROW factor / offset (transposed activation searches)
     float* partial; int MT, NT, Npad;
     float* out; int64_t ldo, sOc, sOg;
     float sa_mul;                    // constant folded into sa (e.g. 1/(4L-2) for AdaLog numerators)
@@ -229,6 +230,190 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ large-tile kernel
+// Second-generation scoring kernel, used whenever the candidates sit in the GEMM's column axis (every search) or there
+// is a single problem per group (quant_forward).  Per 512-thread workgroup (8 waves as 2 x 4): (64*TM) x 256 output tile,
+// K-step = 128 BYTES so that every staged row is one full 128-byte cache line (the 64-byte steps of the first kernel
+// fetched each line twice and left it latency-bound: MFMA 13 % busy, 64 % of wave cycles parked, profiles/r01_pmc_*).
+// Per wave (32*TM) x 64 = TM x 2 MFMA 32x32 tiles; operand bytes per MAC are half those of the 128 x 128 tile.
+// One LDS stage (<= 64 KiB -> 2 workgroups per CU) + register prefetch of the next K-step.
+constexpr int BN2 = 256, BK2 = 128;
+
+__device__ __forceinline__ int swz2(int row, int slot) { return row * BK2 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int DT, int TM, bool STORE>
+__global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
+    constexpr int BM2 = 64 * TM;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* As = smem;
+    uint8_t* Bs = smem + BM2 * BK2;
+    float* red = reinterpret_cast<float*>(smem + (BM2 + BN2) * BK2);       // [2][4][2][32] then colv[256]
+    float* colv = red + 512;
+
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const unsigned lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    unsigned t = lid;
+    int nt, mt, g;
+    if (p.order == 2) { mt = t % p.MT; t /= p.MT; nt = t % p.NT; g = t / p.NT; }
+    else { nt = t % p.NT; t /= p.NT; mt = t % p.MT; g = t / p.MT; }
+    const int c = 0;
+    const int gh = g % p.gmod;
+    const int m0 = mt * BM2, n0 = nt * BN2;
+    const uint8_t* Ag = p.A + g * p.sAg;
+    const uint8_t* Bg = p.B + g * p.sBg;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 2, wc = w & 3;
+    const int lrow = tid >> 3, lslot = tid & 7;
+    const uint4* ga[TM];
+    const uint4* gb[4];
+    int soa[TM], sob[4];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int r = m0 + lrow + 64 * i;
+        r = r < p.M ? r : p.M - 1;
+        ga[i] = reinterpret_cast<const uint4*>(Ag + (int64_t)r * p.Kb) + lslot;
+        soa[i] = swz2(lrow + 64 * i, lslot);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int r = n0 + lrow + 64 * i;
+        r = r < p.N ? r : p.N - 1;
+        gb[i] = reinterpret_cast<const uint4*>(Bg + (int64_t)r * p.Kb) + lslot;
+        sob[i] = swz2(lrow + 64 * i, lslot);
+    }
+
+    typename Acc<DT>::type acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int nk = (int)((p.Kb + BK2 - 1) / BK2);
+    const int ktail = (int)(p.Kb - (int64_t)(nk - 1) * BK2);           // bytes valid in the last step: 64 or 128
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    uint4 ra[TM], rb[4];
+    auto gload = [&](int kt) {
+        const bool ok = (kt < nk - 1) || (lslot * 16 < ktail);
+        const int o = kt * (BK2 / 16);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ra[i] = ok ? ga[i][o] : zero4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = ok ? gb[i][o] : zero4;
+    };
+    auto sstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) *reinterpret_cast<uint4*>(As + soa[i]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Bs + sob[i]) = rb[i];
+    };
+    gload(0);
+    sstore();
+    __syncthreads();
+
+    const int frow = lane & 31, fkg = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const int nks = (kt == nk - 1) ? (ktail >> 5) : 4;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < nks) {
+                uint4 af[TM], bf[2];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(As + swz2(wr * (BM2 / 2) + i * 32 + frow, ks * 2 + fkg));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bs + swz2(wc * 64 + j * 32 + frow, ks * 2 + fkg));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) mma<DT>(af[i], bf[j], acc[i][j]);
+            }
+        }
+        if (kt + 1 < nk) {
+            __syncthreads();
+            sstore();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (same contract as k_gemm_score; adds the optional per-row scale / bias)
+    const float* refg = p.ref ? p.ref + (int64_t)g * p.sRg : nullptr;
+    float* outg = STORE ? p.out + (int64_t)g * p.sOg : nullptr;
+    const int ldr = (int)p.ldr, rcs = (int)p.ref_cs, ldo = (int)p.ldo;
+    const bool interior = (m0 + BM2 <= p.M) && (n0 + BN2 <= p.N);
+    float alpha[2], beta[2], cm[2], csum[2] = {0.0f, 0.0f};
+    int rc0[2], colj[2];
+    bool cvj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + frow;
+        cvj[j] = col < p.N;
+        colj[j] = col;
+        const int colc = cvj[j] ? col : p.N - 1;
+        const int ci = p.ref_div > 1 ? colc % p.ref_div : c;
+        const int ni = p.ref_div > 1 ? colc / p.ref_div : colc;
+        alpha[j] = p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g + ni * p.sb_n];
+        beta[j] = p.bias ? p.bias[ci * p.bi_c + gh * p.bi_g + ni * p.bi_n] : 0.0f;
+        rc0[j] = ni * rcs;
+        cm[j] = cvj[j] ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rb0 = m0 + wr * (BM2 / 2) + i * 32 + 4 * fkg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb0 + (r & 3) + 8 * (r >> 2);
+            const bool rv = interior || row < p.M;
+            const int rowc = rv ? row : p.M - 1;
+            const float rs = p.row_scale ? p.row_scale[rowc] : 1.0f;
+            const float rbv = p.row_bias ? p.row_bias[rowc] : 0.0f;
+            const float rw = rv ? 1.0f : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float o = (float)acc[i][j][r] * alpha[j];
+                if (p.row_scale) o = o * rs + rbv;
+                o += beta[j];
+                if (STORE) { if (interior || (rv && cvj[j])) outg[rowc * ldo + colj[j]] = o; }
+                if (refg) {
+                    const float e = refg[rowc * ldr + rc0[j]] - o;
+                    csum[j] += interior ? e * e : (e * e) * (rw * cm[j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float cs = csum[j];
+        cs += __shfl_xor(cs, 32);
+        if (fkg == 0) red[((wr * 4 + wc) * 2 + j) * 32 + frow] = cs;
+    }
+    if (p.partial) {
+        __syncthreads();
+        float v = 0.0f;
+        const int col = n0 + tid;                                      // tid < 256: column tid of the tile
+        if (tid < 256) v = red[tid] + red[256 + tid];                  // wr = 0 plus wr = 1 (index = wc*64 + j*32 + lane)
+        if (p.reduce_cols) {
+            if (tid < 256) colv[tid] = v;
+            __syncthreads();
+            if (tid < 64) {
+                float t2 = (colv[tid] + colv[tid + 64]) + (colv[tid + 128] + colv[tid + 192]);
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) t2 += __shfl_xor(t2, sft);
+                if (tid == 0) p.partial[(((int64_t)g) * p.MT + mt) * p.Npad + nt] = t2;
+            }
+        } else if (tid < 256) {
+            if (p.ref_div > 1) {
+                if (col < p.N)
+                    p.partial[(((int64_t)(col % p.ref_div) * p.G + g) * p.MT + mt) * p.Npad + col / p.ref_div] = v;
+            } else if (col < p.Npad) {
+                p.partial[(((int64_t)g) * p.MT + mt) * p.Npad + col] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ finish
 // scores[c][h?][n?] = -norm * sum over (image = g / gmod, [h], m-tile, [n]) of partial[c][g][mt][n]   in fp64,
 // fixed summation order: each thread takes a strided subset, then a fixed LDS tree.
@@ -271,13 +456,53 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
 
 }  // namespace
 
+// ---- tile selection shared by launch, layout query and finish
+static int pick_tm(int M) {
+    // largest row tile whose padding waste stays within 10 % of the best achievable
+    double best = 0.0;
+    int tms[3] = {4, 2, 1};
+    double util[3];
+    for (int i = 0; i < 3; ++i) {
+        const int bm = 64 * tms[i];
+        util[i] = (double)M / ((double)cdiv(M, bm) * bm);
+        if (util[i] > best) best = util[i];
+    }
+    for (int i = 0; i < 3; ++i)
+        if (util[i] >= 0.9 * best) return tms[i];
+    return 1;
+}
+
+struct Layout { int big, tm, MT, NT, Npad, c_eff, n_eff; int64_t elems; };
+
+static Layout layout_of(int M, int N, int C, int ref_div, int reduce_cols) {
+    Layout L{};
+    L.big = (C == 1);
+    L.tm = L.big ? pick_tm(M) : 2;
+    const int bm = L.big ? 64 * L.tm : BM, bn = L.big ? BN2 : BN;
+    L.MT = cdiv(M, bm);
+    L.NT = cdiv(N, bn);
+    L.n_eff = ref_div > 1 ? N / ref_div : N;
+    L.c_eff = ref_div > 1 ? ref_div : C;
+    L.Npad = reduce_cols ? L.NT : (ref_div > 1 ? cdiv(L.n_eff, 64) * 64 : L.NT * bn);
+    return L;
+}
+
+// M, N: GEMM rows / columns (N includes the candidate factor when ref_div > 1).  Outputs the partial-buffer layout
+// [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
+extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int* MT, int* Npad) {
+    const Layout L = layout_of(M, N, C, ref_div, reduce_cols);
+    if (MT) *MT = L.MT;
+    if (Npad) *Npad = L.Npad;
+    return (int64_t)L.c_eff * G * L.MT * L.Npad;
+}
+
 extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
                                  int64_t sBg, int M, int N, int64_t Kp, int C, int G, int gmod, const float* ref,
-                                 int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c, int64_t sa_g,
-                                 float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
-                                 const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, float* partial,
-                                 int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, int order,
-                                 int reduce_cols, void* stream) {
+                                 int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c,
+                                 int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
+                                 const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, const float* row_scale,
+                                 const float* row_bias, float* partial, int64_t partial_elems, float* out, int64_t ldo,
+                                 int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream) {
     ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 2, "gemm_score: dtype must be 0 (i8), 1 (bf16) or 2 (f32)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
@@ -285,56 +510,78 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK((Kp * esz) % BKB == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 64 bytes");
     ADALOG_ARG_CHECK((partial != nullptr) == (ref != nullptr), "gemm_score: partial and ref go together");
     ADALOG_ARG_CHECK(partial || out, "gemm_score: nothing to produce");
+    ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
+    ADALOG_ARG_CHECK(ref_div == 1 || (C == 1 && N % ref_div == 0 && !out), "gemm_score: ref_div > 1 needs C == 1, N % ref_div == 0, no out");
+    ADALOG_ARG_CHECK(!(reduce_cols && ref_div > 1), "gemm_score: reduce_cols and ref_div > 1 are exclusive");
+    ADALOG_ARG_CHECK(!row_scale || C == 1, "gemm_score: per-row scale needs C == 1");
+    const Layout L = layout_of(M, N, C, ref_div, reduce_cols);
     GemmArgs p{};
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
     p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;
     p.M = M; p.N = N; p.Kb = Kp * esz; p.C = C; p.G = G; p.gmod = gmod;
     p.ref = ref; p.ldr = ldr; p.sRg = sRg; p.ref_cs = ref_cs; p.ref_div = ref_div;
-    ADALOG_ARG_CHECK(!ref || ((int64_t)(M - 1) * ldr + (int64_t)(N - 1) * (ref_cs > 0 ? ref_cs : 1) < ((int64_t)1 << 31)),
+    ADALOG_ARG_CHECK(!ref || ((int64_t)(M - 1) * ldr + (int64_t)(L.n_eff - 1) * (ref_cs > 0 ? ref_cs : 1) < ((int64_t)1 << 31)),
                      "gemm_score: reference group exceeds 32-bit addressing");
     p.sa = sa; p.sa_c = sa_c; p.sa_g = sa_g; p.sa_mul = sa_mul;
     p.sb = sb; p.sb_c = sb_c; p.sb_g = sb_g; p.sb_n = sb_n;
     p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;
-    p.MT = cdiv(M, BM); p.NT = cdiv(N, BN);
-    p.order = order;
-    p.reduce_cols = reduce_cols;
-    ADALOG_ARG_CHECK(!(reduce_cols && ref_div > 1), "gemm_score: reduce_cols and ref_div > 1 are exclusive");
-    // partial layout [C_eff][G][MT][Npad] with C_eff = ref_div, N_eff = N / ref_div when columns carry the candidates
-    const int n_eff = ref_div > 1 ? N / ref_div : N;
-    const int c_eff = ref_div > 1 ? ref_div : C;
-    p.Npad = reduce_cols ? p.NT : cdiv(n_eff, BN) * BN;
-    ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
-    ADALOG_ARG_CHECK(ref_div == 1 || (C == 1 && N % ref_div == 0 && !out), "gemm_score: ref_div > 1 needs C == 1, N % ref_div == 0, no out");
+    p.row_scale = row_scale; p.row_bias = row_bias;
+    p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad;
+    p.order = order; p.reduce_cols = reduce_cols;
     p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
-    if (partial) ADALOG_ARG_CHECK(partial_elems >= (int64_t)c_eff * G * p.MT * p.Npad, "gemm_score: partial buffer too small");
-    const int64_t nwg = (int64_t)p.MT * p.NT * G * C;
+    if (partial) ADALOG_ARG_CHECK(partial_elems >= (int64_t)L.c_eff * G * L.MT * L.Npad, "gemm_score: partial buffer too small");
+    const int64_t nwg = (int64_t)L.MT * L.NT * G * C;
     ADALOG_ARG_CHECK(nwg < (int64_t)1 << 31, "gemm_score: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)nwg), block(256);
+    dim3 grid((unsigned)nwg);
+    if (L.big) {
+        const size_t shm = (size_t)(64 * L.tm + BN2) * BK2 + (512 + 256) * sizeof(float);
+#define LAUNCH_BIG(DT, TMV, ST)                                                                                   \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_cand<DT, TMV, ST>),                   \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);                       \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            hipLaunchKernelGGL((k_gemm_cand<DT, TMV, ST>), grid, dim3(512), shm, st, p);                          \
+        } while (0)
+#define LAUNCH_BIG_TM(DT, ST)                                                                                     \
+        do {                                                                                                      \
+            if (L.tm == 4) LAUNCH_BIG(DT, 4, ST); else if (L.tm == 2) LAUNCH_BIG(DT, 2, ST); else LAUNCH_BIG(DT, 1, ST); \
+        } while (0)
+#define LAUNCH_BIG_DT(ST)                                                                                         \
+        do {                                                                                                      \
+            if (dtype == 0) LAUNCH_BIG_TM(0, ST); else if (dtype == 1) LAUNCH_BIG_TM(1, ST); else LAUNCH_BIG_TM(2, ST); \
+        } while (0)
+        if (out) LAUNCH_BIG_DT(true); else LAUNCH_BIG_DT(false);
+#undef LAUNCH_BIG_DT
+#undef LAUNCH_BIG_TM
+#undef LAUNCH_BIG
+    } else {
+        ADALOG_ARG_CHECK(!row_scale, "gemm_score: per-row scale is only available with C == 1");
+        dim3 block(256);
 #define LAUNCH(DT)                                                                                   \
-    do {                                                                                             \
-        if (out) hipLaunchKernelGGL((k_gemm_score<DT, true>), grid, block, 0, st, p);                \
-        else hipLaunchKernelGGL((k_gemm_score<DT, false>), grid, block, 0, st, p);                   \
-    } while (0)
-    if (dtype == 0) LAUNCH(0); else if (dtype == 1) LAUNCH(1); else LAUNCH(2);
+        do {                                                                                         \
+            if (out) hipLaunchKernelGGL((k_gemm_score<DT, true>), grid, block, 0, st, p);            \
+            else hipLaunchKernelGGL((k_gemm_score<DT, false>), grid, block, 0, st, p);               \
+        } while (0)
+        if (dtype == 0) LAUNCH(0); else if (dtype == 1) LAUNCH(1); else LAUNCH(2);
 #undef LAUNCH
+    }
     ADALOG_LAUNCH_CHECK("adalog_gemm_score");
     return 0;
 }
 
-extern "C" int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G, int reduce_cols) {
-    return (int64_t)C * G * cdiv(M, BM) * (reduce_cols ? cdiv(N, BN) : cdiv(N, BN) * BN);
-}
-
-extern "C" int adalog_finish_scores(const float* partial, float* scores, int M, int N, int C, int G, int gmod,
-                                    int keep_h, int keep_n, int reduced_cols, double norm, void* stream) {
-    ADALOG_ARG_CHECK(partial && scores && M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0,
+// scores[c][h?][n?] = -norm * sum over (image, [h], m_tile, [n]) of partial[c][g][m_tile][n] with the layout returned by
+// adalog_gemm_score_layout (MT, Npad); N = number of valid entries along the last axis (n_eff, or NT when reduced).
+extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
+                                    int keep_h, int keep_n, double norm, void* stream) {
+    ADALOG_ARG_CHECK(partial && scores && MT >= 1 && N >= 1 && Npad >= N && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0,
                      "finish_scores: bad arguments");
     FinishArgs p{};
-    ADALOG_ARG_CHECK(!(reduced_cols && keep_n), "finish_scores: per-tile partials cannot keep the column axis");
-    p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = cdiv(M, BM);
-    p.N = reduced_cols ? cdiv(N, BN) : N;
-    p.Npad = reduced_cols ? cdiv(N, BN) : cdiv(N, BN) * BN; p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm;
+    p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = MT; p.N = N; p.Npad = Npad;
+    p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm;
     const int64_t nout = (int64_t)C * (keep_h ? gmod : 1) * (keep_n ? N : 1);
     hipLaunchKernelGGL(k_finish, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     ADALOG_LAUNCH_CHECK("adalog_finish_scores");

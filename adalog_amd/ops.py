@@ -154,20 +154,28 @@ class Strided:
         return self
 
 
+def _layout(M, n_cols, c_grid, G, ref_div, reduce_cols):
+    import ctypes
+    mt, npad = ctypes.c_int(0), ctypes.c_int(0)
+    elems = _lib.load().adalog_gemm_score_layout(M, n_cols, c_grid, G, ref_div, reduce_cols, ctypes.byref(mt), ctypes.byref(npad))
+    return elems, mt.value, npad.value
+
+
 def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
                bias: Optional[Strided], keep_h: bool, keep_n: bool, norm: float, sa_mul: float = 1.0,
-               ref_div: int = 1, order: int = 1, ref_transposed: bool = False):
-    """scores = finish(gemm_score(...)).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N, Kp]; ref: [G, M, N/ref_div] fp32.
+               ref_div: int = 1, order: int = 1, ref_transposed: bool = False, row_scale=None, row_bias=None):
+    """scores = finish(gemm_score(...)).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N, Kp]; ref: [G, M, N] fp32.
 
-    With ``ref_div`` = P > 1 (weight searches) B is packed candidates-innermost ([1, G, N*P, Kp]), C must be 1 and the
-    GEMM runs over N*P columns; scores come back as [P, N] all the same.
+    With ``ref_div`` = P > 1 B is packed candidates-innermost ([1, G, N*P, Kp]), the GEMM runs over N*P columns and the
+    P candidates of a column group share one reference column; scores come back as [P, ...] all the same.
+    ``ref_transposed``: ref is stored [G, N, M].  ``row_scale`` / ``row_bias``: optional per-row factor / offset [M].
     Returns fp32 scores of shape [C, (gmod if keep_h) * (N if keep_n)].
     """
     lib = _lib.load()
     sa, sb = sa.checked(), sb.checked()
     bias = None if bias is None else bias.checked()
     Kp = A.shape[-1]
-    n_cols = N * ref_div                      # GEMM columns
+    n_cols = N * ref_div
     c_grid = 1 if ref_div > 1 else C
     assert B.shape[-1] == Kp and A.shape[-2] == M and B.shape[-2] == n_cols
     assert A.dtype == _TORCH_DT[dtype] and B.dtype == _TORCH_DT[dtype] and A.is_contiguous() and B.is_contiguous()
@@ -183,7 +191,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
         ldr, ref_cs = ref.shape[-1], 1
     sRg = 0 if G == 1 else ref.shape[-1] * ref.shape[-2]
     reduce_cols = 0 if (keep_n or ref_div > 1) else 1
-    n_part = lib.adalog_gemm_score_partial_elems(M, N, C, G, reduce_cols)
+    n_part, MT, Npad = _layout(M, n_cols, c_grid, G, ref_div, reduce_cols)
     partial = torch.empty(n_part, dtype=torch.float32, device=A.device)
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -194,6 +202,8 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
                                0 if bias is None else bias.n,
+                               _ptr(None if row_scale is None else _f32c(row_scale, "row_scale")),
+                               _ptr(None if row_bias is None else _f32c(row_bias, "row_bias")),
                                partial.data_ptr(), n_part, None, 0, 0, 0, int(order), reduce_cols, _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
@@ -201,8 +211,9 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     _lib.check(rc, "adalog_gemm_score")
     cols = (gmod if keep_h else 1) * (N if keep_n else 1)
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
-    rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), M, N, C, G, gmod, int(keep_h), int(keep_n),
-                                  reduce_cols, float(norm), _stream())
+    n_last = Npad if reduce_cols else N                 # reduced: one partial per n-tile (Npad = NT)
+    rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), MT, n_last, Npad, C, G, gmod, int(keep_h),
+                                  int(keep_n), float(norm), _stream())
     _lib.check(rc, "adalog_finish_scores")
     return scores
 
@@ -222,7 +233,7 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
                                sa.t.data_ptr(), sa.c, sa.g, float(sa_mul), sb.t.data_ptr(), sb.c, sb.g, sb.n,
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,
-                               0 if bias is None else bias.n,
+                               0 if bias is None else bias.n, None, None,
                                None, 0, out.data_ptr(), N, 0, M * N, 0, 0, _stream())
     _lib.check(rc, "adalog_gemm_score(out)")
     return out

@@ -212,7 +212,11 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
                                wq.n_bits, dt, want_rowsum=want_rowsum)
 
     def _score_a(self, wp, scale, zp):
-        """linear.py:394-423 -> scores [P, 1] = -sum_images mean_{tokens,out} (raw_out - fq_p(x) . q_w(W)^T - b)^2."""
+        """linear.py:394-423 -> scores [P, 1] = -sum_images mean_{tokens,out} (raw_out - fq_p(x) . q_w(W)^T - b)^2.
+
+        Evaluated transposed, out^T = q_w(W) . fq_p(x)^T: GEMM rows = output channels, GEMM columns = (token, candidate)
+        with the candidates innermost, so the 128 candidates of a token share one reference column and the weight scale /
+        bias become per-row factors of the epilogue."""
         be = backend.get()
         aq = self.a_quantizer
         x3 = self._x2().unsqueeze(0)
@@ -220,14 +224,16 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         P = scale.shape[0]
         out = []
         chunk = self._cand_chunk(M, pad_k(self.in_features, I8))
-        bias = None if self.bias is None else Strided(self.bias.data, n=1)
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
-            xp = be.pack_uniform(x3, sc, zc, e - s, 1, 1, 0, 0, aq.n_bits, I8)
-            out.append(be.gemm_score(I8, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2(),
-                                     Strided(sc, c=1), Strided(self.w_quantizer.scale.data.view(-1), n=1), bias,
-                                     False, False, 1.0 / (self._tokens_per_image() * self.out_features)))
+            xp = be.pack_uniform(x3, sc, zc, e - s, 1, 1, 0, 0, aq.n_bits, I8, c_inner=True)
+            out.append(be.gemm_score(I8, wp, xp, self.out_features, M, e - s, 1, 1, self._ref2(),
+                                     Strided(search.const_tensor([1.0], x3.device)), Strided(sc, c=1), None,
+                                     False, False, 1.0 / (self._tokens_per_image() * self.out_features),
+                                     ref_div=e - s, order=2, ref_transposed=True,
+                                     row_scale=self.w_quantizer.scale.data.view(-1),
+                                     row_bias=None if self.bias is None else self.bias.data))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _score_w_self(self, scale, zp):
@@ -417,7 +423,8 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         return BF16, xp, Strided(aq.scale.data.view(-1)), self._ts32(), aq.shift.data
 
     def _score_scale_logbase(self, wp, bias_fold, scale, qv):
-        """linear.py:816-848 / 856-890 / 898-931 -> scores [P, 1] for per-candidate (scale_p, q_p)."""
+        """linear.py:816-848 / 856-890 / 898-931 -> scores [P, 1] for per-candidate (scale_p, q_p); transposed like
+        _score_a (rows = output channels, columns = (token, candidate))."""
         be = backend.get()
         aq = self.a_quantizer
         dev = self.weight.device
@@ -429,11 +436,13 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, qc = scale[s:e].contiguous(), qv[s:e].contiguous()
-            xp = be.pack_adalog(x3, sc, qc, e - s, 1, 1, 0, aq.n_bits, self._mant37(dev), shift=aq.shift.data, clamp_u=True)
-            out.append(be.gemm_score(BF16, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2(),
-                                     Strided(sc, c=1), Strided(self.w_quantizer.scale.data.view(-1), n=1),
-                                     Strided(bias_fold, n=1), False, False,
-                                     1.0 / (self._tokens_per_image() * self.out_features), sa_mul=self._ts32()))
+            xp = be.pack_adalog(x3, sc, qc, e - s, 1, 1, 0, aq.n_bits, self._mant37(dev), shift=aq.shift.data, clamp_u=True,
+                                c_inner=True)
+            out.append(be.gemm_score(BF16, wp, xp, self.out_features, M, e - s, 1, 1, self._ref2(),
+                                     Strided(search.const_tensor([1.0], dev)), Strided(sc, c=1), None, False, False,
+                                     1.0 / (self._tokens_per_image() * self.out_features), sa_mul=self._ts32(),
+                                     ref_div=e - s, order=2, ref_transposed=True,
+                                     row_scale=self.w_quantizer.scale.data.view(-1), row_bias=bias_fold))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def activation_fpcs(self, ud_candidates, base_num=8, scale_num=16, fpcs_width=32, steps=6):

@@ -89,21 +89,26 @@ int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t
  * partial must hold adalog_gemm_score_partial_elems(M, N, C, G) floats. */
 int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc, int64_t sBg, int M,
                       int N, int64_t Kp, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int64_t ref_cs,
-                      int ref_div,
-                      const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
+                      int ref_div, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
                       int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n,
-                      float* partial, int64_t partial_elems, float* out, int64_t ldo, int64_t sOc, int64_t sOg, int order,
-                      int reduce_cols, void* stream);
-int64_t adalog_gemm_score_partial_elems(int M, int N, int C, int G, int reduce_cols);
+                      const float* row_scale, const float* row_bias, float* partial, int64_t partial_elems, float* out,
+                      int64_t ldo, int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream);
+/* row_scale / row_bias (optional, C = 1): out[m][n] = (D*alpha) * row_scale[m] + row_bias[m] + bias -- the activation
+ * searches run transposed (rows = output channels, columns = (token, candidate)), so the per-channel weight scale and
+ * the layer bias are per-ROW there.
+ * Layout of `partial`: [c_eff][G][MT][Npad]; adalog_gemm_score_layout returns its size and (MT, Npad) for the given
+ * problem (two tilings exist: 128x128 for C > 1, (64..256)x256 with 128-byte K-steps when C = 1). */
+int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int* MT, int* Npad);
 
-/* scores[c][h?][n?] = -norm * sum_{image = g/gmod, (h), m_tile, (n)} partial[c][g][m_tile][n], accumulated in fp64 in a
+/* scores[c][h?][n?] = -norm * sum_{image = g/gmod, (h), m_tile, (n < N)} partial[c][g][m_tile][n] (layout MT, Npad from
+ * adalog_gemm_score_layout; C = c_eff), accumulated in fp64 in a
  * fixed order (deterministic).  keep_h / keep_n select which axes survive:
  *   Linear weight search  keep_n=1 -> [P][O]   (linear.py:378-385, norm = 1/T)
  *   Linear act. search    keep_n=0 -> [P]      (linear.py:415-424, norm = 1/(T*O))
  *   MatMul per head       keep_h=1 -> [P][H]   (matmul.py:154-164, norm = 1/(S*S'))
  *   post-softmax base     none     -> [P]      (matmul.py:345-352, norm = 1/(H*S*S')) */
-int adalog_finish_scores(const float* partial, float* scores, int M, int N, int C, int G, int gmod, int keep_h, int keep_n,
-                         int reduced_cols, double norm, void* stream);
+int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
+                         int keep_n, double norm, void* stream);
 
 /* ---- K16  FPCS driver pieces                 reference linear.py:483-523, matmul.py:243-262, conv.py:292-311
  * adalog_topk: idx[j][col] = candidate with the j-th best score of column col, j < k; order (score desc, index asc),

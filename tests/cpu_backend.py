@@ -120,12 +120,16 @@ def _gemm(dtype, A, B, C, G):
 
 
 def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1, order=1,
-               ref_transposed=False):
+               ref_transposed=False, row_scale=None, row_bias=None):
     if ref_div > 1:                               # columns = (n, candidate): un-interleave back to [C, G, N, Kp]
         B = B.view(G, N, ref_div, -1).permute(2, 0, 1, 3)
     D = _gemm(dtype, A, B, C, G)                                            # [C, G, M, N]
     alpha = (_epi(sa, C, G, gmod, 1) * float(torch.tensor(sa_mul, dtype=torch.float32))) * _epi(sb, C, G, gmod, N)
     out = D * alpha.unsqueeze(2)
+    if row_scale is not None:
+        out = out * row_scale.double().view(1, 1, M, 1)
+        if row_bias is not None:
+            out = out + row_bias.double().view(1, 1, M, 1)
     if bias is not None:
         out = out + _epi(bias, C, G, gmod, N).unsqueeze(2)
     r = (ref.reshape(G, N, M).transpose(1, 2) if ref_transposed else ref.reshape(G, M, -1)).double()

@@ -447,3 +447,32 @@ def test_adaround_and_round_loss(ops):
         l = ops.round_loss(alpha.to(DEV), b, galpha=ga, gscale=0.5)
         torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(ga.cpu(), ga_ref, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["i8", "bf16"])
+@pytest.mark.parametrize("M", [64, 100, 197, 384, 600])
+def test_gemm_cand_kernel_row_scale_and_tiles(ops, dtype, M):
+    """Large-tile kernel (C = 1, candidates in columns): every row-tile size, K tails of 64 and 128 bytes, transposed
+    reference, per-row scale/bias -- against the CPU specification."""
+    gen = g(900 + M)
+    dt_c, dt_o = (CB.I8, ops.I8) if dtype == "i8" else (CB.BF16, ops.BF16)
+    tdt = torch.int8 if dtype == "i8" else torch.bfloat16
+    P, Ncols, G, gmod = 128, 37, 4, 2
+    for K in (64, 200):
+        Kp = CB.pad_k(K, dt_c)
+        A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
+        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).to(tdt)
+        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).to(tdt)
+        ref = torch.randn(G, Ncols, M, generator=gen) * 3                      # stored [G, N, M] (transposed)
+        sa = torch.rand(gmod, generator=gen) * 0.02 + 0.01
+        sb = torch.rand(P, gmod, generator=gen) * 0.5 + 0.5
+        rs = torch.rand(M, generator=gen) + 0.5; rb = torch.randn(M, generator=gen)
+        for keep_h in (True, False):
+            want = CB.gemm_score(dt_c, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa, g=1), CB.Strided(sb, c=gmod, g=1), None,
+                                 keep_h, False, 0.01, sa_mul=0.5, ref_div=P, ref_transposed=True, row_scale=rs, row_bias=rb)
+            for order in (1, 2):
+                got = ops.gemm_score(dt_o, A.to(DEV), B.to(DEV), M, Ncols, P, G, gmod, ref.to(DEV),
+                                     ops.Strided(sa.to(DEV), g=1), ops.Strided(sb.to(DEV), c=gmod, g=1), None, keep_h, False,
+                                     0.01, sa_mul=0.5, ref_div=P, order=order, ref_transposed=True, row_scale=rs.to(DEV),
+                                     row_bias=rb.to(DEV))
+                assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (K, keep_h, order, rel_err(got.cpu(), want))

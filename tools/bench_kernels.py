@@ -55,10 +55,11 @@ for name, I, O in (("qkv", 384, 1152), ("proj", 384, 384), ("fc1", 384, 1536), (
     t_gw = timeit(lambda: ops.gemm_score(ops.I8, xp, wp, M, O, P, 1, 1, ref, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True,
                                          1.0 / T, ref_div=P, order=2))
     wfix = ops.pack_uniform(W, ws, wz, 1, 0, 1, 0, 1, 4, ops.I8)
-    t_pa = timeit(lambda: ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8))
-    xP = ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8)
-    t_ga = timeit(lambda: ops.gemm_score(ops.I8, xP, wfix, M, O, P, 1, 1, ref, S(csa, c=1), S(ws, n=1), S(bias, n=1), False, False,
-                                         1.0 / (T * O), order=1))
+    one = torch.ones(1, device=dev)
+    t_pa = timeit(lambda: ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8, c_inner=True))
+    xP = ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8, c_inner=True)
+    t_ga = timeit(lambda: ops.gemm_score(ops.I8, wfix, xP, O, M, P, 1, 1, ref, S(one), S(csa, c=1), None, False, False,
+                                         1.0 / (T * O), ref_div=P, order=2, ref_transposed=True, row_scale=ws, row_bias=bias))
     print(f"{name:5s} i8  W-search: pack {t_pw*1e3:7.0f} us  gemm {t_gw*1e3:7.0f} us = {fl/t_gw/1e9:7.1f} TOPS | "
           f"A-search: pack {t_pa*1e3:7.0f} us ({P*M*I/t_pa/1e6:6.1f} GB/s out) gemm {t_ga*1e3:7.0f} us = {fl/t_ga/1e9:7.1f} TOPS", flush=True)
     if name == "fc2":
@@ -67,11 +68,12 @@ for name, I, O in (("qkv", 384, 1152), ("proj", 384, 384), ("fc1", 384, 1536), (
         cs = torch.rand(P, device=dev) * 2 + 2
         sh = torch.tensor([0.17], device=dev)
         xg = torch.nn.functional.gelu(x * 2)
-        t_pl = timeit(lambda: ops.pack_adalog(xg, cs, qv, P, 1, 1, 0, 4, mant, sh, True))
-        xL = ops.pack_adalog(xg, cs, qv, P, 1, 1, 0, 4, mant, sh, True)
+        t_pl = timeit(lambda: ops.pack_adalog(xg, cs, qv, P, 1, 1, 0, 4, mant, sh, True, c_inner=True))
+        xL = ops.pack_adalog(xg, cs, qv, P, 1, 1, 0, 4, mant, sh, True, c_inner=True)
         wb = ops.pack_uniform(W, ws, wz, 1, 0, 1, 0, 1, 4, ops.BF16)
-        t_gl = timeit(lambda: ops.gemm_score(ops.BF16, xL, wb, M, O, P, 1, 1, ref, S(cs, c=1), S(ws, n=1), S(bias, n=1), False,
-                                             False, 1.0 / (T * O), sa_mul=1 / 30.0, order=1))
+        t_gl = timeit(lambda: ops.gemm_score(ops.BF16, wb, xL, O, M, P, 1, 1, ref, S(one), S(cs, c=1), None, False, False,
+                                             1.0 / (T * O), sa_mul=1 / 30.0, ref_div=P, order=2, ref_transposed=True,
+                                             row_scale=ws, row_bias=bias))
         print(f"{name:5s} bf16 A-search (AdaLog): pack {t_pl*1e3:7.0f} us ({2*P*M*I/t_pl/1e6:6.1f} GB/s out)  gemm {t_gl*1e3:7.0f} us "
               f"= {fl/t_gl/1e9:7.1f} TFLOPS", flush=True)
 if not args.only or "matmul" in args.only:
