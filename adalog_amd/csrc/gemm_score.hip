@@ -241,6 +241,66 @@ constexpr int BN2 = 256, BK2 = 128;
 
 __device__ __forceinline__ int swz2(int row, int slot) { return row * BK2 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
+// Epilogue of the large-tile kernel, specialised at compile time so the unrolled body is branch-free:
+//   STORE: write out (quant_forward) / else: squared error against ref;  EDGE: tile touches the M or N boundary;
+//   ROWS: per-row scale and bias present.
+template <int DT, int TM, bool STORE, bool EDGE, bool ROWS>
+__device__ __forceinline__ void epilogue2(const GemmArgs& p, typename Acc<DT>::type (&acc)[TM][2], int g, int gh, int m0,
+                                          int n0, int wr, int wc, int frow, int fkg, float* red) {
+    constexpr int BM2 = 64 * TM;
+    const float* refg = STORE ? nullptr : p.ref + (int64_t)g * p.sRg;
+    float* outg = STORE ? p.out + (int64_t)g * p.sOg : nullptr;
+    const int ldr = (int)p.ldr, rcs = (int)p.ref_cs, ldo = (int)p.ldo;
+    float alpha[2], beta[2], cm[2], csum[2] = {0.0f, 0.0f};
+    int rc0[2], colj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + frow;
+        const bool cv = !EDGE || col < p.N;
+        colj[j] = col;
+        const int colc = cv ? col : p.N - 1;
+        const int ci = p.ref_div > 1 ? colc % p.ref_div : 0;
+        const int ni = p.ref_div > 1 ? colc / p.ref_div : colc;
+        alpha[j] = p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g + ni * p.sb_n];
+        beta[j] = p.bias ? p.bias[ci * p.bi_c + gh * p.bi_g + ni * p.bi_n] : 0.0f;
+        rc0[j] = ni * rcs;
+        cm[j] = cv ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int rb0 = m0 + wr * (BM2 / 2) + i * 32 + 4 * fkg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rb0 + (r & 3) + 8 * (r >> 2);
+            if (!EDGE || row < p.M) {                   // edge tiles (rare) predicate whole rows; interior tiles have no branch
+                float rs = 1.0f, rbv = 0.0f;
+                if (ROWS) { rs = p.row_scale[row]; rbv = p.row_bias[row]; }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float o = (float)acc[i][j][r] * alpha[j];
+                    if (ROWS) o = o * rs + rbv;
+                    o += beta[j];
+                    if (STORE) {
+                        if (!EDGE || cm[j] != 0.0f) outg[row * ldo + colj[j]] = o;
+                    } else {
+                        const float e = refg[row * ldr + rc0[j]] - o;
+                        csum[j] += EDGE ? (e * e) * cm[j] : e * e;
+                    }
+                }
+            }
+            if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (!STORE) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float cs = csum[j];
+            cs += __shfl_xor(cs, 32);
+            if (fkg == 0) red[((wr * 4 + wc) * 2 + j) * 32 + frow] = cs;
+        }
+    }
+}
+
 template <int DT, int TM, bool STORE>
 __global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
     constexpr int BM2 = 64 * TM;
@@ -257,31 +317,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
     int nt, mt, g;
     if (p.order == 2) { mt = t % p.MT; t /= p.MT; nt = t % p.NT; g = t / p.NT; }
     else { nt = t % p.NT; t /= p.NT; mt = t % p.MT; g = t / p.MT; }
-    const int c = 0;
     const int gh = g % p.gmod;
     const int m0 = mt * BM2, n0 = nt * BN2;
-    const uint8_t* Ag = p.A + g * p.sAg;
-    const uint8_t* Bg = p.B + g * p.sBg;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 2, wc = w & 3;
     const int lrow = tid >> 3, lslot = tid & 7;
-    const uint4* ga[TM];
-    const uint4* gb[4];
-    int soa[TM], sob[4];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int r = m0 + lrow + 64 * i;
-        r = r < p.M ? r : p.M - 1;
-        ga[i] = reinterpret_cast<const uint4*>(Ag + (int64_t)r * p.Kb) + lslot;
-        soa[i] = swz2(lrow + 64 * i, lslot);
+    // per-thread global source addresses (clamped rows at the edges) and swizzled LDS destinations
+    const uint8_t* Ab = p.A + g * p.sAg + lslot * 16;
+    const uint8_t* Bb = p.B + g * p.sBg + lslot * 16;
+    int64_t oa0, oa1, oa2, oa3, ob0, ob1, ob2, ob3;
+    {
+        auto rowoff = [&](int base, int lim) { int r = base < lim ? base : lim - 1; return (int64_t)r * p.Kb; };
+        oa0 = rowoff(m0 + lrow, p.M); oa1 = rowoff(m0 + lrow + 64, p.M);
+        oa2 = rowoff(m0 + lrow + 128, p.M); oa3 = rowoff(m0 + lrow + 192, p.M);
+        ob0 = rowoff(n0 + lrow, p.N); ob1 = rowoff(n0 + lrow + 64, p.N);
+        ob2 = rowoff(n0 + lrow + 128, p.N); ob3 = rowoff(n0 + lrow + 192, p.N);
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r = n0 + lrow + 64 * i;
-        r = r < p.N ? r : p.N - 1;
-        gb[i] = reinterpret_cast<const uint4*>(Bg + (int64_t)r * p.Kb) + lslot;
-        sob[i] = swz2(lrow + 64 * i, lslot);
-    }
+    const int s0 = swz2(lrow, lslot), s1 = swz2(lrow + 64, lslot), s2 = swz2(lrow + 128, lslot), s3 = swz2(lrow + 192, lslot);
 
     typename Acc<DT>::type acc[TM][2];
 #pragma unroll
@@ -291,105 +343,69 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
 
-    const int nk = (int)((p.Kb + BK2 - 1) / BK2);
-    const int ktail = (int)(p.Kb - (int64_t)(nk - 1) * BK2);           // bytes valid in the last step: 64 or 128
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
-    uint4 ra[TM], rb[4];
-    auto gload = [&](int kt) {
-        const bool ok = (kt < nk - 1) || (lslot * 16 < ktail);
-        const int o = kt * (BK2 / 16);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) ra[i] = ok ? ga[i][o] : zero4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = ok ? gb[i][o] : zero4;
-    };
-    auto sstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) *reinterpret_cast<uint4*>(As + soa[i]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(Bs + sob[i]) = rb[i];
-    };
-    gload(0);
-    sstore();
+    const int nk = (int)(p.Kb / BK2);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    ra1 = ra2 = ra3 = make_uint4(0, 0, 0, 0);
+#define GLOAD(KT)                                                                              \
+    do {                                                                                       \
+        const int64_t ko = (int64_t)(KT) * BK2;                                                \
+        ra0 = *reinterpret_cast<const uint4*>(Ab + oa0 + ko);                                  \
+        if (TM >= 2) ra1 = *reinterpret_cast<const uint4*>(Ab + oa1 + ko);                     \
+        if (TM >= 4) { ra2 = *reinterpret_cast<const uint4*>(Ab + oa2 + ko);                   \
+                       ra3 = *reinterpret_cast<const uint4*>(Ab + oa3 + ko); }                 \
+        rb0 = *reinterpret_cast<const uint4*>(Bb + ob0 + ko);                                  \
+        rb1 = *reinterpret_cast<const uint4*>(Bb + ob1 + ko);                                  \
+        rb2 = *reinterpret_cast<const uint4*>(Bb + ob2 + ko);                                  \
+        rb3 = *reinterpret_cast<const uint4*>(Bb + ob3 + ko);                                  \
+    } while (0)
+#define SSTORE()                                                                               \
+    do {                                                                                       \
+        *reinterpret_cast<uint4*>(As + s0) = ra0;                                              \
+        if (TM >= 2) *reinterpret_cast<uint4*>(As + s1) = ra1;                                 \
+        if (TM >= 4) { *reinterpret_cast<uint4*>(As + s2) = ra2;                               \
+                       *reinterpret_cast<uint4*>(As + s3) = ra3; }                             \
+        *reinterpret_cast<uint4*>(Bs + s0) = rb0; *reinterpret_cast<uint4*>(Bs + s1) = rb1;    \
+        *reinterpret_cast<uint4*>(Bs + s2) = rb2; *reinterpret_cast<uint4*>(Bs + s3) = rb3;    \
+    } while (0)
+    GLOAD(0);
+    SSTORE();
     __syncthreads();
 
     const int frow = lane & 31, fkg = lane >> 5;
+    const int arow = wr * (BM2 / 2) + frow, brow = wc * 64 + frow;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
-        const int nks = (kt == nk - 1) ? (ktail >> 5) : 4;
+        if (kt + 1 < nk) GLOAD(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks < nks) {
-                uint4 af[TM], bf[2];
+            uint4 af[TM], bf[2];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(As + swz2(wr * (BM2 / 2) + i * 32 + frow, ks * 2 + fkg));
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(As + swz2(arow + i * 32, ks * 2 + fkg));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bs + swz2(wc * 64 + j * 32 + frow, ks * 2 + fkg));
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bs + swz2(brow + j * 32, ks * 2 + fkg));
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) mma<DT>(af[i], bf[j], acc[i][j]);
-            }
+                for (int j = 0; j < 2; ++j) mma<DT>(af[i], bf[j], acc[i][j]);
         }
         if (kt + 1 < nk) {
             __syncthreads();
-            sstore();
+            SSTORE();
             __syncthreads();
         }
     }
+#undef GLOAD
+#undef SSTORE
 
-    // ---- epilogue (same contract as k_gemm_score; adds the optional per-row scale / bias)
-    const float* refg = p.ref ? p.ref + (int64_t)g * p.sRg : nullptr;
-    float* outg = STORE ? p.out + (int64_t)g * p.sOg : nullptr;
-    const int ldr = (int)p.ldr, rcs = (int)p.ref_cs, ldo = (int)p.ldo;
-    const bool interior = (m0 + BM2 <= p.M) && (n0 + BN2 <= p.N);
-    float alpha[2], beta[2], cm[2], csum[2] = {0.0f, 0.0f};
-    int rc0[2], colj[2];
-    bool cvj[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wc * 64 + j * 32 + frow;
-        cvj[j] = col < p.N;
-        colj[j] = col;
-        const int colc = cvj[j] ? col : p.N - 1;
-        const int ci = p.ref_div > 1 ? colc % p.ref_div : c;
-        const int ni = p.ref_div > 1 ? colc / p.ref_div : colc;
-        alpha[j] = p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g + ni * p.sb_n];
-        beta[j] = p.bias ? p.bias[ci * p.bi_c + gh * p.bi_g + ni * p.bi_n] : 0.0f;
-        rc0[j] = ni * rcs;
-        cm[j] = cvj[j] ? 1.0f : 0.0f;
+    const bool edge = (m0 + BM2 > p.M) || (n0 + BN2 > p.N);
+    const bool rows = p.row_scale != nullptr;
+    if (edge) {
+        if (rows) epilogue2<DT, TM, STORE, true, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
+        else epilogue2<DT, TM, STORE, true, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
+    } else {
+        if (rows) epilogue2<DT, TM, STORE, false, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
+        else epilogue2<DT, TM, STORE, false, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int rb0 = m0 + wr * (BM2 / 2) + i * 32 + 4 * fkg;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = rb0 + (r & 3) + 8 * (r >> 2);
-            const bool rv = interior || row < p.M;
-            const int rowc = rv ? row : p.M - 1;
-            const float rs = p.row_scale ? p.row_scale[rowc] : 1.0f;
-            const float rbv = p.row_bias ? p.row_bias[rowc] : 0.0f;
-            const float rw = rv ? 1.0f : 0.0f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float o = (float)acc[i][j][r] * alpha[j];
-                if (p.row_scale) o = o * rs + rbv;
-                o += beta[j];
-                if (STORE) { if (interior || (rv && cvj[j])) outg[rowc * ldo + colj[j]] = o; }
-                if (refg) {
-                    const float e = refg[rowc * ldr + rc0[j]] - o;
-                    csum[j] += interior ? e * e : (e * e) * (rw * cm[j]);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        float cs = csum[j];
-        cs += __shfl_xor(cs, 32);
-        if (fkg == 0) red[((wr * 4 + wc) * 2 + j) * 32 + frow] = cs;
-    }
-    if (p.partial) {
+    if (!STORE && p.partial) {
         __syncthreads();
         float v = 0.0f;
         const int col = n0 + tid;                                      // tid < 256: column tid of the tile
@@ -507,13 +523,14 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 2, "gemm_score: dtype must be 0 (i8), 1 (bf16) or 2 (f32)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
     const int esz = dtype == 0 ? 1 : dtype == 1 ? 2 : 4;
-    ADALOG_ARG_CHECK((Kp * esz) % BKB == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 64 bytes");
+    ADALOG_ARG_CHECK((Kp * esz) % BK2 == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 128 bytes");
     ADALOG_ARG_CHECK((partial != nullptr) == (ref != nullptr), "gemm_score: partial and ref go together");
     ADALOG_ARG_CHECK(partial || out, "gemm_score: nothing to produce");
     ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
     ADALOG_ARG_CHECK(ref_div == 1 || (C == 1 && N % ref_div == 0 && !out), "gemm_score: ref_div > 1 needs C == 1, N % ref_div == 0, no out");
     ADALOG_ARG_CHECK(!(reduce_cols && ref_div > 1), "gemm_score: reduce_cols and ref_div > 1 are exclusive");
-    ADALOG_ARG_CHECK(!row_scale || C == 1, "gemm_score: per-row scale needs C == 1");
+    ADALOG_ARG_CHECK(!row_scale || (C == 1 && row_bias), "gemm_score: per-row scale needs C == 1 and a row_bias vector");
+    ADALOG_ARG_CHECK(!(partial && out), "gemm_score: either score against ref or store out, not both");
     const Layout L = layout_of(M, N, C, ref_div, reduce_cols);
     GemmArgs p{};
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;

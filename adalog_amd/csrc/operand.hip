@@ -224,8 +224,8 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
                                    int32_t* rowsum, int c_inner, void* stream) {
     ADALOG_ARG_CHECK(x && scale && zero_point && out, "pack_uniform: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_uniform: bad sizes");
-    ADALOG_ARG_CHECK(Kp >= K && (Kp * (out_dtype == 0 ? 1 : out_dtype == 1 ? 2 : 4)) % 64 == 0,
-                     "pack_uniform: Kp must cover K and be a multiple of 64 bytes");
+    ADALOG_ARG_CHECK(Kp >= K && (Kp * (out_dtype == 0 ? 1 : out_dtype == 1 ? 2 : 4)) % 128 == 0,
+                     "pack_uniform: Kp must cover K and be a multiple of 128 bytes");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_uniform: n_bits must be in [2,7] (q - z must fit int8)");
     hipStream_t st = (hipStream_t)stream;
     PackArgs a{};
@@ -250,7 +250,7 @@ extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int
                                        int clamp_u, void* out, int64_t Kp, int c_inner, void* stream) {
     ADALOG_ARG_CHECK(x && scale && qv && mant37 && out, "pack_adalog: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_adalog: bad sizes");
-    ADALOG_ARG_CHECK(Kp >= K && (Kp * 2) % 64 == 0, "pack_adalog: Kp must cover K and be a multiple of 32 elements");
+    ADALOG_ARG_CHECK(Kp >= K && (Kp * 2) % 128 == 0, "pack_adalog: Kp must cover K and be a multiple of 64 elements");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_adalog: n_bits must be in [2,7] (numerators must fit bf16)");
     PackArgs a{};
     a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk;
@@ -265,7 +265,7 @@ extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int
 extern "C" int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
                                    void* out, int64_t Kp, void* stream) {
     ADALOG_ARG_CHECK(x && out && G >= 1 && R >= 1 && K >= 1, "pack_raw: bad arguments");
-    ADALOG_ARG_CHECK(Kp >= K && Kp % 16 == 0, "pack_raw: Kp must cover K and be a multiple of 16 elements");
+    ADALOG_ARG_CHECK(Kp >= K && Kp % 32 == 0, "pack_raw: Kp must cover K and be a multiple of 32 elements");
     PackArgs a{};
     a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk; a.C = 1; a.gmod = 1;
     a.out = out; a.Kp = Kp;

@@ -37,7 +37,7 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def pad_k(K: int, dtype: int) -> int:
-    per = 64 // _ESZ[dtype]
+    per = 128 // _ESZ[dtype]
     return ((K + per - 1) // per) * per
 
 

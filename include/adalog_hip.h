@@ -46,7 +46,7 @@ int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n
 
 /* ---- operand packing for the scoring GEMMs (prologue of K7/K8/K11-K15)
  * Input: fp32 view x[g][r][k] with element strides (sxg, sxr, sxk), g < G, r < R, k < K.
- * Output: out[c][g][r][Kp], K-contiguous, zero padded to Kp (Kp * sizeof(elem) a multiple of 64 bytes);
+ * Output: out[c][g][r][Kp], K-contiguous, zero padded to Kp (Kp * sizeof(elem) a multiple of 128 bytes = one cache line);
  *   adalog_pack_uniform / adalog_pack_adalog_bf16 with c_inner = 1 write out[g][r][c][Kp] instead (candidates innermost, see ref_div below).
  * Parameter addressing for candidate c: idx = c*pc + (g % gmod)*pg + r*pr.
  * out_dtype: 0 = int8, 1 = bf16, 2 = fp32.

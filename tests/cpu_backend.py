@@ -18,7 +18,7 @@ _TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32}
 
 
 def pad_k(K, dtype):
-    per = 64 // _ESZ[dtype]
+    per = 128 // _ESZ[dtype]
     return ((K + per - 1) // per) * per
 
 
