@@ -473,10 +473,11 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
 }  // namespace
 
 // ---- tile selection shared by launch, layout query and finish
-static int pick_tm(int M) {
-    // largest row tile whose padding waste stays within 10 % of the best achievable
+static int pick_tm(int M, bool scoring) {
+    // largest row tile whose padding waste stays within 10 % of the best achievable.  The scoring epilogue keeps more
+    // state than the store epilogue: with TM = 4 (128 accumulator VGPRs) it spills, so scoring launches use TM <= 2.
     double best = 0.0;
-    int tms[3] = {4, 2, 1};
+    int tms[3] = {scoring ? 2 : 4, 2, 1};
     double util[3];
     for (int i = 0; i < 3; ++i) {
         const int bm = 64 * tms[i];
@@ -490,10 +491,10 @@ static int pick_tm(int M) {
 
 struct Layout { int big, tm, MT, NT, Npad, c_eff, n_eff; int64_t elems; };
 
-static Layout layout_of(int M, int N, int C, int ref_div, int reduce_cols) {
+static Layout layout_of(int M, int N, int C, int ref_div, int reduce_cols, bool scoring = true) {
     Layout L{};
     L.big = (C == 1);
-    L.tm = L.big ? pick_tm(M) : 2;
+    L.tm = L.big ? pick_tm(M, scoring) : 2;
     const int bm = L.big ? 64 * L.tm : BM, bn = L.big ? BN2 : BN;
     L.MT = cdiv(M, bm);
     L.NT = cdiv(N, bn);
@@ -531,7 +532,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(!(reduce_cols && ref_div > 1), "gemm_score: reduce_cols and ref_div > 1 are exclusive");
     ADALOG_ARG_CHECK(!row_scale || (C == 1 && row_bias), "gemm_score: per-row scale needs C == 1 and a row_bias vector");
     ADALOG_ARG_CHECK(!(partial && out), "gemm_score: either score against ref or store out, not both");
-    const Layout L = layout_of(M, N, C, ref_div, reduce_cols);
+    const Layout L = layout_of(M, N, C, ref_div, reduce_cols, out == nullptr);
     GemmArgs p{};
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
     p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;

@@ -225,8 +225,8 @@ def test_gemm_score_transpose_detecting(ops):
 
 def test_gemm_score_deterministic(ops):
     gen = g(7)
-    A = torch.randint(-8, 8, (8, 1, 1000, 192), generator=gen).to(torch.int8).to(DEV)
-    B = torch.randint(-8, 8, (1, 1, 300, 192), generator=gen).to(torch.int8).to(DEV)
+    A = torch.randint(-8, 8, (8, 1, 1000, 256), generator=gen).to(torch.int8).to(DEV)
+    B = torch.randint(-8, 8, (1, 1, 300, 256), generator=gen).to(torch.int8).to(DEV)
     ref = torch.randn(1, 1000, 300, generator=gen).to(DEV)
     s = torch.rand(8, generator=gen).to(DEV) * 0.01; sb = torch.rand(300, generator=gen).to(DEV)
     run = lambda: ops.gemm_score(ops.I8, A, B, 1000, 300, 8, 1, 1, ref, ops.Strided(s, c=1), ops.Strided(sb, n=1), None,
