@@ -17,6 +17,10 @@
 // XCD-aware block order so the workgroups sharing an A tile sit on one XCD's L2.
 #include "common.h"
 
+// The quantisation kernels are compiled without FMA contraction (bin indices must round like the reference); this file
+// holds no bin-defining arithmetic, so the epilogues may fuse multiply-adds.
+#pragma clang fp contract(fast)
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -301,6 +305,86 @@ __device__ __forceinline__ void epilogue2(const GemmArgs& p, typename Acc<DT>::t
     }
 }
 
+// Scoring epilogue with the reference slice staged through LDS (candidates-in-columns layout, rows contiguous in ref:
+// ldr == 1).  The tile needs only (256 / ref_div) reference columns x BM2 rows (1-4 KiB instead of BM2 x 256 values):
+// they are fetched with one coalesced pass, and each thread then reads four consecutive rows per ds_read_b128.
+template <int DT, int TM, bool EDGE, bool ROWS>
+__device__ __forceinline__ void epilogue_lds(const GemmArgs& p, typename Acc<DT>::type (&acc)[TM][2], int g, int gh, int m0,
+                                             int n0, int wr, int wc, int frow, int fkg, float* red, float* stage) {
+    constexpr int BM2 = 64 * TM;
+    const float* refg = p.ref + (int64_t)g * p.sRg;
+    const int rcs = (int)p.ref_cs;
+    const int nref = BN2 / p.ref_div;                       // reference columns touched by this tile (<= 8)
+    const int ni0 = n0 / p.ref_div;
+    const int nvalid = (p.N / p.ref_div) - ni0;              // reference columns that exist
+    float* refs = stage;                                     // [nref][BM2]
+    float* rsc = stage + 8 * BM2;                            // [BM2]
+    float* rbi = rsc + BM2;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < nref * BM2; e += 512) {
+        const int nl = e / BM2, rl = e - nl * BM2;
+        const int row = m0 + rl;
+        float v = 0.0f;
+        if ((!EDGE || row < p.M) && nl < nvalid) v = refg[row + (ni0 + nl) * rcs];
+        refs[e] = v;
+    }
+    if (ROWS) {
+        for (int e = tid; e < BM2; e += 512) {
+            const int row = m0 + e;
+            const bool ok = !EDGE || row < p.M;
+            rsc[e] = ok ? p.row_scale[row] : 0.0f;
+            rbi[e] = ok ? p.row_bias[row] : 0.0f;
+        }
+    }
+    __syncthreads();
+    float alpha[2], beta[2], cm[2], csum[2] = {0.0f, 0.0f};
+    const float* rj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wc * 64 + j * 32 + frow;
+        const bool cv = !EDGE || col < p.N;
+        const int colc = cv ? col : p.N - 1;
+        const int ci = colc % p.ref_div, ni = colc / p.ref_div;
+        alpha[j] = p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g + ni * p.sb_n];
+        beta[j] = p.bias ? p.bias[ci * p.bi_c + gh * p.bi_g + ni * p.bi_n] : 0.0f;
+        cm[j] = cv ? 1.0f : 0.0f;
+        rj[j] = refs + (ni - ni0) * BM2;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int rl = wr * (BM2 / 2) + i * 32 + 4 * fkg + 8 * q4;          // 4 consecutive rows rl .. rl+3
+            const float4 r0 = *reinterpret_cast<const float4*>(rj[0] + rl);
+            const float4 r1 = *reinterpret_cast<const float4*>(rj[1] + rl);
+            float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ROWS) { s4 = *reinterpret_cast<const float4*>(rsc + rl); b4 = *reinterpret_cast<const float4*>(rbi + rl); }
+            const float rr0[4] = {r0.x, r0.y, r0.z, r0.w}, rr1[4] = {r1.x, r1.y, r1.z, r1.w};
+            const float ss[4] = {s4.x, s4.y, s4.z, s4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int r = q4 * 4 + k;
+                float w = 1.0f;
+                if (EDGE) w = (m0 + rl + k < p.M) ? 1.0f : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float o = (float)acc[i][j][r] * alpha[j];
+                    if (ROWS) o = o * ss[k] + bb[k];
+                    o += beta[j];
+                    const float e = (j == 0 ? rr0[k] : rr1[k]) - o;
+                    csum[j] += EDGE ? (e * e) * (w * cm[j]) : e * e;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float cs = csum[j];
+        cs += __shfl_xor(cs, 32);
+        if (fkg == 0) red[((wr * 4 + wc) * 2 + j) * 32 + frow] = cs;
+    }
+}
+
 template <int DT, int TM, bool STORE>
 __global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
     constexpr int BM2 = 64 * TM;
@@ -398,7 +482,18 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
 
     const bool edge = (m0 + BM2 > p.M) || (n0 + BN2 > p.N);
     const bool rows = p.row_scale != nullptr;
-    if (edge) {
+    const bool lds_ref = !STORE && p.ldr == 1 && p.ref_div >= 32 && (BN2 % p.ref_div) == 0;
+    if (lds_ref) {
+        __syncthreads();                                   // every wave is done with the operand tiles: reuse As as staging
+        float* stage = reinterpret_cast<float*>(smem);
+        if (edge) {
+            if (rows) epilogue_lds<DT, TM, true, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+            else epilogue_lds<DT, TM, true, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+        } else {
+            if (rows) epilogue_lds<DT, TM, false, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+            else epilogue_lds<DT, TM, false, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+        }
+    } else if (edge) {
         if (rows) epilogue2<DT, TM, STORE, true, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
         else epilogue2<DT, TM, STORE, true, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
     } else {

@@ -145,7 +145,7 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
             wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, oc, 1, 0, 1, self.w_quantizer.n_bits, F32,
                                  c_inner=True)
             out.append(be.gemm_score(F32, xp, wp, M, oc, e - s, 1, 1, ref, Strided(ones), Strided(sc, c=oc, n=1), bias,
-                                     False, True, 1.0 / fmap, ref_div=e - s, order=2))
+                                     False, True, 1.0 / fmap, ref_div=e - s, order=2, ref_transposed=True))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def weight_fpcs(self, fpcs_width=16, steps=4):
@@ -155,7 +155,7 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
         patches, gh, gw = self._patches(self.raw_input)
         M = patches.shape[0]
         xp = be.pack_raw(patches.unsqueeze(0))
-        ref = self.raw_out.permute(0, 2, 3, 1).reshape(1, M, self.out_channels)
+        ref = self.raw_out.permute(1, 0, 2, 3).reshape(1, self.out_channels, M).contiguous()      # [1, oc, tokens]
         scale, zp, delta = search.weight_grid(self._w2(), self.w_quantizer.n_bits, self.eq_n, conv=True)
         fn = lambda s, z, t: self._score_w(xp, ref, M, gh * gw, s, z)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)

@@ -151,6 +151,15 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
     def _ref2(self):
         return self.raw_out.reshape(1, -1, self.out_features)
 
+    def _ref2_t(self):
+        """raw_out as [1, O, tokens] (one transposing copy per layer): the weight searches walk the reference along the
+        token axis, which the scoring kernel stages through LDS when that axis is contiguous."""
+        key = self.raw_out.data_ptr()
+        if getattr(self, "_ref_t_key", None) != key:
+            self._ref_t = self.raw_out.reshape(-1, self.out_features).t().contiguous().unsqueeze(0)
+            self._ref_t_key = key
+        return self._ref_t
+
     def _w2(self):
         return self.weight.data.view(self.out_features, self.in_features)
 
@@ -200,9 +209,10 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
                                              wq.n_bits, dt, want_rowsum=True, c_inner=True)
                 fold = be.shift_fold(rowsum.view(e - s, -1), sc, shift, None if self.bias is None else self.bias.data)
                 bias = Strided(fold, c=self.out_features, n=1)
-            out.append(be.gemm_score(dt, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2(), sa,
+            out.append(be.gemm_score(dt, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2_t(), sa,
                                      Strided(sc, c=self.out_features, n=1), bias, False, True,
-                                     1.0 / self._tokens_per_image(), sa_mul=sa_mul, ref_div=e - s, order=2))
+                                     1.0 / self._tokens_per_image(), sa_mul=sa_mul, ref_div=e - s, order=2,
+                                     ref_transposed=True))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _pack_w_fixed(self, dt=I8, want_rowsum=False):
@@ -281,6 +291,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             self.activation_fpcs(steps=self.steps, search_strategy="output")
         self.calibrated = True
         del self.raw_input, self.raw_out
+        self._ref_t = self._ref_t_key = None
         return None
 
     # ------------------------------------------------------------------ quantised forward (linear.py:46-51), fused
@@ -488,6 +499,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
             self.weight_fpcs(steps=self.steps, search_strategy="output")
         self.calibrated = True
         del self.raw_input, self.raw_out
+        self._ref_t = self._ref_t_key = None
 
     def reparam_bias(self):
         """linear.py:999-1006: bias += (-shift * 1^T) . q_w(W)^T, then the quantiser stops subtracting the shift."""

@@ -119,6 +119,15 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         G, S, K, Sp = self._dims()
         return self.raw_out.reshape(G, S, Sp)
 
+    def _ref3_t(self):
+        """raw_out transposed per group, [G, S', S] (one copy per layer) for the B-operand searches, whose GEMM rows run
+        along S: the kernel stages the reference through LDS when its row axis is contiguous."""
+        key = self.raw_out.data_ptr()
+        if getattr(self, "_ref_t_key", None) != key:
+            self._ref_t = self._ref3().transpose(1, 2).contiguous()
+            self._ref_t_key = key
+        return self._ref_t
+
     def _cand_chunk(self, bytes_per_cand):
         return max(1, min(self.eq_n, MAX_PACK_BYTES // max(1, bytes_per_cand)))
 
@@ -167,9 +176,9 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
                                          ref_div=e - s0, order=2, ref_transposed=True))
             else:
                 sa = fixed_sa if fixed_sa is not None else Strided(self.A_quantizer.scale.data.view(-1), g=pg)
-                out.append(be.gemm_score(dt, fixed, cand, S, Sp, e - s0, G, H, self._ref3(), sa, sb, None,
+                out.append(be.gemm_score(dt, fixed, cand, S, Sp, e - s0, G, H, self._ref3_t(), sa, sb, None,
                                          self.head_channel_wise, False, self._norm(A, S, Sp), sa_mul=sa_mul,
-                                         ref_div=e - s0, order=2))
+                                         ref_div=e - s0, order=2, ref_transposed=True))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _commit(self, quantizer, scale, zp):
@@ -207,6 +216,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
             self._fpcs("B", steps=self.steps)
         self.calibrated = True
         del self.raw_input, self.raw_out
+        self._ref_t = self._ref_t_key = None
         return None
 
     # ------------------------------------------------------------------ fused quantised forward (matmul.py:43-45)
@@ -309,6 +319,7 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
                        sa_mul=self._ts32())
         self.calibrated = True
         del self.raw_input, self.raw_out
+        self._ref_t = self._ref_t_key = None
         return None
 
     def quant_forward(self, A, B):

@@ -43,6 +43,7 @@ for name, I, O in (("qkv", 384, 1152), ("proj", 384, 384), ("fc1", 384, 1536), (
     x = torch.randn(1, M, I, device=dev)
     W = torch.randn(1, O, I, device=dev) * 0.05
     ref = torch.randn(1, M, O, device=dev)
+    ref_t = ref.transpose(1, 2).contiguous()
     bias = torch.zeros(O, device=dev)
     xs, xz = torch.tensor([0.3], device=dev), torch.tensor([8.0], device=dev)
     ws, wz = torch.full((O,), 0.01, device=dev), torch.full((O,), 8.0, device=dev)
@@ -52,8 +53,8 @@ for name, I, O in (("qkv", 384, 1152), ("proj", 384, 384), ("fc1", 384, 1536), (
     xp = ops.pack_uniform(x, xs, xz, 1, 0, 1, 0, 0, 4, ops.I8)
     t_pw = timeit(lambda: ops.pack_uniform(W, csw, czw, P, O, 1, 0, 1, 4, ops.I8, c_inner=True))
     wp = ops.pack_uniform(W, csw, czw, P, O, 1, 0, 1, 4, ops.I8, c_inner=True)
-    t_gw = timeit(lambda: ops.gemm_score(ops.I8, xp, wp, M, O, P, 1, 1, ref, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True,
-                                         1.0 / T, ref_div=P, order=2))
+    t_gw = timeit(lambda: ops.gemm_score(ops.I8, xp, wp, M, O, P, 1, 1, ref_t, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True,
+                                         1.0 / T, ref_div=P, order=2, ref_transposed=True))
     wfix = ops.pack_uniform(W, ws, wz, 1, 0, 1, 0, 1, 4, ops.I8)
     one = torch.ones(1, device=dev)
     t_pa = timeit(lambda: ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8, c_inner=True))
