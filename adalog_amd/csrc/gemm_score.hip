@@ -535,12 +535,16 @@ struct FinishArgs {
     double norm;
 };
 
-// One wavefront per output (4 per block): lanes take a fixed strided subset, then a fixed xor-shuffle tree in fp64.
+// WPO = 1: one wavefront per output (4 per block) -- many outputs with short sums (weight searches);
+// WPO = 0: one 256-thread block per output -- few outputs with long sums (activation / attention searches).
+// Either way each thread takes a fixed strided subset and the combine is a fixed tree in fp64: bit-reproducible.
+template <bool WPO>
 __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
+    __shared__ double sm[4];
     const int nh = p.keep_h ? p.gmod : 1, nn = p.keep_n ? p.N : 1;
     const int64_t nout = (int64_t)p.C * nh * nn;
-    const int64_t oid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t oid = WPO ? (int64_t)blockIdx.x * 4 + wv : (int64_t)blockIdx.x;
     if (oid >= nout) return;
     int64_t o = oid;
     const int n = (int)(o % nn); o /= nn;
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
     const int h_lo = p.keep_h ? h : 0, h_cnt = p.keep_h ? 1 : p.gmod;
     const int64_t total = (int64_t)imgs * h_cnt * p.MT * n_cnt;
     double acc = 0.0;
-    for (int64_t i = lane; i < total; i += 64) {
+    for (int64_t i = WPO ? lane : threadIdx.x; i < total; i += WPO ? 64 : 256) {
         int64_t t = i;
         const int nn_i = (int)(t % n_cnt); t /= n_cnt;
         const int mt = (int)(t % p.MT); t /= p.MT;
@@ -562,7 +566,13 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
-    if (lane == 0) p.scores[oid] = (float)(-p.norm * acc);
+    if (WPO) {
+        if (lane == 0) p.scores[oid] = (float)(-p.norm * acc);
+    } else {
+        if (lane == 0) sm[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) p.scores[oid] = (float)(-p.norm * ((sm[0] + sm[1]) + (sm[2] + sm[3])));
+    }
 }
 
 }  // namespace
@@ -696,7 +706,11 @@ extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT,
     p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = MT; p.N = N; p.Npad = Npad;
     p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm;
     const int64_t nout = (int64_t)C * (keep_h ? gmod : 1) * (keep_n ? N : 1);
-    hipLaunchKernelGGL(k_finish, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+    const int64_t per_out = (int64_t)(G / gmod) * (keep_h ? 1 : gmod) * MT * (keep_n ? 1 : N);
+    if (per_out >= 2048)
+        hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)nout), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     ADALOG_LAUNCH_CHECK("adalog_finish_scores");
     return 0;
 }

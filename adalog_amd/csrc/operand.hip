@@ -183,7 +183,19 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
             if (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(op) = *reinterpret_cast<const uint32_t*>(vals);
             else if (sizeof(T) == 2) *reinterpret_cast<uint2*>(op) = *reinterpret_cast<const uint2*>(vals);
             else *reinterpret_cast<uint4*>(op) = *reinterpret_cast<const uint4*>(vals);
-            if (KIND == KIND_UNIFORM && a.rowsum && isum != 0) atomicAdd(a.rowsum + (c * a.G + g) * a.R + r, isum);
+            if (KIND == KIND_UNIFORM && a.rowsum) {
+                // one atomic per wavefront when all 64 lanes work on the same row (the common case: Kp/4 >= 64)
+                const int64_t ridx = (c * a.G + g) * a.R + r;
+                const int64_t first = __builtin_amdgcn_readfirstlane((int)ridx);
+                if (__all((int)ridx == (int)first) && __popcll(__ballot(1)) == 64) {
+                    int v = isum;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                    if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(a.rowsum + ridx, v);
+                } else if (isum != 0) {
+                    atomicAdd(a.rowsum + ridx, isum);
+                }
+            }
         }
     }
 }

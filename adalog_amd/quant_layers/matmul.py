@@ -101,6 +101,18 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         """[N,H,S,K] -> [G, S, K] view (rows = output rows, K contiguous)."""
         return A.reshape(-1, A.shape[-2], A.shape[-1])
 
+    def _bt3_packable(self, B):
+        """B^T view for the search packs.  softmax@v hands over v [N,H,S,C], whose transpose is not K-contiguous: make ONE
+        K-contiguous copy per layer so the 100+ candidate packs read coalesced rows."""
+        bt = self._bt3(B)
+        if bt.stride(-1) == 1:
+            return bt
+        key = B.data_ptr()
+        if getattr(self, "_bt_key", None) != key:
+            self._bt_c = bt.contiguous()
+            self._bt_key = key
+        return self._bt_c
+
     @staticmethod
     def _bt3(B):
         """[N,H,K,S'] -> B^T as a [G, S', K] view: K-contiguous when B itself was a transposed view (q@k^T), otherwise
@@ -143,7 +155,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
             s, z = self._q_params(self.A_quantizer)
             return be.pack_uniform(self._a3(A), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.A_quantizer.n_bits, dt)
         s, z = self._q_params(self.B_quantizer)
-        return be.pack_uniform(self._bt3(B), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.B_quantizer.n_bits, dt)
+        return be.pack_uniform(self._bt3_packable(B), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.B_quantizer.n_bits, dt)
 
     def _score(self, which, fixed, scale, zp, dt=I8, fixed_sa=None, sa_mul=1.0):
         """matmul.py:135-163 (which='A') / :173-201 (which='B') -> scores [P, H].
@@ -157,7 +169,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         G, S, K, Sp = self._dims()
         A, B = self.raw_input
         P = scale.shape[0]
-        src = self._a3(A) if which == "A" else self._bt3(B)
+        src = self._a3(A) if which == "A" else self._bt3_packable(B)
         bits = self.A_quantizer.n_bits if which == "A" else self.B_quantizer.n_bits
         rows = S if which == "A" else Sp
         esz = 1 if dt == I8 else 2
@@ -217,6 +229,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         self.calibrated = True
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
+        self._bt_c = self._bt_key = None
         return None
 
     # ------------------------------------------------------------------ fused quantised forward (matmul.py:43-45)
@@ -320,6 +333,7 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         self.calibrated = True
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
+        self._bt_c = self._bt_key = None
         return None
 
     def quant_forward(self, A, B):
