@@ -16,6 +16,7 @@
 // K-step 64 bytes, LDS double-buffered with a 16-byte-slot XOR swizzle (conflict-free ds_read_b128),
 // XCD-aware block order so the workgroups sharing an A tile sit on one XCD's L2.
 #include "common.h"
+#include <stdlib.h>
 
 // The quantisation kernels are compiled without FMA contraction (bin indices must round like the reference); this file
 // holds no bin-defining arithmetic, so the epilogues may fuse multiply-adds.
@@ -581,6 +582,10 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
 static int pick_tm(int M, bool scoring) {
     // largest row tile whose padding waste stays within 10 % of the best achievable.  The scoring epilogue keeps more
     // state than the store epilogue: with TM = 4 (128 accumulator VGPRs) it spills, so scoring launches use TM <= 2.
+    if (const char* e = getenv("ADALOG_GEMM_TM")) {             // tuning knob for experiments (1, 2 or 4)
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || (v == 4 && !scoring)) return v;
+    }
     double best = 0.0;
     int tms[3] = {scoring ? 2 : 4, 2, 1};
     double util[3];

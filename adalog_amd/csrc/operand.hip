@@ -117,12 +117,22 @@ template <typename T, int KIND>
 __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
     const int64_t nq = a.Kp >> 2;
     const int64_t total = a.G * a.R * nq;
-    __shared__ float s_mant[ADALOG_R];
+    // AdaLog: per-candidate value LUT  lut[c][k] = m[(k q_c) mod 37] * 2^-floor(k q_c / 37)  (bf16-exact), built once per
+    // block, so a candidate costs ~8 VALU + one LDS read per element; log2(x + shift) is taken once per element and
+    // -log2(u) = log2(s_c) - log2(x + shift) per candidate (exact path re-evaluated inside the tie zone).
+    extern __shared__ unsigned short s_lut[];
+    const float sh = (KIND == KIND_ADALOG && a.shift) ? a.shift[0] : 0.0f;
     if (KIND == KIND_ADALOG) {
-        if (threadIdx.x < ADALOG_R) s_mant[threadIdx.x] = a.mant[threadIdx.x];
+        for (int e = threadIdx.x; e < (int)a.C * a.levels2; e += blockDim.x) {
+            const int c = e / a.levels2, k = e - c * a.levels2;
+            const int kqv = k * (int)a.qv[c * a.pc];
+            const int t = kqv / ADALOG_R, j = kqv - t * ADALOG_R;
+            const float v = (t > 100) ? 0.0f : ldexpf(a.mant[j], -t);
+            s_lut[e] = (unsigned short)(__float_as_uint(v) >> 16);          // exact: <= 8 significant bits
+        }
         __syncthreads();
     }
-    const float sh = (KIND == KIND_ADALOG && a.shift) ? a.shift[0] : 0.0f;
+    const float NL15 = 49.828921f;                                           // -fl32(log2(1e-15f))
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t kq = idx % nq;
         const int64_t t0 = idx / nq;
@@ -137,9 +147,13 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) xv[e] = (k0 + e < a.K) ? xp[e] : 0.0f;
         }
-        if (KIND == KIND_ADALOG && a.shift) {
+        float lx[4] = {0.f, 0.f, 0.f, 0.f};
+        if (KIND == KIND_ADALOG) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) xv[e] += sh;
+            for (int e = 0; e < 4; ++e) {
+                if (a.shift) xv[e] += sh;
+                lx[e] = __log2f(xv[e]);                                       // -inf for 0, NaN for negatives
+            }
         }
         const int64_t pbase = (g % a.gmod) * a.pg + r * a.pr;
         for (int64_t c = blockIdx.y; c < a.C; c += gridDim.y) {
@@ -160,23 +174,30 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
                 }
             } else {
                 const float s = a.scale[c * a.pc + pbase];
-                const float qf = a.qv[c * a.pc + (g % a.gmod) * a.pg];
-                const float inv_s = 1.0f / s, rq37 = 37.0f / qf;
-                const int qi = (int)qf;
+                const float qf = a.qv[c * a.pc];
+                const float ls = __log2f(s), rq37 = 37.0f / qf;
+                const float tmax = NL15 * rq37;
+                const unsigned short* lut = s_lut + c * a.levels2;
+                unsigned short hv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = 0.0f;
+                    unsigned short h = 0;
                     if (k0 + e < a.K) {
-                        float kk = adalog_k_fast(xv[e], s, inv_s, qf, rq37, a.clamp_u != 0);
-                        if (kk < (float)a.levels2 && kk == kk) {
-                            kk = fmaxf(kk, 0.0f);
-                            const int kqv = (int)kk * qi;
-                            const int t = kqv / ADALOG_R, j = kqv - t * ADALOG_R;
-                            v = (t > 100) ? 0.0f : ldexpf(s_mant[j], -t);
+                        float t = (ls - lx[e]) * rq37;
+                        if (a.clamp_u) t = fminf(fmaxf(t, 0.0f), tmax);       // u clamped to [1e-15, 1]; NaN (x<0) -> tmax side
+                        if (a.clamp_u && !(lx[e] == lx[e])) t = tmax;
+                        float kk = rintf(t);
+                        if (__builtin_expect(fabsf(t - kk) > 0.499f && t < 1.0e4f, 0)) {
+                            float ue = xv[e] / s;
+                            if (a.clamp_u) ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
+                            kk = adalog_k(ue, qf);
                         }
+                        if (kk < (float)a.levels2 && kk == kk) h = lut[(int)fmaxf(kk, 0.0f)];
                     }
-                    vals[e] = cvt<T>(v);
+                    hv[e] = h;
                 }
+                *reinterpret_cast<uint2*>(vals) = make_uint2((unsigned)hv[0] | ((unsigned)hv[1] << 16),
+                                                              (unsigned)hv[2] | ((unsigned)hv[3] << 16));
             }
             const int64_t orow = a.c_inner ? (g * a.R + r) * a.C + c : (c * a.G + g) * a.R + r;
             T* op = reinterpret_cast<T*>(a.out) + orow * a.Kp + k0;
@@ -211,9 +232,13 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         // enough candidate groups to fill the chip when the source is small (weights), all candidates per thread otherwise
         int64_t gy = 1;
         while (gx * gy < 2048 && gy < a.C) gy *= 2;
-        hipLaunchKernelGGL((k_pack_kfast<T, KIND>), dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, st, a);
-        return 0;
+        const size_t shm = (KIND == KIND_ADALOG) ? (size_t)a.C * a.levels2 * sizeof(unsigned short) : 0;
+        if (KIND != KIND_ADALOG || (a.pg == 0 && shm <= 64 * 1024)) {
+            hipLaunchKernelGGL((k_pack_kfast<T, KIND>), dim3((unsigned)gx, (unsigned)gy), dim3(256), shm, st, a);
+            return 0;
+        }
     }
+    {
     const int64_t per_c = a.G * a.R * (a.Kp / EPT);
     int64_t gx = (per_c + 255) / 256;
     if (gx > 4096) gx = 4096;
@@ -224,6 +249,7 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((k_pack<T, KIND, true>), grid, dim3(256), 0, st, a);
     else
         hipLaunchKernelGGL((k_pack<T, KIND, false>), grid, dim3(256), 0, st, a);
+    }
     return 0;
 }
 
