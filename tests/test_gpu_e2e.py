@@ -1,0 +1,104 @@
+"""`-m gpu` end-to-end: the test_quant.py entry point (calibrate -> checkpoint -> reload), a Swin stage with PatchMerging
+(`reduction` + LayerNorm fold), and fused quant_forward vs the composed fake-quant forward."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+
+
+def _cfg(bits=4, rounds=1, steps=2):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(f"cfg{bits}e", os.path.join(ROOT, "configs", f"{bits}bit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = mod.Config()
+    cfg.search_round, cfg.steps = rounds, steps
+    return cfg
+
+
+def test_cli_calibrate_save_and_reload(tmp_path):
+    out = str(tmp_path / "run")
+    cmd = [sys.executable, os.path.join(ROOT, "test_quant.py"), "--model", "deit_tiny", "--config",
+           os.path.join(ROOT, "configs", "6bit.py"), "--calibrate", "--calib-size", "8", "--calib-batch-size", "8",
+           "--val-size", "16", "--val-batch-size", "16", "--output-dir", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ckpt = os.path.join(out, "deit_tiny_w6_a6_s6_calibsize_8.pth")            # reference naming, test_quant.py:98-99
+    assert os.path.exists(ckpt)
+    sd = torch.load(ckpt, map_location="cpu")
+    # reference checkpoint wire format: plain layers after un-wrapping, AdaLog buffers, re-parameterised bias flag
+    assert sd["blocks.0.attn.qkv.w_quantizer.scale"].shape == (3, 192, 1)
+    assert sd["blocks.0.attn.qkv.a_quantizer.scale"].shape == (1,)
+    assert sd["blocks.0.attn.matmul2.A_quantizer.q"].dtype == torch.int64
+    assert sd["blocks.0.mlp.fc2.a_quantizer.table2"].shape == (64,)
+    assert bool(sd["blocks.0.mlp.fc2.a_quantizer.bias_reparamed"])
+    assert sd["patch_embed.proj.w_quantizer.zero_point"].shape == (192, 1)
+    assert "agreement" in r.stdout + r.stderr
+    cmd2 = [sys.executable, os.path.join(ROOT, "test_quant.py"), "--model", "deit_tiny", "--config",
+            os.path.join(ROOT, "configs", "6bit.py"), "--load-calibrate-checkpoint", ckpt, "--test-calibrate-checkpoint",
+            "--val-size", "16", "--val-batch-size", "16", "--output-dir", out]
+    r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+
+    def agreement(text):
+        line = [ln for ln in text.splitlines() if "agreement" in ln][-1]
+        return float(line.split("model")[1].split("%")[0])
+    assert abs(agreement(r.stdout + r.stderr) - agreement(r2.stdout + r2.stderr)) < 1e-6     # reload reproduces the model
+
+
+def test_swin_stage_calibration():
+    from adalog_amd import quant_layers as Q
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import SwinTransformer
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    torch.manual_seed(3)
+    model = SwinTransformer(img_size=56, patch_size=4, embed_dim=32, depths=(2, 2), num_heads=(2, 4), window_size=7,
+                            num_classes=10).eval()
+    for p in model.parameters():
+        p.data.mul_(6.0)
+    model.to(DEV)
+    x = torch.randn(8, 3, 56, 56, device=DEV)
+    with torch.no_grad():
+        y_fp = model(x)
+    model = wrap_modules_in_net(model, _cfg(6, 1, 3), reparam=True)
+    names = [n for n, m in model.named_modules() if hasattr(m, "calibrated")]
+    assert "layers.1.downsample.reduction" in names and "layers.0.blocks.1.attn.matmul2" in names and "head.fc" in names
+    red = model.layers[1].downsample.reduction
+    assert isinstance(red, Q.AsymmetricallyChannelWiseBatchingQuantLinear) and red.prev_layer is model.layers[1].downsample.norm
+    assert red.bias is None                                       # timm's reduction is bias-free (test_quant.py:116-117)
+    QuantCalibrator(model, [(x[:4], None), (x[4:], None)]).batching_quant_calib()
+    model = wrap_reparamed_modules_in_net(model)
+    assert model.layers[1].downsample.reduction.bias is not None  # the LayerNorm fold creates it (linear.py:609-611)
+    with torch.no_grad():
+        y_q = model(x)
+    rel = ((y_q - y_fp).norm() / y_fp.norm()).item()
+    assert torch.isfinite(y_q).all() and rel < 0.35, rel
+
+
+def test_fused_quant_forward_matches_composed():
+    """The fused int8/bf16 MFMA forward (pack + GEMM epilogue) equals fake-quant(x) @ fake-quant(W)^T to fp32 rounding."""
+    from adalog_amd import quant_layers as Q
+    from tests import layer_cases as LC
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "linear_w4a4.npz"))
+    LC.DEV[0] = torch.device(DEV)
+    wb, ab, N, Tn, I, Oc, n_V, cbs = [int(v) for v in g["cfg"]]
+    lay = Q.AsymmetricallyBatchingQuantLinear(I, Oc, True, "quant_forward", wb, ab, n_V=n_V, fpcs=True).to(DEV)
+    sd = {k[4:].replace("__", "."): LC.t(v) for k, v in g.items() if k.startswith("out_")}
+    lay.load_state_dict(sd)
+    lay.calibrated = lay.a_quantizer.inited = lay.w_quantizer.inited = True
+    x = LC.t(g["x"])
+    with torch.no_grad():
+        fused = lay(x)
+        composed = Q.MinMaxQuantLinear.quant_forward(lay, x)
+    torch.testing.assert_close(fused, composed, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(fused.cpu(), torch.from_numpy(g["qf_out"]), rtol=1e-4, atol=1e-4)
+    big = torch.randn(3, 300, I, device=DEV)                        # rows not a multiple of any tile
+    with torch.no_grad():
+        torch.testing.assert_close(lay(big), Q.MinMaxQuantLinear.quant_forward(lay, big), rtol=1e-5, atol=1e-5)
