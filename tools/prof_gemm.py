@@ -27,9 +27,16 @@ csa = torch.rand(P, 1, device=dev) * 0.2 + 0.2; cza = torch.randint(4, 12, (P, 1
 xp = ops.pack_uniform(x, xs, xz, 1, 0, 1, 0, 0, 4, ops.I8)
 wp = ops.pack_uniform(W, csw, czw, P, O, 1, 0, 1, 4, ops.I8, c_inner=True)
 wfix = ops.pack_uniform(W, ws, wz, 1, 0, 1, 0, 1, 4, ops.I8)
-xP = ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8)
+xP = ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8, c_inner=True)
+ref_t = ref.transpose(1, 2).contiguous()
+one = torch.ones(1, device=dev)
+mode = sys.argv[2] if len(sys.argv) > 2 else "both"
 for _ in range(3):
-    ops.gemm_score(ops.I8, xp, wp, M, O, P, 1, 1, ref, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True, 1.0 / T, ref_div=P, order=2)
-    ops.gemm_score(ops.I8, xP, wfix, M, O, P, 1, 1, ref, S(csa, c=1), S(ws, n=1), S(bias, n=1), False, False, 1.0 / (T * O), order=1)
+    if mode in ("both", "w"):       # weight search: rows = tokens, columns = (out channel, candidate)
+        ops.gemm_score(ops.I8, xp, wp, M, O, P, 1, 1, ref_t, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True, 1.0 / T,
+                       ref_div=P, order=2, ref_transposed=True)
+    if mode in ("both", "a"):       # activation search (transposed): rows = out channels, columns = (token, candidate)
+        ops.gemm_score(ops.I8, wfix, xP, O, M, P, 1, 1, ref, S(one), S(csa, c=1), None, False, False, 1.0 / (T * O),
+                       ref_div=P, order=2, ref_transposed=True, row_scale=ws, row_bias=bias)
 torch.cuda.synchronize()
 print("done")
