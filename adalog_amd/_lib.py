@@ -24,7 +24,7 @@ SIGNATURES = {
     "adalog_gemm_score": (i32, [i32, p, p, i64, i64, i64, i64, i32, i32, i64, i32, i32, i32, p, i64, i64, i64, i32,
                                 p, i64, i64, f32, p, i64, i64, i64, p, i64, i64, i64, p, p, p, i64, p, i64, i64, i64, i32, i32, p]),
     "adalog_gemm_score_layout": (i64, [i32, i32, i32, i32, i32, i32, p, p]),
-    "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, f64, p]),
+    "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p]),
     "adalog_topk": (i32, [p, i32, i32, i32, p, p]),
     "adalog_fpcs_next": (i32, [p, p, p, i32, p, i32, i32, p, p, i32, f32, p, p, p, p]),
     "adalog_candidate_grid": (i32, [p, i32, i32, i32, i32, i32, p, i32, f32, p, p, p, p]),

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_score(GemmArgs p) {
         } else if (tid < 128) {
             if (p.ref_div > 1) {
                 if (col < p.N)
-                    p.partial[(((int64_t)(col % p.ref_div) * p.G + g) * p.MT + mt) * p.Npad + col / p.ref_div] = v;
+                    p.partial[((((int64_t)g) * p.MT + mt) * p.Npad + col / p.ref_div) * p.ref_div + col % p.ref_div] = v;
             } else if (col < p.Npad) {
                 p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + col] = v;
             }
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
         } else if (tid < 256) {
             if (p.ref_div > 1) {
                 if (col < p.N)
-                    p.partial[(((int64_t)(col % p.ref_div) * p.G + g) * p.MT + mt) * p.Npad + col / p.ref_div] = v;
+                    p.partial[((((int64_t)g) * p.MT + mt) * p.Npad + col / p.ref_div) * p.ref_div + col % p.ref_div] = v;
             } else if (col < p.Npad) {
                 p.partial[(((int64_t)g) * p.MT + mt) * p.Npad + col] = v;
             }
@@ -533,6 +533,7 @@ struct FinishArgs {
     const float* partial; float* scores;
     int C, G, gmod, MT, N, Npad;
     int keep_h, keep_n;
+    int cin;                 // > 0: partial is [G][MT][Npad][cin] (candidate innermost, written by ref_div launches)
     double norm;
 };
 
@@ -563,7 +564,9 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
         const int hh = (int)(t % h_cnt); t /= h_cnt;
         const int img = (int)t;
         const int g = img * p.gmod + h_lo + hh;
-        acc += (double)p.partial[(((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + n_lo + nn_i];
+        const int64_t pi = p.cin > 0 ? ((((int64_t)g) * p.MT + mt) * p.Npad + n_lo + nn_i) * p.cin + c
+                                     : (((int64_t)c * p.G + g) * p.MT + mt) * p.Npad + n_lo + nn_i;
+        acc += (double)p.partial[pi];
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
@@ -574,6 +577,31 @@ __global__ __launch_bounds__(256) void k_finish(FinishArgs p) {
         __syncthreads();
         if (threadIdx.x == 0) p.scores[oid] = (float)(-p.norm * ((sm[0] + sm[1]) + (sm[2] + sm[3])));
     }
+}
+
+// Thread-per-output finish for the candidate-innermost layout with short sums (weight searches: [P][O] outputs, MT terms
+// each): adjacent threads take adjacent candidates, so every step of the sequential fp64 sum is a coalesced read.
+__global__ __launch_bounds__(256) void k_finish_tpo(FinishArgs p) {
+    const int nh = p.keep_h ? p.gmod : 1, nn = p.keep_n ? p.N : 1;
+    const int64_t nout = (int64_t)p.C * nh * nn;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (tid >= nout) return;
+    const int c = (int)(tid % p.C);
+    int64_t o = tid / p.C;
+    const int n = (int)(o % nn);
+    const int h = (int)(o / nn);
+    const int n_lo = p.keep_n ? n : 0, n_cnt = p.keep_n ? 1 : p.N;
+    const int imgs = p.G / p.gmod;
+    const int h_lo = p.keep_h ? h : 0, h_cnt = p.keep_h ? 1 : p.gmod;
+    double acc = 0.0;
+    for (int img = 0; img < imgs; ++img)
+        for (int hh = 0; hh < h_cnt; ++hh) {
+            const int g = img * p.gmod + h_lo + hh;
+            for (int mt = 0; mt < p.MT; ++mt)
+                for (int ni = 0; ni < n_cnt; ++ni)
+                    acc += (double)p.partial[((((int64_t)g) * p.MT + mt) * p.Npad + n_lo + ni) * p.cin + c];
+        }
+    p.scores[((int64_t)c * nh + h) * nn + n] = (float)(-p.norm * acc);
 }
 
 }  // namespace
@@ -704,15 +732,17 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
 // scores[c][h?][n?] = -norm * sum over (image, [h], m_tile, [n]) of partial[c][g][m_tile][n] with the layout returned by
 // adalog_gemm_score_layout (MT, Npad); N = number of valid entries along the last axis (n_eff, or NT when reduced).
 extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
-                                    int keep_h, int keep_n, double norm, void* stream) {
+                                    int keep_h, int keep_n, int cand_inner, double norm, void* stream) {
     ADALOG_ARG_CHECK(partial && scores && MT >= 1 && N >= 1 && Npad >= N && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0,
                      "finish_scores: bad arguments");
     FinishArgs p{};
     p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = MT; p.N = N; p.Npad = Npad;
-    p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm;
+    p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm; p.cin = cand_inner ? C : 0;
     const int64_t nout = (int64_t)C * (keep_h ? gmod : 1) * (keep_n ? N : 1);
     const int64_t per_out = (int64_t)(G / gmod) * (keep_h ? 1 : gmod) * MT * (keep_n ? 1 : N);
-    if (per_out >= 2048)
+    if (p.cin > 0 && per_out <= 512 && nout >= 4096)
+        hipLaunchKernelGGL(k_finish_tpo, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (per_out >= 2048)
         hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)nout), dim3(256), 0, (hipStream_t)stream, p);
     else
         hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);

@@ -213,7 +213,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
     n_last = Npad if reduce_cols else N                 # reduced: one partial per n-tile (Npad = NT)
     rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), MT, n_last, Npad, C, G, gmod, int(keep_h),
-                                  int(keep_n), float(norm), _stream())
+                                  int(keep_n), int(ref_div > 1), float(norm), _stream())
     _lib.check(rc, "adalog_finish_scores")
     return scores
 

@@ -96,7 +96,8 @@ int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int6
 /* row_scale / row_bias (optional, C = 1): out[m][n] = (D*alpha) * row_scale[m] + row_bias[m] + bias -- the activation
  * searches run transposed (rows = output channels, columns = (token, candidate)), so the per-channel weight scale and
  * the layer bias are per-ROW there.
- * Layout of `partial`: [c_eff][G][MT][Npad]; adalog_gemm_score_layout returns its size and (MT, Npad) for the given
+ * Layout of `partial`: [C][G][MT][Npad] for C > 1 launches, [G][MT][Npad][ref_div] (candidate innermost: coalesced
+ * stores) for ref_div > 1 launches -- pass cand_inner = 1 to adalog_finish_scores for the latter; adalog_gemm_score_layout returns its size and (MT, Npad) for the given
  * problem (two tilings exist: 128x128 for C > 1, (64..256)x256 with 128-byte K-steps when C = 1). */
 int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int* MT, int* Npad);
 
@@ -108,7 +109,7 @@ int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int re
  *   MatMul per head       keep_h=1 -> [P][H]   (matmul.py:154-164, norm = 1/(S*S'))
  *   post-softmax base     none     -> [P]      (matmul.py:345-352, norm = 1/(H*S*S')) */
 int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
-                         int keep_n, double norm, void* stream);
+                         int keep_n, int cand_inner, double norm, void* stream);
 
 /* ---- K16  FPCS driver pieces                 reference linear.py:483-523, matmul.py:243-262, conv.py:292-311
  * adalog_topk: idx[j][col] = candidate with the j-th best score of column col, j < k; order (score desc, index asc),
