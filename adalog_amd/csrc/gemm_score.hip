@@ -526,6 +526,174 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand(GemmArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ LDS-DMA pipelined variant
+// Same tile and epilogues as k_gemm_cand, but the operand tiles go global -> LDS directly (global_load_lds_dwordx4, no
+// VGPR round trip, no ds_write pass) into a ring of NS = 3 stages, with counted vmcnt and raw s_barrier so that two
+// K-steps of loads stay in flight across the barrier (cdna guide section 5: "glds span barrier").  The LDS destination of
+// an LDS-DMA is lane-linear (wave base + lane*16), so the bank swizzle is applied to the per-lane GLOBAL source address
+// (rule 21): lane l of a request covering 8 rows fetches logical slot (l & 7) ^ ((row >> 1) & 7) of row (l >> 3).
+typedef const void __attribute__((address_space(1)))* gas_ptr;
+typedef void __attribute__((address_space(3)))* las_ptr;
+
+// One K-step of the LDS-DMA pipeline.  `cur` (stage being read) and `nxt` (ring slot being refilled) are __restrict__ so
+// that, after inlining, the DMA stores and the fragment reads carry disjoint alias scopes: without them the waitcnt
+// insertion pass must assume the ds_reads alias the in-flight LDS-DMA and drains vmcnt(0) every step.
+template <int DT, int TM, int NA>
+__device__ __forceinline__ void glds_step(const uint8_t* __restrict__ cur, uint8_t* __restrict__ nxt, bool do_issue,
+                                          const uint8_t* Ab, const uint8_t* Bb, const int64_t (&oa)[NA], const int64_t (&ob)[4],
+                                          const int (&la)[NA], const int (&lb)[4], int64_t ko, int arow, int brow, int fkg,
+                                          typename Acc<DT>::type (&acc)[TM][2]) {
+    constexpr int BM2 = 64 * TM;
+    if (do_issue) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr)(Ab + oa[i] + ko), (las_ptr)(nxt + la[i]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr)(Bb + ob[i] + ko), (las_ptr)(nxt + lb[i]), 16, 0, 0);
+    }
+    const uint8_t* As = cur;
+    const uint8_t* Bs = cur + BM2 * BK2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        uint4 af[TM], bf[2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(As + swz2(arow + i * 32, ks * 2 + fkg));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const uint4*>(Bs + swz2(brow + j * 32, ks * 2 + fkg));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma<DT>(af[i], bf[j], acc[i][j]);
+    }
+}
+
+template <int DT, int TM>
+__global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
+    constexpr int BM2 = 64 * TM;
+    constexpr int STAGE = (BM2 + BN2) * BK2;
+    constexpr int NS = 3;
+    constexpr int NA = BM2 / 64;                   // 8-row requests per wave for the A tile (BM2/8 requests over 8 waves)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* red = reinterpret_cast<float*>(smem + NS * STAGE);
+    float* colv = red + 512;
+
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const unsigned lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    unsigned t = lid;
+    int nt, mt, g;
+    if (p.order == 2) { mt = t % p.MT; t /= p.MT; nt = t % p.NT; g = t / p.NT; }
+    else { nt = t % p.NT; t /= p.NT; mt = t % p.MT; g = t / p.MT; }
+    const int gh = g % p.gmod;
+    const int m0 = mt * BM2, n0 = nt * BN2;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 2, wc = w & 3;
+    const int lr = lane >> 3, lslot = lane & 7;
+    // per-lane global sources: A requests rbA = w*NA + i (i < NA), B requests rbB = w*4 + i (i < 4); 8 rows per request
+    const uint8_t* Ab = p.A + g * p.sAg;
+    const uint8_t* Bb = p.B + g * p.sBg;
+    int64_t oa[NA], ob[4];
+    int la[NA], lb[4];                              // wave-uniform LDS byte offsets of the requests inside a stage
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int rl = (w * NA + i) * 8 + lr;       // row inside the tile
+        int r = m0 + rl; r = r < p.M ? r : p.M - 1;
+        oa[i] = (int64_t)r * p.Kb + ((lslot ^ ((rl >> 1) & 7)) << 4);
+        la[i] = (w * NA + i) * 1024;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rl = (w * 4 + i) * 8 + lr;
+        int r = n0 + rl; r = r < p.N ? r : p.N - 1;
+        ob[i] = (int64_t)r * p.Kb + ((lslot ^ ((rl >> 1) & 7)) << 4);
+        lb[i] = BM2 * BK2 + (w * 4 + i) * 1024;
+    }
+    auto issue = [&](int kt) {
+        uint8_t* st = smem + (kt % NS) * STAGE;
+        const int64_t ko = (int64_t)kt * BK2;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr)(Ab + oa[i] + ko), (las_ptr)(st + la[i]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gas_ptr)(Bb + ob[i] + ko), (las_ptr)(st + lb[i]), 16, 0, 0);
+    };
+
+    typename Acc<DT>::type acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+
+    const int nk = (int)(p.Kb / BK2);
+    issue(0);
+    if (nk > 1) issue(1);
+    const int frow = lane & 31, fkg = lane >> 5;
+    const int arow = wr * (BM2 / 2) + frow, brow = wc * 64 + frow;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most one later stage (NA + 4 requests of this wave) is still outstanding
+        if (kt + 1 < nk) {
+            if (NA == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();               // everyone's part of stage kt landed; everyone finished stage kt-1
+        asm volatile("" ::: "memory");
+        glds_step<DT, TM, NA>(smem + (kt % NS) * STAGE, smem + ((kt + 2) % NS) * STAGE, kt + 2 < nk, Ab, Bb, oa, ob, la, lb,
+                              (int64_t)(kt + 2) * BK2, arow, brow, fkg, acc);
+    }
+
+    const bool edge = (m0 + BM2 > p.M) || (n0 + BN2 > p.N);
+    const bool rows = p.row_scale != nullptr;
+    const bool lds_ref = p.ldr == 1 && p.ref_div >= 32 && (BN2 % p.ref_div) == 0;
+    __syncthreads();
+    if (lds_ref) {
+        float* stage = reinterpret_cast<float*>(smem);
+        if (edge) {
+            if (rows) epilogue_lds<DT, TM, true, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+            else epilogue_lds<DT, TM, true, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+        } else {
+            if (rows) epilogue_lds<DT, TM, false, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+            else epilogue_lds<DT, TM, false, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red, stage);
+        }
+    } else if (edge) {
+        if (rows) epilogue2<DT, TM, false, true, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
+        else epilogue2<DT, TM, false, true, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
+    } else {
+        if (rows) epilogue2<DT, TM, false, false, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
+        else epilogue2<DT, TM, false, false, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
+    }
+    if (p.partial) {
+        __syncthreads();
+        float v = 0.0f;
+        const int col = n0 + tid;
+        if (tid < 256) v = red[tid] + red[256 + tid];
+        if (p.reduce_cols) {
+            if (tid < 256) colv[tid] = v;
+            __syncthreads();
+            if (tid < 64) {
+                float t2 = (colv[tid] + colv[tid + 64]) + (colv[tid + 128] + colv[tid + 192]);
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) t2 += __shfl_xor(t2, sft);
+                if (tid == 0) p.partial[(((int64_t)g) * p.MT + mt) * p.Npad + nt] = t2;
+            }
+        } else if (tid < 256) {
+            if (p.ref_div > 1) {
+                if (col < p.N)
+                    p.partial[((((int64_t)g) * p.MT + mt) * p.Npad + col / p.ref_div) * p.ref_div + col % p.ref_div] = v;
+            } else if (col < p.Npad) {
+                p.partial[(((int64_t)g) * p.MT + mt) * p.Npad + col] = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ finish
 // scores[c][h?][n?] = -norm * sum over (image = g / gmod, [h], m-tile, [n]) of partial[c][g][mt][n]   in fp64,
 // fixed summation order: each thread takes a strided subset, then a fixed LDS tree.
@@ -690,7 +858,24 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(nwg < (int64_t)1 << 31, "gemm_score: grid too large");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nwg);
-    if (L.big) {
+    static const int use_glds = getenv("ADALOG_GEMM_GLDS") ? atoi(getenv("ADALOG_GEMM_GLDS")) : 0;
+    if (L.big && use_glds && !out && L.tm <= 2) {
+        const size_t shm = (size_t)3 * (64 * L.tm + BN2) * BK2 + (512 + 256) * sizeof(float);
+#define LAUNCH_GLDS(DT, TMV)                                                                                      \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_cand_glds<DT, TMV>),              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            hipLaunchKernelGGL((k_gemm_cand_glds<DT, TMV>), grid, dim3(512), shm, st, p);                         \
+        } while (0)
+        if (dtype == 0) { if (L.tm == 2) LAUNCH_GLDS(0, 2); else LAUNCH_GLDS(0, 1); }
+        else if (dtype == 1) { if (L.tm == 2) LAUNCH_GLDS(1, 2); else LAUNCH_GLDS(1, 1); }
+        else { if (L.tm == 2) LAUNCH_GLDS(2, 2); else LAUNCH_GLDS(2, 1); }
+#undef LAUNCH_GLDS
+    } else if (L.big) {
         const size_t shm = (size_t)(64 * L.tm + BN2) * BK2 + (512 + 256) * sizeof(float);
 #define LAUNCH_BIG(DT, TMV, ST)                                                                                   \
         do {                                                                                                      \
