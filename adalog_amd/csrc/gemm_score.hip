@@ -34,7 +34,8 @@ constexpr int BM = 128, BN = 128, BKB = 64;   // BKB: K-step in bytes
 struct GemmArgs {
     const uint8_t* A; const uint8_t* B;
     int64_t sAc, sAg, sBc, sBg;      // byte strides between candidates / groups (0 = shared operand)
-    int M, N; int64_t Kb;            // Kb = padded K in bytes (multiple of 64)
+    int M, N; int64_t Kb;            // Kb = padded K in bytes (multiple of 128): the row stride
+    int64_t Kvb;                     // bytes of a row that can be non-zero (<= Kb)
     int C, G, gmod;
     const float* ref; int64_t ldr, sRg, ref_cs; int ref_div;
     const float* sa; int64_t sa_c, sa_g;
@@ -46,7 +47,10 @@ struct GemmArgs {
     float sa_mul;                    // constant folded into sa (e.g. 1/(4L-2) for AdaLog numerators)
     int reduce_cols;                 // 1: one partial per tile (sum over its columns) instead of one per column
     int order;                       // tile order (fastest index first): 0 = nt,mt,g,c  1 = nt,c,mt,g  2 = mt,nt,c,g
+    long long* timeline;             // profiling only (tools/gemm_lab.hip): 8 cycle stamps per workgroup, else nullptr
 };
+#define TL_STAMP(i) do { if (p.timeline && threadIdx.x == 0) p.timeline[(size_t)lid * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+static long long* g_timeline = nullptr;   // set only by the lab harness, which includes this file
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * BKB + ((slot ^ ((row >> 2) & 3)) << 4); }
 
@@ -581,6 +585,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
     const unsigned nwg = gridDim.x, bid = blockIdx.x;
     const unsigned q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const unsigned lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    TL_STAMP(0);
     unsigned t = lid;
     int nt, mt, g;
     if (p.order == 2) { mt = t % p.MT; t /= p.MT; nt = t % p.NT; g = t / p.NT; }
@@ -633,6 +638,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
     const int nk = (int)(p.Kb / BK2);
     issue(0);
     if (nk > 1) issue(1);
+    TL_STAMP(1);
     const int frow = lane & 31, fkg = lane >> 5;
     const int arow = wr * (BM2 / 2) + frow, brow = wc * 64 + frow;
     for (int kt = 0; kt < nk; ++kt) {
@@ -645,6 +651,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
         }
         __builtin_amdgcn_s_barrier();               // everyone's part of stage kt landed; everyone finished stage kt-1
         asm volatile("" ::: "memory");
+        if (kt == 0) TL_STAMP(2);
         glds_step<DT, TM, NA>(smem + (kt % NS) * STAGE, smem + ((kt + 2) % NS) * STAGE, kt + 2 < nk, Ab, Bb, oa, ob, la, lb,
                               (int64_t)(kt + 2) * BK2, arow, brow, fkg, acc);
     }
@@ -652,7 +659,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
     const bool edge = (m0 + BM2 > p.M) || (n0 + BN2 > p.N);
     const bool rows = p.row_scale != nullptr;
     const bool lds_ref = p.ldr == 1 && p.ref_div >= 32 && (BN2 % p.ref_div) == 0;
+    TL_STAMP(3);
     __syncthreads();
+    TL_STAMP(4);
     if (lds_ref) {
         float* stage = reinterpret_cast<float*>(smem);
         if (edge) {
@@ -669,8 +678,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
         if (rows) epilogue2<DT, TM, false, false, true>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
         else epilogue2<DT, TM, false, false, false>(p, acc, g, gh, m0, n0, wr, wc, frow, fkg, red);
     }
+    TL_STAMP(5);
     if (p.partial) {
         __syncthreads();
+        TL_STAMP(6);
         float v = 0.0f;
         const int col = n0 + tid;
         if (tid < 256) v = red[tid] + red[256 + tid];
@@ -692,6 +703,355 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
             }
         }
     }
+    TL_STAMP(7);
+}
+
+// ------------------------------------------------------------------------------------------------ streaming kernel
+// Third-generation scoring kernel (every search: candidates in the column axis, reference rows contiguous).
+// What the per-workgroup cycle stamps of tools/lab/gemm_lab.hip showed for the kernel above at K = 384 (three 128-byte
+// steps per tile): of 14.2k cycles per tile only 3.1k were matrix work -- 1.6k set-up (index divisions, 64-bit address
+// arithmetic), 1.7-3.2k waiting for the first stage, 4.8k main loop (every wave issues its six DMA requests back to
+// back at the top of a step while the matrix pipe idles), 4.0-5.4k epilogue (six VALU per output), 2k barriers/stores,
+// and nothing overlaps anything because one 147 KiB workgroup owns the CU.  Hence:
+//   * PERSISTENT workgroups: each walks a strided list of tiles and its LDS-DMA ring (3 stages of 64-byte K-steps)
+//     keeps streaming across tile boundaries, so set-up and first-stage latency are paid once per launch, not per tile;
+//   * 256 threads, (64*TM) x 256 tile, wave tile (32*TM) x 128 (fewer ds_reads per MFMA), 77 KiB of LDS: TWO workgroups
+//     per CU, un-synchronised, so one's epilogue (VALU) runs under the other's main loop (MFMA);
+//   * buffer_load ... lds with a per-tile resource: one VGPR offset per request, k offset in an SGPR, and the requests
+//     are issued between the MFMAs of a step instead of in front of them;
+//   * epilogue on packed fp32 math: reference slice minus row/column bias, row scale and column factors are staged in
+//     LDS during the tile's first K-step; per pair of outputs 2 cvt + 2..4 v_pk_* instead of 12 scalar VALU.
+constexpr int BK3 = 64, NS3 = 3;
+// tools/lab builds this file with GEMM_LAB_NO_DMA / GEMM_LAB_NO_MFMA to time the two halves of the main loop separately
+#if defined(GEMM_LAB_NO_DMA)
+#define STREAM_DMA(rsrc, dst, voff, soff) do { } while (0)
+#else
+#define STREAM_DMA(rsrc, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (las_ptr)(dst), 16, voff, soff, 0, 0)
+#endif
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int swz3(int row, int slot) { return row * BK3 + ((slot ^ ((row >> 2) & 3)) << 4); }
+
+template <int DT> __device__ __forceinline__ typename Acc<DT>::type mma0(const uint4& a, const uint4& b) {
+    typename Acc<DT>::type z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0;
+    mma<DT>(a, b, z);
+    return z;
+}
+
+struct StreamTile { int mt, nt, g; };
+
+// Fragment read through a __restrict__ stage pointer: the load carries alias-scope metadata, which keeps the compiler's
+// waitcnt pass from ordering it behind the (untagged) in-flight LDS-DMA with a vmcnt(0); the hand-written counted vmcnt
+// in front of each step's barrier is what orders them.
+__device__ __forceinline__ uint4 lds_frag(const uint8_t* __restrict__ stage, int off) {
+    return *reinterpret_cast<const uint4*>(stage + off);
+}
+
+template <int DT, int TM>
+__global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist only in the device pass
+    constexpr int BM3 = 64 * TM;
+    constexpr int STAGE3 = (BM3 + BN2) * BK3;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ring[];   // NS3 * STAGE3 bytes (dynamic: keeps the DMA untagged)
+    __shared__ __attribute__((aligned(16))) float s_ref[4 * BM3];     // [nref <= 4][BM3]: ref - row_bias (- column bias if shared)
+    __shared__ __attribute__((aligned(16))) float s_rs[BM3];          // row scale, 0 past M
+    __shared__ __attribute__((aligned(16))) float s_w[BM3];           // 1 for rows < M else 0
+    __shared__ float s_alpha[BN2], s_beta[BN2];                       // per column: -(sa*sb), column bias; 0 past N
+    __shared__ float s_red[2][BN2];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = w >> 1, wc = w & 1;
+    const int frow = lane & 31, fkg = lane >> 5;
+    const int arow = wr * (BM3 / 2) + frow, brow = wc * 128 + frow;
+
+    // ---- tile list of this workgroup: the XCD it runs on owns a contiguous range of tiles (neighbours share operand
+    // tiles in that XCD's L2); its workgroups take them round-robin.
+    const unsigned T = (unsigned)p.MT * p.NT * p.G;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7;
+    const unsigned q8 = T >> 3, r8 = T & 7;
+    const unsigned t_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const unsigned t_cnt = q8 + (xcd < r8 ? 1u : 0u);
+    const unsigned nj = (nwg >> 3) + (xcd < (nwg & 7) ? 1u : 0u);
+    const unsigned j0 = bid >> 3;
+    auto decode = [&](unsigned local) {
+        unsigned t = t_lo + local;
+        StreamTile r;
+        if (p.order == 2) { r.mt = t % p.MT; t /= p.MT; r.nt = t % p.NT; r.g = t / p.NT; }
+        else { r.nt = t % p.NT; t /= p.NT; r.mt = t % p.MT; r.g = t / p.MT; }
+        return r;
+    };
+    const int nk = (int)((p.Kvb + BK3 - 1) / BK3);          // whole 64-byte steps of zero padding are skipped
+    const int Kb = (int)p.Kb;
+
+    // ---- issue cursor: runs two K-steps ahead of the compute cursor, across tile boundaries.  Per request the lane's
+    // source is  row * Kb + 16 * (logical slot);  LDS destinations are lane-linear, so the bank swizzle goes into the
+    // source slot: lane l of a 16-row request lands in (row l>>2, physical slot l&3) = logical slot (l&3) ^ ((l>>4)&3).
+    const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    __amdgpu_buffer_rsrc_t ra, rb;
+    int va[TM], vb[4];
+    unsigned i_local = j0;
+    int i_k = 0;
+    auto issue_tile = [&](unsigned local) {
+        const StreamTile t = decode(local);
+        const int m0 = t.mt * BM3, n0 = t.nt * BN2;
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)t.g * p.sAg + (int64_t)m0 * Kb), 0, 0x7ffffffe, 0x00020000);
+        rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)t.g * p.sBg + (int64_t)n0 * Kb), 0, 0x7ffffffe, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int r = (w * TM + i) * 16 + lrow;
+            r = min(r, p.M - 1 - m0);                       // edge rows: re-read the last valid row (masked in the epilogue)
+            va[i] = r * Kb + lslot16;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = (w * 4 + i) * 16 + lrow;
+            r = min(r, p.N - 1 - n0);
+            vb[i] = r * Kb + lslot16;
+        }
+    };
+    auto issue_advance = [&]() {
+        if (++i_k == nk) {
+            i_k = 0;
+            if (i_local + nj < t_cnt) { i_local += nj; issue_tile(i_local); }   // past the last tile: harmless re-fetch
+        }
+    };
+    auto issue_all = [&](uint8_t* st) {                 // prologue only: the whole step at once
+        uint8_t* An = st + w * TM * 1024;
+        uint8_t* Bn = st + BM3 * BK3 + w * 4 * 1024;
+        const int ko = i_k * BK3;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (las_ptr)(An + i * 1024), 16, va[i], ko, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (las_ptr)(Bn + i * 1024), 16, vb[i], ko, 0, 0);
+    };
+    issue_tile(i_local);
+    issue_all(ring); issue_advance();
+    issue_all(ring + STAGE3); issue_advance();
+
+    const int rsh = __ffs(p.ref_div) - 1, rmask = p.ref_div - 1;   // ref_div is 64, 128 or 256 here
+    const int nref = BN2 >> rsh;                            // reference columns per tile (<= 4)
+    const int n_eff = p.N >> rsh;
+    const bool beta_staged = p.bias && p.bi_c == 0;         // column bias independent of the candidate: fold into s_ref
+    const bool beta_cols = p.bias && p.bi_c != 0;
+    const bool rows = p.row_scale != nullptr;
+    int st = 0;                                             // ring slot of the current step
+    typename Acc<DT>::type acc[TM][4];
+
+    // One 64-byte K-step = 2 sub-steps of (TM + 4) fragment reads and TM x 4 MFMAs.  Both sub-steps' fragments are read
+    // up front; this wave's TM + 4 DMA requests for the step two ahead are issued between the MFMA groups.
+    auto step_first = [&](const uint8_t* cur, uint8_t* nxt, int ko) {
+        constexpr bool FIRST = true;
+        const uint8_t* Bs = cur + BM3 * BK3;
+        uint8_t* An = nxt + w * TM * 1024;
+        uint8_t* Bn = nxt + BM3 * BK3 + w * 4 * 1024;
+        uint4 a0[TM], b0[4], a1[TM], b1[4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = lds_frag(cur, swz3(arow + i * 32, fkg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = lds_frag(Bs, swz3(brow + j * 32, fkg));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = lds_frag(cur, swz3(arow + i * 32, 2 + fkg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = lds_frag(Bs, swz3(brow + j * 32, 2 + fkg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#if defined(GEMM_LAB_NO_MFMA)
+                if (FIRST) { for (int r = 0; r < 16; ++r) acc[i][j][r] = 0; }
+                acc[i][j][0] += (int)(a0[i].x ^ b0[j].x);
+#else
+                if (FIRST) acc[i][j] = mma0<DT>(a0[i], b0[j]);
+                else mma<DT>(a0[i], b0[j], acc[i][j]);
+#endif
+            }
+            STREAM_DMA(rb, Bn + j * 1024, vb[j], ko);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#if defined(GEMM_LAB_NO_MFMA)
+                acc[i][j][1] += (int)(a1[i].x ^ b1[j].x);
+#else
+                mma<DT>(a1[i], b1[j], acc[i][j]);
+#endif
+            }
+            if (j < TM) STREAM_DMA(ra, An + j * 1024, va[j], ko);
+        }
+    };
+    auto step_next = [&](const uint8_t* cur, uint8_t* nxt, int ko) {
+        constexpr bool FIRST = false;
+        const uint8_t* Bs = cur + BM3 * BK3;
+        uint8_t* An = nxt + w * TM * 1024;
+        uint8_t* Bn = nxt + BM3 * BK3 + w * 4 * 1024;
+        uint4 a0[TM], b0[4], a1[TM], b1[4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a0[i] = lds_frag(cur, swz3(arow + i * 32, fkg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = lds_frag(Bs, swz3(brow + j * 32, fkg));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a1[i] = lds_frag(cur, swz3(arow + i * 32, 2 + fkg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = lds_frag(Bs, swz3(brow + j * 32, 2 + fkg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#if defined(GEMM_LAB_NO_MFMA)
+                if (FIRST) { for (int r = 0; r < 16; ++r) acc[i][j][r] = 0; }
+                acc[i][j][0] += (int)(a0[i].x ^ b0[j].x);
+#else
+                if (FIRST) acc[i][j] = mma0<DT>(a0[i], b0[j]);
+                else mma<DT>(a0[i], b0[j], acc[i][j]);
+#endif
+            }
+            STREAM_DMA(rb, Bn + j * 1024, vb[j], ko);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#if defined(GEMM_LAB_NO_MFMA)
+                acc[i][j][1] += (int)(a1[i].x ^ b1[j].x);
+#else
+                mma<DT>(a1[i], b1[j], acc[i][j]);
+#endif
+            }
+            if (j < TM) STREAM_DMA(ra, An + j * 1024, va[j], ko);
+        }
+    };
+
+    for (unsigned local = j0; local < t_cnt; local += nj) {
+        const StreamTile tl = decode(local);
+        const int g = tl.g, gh = g % p.gmod, m0 = tl.mt * BM3, n0 = tl.nt * BN2;
+        const int ni0 = n0 >> rsh;
+        const bool edge = (m0 + BM3 > p.M) || (n0 + BN2 > p.N);
+        const unsigned lid = t_lo + local;
+        TL_STAMP(0);
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage `st` has landed once only the newest step's NP requests of this wave are still outstanding
+            if (TM == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int st2 = st == 0 ? 2 : st - 1;           // (st + 2) % 3
+            const int ko = i_k * BK3;
+            if (kt == 0) {
+                TL_STAMP(1);
+                // ---- epilogue operands of this tile: plain loads now (clamped addresses, no dependent arithmetic, so
+                // nothing waits before the MFMAs), masks + arithmetic + LDS staging writes after the step
+                const float* refg = p.ref + (int64_t)g * p.sRg;
+                const int rcs = (int)p.ref_cs;
+                constexpr int EU = (4 * BM3) / 256;
+                float e_ref[EU], e_rb[EU], e_cb[EU];
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int e = tid + u * 256;
+                    const int nl = e / BM3, rl = e - nl * BM3;
+                    const int rowc = min(m0 + rl, p.M - 1), nic = min(ni0 + nl, n_eff - 1);
+                    e_ref[u] = refg[rowc + nic * rcs];
+                    e_rb[u] = p.row_bias ? p.row_bias[rowc] : 0.0f;
+                    e_cb[u] = beta_staged ? p.bias[gh * p.bi_g + nic * p.bi_n] : 0.0f;
+                }
+                const int rrow = min(m0 + min(tid, BM3 - 1), p.M - 1);
+                const float e_rs = rows ? p.row_scale[rrow] : 1.0f;
+                const int colc = min(n0 + tid, p.N - 1);
+                const int cci = colc & rmask, cni = colc >> rsh;
+                const float e_sa = p.sa[cci * p.sa_c + gh * p.sa_g];
+                const float e_sb = p.sb[cci * p.sb_c + gh * p.sb_g + cni * p.sb_n];
+                const float e_be = beta_cols ? p.bias[cci * p.bi_c + gh * p.bi_g + cni * p.bi_n] : 0.0f;
+                step_first(ring + st * STAGE3, ring + st2 * STAGE3, ko);
+#pragma unroll
+                for (int u = 0; u < EU; ++u) {
+                    const int e = tid + u * 256;
+                    const int nl = e / BM3, rl = e - nl * BM3;
+                    const bool ok = (m0 + rl < p.M) && (ni0 + nl < n_eff);
+                    if (nl < nref) s_ref[e] = ok ? (e_ref[u] - e_rb[u]) - e_cb[u] : 0.0f;
+                }
+                if (tid < BM3) {
+                    const bool ok = m0 + tid < p.M;
+                    s_rs[tid] = ok ? e_rs : 0.0f;
+                    s_w[tid] = ok ? 1.0f : 0.0f;
+                }
+                {
+                    const bool ok = n0 + tid < p.N;
+                    s_alpha[tid] = ok ? -(e_sa * p.sa_mul * e_sb) : 0.0f;
+                    s_beta[tid] = ok ? e_be : 0.0f;
+                }
+                TL_STAMP(2);
+            } else {
+                step_next(ring + st * STAGE3, ring + st2 * STAGE3, ko);
+            }
+            issue_advance();
+            st = st == 2 ? 0 : st + 1;
+        }
+        TL_STAMP(3);
+
+        // ---- epilogue.  The staging written after the first step must be visible: with nk >= 2 a later step's barrier
+        // already separates them.
+        if (nk == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        v2f cs2[4];
+        float nal[4], bet[4], cm[4];
+        const float* rj[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cl = wc * 128 + j * 32 + frow;
+            nal[j] = s_alpha[cl]; bet[j] = s_beta[cl];
+            cm[j] = (n0 + cl < p.N) ? 1.0f : 0.0f;
+            rj[j] = s_ref + (cl >> rsh) * BM3;
+            cs2[j] = (v2f){0.0f, 0.0f};
+        }
+        const bool full = edge || beta_cols;                // generic body: row weights and column bias applied
+#define STREAM_EPILOGUE(ROWS_, FULL_)                                                                          \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                       \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                 \
+                const int rl = wr * (BM3 / 2) + i * 32 + 4 * fkg + 8 * q4;                                     \
+                float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), w4 = s4;                                          \
+                if (ROWS_) s4 = *reinterpret_cast<const float4*>(s_rs + rl);                                   \
+                if (FULL_) w4 = *reinterpret_cast<const float4*>(s_w + rl);                                    \
+                const v2f sA = {s4.x, s4.y}, sB = {s4.z, s4.w}, wA = {w4.x, w4.y}, wB = {w4.z, w4.w};          \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+                    const float4 r4 = *reinterpret_cast<const float4*>(rj[j] + rl);                            \
+                    v2f rA = {r4.x, r4.y}, rB = {r4.z, r4.w};                                                  \
+                    v2f tA = {(float)acc[i][j][q4 * 4 + 0], (float)acc[i][j][q4 * 4 + 1]};                     \
+                    v2f tB = {(float)acc[i][j][q4 * 4 + 2], (float)acc[i][j][q4 * 4 + 3]};                     \
+                    const v2f na = {nal[j], nal[j]};                                                           \
+                    if (ROWS_) { tA *= sA; tB *= sB; }                                                         \
+                    if (FULL_) { const v2f b2 = {bet[j], bet[j]}; rA -= b2; rB -= b2; }                        \
+                    v2f dA = tA * na + rA, dB = tB * na + rB;                                                  \
+                    if (FULL_) { dA *= wA; dB *= wB; }                                                         \
+                    cs2[j] += dA * dA; cs2[j] += dB * dB;                                                      \
+                }                                                                                              \
+            }                                                                                                  \
+        }
+        if (full) { STREAM_EPILOGUE(true, true) }
+        else if (rows) { STREAM_EPILOGUE(true, false) }
+        else { STREAM_EPILOGUE(false, false) }
+#undef STREAM_EPILOGUE
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float cs = (cs2[j].x + cs2[j].y) * cm[j];
+            cs += __shfl_xor(cs, 32);
+            if (fkg == 0) s_red[wr][wc * 128 + j * 32 + frow] = cs;
+        }
+        TL_STAMP(4);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // not __syncthreads(): its fence would drain the DMA
+        TL_STAMP(5);
+        {
+            const int col = n0 + tid;
+            if (col < p.N)
+                p.partial[((((int64_t)g) * p.MT + tl.mt) * p.Npad + (col >> rsh)) * p.ref_div + (col & rmask)] =
+                    s_red[0][tid] + s_red[1][tid];
+        }
+        TL_STAMP(6);
+        TL_STAMP(7);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the two run-ahead steps before the LDS is released
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ finish
@@ -772,6 +1132,51 @@ __global__ __launch_bounds__(256) void k_finish_tpo(FinishArgs p) {
     p.scores[((int64_t)c * nh + h) * nn + n] = (float)(-p.norm * acc);
 }
 
+// Two-stage finish for the candidate-innermost layout when the score does not keep the column axis (activation and
+// attention searches: 10^4..10^5 terms per output).  Stage 1 walks [rows][cin] with the candidates across adjacent
+// threads (every load instruction reads whole 256..1024-byte rows; the one-block-per-output form above strides by cin
+// floats and reached 0.3 TB/s), 128 rows per block in fp64; stage 2 adds the per-block sums in a fixed order.
+constexpr int FSEG = 128;
+__global__ __launch_bounds__(256) void k_finish_rows(FinishArgs p, double* part2, int nseg) {
+    __shared__ double sm[256];
+    const int cin = p.cin, lanes = 256 / cin;                 // cin is 64, 128 or 256
+    const int c = threadIdx.x % cin, rl = threadIdx.x / cin;
+    const int seg = blockIdx.x;
+    const int64_t combo = blockIdx.y;                         // g * MT + mt
+    const float* base = p.partial + (combo * p.Npad) * cin + c;
+    const int n_hi = min(p.N, (seg + 1) * FSEG);
+    double acc = 0.0;
+    for (int n = seg * FSEG + rl; n < n_hi; n += lanes) acc += (double)base[(int64_t)n * cin];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; ++l) acc += sm[l * cin + c];
+        part2[(combo * nseg + seg) * cin + c] = acc;
+    }
+}
+
+// one wavefront per output (c, h): terms = (image, [head], m-tile, segment) in a fixed lane-strided order
+__global__ __launch_bounds__(256) void k_finish_stage2(FinishArgs p, const double* part2, int nseg) {
+    const int nh = p.keep_h ? p.gmod : 1;
+    const int lane = threadIdx.x & 63;
+    const int oid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (oid >= p.C * nh) return;
+    const int h = oid % nh, c = oid / nh;
+    const int imgs = p.G / p.gmod, h_lo = p.keep_h ? h : 0, h_cnt = p.keep_h ? 1 : p.gmod;
+    const int per_g = p.MT * nseg;
+    const int64_t total = (int64_t)imgs * h_cnt * per_g;
+    double acc = 0.0;
+    for (int64_t i = lane; i < total; i += 64) {
+        const int r = (int)(i % per_g);
+        const int64_t t = i / per_g;
+        const int g = (int)(t / h_cnt) * p.gmod + h_lo + (int)(t % h_cnt);
+        acc += part2[((int64_t)g * per_g + r) * p.cin + c];
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) acc += __shfl_xor(acc, s);
+    if (lane == 0) p.scores[(int64_t)c * nh + h] = (float)(-p.norm * acc);
+}
+
 }  // namespace
 
 // ---- tile selection shared by launch, layout query and finish
@@ -820,7 +1225,7 @@ extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_
 }
 
 extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
-                                 int64_t sBg, int M, int N, int64_t Kp, int C, int G, int gmod, const float* ref,
+                                 int64_t sBg, int M, int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref,
                                  int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c,
                                  int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
                                  const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, const float* row_scale,
@@ -842,7 +1247,8 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     GemmArgs p{};
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
     p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;
-    p.M = M; p.N = N; p.Kb = Kp * esz; p.C = C; p.G = G; p.gmod = gmod;
+    ADALOG_ARG_CHECK(k_valid >= 0 && k_valid <= Kp, "gemm_score: k_valid must be in [0, Kp]");
+    p.M = M; p.N = N; p.Kb = Kp * esz; p.Kvb = (k_valid > 0 ? k_valid : Kp) * esz; p.C = C; p.G = G; p.gmod = gmod;
     p.ref = ref; p.ldr = ldr; p.sRg = sRg; p.ref_cs = ref_cs; p.ref_div = ref_div;
     ADALOG_ARG_CHECK(!ref || ((int64_t)(M - 1) * ldr + (int64_t)(L.n_eff - 1) * (ref_cs > 0 ? ref_cs : 1) < ((int64_t)1 << 31)),
                      "gemm_score: reference group exceeds 32-bit addressing");
@@ -851,7 +1257,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;
     p.row_scale = row_scale; p.row_bias = row_bias;
     p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad;
-    p.order = order; p.reduce_cols = reduce_cols;
+    p.order = order; p.reduce_cols = reduce_cols; p.timeline = g_timeline;
     p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
     if (partial) ADALOG_ARG_CHECK(partial_elems >= (int64_t)L.c_eff * G * L.MT * L.Npad, "gemm_score: partial buffer too small");
     const int64_t nwg = (int64_t)L.MT * L.NT * G * C;
@@ -859,7 +1265,34 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nwg);
     static const int use_glds = getenv("ADALOG_GEMM_GLDS") ? atoi(getenv("ADALOG_GEMM_GLDS")) : 1;   // LDS-DMA pipeline (default on)
-    if (L.big && use_glds && !out && L.tm <= 2) {
+    static const int use_stream = getenv("ADALOG_GEMM_STREAM") ? atoi(getenv("ADALOG_GEMM_STREAM")) : 1;
+    if (L.big && use_stream && !out && L.tm <= 2 && ldr == 1 && (ref_div == 64 || ref_div == 128 || ref_div == 256) &&
+        (int64_t)(64 * L.tm + BN2) * p.Kb < ((int64_t)1 << 31)) {
+        // persistent streaming kernel: two workgroups per CU walk the tile list
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+            if (n_cu <= 0) n_cu = 256;
+        }
+        const int64_t want = (int64_t)2 * n_cu;
+        dim3 pgrid((unsigned)(nwg < want ? nwg : want));
+        const size_t shm = (size_t)NS3 * (64 * L.tm + BN2) * BK3;
+#define LAUNCH_STREAM(DT, TMV)                                                                                    \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<DT, TMV>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            hipLaunchKernelGGL((k_gemm_stream<DT, TMV>), pgrid, dim3(256), shm, st, p);                           \
+        } while (0)
+        if (dtype == 0) { if (L.tm == 2) LAUNCH_STREAM(0, 2); else LAUNCH_STREAM(0, 1); }
+        else if (dtype == 1) { if (L.tm == 2) LAUNCH_STREAM(1, 2); else LAUNCH_STREAM(1, 1); }
+        else { if (L.tm == 2) LAUNCH_STREAM(2, 2); else LAUNCH_STREAM(2, 1); }
+#undef LAUNCH_STREAM
+    } else if (L.big && use_glds && !out && L.tm <= 2) {
         const size_t shm = (size_t)3 * (64 * L.tm + BN2) * BK2 + (512 + 256) * sizeof(float);
 #define LAUNCH_GLDS(DT, TMV)                                                                                      \
         do {                                                                                                      \
@@ -916,8 +1349,14 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
 
 // scores[c][h?][n?] = -norm * sum over (image, [h], m_tile, [n]) of partial[c][g][m_tile][n] with the layout returned by
 // adalog_gemm_score_layout (MT, Npad); N = number of valid entries along the last axis (n_eff, or NT when reduced).
+extern "C" int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, int cand_inner) {
+    if (!cand_inner || keep_n || !(C == 64 || C == 128 || C == 256)) return 0;
+    return (int64_t)G * MT * cdiv(N, FSEG) * C * (int64_t)sizeof(double);
+}
+
 extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
-                                    int keep_h, int keep_n, int cand_inner, double norm, void* stream) {
+                                    int keep_h, int keep_n, int cand_inner, double norm, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
     ADALOG_ARG_CHECK(partial && scores && MT >= 1 && N >= 1 && Npad >= N && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0,
                      "finish_scores: bad arguments");
     FinishArgs p{};
@@ -925,7 +1364,14 @@ extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT,
     p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm; p.cin = cand_inner ? C : 0;
     const int64_t nout = (int64_t)C * (keep_h ? gmod : 1) * (keep_n ? N : 1);
     const int64_t per_out = (int64_t)(G / gmod) * (keep_h ? 1 : gmod) * MT * (keep_n ? 1 : N);
-    if (p.cin > 0 && per_out <= 512 && nout >= 4096)
+    const int64_t need = adalog_finish_workspace_bytes(MT, N, C, G, keep_n, cand_inner);
+    if (need > 0 && workspace && workspace_bytes >= need && per_out >= 1024) {
+        const int nseg = cdiv(N, FSEG);
+        hipLaunchKernelGGL(k_finish_rows, dim3((unsigned)nseg, (unsigned)(G * MT)), dim3(256), 0, (hipStream_t)stream, p,
+                           (double*)workspace, nseg);
+        hipLaunchKernelGGL(k_finish_stage2, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                           (const double*)workspace, nseg);
+    } else if (p.cin > 0 && per_out <= 512 && nout >= 4096)
         hipLaunchKernelGGL(k_finish_tpo, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     else if (per_out >= 2048)
         hipLaunchKernelGGL(k_finish<false>, dim3((unsigned)nout), dim3(256), 0, (hipStream_t)stream, p);

@@ -115,6 +115,7 @@ def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr:
                                         pg, pr, int(n_bits), dtype, out.data_ptr(), Kp, _ptr(rowsum), int(bool(c_inner)),
                                         _stream())
     _lib.check(rc, "adalog_pack_uniform")
+    out.k_valid = K                                     # columns [K, Kp) are zero padding: gemm_score may skip them
     return (out, rowsum) if want_rowsum else out
 
 
@@ -129,6 +130,7 @@ def pack_adalog(x3, scale, qv, C: int, pc: int, gmod: int, pg: int, n_bits: int,
                                             _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(clamp_u)),
                                             out.data_ptr(), Kp, int(bool(c_inner)), _stream())
     _lib.check(rc, "adalog_pack_adalog_bf16")
+    out.k_valid = K
     return out
 
 
@@ -196,7 +198,8 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, n_cols, Kp, c_grid, G, gmod,
+    k_valid = min(getattr(A, "k_valid", Kp), getattr(B, "k_valid", Kp))
+    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, n_cols, Kp, k_valid, c_grid, G, gmod,
                                ref.data_ptr(), ldr, sRg, ref_cs, ref_div, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul),
                                sb.t.data_ptr(), sb.c, sb.g, sb.n,
                                None if bias is None else bias.t.data_ptr(),
@@ -212,8 +215,10 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     cols = (gmod if keep_h else 1) * (N if keep_n else 1)
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
     n_last = Npad if reduce_cols else N                 # reduced: one partial per n-tile (Npad = NT)
+    ws_bytes = lib.adalog_finish_workspace_bytes(MT, n_last, C, G, int(keep_n), int(ref_div > 1))
+    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=A.device) if ws_bytes else None
     rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), MT, n_last, Npad, C, G, gmod, int(keep_h),
-                                  int(keep_n), int(ref_div > 1), float(norm), _stream())
+                                  int(keep_n), int(ref_div > 1), float(norm), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, "adalog_finish_scores")
     return scores
 
@@ -229,7 +234,7 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
     sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
     sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
     out = torch.empty((G, M, N), dtype=torch.float32, device=A.device)
-    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), 0, sAg, 0, sBg, M, N, Kp, 1, G, gmod, None, 0, 0, 1, 1,
+    rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), 0, sAg, 0, sBg, M, N, Kp, 0, 1, G, gmod, None, 0, 0, 1, 1,
                                sa.t.data_ptr(), sa.c, sa.g, float(sa_mul), sb.t.data_ptr(), sb.c, sb.g, sb.n,
                                None if bias is None else bias.t.data_ptr(),
                                0 if bias is None else bias.c, 0 if bias is None else bias.g,

@@ -65,14 +65,24 @@ class GemmProfiler:
     def stop(self):
         ev, self.ops.GEMM_EVENTS = self.ops.GEMM_EVENTS, None
         torch.cuda.synchronize()
-        by = {}
+        by, shapes = {}, {}
         for dt, M, N, Kp, C, G, pa, pb, s, e in ev:
             K = min(self.true_k.get(pa, Kp), self.true_k.get(pb, Kp))
-            b = by.setdefault(dt, [0.0, 0.0, 0])
-            b[0] += 2.0 * M * N * K * C * G
-            b[1] += s.elapsed_time(e)
-            b[2] += 1
+            ms = s.elapsed_time(e)
+            for d, key in ((by, dt), (shapes, (dt, M, N, K, C, G))):
+                b = d.setdefault(key, [0.0, 0.0, 0])
+                b[0] += 2.0 * M * N * K * C * G
+                b[1] += ms
+                b[2] += 1
+        self.shapes = shapes
         return by
+
+    def top_shapes(self, steps, n=14):
+        """Per-shape totals (rows x columns x K, candidates, groups), largest time first."""
+        rows = sorted(self.shapes.items(), key=lambda kv: -kv[1][1])[:n]
+        return [{"dtype": DT_NAME[k[0]], "M": k[1], "N": k[2], "K": k[3], "cands": k[4], "groups": k[5],
+                 "launches_per_step": v[2] / steps, "ms_per_step": round(v[1] / steps, 2),
+                 "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in rows]
 
 
 def cpu_baseline(threads):
@@ -191,6 +201,7 @@ def main():
                        "scoring_gemm_by_dtype": {DT_NAME[d]: {"launches_per_step": v[2] / args.steps,
                                                               "ms_per_step": v[1] / args.steps,
                                                               "tflops": v[0] / (v[1] * 1e-3) / 1e12} for d, v in by.items()},
+                       "scoring_gemm_top_shapes": prof.top_shapes(args.steps),
                        "depth_override": args.depth},
             "roofline": {"bound": "mfma", "kernel": f"k_gemm_score<{DT_NAME[dom]}>", "achieved": achieved,
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom], "traffic": None,

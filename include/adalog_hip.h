@@ -86,9 +86,12 @@ int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t
  *   [C][G][m_tile][n_tile] -- for searches whose score does not keep the column axis.
  * order: workgroup -> tile order, fastest index first (L2 reuse): 0 = n,m,g,c   1 = n,c,m,g   2 = m,n,c,g.
  * dtype: 0 = int8 (exact integer dot products), 1 = bf16, 2 = fp32.  bias may be NULL.  partial and ref go together.
- * partial must hold adalog_gemm_score_partial_elems(M, N, C, G) floats. */
+ * Kp: row stride of both packed operands in elements (a multiple of 128 bytes); k_valid: leading elements of a row that
+ *   can be non-zero (the pack kernels zero-fill [K, Kp)); 0 means Kp.  The streaming kernel skips whole 64-byte
+ *   K-steps of padding (q.k^T with head_dim 64: half of the padded row).
+ * partial must hold adalog_gemm_score_layout(M, N, C, G, ...) floats. */
 int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc, int64_t sBg, int M,
-                      int N, int64_t Kp, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int64_t ref_cs,
+                      int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int64_t ref_cs,
                       int ref_div, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
                       int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n,
                       const float* row_scale, const float* row_bias, float* partial, int64_t partial_elems, float* out,
@@ -109,7 +112,10 @@ int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int re
  *   MatMul per head       keep_h=1 -> [P][H]   (matmul.py:154-164, norm = 1/(S*S'))
  *   post-softmax base     none     -> [P]      (matmul.py:345-352, norm = 1/(H*S*S')) */
 int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
-                         int keep_n, int cand_inner, double norm, void* stream);
+                         int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes, void* stream);
+/* Scratch for the two-stage form used when cand_inner = 1 and keep_n = 0 (sums of 10^4..10^5 terms per candidate): bytes
+ * to pass as `workspace` (0: not needed; a NULL / short workspace falls back to the one-pass kernels). */
+int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, int cand_inner);
 
 /* ---- K16  FPCS driver pieces                 reference linear.py:483-523, matmul.py:243-262, conv.py:292-311
  * adalog_topk: idx[j][col] = candidate with the j-th best score of column col, j < k; order (score desc, index asc),

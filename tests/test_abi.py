@@ -38,7 +38,7 @@ def test_argument_rejection_without_gpu():
     lib = _lib.load()
     rc = lib.adalog_topk(None, 128, 4, 1, None, None)
     assert rc == -1 and b"topk" in lib.adalog_last_error()
-    rc = lib.adalog_gemm_score(7, None, None, 0, 0, 0, 0, 1, 1, 64, 1, 1, 1, None, 0, 0, 1, 1, None, 0, 0, 1.0,
+    rc = lib.adalog_gemm_score(7, None, None, 0, 0, 0, 0, 1, 1, 64, 0, 1, 1, 1, None, 0, 0, 1, 1, None, 0, 0, 1.0,
                                None, 0, 0, 0, None, 0, 0, 0, None, None, None, 0, None, 0, 0, 0, 0, 0, None)
     assert rc == -1
 

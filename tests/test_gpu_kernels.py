@@ -476,3 +476,42 @@ def test_gemm_cand_kernel_row_scale_and_tiles(ops, dtype, M):
                                      0.01, sa_mul=0.5, ref_div=P, order=order, ref_transposed=True, row_scale=rs.to(DEV),
                                      row_bias=rb.to(DEV))
                 assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (K, keep_h, order, rel_err(got.cpu(), want))
+
+
+@pytest.mark.parametrize("dtype", ["i8", "bf16"])
+@pytest.mark.parametrize("P", [64, 128, 256])
+def test_gemm_stream_kernel_variants(ops, dtype, P):
+    """Persistent streaming kernel (ref_div in {64, 128, 256}, transposed reference): column bias shared by the candidates
+    (folded into the staged reference), per-(candidate, column) bias, no bias; with and without a row scale; K padding
+    skipped through k_valid; ragged M and N edges; several groups -- against the CPU specification."""
+    gen = g(1200 + P)
+    dt_c, dt_o = (CB.I8, ops.I8) if dtype == "i8" else (CB.BF16, ops.BF16)
+    tdt = torch.int8 if dtype == "i8" else torch.bfloat16
+    G, gmod = 3, 1
+    for M, Ncols, K in ((197, 5, 64), (300, 11, 136), (64, 3, 40)):
+        Kp = CB.pad_k(K, dt_c)
+        A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
+        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).to(tdt)
+        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).to(tdt)
+        ref = torch.randn(G, Ncols, M, generator=gen) * 3
+        sa = torch.rand(1, generator=gen) * 0.02 + 0.01
+        sb = torch.rand(P, Ncols, generator=gen) * 0.5 + 0.5
+        rs = torch.rand(M, generator=gen) + 0.5; rb = torch.randn(M, generator=gen)
+        b_n = torch.randn(Ncols, generator=gen); b_cn = torch.randn(P, Ncols, generator=gen)
+        for bias_kind in ("none", "n", "cn"):
+            for rows in (False, True):
+                cb = {"none": None, "n": CB.Strided(b_n, n=1), "cn": CB.Strided(b_cn, c=Ncols, n=1)}[bias_kind]
+                want = CB.gemm_score(dt_c, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa), CB.Strided(sb, c=Ncols, n=1), cb,
+                                     False, True, 0.01, ref_div=P, ref_transposed=True,
+                                     row_scale=rs if rows else None, row_bias=rb if rows else None)
+                ob = {"none": None, "n": ops.Strided(b_n.to(DEV), n=1), "cn": ops.Strided(b_cn.to(DEV), c=Ncols, n=1)}[bias_kind]
+                for kv in (None, K):
+                    Ad, Bd = A.to(DEV), B.to(DEV)
+                    if kv is not None:
+                        Ad.k_valid = kv; Bd.k_valid = kv
+                    got = ops.gemm_score(dt_o, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV)),
+                                         ops.Strided(sb.to(DEV), c=Ncols, n=1), ob, False, True, 0.01, ref_div=P, order=2,
+                                         ref_transposed=True, row_scale=rs.to(DEV) if rows else None,
+                                         row_bias=rb.to(DEV) if rows else None)
+                    assert got.shape == want.shape
+                    assert rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, K, bias_kind, rows, kv, rel_err(got.cpu(), want))
