@@ -47,6 +47,7 @@ struct GemmArgs {
     float sa_mul;                    // constant folded into sa (e.g. 1/(4L-2) for AdaLog numerators)
     int reduce_cols;                 // 1: one partial per tile (sum over its columns) instead of one per column
     int order;                       // tile order (fastest index first): 0 = nt,mt,g,c  1 = nt,c,mt,g  2 = mt,nt,c,g
+    int gm;                          // streaming kernel, order 2: m-tiles per L2 group (rows of A kept hot while n advances)
     long long* timeline;             // profiling only (tools/gemm_lab.hip): 8 cycle stamps per workgroup, else nullptr
 };
 #define TL_STAMP(i) do { if (p.timeline && threadIdx.x == 0) p.timeline[(size_t)lid * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
@@ -779,8 +780,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
     auto decode = [&](unsigned local) {
         unsigned t = t_lo + local;
         StreamTile r;
-        if (p.order == 2) { r.mt = t % p.MT; t /= p.MT; r.nt = t % p.NT; r.g = t / p.NT; }
-        else { r.nt = t % p.NT; t /= p.NT; r.mt = t % p.MT; r.g = t / p.MT; }
+        if (p.order == 2) {
+            // grouped: within a group of gm m-tiles the m index runs fastest, then n; the group's A rows (<= ~2 MiB)
+            // stay in the XCD's L2 while the B tiles stream through once per group
+            const unsigned per_g = (unsigned)p.MT * p.NT;
+            r.g = t / per_g; t -= r.g * per_g;
+            const unsigned grp = t / ((unsigned)p.gm * p.NT), first = grp * p.gm;
+            const unsigned gsz = min((unsigned)p.gm, (unsigned)p.MT - first);
+            t -= grp * p.gm * p.NT;
+            r.nt = t / gsz; r.mt = first + (t - r.nt * gsz);
+        } else { r.nt = t % p.NT; t /= p.NT; r.mt = t % p.MT; r.g = t / p.MT; }
         return r;
     };
     const int nk = (int)((p.Kvb + BK3 - 1) / BK3);          // whole 64-byte steps of zero padding are skipped
@@ -1276,6 +1285,12 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
             if (n_cu <= 0) n_cu = 256;
         }
         const int64_t want = (int64_t)2 * n_cu;
+        {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)
+            const int64_t a_tile = (int64_t)64 * L.tm * p.Kb;
+            int64_t gm = ((int64_t)2 << 20) / a_tile;
+            if (const char* e = getenv("ADALOG_GEMM_GM")) gm = atoi(e);
+            p.gm = (int)(gm < 1 ? 1 : gm > L.MT ? L.MT : gm);
+        }
         dim3 pgrid((unsigned)(nwg < want ? nwg : want));
         const size_t shm = (size_t)NS3 * (64 * L.tm + BN2) * BK3;
 #define LAUNCH_STREAM(DT, TMV)                                                                                    \

@@ -123,11 +123,12 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
     extern __shared__ unsigned short s_lut[];
     const float sh = (KIND == KIND_ADALOG && a.shift) ? a.shift[0] : 0.0f;
     if (KIND == KIND_ADALOG) {
-        for (int e = threadIdx.x; e < (int)a.C * a.levels2; e += blockDim.x) {
-            const int c = e / a.levels2, k = e - c * a.levels2;
+        const int lw = a.levels2 + 1;                                        // entry [2L] = 0: masked bins
+        for (int e = threadIdx.x; e < (int)a.C * lw; e += blockDim.x) {
+            const int c = e / lw, k = e - c * lw;
             const int kqv = k * (int)a.qv[c * a.pc];
             const int t = kqv / ADALOG_R, j = kqv - t * ADALOG_R;
-            const float v = (t > 100) ? 0.0f : ldexpf(a.mant[j], -t);
+            const float v = (k == a.levels2 || t > 100) ? 0.0f : ldexpf(a.mant[j], -t);
             s_lut[e] = (unsigned short)(__float_as_uint(v) >> 16);          // exact: <= 8 significant bits
         }
         __syncthreads();
@@ -153,8 +154,10 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
             for (int e = 0; e < 4; ++e) {
                 if (a.shift) xv[e] += sh;
                 lx[e] = __log2f(xv[e]);                                       // -inf for 0, NaN for negatives
+                if (a.clamp_u && !(lx[e] == lx[e])) lx[e] = -__builtin_inff(); // negatives clamp to u = 1e-15 like zeros
             }
         }
+        const bool full = k0 + 3 < a.K;
         const int64_t pbase = (g % a.gmod) * a.pg + r * a.pr;
         for (int64_t c = blockIdx.y; c < a.C; c += gridDim.y) {
             alignas(16) T vals[4];
@@ -163,37 +166,53 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vals[e] = cvt<T>(xv[e]);
             } else if (KIND == KIND_UNIFORM) {
+                // per element: mul, rint, sub, cmp (tie zone -> exact divide, rare), med3 [, add, cvt_pk_u8]
                 const float s = a.scale[c * a.pc + pbase], z = rintf(a.zp[c * a.pc + pbase]);
-                const float inv_s = 1.0f / s;
+                const float inv_s = __builtin_amdgcn_rcpf(s);
+                const float lo = -z, hi = a.qmax - z;                     // clamp(k + z, 0, qmax) - z == med3(k, -z, qmax - z)
+                float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = 0.0f;
-                    if (k0 + e < a.K) v = uni_bin_fast(xv[e], s, inv_s, z, a.qmax) - z;
-                    isum += (int)v;
-                    vals[e] = cvt<T>(v);
+                    const float t = xv[e] * inv_s;
+                    float k = rintf(t);
+                    if (__builtin_expect(fabsf(t - k) > 0.499f, 0)) k = rintf(xv[e] / s);
+                    v[e] = __builtin_amdgcn_fmed3f(k, lo, hi);
+                    if (!full && !(k0 + e < a.K)) v[e] = 0.0f;
+                }
+                if (a.rowsum) isum = (int)((v[0] + v[1]) + (v[2] + v[3]));    // small integers: exact in fp32
+                if (sizeof(T) == 1) {
+                    // (v + 128) saturates into a byte lane per instruction; xor 0x80 turns it into two's complement
+                    unsigned pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(v[e] + 128.0f, e, pk);
+                    *reinterpret_cast<unsigned*>(vals) = pk ^ 0x80808080u;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vals[e] = cvt<T>(v[e]);
                 }
             } else {
+                // per element: fma, med3, rint, sub, cmp (tie zone -> exact path, rare), min, cvt, LDS read
                 const float s = a.scale[c * a.pc + pbase];
                 const float qf = a.qv[c * a.pc];
-                const float ls = __log2f(s), rq37 = 37.0f / qf;
+                const float rq37 = 37.0f / qf, lsr = __log2f(s) * rq37;
                 const float tmax = NL15 * rq37;
-                const unsigned short* lut = s_lut + c * a.levels2;
+                const unsigned short* lut = s_lut + c * (a.levels2 + 1);
                 unsigned short hv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    unsigned short h = 0;
-                    if (k0 + e < a.K) {
-                        float t = (ls - lx[e]) * rq37;
-                        if (a.clamp_u) t = fminf(fmaxf(t, 0.0f), tmax);       // u clamped to [1e-15, 1]; NaN (x<0) -> tmax side
-                        if (a.clamp_u && !(lx[e] == lx[e])) t = tmax;
-                        float kk = rintf(t);
-                        if (__builtin_expect(fabsf(t - kk) > 0.499f && t < 1.0e4f, 0)) {
-                            float ue = xv[e] / s;
-                            if (a.clamp_u) ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
-                            kk = adalog_k(ue, qf);
-                        }
-                        if (kk < (float)a.levels2 && kk == kk) h = lut[(int)fmaxf(kk, 0.0f)];
+                    float t = lsr - lx[e] * rq37;                             // (log2 s - log2 x) * 37 / q
+                    if (a.clamp_u) t = __builtin_amdgcn_fmed3f(t, 0.0f, tmax); // u clamped to [1e-15, 1]  (lx = -inf for x <= 0)
+                    float kk = rintf(t);
+                    if (__builtin_expect(fabsf(t - kk) > 0.499f && t < 1.0e4f, 0)) {
+                        float ue = xv[e] / s;
+                        if (a.clamp_u) ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
+                        kk = adalog_k(ue, qf);
                     }
+                    // bins >= 2L are masked: LUT entry [2L] is 0.  NaN (x < 0 without the clamp) -> 0 as well.
+                    const float kc = fminf(fmaxf(kk, 0.0f), (float)a.levels2);
+                    unsigned short h = lut[(int)kc];
+                    if (!a.clamp_u && !(kk == kk)) h = 0;
+                    if (!full && !(k0 + e < a.K)) h = 0;
                     hv[e] = h;
                 }
                 *reinterpret_cast<uint2*>(vals) = make_uint2((unsigned)hv[0] | ((unsigned)hv[1] << 16),
@@ -232,7 +251,7 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         // enough candidate groups to fill the chip when the source is small (weights), all candidates per thread otherwise
         int64_t gy = 1;
         while (gx * gy < 2048 && gy < a.C) gy *= 2;
-        const size_t shm = (KIND == KIND_ADALOG) ? (size_t)a.C * a.levels2 * sizeof(unsigned short) : 0;
+        const size_t shm = (KIND == KIND_ADALOG) ? (size_t)a.C * (a.levels2 + 1) * sizeof(unsigned short) : 0;
         if (KIND != KIND_ADALOG || (a.pg == 0 && shm <= 64 * 1024)) {
             hipLaunchKernelGGL((k_pack_kfast<T, KIND>), dim3((unsigned)gx, (unsigned)gy), dim3(256), shm, st, a);
             return 0;

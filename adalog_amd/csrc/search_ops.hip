@@ -134,16 +134,34 @@ __global__ __launch_bounds__(256) void k_score_a_self(const float* __restrict__ 
         xv[r] = (cv && row < rows) ? x[row * I + ch] : __builtin_nanf("");
     }
     const int cols = pstride_ch ? I : 1;
+    const bool slab_full = cv && (r0 + 4 * (SLAB_ROWS_PER_THREAD - 1) < rows);
     for (int p = 0; p < P; ++p) {
         const int64_t pi = (int64_t)p * cols + (pstride_ch ? (cv ? ch : 0) : 0);
         const float s = scale[pi], z = zp[pi];
         float acc = 0.0f;
+        if (slab_full) {
+            // reciprocal fast path; inside the tie zone (|frac - 0.5| < 1e-3) the exact IEEE quotient decides, so the bin
+            // is the one rintf(v / s) gives.  clamp(k + z, 0, qmax) - z == med3(k, -z, qmax - z) for integral z.
+            const float inv_s = __builtin_amdgcn_rcpf(s), lo = -z, hi = qmax - z;
+            const bool zint = rintf(z) == z;
 #pragma unroll
-        for (int r = 0; r < SLAB_ROWS_PER_THREAD; ++r) {
-            const float v = xv[r];
-            const float dq = (fminf(fmaxf(rintf(v / s) + z, 0.0f), qmax) - z) * s;
-            const float e = v - dq;
-            acc += (v == v) ? e * e : 0.0f;
+            for (int r = 0; r < SLAB_ROWS_PER_THREAD; ++r) {
+                const float v = xv[r];
+                const float t = v * inv_s;
+                float k = rintf(t);
+                if (__builtin_expect(fabsf(t - k) > 0.499f, 0)) k = rintf(v / s);
+                const float kq = zint ? __builtin_amdgcn_fmed3f(k, lo, hi) : fminf(fmaxf(k + z, 0.0f), qmax) - z;
+                const float e = v - kq * s;
+                acc += e * e;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < SLAB_ROWS_PER_THREAD; ++r) {
+                const float v = xv[r];
+                const float dq = (fminf(fmaxf(rintf(v / s) + z, 0.0f), qmax) - z) * s;
+                const float e = v - dq;
+                acc += (v == v) ? e * e : 0.0f;
+            }
         }
         red[rg][chl] = acc;
         __syncthreads();
