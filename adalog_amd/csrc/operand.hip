@@ -11,6 +11,7 @@
 // zero padded (zeros contribute nothing to the integer dot product).
 #include "common.h"
 #include <hip/hip_bf16.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -175,7 +176,9 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     const float t = xv[e] * inv_s;
                     float k = rintf(t);
-                    if (__builtin_expect(fabsf(t - k) > 0.499f, 0)) k = rintf(xv[e] / s);
+                    // tie zone: the reciprocal path is within 1.8e-7 * |t| of x/s, i.e. < 1e-4 wherever the clamp does not
+                    // decide anyway (|t| < 555), so only |frac - 0.5| < 1e-4 needs the exact quotient
+                    if (__builtin_expect(fabsf(t - k) > 0.4999f, 0)) k = rintf(xv[e] / s);
                     v[e] = __builtin_amdgcn_fmed3f(k, lo, hi);
                     if (!full && !(k0 + e < a.K)) v[e] = 0.0f;
                 }
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
                 const float s = a.scale[c * a.pc + pbase];
                 const float qf = a.qv[c * a.pc];
                 const float rq37 = 37.0f / qf, lsr = __log2f(s) * rq37;
-                const float tmax = NL15 * rq37;
+                const float tmax = NL15 * rq37, lvl1 = (float)a.levels2 + 1.0f;
                 const unsigned short* lut = s_lut + c * (a.levels2 + 1);
                 unsigned short hv[4];
 #pragma unroll
@@ -203,7 +206,10 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
                     float t = lsr - lx[e] * rq37;                             // (log2 s - log2 x) * 37 / q
                     if (a.clamp_u) t = __builtin_amdgcn_fmed3f(t, 0.0f, tmax); // u clamped to [1e-15, 1]  (lx = -inf for x <= 0)
                     float kk = rintf(t);
-                    if (__builtin_expect(fabsf(t - kk) > 0.499f && t < 1.0e4f, 0)) {
+                    // tie zone: for t < 2L + 1 (larger bins are masked to 0 whatever they round to) the fast t is within ~1e-5
+                    // of the reference's fp32 pipeline, so |frac - 0.5| < 1e-4 is where the exact path (fp64 log2) decides.
+                    // Any lane taking it stalls its whole wave: the margin is kept as narrow as the error bound allows.
+                    if (__builtin_expect(fabsf(t - kk) > 0.4999f && t < lvl1 && t > -1.0f, 0)) {
                         float ue = xv[e] / s;
                         if (a.clamp_u) ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
                         kk = adalog_k(ue, qf);
@@ -240,6 +246,97 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
     }
 }
 
+// AdaLog packing, per-tensor scale (pg == 0), K-contiguous source: the hot form (post-GELU and post-softmax
+// searches write 2.5 GB of bf16 per call).  Everything that depends only on the candidate -- the value LUT, 37/q,
+// log2(s)*37/q, the clamp bound -- is built once per block in LDS, so a candidate costs per element
+//   fma, med3, rndne, sub, cmp(tie zone), cvt, address, ds_read_u16   (+ 1/2 v_perm, 1/4 store).
+// Bins >= 2L and x <= 0 without the u-clamp read one of two zero entries behind each LUT row, so no select is needed.
+__global__ __launch_bounds__(256) void k_pack_adalog_fast(PackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    const int lw = a.levels2 + 2;
+    float4* s_par = reinterpret_cast<float4*>(s_raw);                       // [C] {37/q, log2(s)*37/q, lower, upper}
+    unsigned short* s_lut = reinterpret_cast<unsigned short*>(s_raw + (size_t)a.C * sizeof(float4));   // [C][2L + 2]
+    const float NL15 = 49.828921f;                                           // -fl32(log2(1e-15f))
+    for (int e = threadIdx.x; e < (int)a.C * lw; e += blockDim.x) {
+        const int c = e / lw, k = e - c * lw;
+        const int kqv = k * (int)a.qv[c * a.pc];
+        const int t = kqv / ADALOG_R, j = kqv - t * ADALOG_R;
+        const float v = (k >= a.levels2 || t > 100) ? 0.0f : ldexpf(a.mant[j], -t);
+        s_lut[e] = (unsigned short)(__float_as_uint(v) >> 16);              // exact: <= 8 significant bits
+    }
+    for (int c = threadIdx.x; c < (int)a.C; c += blockDim.x) {
+        const float s = a.scale[c * a.pc], qf = a.qv[c * a.pc];
+        const float rq37 = 37.0f / qf;
+        const float top = (float)a.levels2 + 0.75f;                          // rounds to 2L + 1: a zero entry
+        s_par[c] = make_float4(rq37, __log2f(s) * rq37, a.clamp_u ? 0.0f : -0.25f,
+                               a.clamp_u ? fminf(NL15 * rq37, top) : top);
+    }
+    __syncthreads();
+    const float sh = a.shift ? a.shift[0] : 0.0f;
+    const int64_t nq = a.Kp >> 2;
+    const int64_t total = a.G * a.R * nq;
+    const int64_t cstep = gridDim.y;
+    const bool ragged = (a.K & 3) != 0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t kq = idx % nq;
+        const int64_t t0 = idx / nq;
+        const int64_t r = t0 % a.R, g = t0 / a.R;
+        const int64_t k0 = kq << 2;
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        const int nlive = (int)min((int64_t)4, max((int64_t)0, a.K - k0));   // data elements of this quad (rest: zero padding)
+        const bool live = nlive > 0;
+        if (live) {
+            const float* xp = a.x + g * a.sxg + r * a.sxr + k0;
+            if (nlive == 4 && ((uintptr_t)xp & 15) == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(xp);
+                xv[0] = v.x + sh; xv[1] = v.y + sh; xv[2] = v.z + sh; xv[3] = v.w + sh;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nlive) xv[e] = xp[e] + sh;
+            }
+        }
+        float lx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            lx[e] = __log2f(xv[e]);                                          // -inf for 0, NaN for negatives
+            if (!(lx[e] == lx[e])) lx[e] = -__builtin_inff();                // x < 0: u clamps to 1e-15 / bin masked, like x = 0
+        }
+        const int64_t c0 = blockIdx.y;
+        const int64_t orow = a.c_inner ? (g * a.R + r) * a.C + c0 : (c0 * a.G + g) * a.R + r;
+        const int64_t ostep = (a.c_inner ? cstep : cstep * a.G * a.R) * a.Kp;   // elements between this thread's candidates
+        __hip_bfloat16* op = reinterpret_cast<__hip_bfloat16*>(a.out) + orow * a.Kp + k0;
+        for (int64_t c = c0; c < a.C; c += cstep, op += ostep) {
+            uint2 pk = make_uint2(0u, 0u);
+            if (live) {
+                const float4 pr = s_par[c];
+                const unsigned short* lut = s_lut + c * lw;
+                unsigned short hv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = __builtin_amdgcn_fmed3f(pr.y - lx[e] * pr.x, pr.z, pr.w);   // (log2 s - log2 x) * 37/q
+                    float kk = rintf(t);
+                    // within 1e-4 of a rounding tie the fast t (error ~1e-5 below 2L + 1) does not decide: exact path.
+                    // One lane taking it stalls the wave, so the zone is as narrow as the error bound allows.
+                    if (__builtin_expect(fabsf(t - kk) > 0.4999f, 0)) {
+                        const float s = a.scale[c * a.pc], qf = a.qv[c * a.pc];
+                        float ue = xv[e] / s;
+                        if (a.clamp_u) ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
+                        kk = adalog_k(ue, qf);
+                        kk = (kk == kk) ? fminf(fmaxf(kk, 0.0f), (float)(a.levels2 + 1)) : (float)(a.levels2 + 1);
+                    }
+                    hv[e] = lut[(int)kk];
+                }
+                if (ragged) {                                                // K % 4 != 0: the row's last quad is part padding
+#pragma unroll
+                    for (int e = 1; e < 4; ++e) if (e >= nlive) hv[e] = 0;
+                }
+                pk = make_uint2((unsigned)hv[0] | ((unsigned)hv[1] << 16), (unsigned)hv[2] | ((unsigned)hv[3] << 16));
+            }
+            *reinterpret_cast<uint2*>(op) = pk;
+        }
+    }
+}
+
 template <typename T, int KIND>
 int launch_pack(const PackArgs& a, hipStream_t st) {
     constexpr int EPT = Out<T>::EPT;
@@ -251,6 +348,13 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         // enough candidate groups to fill the chip when the source is small (weights), all candidates per thread otherwise
         int64_t gy = 1;
         while (gx * gy < 2048 && gy < a.C) gy *= 2;
+        if (KIND == KIND_ADALOG && a.pg == 0 && !getenv("ADALOG_PACK_GENERIC")) {
+            const size_t shm2 = (size_t)a.C * (sizeof(float4) + (size_t)(a.levels2 + 2) * sizeof(unsigned short));
+            if (shm2 <= 64 * 1024) {
+                hipLaunchKernelGGL(k_pack_adalog_fast, dim3((unsigned)gx, (unsigned)gy), dim3(256), shm2, st, a);
+                return 0;
+            }
+        }
         const size_t shm = (KIND == KIND_ADALOG) ? (size_t)a.C * (a.levels2 + 1) * sizeof(unsigned short) : 0;
         if (KIND != KIND_ADALOG || (a.pg == 0 && shm <= 64 * 1024)) {
             hipLaunchKernelGGL((k_pack_kfast<T, KIND>), dim3((unsigned)gx, (unsigned)gy), dim3(256), shm, st, a);

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void k_score_a_self(const float* __restrict__ 
                 const float v = xv[r];
                 const float t = v * inv_s;
                 float k = rintf(t);
-                if (__builtin_expect(fabsf(t - k) > 0.499f, 0)) k = rintf(v / s);
+                if (__builtin_expect(fabsf(t - k) > 0.4999f, 0)) k = rintf(v / s);
                 const float kq = zint ? __builtin_amdgcn_fmed3f(k, lo, hi) : fminf(fmaxf(k + z, 0.0f), qmax) - z;
                 const float e = v - kq * s;
                 acc += e * e;

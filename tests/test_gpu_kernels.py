@@ -168,6 +168,37 @@ def test_pack_adalog(ops, bits):
     torch.testing.assert_close(got, v_ref, rtol=1e-6, atol=0)
 
 
+def test_pack_adalog_fast_vs_generic(ops, monkeypatch):
+    """The LDS-parameter AdaLog packer (narrow tie zone, clamped LUT index) against the generic kernel on 1.3e8
+    element-candidates, and against the CPU specification on the no-clamp K % 4 == 0 form."""
+    gen = g(431)
+    bits, P = 4, 128
+    table = O.search_table(bits)
+    mant = torch.round(table[:37] * (4 * 2 ** (bits - 1) - 2)).to(DEV)
+    x3 = torch.nn.functional.gelu(2 * torch.randn(1, 2000, 512, generator=gen)).to(DEV)
+    x3[0, 0, :4] = torch.tensor([0.0, -0.1699, 1e-30, 5.0])
+    sc = (torch.rand(P, generator=gen) * 2 + 0.5).to(DEV)
+    qv = torch.randint(10, 138, (P,), generator=gen).float().to(DEV)
+    sh = torch.tensor([O.GELU_SHIFT]).to(DEV)
+    for clamp, shift in ((True, sh), (False, None)):
+        src = x3 if clamp else torch.softmax(x3 * 3, -1)
+        for c_inner in (True, False):
+            monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
+            fast = ops.pack_adalog(src, sc if clamp else torch.ones_like(sc), qv, P, 1, 1, 0, bits, mant, shift, clamp,
+                                   c_inner=c_inner)
+            monkeypatch.setenv("ADALOG_PACK_GENERIC", "1")
+            slow = ops.pack_adalog(src, sc if clamp else torch.ones_like(sc), qv, P, 1, 1, 0, bits, mant, shift, clamp,
+                                   c_inner=c_inner)
+            monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
+            assert torch.equal(fast.view(torch.int16), slow.view(torch.int16)), (clamp, c_inner)
+    A3 = torch.softmax(4 * torch.randn(6, 50, 52, generator=gen), -1)
+    A3[0, 0, :5] = torch.tensor([0.0, 1e-40, 1e-20, 1.0, 0.5])
+    q16 = torch.tensor([10., 11, 23, 36, 37, 38, 53, 64, 77, 90, 100, 111, 120, 130, 136, 137])
+    ref = CB.pack_adalog(A3, torch.ones(16), q16, 16, 1, 1, 0, bits, mant.cpu(), None, False)
+    out = ops.pack_adalog(A3.to(DEV), torch.ones(16).to(DEV), q16.to(DEV), 16, 1, 1, 0, bits, mant, None, False)
+    assert (out.cpu().float() != ref.float()).sum().item() == 0
+
+
 def test_pack_raw(ops):
     x3 = torch.randn(1, 77, 48 * 3, generator=g(5))
     assert torch.equal(ops.pack_raw(x3.to(DEV)).cpu(), CB.pack_raw(x3))
