@@ -337,6 +337,63 @@ __global__ __launch_bounds__(256) void k_pack_adalog_fast(PackArgs a) {
     }
 }
 
+// Uniform int8 packing with per-tensor candidates (pg == pr == 0: the activation searches, 0.3-1.2 GB per call): the
+// candidate's reciprocal scale and clamp bounds come from LDS; per element  mul, rndne, sub, cmp(tie zone), med3, add,
+// cvt_pk_u8;  the output pointer advances by a constant per candidate.
+__global__ __launch_bounds__(256) void k_pack_uniform_i8_fast(PackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float4* s_par = reinterpret_cast<float4*>(s_raw);                       // [C] {1/s, s, -z + 128, qmax - z + 128}
+    for (int c = threadIdx.x; c < (int)a.C; c += blockDim.x) {
+        const float s = a.scale[c * a.pc], z = rintf(a.zp[c * a.pc]);
+        s_par[c] = make_float4(__builtin_amdgcn_rcpf(s), s, 128.0f - z, 128.0f + (a.qmax - z));
+    }
+    __syncthreads();
+    const int64_t nq = a.Kp >> 2;
+    const int64_t total = a.G * a.R * nq;
+    const int64_t cstep = gridDim.y;
+    const bool ragged = (a.K & 3) != 0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t kq = idx % nq;
+        const int64_t t0 = idx / nq;
+        const int64_t r = t0 % a.R, g = t0 / a.R;
+        const int64_t k0 = kq << 2;
+        float xv[4] = {0.f, 0.f, 0.f, 0.f};
+        const int nlive = (int)min((int64_t)4, max((int64_t)0, a.K - k0));
+        const bool live = nlive > 0;
+        if (live) {
+            const float* xp = a.x + g * a.sxg + r * a.sxr + k0;
+            if (nlive == 4 && ((uintptr_t)xp & 15) == 0) {
+                const float4 v = *reinterpret_cast<const float4*>(xp);
+                xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (e < nlive) xv[e] = xp[e];
+            }
+        }
+        const int64_t c0 = blockIdx.y;
+        const int64_t orow = a.c_inner ? (g * a.R + r) * a.C + c0 : (c0 * a.G + g) * a.R + r;
+        const int64_t ostep = (a.c_inner ? cstep : cstep * a.G * a.R) * a.Kp;
+        int8_t* op = reinterpret_cast<int8_t*>(a.out) + orow * a.Kp + k0;
+        for (int64_t c = c0; c < a.C; c += cstep, op += ostep) {
+            unsigned pk = 0x80808080u;                                        // biased zeros
+            if (live) {
+                const float4 pr = s_par[c];
+                pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = xv[e] * pr.x;
+                    float k = rintf(t);
+                    if (__builtin_expect(fabsf(t - k) > 0.4999f, 0)) k = rintf(xv[e] / pr.y);   // see k_pack_kfast
+                    float vb = __builtin_amdgcn_fmed3f(k + 128.0f, pr.z, pr.w);                 // (q - z) + 128 in [1, 255]
+                    if (ragged && e >= nlive) vb = 128.0f;
+                    pk = __builtin_amdgcn_cvt_pk_u8_f32(vb, e, pk);
+                }
+            }
+            *reinterpret_cast<unsigned*>(op) = pk ^ 0x80808080u;              // un-bias: two's complement int8
+        }
+    }
+}
+
 template <typename T, int KIND>
 int launch_pack(const PackArgs& a, hipStream_t st) {
     constexpr int EPT = Out<T>::EPT;
@@ -348,6 +405,12 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         // enough candidate groups to fill the chip when the source is small (weights), all candidates per thread otherwise
         int64_t gy = 1;
         while (gx * gy < 2048 && gy < a.C) gy *= 2;
+        if (KIND == KIND_UNIFORM && sizeof(T) == 1 && a.pg == 0 && a.pr == 0 && !a.rowsum && a.C <= 2048 &&
+            !getenv("ADALOG_PACK_GENERIC")) {
+            hipLaunchKernelGGL(k_pack_uniform_i8_fast, dim3((unsigned)gx, (unsigned)gy), dim3(256),
+                               (size_t)a.C * sizeof(float4), st, a);
+            return 0;
+        }
         if (KIND == KIND_ADALOG && a.pg == 0 && !getenv("ADALOG_PACK_GENERIC")) {
             const size_t shm2 = (size_t)a.C * (sizeof(float4) + (size_t)(a.levels2 + 2) * sizeof(unsigned short));
             if (shm2 <= 64 * 1024) {

@@ -191,6 +191,16 @@ def test_pack_adalog_fast_vs_generic(ops, monkeypatch):
                                    c_inner=c_inner)
             monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
             assert torch.equal(fast.view(torch.int16), slow.view(torch.int16)), (clamp, c_inner)
+    # uniform int8, per-tensor candidates: LDS-parameter kernel vs the generic one (6.6e7 element-candidates, ragged K)
+    xa = torch.randn(2, 1000, 257, generator=gen).to(DEV) * 2
+    su = (torch.rand(P, 1, generator=gen) * 0.3 + 0.02).to(DEV)
+    zu = torch.randint(0, 16, (P, 1), generator=gen).float().to(DEV)
+    for c_inner in (True, False):
+        fast = ops.pack_uniform(xa, su, zu, P, 1, 1, 0, 0, 4, ops.I8, c_inner=c_inner)
+        monkeypatch.setenv("ADALOG_PACK_GENERIC", "1")
+        slow = ops.pack_uniform(xa, su, zu, P, 1, 1, 0, 0, 4, ops.I8, c_inner=c_inner)
+        monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
+        assert torch.equal(fast, slow), c_inner
     A3 = torch.softmax(4 * torch.randn(6, 50, 52, generator=gen), -1)
     A3[0, 0, :5] = torch.tensor([0.0, 1e-40, 1e-20, 1.0, 0.5])
     q16 = torch.tensor([10., 11, 23, 36, 37, 38, 53, 64, 77, 90, 100, 111, 120, 130, 136, 137])
