@@ -722,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_cand_glds(GemmArgs p) {
 //     are issued between the MFMAs of a step instead of in front of them;
 //   * epilogue on packed fp32 math: reference slice minus row/column bias, row scale and column factors are staged in
 //     LDS during the tile's first K-step; per pair of outputs 2 cvt + 2..4 v_pk_* instead of 12 scalar VALU.
-constexpr int BK3 = 64, NS3 = 3;
+constexpr int BK3 = 64;
 // tools/lab builds this file with GEMM_LAB_NO_DMA / GEMM_LAB_NO_MFMA to time the two halves of the main loop separately
 #if defined(GEMM_LAB_NO_DMA)
 #define STREAM_DMA(rsrc, dst, voff, soff) do { } while (0)
@@ -750,12 +750,26 @@ __device__ __forceinline__ uint4 lds_frag(const uint8_t* __restrict__ stage, int
     return *reinterpret_cast<const uint4*>(stage + off);
 }
 
-template <int DT, int TM>
-__global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
+// Two shapes of the same kernel:
+//   NW = 4 waves, tile (64*RI) x 256, RI <= 2, 3-stage ring, 79 KiB of LDS -> TWO workgroups per CU (small K: the other
+//          workgroup's main loop covers this one's epilogue);
+//   NW = 8 waves, tile (64*RI) x 256, RI = 3 or 4, 4-stage ring, <= 138 KiB -> one workgroup per CU (large K: the main
+//          loop is bound by the L2 -> LDS DMA path, measured ~30 B/clk/CU, and the 192/256-row tile moves 23/33 % fewer
+//          operand bytes per MAC; the epilogue is < 10 % of such a tile).
+// Waves form a 2 x (NW/2) grid; each owns RI x CJ MFMA tiles (CJ = 16/NW), 128 accumulator registers at most.
+template <int DT, int RI, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_gemm_stream(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist only in the device pass
-    constexpr int BM3 = 64 * TM;
+    constexpr int NT3 = 64 * NW;                     // threads
+    constexpr int CJ = 16 / NW;                      // column MFMA tiles per wave
+    constexpr int WCOLS = CJ * 32;                   // columns per wave
+    constexpr int BM3 = 64 * RI;
+    constexpr int NS = NW == 4 ? 3 : 4;              // ring stages
     constexpr int STAGE3 = (BM3 + BN2) * BK3;
-    extern __shared__ __attribute__((aligned(16))) uint8_t ring[];   // NS3 * STAGE3 bytes (dynamic: keeps the DMA untagged)
+    constexpr int AP = BM3 / 16;                     // 16-row DMA requests of the A tile per K-step; B has 16
+    constexpr int PT = AP + 16;
+    constexpr int MAXQ = (PT + NW - 1) / NW;         // requests per wave per K-step (the first PT % NW waves own MAXQ)
+    extern __shared__ __attribute__((aligned(16))) uint8_t ring[];   // NS * STAGE3 bytes (dynamic: keeps the DMA untagged)
     __shared__ __attribute__((aligned(16))) float s_ref[4 * BM3];     // [nref <= 4][BM3]: ref - row_bias (- column bias if shared)
     __shared__ __attribute__((aligned(16))) float s_rs[BM3];          // row scale, 0 past M
     __shared__ __attribute__((aligned(16))) float s_w[BM3];           // 1 for rows < M else 0
@@ -764,9 +778,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = w >> 1, wc = w & 1;
+    const int wr = w / (NW / 2), wc = w % (NW / 2);
     const int frow = lane & 31, fkg = lane >> 5;
-    const int arow = wr * (BM3 / 2) + frow, brow = wc * 128 + frow;
+    const int arow = wr * (BM3 / 2) + frow, brow = wc * WCOLS + frow;
 
     // ---- tile list of this workgroup: the XCD it runs on owns a contiguous range of tiles (neighbours share operand
     // tiles in that XCD's L2); its workgroups take them round-robin.
@@ -795,12 +809,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
     const int nk = (int)((p.Kvb + BK3 - 1) / BK3);          // whole 64-byte steps of zero padding are skipped
     const int Kb = (int)p.Kb;
 
-    // ---- issue cursor: runs two K-steps ahead of the compute cursor, across tile boundaries.  Per request the lane's
-    // source is  row * Kb + 16 * (logical slot);  LDS destinations are lane-linear, so the bank swizzle goes into the
-    // source slot: lane l of a 16-row request lands in (row l>>2, physical slot l&3) = logical slot (l&3) ^ ((l>>4)&3).
+    // ---- issue cursor: runs NS - 1 K-steps ahead of the compute cursor, across tile boundaries.  Request r of a step
+    // covers 16 rows x 64 bytes and lands at stage + r * 1024 (A rows first, then B rows); wave w owns r = w + q * NW.
+    // Per request the lane's source is  row * Kb + 16 * (logical slot);  LDS destinations are lane-linear, so the bank
+    // swizzle goes into the source slot: lane l lands in (row l>>2, physical slot l&3) = logical slot (l&3) ^ ((l>>4)&3).
     const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
     __amdgpu_buffer_rsrc_t ra, rb;
-    int va[TM], vb[4];
+    int vo[MAXQ];
     unsigned i_local = j0;
     int i_k = 0;
     auto issue_tile = [&](unsigned local) {
@@ -809,16 +824,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
         ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)t.g * p.sAg + (int64_t)m0 * Kb), 0, 0x7ffffffe, 0x00020000);
         rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)t.g * p.sBg + (int64_t)n0 * Kb), 0, 0x7ffffffe, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            int r = (w * TM + i) * 16 + lrow;
-            r = min(r, p.M - 1 - m0);                       // edge rows: re-read the last valid row (masked in the epilogue)
-            va[i] = r * Kb + lslot16;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int r = (w * 4 + i) * 16 + lrow;
-            r = min(r, p.N - 1 - n0);
-            vb[i] = r * Kb + lslot16;
+        for (int q = 0; q < MAXQ; ++q) {
+            const int r = w + q * NW;                       // wave-uniform
+            const bool isA = r < AP;
+            int row = (isA ? r : r - AP) * 16 + lrow;
+            row = min(row, isA ? p.M - 1 - m0 : p.N - 1 - n0);   // edge rows: re-read the last valid row (masked in the epilogue)
+            vo[q] = row * Kb + lslot16;
         }
     };
     auto issue_advance = [&]() {
@@ -827,18 +838,20 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
             if (i_local + nj < t_cnt) { i_local += nj; issue_tile(i_local); }   // past the last tile: harmless re-fetch
         }
     };
-    auto issue_all = [&](uint8_t* st) {                 // prologue only: the whole step at once
-        uint8_t* An = st + w * TM * 1024;
-        uint8_t* Bn = st + BM3 * BK3 + w * 4 * 1024;
-        const int ko = i_k * BK3;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (las_ptr)(An + i * 1024), 16, va[i], ko, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (las_ptr)(Bn + i * 1024), 16, vb[i], ko, 0, 0);
+    auto issue_slot = [&](int q, uint8_t* st, int ko) {
+        const int r = w + q * NW;
+        if (PT % NW == 0 || q + 1 < MAXQ || r < PT) {
+            if (r < AP) STREAM_DMA(ra, st + r * 1024, vo[q], ko);
+            else STREAM_DMA(rb, st + r * 1024, vo[q], ko);
+        }
     };
     issue_tile(i_local);
-    issue_all(ring); issue_advance();
-    issue_all(ring + STAGE3); issue_advance();
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0) {                   // prologue: the first NS - 1 steps
+#pragma unroll
+        for (int q = 0; q < MAXQ; ++q) issue_slot(q, ring + s0 * STAGE3, i_k * BK3);
+        issue_advance();
+    }
 
     const int rsh = __ffs(p.ref_div) - 1, rmask = p.ref_div - 1;   // ref_div is 64, 128 or 256 here
     const int nref = BN2 >> rsh;                            // reference columns per tile (<= 4)
@@ -847,92 +860,30 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
     const bool beta_cols = p.bias && p.bi_c != 0;
     const bool rows = p.row_scale != nullptr;
     int st = 0;                                             // ring slot of the current step
-    typename Acc<DT>::type acc[TM][4];
+    typename Acc<DT>::type acc[RI][CJ];
 
-    // One 64-byte K-step = 2 sub-steps of (TM + 4) fragment reads and TM x 4 MFMAs.  Both sub-steps' fragments are read
-    // up front; this wave's TM + 4 DMA requests for the step two ahead are issued between the MFMA groups.
-    auto step_first = [&](const uint8_t* cur, uint8_t* nxt, int ko) {
-        constexpr bool FIRST = true;
-        const uint8_t* Bs = cur + BM3 * BK3;
-        uint8_t* An = nxt + w * TM * 1024;
-        uint8_t* Bn = nxt + BM3 * BK3 + w * 4 * 1024;
-        uint4 a0[TM], b0[4], a1[TM], b1[4];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a0[i] = lds_frag(cur, swz3(arow + i * 32, fkg));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b0[j] = lds_frag(Bs, swz3(brow + j * 32, fkg));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a1[i] = lds_frag(cur, swz3(arow + i * 32, 2 + fkg));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = lds_frag(Bs, swz3(brow + j * 32, 2 + fkg));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#if defined(GEMM_LAB_NO_MFMA)
-                if (FIRST) { for (int r = 0; r < 16; ++r) acc[i][j][r] = 0; }
-                acc[i][j][0] += (int)(a0[i].x ^ b0[j].x);
-#else
-                if (FIRST) acc[i][j] = mma0<DT>(a0[i], b0[j]);
-                else mma<DT>(a0[i], b0[j], acc[i][j]);
-#endif
-            }
-            STREAM_DMA(rb, Bn + j * 1024, vb[j], ko);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#if defined(GEMM_LAB_NO_MFMA)
-                acc[i][j][1] += (int)(a1[i].x ^ b1[j].x);
-#else
-                mma<DT>(a1[i], b1[j], acc[i][j]);
-#endif
-            }
-            if (j < TM) STREAM_DMA(ra, An + j * 1024, va[j], ko);
-        }
-    };
-    auto step_next = [&](const uint8_t* cur, uint8_t* nxt, int ko) {
-        constexpr bool FIRST = false;
-        const uint8_t* Bs = cur + BM3 * BK3;
-        uint8_t* An = nxt + w * TM * 1024;
-        uint8_t* Bn = nxt + BM3 * BK3 + w * 4 * 1024;
-        uint4 a0[TM], b0[4], a1[TM], b1[4];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a0[i] = lds_frag(cur, swz3(arow + i * 32, fkg));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b0[j] = lds_frag(Bs, swz3(brow + j * 32, fkg));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a1[i] = lds_frag(cur, swz3(arow + i * 32, 2 + fkg));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = lds_frag(Bs, swz3(brow + j * 32, 2 + fkg));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#if defined(GEMM_LAB_NO_MFMA)
-                if (FIRST) { for (int r = 0; r < 16; ++r) acc[i][j][r] = 0; }
-                acc[i][j][0] += (int)(a0[i].x ^ b0[j].x);
-#else
-                if (FIRST) acc[i][j] = mma0<DT>(a0[i], b0[j]);
-                else mma<DT>(a0[i], b0[j], acc[i][j]);
-#endif
-            }
-            STREAM_DMA(rb, Bn + j * 1024, vb[j], ko);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-#if defined(GEMM_LAB_NO_MFMA)
-                acc[i][j][1] += (int)(a1[i].x ^ b1[j].x);
-#else
-                mma<DT>(a1[i], b1[j], acc[i][j]);
-#endif
-            }
-            if (j < TM) STREAM_DMA(ra, An + j * 1024, va[j], ko);
-        }
-    };
+    // One 64-byte K-step = 2 sub-steps of (RI + CJ) fragment reads and RI x CJ MFMAs.  Both sub-steps' fragments are read
+    // up front; this wave's DMA requests for the step NS - 1 ahead are issued between the MFMA groups.
+#define STREAM_STEP(FIRST, cur, nxt, ko)                                                                   \
+    do {                                                                                                   \
+        const uint8_t* Bs_ = (cur) + BM3 * BK3;                                                            \
+        uint4 a0[RI], b0[CJ], a1[RI], b1[CJ];                                                              \
+        _Pragma("unroll") for (int i = 0; i < RI; ++i) a0[i] = lds_frag((cur), swz3(arow + i * 32, fkg));  \
+        _Pragma("unroll") for (int j = 0; j < CJ; ++j) b0[j] = lds_frag(Bs_, swz3(brow + j * 32, fkg));    \
+        _Pragma("unroll") for (int i = 0; i < RI; ++i) a1[i] = lds_frag((cur), swz3(arow + i * 32, 2 + fkg)); \
+        _Pragma("unroll") for (int j = 0; j < CJ; ++j) b1[j] = lds_frag(Bs_, swz3(brow + j * 32, 2 + fkg)); \
+        _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < RI; ++i) {                                               \
+                if (FIRST) acc[i][j] = mma0<DT>(a0[i], b0[j]);                                             \
+                else mma<DT>(a0[i], b0[j], acc[i][j]);                                                     \
+            }                                                                                              \
+            _Pragma("unroll") for (int q = j; q < MAXQ; q += 2 * CJ) issue_slot(q, (nxt), (ko));           \
+        }                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                                   \
+            _Pragma("unroll") for (int i = 0; i < RI; ++i) mma<DT>(a1[i], b1[j], acc[i][j]);               \
+            _Pragma("unroll") for (int q = CJ + j; q < MAXQ; q += 2 * CJ) issue_slot(q, (nxt), (ko));      \
+        }                                                                                                  \
+    } while (0)
 
     for (unsigned local = j0; local < t_cnt; local += nj) {
         const StreamTile tl = decode(local);
@@ -942,12 +893,21 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
         const unsigned lid = t_lo + local;
         TL_STAMP(0);
         for (int kt = 0; kt < nk; ++kt) {
-            // stage `st` has landed once only the newest step's NP requests of this wave are still outstanding
-            if (TM == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            // stage `st` has landed once only the newest NS - 2 steps' requests of this wave are still outstanding
+            if (PT % NW != 0 && w >= PT % NW) {
+                if ((NS - 2) * (MAXQ - 1) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                else if ((NS - 2) * (MAXQ - 1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if ((NS - 2) * (MAXQ - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else {
+                if ((NS - 2) * MAXQ == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else if ((NS - 2) * MAXQ == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if ((NS - 2) * MAXQ == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const int st2 = st == 0 ? 2 : st - 1;           // (st + 2) % 3
+            const int stn = st == 0 ? NS - 1 : st - 1;       // (st + NS - 1) % NS: the slot read in the previous step
             const int ko = i_k * BK3;
             if (kt == 0) {
                 TL_STAMP(1);
@@ -955,11 +915,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
                 // nothing waits before the MFMAs), masks + arithmetic + LDS staging writes after the step
                 const float* refg = p.ref + (int64_t)g * p.sRg;
                 const int rcs = (int)p.ref_cs;
-                constexpr int EU = (4 * BM3) / 256;
+                constexpr int EU = (4 * BM3 + NT3 - 1) / NT3;
                 float e_ref[EU], e_rb[EU], e_cb[EU];
 #pragma unroll
                 for (int u = 0; u < EU; ++u) {
-                    const int e = tid + u * 256;
+                    const int e = min(tid + u * NT3, 4 * BM3 - 1);
                     const int nl = e / BM3, rl = e - nl * BM3;
                     const int rowc = min(m0 + rl, p.M - 1), nic = min(ni0 + nl, n_eff - 1);
                     e_ref[u] = refg[rowc + nic * rcs];
@@ -968,47 +928,47 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
                 }
                 const int rrow = min(m0 + min(tid, BM3 - 1), p.M - 1);
                 const float e_rs = rows ? p.row_scale[rrow] : 1.0f;
-                const int colc = min(n0 + tid, p.N - 1);
+                const int colc = min(n0 + min(tid, BN2 - 1), p.N - 1);
                 const int cci = colc & rmask, cni = colc >> rsh;
                 const float e_sa = p.sa[cci * p.sa_c + gh * p.sa_g];
                 const float e_sb = p.sb[cci * p.sb_c + gh * p.sb_g + cni * p.sb_n];
                 const float e_be = beta_cols ? p.bias[cci * p.bi_c + gh * p.bi_g + cni * p.bi_n] : 0.0f;
-                step_first(ring + st * STAGE3, ring + st2 * STAGE3, ko);
+                STREAM_STEP(true, ring + st * STAGE3, ring + stn * STAGE3, ko);
 #pragma unroll
                 for (int u = 0; u < EU; ++u) {
-                    const int e = tid + u * 256;
+                    const int e = tid + u * NT3;
                     const int nl = e / BM3, rl = e - nl * BM3;
                     const bool ok = (m0 + rl < p.M) && (ni0 + nl < n_eff);
-                    if (nl < nref) s_ref[e] = ok ? (e_ref[u] - e_rb[u]) - e_cb[u] : 0.0f;
+                    if (e < nref * BM3) s_ref[e] = ok ? (e_ref[u] - e_rb[u]) - e_cb[u] : 0.0f;
                 }
                 if (tid < BM3) {
                     const bool ok = m0 + tid < p.M;
                     s_rs[tid] = ok ? e_rs : 0.0f;
                     s_w[tid] = ok ? 1.0f : 0.0f;
                 }
-                {
+                if (tid < BN2) {
                     const bool ok = n0 + tid < p.N;
                     s_alpha[tid] = ok ? -(e_sa * p.sa_mul * e_sb) : 0.0f;
                     s_beta[tid] = ok ? e_be : 0.0f;
                 }
                 TL_STAMP(2);
             } else {
-                step_next(ring + st * STAGE3, ring + st2 * STAGE3, ko);
+                STREAM_STEP(false, ring + st * STAGE3, ring + stn * STAGE3, ko);
             }
             issue_advance();
-            st = st == 2 ? 0 : st + 1;
+            st = st == NS - 1 ? 0 : st + 1;
         }
         TL_STAMP(3);
 
         // ---- epilogue.  The staging written after the first step must be visible: with nk >= 2 a later step's barrier
         // already separates them.
         if (nk == 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        v2f cs2[4];
-        float nal[4], bet[4], cm[4];
-        const float* rj[4];
+        v2f cs2[CJ];
+        float nal[CJ], bet[CJ], cm[CJ];
+        const float* rj[CJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cl = wc * 128 + j * 32 + frow;
+        for (int j = 0; j < CJ; ++j) {
+            const int cl = wc * WCOLS + j * 32 + frow;
             nal[j] = s_alpha[cl]; bet[j] = s_beta[cl];
             cm[j] = (n0 + cl < p.N) ? 1.0f : 0.0f;
             rj[j] = s_ref + (cl >> rsh) * BM3;
@@ -1016,14 +976,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
         }
         const bool full = edge || beta_cols;                // generic body: row weights and column bias applied
 #define STREAM_EPILOGUE(ROWS_, FULL_)                                                                          \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                       \
+        _Pragma("unroll") for (int i = 0; i < RI; ++i) {                                                       \
             _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                 \
                 const int rl = wr * (BM3 / 2) + i * 32 + 4 * fkg + 8 * q4;                                     \
                 float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), w4 = s4;                                          \
                 if (ROWS_) s4 = *reinterpret_cast<const float4*>(s_rs + rl);                                   \
                 if (FULL_) w4 = *reinterpret_cast<const float4*>(s_w + rl);                                    \
                 const v2f sA = {s4.x, s4.y}, sB = {s4.z, s4.w}, wA = {w4.x, w4.y}, wB = {w4.z, w4.w};          \
-                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                \
+                _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                               \
                     const float4 r4 = *reinterpret_cast<const float4*>(rj[j] + rl);                            \
                     v2f rA = {r4.x, r4.y}, rB = {r4.z, r4.w};                                                  \
                     v2f tA = {(float)acc[i][j][q4 * 4 + 0], (float)acc[i][j][q4 * 4 + 1]};                     \
@@ -1042,15 +1002,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
         else { STREAM_EPILOGUE(false, false) }
 #undef STREAM_EPILOGUE
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CJ; ++j) {
             float cs = (cs2[j].x + cs2[j].y) * cm[j];
             cs += __shfl_xor(cs, 32);
-            if (fkg == 0) s_red[wr][wc * 128 + j * 32 + frow] = cs;
+            if (fkg == 0) s_red[wr][wc * WCOLS + j * 32 + frow] = cs;
         }
         TL_STAMP(4);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // not __syncthreads(): its fence would drain the DMA
         TL_STAMP(5);
-        {
+        if (tid < BN2) {
             const int col = n0 + tid;
             if (col < p.N)
                 p.partial[((((int64_t)g) * p.MT + tl.mt) * p.Npad + (col >> rsh)) * p.ref_div + (col & rmask)] =
@@ -1059,7 +1019,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_stream(GemmArgs p) {
         TL_STAMP(6);
         TL_STAMP(7);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the two run-ahead steps before the LDS is released
+#undef STREAM_STEP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead steps before the LDS is released
 #endif
 }
 
@@ -1209,12 +1170,28 @@ static int pick_tm(int M, bool scoring) {
     return 1;
 }
 
-struct Layout { int big, tm, MT, NT, Npad, c_eff, n_eff; int64_t elems; };
+struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff; int64_t elems; };
 
-static Layout layout_of(int M, int N, int C, int ref_div, int reduce_cols, bool scoring = true) {
+// Wide (one workgroup per CU, 192/256-row tile) form of the streaming kernel: long K only -- 16+ K-steps, where the
+// L2 -> LDS path bounds the main loop and the un-overlapped epilogue is < 10 % of a tile.
+static int pick_wide(int M, int64_t kvalid_bytes) {
+    static const int use_wide = getenv("ADALOG_GEMM_WIDE") ? atoi(getenv("ADALOG_GEMM_WIDE")) : 1;
+    if (!use_wide || kvalid_bytes < 1024 || M < 192) return 0;
+    const int64_t pad4 = (int64_t)cdiv(M, 256) * 256, pad3 = (int64_t)cdiv(M, 192) * 192, pad2 = (int64_t)cdiv(M, 128) * 128;
+    const int ri = pad4 <= pad3 + pad3 / 32 ? 4 : 3;                      // 256 rows unless 192 pads > 3 % less
+    const int64_t padw = ri == 4 ? pad4 : pad3;
+    return padw <= pad2 + pad2 / 8 ? ri : 0;                              // not if it pads > 12 % more than 128-row tiles
+}
+
+static Layout layout_of(int M, int N, int C, int ref_div, int reduce_cols, bool scoring = true, int64_t kvalid_bytes = 0,
+                        bool ref_transposed = false) {
     Layout L{};
     L.big = (C == 1);
     L.tm = L.big ? pick_tm(M, scoring) : 2;
+    if (L.big && scoring && ref_transposed && !reduce_cols && (ref_div == 64 || ref_div == 128 || ref_div == 256)) {
+        L.wide = pick_wide(M, kvalid_bytes);
+        if (L.wide) L.tm = L.wide;
+    }
     const int bm = L.big ? 64 * L.tm : BM, bn = L.big ? BN2 : BN;
     L.MT = cdiv(M, bm);
     L.NT = cdiv(N, bn);
@@ -1226,8 +1203,10 @@ static Layout layout_of(int M, int N, int C, int ref_div, int reduce_cols, bool 
 
 // M, N: GEMM rows / columns (N includes the candidate factor when ref_div > 1).  Outputs the partial-buffer layout
 // [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
-extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int* MT, int* Npad) {
-    const Layout L = layout_of(M, N, C, ref_div, reduce_cols);
+extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int dtype,
+                                            int64_t k_valid, int ref_transposed, int* MT, int* Npad) {
+    const int esz = dtype == 0 ? 1 : dtype == 1 ? 2 : 4;
+    const Layout L = layout_of(M, N, C, ref_div, reduce_cols, true, k_valid * esz, ref_transposed != 0);
     if (MT) *MT = L.MT;
     if (Npad) *Npad = L.Npad;
     return (int64_t)L.c_eff * G * L.MT * L.Npad;
@@ -1252,7 +1231,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(!(reduce_cols && ref_div > 1), "gemm_score: reduce_cols and ref_div > 1 are exclusive");
     ADALOG_ARG_CHECK(!row_scale || (C == 1 && row_bias), "gemm_score: per-row scale needs C == 1 and a row_bias vector");
     ADALOG_ARG_CHECK(!(partial && out), "gemm_score: either score against ref or store out, not both");
-    const Layout L = layout_of(M, N, C, ref_div, reduce_cols, out == nullptr);
+    const Layout L = layout_of(M, N, C, ref_div, reduce_cols, out == nullptr, (k_valid > 0 ? k_valid : Kp) * esz, ldr == 1 && ref != nullptr);
     GemmArgs p{};
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
     p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;
@@ -1275,7 +1254,8 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     dim3 grid((unsigned)nwg);
     static const int use_glds = getenv("ADALOG_GEMM_GLDS") ? atoi(getenv("ADALOG_GEMM_GLDS")) : 1;   // LDS-DMA pipeline (default on)
     static const int use_stream = getenv("ADALOG_GEMM_STREAM") ? atoi(getenv("ADALOG_GEMM_STREAM")) : 1;
-    if (L.big && use_stream && !out && L.tm <= 2 && ldr == 1 && (ref_div == 64 || ref_div == 128 || ref_div == 256) &&
+    ADALOG_ARG_CHECK(!L.wide || use_stream, "gemm_score: ADALOG_GEMM_STREAM=0 needs ADALOG_GEMM_WIDE=0");
+    if (L.big && use_stream && !out && (L.tm <= 2 || L.wide) && ldr == 1 && (ref_div == 64 || ref_div == 128 || ref_div == 256) &&
         (int64_t)(64 * L.tm + BN2) * p.Kb < ((int64_t)1 << 31)) {
         // persistent streaming kernel: two workgroups per CU walk the tile list
         static int n_cu = 0;
@@ -1284,7 +1264,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
             if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
             if (n_cu <= 0) n_cu = 256;
         }
-        const int64_t want = (int64_t)2 * n_cu;
+        const int64_t want = (int64_t)(L.wide ? 1 : 2) * n_cu;
         {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)
             const int64_t a_tile = (int64_t)64 * L.tm * p.Kb;
             int64_t gm = ((int64_t)2 << 20) / a_tile;
@@ -1292,20 +1272,24 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
             p.gm = (int)(gm < 1 ? 1 : gm > L.MT ? L.MT : gm);
         }
         dim3 pgrid((unsigned)(nwg < want ? nwg : want));
-        const size_t shm = (size_t)NS3 * (64 * L.tm + BN2) * BK3;
-#define LAUNCH_STREAM(DT, TMV)                                                                                    \
+        const size_t shm = (size_t)(L.wide ? 4 : 3) * (64 * L.tm + BN2) * BK3;
+#define LAUNCH_STREAM(DT, RIV, NWV)                                                                               \
         do {                                                                                                      \
             static bool attr_set = false;                                                                         \
             if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<DT, TMV>),                 \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<DT, RIV, NWV>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (NWV == 8 ? 128 : 80) * 1024); \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
-            hipLaunchKernelGGL((k_gemm_stream<DT, TMV>), pgrid, dim3(256), shm, st, p);                           \
+            hipLaunchKernelGGL((k_gemm_stream<DT, RIV, NWV>), pgrid, dim3(64 * NWV), shm, st, p);                 \
         } while (0)
-        if (dtype == 0) { if (L.tm == 2) LAUNCH_STREAM(0, 2); else LAUNCH_STREAM(0, 1); }
-        else if (dtype == 1) { if (L.tm == 2) LAUNCH_STREAM(1, 2); else LAUNCH_STREAM(1, 1); }
-        else { if (L.tm == 2) LAUNCH_STREAM(2, 2); else LAUNCH_STREAM(2, 1); }
+#define LAUNCH_STREAM_DT(DT)                                                                                      \
+        do {                                                                                                      \
+            if (L.wide == 4) LAUNCH_STREAM(DT, 4, 8); else if (L.wide == 3) LAUNCH_STREAM(DT, 3, 8);              \
+            else if (L.tm == 2) LAUNCH_STREAM(DT, 2, 4); else LAUNCH_STREAM(DT, 1, 4);                            \
+        } while (0)
+        if (dtype == 0) LAUNCH_STREAM_DT(0); else if (dtype == 1) LAUNCH_STREAM_DT(1); else LAUNCH_STREAM_DT(2);
+#undef LAUNCH_STREAM_DT
 #undef LAUNCH_STREAM
     } else if (L.big && use_glds && !out && L.tm <= 2) {
         const size_t shm = (size_t)3 * (64 * L.tm + BN2) * BK2 + (512 + 256) * sizeof(float);

@@ -156,10 +156,11 @@ class Strided:
         return self
 
 
-def _layout(M, n_cols, c_grid, G, ref_div, reduce_cols):
+def _layout(M, n_cols, c_grid, G, ref_div, reduce_cols, dtype, k_valid, ref_transposed):
     import ctypes
     mt, npad = ctypes.c_int(0), ctypes.c_int(0)
-    elems = _lib.load().adalog_gemm_score_layout(M, n_cols, c_grid, G, ref_div, reduce_cols, ctypes.byref(mt), ctypes.byref(npad))
+    elems = _lib.load().adalog_gemm_score_layout(M, n_cols, c_grid, G, ref_div, reduce_cols, dtype, k_valid,
+                                                 int(bool(ref_transposed)), ctypes.byref(mt), ctypes.byref(npad))
     return elems, mt.value, npad.value
 
 
@@ -193,12 +194,12 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
         ldr, ref_cs = ref.shape[-1], 1
     sRg = 0 if G == 1 else ref.shape[-1] * ref.shape[-2]
     reduce_cols = 0 if (keep_n or ref_div > 1) else 1
-    n_part, MT, Npad = _layout(M, n_cols, c_grid, G, ref_div, reduce_cols)
+    k_valid = min(getattr(A, "k_valid", Kp), getattr(B, "k_valid", Kp))
+    n_part, MT, Npad = _layout(M, n_cols, c_grid, G, ref_div, reduce_cols, dtype, k_valid, ref_transposed)
     partial = torch.empty(n_part, dtype=torch.float32, device=A.device)
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    k_valid = min(getattr(A, "k_valid", Kp), getattr(B, "k_valid", Kp))
     rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, M, n_cols, Kp, k_valid, c_grid, G, gmod,
                                ref.data_ptr(), ldr, sRg, ref_cs, ref_div, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul),
                                sb.t.data_ptr(), sb.c, sb.g, sb.n,

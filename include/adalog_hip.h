@@ -101,8 +101,10 @@ int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int6
  * the layer bias are per-ROW there.
  * Layout of `partial`: [C][G][MT][Npad] for C > 1 launches, [G][MT][Npad][ref_div] (candidate innermost: coalesced
  * stores) for ref_div > 1 launches -- pass cand_inner = 1 to adalog_finish_scores for the latter; adalog_gemm_score_layout returns its size and (MT, Npad) for the given
- * problem (two tilings exist: 128x128 for C > 1, (64..256)x256 with 128-byte K-steps when C = 1). */
-int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int* MT, int* Npad);
+ * problem (tilings: 128x128 for C > 1; (64..256)x256 when C = 1 -- the row count of a tile depends on M and, for the
+ * streaming kernel, on the dtype / k_valid / reference orientation of the launch, so pass the same values here). */
+int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int dtype, int64_t k_valid,
+                                 int ref_transposed, int* MT, int* Npad);
 
 /* scores[c][h?][n?] = -norm * sum_{image = g/gmod, (h), m_tile, (n < N)} partial[c][g][m_tile][n] (layout MT, Npad from
  * adalog_gemm_score_layout; C = c_eff), accumulated in fp64 in a

@@ -40,9 +40,9 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(sa, ones.data(), 4 * 128, hipMemcpyHostToDevice)); CK(hipMemcpy(sb, ones.data(), (size_t)cs.N * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(rs, ones.data(), cs.M * 4, hipMemcpyHostToDevice)); CK(hipMemset(rb, 0, cs.M * 4));
         int MT, Npad;
-        const int64_t pe = adalog_gemm_score_layout(cs.M, cs.N, 1, 1, cs.P, 0, &MT, &Npad);
+        const int64_t pe = adalog_gemm_score_layout(cs.M, cs.N, 1, 1, cs.P, 0, cs.dtype, cs.K, 1, &MT, &Npad);
         CK(hipMalloc(&partial, pe * 4));
-        const Layout L = layout_of(cs.M, cs.N, 1, cs.P, 0, true);
+        const Layout L = layout_of(cs.M, cs.N, 1, cs.P, 0, true, (int64_t)cs.K * esz, true);
         const size_t nwg = (size_t)L.MT * L.NT;
         CK(hipMalloc(&tl, nwg * 8 * sizeof(long long))); CK(hipMemset(tl, 0, nwg * 8 * sizeof(long long)));
         auto run = [&]() {
@@ -58,7 +58,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0)); for (int i = 0; i < 5; ++i) run(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
         const double flop = 2.0 * cs.M * (double)cs.N * cs.K;
-        printf("%-28s tiles %zu (MT %d NT %d tm %d)  %.3f ms  %.1f TFLOP/s\n", cs.name, nwg, L.MT, L.NT, L.tm, ms, flop / ms * 1e-9);
+        printf("%-28s tiles %zu (MT %d NT %d rows/64 %d)  %.3f ms  %.1f TFLOP/s\n", cs.name, nwg, L.MT, L.NT, L.tm, ms, flop / ms * 1e-9);
         g_timeline = tl;
         hipEvent_t e2, e3; CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
         CK(hipEventRecord(e2)); run(); CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3));
