@@ -32,38 +32,45 @@ __global__ __launch_bounds__(256) void k_topk(const float* __restrict__ scores, 
     if (rank < k) idx[(int64_t)rank * cols + col] = p;
 }
 
-// gather survivors, then either commit the winner (k == 1) or emit the next survivor-major grid
+// gather survivors, then either commit the winner (k == 1) or emit the next survivor-major grid.
+// A block is CL column lanes x OL output lanes (CL = min(64, cols rounded up to a power of two), CL * OL = 256): the
+// k * new_cnt grid points of a column are spread over the output lanes (a per-tensor search has ONE column: a thread
+// per column walked its 128 points alone for 14 us), and neighbouring threads write neighbouring columns.
 __global__ __launch_bounds__(256) void k_fpcs_next(const float* __restrict__ scale, const float* __restrict__ zp,
                                                    const float* __restrict__ third, int cols, const int* __restrict__ idx,
                                                    int k, int new_cnt, const float* __restrict__ lin,
                                                    float* __restrict__ delta, float clamp_min, int has_clamp,
                                                    float* __restrict__ o_scale, float* __restrict__ o_zp,
-                                                   float* __restrict__ o_third) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= cols) return;
+                                                   float* __restrict__ o_third, int CL) {
+    const int cl = threadIdx.x % CL, ol = threadIdx.x / CL, OL = 256 / CL;
+    const int col = blockIdx.x * CL + cl;
+    const bool live = col < cols;
     if (new_cnt == 0) {                                   // commit (topk == 1 branch, linear.py:387-391)
-        const int p = idx[col];
-        o_scale[col] = scale[(int64_t)p * cols + col];
-        if (zp) o_zp[col] = zp[(int64_t)p * cols + col];
-        if (third) o_third[col] = third[(int64_t)p * cols + col];
+        if (live && ol == 0) {
+            const int p = idx[col];
+            o_scale[col] = scale[(int64_t)p * cols + col];
+            if (zp) o_zp[col] = zp[(int64_t)p * cols + col];
+            if (third) o_third[col] = third[(int64_t)p * cols + col];
+        }
         return;
     }
-    const float d = delta[col];
-    for (int j = 0; j < k; ++j) {
-        const int p = idx[(int64_t)j * cols + col];
-        const float ts = scale[(int64_t)p * cols + col];
-        const float tz = zp ? zp[(int64_t)p * cols + col] : 0.0f;
-        const float tt = third ? third[(int64_t)p * cols + col] : 0.0f;
-        for (int i = 0; i < new_cnt; ++i) {
-            float v = ts + (lin[i] - 0.5f) * d;            // linear.py:492-495
-            if (has_clamp) v = fmaxf(v, clamp_min);        // linear.py:516
-            const int64_t o = (int64_t)(j * new_cnt + i) * cols + col;
-            o_scale[o] = v;
-            if (zp) o_zp[o] = tz;
-            if (third) o_third[o] = tt;
+    const float d = live ? delta[col] : 0.0f;
+    if (live) {
+        const int total = k * new_cnt;
+        for (int o = ol; o < total; o += OL) {
+            const int j = o / new_cnt, i = o - j * new_cnt;
+            const int p = idx[(int64_t)j * cols + col];
+            const float ts = scale[(int64_t)p * cols + col];
+            float v = ts + (lin[i] - 0.5f) * d;                // linear.py:492-495
+            if (has_clamp) v = fmaxf(v, clamp_min);            // linear.py:516
+            const int64_t oo = (int64_t)o * cols + col;
+            o_scale[oo] = v;
+            if (zp) o_zp[oo] = zp[(int64_t)p * cols + col];
+            if (third) o_third[oo] = third[(int64_t)p * cols + col];
         }
     }
-    delta[col] = d / ((float)new_cnt - 0.5f);              // linear.py:493
+    __syncthreads();                                          // every lane of this column has read delta
+    if (live && ol == 0) delta[col] = d / ((float)new_cnt - 0.5f);   // linear.py:493
 }
 
 // initial percentile grid: quant = [4][cols] = {Q_hi0, Q_hi1, Q_lo0, Q_lo1} (e.g. Q.9, Q1.0, Q.1, Q0)
@@ -209,8 +216,10 @@ extern "C" int adalog_fpcs_next(const float* scale, const float* zp, const float
     ADALOG_ARG_CHECK(new_cnt == 0 || (lin && delta), "fpcs_next: expansion needs lin and delta");
     ADALOG_ARG_CHECK((zp == nullptr) == (out_zp == nullptr) && (third == nullptr) == (out_third == nullptr),
                      "fpcs_next: in/out parameter planes must match");
-    hipLaunchKernelGGL(k_fpcs_next, dim3(cdiv(cols, 256)), dim3(256), 0, (hipStream_t)stream, scale, zp, third, cols, idx, k,
-                       new_cnt, lin, delta, clamp_min, has_clamp, out_scale, out_zp, out_third);
+    int CL = 1;
+    while (CL < 64 && CL < cols) CL <<= 1;
+    hipLaunchKernelGGL(k_fpcs_next, dim3(cdiv(cols, CL)), dim3(256), 0, (hipStream_t)stream, scale, zp, third, cols, idx, k,
+                       new_cnt, lin, delta, clamp_min, has_clamp, out_scale, out_zp, out_third, CL);
     ADALOG_LAUNCH_CHECK("adalog_fpcs_next");
     return 0;
 }

@@ -140,6 +140,7 @@ def pack_raw(x3):
     out = torch.empty((1, G, R, Kp), dtype=torch.float32, device=x3.device)
     rc = _lib.load().adalog_pack_raw_f32(x3.data_ptr(), G, R, K, sg, sr, sk, out.data_ptr(), Kp, _stream())
     _lib.check(rc, "adalog_pack_raw_f32")
+    out.k_valid = K
     return out
 
 
@@ -211,7 +212,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
                                partial.data_ptr(), n_part, None, 0, 0, 0, int(order), reduce_cols, _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
-        GEMM_EVENTS.append((dtype, M, N, Kp, C, G, A.data_ptr(), B.data_ptr(), ev0, ev1))
+        GEMM_EVENTS.append((dtype, M, N, k_valid, C, G, ev0, ev1))      # k_valid: the un-padded K of the packed operands
     _lib.check(rc, "adalog_gemm_score")
     cols = (gmod if keep_h else 1) * (N if keep_n else 1)
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)

@@ -40,24 +40,11 @@ def load_cfg(bits):
 
 
 class GemmProfiler:
-    """Collects the event pairs adalog_amd.ops records around every scoring-GEMM launch (on the launch stream) and the
-    true (un-padded) K of each packed operand, so that ALGORITHMIC flops = 2*M*N*K*C*G are divided by kernel time."""
+    """Collects the event pairs adalog_amd.ops records around every scoring-GEMM launch (on the launch stream) together
+    with the true (un-padded) K of the packed operands, so that ALGORITHMIC flops = 2*M*N*K*C*G are divided by kernel time."""
 
     def __init__(self, ops):
         self.ops = ops
-        self.true_k = {}
-
-    def install(self):
-        ops, prof = self.ops, self
-        orig_pu, orig_pa, orig_pr = ops.pack_uniform, ops.pack_adalog, ops.pack_raw
-
-        def note(out, x3):
-            t = out[0] if isinstance(out, tuple) else out
-            prof.true_k[t.data_ptr()] = x3.shape[-1]
-            return out
-        ops.pack_uniform = lambda x3, *a, **k: note(orig_pu(x3, *a, **k), x3)
-        ops.pack_adalog = lambda x3, *a, **k: note(orig_pa(x3, *a, **k), x3)
-        ops.pack_raw = lambda x3, *a, **k: note(orig_pr(x3, *a, **k), x3)
 
     def start(self):
         self.ops.GEMM_EVENTS = []
@@ -66,8 +53,7 @@ class GemmProfiler:
         ev, self.ops.GEMM_EVENTS = self.ops.GEMM_EVENTS, None
         torch.cuda.synchronize()
         by, shapes = {}, {}
-        for dt, M, N, Kp, C, G, pa, pb, s, e in ev:
-            K = min(self.true_k.get(pa, Kp), self.true_k.get(pb, Kp))
+        for dt, M, N, K, C, G, s, e in ev:
             ms = s.elapsed_time(e)
             for d, key in ((by, dt), (shapes, (dt, M, N, K, C, G))):
                 b = d.setdefault(key, [0.0, 0.0, 0])
@@ -83,6 +69,24 @@ class GemmProfiler:
         return [{"dtype": DT_NAME[k[0]], "M": k[1], "N": k[2], "K": k[3], "cands": k[4], "groups": k[5],
                  "launches_per_step": v[2] / steps, "ms_per_step": round(v[1] / steps, 2),
                  "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in rows]
+
+
+def pmc_traffic(dom):
+    """HBM bytes per launch of the dominant scoring-GEMM dtype, from the committed PMC passes over this same workload
+    (tools/pmc_bench.sh -> profiles/r01_pmc_bench_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
+    averaged over every dispatch of one calibration step).  None when the summary is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench_traffic.json")
+    try:
+        with open(path) as f:
+            rows = json.load(f)
+    except OSError:
+        return None
+    tot, n = 0.0, 0
+    for name, v in rows.items():
+        if name.startswith(f"k_gemm_stream<{dom},") and v.get("hbm_read_bytes_per_launch") is not None:
+            tot += (v["hbm_read_bytes_per_launch"] + (v.get("hbm_write_bytes_per_launch") or 0.0)) * v["launches"]
+            n += v["launches"]
+    return tot / n if n else None
 
 
 def cpu_baseline(threads):
@@ -157,7 +161,6 @@ def main():
     loader = [(local[i:i + cfg.calib_batch_size], None) for i in range(0, local.shape[0], cfg.calib_batch_size)]
 
     prof = GemmProfiler(ops)
-    prof.install()
 
     def one_step(model):
         QuantCalibrator(model, loader, capture="block").batching_quant_calib()
@@ -203,8 +206,9 @@ def main():
                                                               "tflops": v[0] / (v[1] * 1e-3) / 1e12} for d, v in by.items()},
                        "scoring_gemm_top_shapes": prof.top_shapes(args.steps),
                        "depth_override": args.depth},
-            "roofline": {"bound": "mfma", "kernel": f"k_gemm_score<{DT_NAME[dom]}>", "achieved": achieved,
-                         "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom], "traffic": None,
+            "roofline": {"bound": "mfma", "kernel": f"k_gemm_stream<{DT_NAME[dom]}>", "achieved": achieved,
+                         "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],
+                         "traffic": pmc_traffic(dom),
                          "launches": n, "avg_launch_ms": ms / max(n, 1)},
         }
         if not args.no_cpu_baseline and world == 1:
