@@ -23,7 +23,7 @@ SIGNATURES = {
     "adalog_pack_raw_f32": (i32, [p, i64, i64, i64, i64, i64, i64, p, i64, p]),
     "adalog_gemm_score": (i32, [i32, p, p, i64, i64, i64, i64, i32, i32, i64, i64, i32, i32, i32, p, i64, i64, i64, i32,
                                 p, i64, i64, f32, p, i64, i64, i64, p, i64, i64, i64, p, p, p, i64, p, i64, i64, i64, i32, i32, p]),
-    "adalog_gemm_score_layout": (i64, [i32, i32, i32, i32, i32, i32, i32, i64, i32, p, p]),
+    "adalog_gemm_score_layout": (i64, [i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, p, p, p]),
     "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p, i64, p]),
     "adalog_finish_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "adalog_topk": (i32, [p, i32, i32, i32, p, p]),

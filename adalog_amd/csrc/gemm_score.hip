@@ -47,6 +47,8 @@ struct GemmArgs {
     float sa_mul;                    // constant folded into sa (e.g. 1/(4L-2) for AdaLog numerators)
     int reduce_cols;                 // 1: one partial per tile (sum over its columns) instead of one per column
     int order;                       // tile order (fastest index first): 0 = nt,mt,g,c  1 = nt,c,mt,g  2 = mt,nt,c,g
+    double* wg_acc;                  // streaming kernel: per-workgroup fp64 column sums [workgroup][gmod][256] instead of
+                                     // per-tile partials (searches that do not keep the column axis)
     int gm;                          // streaming kernel, order 2: m-tiles per L2 group (rows of A kept hot while n advances)
     long long* timeline;             // profiling only (tools/gemm_lab.hip): 8 cycle stamps per workgroup, else nullptr
 };
@@ -861,6 +863,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_gemm_stream(GemmAr
     const bool rows = p.row_scale != nullptr;
     int st = 0;                                             // ring slot of the current step
     typename Acc<DT>::type acc[RI][CJ];
+    // per-workgroup accumulation (wg_acc): thread t < 256 owns tile column t; its running fp64 sum covers this workgroup's
+    // tiles of one head in their fixed order and is flushed into [workgroup][head][t] when the head changes
+    double run = 0.0;
+    int run_h = -1;
+    if (p.wg_acc && tid < BN2)
+        for (int h = 0; h < p.gmod; ++h) p.wg_acc[((int64_t)bid * p.gmod + h) * BN2 + tid] = 0.0;
 
     // One 64-byte K-step = 2 sub-steps of (RI + CJ) fragment reads and RI x CJ MFMAs.  Both sub-steps' fragments are read
     // up front; this wave's DMA requests for the step NS - 1 ahead are issued between the MFMA groups.
@@ -1012,13 +1020,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_gemm_stream(GemmAr
         TL_STAMP(5);
         if (tid < BN2) {
             const int col = n0 + tid;
-            if (col < p.N)
-                p.partial[((((int64_t)g) * p.MT + tl.mt) * p.Npad + (col >> rsh)) * p.ref_div + (col & rmask)] =
-                    s_red[0][tid] + s_red[1][tid];
+            const float v = s_red[0][tid] + s_red[1][tid];         // 0 for columns past N (masked above)
+            if (p.wg_acc) {
+                if (gh != run_h) {
+                    if (run_h >= 0) p.wg_acc[((int64_t)bid * p.gmod + run_h) * BN2 + tid] += run;
+                    run = 0.0; run_h = gh;
+                }
+                run += (double)v;
+            } else if (col < p.N) {
+                p.partial[((((int64_t)g) * p.MT + tl.mt) * p.Npad + (col >> rsh)) * p.ref_div + (col & rmask)] = v;
+            }
         }
         TL_STAMP(6);
         TL_STAMP(7);
     }
+    if (p.wg_acc && tid < BN2 && run_h >= 0) p.wg_acc[((int64_t)bid * p.gmod + run_h) * BN2 + tid] += run;
 #undef STREAM_STEP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead steps before the LDS is released
 #endif
@@ -1147,7 +1163,40 @@ __global__ __launch_bounds__(256) void k_finish_stage2(FinishArgs p, const doubl
     if (lane == 0) p.scores[(int64_t)c * nh + h] = (float)(-p.norm * acc);
 }
 
+// Finish for per-workgroup accumulators acc[wg][head][256] (fp64): one wavefront per output (candidate, head); terms =
+// (workgroup, [head], column replica with col % cin == candidate) in a fixed lane-strided order.
+__global__ __launch_bounds__(256) void k_finish_wgacc(FinishArgs p, const double* acc, int nwg) {
+    const int nh = p.keep_h ? p.gmod : 1;
+    const int lane = threadIdx.x & 63;
+    const int oid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (oid >= p.C * nh) return;
+    const int h = oid % nh, c = oid / nh;
+    const int reps = 256 / p.cin, h_lo = p.keep_h ? h : 0, h_cnt = p.keep_h ? 1 : p.gmod;
+    const int per_wg = h_cnt * reps;
+    const int64_t total = (int64_t)nwg * per_wg;
+    double sum = 0.0;
+    for (int64_t i = lane; i < total; i += 64) {
+        const int r = (int)(i % per_wg);
+        const int64_t wg = i / per_wg;
+        const int hh = h_lo + r / reps, rep = r % reps;
+        sum += acc[(wg * p.gmod + hh) * 256 + rep * p.cin + c];
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+    if (lane == 0) p.scores[(int64_t)c * nh + h] = (float)(-p.norm * sum);
+}
+
 }  // namespace
+
+static int device_cus() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
 
 // ---- tile selection shared by launch, layout query and finish
 static int pick_tm(int M, bool scoring) {
@@ -1170,7 +1219,7 @@ static int pick_tm(int M, bool scoring) {
     return 1;
 }
 
-struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff; int64_t elems; };
+struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff, stream, acc, wgs; int64_t elems; };
 
 // Wide (one workgroup per CU, 192/256-row tile) form of the streaming kernel: long K only -- 16+ K-steps, where the
 // L2 -> LDS path bounds the main loop and the un-overlapped epilogue is < 10 % of a tile.
@@ -1183,33 +1232,48 @@ static int pick_wide(int M, int64_t kvalid_bytes) {
     return padw <= pad2 + pad2 / 8 ? ri : 0;                              // not if it pads > 12 % more than 128-row tiles
 }
 
-static Layout layout_of(int M, int N, int C, int ref_div, int reduce_cols, bool scoring = true, int64_t kvalid_bytes = 0,
-                        bool ref_transposed = false) {
+// reduce_cols with ref_div > 1 asks for per-workgroup accumulation, which only the streaming kernel provides: when that
+// kernel is not eligible the launch falls back to per-tile partials (candidate innermost), and the layout says so.
+static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, bool scoring = true,
+                        int64_t kvalid_bytes = 0, int64_t kb = 0, bool ref_transposed = false) {
+    static const int use_stream = getenv("ADALOG_GEMM_STREAM") ? atoi(getenv("ADALOG_GEMM_STREAM")) : 1;
+    static const int use_wgacc = getenv("ADALOG_GEMM_WGACC") ? atoi(getenv("ADALOG_GEMM_WGACC")) : 1;
     Layout L{};
     L.big = (C == 1);
     L.tm = L.big ? pick_tm(M, scoring) : 2;
-    if (L.big && scoring && ref_transposed && !reduce_cols && (ref_div == 64 || ref_div == 128 || ref_div == 256)) {
+    const bool cand_cols = L.big && scoring && ref_transposed && (ref_div == 64 || ref_div == 128 || ref_div == 256);
+    if (cand_cols && use_stream) {
         L.wide = pick_wide(M, kvalid_bytes);
         if (L.wide) L.tm = L.wide;
     }
+    L.stream = cand_cols && use_stream && (L.tm <= 2 || L.wide) && (int64_t)(64 * L.tm + BN2) * kb < ((int64_t)1 << 31);
+    if (!L.stream && L.wide) { L.wide = 0; L.tm = pick_tm(M, scoring); }
     const int bm = L.big ? 64 * L.tm : BM, bn = L.big ? BN2 : BN;
     L.MT = cdiv(M, bm);
     L.NT = cdiv(N, bn);
     L.n_eff = ref_div > 1 ? N / ref_div : N;
     L.c_eff = ref_div > 1 ? ref_div : C;
-    L.Npad = reduce_cols ? L.NT : (ref_div > 1 ? cdiv(L.n_eff, 64) * 64 : L.NT * bn);
+    const int64_t tiles = (int64_t)L.MT * L.NT * G * C;
+    const int64_t want = (int64_t)(L.wide ? 1 : 2) * device_cus();
+    L.wgs = (int)(tiles < want ? tiles : want);
+    L.acc = L.stream && reduce_cols && ref_div > 1 && use_wgacc;
+    const int red = reduce_cols && ref_div == 1;
+    L.Npad = red ? L.NT : (ref_div > 1 ? cdiv(L.n_eff, 64) * 64 : L.NT * bn);
+    L.elems = L.acc ? (int64_t)2 * L.wgs * gmod * BN2 : (int64_t)L.c_eff * G * L.MT * L.Npad;
     return L;
 }
 
 // M, N: GEMM rows / columns (N includes the candidate factor when ref_div > 1).  Outputs the partial-buffer layout
 // [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
-extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int dtype,
-                                            int64_t k_valid, int ref_transposed, int* MT, int* Npad) {
+extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype,
+                                            int64_t Kp, int64_t k_valid, int ref_transposed, int* MT, int* Npad, int* mode) {
     const int esz = dtype == 0 ? 1 : dtype == 1 ? 2 : 4;
-    const Layout L = layout_of(M, N, C, ref_div, reduce_cols, true, k_valid * esz, ref_transposed != 0);
-    if (MT) *MT = L.MT;
-    if (Npad) *Npad = L.Npad;
-    return (int64_t)L.c_eff * G * L.MT * L.Npad;
+    const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, true, (k_valid > 0 ? k_valid : Kp) * esz, Kp * esz,
+                               ref_transposed != 0);
+    if (MT) *MT = L.acc ? L.wgs : L.MT;
+    if (Npad) *Npad = L.acc ? BN2 : L.Npad;
+    if (mode) *mode = L.acc ? 2 : (ref_div > 1 ? 1 : 0);
+    return L.elems;
 }
 
 extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
@@ -1228,10 +1292,10 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(partial || out, "gemm_score: nothing to produce");
     ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
     ADALOG_ARG_CHECK(ref_div == 1 || (C == 1 && N % ref_div == 0 && !out), "gemm_score: ref_div > 1 needs C == 1, N % ref_div == 0, no out");
-    ADALOG_ARG_CHECK(!(reduce_cols && ref_div > 1), "gemm_score: reduce_cols and ref_div > 1 are exclusive");
     ADALOG_ARG_CHECK(!row_scale || (C == 1 && row_bias), "gemm_score: per-row scale needs C == 1 and a row_bias vector");
     ADALOG_ARG_CHECK(!(partial && out), "gemm_score: either score against ref or store out, not both");
-    const Layout L = layout_of(M, N, C, ref_div, reduce_cols, out == nullptr, (k_valid > 0 ? k_valid : Kp) * esz, ldr == 1 && ref != nullptr);
+    const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, out == nullptr, (k_valid > 0 ? k_valid : Kp) * esz, Kp * esz,
+                               ldr == 1 && ref != nullptr);
     GemmArgs p{};
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
     p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;
@@ -1245,33 +1309,24 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;
     p.row_scale = row_scale; p.row_bias = row_bias;
     p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad;
-    p.order = order; p.reduce_cols = reduce_cols; p.timeline = g_timeline;
+    p.order = order; p.reduce_cols = reduce_cols && ref_div == 1; p.timeline = g_timeline;
     p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
-    if (partial) ADALOG_ARG_CHECK(partial_elems >= (int64_t)L.c_eff * G * L.MT * L.Npad, "gemm_score: partial buffer too small");
+    if (partial) ADALOG_ARG_CHECK(partial_elems >= L.elems, "gemm_score: partial buffer too small");
+    if (L.acc) { ADALOG_ARG_CHECK(((uintptr_t)partial & 7) == 0, "gemm_score: accumulator buffer must be 8-byte aligned"); p.wg_acc = (double*)partial; }
     const int64_t nwg = (int64_t)L.MT * L.NT * G * C;
     ADALOG_ARG_CHECK(nwg < (int64_t)1 << 31, "gemm_score: grid too large");
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nwg);
     static const int use_glds = getenv("ADALOG_GEMM_GLDS") ? atoi(getenv("ADALOG_GEMM_GLDS")) : 1;   // LDS-DMA pipeline (default on)
-    static const int use_stream = getenv("ADALOG_GEMM_STREAM") ? atoi(getenv("ADALOG_GEMM_STREAM")) : 1;
-    ADALOG_ARG_CHECK(!L.wide || use_stream, "gemm_score: ADALOG_GEMM_STREAM=0 needs ADALOG_GEMM_WIDE=0");
-    if (L.big && use_stream && !out && (L.tm <= 2 || L.wide) && ldr == 1 && (ref_div == 64 || ref_div == 128 || ref_div == 256) &&
-        (int64_t)(64 * L.tm + BN2) * p.Kb < ((int64_t)1 << 31)) {
-        // persistent streaming kernel: two workgroups per CU walk the tile list
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0; hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-            if (n_cu <= 0) n_cu = 256;
-        }
-        const int64_t want = (int64_t)(L.wide ? 1 : 2) * n_cu;
+    if (L.stream && !out) {
+        // persistent streaming kernel: two (wide form: one) workgroups per CU walk the tile list
         {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)
             const int64_t a_tile = (int64_t)64 * L.tm * p.Kb;
             int64_t gm = ((int64_t)2 << 20) / a_tile;
             if (const char* e = getenv("ADALOG_GEMM_GM")) gm = atoi(e);
             p.gm = (int)(gm < 1 ? 1 : gm > L.MT ? L.MT : gm);
         }
-        dim3 pgrid((unsigned)(nwg < want ? nwg : want));
+        dim3 pgrid((unsigned)L.wgs);
         const size_t shm = (size_t)(L.wide ? 4 : 3) * (64 * L.tm + BN2) * BK3;
 #define LAUNCH_STREAM(DT, RIV, NWV)                                                                               \
         do {                                                                                                      \
@@ -1349,7 +1404,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
 // scores[c][h?][n?] = -norm * sum over (image, [h], m_tile, [n]) of partial[c][g][m_tile][n] with the layout returned by
 // adalog_gemm_score_layout (MT, Npad); N = number of valid entries along the last axis (n_eff, or NT when reduced).
 extern "C" int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, int cand_inner) {
-    if (!cand_inner || keep_n || !(C == 64 || C == 128 || C == 256)) return 0;
+    if (cand_inner != 1 || keep_n || !(C == 64 || C == 128 || C == 256)) return 0;
     return (int64_t)G * MT * cdiv(N, FSEG) * C * (int64_t)sizeof(double);
 }
 
@@ -1361,6 +1416,14 @@ extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT,
     FinishArgs p{};
     p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = MT; p.N = N; p.Npad = Npad;
     p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm; p.cin = cand_inner ? C : 0;
+    if (cand_inner == 2) {                  // per-workgroup accumulators: partial = double [MT = workgroups][gmod][256]
+        ADALOG_ARG_CHECK(!keep_n && (C == 64 || C == 128 || C == 256) && Npad == 256, "finish_scores: bad accumulator layout");
+        const int64_t nout2 = (int64_t)C * (keep_h ? gmod : 1);
+        hipLaunchKernelGGL(k_finish_wgacc, dim3((unsigned)((nout2 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                           (const double*)partial, MT);
+        ADALOG_LAUNCH_CHECK("adalog_finish_scores");
+        return 0;
+    }
     const int64_t nout = (int64_t)C * (keep_h ? gmod : 1) * (keep_n ? N : 1);
     const int64_t per_out = (int64_t)(G / gmod) * (keep_h ? 1 : gmod) * MT * (keep_n ? 1 : N);
     const int64_t need = adalog_finish_workspace_bytes(MT, N, C, G, keep_n, cand_inner);

@@ -157,12 +157,15 @@ class Strided:
         return self
 
 
-def _layout(M, n_cols, c_grid, G, ref_div, reduce_cols, dtype, k_valid, ref_transposed):
+def _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid, ref_transposed):
+    """-> (floats to allocate, MT, Npad, mode) of the partial buffer adalog_gemm_score will write for this launch;
+    mode: 0 = [C][G][MT][Npad], 1 = candidate innermost, 2 = per-workgroup fp64 accumulators."""
     import ctypes
-    mt, npad = ctypes.c_int(0), ctypes.c_int(0)
-    elems = _lib.load().adalog_gemm_score_layout(M, n_cols, c_grid, G, ref_div, reduce_cols, dtype, k_valid,
-                                                 int(bool(ref_transposed)), ctypes.byref(mt), ctypes.byref(npad))
-    return elems, mt.value, npad.value
+    mt, npad, mode = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    elems = _lib.load().adalog_gemm_score_layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid,
+                                                 int(bool(ref_transposed)), ctypes.byref(mt), ctypes.byref(npad),
+                                                 ctypes.byref(mode))
+    return elems, mt.value, npad.value, mode.value
 
 
 def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
@@ -194,10 +197,10 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     else:
         ldr, ref_cs = ref.shape[-1], 1
     sRg = 0 if G == 1 else ref.shape[-1] * ref.shape[-2]
-    reduce_cols = 0 if (keep_n or ref_div > 1) else 1
+    reduce_cols = 0 if keep_n else 1                    # column axis not kept: the kernel may sum it (per tile / per workgroup)
     k_valid = min(getattr(A, "k_valid", Kp), getattr(B, "k_valid", Kp))
-    n_part, MT, Npad = _layout(M, n_cols, c_grid, G, ref_div, reduce_cols, dtype, k_valid, ref_transposed)
-    partial = torch.empty(n_part, dtype=torch.float32, device=A.device)
+    n_part, MT, Npad, mode = _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid, ref_transposed)
+    partial = torch.empty((n_part + 1) // 2, dtype=torch.float64, device=A.device).view(torch.float32)   # 8-byte aligned
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -216,11 +219,11 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     _lib.check(rc, "adalog_gemm_score")
     cols = (gmod if keep_h else 1) * (N if keep_n else 1)
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
-    n_last = Npad if reduce_cols else N                 # reduced: one partial per n-tile (Npad = NT)
-    ws_bytes = lib.adalog_finish_workspace_bytes(MT, n_last, C, G, int(keep_n), int(ref_div > 1))
+    n_last = Npad if (reduce_cols and mode != 1) else N   # reduced: one partial per n-tile (Npad = NT) / per workgroup
+    ws_bytes = lib.adalog_finish_workspace_bytes(MT, n_last, C, G, int(keep_n), mode)
     ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=A.device) if ws_bytes else None
     rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), MT, n_last, Npad, C, G, gmod, int(keep_h),
-                                  int(keep_n), int(ref_div > 1), float(norm), _ptr(ws), ws_bytes, _stream())
+                                  int(keep_n), mode, float(norm), _ptr(ws), ws_bytes, _stream())
     _lib.check(rc, "adalog_finish_scores")
     return scores
 

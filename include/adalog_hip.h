@@ -103,8 +103,12 @@ int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int6
  * stores) for ref_div > 1 launches -- pass cand_inner = 1 to adalog_finish_scores for the latter; adalog_gemm_score_layout returns its size and (MT, Npad) for the given
  * problem (tilings: 128x128 for C > 1; (64..256)x256 when C = 1 -- the row count of a tile depends on M and, for the
  * streaming kernel, on the dtype / k_valid / reference orientation of the launch, so pass the same values here). */
-int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int ref_div, int reduce_cols, int dtype, int64_t k_valid,
-                                 int ref_transposed, int* MT, int* Npad);
+int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype, int64_t Kp,
+                                 int64_t k_valid, int ref_transposed, int* MT, int* Npad, int* mode);
+/* -> number of floats `partial` must hold (8-byte aligned); *mode is what to pass as `cand_inner` to adalog_finish_scores:
+ *    0 = [C][G][MT][Npad]; 1 = [G][MT][Npad][ref_div] (candidate innermost); 2 = per-workgroup fp64 accumulators
+ *    [MT = workgroups][gmod][256] (reduce_cols = 1 with ref_div > 1 on the streaming kernel: the column axis is summed
+ *    inside the launch, in a fixed order, and no per-tile partial is written). */
 
 /* scores[c][h?][n?] = -norm * sum_{image = g/gmod, (h), m_tile, (n < N)} partial[c][g][m_tile][n] (layout MT, Npad from
  * adalog_gemm_score_layout; C = c_eff), accumulated in fp64 in a

@@ -40,9 +40,10 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(sa, ones.data(), 4 * 128, hipMemcpyHostToDevice)); CK(hipMemcpy(sb, ones.data(), (size_t)cs.N * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(rs, ones.data(), cs.M * 4, hipMemcpyHostToDevice)); CK(hipMemset(rb, 0, cs.M * 4));
         int MT, Npad;
-        const int64_t pe = adalog_gemm_score_layout(cs.M, cs.N, 1, 1, cs.P, 0, cs.dtype, cs.K, 1, &MT, &Npad);
+        int mode;
+        const int64_t pe = adalog_gemm_score_layout(cs.M, cs.N, 1, 1, 1, cs.P, 0, cs.dtype, cs.K, cs.K, 1, &MT, &Npad, &mode);
         CK(hipMalloc(&partial, pe * 4));
-        const Layout L = layout_of(cs.M, cs.N, 1, cs.P, 0, true, (int64_t)cs.K * esz, true);
+        const Layout L = layout_of(cs.M, cs.N, 1, 1, 1, cs.P, 0, true, (int64_t)cs.K * esz, (int64_t)cs.K * esz, true);
         const size_t nwg = (size_t)L.MT * L.NT;
         CK(hipMalloc(&tl, nwg * 8 * sizeof(long long))); CK(hipMemset(tl, 0, nwg * 8 * sizeof(long long)));
         auto run = [&]() {
