@@ -755,18 +755,18 @@ __device__ __forceinline__ uint4 lds_frag(const uint8_t* __restrict__ stage, int
 // Two shapes of the same kernel:
 //   NW = 4 waves, tile (64*RI) x 256, RI <= 2, 3-stage ring, 79 KiB of LDS -> TWO workgroups per CU (small K: the other
 //          workgroup's main loop covers this one's epilogue);
+//          (eight waves x 128 x 256 at two per CU -- four waves per SIMD, 128 VGPRs -- measured 8-12 % slower);
 //   NW = 8 waves, tile (64*RI) x 256, RI = 3 or 4, 4-stage ring, <= 138 KiB -> one workgroup per CU (large K: the main
 //          loop is bound by the L2 -> LDS DMA path, measured ~30 B/clk/CU, and the 192/256-row tile moves 23/33 % fewer
 //          operand bytes per MAC; the epilogue is < 10 % of such a tile).
 // Waves form a 2 x (NW/2) grid; each owns RI x CJ MFMA tiles (CJ = 16/NW), 128 accumulator registers at most.
-template <int DT, int RI, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void k_gemm_stream(GemmArgs p) {
+template <int DT, int RI, int NW, int NS = (NW == 4 ? 3 : 4)>
+__global__ __launch_bounds__(64 * NW, NS == 3 ? (NW == 8 ? 4 : 2) : 1) void k_gemm_stream(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type and builtins exist only in the device pass
     constexpr int NT3 = 64 * NW;                     // threads
     constexpr int CJ = 16 / NW;                      // column MFMA tiles per wave
     constexpr int WCOLS = CJ * 32;                   // columns per wave
     constexpr int BM3 = 64 * RI;
-    constexpr int NS = NW == 4 ? 3 : 4;              // ring stages
     constexpr int STAGE3 = (BM3 + BN2) * BK3;
     constexpr int AP = BM3 / 16;                     // 16-row DMA requests of the A tile per K-step; B has 16
     constexpr int PT = AP + 16;
@@ -1328,20 +1328,20 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         }
         dim3 pgrid((unsigned)L.wgs);
         const size_t shm = (size_t)(L.wide ? 4 : 3) * (64 * L.tm + BN2) * BK3;
-#define LAUNCH_STREAM(DT, RIV, NWV)                                                                               \
+#define LAUNCH_STREAM(DT, RIV, NWV, NSV)                                                                          \
         do {                                                                                                      \
             static bool attr_set = false;                                                                         \
             if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<DT, RIV, NWV>),            \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (NWV == 8 ? 128 : 80) * 1024); \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<DT, RIV, NWV, NSV>),       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (NSV == 4 ? 128 : 80) * 1024); \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
-            hipLaunchKernelGGL((k_gemm_stream<DT, RIV, NWV>), pgrid, dim3(64 * NWV), shm, st, p);                 \
+            hipLaunchKernelGGL((k_gemm_stream<DT, RIV, NWV, NSV>), pgrid, dim3(64 * NWV), shm, st, p);            \
         } while (0)
 #define LAUNCH_STREAM_DT(DT)                                                                                      \
         do {                                                                                                      \
-            if (L.wide == 4) LAUNCH_STREAM(DT, 4, 8); else if (L.wide == 3) LAUNCH_STREAM(DT, 3, 8);              \
-            else if (L.tm == 2) LAUNCH_STREAM(DT, 2, 4); else LAUNCH_STREAM(DT, 1, 4);                            \
+            if (L.wide == 4) LAUNCH_STREAM(DT, 4, 8, 4); else if (L.wide == 3) LAUNCH_STREAM(DT, 3, 8, 4);        \
+            else if (L.tm == 2) LAUNCH_STREAM(DT, 2, 4, 3); else LAUNCH_STREAM(DT, 1, 4, 3);                      \
         } while (0)
         if (dtype == 0) LAUNCH_STREAM_DT(0); else if (dtype == 1) LAUNCH_STREAM_DT(1); else LAUNCH_STREAM_DT(2);
 #undef LAUNCH_STREAM_DT
