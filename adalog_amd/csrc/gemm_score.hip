@@ -12,9 +12,14 @@
 // Data types:  0 = int8  (v_mfma_i32_32x32x32_i8,  exact integer dot products)
 //              1 = bf16  (v_mfma_f32_32x32x16_bf16, AdaLog operand m*2^-t and integer operand exact in bf16)
 //              2 = fp32  (v_mfma_f32_32x32x2_f32,   conv patch-embed with unquantised 8-bit input)
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 MFMA 32x32 tiles),
-// K-step 64 bytes, LDS double-buffered with a 16-byte-slot XOR swizzle (conflict-free ds_read_b128),
-// XCD-aware block order so the workgroups sharing an A tile sit on one XCD's L2.
+// Three kernels live here (DESIGN.md section 4 has the measurements that led from one to the next):
+//   k_gemm_stream  -- every search (candidates in the GEMM columns, reference rows contiguous): persistent workgroups,
+//                     LDS-DMA ring streaming across tiles, packed-fp32 epilogue, per-workgroup fp64 score accumulation;
+//   k_gemm_cand    -- quant_forward (stores the product) and the launches k_gemm_stream does not take
+//                     (k_gemm_cand_glds is its LDS-DMA variant): (64..256) x 256 tile, 128-byte K-steps;
+//   k_gemm_score   -- candidates in a grid dimension (C > 1): 128 x 128 tile, 64-byte K-steps.
+// All stage operands through LDS with a 16-byte-slot XOR swizzle (0 bank conflicts measured) and order workgroups so that
+// tiles sharing an operand run on one XCD (its L2).
 #include "common.h"
 #include <stdlib.h>
 
