@@ -10,6 +10,8 @@
 // A second tiny kernel adds the partials in fp64 in a fixed order (deterministic, SURVEY "hard parts").
 //
 // Data types:  0 = int8  (v_mfma_i32_32x32x32_i8,  exact integer dot products)
+//              3 = fp8   (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3: operands q - z in [-15, 15] of <= 4-bit layers are exact,
+//                         sums < 2^24 exact in the fp32 accumulator; same rate as int8, no cvt in the epilogue)
 //              1 = bf16  (v_mfma_f32_32x32x16_bf16, AdaLog operand m*2^-t and integer operand exact in bf16)
 //              2 = fp32  (v_mfma_f32_32x32x2_f32,   conv patch-embed with unquantised 8-bit input)
 // Three kernels live here (DESIGN.md section 4 has the measurements that led from one to the next):
@@ -57,7 +59,11 @@ struct GemmArgs {
     int gm;                          // streaming kernel, order 2: m-tiles per L2 group (rows of A kept hot while n advances)
     long long* timeline;             // profiling only (tools/gemm_lab.hip): 8 cycle stamps per workgroup, else nullptr
 };
+#if defined(GEMM_LAB_TIMELINE)   // tools/lab only: the stamp stores would otherwise cost waits in the production kernel
 #define TL_STAMP(i) do { if (p.timeline && threadIdx.x == 0) p.timeline[(size_t)lid * 8 + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define TL_STAMP(i) do { } while (0)
+#endif
 static long long* g_timeline = nullptr;   // set only by the lab harness, which includes this file
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * BKB + ((slot ^ ((row >> 2) & 3)) << 4); }
@@ -77,6 +83,15 @@ __device__ __forceinline__ void mma(const uint4& a, const uint4& b, typename Acc
 #pragma unroll
         for (int s = 0; s < 4; ++s) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s], bf[s], c, 0, 0, 0);
     }
+}
+
+// fp8 (e4m3) operands, 64 K-bytes per instruction: lane = (row, K half) holds 32 bytes.  Any fixed permutation of K is
+// fine as long as A and B share it, so the two 16-byte fragments a lane reads for the int8 path are simply concatenated.
+typedef int v8i __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v16f mma_fp8x64(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1, v16f c) {
+    const v8i a = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+    const v8i b = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);   // scales 2^0
 }
 
 template <int DT, bool STORE>
@@ -885,16 +900,27 @@ __global__ __launch_bounds__(64 * NW, NS == 3 ? (NW == 8 ? 4 : 2) : 1) void k_ge
         _Pragma("unroll") for (int j = 0; j < CJ; ++j) b0[j] = lds_frag(Bs_, swz3(brow + j * 32, fkg));    \
         _Pragma("unroll") for (int i = 0; i < RI; ++i) a1[i] = lds_frag((cur), swz3(arow + i * 32, 2 + fkg)); \
         _Pragma("unroll") for (int j = 0; j < CJ; ++j) b1[j] = lds_frag(Bs_, swz3(brow + j * 32, 2 + fkg)); \
-        _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                                   \
-            _Pragma("unroll") for (int i = 0; i < RI; ++i) {                                               \
-                if (FIRST) acc[i][j] = mma0<DT>(a0[i], b0[j]);                                             \
-                else mma<DT>(a0[i], b0[j], acc[i][j]);                                                     \
+        if constexpr (DT == 3) {                                                                           \
+            _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                               \
+                _Pragma("unroll") for (int i = 0; i < RI; ++i) {                                           \
+                    v16f z_;                                                                               \
+                    _Pragma("unroll") for (int r = 0; r < 16; ++r) z_[r] = 0.0f;                           \
+                    acc[i][j] = mma_fp8x64(a0[i], a1[i], b0[j], b1[j], FIRST ? z_ : acc[i][j]);            \
+                }                                                                                          \
+                _Pragma("unroll") for (int q = j; q < MAXQ; q += CJ) issue_slot(q, (nxt), (ko));           \
             }                                                                                              \
-            _Pragma("unroll") for (int q = j; q < MAXQ; q += 2 * CJ) issue_slot(q, (nxt), (ko));           \
-        }                                                                                                  \
-        _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                                   \
-            _Pragma("unroll") for (int i = 0; i < RI; ++i) mma<DT>(a1[i], b1[j], acc[i][j]);               \
-            _Pragma("unroll") for (int q = CJ + j; q < MAXQ; q += 2 * CJ) issue_slot(q, (nxt), (ko));      \
+        } else {                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                               \
+                _Pragma("unroll") for (int i = 0; i < RI; ++i) {                                           \
+                    if (FIRST) acc[i][j] = mma0<DT == 3 ? 1 : DT>(a0[i], b0[j]);                           \
+                    else mma<DT == 3 ? 1 : DT>(a0[i], b0[j], acc[i][j]);                                   \
+                }                                                                                          \
+                _Pragma("unroll") for (int q = j; q < MAXQ; q += 2 * CJ) issue_slot(q, (nxt), (ko));       \
+            }                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                               \
+                _Pragma("unroll") for (int i = 0; i < RI; ++i) mma<DT == 3 ? 1 : DT>(a1[i], b1[j], acc[i][j]); \
+                _Pragma("unroll") for (int q = CJ + j; q < MAXQ; q += 2 * CJ) issue_slot(q, (nxt), (ko));  \
+            }                                                                                              \
         }                                                                                                  \
     } while (0)
 
@@ -1010,9 +1036,51 @@ __global__ __launch_bounds__(64 * NW, NS == 3 ? (NW == 8 ? 4 : 2) : 1) void k_ge
                 }                                                                                              \
             }                                                                                                  \
         }
-        if (full) { STREAM_EPILOGUE(true, true) }
-        else if (rows) { STREAM_EPILOGUE(true, false) }
-        else { STREAM_EPILOGUE(false, false) }
+        // ref_div >= 128: the wave's CJ * 32 columns share ONE reference column, so a row group needs one float4 of the
+        // staged reference (not CJ); the next group's LDS values are fetched before the current group's arithmetic (the
+        // epilogue was LDS-latency-bound: ~4.2 k cycles for ~300 VALU, with or without the int->float conversions).
+#define STREAM_EPILOGUE_SAME(ROWS_, FULL_)                                                                     \
+        {                                                                                                      \
+            constexpr int NG_ = RI * 4;                                                                        \
+            const float* rbase_ = rj[0] + wr * (BM3 / 2) + 4 * fkg;                                            \
+            const float* sbase_ = s_rs + wr * (BM3 / 2) + 4 * fkg;                                             \
+            const float* wbase_ = s_w + wr * (BM3 / 2) + 4 * fkg;                                              \
+            float4 r_n = *reinterpret_cast<const float4*>(rbase_), s_n = make_float4(1.f, 1.f, 1.f, 1.f), w_n = s_n; \
+            if (ROWS_) s_n = *reinterpret_cast<const float4*>(sbase_);                                         \
+            if (FULL_) w_n = *reinterpret_cast<const float4*>(wbase_);                                         \
+            _Pragma("unroll") for (int gi = 0; gi < NG_; ++gi) {                                               \
+                const int i = gi >> 2, q4 = gi & 3;                                                            \
+                const float4 r4 = r_n, s4 = s_n, w4 = w_n;                                                     \
+                if (gi + 1 < NG_) {                                                                            \
+                    const int o_ = ((gi + 1) >> 2) * 32 + 8 * ((gi + 1) & 3);                                  \
+                    r_n = *reinterpret_cast<const float4*>(rbase_ + o_);                                       \
+                    if (ROWS_) s_n = *reinterpret_cast<const float4*>(sbase_ + o_);                            \
+                    if (FULL_) w_n = *reinterpret_cast<const float4*>(wbase_ + o_);                            \
+                }                                                                                              \
+                const v2f sA = {s4.x, s4.y}, sB = {s4.z, s4.w}, wA = {w4.x, w4.y}, wB = {w4.z, w4.w};          \
+                _Pragma("unroll") for (int j = 0; j < CJ; ++j) {                                               \
+                    v2f rA = {r4.x, r4.y}, rB = {r4.z, r4.w};                                                  \
+                    v2f tA = {(float)acc[i][j][q4 * 4 + 0], (float)acc[i][j][q4 * 4 + 1]};                     \
+                    v2f tB = {(float)acc[i][j][q4 * 4 + 2], (float)acc[i][j][q4 * 4 + 3]};                     \
+                    const v2f na = {nal[j], nal[j]};                                                           \
+                    if (ROWS_) { tA *= sA; tB *= sB; }                                                         \
+                    if (FULL_) { const v2f b2 = {bet[j], bet[j]}; rA -= b2; rB -= b2; }                        \
+                    v2f dA = tA * na + rA, dB = tB * na + rB;                                                  \
+                    if (FULL_) { dA *= wA; dB *= wB; }                                                         \
+                    cs2[j] += dA * dA; cs2[j] += dB * dB;                                                      \
+                }                                                                                              \
+            }                                                                                                  \
+        }
+        if (p.ref_div >= WCOLS) {
+            if (full) STREAM_EPILOGUE_SAME(true, true)
+            else if (rows) STREAM_EPILOGUE_SAME(true, false)
+            else STREAM_EPILOGUE_SAME(false, false)
+        } else {
+            if (full) { STREAM_EPILOGUE(true, true) }
+            else if (rows) { STREAM_EPILOGUE(true, false) }
+            else { STREAM_EPILOGUE(false, false) }
+        }
+#undef STREAM_EPILOGUE_SAME
 #undef STREAM_EPILOGUE
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
@@ -1272,7 +1340,7 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
 // [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
 extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype,
                                             int64_t Kp, int64_t k_valid, int ref_transposed, int* MT, int* Npad, int* mode) {
-    const int esz = dtype == 0 ? 1 : dtype == 1 ? 2 : 4;
+    const int esz = (dtype == 0 || dtype == 3) ? 1 : dtype == 1 ? 2 : 4;
     const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, true, (k_valid > 0 ? k_valid : Kp) * esz, Kp * esz,
                                ref_transposed != 0);
     if (MT) *MT = L.acc ? L.wgs : L.MT;
@@ -1289,9 +1357,9 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                  const float* row_bias, float* partial, int64_t partial_elems, float* out, int64_t ldo,
                                  int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream) {
     ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
-    ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 2, "gemm_score: dtype must be 0 (i8), 1 (bf16) or 2 (f32)");
+    ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 3, "gemm_score: dtype must be 0 (i8), 1 (bf16), 2 (f32) or 3 (fp8 e4m3)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
-    const int esz = dtype == 0 ? 1 : dtype == 1 ? 2 : 4;
+    const int esz = (dtype == 0 || dtype == 3) ? 1 : dtype == 1 ? 2 : 4;
     ADALOG_ARG_CHECK((Kp * esz) % BK2 == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 128 bytes");
     ADALOG_ARG_CHECK((partial != nullptr) == (ref != nullptr), "gemm_score: partial and ref go together");
     ADALOG_ARG_CHECK(partial || out, "gemm_score: nothing to produce");
@@ -1323,6 +1391,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nwg);
     static const int use_glds = getenv("ADALOG_GEMM_GLDS") ? atoi(getenv("ADALOG_GEMM_GLDS")) : 1;   // LDS-DMA pipeline (default on)
+    ADALOG_ARG_CHECK(dtype != 3 || (L.stream && !out), "gemm_score: fp8 operands are taken by the streaming search kernel only (ref_div 64/128/256, transposed reference)");
     if (L.stream && !out) {
         // persistent streaming kernel: two (wide form: one) workgroups per CU walk the tile list
         {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)
@@ -1348,7 +1417,8 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
             if (L.wide == 4) LAUNCH_STREAM(DT, 4, 8, 4); else if (L.wide == 3) LAUNCH_STREAM(DT, 3, 8, 4);        \
             else if (L.tm == 2) LAUNCH_STREAM(DT, 2, 4, 3); else LAUNCH_STREAM(DT, 1, 4, 3);                      \
         } while (0)
-        if (dtype == 0) LAUNCH_STREAM_DT(0); else if (dtype == 1) LAUNCH_STREAM_DT(1); else LAUNCH_STREAM_DT(2);
+        if (dtype == 0) LAUNCH_STREAM_DT(0); else if (dtype == 1) LAUNCH_STREAM_DT(1); else if (dtype == 2) LAUNCH_STREAM_DT(2);
+        else LAUNCH_STREAM_DT(3);
 #undef LAUNCH_STREAM_DT
 #undef LAUNCH_STREAM
     } else if (L.big && use_glds && !out && L.tm <= 2) {

@@ -11,6 +11,7 @@
 // zero padded (zeros contribute nothing to the integer dot product).
 #include "common.h"
 #include <hip/hip_bf16.h>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -36,13 +37,19 @@ struct PackArgs {
     int c_inner;          // 0: out[c][g][r][Kp]   1: out[g][r][c][Kp] (candidates innermost: GEMM columns = (row, candidate))
 };
 
+struct fp8_t { uint8_t b; };   // e4m3 byte as the hardware converts it (v_cvt_pk_fp8_f32); integers up to 16 are exact
+
 template <typename T> struct Out;
 template <> struct Out<int8_t> { static constexpr int EPT = 16; };
+template <> struct Out<fp8_t> { static constexpr int EPT = 16; };
 template <> struct Out<__hip_bfloat16> { static constexpr int EPT = 8; };
 template <> struct Out<float> { static constexpr int EPT = 4; };
 
 template <typename T> __device__ __forceinline__ T cvt(float v);
 template <> __device__ __forceinline__ int8_t cvt<int8_t>(float v) { return (int8_t)(int)v; }
+template <> __device__ __forceinline__ fp8_t cvt<fp8_t>(float v) {
+    fp8_t r; r.b = (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(v, 0.0f, 0, false) & 0xff); return r;
+}
 template <> __device__ __forceinline__ __hip_bfloat16 cvt<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 template <> __device__ __forceinline__ float cvt<float>(float v) { return v; }
 
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(256) void k_pack(PackArgs a) {
 // instruction of a wave writes one contiguous 256 B / 512 B / 1 KiB run.
 template <typename T, int KIND>
 __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
+    constexpr bool FP8OUT = sizeof(T) == 1 && !std::is_same<T, int8_t>::value;
     const int64_t nq = a.Kp >> 2;
     const int64_t total = a.G * a.R * nq;
     // AdaLog: per-candidate value LUT  lut[c][k] = m[(k q_c) mod 37] * 2^-floor(k q_c / 37)  (bf16-exact), built once per
@@ -183,7 +191,11 @@ __global__ __launch_bounds__(256) void k_pack_kfast(PackArgs a) {
                     if (!full && !(k0 + e < a.K)) v[e] = 0.0f;
                 }
                 if (a.rowsum) isum = (int)((v[0] + v[1]) + (v[2] + v[3]));    // small integers: exact in fp32
-                if (sizeof(T) == 1) {
+                if (FP8OUT) {
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+                    *reinterpret_cast<int*>(vals) = pk;
+                } else if (sizeof(T) == 1) {
                     // (v + 128) saturates into a byte lane per instruction; xor 0x80 turns it into two's complement
                     unsigned pk = 0;
 #pragma unroll
@@ -340,12 +352,14 @@ __global__ __launch_bounds__(256) void k_pack_adalog_fast(PackArgs a) {
 // Uniform int8 packing with per-tensor candidates (pg == pr == 0: the activation searches, 0.3-1.2 GB per call): the
 // candidate's reciprocal scale and clamp bounds come from LDS; per element  mul, rndne, sub, cmp(tie zone), med3, add,
 // cvt_pk_u8;  the output pointer advances by a constant per candidate.
+template <bool FP8>
 __global__ __launch_bounds__(256) void k_pack_uniform_i8_fast(PackArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    float4* s_par = reinterpret_cast<float4*>(s_raw);                       // [C] {1/s, s, -z + 128, qmax - z + 128}
+    float4* s_par = reinterpret_cast<float4*>(s_raw);                       // [C] {1/s, s, -z + bias, qmax - z + bias}
+    const float vbias = FP8 ? 0.0f : 128.0f;                                 // int8 goes through a biased u8 conversion
     for (int c = threadIdx.x; c < (int)a.C; c += blockDim.x) {
         const float s = a.scale[c * a.pc], z = rintf(a.zp[c * a.pc]);
-        s_par[c] = make_float4(__builtin_amdgcn_rcpf(s), s, 128.0f - z, 128.0f + (a.qmax - z));
+        s_par[c] = make_float4(__builtin_amdgcn_rcpf(s), s, vbias - z, vbias + (a.qmax - z));
     }
     __syncthreads();
     const int64_t nq = a.Kp >> 2;
@@ -375,21 +389,28 @@ __global__ __launch_bounds__(256) void k_pack_uniform_i8_fast(PackArgs a) {
         const int64_t ostep = (a.c_inner ? cstep : cstep * a.G * a.R) * a.Kp;
         int8_t* op = reinterpret_cast<int8_t*>(a.out) + orow * a.Kp + k0;
         for (int64_t c = c0; c < a.C; c += cstep, op += ostep) {
-            unsigned pk = 0x80808080u;                                        // biased zeros
+            unsigned pk = FP8 ? 0u : 0x80808080u;                             // (biased) zeros
             if (live) {
                 const float4 pr = s_par[c];
-                pk = 0;
+                float vb[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = xv[e] * pr.x;
                     float k = rintf(t);
                     if (__builtin_expect(fabsf(t - k) > 0.4999f, 0)) k = rintf(xv[e] / pr.y);   // see k_pack_kfast
-                    float vb = __builtin_amdgcn_fmed3f(k + 128.0f, pr.z, pr.w);                 // (q - z) + 128 in [1, 255]
-                    if (ragged && e >= nlive) vb = 128.0f;
-                    pk = __builtin_amdgcn_cvt_pk_u8_f32(vb, e, pk);
+                    vb[e] = __builtin_amdgcn_fmed3f(k + vbias, pr.z, pr.w);                     // int8: (q - z) + 128 in [1, 255]
+                    if (ragged && e >= nlive) vb[e] = vbias;
+                }
+                if (FP8) {
+                    int q = __builtin_amdgcn_cvt_pk_fp8_f32(vb[0], vb[1], 0, false);
+                    pk = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(vb[2], vb[3], q, true);
+                } else {
+                    pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(vb[e], e, pk);
                 }
             }
-            *reinterpret_cast<unsigned*>(op) = pk ^ 0x80808080u;              // un-bias: two's complement int8
+            *reinterpret_cast<unsigned*>(op) = FP8 ? pk : pk ^ 0x80808080u;   // int8: un-bias to two's complement
         }
     }
 }
@@ -407,8 +428,12 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         while (gx * gy < 2048 && gy < a.C) gy *= 2;
         if (KIND == KIND_UNIFORM && sizeof(T) == 1 && a.pg == 0 && a.pr == 0 && !a.rowsum && a.C <= 2048 &&
             !getenv("ADALOG_PACK_GENERIC")) {
-            hipLaunchKernelGGL(k_pack_uniform_i8_fast, dim3((unsigned)gx, (unsigned)gy), dim3(256),
-                               (size_t)a.C * sizeof(float4), st, a);
+            if (std::is_same<T, int8_t>::value)
+                hipLaunchKernelGGL(k_pack_uniform_i8_fast<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256),
+                                   (size_t)a.C * sizeof(float4), st, a);
+            else
+                hipLaunchKernelGGL(k_pack_uniform_i8_fast<true>, dim3((unsigned)gx, (unsigned)gy), dim3(256),
+                                   (size_t)a.C * sizeof(float4), st, a);
             return 0;
         }
         if (KIND == KIND_ADALOG && a.pg == 0 && !getenv("ADALOG_PACK_GENERIC")) {
@@ -448,7 +473,8 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
                                    int32_t* rowsum, int c_inner, void* stream) {
     ADALOG_ARG_CHECK(x && scale && zero_point && out, "pack_uniform: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_uniform: bad sizes");
-    ADALOG_ARG_CHECK(Kp >= K && (Kp * (out_dtype == 0 ? 1 : out_dtype == 1 ? 2 : 4)) % 128 == 0,
+    ADALOG_ARG_CHECK(out_dtype != 3 || n_bits <= 4, "pack_uniform: fp8 output holds q - z exactly only for n_bits <= 4");
+    ADALOG_ARG_CHECK(Kp >= K && (Kp * ((out_dtype == 0 || out_dtype == 3) ? 1 : out_dtype == 1 ? 2 : 4)) % 128 == 0,
                      "pack_uniform: Kp must cover K and be a multiple of 128 bytes");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_uniform: n_bits must be in [2,7] (q - z must fit int8)");
     hipStream_t st = (hipStream_t)stream;
@@ -463,6 +489,7 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
     if (out_dtype == 0) launch_pack<int8_t, KIND_UNIFORM>(a, st);
     else if (out_dtype == 1) launch_pack<__hip_bfloat16, KIND_UNIFORM>(a, st);
     else if (out_dtype == 2) launch_pack<float, KIND_UNIFORM>(a, st);
+    else if (out_dtype == 3) launch_pack<fp8_t, KIND_UNIFORM>(a, st);
     else { adalog_set_error_msg("pack_uniform: unknown out_dtype"); return -1; }
     ADALOG_LAUNCH_CHECK("adalog_pack_uniform");
     return 0;

@@ -12,12 +12,12 @@ import torch
 
 from . import _lib
 
-I8, BF16, F32 = 0, 1, 2
+I8, BF16, F32, FP8 = 0, 1, 2, 3        # FP8: e4m3 bytes holding q - z of <= 4-bit layers exactly (same MFMA rate as int8)
 # bench.py sets this to a list to time the scoring GEMM launches: (dtype, M, N, Kp, C, G, A.data_ptr(), start, end) with
 # the two events recorded on the launch stream immediately around the adalog_gemm_score kernel (not the finish kernel)
 GEMM_EVENTS = None
-_ESZ = {I8: 1, BF16: 2, F32: 4}
-_TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32}
+_ESZ = {I8: 1, BF16: 2, F32: 4, FP8: 1}
+_TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32, FP8: torch.float8_e4m3fn}
 
 
 def _stream():

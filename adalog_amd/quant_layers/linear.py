@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import backend, search
-from ..ops import BF16, I8, Strided, pad_k  # noqa: F401  (dtype codes / epilogue parameter helper; pure metadata)
+from ..ops import BF16, FP8, I8, Strided, pad_k  # noqa: F401  (dtype codes / epilogue parameter helper; pure metadata)
 from ..quantizers.logarithm import ShiftAdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
@@ -121,6 +121,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
 
     # ------------------------------------------------------------------ min/max initialisation (linear.py:265-294)
     def _initialize_weight_scale(self):
+        self.w_quantizer._zp_on_grid = False         # min/max initialisation: the zero point may fall outside [0, 2^bits - 1]
         be = backend.get()
         mn, mx = be.minmax_rows(self.weight.data.view(self.out_features, self.in_features))
         L2 = 2 * self.w_quantizer.n_levels - 1
@@ -130,6 +131,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         self.w_quantizer.inited = True
 
     def _initialize_activation_scale(self):
+        self.a_quantizer._zp_on_grid = False
         from .. import parallel
         be = backend.get()
         x2 = self.raw_input.reshape(-1, self.in_features)
@@ -167,11 +169,19 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         self.w_quantizer.scale.data.copy_(scale.view(self.n_V, self.crb_rows, 1))
         self.w_quantizer.zero_point.data.copy_(zp.view(self.n_V, self.crb_rows, 1))
         self.w_quantizer.inited = True
+        self.w_quantizer._zp_on_grid = True          # zero point taken from an FPCS grid: inside [0, 2^bits - 1]
 
     def _commit_a(self, scale, zp):
         self.a_quantizer.scale.data.copy_(scale.view(self.a_quantizer.scale.shape))
         self.a_quantizer.zero_point.data.copy_(zp.view(self.a_quantizer.zero_point.shape))
         self.a_quantizer.inited = True
+        self.a_quantizer._zp_on_grid = True
+
+    def _int_dt(self, rows):
+        """Storage type of the integer operand pair of an output-based search over `rows` candidate rows."""
+        chunk = self._cand_chunk(rows, pad_k(self.in_features, I8))
+        on_grid = getattr(self.w_quantizer, "_zp_on_grid", False) and getattr(self.a_quantizer, "_zp_on_grid", False)
+        return search.int_operand_dtype(self.w_quantizer.n_bits, self.a_quantizer.n_bits, chunk, on_grid)
 
     def _cand_chunk(self, rows, kp_bytes):
         return max(1, min(self.eq_n, MAX_PACK_BYTES // max(1, rows * kp_bytes)))
@@ -182,8 +192,9 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         be = backend.get()
         aq = self.a_quantizer
         x3 = self._x2().unsqueeze(0)
-        xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
-        return I8, xp, Strided(aq.scale.data.view(-1)), 1.0, None
+        dt = self._int_dt(self.out_features)
+        xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, dt)
+        return dt, xp, Strided(aq.scale.data.view(-1)), 1.0, None
 
     def _score_w(self, fixed, scale, zp):
         """linear.py:355-384 -> scores [P, O] = -sum_images mean_tokens (raw_out - q_a(x) . fq_p(W)^T - b)^2."""
@@ -193,7 +204,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         P = scale.shape[0]
         wq = self.w_quantizer
         out = []
-        chunk = self._cand_chunk(self.out_features, pad_k(self.in_features, dt) * (1 if dt == I8 else 2))
+        chunk = self._cand_chunk(self.out_features, pad_k(self.in_features, dt) * (2 if dt == BF16 else 1))
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
@@ -233,12 +244,13 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         M = x3.shape[1]
         P = scale.shape[0]
         out = []
+        dt = getattr(wp, "int_dt", I8)
         chunk = self._cand_chunk(M, pad_k(self.in_features, I8))
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
-            xp = be.pack_uniform(x3, sc, zc, e - s, 1, 1, 0, 0, aq.n_bits, I8, c_inner=True)
-            out.append(be.gemm_score(I8, wp, xp, self.out_features, M, e - s, 1, 1, self._ref2(),
+            xp = be.pack_uniform(x3, sc, zc, e - s, 1, 1, 0, 0, aq.n_bits, dt, c_inner=True)
+            out.append(be.gemm_score(dt, wp, xp, self.out_features, M, e - s, 1, 1, self._ref2(),
                                      Strided(search.const_tensor([1.0], x3.device)), Strided(sc, c=1), None,
                                      False, False, 1.0 / (self._tokens_per_image() * self.out_features),
                                      ref_div=e - s, order=2, ref_transposed=True,
@@ -273,7 +285,9 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_a_self(s, z)
         else:
-            wp = self._pack_w_fixed()
+            dt = self._int_dt(self.raw_input.numel() // self.in_features)
+            wp = self._pack_w_fixed(dt)
+            wp.int_dt = dt
             fn = lambda s, z, t: self._score_a(wp, s, z)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, 1e-4)
         if res is not None:

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import backend, search
-from ..ops import BF16, I8, Strided, pad_k
+from ..ops import BF16, FP8, I8, Strided, pad_k  # noqa: F401
 from ..quantizers.logarithm import AdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
@@ -172,7 +172,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         src = self._a3(A) if which == "A" else self._bt3_packable(B)
         bits = self.A_quantizer.n_bits if which == "A" else self.B_quantizer.n_bits
         rows = S if which == "A" else Sp
-        esz = 1 if dt == I8 else 2
+        esz = 2 if dt == BF16 else 1
         chunk = self._cand_chunk(G * rows * pad_k(K, dt) * esz)
         pg = 1 if H > 1 else 0
         out = []
@@ -223,9 +223,13 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         self._initialize_calib_parameters()
         self._init_from_grid("A")
         self._init_from_grid("B")
+        G, S, K, Sp = self._dims()
+        # both zero points come from the percentile grid (_init_from_grid, then FPCS commits): fp8 storage when <= 4 bit
+        dt = search.int_operand_dtype(self.A_quantizer.n_bits, self.B_quantizer.n_bits,
+                                      self._cand_chunk(G * max(S, Sp) * pad_k(K, I8)))
         for _ in range(self.search_round):
-            self._fpcs("A", steps=self.steps)
-            self._fpcs("B", steps=self.steps)
+            self._fpcs("A", steps=self.steps, dt=dt)
+            self._fpcs("B", steps=self.steps, dt=dt)
         self.calibrated = True
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None

@@ -12,9 +12,9 @@ import torch
 
 from oracle import adalog_oracle as O
 
-I8, BF16, F32 = 0, 1, 2
-_ESZ = {I8: 1, BF16: 2, F32: 4}
-_TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32}
+I8, BF16, F32, FP8 = 0, 1, 2, 3
+_ESZ = {I8: 1, BF16: 2, F32: 4, FP8: 1}
+_TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32, FP8: torch.float8_e4m3fn}
 
 
 def pad_k(K, dtype):

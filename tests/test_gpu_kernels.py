@@ -123,6 +123,16 @@ def test_pack_uniform(ops, bits):
     ref = CB.pack_uniform(x3, sc, zp, 16, 1, 1, 0, 0, bits, CB.I8)
     out = ops.pack_uniform(x3.to(DEV), sc.to(DEV), zp.to(DEV), 16, 1, 1, 0, 0, bits, ops.I8)
     assert torch.equal(out.cpu(), ref)
+    if bits <= 4:                                  # fp8 (e4m3) storage of q - z: exact for <= 4-bit operands
+        ref8 = CB.pack_uniform(x3, sc, zp, 16, 1, 1, 0, 0, bits, CB.FP8)
+        out8 = ops.pack_uniform(x3.to(DEV), sc.to(DEV), zp.to(DEV), 16, 1, 1, 0, 0, bits, ops.FP8)
+        assert torch.equal(out8.cpu().float(), ref8.float()) and torch.equal(out8.cpu().float(), ref.float())
+        w8 = torch.randn(1, 96, 384, generator=gen) * 0.1
+        s8 = torch.rand(8, 96, generator=gen) * 0.02 + 0.005; z8 = torch.randint(0, 2 * L, (8, 96), generator=gen).float()
+        r8, rs8 = CB.pack_uniform(w8, s8, z8, 8, 96, 1, 0, 1, bits, CB.FP8, want_rowsum=True, c_inner=True)
+        o8, ro8 = ops.pack_uniform(w8.to(DEV), s8.to(DEV), z8.to(DEV), 8, 96, 1, 0, 1, bits, ops.FP8, want_rowsum=True,
+                                   c_inner=True)
+        assert torch.equal(o8.cpu().float(), r8.float()) and torch.equal(ro8.cpu(), rs8)
     # per-row weight candidates with rowsum, bf16 and fp32 outputs
     w3 = torch.randn(1, 96, 384, generator=gen) * 0.1
     sc = torch.rand(8, 96, generator=gen) * 0.02 + 0.005; zp = torch.randint(0, 2 * L, (8, 96), generator=gen).float()
@@ -519,22 +529,22 @@ def test_gemm_cand_kernel_row_scale_and_tiles(ops, dtype, M):
                 assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (K, keep_h, order, rel_err(got.cpu(), want))
 
 
-@pytest.mark.parametrize("dtype", ["i8", "bf16"])
+@pytest.mark.parametrize("dtype", ["i8", "bf16", "fp8"])
 @pytest.mark.parametrize("P", [64, 128, 256])
 def test_gemm_stream_kernel_variants(ops, dtype, P):
     """Persistent streaming kernel (ref_div in {64, 128, 256}, transposed reference): column bias shared by the candidates
     (folded into the staged reference), per-(candidate, column) bias, no bias; with and without a row scale; K padding
     skipped through k_valid; ragged M and N edges; several groups -- against the CPU specification."""
     gen = g(1200 + P)
-    dt_c, dt_o = (CB.I8, ops.I8) if dtype == "i8" else (CB.BF16, ops.BF16)
-    tdt = torch.int8 if dtype == "i8" else torch.bfloat16
+    dt_c, dt_o = {"i8": (CB.I8, ops.I8), "bf16": (CB.BF16, ops.BF16), "fp8": (CB.FP8, ops.FP8)}[dtype]
+    tdt = {"i8": torch.int8, "bf16": torch.bfloat16, "fp8": torch.float8_e4m3fn}[dtype]
     G, gmod = 3, 1
     # the last three shapes have >= 1024 bytes of K: the one-workgroup-per-CU 192/256-row form (ragged and exact M)
     for M, Ncols, K in ((197, 5, 64), (300, 11, 136), (64, 3, 40), (384, 3, 1100), (200, 5, 1030), (700, 2, 1100)):
         Kp = CB.pad_k(K, dt_c)
         A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
-        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).to(tdt)
-        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).to(tdt)
+        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).float().to(tdt)
+        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).float().to(tdt)
         ref = torch.randn(G, Ncols, M, generator=gen) * 3
         sa = torch.rand(1, generator=gen) * 0.002 + 0.001
         sb = torch.rand(P, Ncols, generator=gen) * 0.5 + 0.5

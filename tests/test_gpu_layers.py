@@ -54,6 +54,25 @@ def test_modes_and_errors():
     LC.case_modes_and_errors(DEV)
 
 
+def test_searches_with_fp8_operand_storage(golden, monkeypatch):
+    """ADALOG_INT_FP8=1: <= 4-bit integer operands stored as fp8 e4m3 (exact) and multiplied on the f8f6f4 MFMA -- the
+    searches must reach the reference's golden results exactly as with int8 storage."""
+    monkeypatch.setenv("ADALOG_INT_FP8", "1")
+    seen = []
+    from adalog_amd import backend
+    be = backend.get()
+    orig = be.gemm_score
+
+    def spy(dtype, *a, **k):
+        seen.append(dtype)
+        return orig(dtype, *a, **k)
+    monkeypatch.setattr(be, "gemm_score", spy)
+    LC.case_linear_search(golden, "linear_w4a4", DEV)
+    LC.case_linear_search(golden, "linear_w3a3", DEV)
+    LC.case_matmul_search(golden, 4, DEV)
+    assert be.FP8 in seen, "the fp8 path was not exercised"
+
+
 def t(a):
     return torch.from_numpy(np.asarray(a))
 

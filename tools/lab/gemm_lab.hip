@@ -20,18 +20,20 @@ int main(int argc, char** argv) {
     std::vector<Case> cases = {
         {"w-search qkv  i8  K=384", 0, T, 1152 * 128, 384, 128, 0, 2},
         {"a-search qkv  i8  K=384", 0, 1152, T * 128, 384, 128, 1, 2},
+        {"w-search qkv  fp8 K=384", 3, T, 1152 * 128, 384, 128, 0, 2},
+        {"a-search qkv  fp8 K=384", 3, 1152, T * 128, 384, 128, 1, 2},
         {"a-search fc2  bf16 K=1536", 1, 384, T * 128, 1536, 128, 1, 2},
         {"w-search fc2  bf16 K=1536", 1, T, 384 * 128, 1536, 128, 0, 2},
         {"a-search proj i8  K=384", 0, 384, T * 128, 384, 128, 1, 2},
         {"a-search fc2  i8  K=1536", 0, 384, T * 128, 1536, 128, 1, 2},
     };
     for (const Case& cs : cases) {
-        const int esz = cs.dtype == 0 ? 1 : 2;
+        const int esz = (cs.dtype == 0 || cs.dtype == 3) ? 1 : 2;
         const size_t abytes = (size_t)cs.M * cs.K * esz, bbytes = (size_t)cs.N * cs.K * esz;
         uint8_t *A, *B; float *ref, *sa, *sb, *rs, *rb, *partial; long long* tl;
         CK(hipMalloc(&A, abytes)); CK(hipMalloc(&B, bbytes));
         std::vector<uint8_t> h(std::max(abytes, bbytes));
-        for (size_t i = 0; i < h.size(); ++i) h[i] = cs.dtype == 0 ? (uint8_t)((i * 2654435761u >> 13) & 7) : (uint8_t)((i & 1) ? 0x3f : ((i * 2654435761u >> 13) & 0x7f));
+        for (size_t i = 0; i < h.size(); ++i) h[i] = (cs.dtype == 0 || cs.dtype == 3) ? (uint8_t)((i * 2654435761u >> 13) & 7) : (uint8_t)((i & 1) ? 0x3f : ((i * 2654435761u >> 13) & 0x7f));
         CK(hipMemcpy(A, h.data(), abytes, hipMemcpyHostToDevice)); CK(hipMemcpy(B, h.data(), bbytes, hipMemcpyHostToDevice));
         const int n_eff = cs.N / cs.P;
         CK(hipMalloc(&ref, (size_t)cs.M * n_eff * 4)); CK(hipMemset(ref, 0, (size_t)cs.M * n_eff * 4));
