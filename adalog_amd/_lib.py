@@ -35,6 +35,11 @@ SIGNATURES = {
     "adalog_quantile_rows": (i32, [p, i64, i64, i32, p, p, i32, p, p, i64, p]),
     "adalog_positive_percentile_rows": (i32, [p, i64, i64, i32, p, p, p, i64, p]),
     "adalog_select_workspace_bytes": (i64, [i64, i32]),
+    "adalog_select_init": (i32, [p, i64, i64, i32, p, p]),
+    "adalog_select_hist": (i32, [p, i64, i64, i32, i32, i32, i64, i32, i32, i32, p, p]),
+    "adalog_select_pick": (i32, [p, i64, i32, i32, p, i32, p]),
+    "adalog_select_quantile_out": (i32, [p, i64, i32, p, i32, p, p]),
+    "adalog_select_value_out": (i32, [p, i64, i32, p, p]),
     "adalog_uniform_fq_backward_blocks": (i32, [i64, i64, i64]),
     "adalog_uniform_fq_backward": (i32, [p, p, p, i64, p, p, i64, i64, i32, i32, p, p, p, p]),
     "adalog_log_fq_backward": (i32, [p, p, p, p, i64, p, p, i32, p, i32, p, p, p]),

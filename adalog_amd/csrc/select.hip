@@ -34,14 +34,18 @@ __global__ __launch_bounds__(256) void k_sel_init(SelState* st, const int64_t* r
     st[i].remaining = ranks ? ranks[i % R] : 0;
 }
 
+// Local segment `seg` (rows of x) accumulates into state / histogram slot  first + (seg / inner) * outer + seg % inner:
+// identity for a single process; with image-sharded ranks each rank adds its rows' counts into the GLOBAL segment they
+// belong to and the histograms are summed across ranks before the pick (adalog_select_* entry points).
 __global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ x, int64_t n, int R, int pass,
                                                   const SelState* __restrict__ st, unsigned* __restrict__ hist,
-                                                  int positive_only) {
+                                                  int positive_only, int first, int inner, int outer) {
     __shared__ unsigned h[MAXR][256];
     __shared__ uint32_t pre[MAXR];
     const int seg = blockIdx.y;
+    const int slot = first + (seg / inner) * outer + seg % inner;
     for (int i = threadIdx.x; i < R * 256; i += blockDim.x) (&h[0][0])[i] = 0;
-    if ((int)threadIdx.x < R) pre[threadIdx.x] = st[seg * R + threadIdx.x].prefix;
+    if ((int)threadIdx.x < R) pre[threadIdx.x] = st[slot * R + threadIdx.x].prefix;
     __syncthreads();
     const int shift = 24 - 8 * pass;
     const float* xs = x + (int64_t)seg * n;
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ x, i
             if (pass == 0 || hi == pre[r]) atomicAdd(&h[r][bin], 1u);
     }
     __syncthreads();
-    unsigned* gh = hist + ((int64_t)seg * R) * 256;
+    unsigned* gh = hist + ((int64_t)slot * R) * 256;
     for (int i = threadIdx.x; i < R * 256; i += blockDim.x) {
         const unsigned c = (&h[0][0])[i];
         if (c) atomicAdd(gh + i, c);
@@ -147,7 +151,7 @@ int run_select(const float* x, int64_t S, int64_t n, int R, const int64_t* d_ran
     while (bps * S > 65535LL * 16 && bps > 1) bps /= 2;
     for (int pass = 0; pass < 4; ++pass) {
         hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)bps, (unsigned)S), dim3(256), 0, stream, x, n, R, pass, st, hist,
-                           positive_only);
+                           positive_only, 0, 1, 1);
         hipLaunchKernelGGL(k_sel_pick, dim3(cdiv(nsr, 4)), dim3(256), 0, stream, st, hist, (int)S, R, pass, d_qfrac,
                            positive_only);
     }
@@ -195,5 +199,67 @@ extern "C" int adalog_positive_percentile_rows(const float* x, int64_t S, int64_
     if (rc) return rc;
     hipLaunchKernelGGL(k_sel_value_out, dim3(cdiv(S * nq, 256)), dim3(256), 0, st, state, (int)S, nq, out);
     ADALOG_LAUNCH_CHECK("adalog_positive_percentile_rows");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- sharded form (multi-GPU)
+// The same four radix passes, split so that the caller can sum the histograms of all ranks between a pass's counting and
+// its pick (torch.distributed all_reduce on the first S*R*256 uint32 of the workspace; integer sums: every rank then
+// descends identically).  S, R describe the GLOBAL segments; a rank counts only the rows it holds.
+static inline unsigned* ws_hist(void* ws) { return (unsigned*)ws; }
+static inline SelState* ws_state(void* ws, int64_t S, int R) {
+    return (SelState*)((char*)ws + ((sizeof(unsigned) * S * R * 256 + 15) / 16) * 16);
+}
+
+extern "C" int adalog_select_init(void* workspace, int64_t workspace_bytes, int64_t S, int R, const int64_t* ranks, void* stream) {
+    ADALOG_ARG_CHECK(workspace && S >= 1 && S <= 65535 && R >= 1 && R <= MAXR, "select_init: bad arguments");
+    ADALOG_ARG_CHECK(workspace_bytes >= adalog_select_workspace_bytes(S, R), "select_init: workspace too small");
+    hipError_t e = hipMemsetAsync(workspace, 0, sizeof(unsigned) * S * R * 256, (hipStream_t)stream);
+    if (e != hipSuccess) { adalog_set_error("select_init/memset", e); return (int)e; }
+    hipLaunchKernelGGL(k_sel_init, dim3(cdiv(S * R, 256)), dim3(256), 0, (hipStream_t)stream, ws_state(workspace, S, R), ranks,
+                       (int)S, R);
+    ADALOG_LAUNCH_CHECK("adalog_select_init");
+    return 0;
+}
+
+// x: this rank's rows, contiguous [S_local][n_local]; row s counts into global segment first + (s / inner) * outer + s % inner
+extern "C" int adalog_select_hist(const float* x, int64_t S_local, int64_t n_local, int first, int inner, int outer,
+                                  int64_t S, int R, int pass, int positive_only, void* workspace, void* stream) {
+    ADALOG_ARG_CHECK(x && workspace && S_local >= 1 && S_local <= 65535 && n_local >= 1 && inner >= 1 && pass >= 0 && pass < 4,
+                     "select_hist: bad arguments");
+    ADALOG_ARG_CHECK(first >= 0 && first + ((S_local - 1) / inner) * outer + (S_local - 1) % inner < S, "select_hist: slot out of range");
+    int64_t bps = (n_local + 256 * 16 - 1) / (256 * 16);
+    if (bps > 512) bps = 512;
+    if (bps < 1) bps = 1;
+    while (bps * S_local > 65535LL * 16 && bps > 1) bps /= 2;
+    hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)bps, (unsigned)S_local), dim3(256), 0, (hipStream_t)stream, x, n_local, R, pass,
+                       ws_state(workspace, S, R), ws_hist(workspace), positive_only, first, inner, outer);
+    ADALOG_LAUNCH_CHECK("adalog_select_hist");
+    return 0;
+}
+
+extern "C" int adalog_select_pick(void* workspace, int64_t S, int R, int pass, const float* qfrac, int positive_only, void* stream) {
+    ADALOG_ARG_CHECK(workspace && (!positive_only || qfrac), "select_pick: bad arguments");
+    hipLaunchKernelGGL(k_sel_pick, dim3(cdiv(S * R, 4)), dim3(256), 0, (hipStream_t)stream, ws_state(workspace, S, R),
+                       ws_hist(workspace), (int)S, R, pass, qfrac, positive_only);
+    ADALOG_LAUNCH_CHECK("adalog_select_pick");
+    return 0;
+}
+
+// quantile: out [nq][S / mbs] (R = 2 * nq ranks per segment);  value: out [R][S] (0 where nothing was selected)
+extern "C" int adalog_select_quantile_out(void* workspace, int64_t S, int nq, const float* weights, int mbs, float* out, void* stream) {
+    ADALOG_ARG_CHECK(workspace && weights && out && mbs >= 1 && S % mbs == 0, "select_quantile_out: bad arguments");
+    const int cols = (int)(S / mbs);
+    hipLaunchKernelGGL(k_sel_quantile_out, dim3(cdiv((int64_t)cols * nq, 256)), dim3(256), 0, (hipStream_t)stream,
+                       ws_state(workspace, S, 2 * nq), 2 * nq, nq, weights, cols, mbs, out);
+    ADALOG_LAUNCH_CHECK("adalog_select_quantile_out");
+    return 0;
+}
+
+extern "C" int adalog_select_value_out(void* workspace, int64_t S, int R, float* out, void* stream) {
+    ADALOG_ARG_CHECK(workspace && out, "select_value_out: bad arguments");
+    hipLaunchKernelGGL(k_sel_value_out, dim3(cdiv(S * R, 256)), dim3(256), 0, (hipStream_t)stream, ws_state(workspace, S, R),
+                       (int)S, R, out);
+    ADALOG_LAUNCH_CHECK("adalog_select_value_out");
     return 0;
 }

@@ -359,6 +359,51 @@ def positive_percentile_rows(x2, qs):
     return out
 
 
+class ShardedSelect:
+    """Radix select over segments whose elements are spread over the ranks (adalog_select_*): ``S`` global segments,
+    ``R`` order statistics each.  Usage: ``hist_pass(p)`` on every rank, sum ``hist`` across ranks, ``pick(p)``, for the
+    four passes; then ``quantiles()`` / ``values()``.  Local row s of ``x2`` belongs to global segment
+    first + (s // inner) * outer + s % inner."""
+
+    def __init__(self, x2, S: int, R: int, first: int, inner: int, outer: int, ranks=None, qfrac=None):
+        self.x2 = _f32c(x2, "x")
+        self.S, self.R, self.first, self.inner, self.outer = int(S), int(R), int(first), int(inner), int(outer)
+        self.positive = qfrac is not None
+        dev = self.x2.device
+        self.qfrac = None if qfrac is None else torch.tensor(qfrac, dtype=torch.float32).to(dev)
+        lib = _lib.load()
+        self.ws_bytes = lib.adalog_select_workspace_bytes(self.S, self.R)
+        self.ws = torch.empty((self.ws_bytes + 3) // 4, dtype=torch.int32, device=dev)
+        self.hist = self.ws[: self.S * self.R * 256]          # the part ranks sum between counting and pick
+        self._ranks = None if ranks is None else ranks.to(dev)
+        rc = lib.adalog_select_init(self.ws.data_ptr(), self.ws_bytes, self.S, self.R, _ptr(self._ranks), _stream())
+        _lib.check(rc, "adalog_select_init")
+
+    def hist_pass(self, p: int):
+        S_local, n_local = self.x2.shape
+        rc = _lib.load().adalog_select_hist(self.x2.data_ptr(), S_local, n_local, self.first, self.inner, self.outer, self.S,
+                                           self.R, p, int(self.positive), self.ws.data_ptr(), _stream())
+        _lib.check(rc, "adalog_select_hist")
+
+    def pick(self, p: int):
+        rc = _lib.load().adalog_select_pick(self.ws.data_ptr(), self.S, self.R, p, _ptr(self.qfrac), int(self.positive), _stream())
+        _lib.check(rc, "adalog_select_pick")
+
+    def quantiles(self, weights, mbs: int):
+        nq = self.R // 2
+        out = torch.empty((nq, self.S // mbs), dtype=torch.float32, device=self.x2.device)
+        w = weights.to(self.x2.device)
+        rc = _lib.load().adalog_select_quantile_out(self.ws.data_ptr(), self.S, nq, w.data_ptr(), int(mbs), out.data_ptr(), _stream())
+        _lib.check(rc, "adalog_select_quantile_out")
+        return out
+
+    def values(self):
+        out = torch.empty((self.R, self.S), dtype=torch.float32, device=self.x2.device)
+        rc = _lib.load().adalog_select_value_out(self.ws.data_ptr(), self.S, self.R, out.data_ptr(), _stream())
+        _lib.check(rc, "adalog_select_value_out")
+        return out
+
+
 # ------------------------------------------------------------------------------------------------ small vector ops
 def shift_fold(rowsum, w_scale, shift, bias):
     """fold[c][o] = bias[o] - shift * (w_scale[c][o] * rowsum[c][o])   (post-GELU shift folded into the bias)."""

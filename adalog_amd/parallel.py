@@ -4,7 +4,8 @@ The reference is single-device (test_quant.py:156-160).  Calibration images are 
 sum over images, so each rank keeps its contiguous slice of every module's captured activations and the
 only data-path collective is an all-reduce(SUM) of the small [P, cols] score tensor per scoring call (<= 1.5 MB,
 latency-bound on xGMI).  RCCL delivers bit-identical sums to every rank, so the deterministic top-k that follows picks
-the same survivors everywhere.  Global order statistics (percentile candidates) gather the shards once per FPCS call.
+the same survivors everywhere.  Global order statistics (percentile candidates) use a distributed radix select: the
+per-rank histograms are all-reduced (search._sharded_quantiles), the activations stay where they are.
 """
 import torch
 import torch.distributed as dist

@@ -429,8 +429,18 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
     def calculate_percentile_activation_candidates(self, l=0.9, r=1.0):
         from .. import parallel
         be = backend.get()
-        xg = parallel.gather_images(self.raw_input)
-        pp = be.positive_percentile_rows(xg.reshape(1, -1), torch.tensor([l, r]).tolist())     # [2, 1]
+        qs = torch.tensor([l, r]).tolist()
+        if parallel.is_dist():
+            # one global segment spread over the ranks: distributed radix select (the rank of the percentile comes from
+            # the GLOBAL count of positive entries, known after the first all-reduced histogram)
+            sel = be.ShardedSelect(self.raw_input.reshape(1, -1), 1, 2, 0, 1, 0, qfrac=qs)
+            for p in range(4):
+                sel.hist_pass(p)
+                parallel.all_reduce_sum(sel.hist)
+                sel.pick(p)
+            pp = sel.values()                                                                   # [2, 1]
+        else:
+            pp = be.positive_percentile_rows(self.raw_input.reshape(1, -1), qs)                 # [2, 1]
         cand = (pp.view(1, 2) + self.a_quantizer.shift.data.view(1, 1))
         frac = search.const_tensor([i / (self.eq_n - 1) for i in range(self.eq_n)], cand.device).view(1, -1)
         scales = cand[:, 0:1] + (cand[:, 1:] - cand[:, 0:1]) * frac

@@ -87,6 +87,37 @@ def _chunk_rows(numel: int) -> int:
     return mbs
 
 
+def _sharded_quantiles(x2, S: int, first: int, inner: int, outer: int, n_total: int, mbs: int):
+    """torch.quantile over GLOBAL segments whose elements are spread over the ranks, without moving the data: every rank
+    histograms its rows (4 radix passes), the [S, R, 256] int32 histograms are all-reduced, and all ranks descend
+    identically (exact distributed radix select).  Returns [4, S / mbs] like backend.quantile_rows."""
+    be = backend.get()
+    qs = _pct_lists()
+    lohi, w = be.quantile_ranks(qs, n_total)
+    sel = be.ShardedSelect(x2, S, 2 * len(qs), first, inner, outer, ranks=lohi)
+    for p in range(4):
+        sel.hist_pass(p)
+        parallel.all_reduce_sum(sel.hist)
+        sel.pick(p)
+    return sel.quantiles(w, mbs)
+
+
+def _flat_layout(local_numel: int, rows: int = 1):
+    """Where this rank's contiguous image shard sits among the reference's quantile chunks (x.view(mbs, -1) of the GLOBAL
+    tensor, per `rows` leading rows such as heads): -> (mbs, local_rows_per_row, first, inner, outer, n_total) or None
+    when chunk and shard boundaries do not nest (then the shards are gathered instead)."""
+    ws, r = parallel.world_size(), parallel.rank()
+    per_row_global = ws * (local_numel // rows)
+    mbs = _chunk_rows(per_row_global)
+    n_total = per_row_global // mbs
+    if mbs <= ws and ws % mbs == 0:                        # a chunk spans ws/mbs ranks
+        return mbs, 1, r // (ws // mbs), 1, mbs, n_total
+    if mbs % ws == 0:                                      # a rank holds mbs/ws whole chunks
+        per = mbs // ws
+        return mbs, per, r * per, per, mbs, n_total
+    return None
+
+
 def weight_grid(w2, n_bits: int, eq_n: int, conv: bool = False):
     """linear.py:432-451 / conv.py:271-290 -> (scale [P, rows], zp [P, rows], delta [rows])."""
     be = backend.get()
@@ -99,18 +130,28 @@ def weight_grid(w2, n_bits: int, eq_n: int, conv: bool = False):
 
 def activation_grid(x, n_bits: int, eq_n: int, channel_wise: bool):
     """linear.py:453-481 -> (scale [P, C], zp [P, C], delta [C]), C = in_features or 1.  ``x`` is the rank-local shard;
-    quantiles are global order statistics, so the shards are gathered for this one-off HBM-bound step."""
+    quantiles are global order statistics: with several ranks they come from a distributed radix select (histograms
+    all-reduced, data stays put)."""
     be = backend.get()
     L = 2 ** (n_bits - 1)
     num_zp = min(16, 2 * L)
     num_scale = int(eq_n / num_zp)
-    xg = parallel.gather_images(x)
-    if channel_wise:
-        x2 = xg.reshape(-1, xg.shape[-1]).t().contiguous()
-        quant4 = be.quantile_rows(x2, _pct_lists(), 1)
+    lay = _flat_layout(x.numel()) if parallel.is_dist() else None
+    if parallel.is_dist() and channel_wise:
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C).t().contiguous()              # [C, local rows]: every rank holds a part of every channel
+        quant4 = _sharded_quantiles(x2, C, 0, C, 0, parallel.world_size() * x2.shape[1], 1)
+    elif lay is not None:
+        mbs, per, first, inner, outer, n_total = lay
+        quant4 = _sharded_quantiles(x.reshape(per, -1), mbs, first, inner, outer, n_total, mbs)
     else:
-        mbs = _chunk_rows(xg.numel())
-        quant4 = be.quantile_rows(xg.reshape(mbs, -1), _pct_lists(), mbs)
+        xg = parallel.gather_images(x)
+        if channel_wise:
+            x2 = xg.reshape(-1, xg.shape[-1]).t().contiguous()
+            quant4 = be.quantile_rows(x2, _pct_lists(), 1)
+        else:
+            mbs = _chunk_rows(xg.numel())
+            quant4 = be.quantile_rows(xg.reshape(mbs, -1), _pct_lists(), mbs)
     return be.candidate_grid(quant4, num_scale, num_zp, int(L - num_zp / 2), n_bits, linspace01(num_scale, x.device), 1e-4)
 
 
@@ -120,16 +161,22 @@ def matmul_grid(x, n_bits_B: int, eq_n: int, head_wise: bool = True):
     L = 2 ** (n_bits_B - 1)
     num_zp = min(16, L)
     num_scale = int(eq_n / num_zp)
-    xg = parallel.gather_images(x)
-    if head_wise:
-        H = xg.shape[1]
-        xt = xg.transpose(0, 1).contiguous()
-        mbs = _chunk_rows(xt.numel() // H)
-        x2 = xt.view(H * mbs, -1)
+    H = x.shape[1] if head_wise else 1
+    lay = _flat_layout(x.numel(), H) if parallel.is_dist() else None
+    if lay is not None:
+        mbs, per, first, inner, outer, n_total = lay
+        xl = x.transpose(0, 1).contiguous() if head_wise else x
+        quant4 = _sharded_quantiles(xl.reshape(H * per, -1), H * mbs, first, inner, outer, n_total, mbs)
     else:
-        mbs = _chunk_rows(xg.numel())
-        x2 = xg.reshape(mbs, -1)
-    quant4 = be.quantile_rows(x2, _pct_lists(), mbs)
+        xg = parallel.gather_images(x)
+        if head_wise:
+            xt = xg.transpose(0, 1).contiguous()
+            mbs = _chunk_rows(xt.numel() // H)
+            x2 = xt.view(H * mbs, -1)
+        else:
+            mbs = _chunk_rows(xg.numel())
+            x2 = xg.reshape(mbs, -1)
+        quant4 = be.quantile_rows(x2, _pct_lists(), mbs)
     return be.candidate_grid(quant4, num_scale, num_zp, int(L - num_zp / 2), n_bits_B, linspace01(num_scale, x.device), None)
 
 

@@ -165,6 +165,17 @@ int adalog_quantile_rows(const float* x, int64_t S, int64_t n, int nq, const int
 int adalog_positive_percentile_rows(const float* x, int64_t S, int64_t n, int nq, const float* qfrac, float* out,
                                     void* workspace, int64_t workspace_bytes, void* stream);
 int64_t adalog_select_workspace_bytes(int64_t S, int R);
+/* Sharded form (image-sharded ranks; SURVEY 8e "distributed radix-select with histogram all-reduce"): the same four radix
+ * passes, split so the caller can sum the histograms of all ranks (the first S*R*256 uint32 of the workspace) between a
+ * pass's counting and its pick.  S, R describe the GLOBAL segments; a rank counts only the rows it holds: local row s
+ * belongs to global segment first + (s / inner) * outer + s % inner.  ranks: int64 [R] (NULL with positive_only, where
+ * the rank is ceil(count * qfrac) - 1 of the GLOBAL positive count).  Outputs as the fused entry points above. */
+int adalog_select_init(void* workspace, int64_t workspace_bytes, int64_t S, int R, const int64_t* ranks, void* stream);
+int adalog_select_hist(const float* x, int64_t S_local, int64_t n_local, int first, int inner, int outer, int64_t S, int R,
+                       int pass, int positive_only, void* workspace, void* stream);
+int adalog_select_pick(void* workspace, int64_t S, int R, int pass, const float* qfrac, int positive_only, void* stream);
+int adalog_select_quantile_out(void* workspace, int64_t S, int nq, const float* weights, int mbs, float* out, void* stream);
+int adalog_select_value_out(void* workspace, int64_t S, int R, float* out, void* stream);
 
 /* ---- small vector kernels
  * adalog_shift_fold: out[c][o] = bias[o] - shift[0] * (w_scale[c][o] * rowsum[c][o])      reference linear.py:999-1006

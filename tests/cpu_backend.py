@@ -216,6 +216,86 @@ def positive_percentile_rows(x2, qs):
     return torch.stack([O.positive_percentile(row, torch.tensor(qs, dtype=torch.float32)) for row in x2], dim=1)
 
 
+class ShardedSelect:
+    """Executable specification of adalog_amd.ops.ShardedSelect: MSB-first radix select (4 passes x 8 bits over
+    order-preserving uint32 keys) with the histograms exposed so that ranks can sum them between counting and pick."""
+
+    def __init__(self, x2, S, R, first, inner, outer, ranks=None, qfrac=None):
+        self.x2 = x2.contiguous().float()
+        self.S, self.R, self.first, self.inner, self.outer = S, R, first, inner, outer
+        self.positive = qfrac is not None
+        self.qfrac = None if qfrac is None else torch.tensor(qfrac, dtype=torch.float32)
+        self.hist = torch.zeros(S * R * 256, dtype=torch.int32)
+        self.prefix = torch.zeros(S, R, dtype=torch.int64)
+        self.remaining = torch.zeros(S, R, dtype=torch.int64) if ranks is None else ranks.view(1, R).repeat(S, 1).clone()
+        u = self.x2.view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        self.keys = torch.where(u >= 0x80000000, (~u) & 0xFFFFFFFF, u | 0x80000000)
+
+    def _slot(self, s):
+        return self.first + (s // self.inner) * self.outer + s % self.inner
+
+    def hist_pass(self, p):
+        shift = 24 - 8 * p
+        h = self.hist.view(self.S, self.R, 256)
+        for s in range(self.x2.shape[0]):
+            k = self.keys[s]
+            if self.positive:
+                k = k[self.x2[s] > 0]
+            slot = self._slot(s)
+            for r in range(self.R):
+                sel = k if p == 0 else k[(k >> (shift + 8)) == self.prefix[slot, r]]
+                h[slot, r] += torch.bincount((sel >> shift) & 255, minlength=256).to(torch.int32)
+
+    def pick(self, p):
+        h = self.hist.view(self.S, self.R, 256).to(torch.int64)
+        for s in range(self.S):
+            for r in range(self.R):
+                total = int(h[s, r].sum())
+                if p == 0 and self.positive:
+                    cq = torch.ceil(torch.tensor(float(total), dtype=torch.float32) * self.qfrac[r % self.R])
+                    rk = int(cq) - 1
+                    self.remaining[s, r] = -1 if total == 0 else max(rk, 0)
+                rem = int(self.remaining[s, r])
+                if rem >= 0:
+                    cum = torch.cumsum(h[s, r], 0)
+                    hit = torch.nonzero(cum > rem)
+                    b = int(hit[0]) if hit.numel() else 255
+                    before = int(cum[b - 1]) if (b > 0 and hit.numel()) else (0 if hit.numel() else total)
+                    self.prefix[s, r] = (self.prefix[s, r] << 8) | b
+                    self.remaining[s, r] = rem - before
+        self.hist.zero_()
+
+    def _vals(self):
+        k = self.prefix
+        u = torch.where(k >= 0x80000000, k & 0x7FFFFFFF, (~k) & 0xFFFFFFFF)
+        return torch.tensor([[_bits_to_float(int(v)) for v in row] for row in u.tolist()], dtype=torch.float32)
+
+    def quantiles(self, weights, mbs):
+        v = self._vals().double()                           # [S, R]
+        nq = self.R // 2
+        a, b = v[:, 0::2], v[:, 1::2]
+        w = weights.view(1, nq).double()
+        d = (b.float() - a.float()).double()
+        # ATen lerp: weight < 0.5 ? fma(w, d, a) : fma(w - 1, d, b)  (one rounding: evaluated in fp64, rounded once)
+        val = torch.where(w.abs() < 0.5, a + w * d, b + (w.float() - 1.0).double() * d).float()
+        val = val.view(self.S // mbs, mbs, nq)
+        acc = torch.zeros(self.S // mbs, nq)
+        for m in range(mbs):
+            acc = acc + val[:, m]
+        if mbs > 1:
+            acc = acc / float(mbs)
+        return acc.t().contiguous()
+
+    def values(self):
+        v = self._vals()
+        return torch.where(self.remaining < 0, torch.zeros_like(v), v).t().contiguous()
+
+
+def _bits_to_float(u):
+    import struct
+    return struct.unpack("<f", struct.pack("<I", u & 0xFFFFFFFF))[0]
+
+
 def shift_fold(rowsum, w_scale, shift, bias):
     f = shift * (w_scale * rowsum.float())
     return (bias.view(1, -1) if bias is not None else 0.0) - f

@@ -567,3 +567,50 @@ def test_gemm_stream_kernel_variants(ops, dtype, P):
                                          row_bias=rb.to(DEV) if rows else None)
                     assert got.shape == want.shape
                     assert rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, K, bias_kind, rows, kv, rel_err(got.cpu(), want))
+
+
+def test_sharded_select_matches_fused(ops):
+    """adalog_select_* (histograms summed over emulated ranks between counting and pick) == the fused single-process
+    kernels == the CPU specification, for every shard/chunk layout the grids use, and for the positive percentile."""
+    gen = g(77)
+    qs = [0.9, 1.0, 1 - 0.9, 0.0]
+
+    def run(mod, shards, S, layouts, n_total, mbs, dev):
+        lohi, w = mod.quantile_ranks(qs, n_total)
+        sels = [mod.ShardedSelect(x2.to(dev), S, 8, *lay, ranks=lohi) for x2, lay in zip(shards, layouts)]
+        for p in range(4):
+            for s in sels:
+                s.hist_pass(p)
+            total = sum(s.hist.clone() for s in sels)
+            for s in sels:
+                s.hist.copy_(total)
+                s.pick(p)
+        return sels[0].quantiles(w, mbs)
+
+    x = torch.randn(4, 50000, generator=gen)
+    cases = [
+        ([x[0:1].reshape(1, -1), x[1:2].reshape(1, -1), x[2:3].reshape(1, -1), x[3:4].reshape(1, -1)], 1, [(0, 1, 0)] * 4, 200000, 1,
+         x.reshape(1, -1), 1),                                                       # one segment over 4 ranks
+        ([x[0:2], x[2:4]], 4, [(0, 2, 4), (2, 2, 4)], 50000, 4, x, 4),                # 2 chunks per rank, mean of 4 chunks
+        ([x[:, :20000].contiguous(), x[:, 20000:].contiguous()], 4, [(0, 4, 0), (0, 4, 0)], 50000, 1, x, 1),   # channel-wise
+    ]
+    for shards, S, layouts, n_total, mbs, full, fmbs in cases:
+        got = run(ops, shards, S, layouts, n_total, mbs, DEV).cpu()
+        fused = ops.quantile_rows(full.to(DEV), qs, fmbs).cpu()
+        spec = run(CB, shards, S, layouts, n_total, mbs, "cpu")
+        assert torch.equal(got, fused), (S, mbs)
+        torch.testing.assert_close(got, spec, rtol=1e-6, atol=0)
+    # positive percentile: rank from the GLOBAL count of positive entries
+    y = torch.nn.functional.gelu(2 * torch.randn(3, 40000, generator=gen))
+    pq = torch.tensor([0.9, 1.0]).tolist()
+    sels = [ops.ShardedSelect(y[i:i + 1].to(DEV), 1, 2, 0, 1, 0, qfrac=pq) for i in range(3)]
+    for p in range(4):
+        for s in sels:
+            s.hist_pass(p)
+        total = sum(s.hist.clone() for s in sels)
+        for s in sels:
+            s.hist.copy_(total)
+            s.pick(p)
+    got = sels[0].values().cpu()
+    want = ops.positive_percentile_rows(y.reshape(1, -1).to(DEV), pq).cpu()
+    assert torch.equal(got, want)
