@@ -41,7 +41,7 @@ constexpr int BM = 128, BN = 128, BKB = 64;   // BKB: K-step in bytes
 struct GemmArgs {
     const uint8_t* A; const uint8_t* B;
     int64_t sAc, sAg, sBc, sBg;      // byte strides between candidates / groups (0 = shared operand)
-    int M, N; int64_t Kb;            // Kb = padded K in bytes (multiple of 128): the row stride
+    int M, N; int64_t Kb;            // Kb = padded K in bytes: the row stride (multiple of 128; 64 for the streaming kernel)
     int64_t Kvb;                     // bytes of a row that can be non-zero (<= Kb)
     int C, G, gmod;
     const float* ref; int64_t ldr, sRg, ref_cs; int ref_div;
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(64 * NW, NS == 3 ? (NW == 8 ? 4 : 2) : 1) void k_ge
         const int g = tl.g, gh = g % p.gmod, m0 = tl.mt * BM3, n0 = tl.nt * BN2;
         const int ni0 = n0 >> rsh;
         const bool edge = (m0 + BM3 > p.M) || (n0 + BN2 > p.N);
-        const unsigned lid = t_lo + local;
+        [[maybe_unused]] const unsigned lid = t_lo + local;
         TL_STAMP(0);
         for (int kt = 0; kt < nk; ++kt) {
             // stage `st` has landed once only the newest NS - 2 steps' requests of this wave are still outstanding
@@ -1360,7 +1360,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 3, "gemm_score: dtype must be 0 (i8), 1 (bf16), 2 (f32) or 3 (fp8 e4m3)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
     const int esz = (dtype == 0 || dtype == 3) ? 1 : dtype == 1 ? 2 : 4;
-    ADALOG_ARG_CHECK((Kp * esz) % BK2 == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 128 bytes");
+    ADALOG_ARG_CHECK((Kp * esz) % BK3 == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 64 bytes");
     ADALOG_ARG_CHECK((partial != nullptr) == (ref != nullptr), "gemm_score: partial and ref go together");
     ADALOG_ARG_CHECK(partial || out, "gemm_score: nothing to produce");
     ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
@@ -1391,6 +1391,8 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nwg);
     static const int use_glds = getenv("ADALOG_GEMM_GLDS") ? atoi(getenv("ADALOG_GEMM_GLDS")) : 1;   // LDS-DMA pipeline (default on)
+    ADALOG_ARG_CHECK((Kp * esz) % BK2 == 0 || (L.stream && !out),
+                     "gemm_score: rows padded to 64 (not 128) bytes are taken by the streaming search kernel only");
     ADALOG_ARG_CHECK(dtype != 3 || (L.stream && !out), "gemm_score: fp8 operands are taken by the streaming search kernel only (ref_div 64/128/256, transposed reference)");
     if (L.stream && !out) {
         // persistent streaming kernel: two (wide form: one) workgroups per CU walk the tile list

@@ -474,8 +474,8 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
     ADALOG_ARG_CHECK(x && scale && zero_point && out, "pack_uniform: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_uniform: bad sizes");
     ADALOG_ARG_CHECK(out_dtype != 3 || n_bits <= 4, "pack_uniform: fp8 output holds q - z exactly only for n_bits <= 4");
-    ADALOG_ARG_CHECK(Kp >= K && (Kp * ((out_dtype == 0 || out_dtype == 3) ? 1 : out_dtype == 1 ? 2 : 4)) % 128 == 0,
-                     "pack_uniform: Kp must cover K and be a multiple of 128 bytes");
+    ADALOG_ARG_CHECK(Kp >= K && (Kp * ((out_dtype == 0 || out_dtype == 3) ? 1 : out_dtype == 1 ? 2 : 4)) % 64 == 0,
+                     "pack_uniform: Kp must cover K and be a multiple of 64 bytes (128 for anything but the search kernel)");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_uniform: n_bits must be in [2,7] (q - z must fit int8)");
     hipStream_t st = (hipStream_t)stream;
     PackArgs a{};
@@ -501,7 +501,7 @@ extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int
                                        int clamp_u, void* out, int64_t Kp, int c_inner, void* stream) {
     ADALOG_ARG_CHECK(x && scale && qv && mant37 && out, "pack_adalog: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_adalog: bad sizes");
-    ADALOG_ARG_CHECK(Kp >= K && (Kp * 2) % 128 == 0, "pack_adalog: Kp must cover K and be a multiple of 64 elements");
+    ADALOG_ARG_CHECK(Kp >= K && (Kp * 2) % 64 == 0, "pack_adalog: Kp must cover K and be a multiple of 32 elements");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_adalog: n_bits must be in [2,7] (numerators must fit bf16)");
     PackArgs a{};
     a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk;

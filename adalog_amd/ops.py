@@ -36,8 +36,10 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
-def pad_k(K: int, dtype: int) -> int:
-    per = 128 // _ESZ[dtype]
+def pad_k(K: int, dtype: int, align: int = 128) -> int:
+    """K rounded up to rows of a multiple of ``align`` bytes: 128 (one cache line; every kernel), or 64 for operands that
+    only the streaming search kernel reads (its K-step) -- q.k^T with head_dim 64 then packs half the bytes."""
+    per = align // _ESZ[dtype]
     return ((K + per - 1) // per) * per
 
 
@@ -102,12 +104,12 @@ def _view3(x3: torch.Tensor):
 
 
 def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr: int, n_bits: int, dtype: int = I8,
-                 want_rowsum: bool = False, c_inner: bool = False):
+                 want_rowsum: bool = False, c_inner: bool = False, k_align: int = 128):
     """-> packed [C, G, R, Kp] (int8 / bf16 / fp32), or [1, G, R*C, Kp] with candidates innermost when ``c_inner``
     [+ int32 rowsum [C, G, R]]."""
     G, R, K, sg, sr, sk = _view3(x3)
     scale, zero_point = _f32c(scale, "scale"), _f32c(zero_point, "zero_point")
-    Kp = pad_k(K, dtype)
+    Kp = pad_k(K, dtype, k_align)
     shape = (1, G, R * C, Kp) if c_inner else (C, G, R, Kp)
     out = torch.empty(shape, dtype=_TORCH_DT[dtype], device=x3.device)
     rowsum = torch.empty((C, G, R), dtype=torch.int32, device=x3.device) if want_rowsum else None
@@ -120,9 +122,9 @@ def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr:
 
 
 def pack_adalog(x3, scale, qv, C: int, pc: int, gmod: int, pg: int, n_bits: int, mant37, shift=None,
-                clamp_u: bool = True, c_inner: bool = False):
+                clamp_u: bool = True, c_inner: bool = False, k_align: int = 128):
     G, R, K, sg, sr, sk = _view3(x3)
-    Kp = pad_k(K, BF16)
+    Kp = pad_k(K, BF16, k_align)
     out = torch.empty((1, G, R * C, Kp) if c_inner else (C, G, R, Kp), dtype=torch.bfloat16, device=x3.device)
     rc = _lib.load().adalog_pack_adalog_bf16(x3.data_ptr(), G, R, K, sg, sr, sk, _ptr(_f32c(scale, "scale")),
                                             _ptr(_f32c(qv, "qv")), C, pc, gmod, pg, int(n_bits),

@@ -147,15 +147,25 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         return quantizer.scale.data.view(-1), quantizer.zero_point.data.view(-1)
 
     # ------------------------------------------------------------------ scoring calls
+    def _kalign(self):
+        """Row padding (bytes) of the operands packed for the searches: 64 when every scoring call takes all candidates in one
+        launch of the streaming kernel (whose K-step is 64 bytes: q.k^T with head_dim 64 then packs and reads half the
+        bytes), else the general 128."""
+        G, S, K, Sp = self._dims()
+        whole = self._cand_chunk(G * max(S, Sp) * pad_k(K, BF16, 64) * 2) >= self.eq_n
+        return 64 if whole and self.eq_n in (64, 128, 256) else 128
+
     def _pack_fixed(self, which, dt=I8):
         be = backend.get()
         H = self._heads()
         A, B = self.raw_input
+        al = self._kalign()
         if which == "A":
             s, z = self._q_params(self.A_quantizer)
-            return be.pack_uniform(self._a3(A), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.A_quantizer.n_bits, dt)
+            return be.pack_uniform(self._a3(A), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.A_quantizer.n_bits, dt, k_align=al)
         s, z = self._q_params(self.B_quantizer)
-        return be.pack_uniform(self._bt3_packable(B), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.B_quantizer.n_bits, dt)
+        return be.pack_uniform(self._bt3_packable(B), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.B_quantizer.n_bits, dt,
+                               k_align=al)
 
     def _score(self, which, fixed, scale, zp, dt=I8, fixed_sa=None, sa_mul=1.0):
         """matmul.py:135-163 (which='A') / :173-201 (which='B') -> scores [P, H].
@@ -173,13 +183,14 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         bits = self.A_quantizer.n_bits if which == "A" else self.B_quantizer.n_bits
         rows = S if which == "A" else Sp
         esz = 2 if dt == BF16 else 1
-        chunk = self._cand_chunk(G * rows * pad_k(K, dt) * esz)
+        al = self._kalign()
+        chunk = self._cand_chunk(G * rows * pad_k(K, dt, al) * esz)
         pg = 1 if H > 1 else 0
         out = []
         for s0 in range(0, P, chunk):
             e = min(P, s0 + chunk)
             sc, zc = scale[s0:e].contiguous(), zp[s0:e].contiguous()
-            cand = be.pack_uniform(src, sc, zc, e - s0, H, H, pg, 0, bits, dt, c_inner=True)
+            cand = be.pack_uniform(src, sc, zc, e - s0, H, H, pg, 0, bits, dt, c_inner=True, k_align=al)
             sb = Strided(sc, c=H, g=pg)
             if which == "A":
                 sa = Strided(self.B_quantizer.scale.data.view(-1), g=pg)
@@ -283,10 +294,10 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
     def _ts32(self):
         return float(torch.tensor(self.table_scale, dtype=torch.float32))
 
-    def _pack_A_adalog(self, A3, qv, scale, C, clamp_u, c_inner=False):
+    def _pack_A_adalog(self, A3, qv, scale, C, clamp_u, c_inner=False, k_align=128):
         be = backend.get()
         return be.pack_adalog(A3, scale, qv, C, 1 if C > 1 else 0, 1, 0, self.A_quantizer.n_bits,
-                              self._mant37(A3.device), shift=None, clamp_u=clamp_u, c_inner=c_inner)
+                              self._mant37(A3.device), shift=None, clamp_u=clamp_u, c_inner=c_inner, k_align=k_align)
 
     def _search_best_A_log_base(self):
         """matmul.py:321-358: 128 bases q = 10..137, per-tensor score, commit the best."""
@@ -301,13 +312,13 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         q_all = search.const_tensor([float(i) for i in range(10, 11 + self.eq_n)], dev)[:self.eq_n]
         P = self.eq_n
         ones = search.const_tensor([1.0] * P, dev)
-        chunk = self._cand_chunk(G * S * pad_k(K, BF16) * 2)
+        chunk = self._cand_chunk(G * S * pad_k(K, BF16, self._kalign()) * 2)
         out = []
         for s0 in range(0, P, chunk):
             e = min(P, s0 + chunk)
             # transposed product: rows = head-dim columns of v, GEMM columns = (attention row, candidate base)
             ap = self._pack_A_adalog(self._a3(A), q_all[s0:e].contiguous(), ones[s0:e].contiguous(), e - s0, False,
-                                     c_inner=True)
+                                     c_inner=True, k_align=self._kalign())
             out.append(be.gemm_score(BF16, bp, ap, Sp, S, e - s0, G, H, self._ref3(),
                                      Strided(self.B_quantizer.scale.data.view(-1), g=pg), Strided(ones[s0:e].contiguous(), c=1),
                                      None, False, False, 1.0 / (A.shape[1] * S * Sp), sa_mul=self._ts32(),
@@ -331,7 +342,7 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
             self._search_best_A_log_base()
             # B search against q_A(A): eval-form AdaLog of A (clamped, scale 1) is the fixed bf16 operand
             qv = search.const_tensor([float(self._q_host)], dev)
-            ap = self._pack_A_adalog(self._a3(A), qv, self.A_quantizer.scale.data.view(-1), 1, True)
+            ap = self._pack_A_adalog(self._a3(A), qv, self.A_quantizer.scale.data.view(-1), 1, True, k_align=self._kalign())
             self._fpcs("B", steps=self.steps, fixed=ap, dt=BF16, fixed_sa=Strided(self.A_quantizer.scale.data.view(-1)),
                        sa_mul=self._ts32())
         self.calibrated = True

@@ -17,8 +17,8 @@ _ESZ = {I8: 1, BF16: 2, F32: 4, FP8: 1}
 _TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32, FP8: torch.float8_e4m3fn}
 
 
-def pad_k(K, dtype):
-    per = 128 // _ESZ[dtype]
+def pad_k(K, dtype, align=128):
+    per = align // _ESZ[dtype]
     return ((K + per - 1) // per) * per
 
 
@@ -56,12 +56,12 @@ def _params(t, C, G, R, pc, gmod, pg, pr):
     return t.reshape(-1)[(c * pc + g * pg + r * pr)]            # [C, G, R]
 
 
-def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, want_rowsum=False, c_inner=False):
+def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, want_rowsum=False, c_inner=False, k_align=128):
     G, R, K = x3.shape
     s = _params(scale, C, G, R, pc, gmod, pg, pr).unsqueeze(-1)
     z = torch.round(_params(zero_point, C, G, R, pc, gmod, pg, pr)).unsqueeze(-1)
     q = (torch.round(x3.unsqueeze(0) / s) + z).clamp(0, 2 ** n_bits - 1) - z
-    Kp = pad_k(K, dtype)
+    Kp = pad_k(K, dtype, k_align)
     out = torch.zeros((C, G, R, Kp), dtype=_TORCH_DT[dtype])
     out[..., :K] = q.to(_TORCH_DT[dtype])
     rs = q.sum(-1).to(torch.int32)
@@ -72,7 +72,7 @@ def pack_uniform(x3, scale, zero_point, C, pc, gmod, pg, pr, n_bits, dtype=I8, w
     return out
 
 
-def pack_adalog(x3, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift=None, clamp_u=True, c_inner=False):
+def pack_adalog(x3, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift=None, clamp_u=True, c_inner=False, k_align=128):
     G, R, K = x3.shape
     s = _params(scale, C, G, R, pc, gmod, pg, 0).unsqueeze(-1)
     qf = _params(qv, C, G, R, pc, gmod, pg, 0).unsqueeze(-1)
@@ -89,7 +89,7 @@ def pack_adalog(x3, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift=None, clam
     v = torch.ldexp(mant37[j], -t.to(torch.int32))
     v[t > 100] = 0
     v[mask] = 0
-    Kp = pad_k(K, BF16)
+    Kp = pad_k(K, BF16, k_align)
     out = torch.zeros((C, G, R, Kp), dtype=torch.bfloat16)
     vb = v.to(torch.bfloat16)
     assert torch.equal(vb.float(), v.float()), "AdaLog operand must be exact in bf16"
