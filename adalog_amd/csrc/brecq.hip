@@ -130,8 +130,10 @@ __global__ __launch_bounds__(256) void k_adaround(const float* __restrict__ w, c
 
 // round loss value (block partials) and, when galpha != null, galpha[i] += gscale * d/d alpha
 __global__ __launch_bounds__(256) void k_round_loss(const float* __restrict__ alpha, int64_t n, float b,
-                                                    float* __restrict__ part, float* __restrict__ galpha, float gscale) {
+                                                    const float* __restrict__ b_dev, float* __restrict__ part,
+                                                    float* __restrict__ galpha, float gscale) {
     __shared__ float sm[4];
+    if (b_dev) b = b_dev[0];                 // exponent read on the device: lets a captured HIP graph follow the decaying b
     float acc = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float dh;
@@ -219,12 +221,12 @@ extern "C" int adalog_adaround(const float* w, const float* alpha, const float* 
 }
 
 // loss[0] = sum_i (1 - |2 h(alpha_i) - 1|^b); if galpha: galpha += gscale * dloss/dalpha.  workspace: 1024 floats
-extern "C" int adalog_round_loss(const float* alpha, int64_t n, float b, float* loss, float* galpha, float gscale,
-                                 float* workspace, void* stream) {
+extern "C" int adalog_round_loss(const float* alpha, int64_t n, float b, const float* b_dev, float* loss, float* galpha,
+                                 float gscale, float* workspace, void* stream) {
     ADALOG_ARG_CHECK(alpha && n >= 1 && (loss == nullptr || workspace), "round_loss: bad arguments");
     const int nb = grid1(n, 1024);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_round_loss, dim3(nb), dim3(256), 0, st, alpha, n, b, loss ? workspace : nullptr, galpha, gscale);
+    hipLaunchKernelGGL(k_round_loss, dim3(nb), dim3(256), 0, st, alpha, n, b, b_dev, loss ? workspace : nullptr, galpha, gscale);
     ADALOG_LAUNCH_CHECK("adalog_round_loss");
     if (loss) hipLaunchKernelGGL(k_param_grad_finish, dim3(1), dim3(64), 0, st, workspace, (int64_t)1, nb, (int64_t)1, loss);
     ADALOG_LAUNCH_CHECK("adalog_round_loss/finish");

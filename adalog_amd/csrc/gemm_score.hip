@@ -961,7 +961,11 @@ __global__ __launch_bounds__(64 * NW, NS == 3 ? (NW == 8 ? 4 : 2) : 1) void k_ge
                     const int e = min(tid + u * NT3, 4 * BM3 - 1);
                     const int nl = e / BM3, rl = e - nl * BM3;
                     const int rowc = min(m0 + rl, p.M - 1), nic = min(ni0 + nl, n_eff - 1);
+#if defined(GEMM_LAB_ELOAD_HOT)   // lab: always-cached address, to tell load latency from instruction overhead
+                    e_ref[u] = refg[(rowc + nic * rcs) & 1023];
+#else
                     e_ref[u] = refg[rowc + nic * rcs];
+#endif
                     e_rb[u] = p.row_bias ? p.row_bias[rowc] : 0.0f;
                     e_cb[u] = beta_staged ? p.bias[gh * p.bi_g + nic * p.bi_n] : 0.0f;
                 }

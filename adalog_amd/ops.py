@@ -491,11 +491,14 @@ def adaround(w2, alpha2, scale, zero_point, n_bits: int, soft: bool, gy=None):
     return out
 
 
-def round_loss(alpha, b: float, galpha=None, gscale: float = 1.0, want_loss: bool = True):
+def round_loss(alpha, b, galpha=None, gscale: float = 1.0, want_loss: bool = True):
+    """``b``: python float, or a device fp32 tensor of one element (read by the kernel: HIP-graph friendly)."""
     alpha = _f32c(alpha, "alpha")
     loss = torch.empty(1, dtype=torch.float32, device=alpha.device) if want_loss else None
     ws = torch.empty(1024, dtype=torch.float32, device=alpha.device)
-    rc = _lib.load().adalog_round_loss(alpha.data_ptr(), alpha.numel(), float(b), _ptr(loss), _ptr(galpha), float(gscale),
+    b_dev = _f32c(b, "b") if torch.is_tensor(b) else None
+    rc = _lib.load().adalog_round_loss(alpha.data_ptr(), alpha.numel(), 0.0 if b_dev is not None else float(b), _ptr(b_dev),
+                                      _ptr(loss), _ptr(galpha), float(gscale),
                                       ws.data_ptr(), _stream())
     _lib.check(rc, "adalog_round_loss")
     return loss

@@ -87,9 +87,10 @@ class AdaRoundQuantizer(nn.Module):
     def get_soft_targets(self):
         return torch.clamp(torch.sigmoid(self.alpha) * (self.zeta - self.gamma) + self.gamma, 0, 1)
 
-    def round_loss(self, b: float):
-        """sum(1 - |2h-1|^b) over this quantiser's weights (block_recon.py:209-210), fused."""
-        return _RoundLossFn.apply(self.alpha, float(b))
+    def round_loss(self, b):
+        """sum(1 - |2h-1|^b) over this quantiser's weights (block_recon.py:209-210), fused.  ``b`` may be a one-element
+        device tensor (captured BRECQ iterations read the exponent on the device)."""
+        return _RoundLossFn.apply(self.alpha, b if torch.is_tensor(b) else float(b))
 
     def init_alpha(self, x: torch.Tensor):
         """adaround.py:62-69: alpha such that h(alpha) equals the fractional part of w/s."""

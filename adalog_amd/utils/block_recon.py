@@ -12,6 +12,7 @@ mini-batch is split over the ranks and the gradients of alpha / activation scale
 (RCCL over xGMI; identical seeds keep randperm in lock-step).
 """
 import logging
+import os
 
 import torch
 import torch.nn.functional as F
@@ -103,36 +104,93 @@ class BlockReconstructor(QuantCalibrator):
                         a_params += [module.A_quantizer.scale, module.B_quantizer.scale]
                     else:
                         module.mode = 'raw'
-        w_optimizer = torch.optim.Adam(w_params)
-        a_optimizer = torch.optim.Adam(a_params, lr=lr) if len(a_params) != 0 else None
+        ws = parallel.world_size()
+        local_bs = max(1, batch_size // ws)
+        n_local = block.raw_input.size(0)
+        # One iteration is ~175 kernel launches (2.6 ms of GPU time, 4.1 ms wall on MI355X for a deit_small block).
+        # ADALOG_BRECQ_GRAPH=1 captures the iteration once in a HIP graph over static batch buffers and replays it: forward,
+        # reconstruction loss, rounding regulariser (its exponent b and on/off weight live in device scalars), backward
+        # and -- single process -- both Adam steps (capturable); with several ranks the gradient all-reduce and the
+        # optimiser steps stay eager.  Measured gain: 3 % (4.13 -> 4.00 ms): the replay pays a per-node cost close to an
+        # eager launch, so the lever is fewer and larger kernels, not the launch path -- hence opt-in.
+        use_graph = (torch.device(device).type == 'cuda' and os.environ.get("ADALOG_BRECQ_GRAPH", "0") == "1"
+                     and n_local >= local_bs and iters > 8)
+        full_graph = use_graph and ws == 1
+        okw = dict(capturable=True) if full_graph else {}
+        w_optimizer = torch.optim.Adam(w_params, **okw)
+        a_lr = torch.tensor(lr, dtype=torch.float32, device=device) if full_graph else lr
+        a_optimizer = torch.optim.Adam(a_params, lr=a_lr, **okw) if len(a_params) != 0 else None
         a_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(a_optimizer, T_max=iters, eta_min=0.) \
             if len(a_params) != 0 else None
         loss_func = LossFunction(block, round_loss='relaxation', weight=weight, max_count=iters,
                                  rec_loss='mse' if 'head' not in name else 'kl_div', b_range=b_range, decay_start=0,
                                  warmup=warmup, p=p)
-        ws = parallel.world_size()
-        local_bs = max(1, batch_size // ws)
-        n_local = block.raw_input.size(0)
         gen = torch.Generator().manual_seed(1234 + parallel.rank())
-        for it in range(iters):
-            idx = torch.randperm(n_local, generator=gen)[:local_bs].to(block.raw_input.device)
-            cur_inp = block.raw_input[idx].to(device)
-            cur_out = block.raw_out[idx].to(device)
-            w_optimizer.zero_grad()
+        graph, static_inp, static_out, static_rec, static_rnd = None, None, None, None, None
+        b_dev = rw_dev = None
+        params = w_params + a_params
+
+        def optim_steps():
+            w_optimizer.step()
             if a_optimizer is not None:
-                a_optimizer.zero_grad()
+                a_optimizer.step()
+
+        def eager_step(cur_inp, cur_out):
+            for prm in params:
+                prm.grad = None
             out_quant = block(cur_inp)
             err = loss_func(out_quant, cur_out)
             err.backward()
             if ws > 1:                                   # data-parallel: mean of the per-rank batch-mean gradients
-                for prm in w_params + a_params:
+                for prm in params:
                     if prm.grad is not None:
                         parallel.all_reduce_sum(prm.grad)
                         prm.grad.div_(ws)
-            w_optimizer.step()
-            if a_optimizer is not None:
-                a_optimizer.step()
+            optim_steps()
+            if a_scheduler is not None:
                 a_scheduler.step()
+
+        for it in range(iters):
+            idx = torch.randperm(n_local, generator=gen)[:local_bs].to(block.raw_input.device)
+            if not use_graph or it < 3:                  # eager (and the warm-up iterations before the capture)
+                eager_step(block.raw_input[idx].to(device), block.raw_out[idx].to(device))
+                continue
+            if graph is None:
+                static_inp, static_out = block.raw_input[idx].to(device).clone(), block.raw_out[idx].to(device).clone()
+                b_dev = torch.zeros(1, dtype=torch.float32, device=device)
+                rw_dev = torch.zeros(1, dtype=torch.float32, device=device)
+            else:
+                if block.raw_input.device == static_inp.device:
+                    torch.index_select(block.raw_input, 0, idx, out=static_inp)
+                    torch.index_select(block.raw_out, 0, idx, out=static_out)
+                else:                                        # keep_gpu=False: block data lives on the host
+                    static_inp.copy_(block.raw_input[idx])
+                    static_out.copy_(block.raw_out[idx])
+            active = loss_func.advance()                 # iteration counter, b of this iteration
+            b_dev.fill_(float(loss_func.b))
+            rw_dev.fill_(1.0 if active else 0.0)
+            if graph is None:
+                for prm in params:
+                    prm.grad = None
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_rec = loss_func.rec_term(block(static_inp), static_out)
+                    static_rnd = (loss_func.round_sum(b_dev) * rw_dev).sum()
+                    (static_rec + static_rnd).backward()
+                    if full_graph:
+                        optim_steps()
+            graph.replay()                               # grads are overwritten, not accumulated (none existed at capture)
+            if not full_graph:
+                for prm in params:
+                    if prm.grad is not None:
+                        parallel.all_reduce_sum(prm.grad)
+                        prm.grad.div_(ws)
+                optim_steps()
+            if a_scheduler is not None:
+                a_scheduler.step()
+            loss_func.log(static_rec, static_rnd)
+        graph = None
         for _, module in block.named_modules():
             if hasattr(module, 'w_quantizer'):
                 module.w_quantizer.soft_targets = False
@@ -177,6 +235,7 @@ class LossFunction:
         self.temp_decay = LinearTempDecay(max_count, rel_start_decay=warmup + (1 - warmup) * decay_start,
                                           start_b=b_range[0], end_b=b_range[1])
         self.count = 0
+        self.b = 0
         self.last = (0.0, 0.0, 0.0)
 
     @staticmethod
@@ -185,31 +244,49 @@ class LossFunction:
             return (pred - tgt).abs().pow(p).sum(1).mean()
         return (pred - tgt).abs().pow(p).mean()
 
-    def __call__(self, pred, tgt):
-        self.count += 1
+    def rec_term(self, pred, tgt):
         if self.rec_loss == 'mse':
-            rec_loss = self.lp_loss(pred, tgt, p=self.p) / 10
-        elif self.rec_loss == 'kl_div':
-            rec_loss = F.kl_div(F.log_softmax(pred, dim=-1), F.softmax(tgt, dim=-1).detach(), reduction="batchmean")
-        else:
-            raise ValueError('Not supported reconstruction loss function: {}'.format(self.rec_loss))
-        b = self.temp_decay(self.count)
+            return self.lp_loss(pred, tgt, p=self.p) / 10
+        if self.rec_loss == 'kl_div':
+            return F.kl_div(F.log_softmax(pred, dim=-1), F.softmax(tgt, dim=-1).detach(), reduction="batchmean")
+        raise ValueError('Not supported reconstruction loss function: {}'.format(self.rec_loss))
+
+    def advance(self):
+        """Advances the iteration counter and sets ``b``; returns whether the rounding regulariser is active."""
+        self.count += 1
+        self.b = self.temp_decay(self.count)
         if self.count < self.loss_start or self.round_loss == 'none':
-            b = round_loss = 0
-        elif self.round_loss == 'relaxation':
-            round_loss = 0
-            for _, module in self.block.named_modules():
-                if hasattr(module, 'w_quantizer') and isinstance(module.w_quantizer, AdaRoundQuantizer):
-                    round_loss = round_loss + self.weight * module.w_quantizer.round_loss(b)
-        else:
+            self.b = 0
+            return False
+        if self.round_loss != 'relaxation':
             raise NotImplementedError
-        total_loss = rec_loss + round_loss
+        return True
+
+    def round_sum(self, b):
+        """weight * sum over the block's AdaRound quantisers of sum(1 - |2h-1|^b); b: float or one-element device tensor."""
+        round_loss = 0
+        for _, module in self.block.named_modules():
+            if hasattr(module, 'w_quantizer') and isinstance(module.w_quantizer, AdaRoundQuantizer):
+                round_loss = round_loss + self.weight * module.w_quantizer.round_loss(b)
+        return round_loss
+
+    def round_term(self):
+        """Advances the iteration counter; returns the rounding regulariser of this iteration (0 during the warm-up)."""
+        return self.round_sum(self.b) if self.advance() else 0
+
+    def log(self, rec_loss, round_loss):
         if self.count == 1 or self.count % 500 == 0:
-            self.last = (float(total_loss.detach()), float(rec_loss.detach()),
-                         float(round_loss.detach()) if torch.is_tensor(round_loss) else float(round_loss))
+            rec = float(rec_loss.detach())
+            rnd = float(round_loss.detach()) if torch.is_tensor(round_loss) else float(round_loss)
+            self.last = (rec + rnd, rec, rnd)
             logging.info('Total loss:\t{:.3f} (rec:{:.3f}, round:{:.3f})\tb={:.2f}\tcount={}'.format(
-                self.last[0], self.last[1], self.last[2], b, self.count))
-        return total_loss
+                self.last[0], self.last[1], self.last[2], self.b, self.count))
+
+    def __call__(self, pred, tgt):
+        rec_loss = self.rec_term(pred, tgt)
+        round_loss = self.round_term()
+        self.log(rec_loss, round_loss)
+        return rec_loss + round_loss
 
 
 class LinearTempDecay:

@@ -201,7 +201,8 @@ int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, 
  *   h = clamp(sigmoid(alpha)*1.2 - 0.1, 0, 1) (soft) or [alpha >= 0] (hard)   (reference quantizers/adaround.py:43-60);
  *   backward = 1: out = d loss / d alpha = gy * s * h'(alpha) * [inside clamp].  w/alpha: [rows][inner], scale/zp: [rows].
  * adalog_round_loss: loss[0] = sum (1 - |2h(alpha)-1|^b)  and, if galpha, galpha += gscale * d/d alpha
- *   (reference utils/block_recon.py:205-210).  workspace: 1024 floats. */
+ *   (reference utils/block_recon.py:205-210).  b_dev (optional, device fp32 [1]) overrides b: the exponent is then read
+ *   on the device, so a captured HIP graph of a BRECQ iteration follows the decaying b.  workspace: 1024 floats. */
 int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, int64_t inner);
 int adalog_uniform_fq_backward(const float* gy, const float* x, float* gx, int64_t n, const float* scale,
                                const float* zero_point, int64_t n_channels, int64_t inner, int n_bits, int symmetric,
@@ -211,8 +212,8 @@ int adalog_log_fq_backward(const float* gy, const float* x, const float* y, floa
                            void* stream);
 int adalog_adaround(const float* w, const float* alpha, const float* gy, float* out, int64_t rows, int64_t inner,
                     const float* scale, const float* zero_point, int n_bits, int soft, int backward, void* stream);
-int adalog_round_loss(const float* alpha, int64_t n, float b, float* loss, float* galpha, float gscale, float* workspace,
-                      void* stream);
+int adalog_round_loss(const float* alpha, int64_t n, float b, const float* b_dev, float* loss, float* galpha, float gscale,
+                      float* workspace, void* stream);
 
 #ifdef __cplusplus
 }
