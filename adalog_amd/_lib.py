@@ -27,6 +27,7 @@ SIGNATURES = {
     "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p, i64, p]),
     "adalog_finish_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "adalog_topk": (i32, [p, i32, i32, i32, p, p]),
+    "adalog_topk_next": (i32, [p, i32, i32, i32, p, p, p, i32, p, p, i32, f32, p, p, p, p, p]),
     "adalog_fpcs_next": (i32, [p, p, p, i32, p, i32, i32, p, p, i32, f32, p, p, p, p]),
     "adalog_candidate_grid": (i32, [p, i32, i32, i32, i32, i32, p, i32, f32, p, p, p, p]),
     "adalog_score_w_self": (i32, [p, i32, i32, p, p, i32, i32, p, p]),

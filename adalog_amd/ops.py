@@ -279,6 +279,23 @@ def fpcs_next(scale, zp, third, idx, k: int, new_cnt: int, lin, delta, clamp_min
     return o_s, o_z, o_t
 
 
+def topk_next(scores, scale, zp, third, k: int, new_cnt: int, lin, delta, clamp_min: Optional[float]):
+    """topk(scores, k) followed by fpcs_next(...) in one launch; same return value as fpcs_next."""
+    scores, scale = _f32c(scores, "scores"), _f32c(scale, "scale")
+    P, cols = scores.shape
+    rows = k * new_cnt if new_cnt > 0 else 1
+    mk = lambda src: None if src is None else torch.empty((rows, cols), dtype=torch.float32, device=scale.device)
+    o_s, o_z, o_t = mk(scale), mk(zp), mk(third)
+    rc = _lib.load().adalog_topk_next(scores.data_ptr(), P, cols, int(k), scale.data_ptr(), _ptr(zp), _ptr(third),
+                                     int(new_cnt), _ptr(lin), _ptr(delta), int(clamp_min is not None),
+                                     float(clamp_min if clamp_min is not None else 0.0), o_s.data_ptr(), _ptr(o_z), _ptr(o_t),
+                                     None, _stream())
+    _lib.check(rc, "adalog_topk_next")
+    if new_cnt == 0:
+        return o_s[0], (None if o_z is None else o_z[0]), (None if o_t is None else o_t[0])
+    return o_s, o_z, o_t
+
+
 def candidate_grid(quant4, num_scale: int, num_zp: int, zp_min: int, n_bits: int, lin, clamp_min: Optional[float]):
     quant4 = _f32c(quant4, "quant4")
     cols = quant4.shape[1]

@@ -51,12 +51,11 @@ def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 1
         scores = parallel.all_reduce_sum(score_fn(scale, zp, third))
         last = (remain == 1) and not first
         k = 1 if last else width
-        idx = be.topk(scores, k)
         if last:
-            return be.fpcs_next(scale, zp, third, idx, 1, 0, None, None, None)
+            return be.topk_next(scores, scale, zp, third, 1, 0, None, None, None)
         if remain == 1:          # steps == 1: survivors are selected but never committed (linear.py:490-491)
             return None
-        scale, zp, third = be.fpcs_next(scale, zp, third, idx, k, new_cnt, lin, delta, clamp_min)
+        scale, zp, third = be.topk_next(scores, scale, zp, third, k, new_cnt, lin, delta, clamp_min)
         remain -= 1
         first = False
     return None

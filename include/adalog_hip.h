@@ -134,6 +134,11 @@ int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, i
  *   quant4 = [4][cols] {Q_hi0, Q_hi1, Q_lo0, Q_lo1};  scale[(zi*num_scale+si)][col] = (dmin + lin[si]*(dmax-dmin))/(2L-1),
  *   zp = zp_min + zi, delta[col] = scale[1][col] - scale[0][col]. */
 int adalog_topk(const float* scores, int P, int cols, int k, int* idx, void* stream);
+/* adalog_topk_next = adalog_topk followed by adalog_fpcs_next in one launch (one workgroup per column); idx_out (optional)
+ * receives the top-k indices [k][cols]. */
+int adalog_topk_next(const float* scores, int P, int cols, int k, const float* scale, const float* zp, const float* third,
+                     int new_cnt, const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale,
+                     float* out_zp, float* out_third, int* idx_out, void* stream);
 int adalog_fpcs_next(const float* scale, const float* zp, const float* third, int cols, const int* idx, int k, int new_cnt,
                      const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale, float* out_zp,
                      float* out_third, void* stream);

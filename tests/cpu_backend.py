@@ -175,6 +175,10 @@ def fpcs_next(scale, zp, third, idx, k, new_cnt, lin, delta, clamp_min):
     return ns, rep(tz), rep(tt)
 
 
+def topk_next(scores, scale, zp, third, k, new_cnt, lin, delta, clamp_min):
+    return fpcs_next(scale, zp, third, topk(scores, k), k, new_cnt, lin, delta, clamp_min)
+
+
 def candidate_grid(quant4, num_scale, num_zp, zp_min, n_bits, lin, clamp_min):
     dmin = quant4[0] - quant4[2]
     dmax = quant4[1] - quant4[3]

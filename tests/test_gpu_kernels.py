@@ -614,3 +614,31 @@ def test_sharded_select_matches_fused(ops):
     got = sels[0].values().cpu()
     want = ops.positive_percentile_rows(y.reshape(1, -1).to(DEV), pq).cpu()
     assert torch.equal(got, want)
+
+
+def test_topk_next_matches_two_kernels(ops):
+    """adalog_topk_next (one launch) == adalog_topk + adalog_fpcs_next, for expansion and commit, with ties and NaNs."""
+    gen = g(91)
+    for cols in (1, 7, 1152):
+        P, k, new_cnt = 128, 16, 8
+        scores = torch.randn(P, cols, generator=gen)
+        scores[5] = scores[9]                                    # exact ties
+        if cols > 1:
+            scores[3, 1] = float("nan")
+        scale = torch.rand(P, cols, generator=gen) + 0.1
+        zp = torch.randint(0, 16, (P, cols), generator=gen).float()
+        third = torch.rand(P, cols, generator=gen)
+        lin = torch.linspace(0, 1, new_cnt)
+        delta = torch.rand(cols, generator=gen) * 0.01 + 0.001
+        for clamp in (None, 0.3):
+            d1, d2 = delta.clone().to(DEV), delta.clone().to(DEV)
+            idx = ops.topk(scores.to(DEV), k)
+            a = ops.fpcs_next(scale.to(DEV), zp.to(DEV), third.to(DEV), idx, k, new_cnt, lin.to(DEV), d1, clamp)
+            b = ops.topk_next(scores.to(DEV), scale.to(DEV), zp.to(DEV), third.to(DEV), k, new_cnt, lin.to(DEV), d2, clamp)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+            assert torch.equal(d1, d2)
+        idx1 = ops.topk(scores.to(DEV), 1)
+        a = ops.fpcs_next(scale.to(DEV), zp.to(DEV), None, idx1, 1, 0, None, None, None)
+        b = ops.topk_next(scores.to(DEV), scale.to(DEV), zp.to(DEV), None, 1, 0, None, None, None)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] is None and b[2] is None
