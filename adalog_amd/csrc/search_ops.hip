@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_score_a_self(const float* __restrict__ 
                                                       const float* __restrict__ scale, const float* __restrict__ zp,
                                                       int P, int pstride_ch, float qmax, float* __restrict__ partial,
                                                       int n_slab, int Cpad) {
-    __shared__ float red[4][64];
+    __shared__ float red[2][4][64];              // double-buffered by candidate parity: one barrier per candidate
     const int chl = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int ch = blockIdx.x * 64 + chl;
     const int slab = blockIdx.y;
@@ -199,25 +199,36 @@ __global__ __launch_bounds__(256) void k_score_a_self(const float* __restrict__ 
     }
     const int cols = pstride_ch ? I : 1;
     const bool slab_full = cv && (r0 + 4 * (SLAB_ROWS_PER_THREAD - 1) < rows);
+    const int64_t pcol = pstride_ch ? (cv ? ch : 0) : 0;
+    float s_n = scale[pcol], z_n = zp[pcol];     // the next candidate's parameters are fetched under the current one's math
     for (int p = 0; p < P; ++p) {
-        const int64_t pi = (int64_t)p * cols + (pstride_ch ? (cv ? ch : 0) : 0);
-        const float s = scale[pi], z = zp[pi];
+        const float s = s_n, z = z_n;
+        if (p + 1 < P) { s_n = scale[(int64_t)(p + 1) * cols + pcol]; z_n = zp[(int64_t)(p + 1) * cols + pcol]; }
         float acc = 0.0f;
-        if (slab_full) {
-            // reciprocal fast path; inside the tie zone (|frac - 0.5| < 1e-3) the exact IEEE quotient decides, so the bin
+        if (slab_full && rintf(z) == z) {
+            // reciprocal fast path; inside the tie zone (|frac - 0.5| < 1e-4) the exact IEEE quotient decides, so the bin
             // is the one rintf(v / s) gives.  clamp(k + z, 0, qmax) - z == med3(k, -z, qmax - z) for integral z.
+            // Two rows per step on packed fp32 math (v_pk_mul / v_pk_add; no contraction in this file): 6 VALU per
+            // element-candidate instead of 9.
+            typedef float v2f __attribute__((ext_vector_type(2)));
             const float inv_s = __builtin_amdgcn_rcpf(s), lo = -z, hi = qmax - z;
-            const bool zint = rintf(z) == z;
+            const v2f inv2 = {inv_s, inv_s}, s2 = {s, s};
+            v2f acc2 = {0.0f, 0.0f};
 #pragma unroll
-            for (int r = 0; r < SLAB_ROWS_PER_THREAD; ++r) {
-                const float v = xv[r];
-                const float t = v * inv_s;
-                float k = rintf(t);
-                if (__builtin_expect(fabsf(t - k) > 0.4999f, 0)) k = rintf(v / s);
-                const float kq = zint ? __builtin_amdgcn_fmed3f(k, lo, hi) : fminf(fmaxf(k + z, 0.0f), qmax) - z;
-                const float e = v - kq * s;
-                acc += e * e;
+            for (int r = 0; r < SLAB_ROWS_PER_THREAD; r += 2) {
+                const v2f v = {xv[r], xv[r + 1]};
+                const v2f t = v * inv2;
+                v2f k = {rintf(t.x), rintf(t.y)};
+                const v2f d = t - k;
+                if (__builtin_expect(fmaxf(fabsf(d.x), fabsf(d.y)) > 0.4999f, 0)) {      // one branch per pair
+                    k.x = rintf(v.x / s);
+                    k.y = rintf(v.y / s);
+                }
+                const v2f kq = {__builtin_amdgcn_fmed3f(k.x, lo, hi), __builtin_amdgcn_fmed3f(k.y, lo, hi)};
+                const v2f e = v - kq * s2;
+                acc2 += e * e;
             }
+            acc = acc2.x + acc2.y;
         } else {
 #pragma unroll
             for (int r = 0; r < SLAB_ROWS_PER_THREAD; ++r) {
@@ -227,11 +238,11 @@ __global__ __launch_bounds__(256) void k_score_a_self(const float* __restrict__ 
                 acc += (v == v) ? e * e : 0.0f;
             }
         }
-        red[rg][chl] = acc;
-        __syncthreads();
+        float (*rb)[64] = red[p & 1];
+        rb[rg][chl] = acc;
+        __syncthreads();                          // the buffer of candidate p - 1 is free again after this barrier
         if (rg == 0 && cv)
-            partial[((int64_t)p * n_slab + slab) * Cpad + ch] = (red[0][chl] + red[1][chl]) + (red[2][chl] + red[3][chl]);
-        __syncthreads();
+            partial[((int64_t)p * n_slab + slab) * Cpad + ch] = (rb[0][chl] + rb[1][chl]) + (rb[2][chl] + rb[3][chl]);
     }
 }
 
