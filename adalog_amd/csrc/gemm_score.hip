@@ -1302,7 +1302,8 @@ struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff, stream, acc, wgs;
 // L2 -> LDS path bounds the main loop and the un-overlapped epilogue is < 10 % of a tile.
 static int pick_wide(int M, int64_t kvalid_bytes) {
     static const int use_wide = getenv("ADALOG_GEMM_WIDE") ? atoi(getenv("ADALOG_GEMM_WIDE")) : 1;
-    if (!use_wide || kvalid_bytes < 1024 || M < 192) return 0;
+    static const int min_k = getenv("ADALOG_GEMM_WIDE_MINK") ? atoi(getenv("ADALOG_GEMM_WIDE_MINK")) : 1024;
+    if (!use_wide || kvalid_bytes < min_k || M < 192) return 0;
     const int64_t pad4 = (int64_t)cdiv(M, 256) * 256, pad3 = (int64_t)cdiv(M, 192) * 192, pad2 = (int64_t)cdiv(M, 128) * 128;
     const int ri = pad4 <= pad3 + pad3 / 32 ? 4 : 3;                      // 256 rows unless 192 pads > 3 % less
     const int64_t padw = ri == 4 ? pad4 : pad3;

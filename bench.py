@@ -9,7 +9,7 @@ BASELINE.json configs[1]: deit_small, W4A4 (configs/4bit.py), 32 synthetic 224x2
 (weak scaling: the global calibration set is 32*N images sharded by rank, scores all-reduced over RCCL).
 Inputs (images, random-init weights) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
   value      = calibration images per second, whole job  (= 32*N*K / wall, wall = max over ranks)
-  roofline   = the dominant kernel (k_gemm_score, int8 MFMA): algorithmic ops of its launches / their summed duration,
+  roofline   = the dominant kernel (k_gemm_stream, int8 MFMA): algorithmic ops of its launches / their summed duration,
                measured live with events on the launch stream during the timed steps
   cpu_baseline = the CPU oracle (a port of the reference's algorithm, oracle/) timed on the host cores on a bounded
                sample of the same workload and scaled to images/s with the work model of BASELINE.md section 2
@@ -108,9 +108,24 @@ def cpu_baseline(threads):
     xq = O.uniform_fake_quant(x, sca[:, 60], zpa[:, 60].float(), bits)[0]
     wq = O.uniform_fake_quant(w3, scw[60], zpw[60].float(), bits)[0].view(Oc, I)
     t0 = time.perf_counter()
-    O.score_w(xq, w3, b, ro, scw, zpw, bits, 32)
-    O.score_a(x, wq, b, ro, sca, zpa, bits, 32)
+    ref_w = O.score_w(xq, w3, b, ro, scw, zpw, bits, 32)
+    ref_a = O.score_a(x, wq, b, ro, sca, zpa, bits, 32)
     dt = time.perf_counter() - t0
+    # the oracle as the CHECKER at full layer size: the same two scoring calls through the product path (HIP kernels)
+    from adalog_amd import quant_layers as Q
+    dev = torch.device("cuda")
+    lay = Q.AsymmetricallyBatchingQuantLinear(I, Oc, True, "raw", bits, bits, calib_batch_size=32, search_round=1, eq_n=128,
+                                              n_V=1, fpcs=True, steps=6).to(dev)
+    lay.weight.data.copy_(W); lay.bias.data.copy_(b)
+    lay.raw_input, lay.raw_out = x.to(dev), ro.to(dev)
+    lay.a_quantizer.scale.data.copy_(sca[:, 60].view(-1)); lay.a_quantizer.zero_point.data.copy_(zpa[:, 60].float().view(-1))
+    lay.w_quantizer.scale.data.copy_(scw[60]); lay.w_quantizer.zero_point.data.copy_(zpw[60].float())
+    got_w = lay._score_w(lay._pack_x_fixed(), scw.reshape(128, -1).to(dev), zpw.reshape(128, -1).float().to(dev)).cpu()
+    got_a = lay._score_a(lay._pack_w_fixed(), sca.t().contiguous().to(dev), zpa.t().contiguous().float().to(dev)).cpu()
+    rw, ra = ref_w.reshape(128, -1), ref_a.reshape(-1, 128).t()
+    err_w = float(((got_w - rw).abs() / rw.abs()).max())
+    err_a = float(((got_a - ra).abs() / ra.abs()).max())
+    same_top = bool(torch.equal(torch.topk(got_a[:, 0], 16).indices.sort().values, torch.topk(ra[:, 0], 16).indices.sort().values))
     flops = 2 * 2.0 * N * T * I * Oc * 128
     rate = flops / dt                                   # candidate-GEMM flop/s of the CPU path
     total = 1354e12                                     # deit_small, 32 images
@@ -118,7 +133,10 @@ def cpu_baseline(threads):
             "sample": f"oracle score_w + score_a, 128 candidates each, deit_small attn.proj 32x197x384->384 W4A4: "
                       f"{dt:.1f} s = {rate / 1e9:.1f} GFLOP/s candidate-GEMM rate; scaled by 1354 TFLOP per 32-image "
                       f"calibration",
-            "sample_seconds": dt}
+            "sample_seconds": dt,
+            "parity_vs_hip": {"max_rel_err_weight_scores": err_w, "max_rel_err_activation_scores": err_a,
+                              "same_top16_activation_candidates": same_top,
+                              "note": "same inputs and candidates through adalog_amd (HIP) at full layer size; bar 1e-3"}}
 
 
 def main():
