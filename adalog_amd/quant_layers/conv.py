@@ -176,6 +176,7 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
     def hyperparameter_searching(self):
         """conv.py:313-334 for the shipped configuration (qconv_a_bit = 8: the input is not quantised and the loop
         breaks after the first weight FPCS, conv.py:328-331)."""
+        search.forget_grids()                     # percentile grids are memoised per search call only
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         if self.a_quantizer.n_bits < 8:
@@ -188,5 +189,6 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
         self.w_quantizer.inited = True
         self.weight_fpcs(steps=self.steps)
         self.calibrated = True
+        search.forget_grids()
         del self.raw_input, self.raw_out
         return None

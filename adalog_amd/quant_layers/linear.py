@@ -295,6 +295,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
 
     def hyperparameter_searching(self):
         """linear.py:525-545 with fpcs=True (the only mode the shipped configs use, configs/*.py:20)."""
+        search.forget_grids()                     # percentile grids are memoised per search call only
         if not self.fpcs:
             raise NotImplementedError("non-FPCS single-pass search is not part of the accelerated path (configs use fpcs=True)")
         self._initialize_calib_parameters()
@@ -304,6 +305,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             self.weight_fpcs(steps=self.steps, search_strategy="output")
             self.activation_fpcs(steps=self.steps, search_strategy="output")
         self.calibrated = True
+        search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
         return None
@@ -357,6 +359,7 @@ class AsymmetricallyChannelWiseBatchingQuantLinear(AsymmetricallyBatchingQuantLi
 
     def hyperparameter_searching(self):
         """linear.py:585-594: per-channel activation FPCS against the activation's own MSE."""
+        search.forget_grids()                     # percentile grids are memoised per search call only
         assert self.a_quantizer.channel_wise and self.w_quantizer.channel_wise
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
@@ -427,6 +430,10 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
 
     # ---- percentile candidates (linear.py:763-814)
     def calculate_percentile_activation_candidates(self, l=0.9, r=1.0):
+        return search.memo_tensor_fn("pp", self.raw_input, (l, r, self.eq_n),
+                                     lambda: self._percentile_activation_candidates(l, r))
+
+    def _percentile_activation_candidates(self, l=0.9, r=1.0):
         from .. import parallel
         be = backend.get()
         qs = torch.tensor([l, r]).tolist()
@@ -510,6 +517,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
 
     def hyperparameter_searching(self):
         """linear.py:969-997 with fpcs=True."""
+        search.forget_grids()                     # percentile grids are memoised per search call only
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         self._initialize_calib_parameters()
@@ -522,6 +530,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
             self.activation_fpcs(ud_candidates=ud_candidates, steps=self.steps)
             self.weight_fpcs(steps=self.steps, search_strategy="output")
         self.calibrated = True
+        search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
 

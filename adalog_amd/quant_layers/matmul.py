@@ -229,6 +229,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
 
     def hyperparameter_searching(self):
         """matmul.py:264-283 with fpcs=True."""
+        search.forget_grids()                     # percentile grids are memoised per search call only
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         self._initialize_calib_parameters()
@@ -242,6 +243,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
             self._fpcs("A", steps=self.steps, dt=dt)
             self._fpcs("B", steps=self.steps, dt=dt)
         self.calibrated = True
+        search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
         self._bt_c = self._bt_key = None
@@ -332,6 +334,7 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
 
     def hyperparameter_searching(self):
         """matmul.py:360-378."""
+        search.forget_grids()                     # percentile grids are memoised per search call only
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         self._initialize_calib_parameters()
@@ -346,6 +349,7 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
             self._fpcs("B", steps=self.steps, fixed=ap, dt=BF16, fixed_sa=Strided(self.A_quantizer.scale.data.view(-1)),
                        sa_mul=self._ts32())
         self.calibrated = True
+        search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
         self._bt_c = self._bt_key = None

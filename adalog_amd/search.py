@@ -117,8 +117,40 @@ def _flat_layout(local_numel: int, rows: int = 1):
     return None
 
 
+_GRID_MEMO = {}
+
+
+def _memo(kind, x, extra, make):
+    """The percentile grid depends only on the tensor it is computed from, and every search round asks for it again
+    (1 + search_round times per operand).  Keyed by storage pointer + in-place version + shape: a re-parameterised
+    weight or a new raw_input gives a new key.  ``delta`` is handed out as a copy (the FPCS driver narrows it in place).
+    Entries die with their tensor's search (forget_grids)."""
+    key = (kind, x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride())) + tuple(extra)
+    hit = _GRID_MEMO.get(key)
+    if hit is None:
+        hit = _GRID_MEMO[key] = make()
+    return hit[0], hit[1], hit[2].clone()
+
+
+def memo_tensor_fn(kind, x, extra, make):
+    """Same memo for other pure functions of a captured tensor (post-GELU positive percentiles); result returned as is."""
+    key = (kind, x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride())) + tuple(extra)
+    if key not in _GRID_MEMO:
+        _GRID_MEMO[key] = make()
+    return _GRID_MEMO[key]
+
+
+def forget_grids():
+    """Drop the memoised grids (called when a module's search ends and its captures are released)."""
+    _GRID_MEMO.clear()
+
+
 def weight_grid(w2, n_bits: int, eq_n: int, conv: bool = False):
     """linear.py:432-451 / conv.py:271-290 -> (scale [P, rows], zp [P, rows], delta [rows])."""
+    return _memo("w", w2, (n_bits, eq_n, conv), lambda: _weight_grid(w2, n_bits, eq_n, conv))
+
+
+def _weight_grid(w2, n_bits: int, eq_n: int, conv: bool = False):
     be = backend.get()
     L = 2 ** (n_bits - 1)
     num_zp = L if conv else min(16, L)
@@ -128,6 +160,10 @@ def weight_grid(w2, n_bits: int, eq_n: int, conv: bool = False):
 
 
 def activation_grid(x, n_bits: int, eq_n: int, channel_wise: bool):
+    return _memo("a", x, (n_bits, eq_n, channel_wise), lambda: _activation_grid(x, n_bits, eq_n, channel_wise))
+
+
+def _activation_grid(x, n_bits: int, eq_n: int, channel_wise: bool):
     """linear.py:453-481 -> (scale [P, C], zp [P, C], delta [C]), C = in_features or 1.  ``x`` is the rank-local shard;
     quantiles are global order statistics: with several ranks they come from a distributed radix select (histograms
     all-reduced, data stays put)."""
@@ -155,6 +191,10 @@ def activation_grid(x, n_bits: int, eq_n: int, channel_wise: bool):
 
 
 def matmul_grid(x, n_bits_B: int, eq_n: int, head_wise: bool = True):
+    return _memo("m", x, (n_bits_B, eq_n, head_wise), lambda: _matmul_grid(x, n_bits_B, eq_n, head_wise))
+
+
+def _matmul_grid(x, n_bits_B: int, eq_n: int, head_wise: bool = True):
     """matmul.py:211-240 -> (scale [P, H], zp [P, H], delta [H]); both operands use B's level count."""
     be = backend.get()
     L = 2 ** (n_bits_B - 1)
