@@ -96,12 +96,8 @@ def test_linear_scores_on_reference_candidates(golden, bits):
     s = lay._score_w(lay._pack_x_fixed(), sc, zp).cpu()
     ref = t(g["trace_012_scores"]).reshape(128, -1)
     assert ((s - ref).abs() / ref.abs()).max().item() <= 1e-4
-    # activation search of round 0 uses the weights committed by trace call 17
-    tr = O.Trace()
-    p1 = O.search_linear(W, b, x, ro, wb, ab, n_V=n_V, batch=cbs, rounds=1, trace=tr)
-    wsel = torch.gather(t(g["cand_w_scale"]), 0, torch.zeros(1, dtype=torch.long).view(1, 1, 1, 1).expand(1, n_V, Oc // n_V, 1))
-    del wsel
-    # recover the weights in force during call 18 by replaying only the weight FPCS of round 0
+    # activation search of round 0 uses the weights committed by trace call 17: recover the weights in force during
+    # call 18 by replaying only the weight FPCS of round 0
     xq = O.uniform_fake_quant(x, p.a_scale, p.a_zp, ab)[0]
     w3 = W.view(n_V, Oc // n_V, I)
     scw, zpw = O.weight_candidates(w3, wb)
