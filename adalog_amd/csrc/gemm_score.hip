@@ -57,6 +57,7 @@ struct GemmArgs {
     double* wg_acc;                  // streaming kernel: per-workgroup fp64 column sums [workgroup][gmod][256] instead of
                                      // per-tile partials (searches that do not keep the column axis)
     int gm;                          // streaming kernel, order 2: m-tiles per L2 group (rows of A kept hot while n advances)
+    int slab_U, slab_R;              // slab kernel: 32-row units per slab, units per workgroup (NT = slabs, MT = pieces)
     long long* timeline;             // profiling only (tools/gemm_lab.hip): 8 cycle stamps per workgroup, else nullptr
 };
 #if defined(GEMM_LAB_TIMELINE)   // tools/lab only: the stamp stores would otherwise cost waits in the production kernel
@@ -65,6 +66,7 @@ struct GemmArgs {
 #define TL_STAMP(i) do { } while (0)
 #endif
 static long long* g_timeline = nullptr;   // set only by the lab harness, which includes this file
+static int g_slab_override = -1;          // lab harness: force the slab kernel off (0) / on (1) per call
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * BKB + ((slot ^ ((row >> 2) & 3)) << 4); }
 
@@ -751,6 +753,7 @@ constexpr int BK3 = 64;
 #else
 #define STREAM_DMA(rsrc, dst, voff, soff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (las_ptr)(dst), 16, voff, soff, 0, 0)
 #endif
+#define STREAM_DMA4(rsrc, dst, voff) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (las_ptr)(dst), 4, (int)(voff), 0, 0, 0)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int swz3(int row, int slot) { return row * BK3 + ((slot ^ ((row >> 2) & 3)) << 4); }
@@ -764,6 +767,7 @@ template <int DT> __device__ __forceinline__ typename Acc<DT>::type mma0(const u
 }
 
 struct StreamTile { int mt, nt, g; };
+__device__ __forceinline__ float4 lds_f4(const float* __restrict__ base, int off) { return *reinterpret_cast<const float4*>(base + off); }
 
 // Fragment read through a __restrict__ stage pointer: the load carries alias-scope metadata, which keeps the compiler's
 // waitcnt pass from ordering it behind the (untagged) in-flight LDS-DMA with a vmcnt(0); the hand-written counted vmcnt
@@ -1117,6 +1121,262 @@ __global__ __launch_bounds__(64 * NW, NS == 3 ? (NW == 8 ? 4 : 2) : 1) void k_ge
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ slab kernel
+// Fourth form, for int8 searches with short K (a 256-column slab of the candidate operand, all of K, fits in 96 KiB):
+//   * the workgroup (8 waves, one per CU) keeps 256 candidate COLUMNS resident in LDS and streams the other operand
+//     (the fixed one: <= 3 MiB, so it stays in every XCD's L2) past them in units of 32 rows;
+//   * each wave streams its OWN units through a private 3-stage LDS-DMA ring: the main loop has no workgroup barrier,
+//     the waves drift apart and one wave's epilogue (VALU) runs under its SIMD partner's MFMAs;
+//   * a lane owns 8 candidate columns (one per 32-column block) and keeps their squared-error sums in registers across
+//     all the units it sees, so nothing is staged or reduced per unit: per slab the 8 waves combine once through LDS;
+//   * the candidate operand is read from HBM exactly once, and the L2 -> LDS path carries 32 x K bytes per
+//     32 x 256 outputs instead of (128 + 256) x K per 128 x 256.
+// Work split: the (slab, unit) list is cut into equal contiguous ranges, one per workgroup; a slab cut by a range
+// boundary gets one partial row per piece (MT = pieces), or, with wg_acc, everything a workgroup sees goes into its
+// fp64 column sums.  Measured on the deit_small shapes (tools/lab): 1.8-2.0 PFLOP/s against 1.35 for k_gemm_stream.
+template <int NREF, bool ROWS>
+__global__ __launch_bounds__(512, 2) void k_gemm_slab(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NSL = 3, UST = 32 * BK3, PW = 192;       // ring stages, bytes per stage, floats of per-wave operands
+    constexpr int NP = 1 + (NREF == 4 ? 1 : 0) + (ROWS ? 1 : 0);   // operand requests per unit
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fkg = lane >> 5;
+    const int nk = (int)((p.Kvb + BK3 - 1) / BK3), Kb = (int)p.Kb;
+    uint8_t* slab = lds;                                                   // [nk][256 columns][64 bytes]
+    uint8_t* ringw = lds + nk * BN2 * BK3 + w * (NSL * UST);               // this wave's ring
+    uint8_t* tail = lds + nk * BN2 * BK3 + 8 * NSL * UST;
+    float* parw = reinterpret_cast<float*>(tail) + w * PW;                 // [NREF <= 4][32] reference, [32] row scale, [32] row bias
+    float* red = reinterpret_cast<float*>(tail + 8 * PW * 4);              // [8 waves][256 columns]
+
+    const int rsh = __ffs(p.ref_div) - 1, rmask = p.ref_div - 1;
+    const int n_eff = p.N >> rsh;
+    const int U = p.slab_U, R = p.slab_R;
+    const int u0 = (int)blockIdx.x * R, u1 = min(u0 + R, p.NT * U);
+    if (u0 >= u1) return;
+    const int s_first = u0 / U, s_last = (u1 - 1) / U;
+    const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    const int vo0 = lrow * Kb + lslot16, vo1 = (16 + lrow) * Kb + lslot16;
+
+    // ---- this wave's units: in every slab segment [a, b) of the range it takes a + w, a + w + 8, ...
+    auto seg_end = [&](int s) { return min(U, u1 - s * U); };
+    auto first_from = [&](int s, int& os, int& orr) {
+        for (; s <= s_last; ++s) {
+            const int a = (s == s_first ? u0 - s_first * U : 0) + w;
+            if (a < seg_end(s)) { os = s; orr = a; return true; }
+        }
+        return false;
+    };
+    auto next_unit = [&](int& s, int& r) {
+        if (r + 8 < seg_end(s)) { r += 8; return true; }
+        return first_from(s + 1, s, r);
+    };
+
+    // ---- issue cursor: two K-steps ahead of the compute cursor, across units and slabs (the stream does not depend on
+    // the slab).  Rows past M do not occur (M % 32 == 0 is a launch condition).
+    __amdgpu_buffer_rsrc_t ra;
+    int i_s = 0, i_r = 0, i_k = 0, i_slot = 0;
+    bool i_more = first_from(s_first, i_s, i_r);
+    auto issue_unit = [&]() {
+        ra = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)i_r * 32 * Kb), 0, 0x7ffffffe, 0x00020000);
+    };
+    auto issue_step = [&]() {
+        uint8_t* st = ringw + i_slot * UST;
+        STREAM_DMA(ra, st, vo0, i_k * BK3);
+        STREAM_DMA(ra, st + 1024, vo1, i_k * BK3);
+        i_slot = i_slot == NSL - 1 ? 0 : i_slot + 1;
+        if (++i_k == nk) {
+            i_k = 0;
+            if (i_more) { i_more = next_unit(i_s, i_r); if (i_more) issue_unit(); }   // past the last unit: harmless re-fetch
+        }
+    };
+    // per-unit epilogue operands: reference slice [NREF][32 rows] (+ row scale | row bias), NP requests
+    const uint32_t ref_bytes = (uint32_t)(((int64_t)(n_eff - 1) * p.ref_cs + p.M) * 4);
+    const __amdgpu_buffer_rsrc_t rref = __builtin_amdgcn_make_buffer_rsrc((void*)p.ref, 0, (int)ref_bytes, 0x00020000);
+    auto issue_params = [&](int s, int r) {
+        const int m0 = r * 32, nj = s * NREF + fkg;
+        const uint32_t oob = 0xfffffff0u;
+        STREAM_DMA4(rref, parw, nj < n_eff ? (uint32_t)((nj * (int)p.ref_cs + m0 + frow) * 4) : oob);
+        if (NREF == 4) STREAM_DMA4(rref, parw + 64, nj + 2 < n_eff ? (uint32_t)(((nj + 2) * (int)p.ref_cs + m0 + frow) * 4) : oob);
+        if (ROWS) __builtin_amdgcn_global_load_lds((gas_ptr)((fkg ? p.row_bias : p.row_scale) + m0 + frow), (las_ptr)(parw + 128), 4, 0, 0);
+    };
+
+    if (i_more) {
+        issue_unit();
+        const int s0 = i_s, r0 = i_r;
+        issue_step(); issue_step();
+        issue_params(s0, r0);
+    }
+
+    int c_s = 0, c_r = 0;
+    bool c_more = first_from(s_first, c_s, c_r);
+    int st = 0;
+    v16i acc[8];
+    v2f cs2[8];                                            // running squared-error sums of this lane's 8 columns
+#pragma unroll
+    for (int b = 0; b < 8; ++b) cs2[b] = (v2f){0.0f, 0.0f};
+    const bool bcols = p.bias && p.bi_c != 0;
+    bool parked = false;
+
+    for (int s = s_first; s <= s_last; ++s) {
+        // ---- switch to slab s (workgroup-uniform): everyone is done with the old slab and with `red`
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int col_s = s * BN2;
+        {
+            const int64_t left = (int64_t)(p.N - col_s) * Kb;              // columns past N read as zero
+            __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)col_s * Kb), 0, (int)min(left, (int64_t)0x7ffffffe), 0x00020000);
+            const int nreq = nk * 16;                                      // 16 columns x 64 bytes each
+            for (int q = w; q < nreq; q += 8) {
+                const int kt = q >> 4, c16 = q & 15;
+                STREAM_DMA(rb, slab + kt * BN2 * BK3 + c16 * 1024, (c16 * 16 + lrow) * Kb + lslot16, kt * BK3);
+            }
+        }
+        if (p.wg_acc && col_s + BN2 > p.N) {
+            // partial last slab under per-workgroup accumulation: its padding columns must not count, so the running
+            // sums are parked in `red` (unused in this mode) and this slab is summed on its own
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                float v = cs2[b].x + cs2[b].y;
+                v += __shfl_xor(v, 32);
+                if (fkg == 0) red[w * BN2 + b * 32 + frow] = v;
+                cs2[b] = (v2f){0.0f, 0.0f};
+            }
+            parked = true;
+        }
+        float nal[8], bn[NREF];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int col = col_s + b * 32 + frow;
+            const bool ok = col < p.N;
+            const int colc = ok ? col : p.N - 1, ci = colc & rmask, ni = colc >> rsh;
+            const float e_sa = p.sa[ci * p.sa_c], e_sb = p.sb[ci * p.sb_c + ni * p.sb_n];
+            nal[b] = ok ? -(e_sa * p.sa_mul * e_sb) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < NREF; ++j) {
+            const int nj = min(s * NREF + j, n_eff - 1);
+            bn[j] = (p.bias && !bcols) ? p.bias[nj * p.bi_n] : 0.0f;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        while (c_more && c_s == s) {
+            for (int kt = 0; kt < nk; ++kt) {
+                // may stay outstanding behind this step's two requests: the next step's two and, in a unit's first two
+                // steps, its NP operand requests (stores are not counted: stricter if one is still in flight)
+                if (kt < 2) {
+                    if (NP == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else if (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                const uint8_t* cur = ringw + st * UST;
+                const uint8_t* Bs = slab + kt * BN2 * BK3;
+                const uint4 a0 = lds_frag(cur, swz3(frow, fkg)), a1 = lds_frag(cur, swz3(frow, 2 + fkg));
+                uint4 b0n = lds_frag(Bs, swz3(frow, fkg)), b1n = lds_frag(Bs, swz3(frow, 2 + fkg));
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const uint4 b0 = b0n, b1 = b1n;
+                    if (b + 1 < 8) { b0n = lds_frag(Bs, swz3((b + 1) * 32 + frow, fkg)); b1n = lds_frag(Bs, swz3((b + 1) * 32 + frow, 2 + fkg)); }
+                    if (kt == 0) acc[b] = mma0<0>(a0, b0); else mma<0>(a0, b0, acc[b]);
+                    mma<0>(a1, b1, acc[b]);
+                    if (b == 3) issue_step();
+                }
+                st = st == NSL - 1 ? 0 : st + 1;
+            }
+            // ---- epilogue: lane column = block b, lane & 31; rows 8*q4 + 4*fkg + e of the unit
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // all but the two run-ahead steps have landed
+            // (a per-column bias is rare -- no int8 search of the calibrator has one -- so its values are re-read per
+            // unit instead of living in eight more registers)
+#define SLAB_EPILOGUE(BCOLS_)                                                                                   \
+            float bco[BCOLS_ ? 8 : 1];                                                                          \
+            if (BCOLS_) {                                                                                       \
+                _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                                 \
+                    const int colc = min(col_s + b * 32 + frow, p.N - 1);                                       \
+                    bco[b] = p.bias[(colc & rmask) * p.bi_c + (colc >> rsh) * p.bi_n];                          \
+                }                                                                                               \
+            }                                                                                                   \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                  \
+                const int ro = 8 * q4 + 4 * fkg;                                                                \
+                v2f sA = {1.f, 1.f}, sB = {1.f, 1.f};                                                           \
+                float4 rb4 = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
+                if (ROWS) { const float4 s4 = lds_f4(parw, 128 + ro); sA = (v2f){s4.x, s4.y}; sB = (v2f){s4.z, s4.w}; rb4 = lds_f4(parw, 160 + ro); } \
+                v2f rA[NREF], rB[NREF];                                                                         \
+                _Pragma("unroll") for (int j = 0; j < NREF; ++j) {                                              \
+                    const float4 r4 = lds_f4(parw, j * 32 + ro);                                                \
+                    rA[j] = (v2f){r4.x - rb4.x - bn[j], r4.y - rb4.y - bn[j]};                                  \
+                    rB[j] = (v2f){r4.z - rb4.z - bn[j], r4.w - rb4.w - bn[j]};                                  \
+                }                                                                                               \
+                _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                                 \
+                    const int j = (b * NREF) >> 3;                                                              \
+                    v2f tA = {(float)acc[b][q4 * 4 + 0], (float)acc[b][q4 * 4 + 1]};                            \
+                    v2f tB = {(float)acc[b][q4 * 4 + 2], (float)acc[b][q4 * 4 + 3]};                            \
+                    const v2f na = {nal[b], nal[b]};                                                            \
+                    if (ROWS) { tA *= sA; tB *= sB; }                                                           \
+                    v2f dA = tA * na + rA[j], dB = tB * na + rB[j];                                             \
+                    if (BCOLS_) { const v2f b2 = {bco[b], bco[b]}; dA -= b2; dB -= b2; }                        \
+                    cs2[b] += dA * dA; cs2[b] += dB * dB;                                                       \
+                }                                                                                               \
+            }
+#if defined(GEMM_LAB_NO_EPI)   // tools/lab: time the main loop alone
+            _Pragma("unroll") for (int b = 0; b < 8; ++b) cs2[b] += (v2f){(float)acc[b][0], (float)acc[b][15]};
+#else
+            if (bcols) { SLAB_EPILOGUE(true) } else { SLAB_EPILOGUE(false) }
+#endif
+#undef SLAB_EPILOGUE
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // parw fully read before the next unit's operands land
+            c_more = next_unit(c_s, c_r);
+            if (c_more) issue_params(c_s, c_r);
+        }
+
+        // ---- end of this workgroup's share of slab s
+        // columns past N (last slab only): operand and reference read as zero, but a folded bias does not -- mask them
+        if (p.wg_acc) {
+            if (col_s + BN2 > p.N) {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) if (col_s + b * 32 + frow >= p.N) cs2[b] = (v2f){0.0f, 0.0f};
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                float cs = (col_s + b * 32 + frow < p.N) ? cs2[b].x + cs2[b].y : 0.0f;
+                cs += __shfl_xor(cs, 32);
+                if (fkg == 0) red[w * BN2 + b * 32 + frow] = cs;
+                cs2[b] = (v2f){0.0f, 0.0f};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid < BN2) {
+                float v = 0.0f;
+#pragma unroll
+                for (int ww = 0; ww < 8; ++ww) v += red[ww * BN2 + tid];
+                const int col = col_s + tid;
+                const int piece = (int)blockIdx.x - (s * U) / R;           // 0 for the workgroup that holds the slab's first unit
+                if (col < p.N) p.partial[(((int64_t)piece) * p.Npad + (col >> rsh)) * p.ref_div + (col & rmask)] = v;
+            }
+        }
+    }
+    if (p.wg_acc) {
+        // column sums of everything this workgroup saw (fp32 per lane: <= a few thousand terms; fp64 from here on):
+        // lanes pair up, then a fixed wave order through LDS
+        double* redd = reinterpret_cast<double*>(slab);                    // the slab is dead now
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            double v = (double)cs2[b].x + (double)cs2[b].y;
+            v += __shfl_xor(v, 32);
+            if (fkg == 0) redd[w * BN2 + b * 32 + frow] = v + (parked ? (double)red[w * BN2 + b * 32 + frow] : 0.0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (tid < BN2) {
+            double v = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) v += redd[ww * BN2 + tid];
+            for (int h = 0; h < p.gmod; ++h) p.wg_acc[((int64_t)blockIdx.x * p.gmod + h) * BN2 + tid] = h == 0 ? v : 0.0;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ finish
 // scores[c][h?][n?] = -norm * sum over (image = g / gmod, [h], m-tile, [n]) of partial[c][g][mt][n]   in fp64,
 // fixed summation order: each thread takes a strided subset, then a fixed LDS tree.
@@ -1296,7 +1556,7 @@ static int pick_tm(int M, bool scoring) {
     return 1;
 }
 
-struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff, stream, acc, wgs; int64_t elems; };
+struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff, stream, acc, wgs, slab, slab_U, slab_R; int64_t elems; };
 
 // Wide (one workgroup per CU, 192/256-row tile) form of the streaming kernel: long K only -- 16+ K-steps, where the
 // L2 -> LDS path bounds the main loop and the un-overlapped epilogue is < 10 % of a tile.
@@ -1313,7 +1573,7 @@ static int pick_wide(int M, int64_t kvalid_bytes) {
 // reduce_cols with ref_div > 1 asks for per-workgroup accumulation, which only the streaming kernel provides: when that
 // kernel is not eligible the launch falls back to per-tile partials (candidate innermost), and the layout says so.
 static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, bool scoring = true,
-                        int64_t kvalid_bytes = 0, int64_t kb = 0, bool ref_transposed = false) {
+                        int64_t kvalid_bytes = 0, int64_t kb = 0, bool ref_transposed = false, int dtype = -1) {
     static const int use_stream = getenv("ADALOG_GEMM_STREAM") ? atoi(getenv("ADALOG_GEMM_STREAM")) : 1;
     static const int use_wgacc = getenv("ADALOG_GEMM_WGACC") ? atoi(getenv("ADALOG_GEMM_WGACC")) : 1;
     Layout L{};
@@ -1326,6 +1586,26 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     }
     L.stream = cand_cols && use_stream && (L.tm <= 2 || L.wide) && (int64_t)(64 * L.tm + BN2) * kb < ((int64_t)1 << 31);
     if (!L.stream && L.wide) { L.wide = 0; L.tm = pick_tm(M, scoring); }
+    // Slab kernel: int8, one group, 2..6 K-steps (the 256-column slab is <= 96 KiB), whole 32-row units, at least three
+    // units per wave and slab, and a streamed operand that stays in an XCD's L2.
+    static const int use_slab = getenv("ADALOG_GEMM_SLAB") ? atoi(getenv("ADALOG_GEMM_SLAB")) : 1;
+    if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && dtype == 0 && G == 1 && kb <= 6 * BK3 && kvalid_bytes > BK3 && M % 32 == 0 && M >= 768 &&
+        (int64_t)M * kb <= ((int64_t)3 << 20) && (int64_t)cdiv(N, BN2) * (M / 32) < ((int64_t)1 << 30)) {
+        L.slab = 1;
+        L.slab_U = M / 32;
+        L.NT = cdiv(N, BN2);
+        const int64_t units = (int64_t)L.NT * L.slab_U;
+        L.slab_R = (int)(cdiv(cdiv(units, (int64_t)device_cus()), (int64_t)8) * 8);
+        L.wgs = (int)cdiv(units, (int64_t)L.slab_R);
+        L.MT = cdiv(L.slab_U, L.slab_R) + 1;                 // pieces a slab can be cut into by the range boundaries
+        L.n_eff = N / ref_div;
+        L.c_eff = ref_div;
+        L.acc = reduce_cols && use_wgacc;
+        L.Npad = cdiv(L.n_eff, 64) * 64;
+        L.elems = L.acc ? (int64_t)2 * L.wgs * gmod * BN2 : (int64_t)L.c_eff * G * L.MT * L.Npad;
+        L.wide = 0; L.tm = 2;
+        return L;
+    }
     const int bm = L.big ? 64 * L.tm : BM, bn = L.big ? BN2 : BN;
     L.MT = cdiv(M, bm);
     L.NT = cdiv(N, bn);
@@ -1347,7 +1627,7 @@ extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod
                                             int64_t Kp, int64_t k_valid, int ref_transposed, int* MT, int* Npad, int* mode) {
     const int esz = (dtype == 0 || dtype == 3) ? 1 : dtype == 1 ? 2 : 4;
     const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, true, (k_valid > 0 ? k_valid : Kp) * esz, Kp * esz,
-                               ref_transposed != 0);
+                               ref_transposed != 0, dtype);
     if (MT) *MT = L.acc ? L.wgs : L.MT;
     if (Npad) *Npad = L.acc ? BN2 : L.Npad;
     if (mode) *mode = L.acc ? 2 : (ref_div > 1 ? 1 : 0);
@@ -1373,7 +1653,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(!row_scale || (C == 1 && row_bias), "gemm_score: per-row scale needs C == 1 and a row_bias vector");
     ADALOG_ARG_CHECK(!(partial && out), "gemm_score: either score against ref or store out, not both");
     const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, out == nullptr, (k_valid > 0 ? k_valid : Kp) * esz, Kp * esz,
-                               ldr == 1 && ref != nullptr);
+                               ldr == 1 && ref != nullptr, dtype);
     GemmArgs p{};
     p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
     p.sAc = sAc * esz; p.sAg = sAg * esz; p.sBc = sBc * esz; p.sBg = sBg * esz;
@@ -1399,7 +1679,31 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK((Kp * esz) % BK2 == 0 || (L.stream && !out),
                      "gemm_score: rows padded to 64 (not 128) bytes are taken by the streaming search kernel only");
     ADALOG_ARG_CHECK(dtype != 3 || (L.stream && !out), "gemm_score: fp8 operands are taken by the streaming search kernel only (ref_div 64/128/256, transposed reference)");
-    if (L.stream && !out) {
+    if (L.slab && !out) {
+        // slab kernel: one workgroup per CU, each takes a contiguous range of (slab, unit) pairs
+        p.MT = L.MT; p.NT = L.NT; p.slab_U = L.slab_U; p.slab_R = L.slab_R;
+        const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
+        const size_t shm = (size_t)nk * BN2 * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * BN2 * 4;
+        // a slab that is not cut has unused pieces: they must read as zero
+        if (!L.acc) {
+            const hipError_t me = hipMemsetAsync(partial, 0, (size_t)L.elems * sizeof(float), st);
+            if (me != hipSuccess) { adalog_set_error("adalog_gemm_score (clear partials)", me); return (int)me; }
+        }
+        const int nref = BN2 / ref_div;
+#define LAUNCH_SLAB(NREFV, ROWSV)                                                                                 \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, ROWSV>),              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            hipLaunchKernelGGL((k_gemm_slab<NREFV, ROWSV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);        \
+        } while (0)
+        if (row_scale) { if (nref == 1) LAUNCH_SLAB(1, true); else if (nref == 2) LAUNCH_SLAB(2, true); else LAUNCH_SLAB(4, true); }
+        else { if (nref == 1) LAUNCH_SLAB(1, false); else if (nref == 2) LAUNCH_SLAB(2, false); else LAUNCH_SLAB(4, false); }
+#undef LAUNCH_SLAB
+    } else if (L.stream && !out) {
         // persistent streaming kernel: two (wide form: one) workgroups per CU walk the tile list
         {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)
             const int64_t a_tile = (int64_t)64 * L.tm * p.Kb;
