@@ -1161,11 +1161,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_slab(GemmArgs p) {
 
     // ---- this wave's units: in every slab segment [a, b) of the range it takes a + w, a + w + 8, ...
     auto seg_end = [&](int s) { return min(U, u1 - s * U); };
+    const int a_first = u0 - s_first * U;
+    // (only the range's first segment can start past 0 and only its last can end before U >= 24, so two probes suffice)
+    auto probe = [&](int s, int& r) { r = (s == s_first ? a_first : 0) + w; return s <= s_last && r < seg_end(s); };
     auto first_from = [&](int s, int& os, int& orr) {
-        for (; s <= s_last; ++s) {
-            const int a = (s == s_first ? u0 - s_first * U : 0) + w;
-            if (a < seg_end(s)) { os = s; orr = a; return true; }
-        }
+        int r;
+        if (probe(s, r)) { os = s; orr = r; return true; }
+        if (probe(s + 1, r)) { os = s + 1; orr = r; return true; }
         return false;
     };
     auto next_unit = [&](int& s, int& r) {
@@ -1261,28 +1263,37 @@ __global__ __launch_bounds__(512, 2) void k_gemm_slab(GemmArgs p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
         while (c_more && c_s == s) {
-            for (int kt = 0; kt < nk; ++kt) {
-                // may stay outstanding behind this step's two requests: the next step's two and, in a unit's first two
-                // steps, its NP operand requests (stores are not counted: stricter if one is still in flight)
-                if (kt < 2) {
-                    if (NP == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else if (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                const uint8_t* cur = ringw + st * UST;
-                const uint8_t* Bs = slab + kt * BN2 * BK3;
-                const uint4 a0 = lds_frag(cur, swz3(frow, fkg)), a1 = lds_frag(cur, swz3(frow, 2 + fkg));
-                uint4 b0n = lds_frag(Bs, swz3(frow, fkg)), b1n = lds_frag(Bs, swz3(frow, 2 + fkg));
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const uint4 b0 = b0n, b1 = b1n;
-                    if (b + 1 < 8) { b0n = lds_frag(Bs, swz3((b + 1) * 32 + frow, fkg)); b1n = lds_frag(Bs, swz3((b + 1) * 32 + frow, 2 + fkg)); }
-                    if (kt == 0) acc[b] = mma0<0>(a0, b0); else mma<0>(a0, b0, acc[b]);
-                    mma<0>(a1, b1, acc[b]);
-                    if (b == 3) issue_step();
+            // One K-step: may stay outstanding behind its two requests: the next step's two and, in a unit's first two
+            // steps, the unit's NP operand requests (stores are not counted: stricter if one is still in flight).
+#define SLAB_BODY(FIRST_)                                                                                       \
+                uint4 b0n = lds_frag(Bs, swz3(frow, fkg)), b1n = lds_frag(Bs, swz3(frow, 2 + fkg));             \
+                _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                                 \
+                    const uint4 b0 = b0n, b1 = b1n;                                                             \
+                    if (b + 1 < 8) { b0n = lds_frag(Bs, swz3((b + 1) * 32 + frow, fkg)); b1n = lds_frag(Bs, swz3((b + 1) * 32 + frow, 2 + fkg)); } \
+                    if (FIRST_) acc[b] = mma0<0>(a0, b0); else mma<0>(a0, b0, acc[b]);                          \
+                    mma<0>(a1, b1, acc[b]);                                                                     \
+                    if (b == 3) issue_step();                                                                   \
+                    /* keep the one-block look-ahead: hoisting more reads costs the accumulators their VGPRs */ \
+                    __builtin_amdgcn_sched_barrier(0);                                                          \
                 }
-                st = st == NSL - 1 ? 0 : st + 1;
-            }
+#define SLAB_STEP(FIRST_, EARLY_, kt_)                                                                          \
+            do {                                                                                                \
+                if (EARLY_) {                                                                                   \
+                    if (NP == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                               \
+                    else if (NP == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                          \
+                    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                       \
+                } else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                         \
+                const uint8_t* cur = ringw + st * UST;                                                          \
+                const uint8_t* Bs = slab + (kt_) * BN2 * BK3;                                                   \
+                const uint4 a0 = lds_frag(cur, swz3(frow, fkg)), a1 = lds_frag(cur, swz3(frow, 2 + fkg));       \
+                SLAB_BODY(FIRST_)                                                                               \
+                st = st == NSL - 1 ? 0 : st + 1;                                                                \
+            } while (0)
+            SLAB_STEP(true, true, 0);
+            SLAB_STEP(false, true, 1);                                     // nk >= 2 is a launch condition
+            for (int kt = 2; kt < nk; ++kt) SLAB_STEP(false, false, kt);
+#undef SLAB_STEP
+#undef SLAB_BODY
             // ---- epilogue: lane column = block b, lane & 31; rows 8*q4 + 4*fkg + e of the unit
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");               // all but the two run-ahead steps have landed
             // (a per-column bias is rare -- no int8 search of the calibrator has one -- so its values are re-read per
