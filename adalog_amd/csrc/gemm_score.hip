@@ -23,6 +23,7 @@
 // All stage operands through LDS with a 16-byte-slot XOR swizzle (0 bank conflicts measured) and order workgroups so that
 // tiles sharing an operand run on one XCD (its L2).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 // The quantisation kernels are compiled without FMA contraction (bin indices must round like the reference); this file
@@ -1388,6 +1389,194 @@ __global__ __launch_bounds__(512, 2) void k_gemm_slab(GemmArgs p) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ group kernel
+// Fifth form, for the attention q.k^T searches: many small groups (image x head), one 64-byte K-step, 129..224 rows.
+// k_gemm_stream spends such a tile on its epilogue and its per-tile set-up (2 MFMAs per 32 x 32 outputs against ~32
+// VALU), at 0.4 PFLOP/s.  Here a workgroup is 7 consumer waves + 1 loader wave:
+//   * consumer w keeps the fragments of row block w of the current group in REGISTERS (8 VGPRs) for a whole item
+//     (= group x chunk of candidate columns) together with the 16 reference values per reference column it needs;
+//   * the loader wave alone issues the LDS-DMA of the candidate columns (stages of 256 columns = 16 KiB, 3-stage ring)
+//     and is the only wave that counts vmcnt; one workgroup barrier per stage hands a stage over;
+//   * per 32 x 32 block a consumer does 2 ds_read_b128, 2 MFMAs and the 32-VALU epilogue; column sums stay in registers
+//     for the item, then go through LDS into per-workgroup fp64 sums per head (fixed order: no atomics).
+// Output: the wg_acc layout of k_gemm_stream ([workgroup][head][256] fp64), same number of workgroups.
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+template <int NJ, int DT>
+__global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NSG = 3, SB = 8, SBYTES = SB * 32 * BK3;     // ring stages, blocks per stage, bytes per stage
+    constexpr int P = NJ * 32;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* ring = lds;                                                        // [NSG][256 columns][64 bytes]
+    float* red = reinterpret_cast<float*>(lds + NSG * SBYTES);                  // [7 waves][256]
+    double* accl = reinterpret_cast<double*>(lds + NSG * SBYTES + 7 * 256 * 4); // [gmod][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fkg = lane >> 5;
+    const int Kb = (int)p.Kb;
+    const int NB = p.N >> 5;                                  // 32-column blocks per group
+    const int CB = p.slab_R, NCH = p.slab_U;                  // blocks per chunk, chunks per group
+    const int items = p.G * NCH;
+    const int n_eff = p.N / P;
+    for (int i = tid; i < p.gmod * 256; i += 512) accl[i] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    if (w == 7) {
+        // ---------------- loader: the stages of every item of this workgroup, two ahead of the consumers
+        const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+        int li = blockIdx.x, lst = 0, slot = 0;               // item / stage cursor of the issue side
+        auto stages_of = [&](int item) { const int c = item % NCH; return (min(CB, NB - c * CB) + SB - 1) / SB; };
+        auto issue = [&]() {                                   // one stage: 16 requests of 16 columns x 64 bytes
+            const int g = li / NCH, c = li - g * NCH;
+            const int col0 = (c * CB + lst * SB) * 32;
+            const int64_t left = (int64_t)(p.N - col0) * Kb;
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)g * p.sBg + (int64_t)col0 * Kb), 0,
+                                                                                (int)(left < 0 ? 0 : min(left, (int64_t)0x7ffffffe)), 0x00020000);
+            uint8_t* st = ring + slot * SBYTES;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) STREAM_DMA(rb, st + q * 1024, (q * 16 + lrow) * Kb + lslot16, 0);
+            slot = slot == NSG - 1 ? 0 : slot + 1;
+            if (++lst == stages_of(li)) { lst = 0; li += gridDim.x; }
+        };
+        int ahead = 0;                                         // stages issued and not yet handed over
+        if (li < items) { issue(); ++ahead; }
+        if (li < items) { issue(); ++ahead; }
+        for (int item = blockIdx.x; item < items; item += gridDim.x) {
+            const int ns = stages_of(item);
+            for (int t = 0; t < ns; ++t) {
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the following stage may still be in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                --ahead;
+                if (li < items) { issue(); ++ahead; }
+            }
+            asm volatile("s_barrier" ::: "memory");                        // item end: column sums are in `red`
+        }
+    } else {
+        // ---------------- consumers: row block w
+        const int row0 = w * 32;
+        const bool rowblock_live = row0 < p.M;                 // (always true for the launches this kernel takes)
+        int st = 0;                                            // ring slot of the next stage (runs on across items)
+        for (int item = blockIdx.x; item < items; item += gridDim.x) {
+            const int g = item / NCH, c = item - g * NCH, gh = g % p.gmod;
+            const int blk0 = c * CB, nblk = min(CB, NB - blk0), ns = (nblk + SB - 1) / SB;
+            // fragments of this row block (rows past M are zero), column factors of the group's head
+            uint4 a0, a1;
+            {
+                const bool ok = row0 + frow < p.M;
+                const uint8_t* ar = p.A + (int64_t)g * p.sAg + (int64_t)min(row0 + frow, p.M - 1) * Kb;
+                a0 = *reinterpret_cast<const uint4*>(ar + fkg * 16);
+                a1 = *reinterpret_cast<const uint4*>(ar + 32 + fkg * 16);
+                if (!ok) { a0 = make_uint4(0, 0, 0, 0); a1 = a0; }
+            }
+            float nal[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int ci = j * 32 + frow;
+                nal[j] = -(p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g]);
+            }
+            // reference slice of one reference column: rows row0 + 8*q + 4*fkg + {0..3}, zero past M.  One 16-byte load
+            // per q from a uniform column base + a per-lane row offset clamped to M - 4; the ragged (last) row block then
+            // shifts the elements it still owns into place.
+            // (buffer loads: uniform column offset in an SGPR + four loop-invariant lane offsets -- with flat pointers the
+            // compiler kept one 64-bit address per call site alive and spilled them)
+            const uint32_t ref_bytes = (uint32_t)(((int64_t)(n_eff - 1) * p.ref_cs + p.M) * 4);   // past it a load returns 0
+            const __amdgpu_buffer_rsrc_t rrg = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref + (int64_t)g * p.sRg), 0, (int)ref_bytes, 0x00020000);
+            const bool full_rows = row0 + 32 <= p.M;          // wave-uniform
+            int roff[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) roff[q] = min(row0 + 8 * q + 4 * fkg, p.M - 4) * 4;
+            v2f cs2[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cs2[j] = (v2f){0.0f, 0.0f};
+            // The stage loop exists twice (whole / ragged row block, chosen per wave) so that its body has no branch: with
+            // one, the compiler's waitcnt pass drains the reference prefetch it has just issued.
+            auto run = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                auto load_ref = [&](int n, float4 (&r)[4]) {
+                    const int coff = n < n_eff ? n * (int)p.ref_cs * 4 : 0x7ffffff0;   // (uniform) past the last column: zeros
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr = row0 + 8 * q + 4 * fkg;
+                        const v4u uu = __builtin_amdgcn_raw_buffer_load_b128(rrg, roff[q], coff, 0);
+                        const float4 u = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
+                        if (FULL) r[q] = u;
+                        else {
+                            const int sh = rr * 4 - roff[q];   // 0 unless the group of four crosses M (then 4, 8 or 12 bytes)
+                            const float e0 = sh == 0 ? u.x : sh == 4 ? u.y : sh == 8 ? u.z : u.w;
+                            const float e1 = sh == 0 ? u.y : sh == 4 ? u.z : u.w;
+                            const float e2 = sh == 0 ? u.z : u.w;
+                            r[q] = make_float4(rr < p.M ? e0 : 0.f, rr + 1 < p.M ? e1 : 0.f, rr + 2 < p.M ? e2 : 0.f, rr + 3 < p.M ? u.w : 0.f);
+                        }
+                    }
+                };
+                int n = blk0 / NJ;                             // chunks start on a reference column (CB % 8 == 0, NJ | 8)
+                float4 rc[4], rn[4];
+                load_ref(n, rc);
+                load_ref(n + 1, rn);
+                for (int t = 0; t < ns; ++t) {
+                    asm volatile("s_barrier" ::: "memory");
+                    const uint8_t* cur = ring + st * SBYTES;
+                    uint4 b0n = lds_frag(cur, swz3(frow, fkg)), b1n = lds_frag(cur, swz3(frow, 2 + fkg));
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) {
+                        const int j = b % NJ;
+                        const uint4 b0 = b0n, b1 = b1n;
+                        if (b + 1 < SB) { b0n = lds_frag(cur, swz3((b + 1) * 32 + frow, fkg)); b1n = lds_frag(cur, swz3((b + 1) * 32 + frow, 2 + fkg)); }
+                        typename Acc<DT == 3 ? 1 : 0>::type acc;      // fp8 operands accumulate in fp32: no conversion below
+                        if constexpr (DT == 3) {
+                            v16f z_;
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) z_[e] = 0.0f;
+                            acc = mma_fp8x64(a0, a1, b0, b1, z_);
+                        } else {
+                            acc = mma0<0>(a0, b0);
+                            mma<0>(a1, b1, acc);
+                        }
+                        const v2f na = {nal[j], nal[j]};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const v2f tA = {(float)acc[q * 4 + 0], (float)acc[q * 4 + 1]}, tB = {(float)acc[q * 4 + 2], (float)acc[q * 4 + 3]};
+                            const v2f rA = {rc[q].x, rc[q].y}, rB = {rc[q].z, rc[q].w};
+                            const v2f dA = tA * na + rA, dB = tB * na + rB;
+                            cs2[j] += dA * dA; cs2[j] += dB * dB;
+                        }
+                        if (j == NJ - 1) {                     // next block starts the next reference column
+                            ++n;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rc[q] = rn[q];
+                            load_ref(n + 1, rn);
+                        }
+                    }
+                    st = st == NSG - 1 ? 0 : st + 1;
+                }
+            };
+            if (!rowblock_live) {                              // (never for the launches this kernel takes)
+                for (int t = 0; t < ns; ++t) { asm volatile("s_barrier" ::: "memory"); st = st == NSG - 1 ? 0 : st + 1; }
+            } else if (full_rows) run(std::true_type{});
+            else run(std::false_type{});
+            // item end: pair up the lanes, park the sums, one thread per candidate adds them in a fixed wave order
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float cs = cs2[j].x + cs2[j].y;
+                cs += __shfl_xor(cs, 32);
+                if (fkg == 0) red[w * 256 + j * 32 + frow] = cs;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid < P) {
+                double v = 0.0;
+                const int nw = min(7, (p.M + 31) / 32);
+                for (int ww = 0; ww < nw; ++ww) v += (double)red[ww * 256 + tid];
+                accl[gh * 256 + tid] += v;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = tid; i < p.gmod * 256; i += 512) p.wg_acc[(int64_t)blockIdx.x * p.gmod * 256 + i] = accl[i];
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ finish
 // scores[c][h?][n?] = -norm * sum over (image = g / gmod, [h], m-tile, [n]) of partial[c][g][mt][n]   in fp64,
 // fixed summation order: each thread takes a strided subset, then a fixed LDS tree.
@@ -1632,6 +1821,16 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     return L;
 }
 
+// Launch-time choice of the group kernel (it shares the streaming kernel's accumulator layout, so the layout query does
+// not need to know): int8 or fp8, one K-step, 5..7 row blocks, many groups, plain column factors.
+static bool grp_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
+                   const float* row_scale, int64_t sb_n, int64_t ref_cs) {
+    static const int use_grp = getenv("ADALOG_GEMM_GRP") ? atoi(getenv("ADALOG_GEMM_GRP")) : 1;
+    return use_grp && (dtype == 0 || dtype == 3) && kvalid_bytes <= BK3 && M > 128 && M <= 224 && G >= 8 && gmod <= 8 && !bias && !row_scale &&
+           sb_n == 0 && (ref_div == 64 || ref_div == 128 || ref_div == 256) && N % ref_div == 0 &&
+           (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
+}
+
 // M, N: GEMM rows / columns (N includes the candidate factor when ref_div > 1).  Outputs the partial-buffer layout
 // [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
 extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype,
@@ -1714,6 +1913,26 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         if (row_scale) { if (nref == 1) LAUNCH_SLAB(1, true); else if (nref == 2) LAUNCH_SLAB(2, true); else LAUNCH_SLAB(4, true); }
         else { if (nref == 1) LAUNCH_SLAB(1, false); else if (nref == 2) LAUNCH_SLAB(2, false); else LAUNCH_SLAB(4, false); }
 #undef LAUNCH_SLAB
+    } else if (L.stream && !out && L.acc && grp_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs)) {
+        // group kernel (q.k^T searches): same accumulator layout and workgroup count as the streaming kernel
+        const int NB = N / 32;
+        const int nch0 = cdiv((int64_t)3 * L.wgs, G);
+        const int CB = cdiv(cdiv(NB, nch0 < 1 ? 1 : nch0), 8) * 8;
+        p.slab_R = CB; p.slab_U = cdiv(NB, CB);
+        const size_t shm = (size_t)3 * 8 * 32 * BK3 + 7 * 256 * 4 + (size_t)gmod * 256 * 8;
+#define LAUNCH_GRP(NJV, DTV)                                                                                      \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_grp<NJV, DTV>),                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            hipLaunchKernelGGL((k_gemm_grp<NJV, DTV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);             \
+        } while (0)
+        if (dtype == 3) { if (ref_div == 64) LAUNCH_GRP(2, 3); else if (ref_div == 128) LAUNCH_GRP(4, 3); else LAUNCH_GRP(8, 3); }
+        else { if (ref_div == 64) LAUNCH_GRP(2, 0); else if (ref_div == 128) LAUNCH_GRP(4, 0); else LAUNCH_GRP(8, 0); }
+#undef LAUNCH_GRP
     } else if (L.stream && !out) {
         // persistent streaming kernel: two (wide form: one) workgroups per CU walk the tile list
         {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)

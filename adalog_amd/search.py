@@ -219,19 +219,22 @@ def _matmul_grid(x, n_bits_B: int, eq_n: int, head_wise: bool = True):
     return be.candidate_grid(quant4, num_scale, num_zp, int(L - num_zp / 2), n_bits_B, linspace01(num_scale, x.device), None)
 
 
-def int_operand_dtype(bits_a: int, bits_b: int, chunk: int, zp_on_grid: bool = True) -> int:
+def int_operand_dtype(bits_a: int, bits_b: int, chunk: int, zp_on_grid: bool = True, one_k_step: bool = False) -> int:
     """Storage type for a pair of uniformly quantised GEMM operands (ops.I8 or ops.FP8).
 
     fp8 (e4m3) holds every integer in [-16, 16] exactly, so ``q - z`` of a <= 4-bit operand whose zero point lies in
     [0, 2^bits - 1] (true for every FPCS grid, linear.py:446-449,476-479; matmul.py:236-239) is exact, products accumulate
     exactly in the fp32 MFMA accumulator (sums < 2^24), the f8f6f4 MFMA runs at the int8 rate and the epilogue needs no
-    int->float conversion.  Requires all candidates of a call in one launch of the streaming kernel (64, 128 or 256).
+    int->float conversion.  Requires all candidates of a call in one launch (64, 128 or 256).
 
-    Measured on MI355X (deit_small W4A4): identical scores, and the same speed as int8 -- the K = 384 launches are bound
-    by the operand stream and the two-workgroup interplay, not by the epilogue's conversions -- so int8 stays the default
-    and ADALOG_INT_FP8=1 opts in."""
+    Measured on MI355X (deit_small W4A4): identical scores everywhere.  The K = 384 launches run at the same speed
+    as int8 (bound by the operand stream, not by the conversions), so there int8 stays unless ADALOG_INT_FP8=1; the
+    attention q.k^T searches (one 64-byte K-step, ``one_k_step``) are bound by the epilogue's VALU work, half of which is
+    those conversions, so they take fp8 unless ADALOG_INT_FP8=0."""
     import os
     from .ops import FP8, I8
-    if os.environ.get("ADALOG_INT_FP8", "0") == "1" and bits_a <= 4 and bits_b <= 4 and zp_on_grid and chunk in (64, 128, 256):
+    env = os.environ.get("ADALOG_INT_FP8", "")
+    want = env == "1" or (one_k_step and env != "0")
+    if want and bits_a <= 4 and bits_b <= 4 and zp_on_grid and chunk in (64, 128, 256):
         return FP8
     return I8

@@ -605,6 +605,35 @@ def test_gemm_slab_kernel(ops, P):
                     assert rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, K, bias_kind, rows, keep_n, rel_err(got.cpu(), want))
 
 
+@pytest.mark.parametrize("dtype", ["i8", "fp8"])
+@pytest.mark.parametrize("P", [64, 128, 256])
+def test_gemm_group_kernel(ops, dtype, P):
+    """Group kernel (attention q.k^T searches: int8 or fp8 storage, one 64-byte K-step, 129..224 rows, many image x head groups, scores
+    summed over the columns): ragged and exact last row block, a column count that leaves the last stage and the last
+    chunk partly empty, head-wise and tensor-wise scores -- against the CPU specification."""
+    gen = g(5200 + P)
+    gmod = 6
+    dt_c, dt_o = {"i8": (CB.I8, ops.I8), "fp8": (CB.FP8, ops.FP8)}[dtype]
+    tdt = {"i8": torch.int8, "fp8": torch.float8_e4m3fn}[dtype]
+    for M, Ncols, G, K in ((197, 197, 12, 64), (160, 37, 24, 48), (224, 9, 18, 64)):
+        Kp = CB.pad_k(K, dt_c, 64)
+        A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
+        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).float().to(tdt)
+        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).float().to(tdt)
+        ref = torch.randn(G, Ncols, M, generator=gen) * 3                      # stored [G, N, M] (transposed)
+        sa = torch.rand(gmod, generator=gen) * 0.02 + 0.01
+        sb = torch.rand(P, gmod, generator=gen) * 0.5 + 0.5
+        Ad, Bd = A.to(DEV), B.to(DEV)
+        Ad.k_valid = K; Bd.k_valid = K
+        for keep_h in (True, False):
+            want = CB.gemm_score(dt_c, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa, g=1), CB.Strided(sb, c=gmod, g=1), None,
+                                 keep_h, False, 0.01, sa_mul=0.5, ref_div=P, ref_transposed=True)
+            got = ops.gemm_score(dt_o, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV), g=1),
+                                 ops.Strided(sb.to(DEV), c=gmod, g=1), None, keep_h, False, 0.01, sa_mul=0.5, ref_div=P,
+                                 order=2, ref_transposed=True)
+            assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, G, K, keep_h, rel_err(got.cpu(), want))
+
+
 def test_sharded_select_matches_fused(ops):
     """adalog_select_* (histograms summed over emulated ranks between counting and pick) == the fused single-process
     kernels == the CPU specification, for every shard/chunk layout the grids use, and for the positive percentile."""
