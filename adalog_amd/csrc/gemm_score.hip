@@ -1512,9 +1512,11 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
                     }
                 };
                 int n = blk0 / NJ;                             // chunks start on a reference column (CB % 8 == 0, NJ | 8)
-                float4 rc[4], rn[4];
-                load_ref(n, rc);
-                load_ref(n + 1, rn);
+                // two register sets take turns (a stage holds an even number of reference columns when NJ <= 4, so which
+                // set a block reads is known at compile time; with NJ = 8 the sets are swapped by copying)
+                float4 rr2[2][4];
+                load_ref(n, rr2[0]);
+                load_ref(n + 1, rr2[1]);
                 for (int t = 0; t < ns; ++t) {
                     asm volatile("s_barrier" ::: "memory");
                     const uint8_t* cur = ring + st * SBYTES;
@@ -1522,6 +1524,7 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
 #pragma unroll
                     for (int b = 0; b < SB; ++b) {
                         const int j = b % NJ;
+                        const int set = NJ == 8 ? 0 : (b / NJ) & 1;
                         const uint4 b0 = b0n, b1 = b1n;
                         if (b + 1 < SB) { b0n = lds_frag(cur, swz3((b + 1) * 32 + frow, fkg)); b1n = lds_frag(cur, swz3((b + 1) * 32 + frow, 2 + fkg)); }
                         typename Acc<DT == 3 ? 1 : 0>::type acc;      // fp8 operands accumulate in fp32: no conversion below
@@ -1538,15 +1541,17 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             const v2f tA = {(float)acc[q * 4 + 0], (float)acc[q * 4 + 1]}, tB = {(float)acc[q * 4 + 2], (float)acc[q * 4 + 3]};
-                            const v2f rA = {rc[q].x, rc[q].y}, rB = {rc[q].z, rc[q].w};
+                            const v2f rA = {rr2[set][q].x, rr2[set][q].y}, rB = {rr2[set][q].z, rr2[set][q].w};
                             const v2f dA = tA * na + rA, dB = tB * na + rB;
                             cs2[j] += dA * dA; cs2[j] += dB * dB;
                         }
                         if (j == NJ - 1) {                     // next block starts the next reference column
                             ++n;
+                            if (NJ == 8) {
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) rc[q] = rn[q];
-                            load_ref(n + 1, rn);
+                                for (int q = 0; q < 4; ++q) rr2[0][q] = rr2[1][q];
+                                load_ref(n + 1, rr2[1]);
+                            } else load_ref(n + 1, rr2[set]);   // this set is free now; the other one holds column n
                         }
                     }
                     st = st == NSG - 1 ? 0 : st + 1;

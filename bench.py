@@ -71,6 +71,11 @@ class GemmProfiler:
                  "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in rows]
 
 
+# scoring-GEMM kernels by operand type: the roofline object covers every launch of the dominant type
+KERNELS = {0: "k_gemm_slab + k_gemm_stream<i8> + k_gemm_grp<i8>", 1: "k_gemm_stream<bf16>", 2: "k_gemm_stream<f32>",
+           3: "k_gemm_grp<fp8> + k_gemm_stream<fp8>"}
+
+
 def pmc_traffic(dom):
     """HBM bytes per launch of the dominant scoring-GEMM dtype, from the committed PMC passes over this same workload
     (tools/pmc_bench.sh -> profiles/r01_pmc_bench_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
@@ -81,9 +86,23 @@ def pmc_traffic(dom):
             rows = json.load(f)
     except OSError:
         return None
+    def dtype_of(name):
+        # k_gemm_stream<DT, RI, NW, NS>; k_gemm_slab<NREF, ROWS> is int8 only; k_gemm_grp<NJ, DT>
+        try:
+            args = name[name.index("<") + 1:name.index(">")].split(",")
+            if name.startswith("k_gemm_stream<"):
+                return int(args[0])
+            if name.startswith("k_gemm_slab<"):
+                return 0
+            if name.startswith("k_gemm_grp<"):
+                return int(args[1])
+        except (ValueError, IndexError):
+            pass
+        return None
+
     tot, n = 0.0, 0
     for name, v in rows.items():
-        if name.startswith(f"k_gemm_stream<{dom},") and v.get("hbm_read_bytes_per_launch") is not None:
+        if dtype_of(name) == dom and v.get("hbm_read_bytes_per_launch") is not None:
             tot += (v["hbm_read_bytes_per_launch"] + (v.get("hbm_write_bytes_per_launch") or 0.0)) * v["launches"]
             n += v["launches"]
     return tot / n if n else None
@@ -232,7 +251,7 @@ def main():
                                                               "tflops": v[0] / (v[1] * 1e-3) / 1e12} for d, v in by.items()},
                        "scoring_gemm_top_shapes": prof.top_shapes(args.steps),
                        "depth_override": args.depth},
-            "roofline": {"bound": "mfma", "kernel": f"k_gemm_stream<{DT_NAME[dom]}>", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": KERNELS[dom], "achieved": achieved,
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],
                          "traffic": pmc_traffic(dom),
                          "launches": n, "avg_launch_ms": ms / max(n, 1)},

@@ -1,0 +1,9 @@
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+mkdir -p gpurun_out/final
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/final/pytest_gpu.log
+timeout 400 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; head -c 300 gpurun_out/final/bench.json; echo
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/final/prof.log 2>&1
+rm -f gpurun_out/final/prof/p_kernel_trace.csv
+timeout 600 bash tools/pmc_bench.sh gpurun_out/final/pmc > gpurun_out/final/pmc.log 2>&1; tail -5 gpurun_out/final/pmc.log
+for m in deit_tiny vit_base swin_small swin_base; do timeout 300 python bench.py --model $m --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/bench_$m.json 2> gpurun_out/final/bench_$m.err; head -c 200 gpurun_out/final/bench_$m.json; echo; done
+for b in 3 6; do timeout 300 python bench.py --bits $b --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/bench_w${b}.json 2> gpurun_out/final/bench_w${b}.err; head -c 200 gpurun_out/final/bench_w${b}.json; echo; done
