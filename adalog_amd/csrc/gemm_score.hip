@@ -14,9 +14,13 @@
 //                         sums < 2^24 exact in the fp32 accumulator; same rate as int8, no cvt in the epilogue)
 //              1 = bf16  (v_mfma_f32_32x32x16_bf16, AdaLog operand m*2^-t and integer operand exact in bf16)
 //              2 = fp32  (v_mfma_f32_32x32x2_f32,   conv patch-embed with unquantised 8-bit input)
-// Three kernels live here (DESIGN.md section 4 has the measurements that led from one to the next):
-//   k_gemm_stream  -- every search (candidates in the GEMM columns, reference rows contiguous): persistent workgroups,
-//                     LDS-DMA ring streaming across tiles, packed-fp32 epilogue, per-workgroup fp64 score accumulation;
+// Five kernels live here (DESIGN.md section 4 has the measurements that led from one to the next):
+//   k_gemm_slab    -- int8 searches with K <= 384 bytes: 256 candidate columns resident in LDS, the fixed operand
+//                     streamed wave-privately past them, column sums in registers, no barrier in the main loop;
+//   k_gemm_grp     -- attention q.k^T searches (one K-step, many small groups): 7 consumer waves with register-resident
+//                     row fragments + 1 LDS-DMA loader wave;
+//   k_gemm_stream  -- every other search (candidates in the GEMM columns, reference rows contiguous): persistent
+//                     workgroups, LDS-DMA ring streaming across tiles, packed-fp32 epilogue, per-workgroup fp64 sums;
 //   k_gemm_cand    -- quant_forward (stores the product) and the launches k_gemm_stream does not take
 //                     (k_gemm_cand_glds is its LDS-DMA variant): (64..256) x 256 tile, 128-byte K-steps;
 //   k_gemm_score   -- candidates in a grid dimension (C > 1): 128 x 128 tile, 64-byte K-steps.
