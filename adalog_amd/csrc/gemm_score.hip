@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(64 * NW, NS == 3 ? (NW == 8 ? 4 : 2) : 1) void k_ge
 // Work split: the (slab, unit) list is cut into equal contiguous ranges, one per workgroup; a slab cut by a range
 // boundary gets one partial row per piece (MT = pieces), or, with wg_acc, everything a workgroup sees goes into its
 // fp64 column sums.  Measured on the deit_small shapes (tools/lab): 1.8-2.0 PFLOP/s against 1.35 for k_gemm_stream.
-template <int NREF, bool ROWS>
+template <int NREF, bool ROWS, int DT>
 __global__ __launch_bounds__(512, 2) void k_gemm_slab(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int NSL = 3, UST = 32 * BK3, PW = 192;       // ring stages, bytes per stage, floats of per-wave operands
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_slab(GemmArgs p) {
     int c_s = 0, c_r = 0;
     bool c_more = first_from(s_first, c_s, c_r);
     int st = 0;
-    v16i acc[8];
+    typename Acc<DT == 3 ? 1 : 0>::type acc[8];              // fp8 storage (DT = 3) accumulates in fp32: no cvt in the epilogue
     v2f cs2[8];                                            // running squared-error sums of this lane's 8 columns
 #pragma unroll
     for (int b = 0; b < 8; ++b) cs2[b] = (v2f){0.0f, 0.0f};
@@ -1275,8 +1275,13 @@ __global__ __launch_bounds__(512, 2) void k_gemm_slab(GemmArgs p) {
                 _Pragma("unroll") for (int b = 0; b < 8; ++b) {                                                 \
                     const uint4 b0 = b0n, b1 = b1n;                                                             \
                     if (b + 1 < 8) { b0n = lds_frag(Bs, swz3((b + 1) * 32 + frow, fkg)); b1n = lds_frag(Bs, swz3((b + 1) * 32 + frow, 2 + fkg)); } \
-                    if (FIRST_) acc[b] = mma0<0>(a0, b0); else mma<0>(a0, b0, acc[b]);                          \
-                    mma<0>(a1, b1, acc[b]);                                                                     \
+                    if constexpr (DT == 3) {                                                                    \
+                        if (FIRST_) { _Pragma("unroll") for (int e_ = 0; e_ < 16; ++e_) acc[b][e_] = 0.0f; }    \
+                        acc[b] = mma_fp8x64(a0, a1, b0, b1, acc[b]);                                            \
+                    } else {                                                                                    \
+                        if (FIRST_) acc[b] = mma0<0>(a0, b0); else mma<0>(a0, b0, acc[b]);                      \
+                        mma<0>(a1, b1, acc[b]);                                                                 \
+                    }                                                                                           \
                     if (b == 3) issue_step();                                                                   \
                     /* keep the one-block look-ahead: hoisting more reads costs the accumulators their VGPRs */ \
                     __builtin_amdgcn_sched_barrier(0);                                                          \
@@ -1795,10 +1800,10 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     }
     L.stream = cand_cols && use_stream && (L.tm <= 2 || L.wide) && (int64_t)(64 * L.tm + BN2) * kb < ((int64_t)1 << 31);
     if (!L.stream && L.wide) { L.wide = 0; L.tm = pick_tm(M, scoring); }
-    // Slab kernel: int8, one group, 2..6 K-steps (the 256-column slab is <= 96 KiB), whole 32-row units, at least three
+    // Slab kernel: int8 or fp8 storage, one group, 2..6 K-steps (the 256-column slab is <= 96 KiB), whole 32-row units, at least three
     // units per wave and slab, and a streamed operand that stays in an XCD's L2.
     static const int use_slab = getenv("ADALOG_GEMM_SLAB") ? atoi(getenv("ADALOG_GEMM_SLAB")) : 1;
-    if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && dtype == 0 && G == 1 && kb <= 6 * BK3 && kvalid_bytes > BK3 && M % 32 == 0 && M >= 768 &&
+    if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && (dtype == 0 || dtype == 3) && G == 1 && kb <= 6 * BK3 && kvalid_bytes > BK3 && M % 32 == 0 && M >= 768 &&
         (int64_t)M * kb <= ((int64_t)3 << 20) && (int64_t)cdiv(N, BN2) * (M / 32) < ((int64_t)1 << 30)) {
         L.slab = 1;
         L.slab_U = M / 32;
@@ -1909,18 +1914,23 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
             if (me != hipSuccess) { adalog_set_error("adalog_gemm_score (clear partials)", me); return (int)me; }
         }
         const int nref = BN2 / ref_div;
-#define LAUNCH_SLAB(NREFV, ROWSV)                                                                                 \
+#define LAUNCH_SLAB(NREFV, ROWSV, DTV)                                                                            \
         do {                                                                                                      \
             static bool attr_set = false;                                                                         \
             if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, ROWSV>),              \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, ROWSV, DTV>),         \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
-            hipLaunchKernelGGL((k_gemm_slab<NREFV, ROWSV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);        \
+            hipLaunchKernelGGL((k_gemm_slab<NREFV, ROWSV, DTV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);   \
         } while (0)
-        if (row_scale) { if (nref == 1) LAUNCH_SLAB(1, true); else if (nref == 2) LAUNCH_SLAB(2, true); else LAUNCH_SLAB(4, true); }
-        else { if (nref == 1) LAUNCH_SLAB(1, false); else if (nref == 2) LAUNCH_SLAB(2, false); else LAUNCH_SLAB(4, false); }
+#define LAUNCH_SLAB_DT(DTV)                                                                                       \
+        do {                                                                                                      \
+            if (row_scale) { if (nref == 1) LAUNCH_SLAB(1, true, DTV); else if (nref == 2) LAUNCH_SLAB(2, true, DTV); else LAUNCH_SLAB(4, true, DTV); } \
+            else { if (nref == 1) LAUNCH_SLAB(1, false, DTV); else if (nref == 2) LAUNCH_SLAB(2, false, DTV); else LAUNCH_SLAB(4, false, DTV); } \
+        } while (0)
+        if (dtype == 3) LAUNCH_SLAB_DT(3); else LAUNCH_SLAB_DT(0);
+#undef LAUNCH_SLAB_DT
 #undef LAUNCH_SLAB
     } else if (L.stream && !out && L.acc && grp_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs)) {
         // group kernel (q.k^T searches): same accumulator layout and workgroup count as the streaming kernel

@@ -177,11 +177,11 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         self.a_quantizer.inited = True
         self.a_quantizer._zp_on_grid = True
 
-    def _int_dt(self, rows):
+    def _int_dt(self, rows, prefer_fp8=False):
         """Storage type of the integer operand pair of an output-based search over `rows` candidate rows."""
         chunk = self._cand_chunk(rows, pad_k(self.in_features, I8))
         on_grid = getattr(self.w_quantizer, "_zp_on_grid", False) and getattr(self.a_quantizer, "_zp_on_grid", False)
-        return search.int_operand_dtype(self.w_quantizer.n_bits, self.a_quantizer.n_bits, chunk, on_grid)
+        return search.int_operand_dtype(self.w_quantizer.n_bits, self.a_quantizer.n_bits, chunk, on_grid, prefer_fp8)
 
     def _cand_chunk(self, rows, kp_bytes):
         return max(1, min(self.eq_n, MAX_PACK_BYTES // max(1, rows * kp_bytes)))
@@ -192,7 +192,8 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         be = backend.get()
         aq = self.a_quantizer
         x3 = self._x2().unsqueeze(0)
-        dt = self._int_dt(self.out_features)
+        # weight searches of short-K layers run on the slab kernel, where fp8 storage saves the epilogue's conversions
+        dt = self._int_dt(self.out_features, prefer_fp8=self.in_features <= 384)
         xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, dt)
         return dt, xp, Strided(aq.scale.data.view(-1)), 1.0, None
 

@@ -238,7 +238,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         G, S, K, Sp = self._dims()
         # both zero points come from the percentile grid (_init_from_grid, then FPCS commits): fp8 storage when <= 4 bit
         dt = search.int_operand_dtype(self.A_quantizer.n_bits, self.B_quantizer.n_bits,
-                                      self._cand_chunk(G * max(S, Sp) * pad_k(K, I8)), one_k_step=K <= 64)
+                                      self._cand_chunk(G * max(S, Sp) * pad_k(K, I8)), prefer_fp8=K <= 64)
         for _ in range(self.search_round):
             self._fpcs("A", steps=self.steps, dt=dt)
             self._fpcs("B", steps=self.steps, dt=dt)

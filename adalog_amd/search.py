@@ -219,7 +219,7 @@ def _matmul_grid(x, n_bits_B: int, eq_n: int, head_wise: bool = True):
     return be.candidate_grid(quant4, num_scale, num_zp, int(L - num_zp / 2), n_bits_B, linspace01(num_scale, x.device), None)
 
 
-def int_operand_dtype(bits_a: int, bits_b: int, chunk: int, zp_on_grid: bool = True, one_k_step: bool = False) -> int:
+def int_operand_dtype(bits_a: int, bits_b: int, chunk: int, zp_on_grid: bool = True, prefer_fp8: bool = False) -> int:
     """Storage type for a pair of uniformly quantised GEMM operands (ops.I8 or ops.FP8).
 
     fp8 (e4m3) holds every integer in [-16, 16] exactly, so ``q - z`` of a <= 4-bit operand whose zero point lies in
@@ -227,14 +227,16 @@ def int_operand_dtype(bits_a: int, bits_b: int, chunk: int, zp_on_grid: bool = T
     exactly in the fp32 MFMA accumulator (sums < 2^24), the f8f6f4 MFMA runs at the int8 rate and the epilogue needs no
     int->float conversion.  Requires all candidates of a call in one launch (64, 128 or 256).
 
-    Measured on MI355X (deit_small W4A4): identical scores everywhere.  The K = 384 launches run at the same speed
-    as int8 (bound by the operand stream, not by the conversions), so there int8 stays unless ADALOG_INT_FP8=1; the
-    attention q.k^T searches (one 64-byte K-step, ``one_k_step``) are bound by the epilogue's VALU work, half of which is
-    those conversions, so they take fp8 unless ADALOG_INT_FP8=0."""
+    Measured on MI355X (deit_small W4A4): identical scores everywhere.  Whether it is faster depends on how much of a
+    launch is epilogue: the attention q.k^T searches (one 64-byte K-step, group kernel) and the weight searches of the
+    K <= 384 linear layers (slab kernel without a row scale: 2.29 -> 2.49 PFLOP/s) gain, so their callers pass
+    ``prefer_fp8``; the activation searches (row scale in the epilogue, more live registers: -4 %) and the streaming
+    kernel's launches (bound by the operand stream) do not.  ADALOG_INT_FP8=1 / 0 forces fp8 wherever it is exact /
+    nowhere."""
     import os
     from .ops import FP8, I8
     env = os.environ.get("ADALOG_INT_FP8", "")
-    want = env == "1" or (one_k_step and env != "0")
+    want = env == "1" or (prefer_fp8 and env != "0")
     if want and bits_a <= 4 and bits_b <= 4 and zp_on_grid and chunk in (64, 128, 256):
         return FP8
     return I8

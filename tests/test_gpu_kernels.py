@@ -569,19 +569,22 @@ def test_gemm_stream_kernel_variants(ops, dtype, P):
                     assert rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, K, bias_kind, rows, kv, rel_err(got.cpu(), want))
 
 
+@pytest.mark.parametrize("dtype", ["i8", "fp8"])
 @pytest.mark.parametrize("P", [64, 128, 256])
-def test_gemm_slab_kernel(ops, P):
-    """Slab kernel (int8, one group, K <= 384 bytes, M a multiple of 32 and >= 768): slabs cut into several pieces by the
+def test_gemm_slab_kernel(ops, dtype, P):
+    """Slab kernel (int8 or fp8 storage, one group, K <= 384 bytes, M a multiple of 32 and >= 768): slabs cut into several pieces by the
     workgroup ranges (small N) and ranges spanning several slabs (large N), a ragged last slab, 2..6 K-steps with and
     without K padding, every bias kind, with and without the row scale, per-column scores and scores summed over the
     columns (per-workgroup accumulators) -- against the CPU specification."""
     gen = g(4100 + P)
     G, gmod = 1, 1
+    dt_c, dt_o = {"i8": (CB.I8, ops.I8), "fp8": (CB.FP8, ops.FP8)}[dtype]
+    tdt = {"i8": torch.int8, "fp8": torch.float8_e4m3fn}[dtype]
     for M, Ncols, K in ((768, 21 * 128 // P + 1, 384), (1152, 9, 136), (800, 70000 // P + 3, 100)):
-        Kp = CB.pad_k(K, CB.I8)
-        A = torch.zeros(1, G, M, Kp, dtype=torch.int8); B = torch.zeros(1, G, Ncols * P, Kp, dtype=torch.int8)
-        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).to(torch.int8)
-        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).to(torch.int8)
+        Kp = CB.pad_k(K, dt_c)
+        A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
+        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).float().to(tdt)
+        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).float().to(tdt)
         ref = torch.randn(G, Ncols, M, generator=gen) * 3
         sa = torch.rand(1, generator=gen) * 0.002 + 0.001
         sb = torch.rand(P, Ncols, generator=gen) * 0.5 + 0.5
@@ -594,10 +597,10 @@ def test_gemm_slab_kernel(ops, P):
             ob = {"none": None, "n": ops.Strided(b_n.to(DEV), n=1), "cn": ops.Strided(b_cn.to(DEV), c=Ncols, n=1)}[bias_kind]
             for rows in (False, True):
                 for keep_n in (True, False):
-                    want = CB.gemm_score(CB.I8, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa), CB.Strided(sb, c=Ncols, n=1), cb,
+                    want = CB.gemm_score(dt_c, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa), CB.Strided(sb, c=Ncols, n=1), cb,
                                          False, keep_n, 0.01, ref_div=P, ref_transposed=True,
                                          row_scale=rs if rows else None, row_bias=rb if rows else None)
-                    got = ops.gemm_score(ops.I8, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV)),
+                    got = ops.gemm_score(dt_o, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV)),
                                          ops.Strided(sb.to(DEV), c=Ncols, n=1), ob, False, keep_n, 0.01, ref_div=P, order=2,
                                          ref_transposed=True, row_scale=rs.to(DEV) if rows else None,
                                          row_bias=rb.to(DEV) if rows else None)

@@ -10,13 +10,15 @@ extern "C" void adalog_set_error(const char* where, hipError_t e) { snprintf(g_e
 extern "C" void adalog_set_error_msg(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-struct Case { const char* name; int M, N, K, P; int rows; };
+struct Case { const char* name; int M, N, K, P; int rows; int dtype = 0; };
 
 int main(int argc, char** argv) {
     const int T = 32 * 197;
     std::vector<Case> cases = {
         {"w-search qkv  i8 K=384", T, 1152 * 128, 384, 128, 0},
+        {"w-search qkv fp8 K=384", T, 1152 * 128, 384, 128, 0, 3},
         {"a-search qkv  i8 K=384", 1152, T * 128, 384, 128, 1},
+        {"a-search qkv fp8 K=384", 1152, T * 128, 384, 128, 1, 3},
         {"a-search fc1  i8 K=384", 1536, T * 128, 384, 128, 1},
         {"w-search fc1  i8 K=384", T, 1536 * 128, 384, 128, 0},
         {"w-search proj i8 K=384", T, 384 * 128, 384, 128, 0},
@@ -29,9 +31,12 @@ int main(int argc, char** argv) {
         uint8_t *A, *B; float *ref, *sa, *sb, *rs, *rb, *bias;
         CK(hipMalloc(&A, abytes)); CK(hipMalloc(&B, bbytes));
         std::vector<uint8_t> h(std::max(abytes, bbytes));
-        for (size_t i = 0; i < h.size(); ++i) h[i] = (uint8_t)(((i * 2654435761u >> 13) & 15) - 8);
+        // integers -8..7, as int8 or as their e4m3 encodings
+        static const uint8_t f8[16] = {0xD0, 0xCE, 0xCC, 0xCA, 0xC8, 0xC4, 0xC0, 0xB8, 0x00, 0x38, 0x40, 0x44, 0x48, 0x4A, 0x4C, 0x4E};
+        auto enc = [&](unsigned v) { return cs.dtype == 3 ? f8[v & 15] : (uint8_t)((v & 15) - 8); };
+        for (size_t i = 0; i < h.size(); ++i) h[i] = enc((unsigned)(i * 2654435761u >> 13));
         CK(hipMemcpy(A, h.data(), abytes, hipMemcpyHostToDevice));
-        for (size_t i = 0; i < h.size(); ++i) h[i] = (uint8_t)(((i * 40503u >> 7) & 15) - 8);
+        for (size_t i = 0; i < h.size(); ++i) h[i] = enc((unsigned)(i * 40503u >> 7));
         CK(hipMemcpy(B, h.data(), bbytes, hipMemcpyHostToDevice));
         const int n_eff = cs.N / cs.P;
         std::vector<float> hr((size_t)cs.M * n_eff);
@@ -53,10 +58,10 @@ int main(int argc, char** argv) {
             for (int slab = 0; slab < 2; ++slab) {
                 g_slab_override = slab;
                 int MT, Npad, mode;
-                const int64_t pe = adalog_gemm_score_layout(cs.M, cs.N, 1, 1, 1, cs.P, red, 0, cs.K, cs.K, 1, &MT, &Npad, &mode);
+                const int64_t pe = adalog_gemm_score_layout(cs.M, cs.N, 1, 1, 1, cs.P, red, cs.dtype, cs.K, cs.K, 1, &MT, &Npad, &mode);
                 float* partial; CK(hipMalloc(&partial, pe * 4)); CK(hipMemset(partial, 0xff, pe * 4));
                 auto run = [&]() {
-                    int rc = adalog_gemm_score(0, A, B, 0, 0, 0, 0, cs.M, cs.N, cs.K, 0, 1, 1, 1, ref, 1, 0, cs.M, cs.P,
+                    int rc = adalog_gemm_score(cs.dtype, A, B, 0, 0, 0, 0, cs.M, cs.N, cs.K, 0, 1, 1, 1, ref, 1, 0, cs.M, cs.P,
                                                sa, cs.rows ? 1 : 0, 0, 1.0f, sb, cs.rows ? 0 : n_eff, 0, cs.rows ? 0 : 1,
                                                cs.rows ? nullptr : bias, 0, 0, cs.rows ? 0 : 1,
                                                cs.rows ? rs : nullptr, cs.rows ? rb : nullptr, partial, pe, nullptr, 0, 0, 0, 2, red, nullptr);
