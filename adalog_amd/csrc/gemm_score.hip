@@ -62,7 +62,8 @@ struct GemmArgs {
     double* wg_acc;                  // streaming kernel: per-workgroup fp64 column sums [workgroup][gmod][256] instead of
                                      // per-tile partials (searches that do not keep the column axis)
     int gm;                          // streaming kernel, order 2: m-tiles per L2 group (rows of A kept hot while n advances)
-    int slab_U, slab_R;              // slab kernel: 32-row units per slab, units per workgroup (NT = slabs, MT = pieces)
+    int slab_U, slab_R;              // slab kernel: 32-row units per slab, units per workgroup (NT = slabs, MT = pieces);
+                                     // group kernel: chunks per group, 32-column blocks per chunk
     long long* timeline;             // profiling only (tools/gemm_lab.hip): 8 cycle stamps per workgroup, else nullptr
 };
 #if defined(GEMM_LAB_TIMELINE)   // tools/lab only: the stamp stores would otherwise cost waits in the production kernel
@@ -1803,7 +1804,8 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     // Slab kernel: int8 or fp8 storage, one group, 2..6 K-steps (the 256-column slab is <= 96 KiB), whole 32-row units, at least three
     // units per wave and slab, and a streamed operand that stays in an XCD's L2.
     static const int use_slab = getenv("ADALOG_GEMM_SLAB") ? atoi(getenv("ADALOG_GEMM_SLAB")) : 1;
-    if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && (dtype == 0 || dtype == 3) && G == 1 && kb <= 6 * BK3 && kvalid_bytes > BK3 && M % 32 == 0 && M >= 768 &&
+    static const int slab_min_m = getenv("ADALOG_GEMM_SLAB_MINM") ? atoi(getenv("ADALOG_GEMM_SLAB_MINM")) : 768;
+    if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && (dtype == 0 || dtype == 3) && G == 1 && kb <= 6 * BK3 && kvalid_bytes > BK3 && M % 32 == 0 && M >= slab_min_m &&
         (int64_t)M * kb <= ((int64_t)3 << 20) && (int64_t)cdiv(N, BN2) * (M / 32) < ((int64_t)1 << 30)) {
         L.slab = 1;
         L.slab_U = M / 32;

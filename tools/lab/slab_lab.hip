@@ -13,6 +13,7 @@ extern "C" void adalog_set_error_msg(const char* msg) { snprintf(g_err, sizeof g
 struct Case { const char* name; int M, N, K, P; int rows; int dtype = 0; };
 
 int main(int argc, char** argv) {
+    if (argc > 1) setenv("ADALOG_GEMM_SLAB_MINM", argv[1], 1);   // e.g. 384: let the slab kernel take attn.proj's activation search
     const int T = 32 * 197;
     std::vector<Case> cases = {
         {"w-search qkv  i8 K=384", T, 1152 * 128, 384, 128, 0},
@@ -20,6 +21,7 @@ int main(int argc, char** argv) {
         {"a-search qkv  i8 K=384", 1152, T * 128, 384, 128, 1},
         {"a-search qkv fp8 K=384", 1152, T * 128, 384, 128, 1, 3},
         {"a-search fc1  i8 K=384", 1536, T * 128, 384, 128, 1},
+        {"a-search proj i8 K=384", 384, T * 128, 384, 128, 1},
         {"w-search fc1  i8 K=384", T, 1536 * 128, 384, 128, 0},
         {"w-search proj i8 K=384", T, 384 * 128, 384, 128, 0},
         {"w-search tiny i8 K=192", T, 576 * 128, 192, 128, 0},
