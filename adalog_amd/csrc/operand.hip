@@ -325,7 +325,8 @@ __global__ __launch_bounds__(256) void k_pack_adalog_fast(PackArgs a) {
                 unsigned short hv[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = __builtin_amdgcn_fmed3f(pr.y - lx[e] * pr.x, pr.z, pr.w);   // (log2 s - log2 x) * 37/q
+                    // (log2 s - log2 x) * 37/q, one explicit fma: this value only steers the fast path (the tie zone covers its error)
+                    const float t = __builtin_amdgcn_fmed3f(__builtin_fmaf(-lx[e], pr.x, pr.y), pr.z, pr.w);
                     float kk = rintf(t);
                     // within 1e-4 of a rounding tie the fast t (error ~1e-5 below 2L + 1) does not decide: exact path.
                     // One lane taking it stalls the wave, so the zone is as narrow as the error bound allows.
@@ -357,19 +358,23 @@ __global__ __launch_bounds__(256) void k_pack_uniform_i8_fast(PackArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     float4* s_par = reinterpret_cast<float4*>(s_raw);                       // [C] {1/s, s, -z + bias, qmax - z + bias}
     const float vbias = FP8 ? 0.0f : 128.0f;                                 // int8 goes through a biased u8 conversion
+    // per-group parameters (pg != 0: one (scale, zp) per candidate and head): grid.z walks the groups, so a block's
+    // parameters are still one LDS table
+    const bool per_group = a.pg != 0;
+    const int64_t pgo = per_group ? ((int64_t)blockIdx.z % a.gmod) * a.pg : 0;
     for (int c = threadIdx.x; c < (int)a.C; c += blockDim.x) {
-        const float s = a.scale[c * a.pc], z = rintf(a.zp[c * a.pc]);
+        const float s = a.scale[c * a.pc + pgo], z = rintf(a.zp[c * a.pc + pgo]);
         s_par[c] = make_float4(__builtin_amdgcn_rcpf(s), s, vbias - z, vbias + (a.qmax - z));
     }
     __syncthreads();
     const int64_t nq = a.Kp >> 2;
-    const int64_t total = a.G * a.R * nq;
+    const int64_t total = (per_group ? 1 : a.G) * a.R * nq;
     const int64_t cstep = gridDim.y;
     const bool ragged = (a.K & 3) != 0;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t kq = idx % nq;
         const int64_t t0 = idx / nq;
-        const int64_t r = t0 % a.R, g = t0 / a.R;
+        const int64_t r = t0 % a.R, g = per_group ? (int64_t)blockIdx.z : t0 / a.R;
         const int64_t k0 = kq << 2;
         float xv[4] = {0.f, 0.f, 0.f, 0.f};
         const int nlive = (int)min((int64_t)4, max((int64_t)0, a.K - k0));
@@ -426,13 +431,22 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         // enough candidate groups to fill the chip when the source is small (weights), all candidates per thread otherwise
         int64_t gy = 1;
         while (gx * gy < 2048 && gy < a.C) gy *= 2;
-        if (KIND == KIND_UNIFORM && sizeof(T) == 1 && a.pg == 0 && a.pr == 0 && !a.rowsum && a.C <= 2048 &&
+        if (KIND == KIND_UNIFORM && sizeof(T) == 1 && a.pr == 0 && (a.pg == 0 || a.G <= 65535) && !a.rowsum && a.C <= 2048 &&
             !getenv("ADALOG_PACK_GENERIC")) {
+            // per-tensor parameters: one grid over all groups; per-group (per-head) parameters: grid.z = groups
+            int64_t fx = gx, fy = gy, fz = 1;
+            if (a.pg != 0) {
+                fz = a.G;
+                fx = (a.R * (a.Kp >> 2) + 255) / 256;
+                if (fx > 16384) fx = 16384;
+                fy = 1;
+                while (fx * fy * fz < 2048 && fy < a.C) fy *= 2;
+            }
             if (std::is_same<T, int8_t>::value)
-                hipLaunchKernelGGL(k_pack_uniform_i8_fast<false>, dim3((unsigned)gx, (unsigned)gy), dim3(256),
+                hipLaunchKernelGGL(k_pack_uniform_i8_fast<false>, dim3((unsigned)fx, (unsigned)fy, (unsigned)fz), dim3(256),
                                    (size_t)a.C * sizeof(float4), st, a);
             else
-                hipLaunchKernelGGL(k_pack_uniform_i8_fast<true>, dim3((unsigned)gx, (unsigned)gy), dim3(256),
+                hipLaunchKernelGGL(k_pack_uniform_i8_fast<true>, dim3((unsigned)fx, (unsigned)fy, (unsigned)fz), dim3(256),
                                    (size_t)a.C * sizeof(float4), st, a);
             return 0;
         }

@@ -211,6 +211,17 @@ def test_pack_adalog_fast_vs_generic(ops, monkeypatch):
         slow = ops.pack_uniform(xa, su, zu, P, 1, 1, 0, 0, 4, ops.I8, c_inner=c_inner)
         monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
         assert torch.equal(fast, slow), c_inner
+    # per-head candidates (attention q / k operands): grid.z walks the groups; int8 and fp8, 64-byte rows, ragged K
+    xh = torch.randn(24, 197, 61, generator=gen).to(DEV) * 2
+    sh_ = (torch.rand(P, 6, generator=gen) * 0.3 + 0.05).to(DEV)
+    zh = torch.randint(0, 16, (P, 6), generator=gen).float().to(DEV)
+    for dt in (ops.I8, ops.FP8):
+        for c_inner in (True, False):
+            fast = ops.pack_uniform(xh, sh_, zh, P, 6, 6, 1, 0, 4, dt, c_inner=c_inner, k_align=64)
+            monkeypatch.setenv("ADALOG_PACK_GENERIC", "1")
+            slow = ops.pack_uniform(xh, sh_, zh, P, 6, 6, 1, 0, 4, dt, c_inner=c_inner, k_align=64)
+            monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
+            assert torch.equal(fast.float(), slow.float()), (dt, c_inner)       # (values: fp8 has a -0 encoding)
     A3 = torch.softmax(4 * torch.randn(6, 50, 52, generator=gen), -1)
     A3[0, 0, :5] = torch.tensor([0.0, 1e-40, 1e-20, 1.0, 0.5])
     q16 = torch.tensor([10., 11, 23, 36, 37, 38, 53, 64, 77, 90, 100, 111, 120, 130, 136, 137])
