@@ -1432,34 +1432,42 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
     for (int i = tid; i < p.gmod * 256; i += 512) accl[i] = 0.0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    if (w == 7) {
-        // ---------------- loader: the stages of every item of this workgroup, two ahead of the consumers
-        const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
-        int li = blockIdx.x, lst = 0, slot = 0;               // item / stage cursor of the issue side
-        auto stages_of = [&](int item) { const int c = item % NCH; return (min(CB, NB - c * CB) + SB - 1) / SB; };
-        auto issue = [&]() {                                   // one stage: 16 requests of 16 columns x 64 bytes
-            const int g = li / NCH, c = li - g * NCH;
-            const int col0 = (c * CB + lst * SB) * 32;
-            const int64_t left = (int64_t)(p.N - col0) * Kb;
-            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)g * p.sBg + (int64_t)col0 * Kb), 0,
-                                                                                (int)(left < 0 ? 0 : min(left, (int64_t)0x7ffffffe)), 0x00020000);
-            uint8_t* st = ring + slot * SBYTES;
+    // ---------------- issue side (every wave): the stages of this workgroup's items, two ahead of the compute side.
+    // A stage is 16 requests of 16 columns x 64 bytes.  Issuing one costs a wave ~100 cycles, so a single loader wave
+    // (1 600 cycles per stage against ~900 of consumer work) was the bottleneck: the loader keeps requests 7..15 and
+    // consumer w issues request w (an even split, two per wave, measured 5 % slower).
+    const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    int li = blockIdx.x, lst = 0, slot = 0;                   // item / stage cursor of the issue side
+    int ahead = 0;                                             // stages issued and not yet handed over
+    auto stages_of = [&](int item) { const int c = item % NCH; return (min(CB, NB - c * CB) + SB - 1) / SB; };
+    auto issue = [&]() {
+        const int g = li / NCH, c = li - g * NCH;
+        const int col0 = (c * CB + lst * SB) * 32;
+        const int64_t left = (int64_t)(p.N - col0) * Kb;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)g * p.sBg + (int64_t)col0 * Kb), 0,
+                                                                            (int)(left < 0 ? 0 : min(left, (int64_t)0x7ffffffe)), 0x00020000);
+        uint8_t* st = ring + slot * SBYTES;
+        if (w == 7) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) STREAM_DMA(rb, st + q * 1024, (q * 16 + lrow) * Kb + lslot16, 0);
-            slot = slot == NSG - 1 ? 0 : slot + 1;
-            if (++lst == stages_of(li)) { lst = 0; li += gridDim.x; }
-        };
-        int ahead = 0;                                         // stages issued and not yet handed over
-        if (li < items) { issue(); ++ahead; }
-        if (li < items) { issue(); ++ahead; }
+            for (int q = 7; q < 16; ++q) STREAM_DMA(rb, st + q * 1024, (q * 16 + lrow) * Kb + lslot16, 0);
+        } else STREAM_DMA(rb, st + w * 1024, (w * 16 + lrow) * Kb + lslot16, 0);
+        slot = slot == NSG - 1 ? 0 : slot + 1;
+        if (++lst == stages_of(li)) { lst = 0; li += gridDim.x; }
+        ++ahead;
+    };
+    if (li < items) issue();
+    if (li < items) issue();
+
+    if (w == 7) {
+        // ---------------- loader wave: nothing but its share of the requests
         for (int item = blockIdx.x; item < items; item += gridDim.x) {
             const int ns = stages_of(item);
             for (int t = 0; t < ns; ++t) {
-                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // the following stage may still be in flight
+                if (ahead >= 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");    // the following stage's nine may be in flight
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
                 --ahead;
-                if (li < items) { issue(); ++ahead; }
+                if (li < items) issue();
             }
             asm volatile("s_barrier" ::: "memory");                        // item end: column sums are in `red`
         }
@@ -1508,17 +1516,24 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
                     const int coff = n < n_eff ? n * (int)p.ref_cs * 4 : 0x7ffffff0;   // (uniform) past the last column: zeros
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int rr = row0 + 8 * q + 4 * fkg;
                         const v4u uu = __builtin_amdgcn_raw_buffer_load_b128(rrg, roff[q], coff, 0);
-                        const float4 u = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
-                        if (FULL) r[q] = u;
-                        else {
-                            const int sh = rr * 4 - roff[q];   // 0 unless the group of four crosses M (then 4, 8 or 12 bytes)
-                            const float e0 = sh == 0 ? u.x : sh == 4 ? u.y : sh == 8 ? u.z : u.w;
-                            const float e1 = sh == 0 ? u.y : sh == 4 ? u.z : u.w;
-                            const float e2 = sh == 0 ? u.z : u.w;
-                            r[q] = make_float4(rr < p.M ? e0 : 0.f, rr + 1 < p.M ? e1 : 0.f, rr + 2 < p.M ? e2 : 0.f, rr + 3 < p.M ? u.w : 0.f);
-                        }
+                        r[q] = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
+                    }
+                };
+                // ragged row block: the loaded group of four starts at min(row, M - 4); move the elements this lane owns
+                // into place and zero the rows past M.  Done when a set becomes the current one, NOT at the load: there
+                // it would wait for the load it has just issued (and the whole workgroup waits for this wave at the barrier).
+                auto fix_ref = [&](float4 (&r)[4]) {
+                    if (FULL) return;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr = row0 + 8 * q + 4 * fkg;
+                        const float4 u = r[q];
+                        const int sh = rr * 4 - roff[q];       // 0 unless the group of four crosses M (then 4, 8 or 12 bytes)
+                        const float e0 = sh == 0 ? u.x : sh == 4 ? u.y : sh == 8 ? u.z : u.w;
+                        const float e1 = sh == 0 ? u.y : sh == 4 ? u.z : u.w;
+                        const float e2 = sh == 0 ? u.z : u.w;
+                        r[q] = make_float4(rr < p.M ? e0 : 0.f, rr + 1 < p.M ? e1 : 0.f, rr + 2 < p.M ? e2 : 0.f, rr + 3 < p.M ? u.w : 0.f);
                     }
                 };
                 int n = blk0 / NJ;                             // chunks start on a reference column (CB % 8 == 0, NJ | 8)
@@ -1527,8 +1542,19 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
                 float4 rr2[2][4];
                 load_ref(n, rr2[0]);
                 load_ref(n + 1, rr2[1]);
+                fix_ref(rr2[0]);
                 for (int t = 0; t < ns; ++t) {
+                    // this wave's request of the stage has landed once only what was issued after it can be outstanding:
+                    // the following stage's request and the R reference loads of the previous stage (the first stage of
+                    // an item comes after the item's set-up loads: drain)
+                    constexpr int R = (SB / NJ) * 4;
+                    if (t == 0 || ahead < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (R == 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                    else if (R == 8) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
                     asm volatile("s_barrier" ::: "memory");
+                    --ahead;
+                    if (li < items) issue();
                     const uint8_t* cur = ring + st * SBYTES;
                     uint4 b0n = lds_frag(cur, swz3(frow, fkg)), b1n = lds_frag(cur, swz3(frow, 2 + fkg));
 #pragma unroll
@@ -1560,15 +1586,24 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
                             if (NJ == 8) {
 #pragma unroll
                                 for (int q = 0; q < 4; ++q) rr2[0][q] = rr2[1][q];
+                                fix_ref(rr2[0]);
                                 load_ref(n + 1, rr2[1]);
-                            } else load_ref(n + 1, rr2[set]);   // this set is free now; the other one holds column n
+                            } else {
+                                fix_ref(rr2[set ^ 1]);         // the other set holds column n: it becomes the current one
+                                load_ref(n + 1, rr2[set]);     // this set is free now
+                            }
                         }
                     }
                     st = st == NSG - 1 ? 0 : st + 1;
                 }
             };
             if (!rowblock_live) {                              // (never for the launches this kernel takes)
-                for (int t = 0; t < ns; ++t) { asm volatile("s_barrier" ::: "memory"); st = st == NSG - 1 ? 0 : st + 1; }
+                for (int t = 0; t < ns; ++t) {
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    --ahead;
+                    if (li < items) issue();
+                    st = st == NSG - 1 ? 0 : st + 1;
+                }
             } else if (full_rows) run(std::true_type{});
             else run(std::false_type{});
             // item end: pair up the lanes, park the sums, one thread per candidate adds them in a fixed wave order

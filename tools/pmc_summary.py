@@ -4,6 +4,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 root = sys.argv[1]
@@ -19,7 +20,8 @@ for d in sorted(glob.glob(os.path.join(root, "*_*_*"))):
         for row in csv.DictReader(open(f)):
             if KERNEL in row["Kernel_Name"]:
                 acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
-                dst["kernel"] = row["Kernel_Name"].split("(")[0][-40:]
+                m = re.search(r"k_gemm_\w+<[^>]*>", row["Kernel_Name"])
+                dst["kernel"] = m.group(0) if m else row["Kernel_Name"][:60]
         for k, v in acc.items():
             dst[k] = sum(v) / len(v)
     for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):

@@ -15,6 +15,22 @@ N, T, P = 32, 197, 128
 M = N * T
 S = ops.Strided
 which = sys.argv[1] if len(sys.argv) > 1 else "qkv"
+if which == "qk":                   # attention q.k^T search: 192 (image, head) groups, fp8 storage, group kernel
+    G, H, D = N * 6, 6, 64
+    q = torch.randn(G, T, D, device=dev)
+    k = torch.randn(G, T, D, device=dev)
+    sq, zq = torch.full((H,), 0.3, device=dev), torch.full((H,), 8.0, device=dev)
+    cs = torch.rand(P, H, device=dev) * 0.2 + 0.2
+    cz = torch.randint(4, 12, (P, H), device=dev).float()
+    qp = ops.pack_uniform(q, sq, zq, 1, 0, H, 1, 0, 4, ops.FP8, k_align=64)
+    kc = ops.pack_uniform(k, cs, cz, P, H, H, 1, 0, 4, ops.FP8, c_inner=True, k_align=64)
+    ref3 = torch.randn(G, T, T, device=dev)
+    for _ in range(3):
+        ops.gemm_score(ops.FP8, qp, kc, T, T, P, G, H, ref3, S(sq, g=1), S(cs, c=H, g=1), None, True, False, 1.0,
+                       ref_div=P, order=2, ref_transposed=True)
+    torch.cuda.synchronize()
+    print("done")
+    sys.exit(0)
 I, O = {"qkv": (384, 1152), "fc2": (1536, 384), "proj": (384, 384)}[which]
 x = torch.randn(1, M, I, device=dev)
 W = torch.randn(1, O, I, device=dev) * 0.05
