@@ -1,16 +1,17 @@
 #!/bin/bash
 # PMC passes over the scoring GEMM at the deit_small qkv / fc2 / q.k^T search shapes (slab, streaming and group kernels) (run on the GPU box from the repo root):
-#   bash tools/pmc_gemm.sh <out_dir>
+#   bash tools/pmc_gemm.sh <out_dir> ["qkv fc2 qk"]
 # One rocprofv3 --pmc run per counter group (the TCC byte counters do not fit one pass; no trace domains alongside --pmc),
 # then tools/pmc_summary.py averages the per-dispatch values of the GEMM kernel.
 set -u
 out=${1:-gpurun_out/pmc_stream}
+shapes=${2:-"qkv fc2 qk"}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 groups=("FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
         "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
         "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE")
-for shape in qkv fc2 qk; do
+for shape in $shapes; do
   for mode in w a; do
     if [ "$shape" = qk ] && [ "$mode" = w ]; then continue; fi
     i=0
