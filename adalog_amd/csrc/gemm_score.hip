@@ -1627,6 +1627,210 @@ __global__ __launch_bounds__(512, NJ == 8 ? 2 : 4) void k_gemm_grp(GemmArgs p) {
 #endif
 }
 
+// The same organisation for groups with several K-steps (the softmax.v weight search: bf16, K = 197 keys = 7 steps, 197
+// attention rows per group, 64 x P candidate columns): a consumer keeps the NK x 2 fragments of its row block in
+// registers for an item, a stage is 2 column blocks x all of K (NK x 4 requests of 16 columns x 64 bytes; consumer w
+// issues two of them, the loader the rest), and a block is 2 NK MFMAs against the same 16-value epilogue.
+template <int NJ, int NK>
+__global__ __launch_bounds__(512, 2) void k_gemm_grpk(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NSG = 3, SB = 2, SBYTES = NK * SB * 32 * BK3;   // ring stages, blocks per stage, bytes per stage
+    constexpr int RQ = NK * SB * 2, CQ = 2;                    // requests per stage, requests per consumer
+    constexpr int STG = NJ / SB > 0 ? NJ / SB : 1;             // stages per reference column
+    constexpr int P = NJ * 32;
+    static_assert(RQ > 7 * CQ, "the loader needs a share");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    uint8_t* ring = lds;                                                        // [NSG][NK][64 columns][64 bytes]
+    float* red = reinterpret_cast<float*>(lds + NSG * SBYTES);                  // [7 waves][P]
+    double* accl = reinterpret_cast<double*>(lds + NSG * SBYTES + 7 * P * 4);   // [gmod][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int frow = lane & 31, fkg = lane >> 5;
+    const int Kb = (int)p.Kb;
+    const int NB = p.N >> 5;
+    const int CB = p.slab_R, NCH = p.slab_U;
+    const int items = p.G * NCH;
+    const int n_eff = p.N / P;
+    for (int i = tid; i < p.gmod * 256; i += 512) accl[i] = 0.0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
+    int li = blockIdx.x, lst = 0, slot = 0, ahead = 0;
+    auto stages_of = [&](int item) { const int c = item % NCH; return (min(CB, NB - c * CB) + SB - 1) / SB; };
+    auto issue = [&]() {
+        const int g = li / NCH, c = li - g * NCH;
+        const int col0 = (c * CB + lst * SB) * 32;
+        const int64_t left = (int64_t)(p.N - col0) * Kb;
+        const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(p.B + (int64_t)g * p.sBg + (int64_t)col0 * Kb), 0,
+                                                                            (int)(left < 0 ? 0 : min(left, (int64_t)0x7ffffffe)), 0x00020000);
+        uint8_t* st = ring + slot * SBYTES;
+        // request r: K-step r / 4, columns 16 * (r % 4) .. + 15
+        if (w == 7) {
+#pragma unroll
+            for (int r = 7 * CQ; r < RQ; ++r) STREAM_DMA(rb, st + r * 1024, ((r & 3) * 16 + lrow) * Kb + lslot16, (r >> 2) * BK3);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CQ; ++i) {
+                const int r = w * CQ + i;
+                STREAM_DMA(rb, st + r * 1024, ((r & 3) * 16 + lrow) * Kb + lslot16, (r >> 2) * BK3);
+            }
+        }
+        slot = slot == NSG - 1 ? 0 : slot + 1;
+        if (++lst == stages_of(li)) { lst = 0; li += gridDim.x; }
+        ++ahead;
+    };
+    if (li < items) issue();
+    if (li < items) issue();
+
+    if (w == 7) {
+        for (int item = blockIdx.x; item < items; item += gridDim.x) {
+            const int ns = stages_of(item);
+            for (int t = 0; t < ns; ++t) {
+                if (ahead >= 2) {
+                    if (RQ - 7 * CQ == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+                    else if (RQ - 7 * CQ == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                --ahead;
+                if (li < items) issue();
+            }
+            asm volatile("s_barrier" ::: "memory");
+        }
+    } else {
+        const int row0 = w * 32;
+        const bool rowblock_live = row0 < p.M;
+        int st = 0;
+        for (int item = blockIdx.x; item < items; item += gridDim.x) {
+            const int g = item / NCH, c = item - g * NCH, gh = g % p.gmod;
+            const int blk0 = c * CB, nblk = min(CB, NB - blk0), ns = (nblk + SB - 1) / SB;
+            uint4 af[NK][2];
+            {
+                const bool ok = row0 + frow < p.M;
+                const uint8_t* ar = p.A + (int64_t)g * p.sAg + (int64_t)min(row0 + frow, p.M - 1) * Kb;
+#pragma unroll
+                for (int kt = 0; kt < NK; ++kt) {
+                    af[kt][0] = *reinterpret_cast<const uint4*>(ar + kt * BK3 + fkg * 16);
+                    af[kt][1] = *reinterpret_cast<const uint4*>(ar + kt * BK3 + 32 + fkg * 16);
+                    if (!ok) { af[kt][0] = make_uint4(0, 0, 0, 0); af[kt][1] = af[kt][0]; }
+                }
+            }
+            float nal[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int ci = j * 32 + frow;
+                nal[j] = -(p.sa[ci * p.sa_c + gh * p.sa_g] * p.sa_mul * p.sb[ci * p.sb_c + gh * p.sb_g]);
+            }
+            const uint32_t ref_bytes = (uint32_t)(((int64_t)(n_eff - 1) * p.ref_cs + p.M) * 4);
+            const __amdgpu_buffer_rsrc_t rrg = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ref + (int64_t)g * p.sRg), 0, (int)ref_bytes, 0x00020000);
+            const bool full_rows = row0 + 32 <= p.M;
+            int roff[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) roff[q] = min(row0 + 8 * q + 4 * fkg, p.M - 4) * 4;
+            v2f cs2[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cs2[j] = (v2f){0.0f, 0.0f};
+            auto run = [&](auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                auto load_ref = [&](int n, float4 (&r)[4]) {
+                    const int coff = n < n_eff ? n * (int)p.ref_cs * 4 : 0x7ffffff0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const v4u uu = __builtin_amdgcn_raw_buffer_load_b128(rrg, roff[q], coff, 0);
+                        r[q] = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
+                    }
+                };
+                auto fix_ref = [&](float4 (&r)[4]) {
+                    if (FULL) return;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int rr = row0 + 8 * q + 4 * fkg;
+                        const float4 u = r[q];
+                        const int sh = rr * 4 - roff[q];
+                        const float e0 = sh == 0 ? u.x : sh == 4 ? u.y : sh == 8 ? u.z : u.w;
+                        const float e1 = sh == 0 ? u.y : sh == 4 ? u.z : u.w;
+                        const float e2 = sh == 0 ? u.z : u.w;
+                        r[q] = make_float4(rr < p.M ? e0 : 0.f, rr + 1 < p.M ? e1 : 0.f, rr + 2 < p.M ? e2 : 0.f, rr + 3 < p.M ? u.w : 0.f);
+                    }
+                };
+                int n = blk0 / NJ;
+                float4 rc[4], rn[4];                           // current / next reference column
+                load_ref(n, rc);
+                load_ref(n + 1, rn);
+                fix_ref(rc);
+                for (int tg = 0; tg < ns; tg += STG) {
+#pragma unroll
+                    for (int s = 0; s < STG; ++s) {
+                        // behind this wave's CQ requests of the stage: the next stage's CQ and the reference loads of
+                        // the two stages in between (at least 8 / 4 / 0 of them for NJ = 2 / 4 / 8)
+                        if ((tg == 0 && s == 0) || ahead < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        else if (NJ == 2) { if (CQ == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); }
+                        else if (NJ == 4) { if (CQ == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); }
+                        else { if (CQ == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+                        asm volatile("s_barrier" ::: "memory");
+                        --ahead;
+                        if (li < items) issue();
+                        const uint8_t* cur = ring + st * SBYTES;
+#pragma unroll
+                        for (int b = 0; b < SB; ++b) {
+                            const int j = (s * SB + b) % NJ;
+                            v16f acc;
+#pragma unroll
+                            for (int kt = 0; kt < NK; ++kt) {
+                                const uint8_t* ks = cur + kt * (SB * 32 * BK3);
+                                const uint4 b0 = lds_frag(ks, swz3(b * 32 + frow, fkg)), b1 = lds_frag(ks, swz3(b * 32 + frow, 2 + fkg));
+                                if (kt == 0) acc = mma0<1>(af[0][0], b0); else mma<1>(af[kt][0], b0, acc);
+                                mma<1>(af[kt][1], b1, acc);
+                            }
+                            const v2f na = {nal[j], nal[j]};
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const v2f tA = {acc[q * 4 + 0], acc[q * 4 + 1]}, tB = {acc[q * 4 + 2], acc[q * 4 + 3]};
+                                const v2f rA = {rc[q].x, rc[q].y}, rB = {rc[q].z, rc[q].w};
+                                const v2f dA = tA * na + rA, dB = tB * na + rB;
+                                cs2[j] += dA * dA; cs2[j] += dB * dB;
+                            }
+                            if (j == NJ - 1) {                 // next block starts the next reference column
+                                ++n;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) rc[q] = rn[q];
+                                fix_ref(rc);
+                                load_ref(n + 1, rn);
+                            }
+                        }
+                        st = st == NSG - 1 ? 0 : st + 1;
+                    }
+                }
+            };
+            if (!rowblock_live) {
+                for (int t = 0; t < ns; ++t) {
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    --ahead;
+                    if (li < items) issue();
+                    st = st == NSG - 1 ? 0 : st + 1;
+                }
+            } else if (full_rows) run(std::true_type{});
+            else run(std::false_type{});
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                float cs = cs2[j].x + cs2[j].y;
+                cs += __shfl_xor(cs, 32);
+                if (fkg == 0) red[w * P + j * 32 + frow] = cs;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (tid < P) {
+                double v = 0.0;
+                const int nw = min(7, (p.M + 31) / 32);
+                for (int ww = 0; ww < nw; ++ww) v += (double)red[ww * P + tid];
+                accl[gh * 256 + tid] += v;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    for (int i = tid; i < p.gmod * 256; i += 512) p.wg_acc[(int64_t)blockIdx.x * p.gmod * 256 + i] = accl[i];
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ finish
 // scores[c][h?][n?] = -norm * sum over (image = g / gmod, [h], m-tile, [n]) of partial[c][g][mt][n]   in fp64,
 // fixed summation order: each thread takes a strided subset, then a fixed LDS tree.
@@ -1882,6 +2086,15 @@ static bool grp_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_
            (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
 }
 
+// ... and of its several-K-steps form: bf16, exactly 7 K-steps (K = 193..224 elements: the 197 tokens of a 224 x 224 ViT).
+static bool grpk_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
+                    const float* row_scale, int64_t sb_n, int64_t ref_cs) {
+    static const int use_grp = getenv("ADALOG_GEMM_GRP") ? atoi(getenv("ADALOG_GEMM_GRP")) : 1;
+    return use_grp && dtype == 1 && kvalid_bytes > 6 * BK3 && kvalid_bytes <= 7 * BK3 && M > 128 && M <= 224 && G >= 8 && gmod <= 8 &&
+           !bias && !row_scale && sb_n == 0 && (ref_div == 64 || ref_div == 128 || ref_div == 256) && N % ref_div == 0 &&
+           (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
+}
+
 // M, N: GEMM rows / columns (N includes the candidate factor when ref_div > 1).  Outputs the partial-buffer layout
 // [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
 extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype,
@@ -1989,6 +2202,25 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         if (dtype == 3) { if (ref_div == 64) LAUNCH_GRP(2, 3); else if (ref_div == 128) LAUNCH_GRP(4, 3); else LAUNCH_GRP(8, 3); }
         else { if (ref_div == 64) LAUNCH_GRP(2, 0); else if (ref_div == 128) LAUNCH_GRP(4, 0); else LAUNCH_GRP(8, 0); }
 #undef LAUNCH_GRP
+    } else if (L.stream && !out && L.acc && grpk_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs)) {
+        // group kernel, 7 K-steps (softmax.v weight search)
+        const int NB = N / 32;
+        const int nch0 = cdiv((int64_t)3 * L.wgs, G);
+        const int CB = cdiv(cdiv(NB, nch0 < 1 ? 1 : nch0), 8) * 8;
+        p.slab_R = CB; p.slab_U = cdiv(NB, CB);
+        const size_t shm = (size_t)3 * 7 * 2 * 32 * BK3 + (size_t)7 * ref_div * 4 + (size_t)gmod * 256 * 8;
+#define LAUNCH_GRPK(NJV)                                                                                          \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_grpk<NJV, 7>),                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            hipLaunchKernelGGL((k_gemm_grpk<NJV, 7>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);              \
+        } while (0)
+        if (ref_div == 64) LAUNCH_GRPK(2); else if (ref_div == 128) LAUNCH_GRPK(4); else LAUNCH_GRPK(8);
+#undef LAUNCH_GRPK
     } else if (L.stream && !out) {
         // persistent streaming kernel: two (wide form: one) workgroups per CU walk the tile list
         {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)

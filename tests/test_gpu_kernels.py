@@ -648,6 +648,32 @@ def test_gemm_group_kernel(ops, dtype, P):
             assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, G, K, keep_h, rel_err(got.cpu(), want))
 
 
+@pytest.mark.parametrize("P", [64, 128, 256])
+def test_gemm_group_kernel_k_steps(ops, P):
+    """Group kernel with seven K-steps (softmax.v weight search: bf16, K = 197, 129..224 rows, 64 x P columns per
+    group): ragged and exact row blocks, ragged K, chunks that end inside the column range, head-wise and tensor-wise
+    scores -- against the CPU specification."""
+    gen = g(6300 + P)
+    gmod = 6
+    for M, Ncols, G, K in ((197, 64, 12, 197), (160, 11, 24, 200), (224, 5, 18, 224)):
+        Kp = CB.pad_k(K, CB.BF16, 64)
+        A = torch.zeros(1, G, M, Kp, dtype=torch.bfloat16); B = torch.zeros(1, G, Ncols * P, Kp, dtype=torch.bfloat16)
+        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).to(torch.bfloat16)
+        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).to(torch.bfloat16)
+        ref = torch.randn(G, Ncols, M, generator=gen) * 3                      # stored [G, N, M] (transposed)
+        sa = torch.rand(gmod, generator=gen) * 0.02 + 0.01
+        sb = torch.rand(P, gmod, generator=gen) * 0.5 + 0.5
+        Ad, Bd = A.to(DEV), B.to(DEV)
+        Ad.k_valid = K; Bd.k_valid = K
+        for keep_h in (True, False):
+            want = CB.gemm_score(CB.BF16, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa, g=1), CB.Strided(sb, c=gmod, g=1), None,
+                                 keep_h, False, 0.01, sa_mul=0.5, ref_div=P, ref_transposed=True)
+            got = ops.gemm_score(ops.BF16, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV), g=1),
+                                 ops.Strided(sb.to(DEV), c=gmod, g=1), None, keep_h, False, 0.01, sa_mul=0.5, ref_div=P,
+                                 order=2, ref_transposed=True)
+            assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, G, K, keep_h, rel_err(got.cpu(), want))
+
+
 def test_sharded_select_matches_fused(ops):
     """adalog_select_* (histograms summed over emulated ranks between counting and pick) == the fused single-process
     kernels == the CPU specification, for every shard/chunk layout the grids use, and for the positive percentile."""
