@@ -72,7 +72,7 @@ class GemmProfiler:
 
 
 # scoring-GEMM kernels by operand type: the roofline object covers every launch of the dominant type
-KERNELS = {0: "k_gemm_slab + k_gemm_stream<i8> + k_gemm_grp<i8>", 1: "k_gemm_stream<bf16>", 2: "k_gemm_stream<f32>",
+KERNELS = {0: "k_gemm_slab + k_gemm_stream<i8> + k_gemm_grp<i8>", 1: "k_gemm_stream<bf16> + k_gemm_grpk<bf16>", 2: "k_gemm_stream<f32>",
            3: "k_gemm_grp<fp8> + k_gemm_stream<fp8>"}
 
 
@@ -87,15 +87,17 @@ def pmc_traffic(dom):
     except OSError:
         return None
     def dtype_of(name):
-        # k_gemm_stream<DT, RI, NW, NS>; k_gemm_slab<NREF, ROWS> is int8 only; k_gemm_grp<NJ, DT>
+        # k_gemm_stream<DT, RI, NW, NS>; k_gemm_slab<NREF, ROWS, DT>; k_gemm_grp<NJ, DT>; k_gemm_grpk<NJ, NK> is bf16
         try:
             args = name[name.index("<") + 1:name.index(">")].split(",")
             if name.startswith("k_gemm_stream<"):
                 return int(args[0])
             if name.startswith("k_gemm_slab<"):
-                return 0
+                return int(args[2])
             if name.startswith("k_gemm_grp<"):
                 return int(args[1])
+            if name.startswith("k_gemm_grpk<"):
+                return 1
         except (ValueError, IndexError):
             pass
         return None
