@@ -102,7 +102,9 @@ int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int6
  * Layout of `partial`: [C][G][MT][Npad] for C > 1 launches, [G][MT][Npad][ref_div] (candidate innermost: coalesced
  * stores) for ref_div > 1 launches -- pass cand_inner = 1 to adalog_finish_scores for the latter; adalog_gemm_score_layout returns its size and (MT, Npad) for the given
  * problem (tilings: 128x128 for C > 1; (64..256)x256 when C = 1 -- the row count of a tile depends on M and, for the
- * streaming kernel, on the dtype / k_valid / reference orientation of the launch, so pass the same values here). */
+ * streaming kernel, on the dtype / k_valid / reference orientation of the launch, so pass the same values here; for
+ * the slab kernel -- int8 / fp8 storage, K <= 384 bytes, one group -- MT is the number of pieces a 256-column slab can be
+ * cut into by the workgroups' ranges, and the launch clears `partial` itself). */
 int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype, int64_t Kp,
                                  int64_t k_valid, int ref_transposed, int* MT, int* Npad, int* mode);
 /* -> number of floats `partial` must hold (8-byte aligned); *mode is what to pass as `cand_inner` to adalog_finish_scores:
