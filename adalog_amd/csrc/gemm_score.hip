@@ -1954,19 +1954,19 @@ __global__ __launch_bounds__(256) void k_finish_stage2(FinishArgs p, const doubl
     if (lane == 0) p.scores[(int64_t)c * nh + h] = (float)(-p.norm * acc);
 }
 
-// Finish for per-workgroup accumulators acc[wg][head][256] (fp64): one wavefront per output (candidate, head); terms =
-// (workgroup, [head], column replica with col % cin == candidate) in a fixed lane-strided order.
+// Finish for per-workgroup accumulators acc[wg][head][256] (fp64): one 256-thread block per output (candidate, head);
+// terms = (workgroup, [head], column replica with col % cin == candidate), thread-strided, then a fixed LDS tree.
+// (One wavefront per output looped 16 times over dependent loads: 10 us; this form is bound by the launch itself.)
 __global__ __launch_bounds__(256) void k_finish_wgacc(FinishArgs p, const double* acc, int nwg) {
+    __shared__ double red[4];
     const int nh = p.keep_h ? p.gmod : 1;
-    const int lane = threadIdx.x & 63;
-    const int oid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (oid >= p.C * nh) return;
+    const int oid = blockIdx.x;
     const int h = oid % nh, c = oid / nh;
     const int reps = 256 / p.cin, h_lo = p.keep_h ? h : 0, h_cnt = p.keep_h ? 1 : p.gmod;
     const int per_wg = h_cnt * reps;
     const int64_t total = (int64_t)nwg * per_wg;
     double sum = 0.0;
-    for (int64_t i = lane; i < total; i += 64) {
+    for (int64_t i = threadIdx.x; i < total; i += 256) {
         const int r = (int)(i % per_wg);
         const int64_t wg = i / per_wg;
         const int hh = h_lo + r / reps, rep = r % reps;
@@ -1974,7 +1974,9 @@ __global__ __launch_bounds__(256) void k_finish_wgacc(FinishArgs p, const double
     }
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
-    if (lane == 0) p.scores[(int64_t)c * nh + h] = (float)(-p.norm * sum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) p.scores[(int64_t)c * nh + h] = (float)(-p.norm * ((red[0] + red[1]) + (red[2] + red[3])));
 }
 
 }  // namespace
@@ -2323,7 +2325,7 @@ extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT,
     if (cand_inner == 2) {                  // per-workgroup accumulators: partial = double [MT = workgroups][gmod][256]
         ADALOG_ARG_CHECK(!keep_n && (C == 64 || C == 128 || C == 256) && Npad == 256, "finish_scores: bad accumulator layout");
         const int64_t nout2 = (int64_t)C * (keep_h ? gmod : 1);
-        hipLaunchKernelGGL(k_finish_wgacc, dim3((unsigned)((nout2 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+        hipLaunchKernelGGL(k_finish_wgacc, dim3((unsigned)nout2), dim3(256), 0, (hipStream_t)stream, p,
                            (const double*)partial, MT);
         ADALOG_LAUNCH_CHECK("adalog_finish_scores");
         return 0;
