@@ -1,3 +1,8 @@
+#!/bin/bash
+# End-of-round validation on the GPU box (run from the repo root, e.g. gpurun -- 'bash tools/final_run.sh'):
+# the -m gpu test suite, the default bench line, a rocprofv3 kernel-stats pass, the PMC traffic passes, and one
+# calibration each of the other model families / bit widths.  Everything lands under gpurun_out/final/; the summaries
+# that are kept go to profiles/r01_* by hand.
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 mkdir -p gpurun_out/final
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/final/pytest_gpu.log
