@@ -301,10 +301,9 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         return be.pack_adalog(A3, scale, qv, C, 1 if C > 1 else 0, 1, 0, self.A_quantizer.n_bits,
                               self._mant37(A3.device), shift=None, clamp_u=clamp_u, c_inner=c_inner, k_align=k_align)
 
-    def _search_best_A_log_base(self):
-        """matmul.py:321-358: 128 bases q = 10..137, per-tensor score, commit the best."""
+    def _score_A_log_base(self):
+        """matmul.py:321-351 -> (q_all [P], scores [P, 1]): per-tensor output MSE of the 128 log bases q = 10..137."""
         be = backend.get()
-        aq = self.A_quantizer
         H = self._heads()
         pg = 1 if H > 1 else 0
         G, S, K, Sp = self._dims()
@@ -325,7 +324,13 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
                                      Strided(self.B_quantizer.scale.data.view(-1), g=pg), Strided(ones[s0:e].contiguous(), c=1),
                                      None, False, False, 1.0 / (A.shape[1] * S * Sp), sa_mul=self._ts32(),
                                      ref_div=e - s0, order=2, ref_transposed=True))
-        scores = out[0] if len(out) == 1 else torch.cat(out, 0)
+        return q_all, (out[0] if len(out) == 1 else torch.cat(out, 0))
+
+    def _search_best_A_log_base(self):
+        """matmul.py:321-358: score the 128 bases, commit the best."""
+        be = backend.get()
+        aq = self.A_quantizer
+        q_all, scores = self._score_A_log_base()
         idx = search.argbest(scores, 1)
         best_q = be.fpcs_next(q_all.view(-1, 1), None, None, idx, 1, 0, None, None, None)[0]
         aq.q.data.copy_(best_q.view(aq.q.shape).to(aq.q.dtype))

@@ -478,6 +478,14 @@ def fpcs(scales, zps, score_fn: Callable, cand_dim: int, steps=6, width=16, eq_n
 
 
 # ====================================================================== layer searches
+def _obs(observer, kind, p, a, b, s):
+    """Report one scoring call to a test observer: (kind, parameters in force, the two candidate tensors, scores).
+    Called right after every score function, i.e. once per Trace entry and in the same order."""
+    if observer is not None:
+        observer(kind, p, a, b, s)
+    return s
+
+
 @dataclass
 class LinearParams:
     w_scale: torch.Tensor = None      # [n_V, rows, 1]
@@ -494,7 +502,7 @@ def _w_fq(w3, p: LinearParams, bits):
 
 
 def search_linear(weight, bias, x, raw_out, w_bit, a_bit, n_V=1, rounds=3, steps=6, eq_n=128, batch=32,
-                  trace: Optional[Trace] = None, a_init=None) -> LinearParams:
+                  trace: Optional[Trace] = None, a_init=None, observer=None) -> LinearParams:
     """AsymmetricallyBatchingQuantLinear.hyperparameter_searching, linear.py:525-545 (fpcs=True)."""
     O, I = weight.shape
     w3 = weight.view(n_V, O // n_V, I)
@@ -511,20 +519,21 @@ def search_linear(weight, bias, x, raw_out, w_bit, a_bit, n_V=1, rounds=3, steps
         s, z = fpcs(sc, zp, score, -1, steps, 16, eq_n, 1e-4, trace)
         p.a_scale, p.a_zp = s.squeeze(-1), z.squeeze(-1).float()
 
-    w_search(lambda sc, zp: score_w_self(w3, sc, zp, w_bit))
-    a_search(lambda sc, zp: score_a_self(x, sc, zp, a_bit, False, batch))
+    w_search(lambda sc, zp: _obs(observer, "w_self", p, sc, zp, score_w_self(w3, sc, zp, w_bit)))
+    a_search(lambda sc, zp: _obs(observer, "a_self", p, sc, zp, score_a_self(x, sc, zp, a_bit, False, batch)))
     for _ in range(rounds):
         xq = uniform_fake_quant(x, p.a_scale, p.a_zp, a_bit)[0]
-        w_search(lambda sc, zp: score_w(xq, w3, bias, raw_out, sc, zp, w_bit, batch))
+        w_search(lambda sc, zp: _obs(observer, "w_out", p, sc, zp, score_w(xq, w3, bias, raw_out, sc, zp, w_bit, batch)))
         wq = _w_fq(w3, p, w_bit).view(O, I)
-        a_search(lambda sc, zp: score_a(x, wq, bias, raw_out, sc, zp, a_bit, batch))
+        a_search(lambda sc, zp: _obs(observer, "a_out", p, sc, zp, score_a(x, wq, bias, raw_out, sc, zp, a_bit, batch)))
     return p
 
 
-def search_linear_channelwise(x, a_bit, steps=6, eq_n=128, batch=32, trace=None):
+def search_linear_channelwise(x, a_bit, steps=6, eq_n=128, batch=32, trace=None, observer=None):
     """AsymmetricallyChannelWiseBatchingQuantLinear.hyperparameter_searching, linear.py:585-594."""
     sc, zp = activation_candidates(x, a_bit, True, eq_n)
-    s, z = fpcs(sc, zp, lambda a, b: score_a_self(x, a, b, a_bit, True, batch), -1, steps, 16, eq_n, 1e-4, trace)
+    s, z = fpcs(sc, zp, lambda a, b: _obs(observer, "a_self_cw", None, a, b, score_a_self(x, a, b, a_bit, True, batch)),
+                -1, steps, 16, eq_n, 1e-4, trace)
     return s.squeeze(-1), z.squeeze(-1).float()
 
 
@@ -545,7 +554,7 @@ def reparam_step1(a_scale, a_zp, ln_weight, ln_bias, weight, bias):
 
 
 def search_postgelu(weight, bias, x, raw_out, w_bit, a_bit, rounds=3, steps=6, eq_n=128, batch=32,
-                    trace: Optional[Trace] = None) -> LinearParams:
+                    trace: Optional[Trace] = None, observer=None) -> LinearParams:
     """PostGeluLogBasedBatchingQuantLinear.hyperparameter_searching, linear.py:969-997 (fpcs=True)."""
     O, I = weight.shape
     w3 = weight.view(1, O, I)
@@ -559,7 +568,7 @@ def search_postgelu(weight, bias, x, raw_out, w_bit, a_bit, rounds=3, steps=6, e
         s, z = fpcs(sc, zp, score, 0, steps, 16, eq_n, None, trace, shape_w)
         p.w_scale, p.w_zp = s.squeeze(0), z.squeeze(0).float()
 
-    w_search(lambda sc, zp: score_w_self(w3, sc, zp, w_bit))
+    w_search(lambda sc, zp: _obs(observer, "w_self", p, sc, zp, score_w_self(w3, sc, zp, w_bit)))
     ud, sc_all = postgelu_candidates(x, shift.item(), eq_n)
     p.a_scale = sc_all[:, -2].clone()
     p.a_q = 37
@@ -569,6 +578,7 @@ def search_postgelu(weight, bias, x, raw_out, w_bit, a_bit, rounds=3, steps=6, e
         q_all = torch.tensor([i for i in range(10, 11 + eq_n)]).view(1, -1)
         s0 = score_postgelu(x, wq, bias, raw_out, p.a_scale.view(1, 1).expand(1, eq_n), q_all[:, :eq_n],
                             shift, a_bit, table, batch)
+        _obs(observer, "a_logbase", p, p.a_scale.view(1, 1).expand(1, eq_n), q_all[:, :eq_n], s0)
         _, qi = torch.topk(s0, k=8, dim=-1)
         if trace is not None:
             trace.add(s0, 8, qi)
@@ -579,7 +589,8 @@ def search_postgelu(weight, bias, x, raw_out, w_bit, a_bit, rounds=3, steps=6, e
         width, new_cnt = 32, int(eq_n / 32)
 
         def sel(scs, qs, k):
-            s = score_postgelu(x, wq, bias, raw_out, scs, qs, shift, a_bit, table, batch)
+            s = _obs(observer, "a_logbase", p, scs, qs,
+                     score_postgelu(x, wq, bias, raw_out, scs, qs, shift, a_bit, table, batch))
             _, idx = torch.topk(s, k=k, dim=-1)
             if trace is not None:
                 trace.add(s, k, idx)
@@ -597,7 +608,7 @@ def search_postgelu(weight, bias, x, raw_out, w_bit, a_bit, rounds=3, steps=6, e
         p.a_scale, p.a_q = ts.squeeze(-1), int(tq.item())
         t1, t2 = adalog_tables(p.a_q, a_bit)
         xq = shift_adalog_fake_quant(x, p.a_scale, p.a_q, a_bit, shift, False, (t1, t2))[0]
-        w_search(lambda sc, zp: score_w(xq, w3, bias, raw_out, sc, zp, w_bit, batch))
+        w_search(lambda sc, zp: _obs(observer, "w_out", p, sc, zp, score_w(xq, w3, bias, raw_out, sc, zp, w_bit, batch)))
     return p
 
 
@@ -617,7 +628,7 @@ class MatMulParams:
 
 
 def search_matmul(A, B, raw_out, A_bit, B_bit, rounds=3, steps=6, eq_n=128, batch=32,
-                  trace: Optional[Trace] = None) -> MatMulParams:
+                  trace: Optional[Trace] = None, observer=None) -> MatMulParams:
     """AsymmetricallyBatchingQuantMatMul.hyperparameter_searching, matmul.py:264-283 (head-wise, fpcs)."""
     H = A.shape[1]
     p = MatMulParams()
@@ -629,19 +640,21 @@ def search_matmul(A, B, raw_out, A_bit, B_bit, rounds=3, steps=6, eq_n=128, batc
     for _ in range(rounds):
         Bq = uniform_fake_quant(B, p.B_scale, p.B_zp, B_bit)[0]
         s, z = fpcs(*matmul_candidates(A, B_bit, True, eq_n),
-                    lambda sc, zp: score_matmul(A, B, raw_out, sc, zp, A_bit, "A", Bq, True, batch),
+                    lambda sc, zp: _obs(observer, "A", p, sc, zp,
+                                        score_matmul(A, B, raw_out, sc, zp, A_bit, "A", Bq, True, batch)),
                     0, steps, 16, eq_n, None, trace, shp)
         p.A_scale, p.A_zp = s.view(1, H, 1, 1), z.view(1, H, 1, 1).float()
         Aq = uniform_fake_quant(A, p.A_scale, p.A_zp, A_bit)[0]
         s, z = fpcs(*matmul_candidates(B, B_bit, True, eq_n),
-                    lambda sc, zp: score_matmul(A, B, raw_out, sc, zp, B_bit, "B", Aq, True, batch),
+                    lambda sc, zp: _obs(observer, "B", p, sc, zp,
+                                        score_matmul(A, B, raw_out, sc, zp, B_bit, "B", Aq, True, batch)),
                     0, steps, 16, eq_n, None, trace, shp)
         p.B_scale, p.B_zp = s.view(1, H, 1, 1), z.view(1, H, 1, 1).float()
     return p
 
 
 def search_postsoftmax(A, B, raw_out, A_bit, B_bit, rounds=3, steps=6, eq_n=128, batch=32,
-                       trace: Optional[Trace] = None) -> MatMulParams:
+                       trace: Optional[Trace] = None, observer=None) -> MatMulParams:
     """PostSoftmaxAsymmetricallyBatchingQuantMatMul.hyperparameter_searching, matmul.py:360-378."""
     H = A.shape[1]
     p = MatMulParams(A_scale=torch.ones(1, 1, 1, 1))
@@ -652,20 +665,21 @@ def search_postsoftmax(A, B, raw_out, A_bit, B_bit, rounds=3, steps=6, eq_n=128,
     for _ in range(rounds):
         Bq = uniform_fake_quant(B, p.B_scale, p.B_zp, B_bit)[0]
         qs = torch.tensor([i for i in range(10, 11 + eq_n)]).view(-1, 1, 1, 1, 1)
-        s0 = score_log_base_A(A, Bq, raw_out, qs[:eq_n], A_bit, table, batch)
+        s0 = _obs(observer, "A_logbase", p, None, qs[:eq_n], score_log_base_A(A, Bq, raw_out, qs[:eq_n], A_bit, table, batch))
         _, qi = torch.topk(s0, k=1, dim=0)
         if trace is not None:
             trace.add(s0, 1, qi)
         p.A_q = int(qs[qi.item()].item())
         Aq = adalog_fake_quant(A, p.A_scale, p.A_q, A_bit)[0]
         s, z = fpcs(*matmul_candidates(B, B_bit, True, eq_n),
-                    lambda sc, zp: score_matmul(A, B, raw_out, sc, zp, B_bit, "B", Aq, True, batch),
+                    lambda sc, zp: _obs(observer, "B", p, sc, zp,
+                                        score_matmul(A, B, raw_out, sc, zp, B_bit, "B", Aq, True, batch)),
                     0, steps, 16, eq_n, None, trace, shp)
         p.B_scale, p.B_zp = s.view(1, H, 1, 1), z.view(1, H, 1, 1).float()
     return p
 
 
-def search_conv(weight, bias, x, raw_out, w_bit, stride, steps=6, eq_n=128, batch=32, trace=None):
+def search_conv(weight, bias, x, raw_out, w_bit, stride, steps=6, eq_n=128, batch=32, trace=None, observer=None):
     """AsymmetricallyBatchingQuantConv2d.hyperparameter_searching, conv.py:313-334.
 
     With ``qconv_a_bit = 8`` (configs/*.py:12) the input is left in fp32 (conv.py:55-58) and
@@ -676,7 +690,8 @@ def search_conv(weight, bias, x, raw_out, w_bit, stride, steps=6, eq_n=128, batc
     sc, zp = weight_candidates(w2, w_bit, eq_n, conv=True)
     shp = lambda idx, k: idx.view(k, -1, 1)
     s, z = fpcs(sc, zp,
-                lambda a, b: score_conv_w(x, w2, bias, raw_out, a, b, w_bit, stride, tuple(weight.shape[2:]), batch),
+                lambda a, b: _obs(observer, "w_out", None, a, b,
+                                  score_conv_w(x, w2, bias, raw_out, a, b, w_bit, stride, tuple(weight.shape[2:]), batch)),
                 0, steps, 16, eq_n, None, trace, shp)
     return s.squeeze(0), z.squeeze(0).float()
 

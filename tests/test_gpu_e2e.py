@@ -102,3 +102,23 @@ def test_fused_quant_forward_matches_composed():
     big = torch.randn(3, 300, I, device=DEV)                        # rows not a multiple of any tile
     with torch.no_grad():
         torch.testing.assert_close(lay(big), Q.MinMaxQuantLinear.quant_forward(lay, big), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("capture", ["module", "block"])
+def test_calibrator_matches_reference_run_on_hip(golden, capture):
+    """The reference's own calibrator run on the toy tree (golden calibrator_toy): visiting order, captured shapes,
+    every calibrated parameter and the quantised output, with the HIP kernels doing the searches."""
+    from adalog_amd import backend
+    from tests import calibrator_cases as CC
+    backend.set_backend(None)
+    CC.case_calibrator_matches_reference_run(golden, capture, DEV)
+
+
+@pytest.mark.parametrize("bits", [4, 6])
+def test_block_capture_equals_module_capture_on_hip(bits):
+    from adalog_amd import backend
+    from tests import calibrator_cases as CC
+    backend.set_backend(None)
+    r = CC.case_capture_equivalence(DEV, bits)
+    assert r["scales_off"] <= 0.01 * r["scales"], r                # near-tie flips only
+    assert abs(r["mse_block"] / r["mse_module"] - 1.0) <= 0.02, r

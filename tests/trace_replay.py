@@ -1,0 +1,293 @@
+"""Per-call score parity of the PRODUCT scoring methods against the reference's golden FPCS traces.
+
+The oracle (oracle/adalog_oracle.py, pinned bit-for-bit on top-k indices against the golden traces by
+tests/test_oracle_golden.py) walks the reference's search path; at EVERY scoring call its observer hands the same
+candidates and the parameters in force to the product layer's ``_score_*`` method on ``device`` (HIP kernels under
+``-m gpu``, the executable specs of tests/cpu_backend.py in the CPU tier) and the result is compared with the
+reference's own ``trace_NNN_scores``:
+
+  * score vectors: max relative error <= SCORE_RTOL (1e-4; the north-star bar for fp32 tensors is 1e-3);
+  * top-k sets: the product's deterministic top-k of ITS scores must equal the reference's ``trace_NNN_idx`` as a set per
+    column, except for members whose REFERENCE scores lie within TIE_RTOL (1e-5 relative) of the k-th best reference
+    score -- exact and near ties are structural in FPCS and torch.topk's order among them is unspecified.
+
+Every layer class x {3, 4, 6} bit is covered; nothing here uses the +-10 % objective band.
+"""
+import numpy as np
+import torch
+
+from adalog_amd import backend, quant_layers as Q
+from adalog_amd.ops import BF16, Strided
+from oracle import adalog_oracle as O
+
+SCORE_RTOL = 1e-4
+TIE_RTOL = 1e-5
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+class Replay:
+    """Counts scoring calls and compares each with golden ``<prefix>_NNN_{scores,idx,k}``."""
+
+    def __init__(self, g, prefix="trace"):
+        self.g, self.prefix, self.n = g, prefix, 0
+        self.max_err, self.flips, self.members = 0.0, 0, 0
+
+    def check(self, got, cand_axis0: bool):
+        """``got``: product scores [P, cols] (any device).  cand_axis0: golden arrays carry the candidate axis first
+        (weights / matmul / conv) or last (activations)."""
+        g, i = self.g, self.n
+        ref = t(g[f"{self.prefix}_{i:03d}_scores"]).float()
+        idx = t(g[f"{self.prefix}_{i:03d}_idx"]).long()
+        k = int(g[f"{self.prefix}_{i:03d}_k"])
+        P = got.shape[0]
+        if cand_axis0:
+            ref, idx = ref.reshape(P, -1), idx.reshape(k, -1)
+        else:
+            ref, idx = ref.reshape(-1, P).t(), idx.reshape(-1, k).t()
+        mine = got.detach().float().cpu().reshape(ref.shape)
+        err = ((mine - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+        assert err <= SCORE_RTOL, f"{self.prefix} call {i}: score rel err {err:.3e} > {SCORE_RTOL}"
+        self.max_err = max(self.max_err, err)
+        my_idx = backend.get().topk(got.detach().float().contiguous(), k).long().cpu()          # [k, cols]
+        kth = ref.topk(k, dim=0).values[-1]                                           # k-th best reference score
+        for c in range(ref.shape[1]):
+            a, b = set(my_idx[:, c].tolist()), set(idx[:, c].tolist())
+            self.members += k
+            for j in a ^ b:
+                self.flips += 1
+                d = abs(ref[j, c].item() - kth[c].item())
+                assert d <= TIE_RTOL * abs(kth[c].item()), \
+                    f"{self.prefix} call {i} col {c}: top-{k} sets differ at candidate {j} whose reference score is " \
+                    f"{d / abs(kth[c].item()):.2e} (rel) from the k-th best -- not a tie"
+        self.n += 1
+
+    def done(self):
+        assert self.n == int(self.g[f"{self.prefix}_n"]), (self.n, int(self.g[f"{self.prefix}_n"]))
+        return {"calls": self.n, "max_rel_err": self.max_err, "tie_flips": self.flips, "members": self.members}
+
+
+def _set_uniform(q, scale, zp):
+    q.scale.data.copy_(scale.reshape(q.scale.shape).to(q.scale.device))
+    q.zero_point.data.copy_(zp.reshape(q.zero_point.shape).float().to(q.zero_point.device))
+    q.inited = True
+    q._zp_on_grid = True                      # every value the oracle commits comes from an FPCS grid
+
+
+def _pc(a, dev):
+    """[P, ...] candidates-first golden/oracle tensor -> [P, cols] fp32 on the device."""
+    return a.reshape(a.shape[0], -1).float().contiguous().to(dev)
+
+
+def _pl(a, dev):
+    """[cols, P] candidates-last -> [P, cols]."""
+    return a.reshape(-1, a.shape[-1]).t().float().contiguous().to(dev)
+
+
+# ------------------------------------------------------------------------------------------------ Linear
+def _linear_observer(lay, rp, dev):
+    def obs(kind, p, a, b, s):
+        if kind == "w_self":
+            rp.check(lay._score_w_self(_pc(a, dev), _pc(b, dev)), True)
+        elif kind == "a_self":
+            rp.check(lay._score_a_self(_pl(a, dev), _pl(b, dev)), False)
+        elif kind == "w_out":
+            _set_uniform(lay.a_quantizer, p.a_scale, p.a_zp)
+            lay.w_quantizer._zp_on_grid = True
+            rp.check(lay._score_w(lay._pack_x_fixed(), _pc(a, dev), _pc(b, dev)), True)
+        elif kind == "a_out":
+            _set_uniform(lay.w_quantizer, p.w_scale, p.w_zp)
+            dt = lay._int_dt(lay.raw_input.numel() // lay.in_features)
+            wp = lay._pack_w_fixed(dt)
+            wp.int_dt = dt
+            rp.check(lay._score_a(wp, _pl(a, dev), _pl(b, dev)), False)
+        else:
+            raise AssertionError(kind)
+    return obs
+
+
+def replay_linear(golden, name, device="cpu"):
+    dev = torch.device(device)
+    g = golden(name)
+    wb, ab, N, Tn, I, Oc, n_V, cbs = [int(v) for v in g["cfg"]]
+    W, b, x, ro = t(g["weight"]), t(g["bias"]), t(g["x"]), t(g["raw_out"])
+    lay = Q.AsymmetricallyBatchingQuantLinear(I, Oc, True, "raw", wb, ab, calib_batch_size=cbs, search_round=3,
+                                              eq_n=128, n_V=n_V, fpcs=True, steps=6).to(dev)
+    lay.weight.data.copy_(W)
+    lay.bias.data.copy_(b)
+    lay.raw_input, lay.raw_out = x.to(dev), ro.to(dev)
+    rp = Replay(g)
+    with torch.no_grad():
+        O.search_linear(W, b, x, ro, wb, ab, n_V=n_V, batch=cbs, observer=_linear_observer(lay, rp, dev))
+    return rp.done()
+
+
+def replay_channelwise(golden, bits, device="cpu"):
+    dev = torch.device(device)
+    g = golden(f"linear_cw_w{bits}a{bits}")
+    wb, ab, N, Tn, I, Oc, n_V, cbs = [int(v) for v in g["cfg"]]
+    W, b, x, ro = t(g["weight"]), t(g["bias"]), t(g["x"]), t(g["raw_out"])
+    lay = Q.AsymmetricallyChannelWiseBatchingQuantLinear(I, Oc, True, "raw", wb, ab, calib_batch_size=cbs, search_round=3,
+                                                         eq_n=128, n_V=n_V, fpcs=True, steps=6).to(dev)
+    lay.weight.data.copy_(W)
+    lay.bias.data.copy_(b)
+    lay.raw_input, lay.raw_out = x.to(dev), ro.to(dev)
+    rp = Replay(g, "cwtrace")
+
+    def obs(kind, p, a, b_, s):
+        assert kind == "a_self_cw"
+        rp.check(lay._score_a_self(_pl(a, dev), _pl(b_, dev)), False)
+    with torch.no_grad():
+        s, z = O.search_linear_channelwise(x, ab, batch=cbs, observer=obs)
+    out = rp.done()
+    # second stage: the plain search on the re-parameterised layer (linear.py:614-621), golden prefix 'trace'
+    r, bb, ts, tz, lw, lb, W2, b2 = O.reparam_step1(s, z, t(g["ln_weight"]), t(g["ln_bias"]), W, b)
+    x2 = x / r - bb
+    lay2 = Q.AsymmetricallyBatchingQuantLinear(I, Oc, True, "raw", wb, ab, calib_batch_size=cbs, search_round=3,
+                                               eq_n=128, n_V=n_V, fpcs=True, steps=6).to(dev)
+    lay2.weight.data.copy_(W2)
+    lay2.bias.data.copy_(b2)
+    lay2.raw_input, lay2.raw_out = x2.to(dev), ro.to(dev)
+    rp2 = Replay(g)
+    with torch.no_grad():
+        O.search_linear(W2, b2, x2, ro, wb, ab, n_V=n_V, batch=cbs, observer=_linear_observer(lay2, rp2, dev))
+    out2 = rp2.done()
+    return {"calls": out["calls"] + out2["calls"], "max_rel_err": max(out["max_rel_err"], out2["max_rel_err"]),
+            "tie_flips": out["tie_flips"] + out2["tie_flips"], "members": out["members"] + out2["members"]}
+
+
+# ------------------------------------------------------------------------------------------------ post-GELU
+def replay_postgelu(golden, bits, device="cpu"):
+    dev = torch.device(device)
+    be = backend.get()
+    g = golden(f"postgelu_w{bits}a{bits}")
+    wb, ab, N, Tn, I, Oc, n_V, cbs = [int(v) for v in g["cfg"]]
+    W, b, x, ro = t(g["weight"]), t(g["bias"]), t(g["x"]), t(g["raw_out"])
+    lay = Q.PostGeluLogBasedBatchingQuantLinear(I, Oc, True, "raw", wb, ab, calib_batch_size=cbs, search_round=3,
+                                                eq_n=128, n_V=1, quantizer="adalog", fpcs=True, steps=6).to(dev)
+    lay.weight.data.copy_(W)
+    lay.bias.data.copy_(b)
+    lay.raw_input, lay.raw_out = x.to(dev), ro.to(dev)
+    rp = Replay(g)
+
+    def obs(kind, p, a, b_, s):
+        aq = lay.a_quantizer
+        if kind == "w_self":
+            rp.check(lay._score_w_self(_pc(a, dev), _pc(b_, dev)), True)
+        elif kind == "a_logbase":
+            _set_uniform(lay.w_quantizer, p.w_scale, p.w_zp)
+            wp, rowsum = lay._pack_w_fixed(BF16, want_rowsum=True)
+            fold = be.shift_fold(rowsum.view(1, -1), lay.w_quantizer.scale.data.view(1, -1), aq.shift.data,
+                                 lay.bias.data).view(-1)
+            rp.check(lay._score_scale_logbase(wp, fold, _pl(a, dev), _pl(b_, dev)), False)
+        elif kind == "w_out":
+            aq.scale.data.copy_(p.a_scale.reshape(aq.scale.shape).to(dev))
+            aq.q.data.fill_(int(p.a_q))
+            aq.inited = True
+            lay._q_host = int(p.a_q)
+            rp.check(lay._score_w(lay._pack_x_fixed(), _pc(a, dev), _pc(b_, dev)), True)
+        else:
+            raise AssertionError(kind)
+    with torch.no_grad():
+        O.search_postgelu(W, b, x, ro, wb, ab, batch=cbs, observer=obs)
+    return rp.done()
+
+
+# ------------------------------------------------------------------------------------------------ MatMul
+def _mm_dt(lay):
+    from adalog_amd import search
+    from adalog_amd.ops import I8, pad_k
+    G, S, K, Sp = lay._dims()
+    return search.int_operand_dtype(lay.A_quantizer.n_bits, lay.B_quantizer.n_bits,
+                                    lay._cand_chunk(G * max(S, Sp) * pad_k(K, I8)), prefer_fp8=K <= 64)
+
+
+def replay_matmul(golden, bits, device="cpu"):
+    dev = torch.device(device)
+    g = golden(f"matmul_a{bits}b{bits}")
+    _, _, N, H, S, C, cbs = [int(v) for v in g["cfg"]]
+    A, B, ro = t(g["A"]), t(g["B"]), t(g["raw_out"])
+    lay = Q.AsymmetricallyBatchingQuantMatMul(A_bit=bits, B_bit=bits, mode="raw", calib_batch_size=cbs, search_round=3,
+                                              eq_n=128, head_channel_wise=True, num_heads=H, fpcs=True, steps=6).to(dev)
+    # q@k^T hands B over as a transposed view (wrap_net.py:25): reproduce that layout
+    Bd = B.to(dev).transpose(-2, -1).contiguous().transpose(-2, -1)
+    lay.raw_input, lay.raw_out = [A.to(dev), Bd], ro.to(dev)
+    lay._initialize_calib_parameters()
+    rp = Replay(g)
+
+    def obs(kind, p, a, b_, s):
+        dt = _mm_dt(lay)
+        if kind == "A":
+            _set_uniform(lay.B_quantizer, p.B_scale, p.B_zp)
+            rp.check(lay._score("A", lay._pack_fixed("B", dt), _pc(a, dev), _pc(b_, dev), dt), True)
+        elif kind == "B":
+            _set_uniform(lay.A_quantizer, p.A_scale, p.A_zp)
+            rp.check(lay._score("B", lay._pack_fixed("A", dt), _pc(a, dev), _pc(b_, dev), dt), True)
+        else:
+            raise AssertionError(kind)
+    with torch.no_grad():
+        O.search_matmul(A, B, ro, bits, bits, batch=cbs, observer=obs)
+    return rp.done()
+
+
+def replay_postsoftmax(golden, bits, device="cpu"):
+    dev = torch.device(device)
+    from adalog_amd import search
+    g = golden(f"postsoftmax_a{bits}b{bits}")
+    _, _, N, H, S, C, cbs = [int(v) for v in g["cfg"]]
+    A, B, ro = t(g["A"]), t(g["B"]), t(g["raw_out"])
+    lay = Q.PostSoftmaxAsymmetricallyBatchingQuantMatMul(A_bit=bits, B_bit=bits, mode="raw", calib_batch_size=cbs,
+                                                         search_round=3, eq_n=128, head_channel_wise=True, num_heads=H,
+                                                         fpcs=True, steps=6, quantizer="adalog").to(dev)
+    lay.raw_input, lay.raw_out = [A.to(dev), B.to(dev)], ro.to(dev)
+    lay._initialize_calib_parameters()
+    rp = Replay(g)
+
+    def obs(kind, p, a, b_, s):
+        aq = lay.A_quantizer
+        if kind == "A_logbase":
+            _set_uniform(lay.B_quantizer, p.B_scale, p.B_zp)
+            q_all, sc = lay._score_A_log_base()
+            assert torch.equal(q_all.cpu().long().view(-1), b_.view(-1))
+            rp.check(sc, True)
+        elif kind == "B":
+            aq.q.data.fill_(int(p.A_q))
+            lay._q_host = int(p.A_q)
+            qv = search.const_tensor([float(p.A_q)], dev)
+            ap = lay._pack_A_adalog(lay._a3(lay.raw_input[0]), qv, aq.scale.data.view(-1), 1, True, k_align=lay._kalign())
+            rp.check(lay._score("B", ap, _pc(a, dev), _pc(b_, dev), BF16, fixed_sa=Strided(aq.scale.data.view(-1)),
+                                sa_mul=lay._ts32()), True)
+        else:
+            raise AssertionError(kind)
+    with torch.no_grad():
+        O.search_postsoftmax(A, B, ro, bits, bits, batch=cbs, observer=obs)
+    return rp.done()
+
+
+# ------------------------------------------------------------------------------------------------ Conv
+def replay_conv(golden, bits, device="cpu"):
+    dev = torch.device(device)
+    be = backend.get()
+    g = golden(f"conv_w{bits}")
+    wb, _, N, ic, oc, k, hw, cbs = [int(v) for v in g["cfg"]]
+    W, b, x, ro = t(g["weight"]), t(g["bias"]), t(g["x"]), t(g["raw_out"])
+    lay = Q.AsymmetricallyBatchingQuantConv2d(in_channels=ic, out_channels=oc, kernel_size=(k, k), stride=(k, k),
+                                              mode="raw", w_bit=wb, a_bit=8, calib_batch_size=cbs, search_round=3,
+                                              eq_n=128, fpcs=True, steps=6).to(dev)
+    lay.weight.data.copy_(W)
+    lay.bias.data.copy_(b)
+    lay.raw_input, lay.raw_out = x.to(dev), ro.to(dev)
+    patches, gh, gw = lay._patches(lay.raw_input)
+    M = patches.shape[0]
+    xp = be.pack_raw(patches.unsqueeze(0))
+    ref = lay.raw_out.permute(1, 0, 2, 3).reshape(1, oc, M).contiguous()
+    rp = Replay(g)
+
+    def obs(kind, p, a, b_, s):
+        assert kind == "w_out"
+        rp.check(lay._score_w(xp, ref, M, gh * gw, _pc(a, dev), _pc(b_, dev)), True)
+    with torch.no_grad():
+        O.search_conv(W, b, x, ro, wb, (k, k), batch=cbs, observer=obs)
+    return rp.done()
