@@ -89,7 +89,9 @@ __global__ __launch_bounds__(256) void k_sel_pick(SelState* st, unsigned* hist, 
         // ranks = clamp(ceil(count * q) - 1, 0)      (linear.py:785-790; counts.float() * q in fp32)
         const float cq = ceilf((float)total * qfrac[i % R]);
         const int64_t rk = (int64_t)cq - 1;
-        s.remaining = total == 0 ? -1 : (rk < 0 ? 0 : rk);
+        // counts.float() rounds to even above 2^24 positives: the rank can land ONE PAST the last positive value, where the
+        // reference's sorted tensor holds NaN and the result is masked to 0 (linear.py:794-797) -- same here (-1 -> 0)
+        s.remaining = (total == 0 || rk >= total) ? -1 : (rk < 0 ? 0 : rk);
     }
     if (s.remaining >= 0) {
         const unsigned long long hit = __ballot(incl > s.remaining);

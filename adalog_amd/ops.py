@@ -251,6 +251,49 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
     return out
 
 
+def log2_shift(x, shift: float):
+    """log2(x + shift), correctly rounded, -inf where x + shift <= 0 (input of score_act_fused; once per layer)."""
+    x = _f32c(x, "x")
+    out = torch.empty_like(x)
+    rc = _lib.load().adalog_log2_shift(x.data_ptr(), out.data_ptr(), x.numel(), float(shift), _stream())
+    _lib.check(rc, "adalog_log2_shift")
+    return out
+
+
+def score_act_fused_ok(M: int, T: int, K: int, Kp: int, P: int, n_bits: int) -> bool:
+    return bool(_lib.load().adalog_score_act_fused_ok(int(M), int(T), int(K), int(Kp), int(P), int(n_bits)))
+
+
+def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: int, mant37, shift: float, clamp_u: bool,
+                    sa_mul: float, norm: float):
+    """Post-GELU activation-candidate scores [P, 1] with the AdaLog quantisation fused into the GEMM's loader
+    (gemm_fused.hip): wp = bf16 weight image [1, 1, M, Kp], x2 / lx2 = activation and log2_shift(activation) [T, K],
+    ref2 = raw_out [T, M]; (scale, qv) = the P = 128 candidates."""
+    lib = _lib.load()
+    M, Kp = wp.shape[-2], wp.shape[-1]
+    T, K = x2.shape
+    P = scale.numel()
+    assert wp.dtype == torch.bfloat16 and wp.is_contiguous() and ref2.shape == (T, M)
+    x2, lx2, ref2 = _f32c(x2, "x"), _f32c(lx2, "log2 x"), _f32c(ref2, "ref")
+    ws_bytes = lib.adalog_score_act_fused_workspace_bytes()
+    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x2.device)
+    scores = torch.empty((P, 1), dtype=torch.float32, device=x2.device)
+    if GEMM_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.adalog_score_act_fused(wp.data_ptr(), M, Kp, x2.data_ptr(), lx2.data_ptr(), T, K, ref2.data_ptr(),
+                                    _f32c(row_scale, "row_scale").data_ptr(),
+                                    _ptr(None if row_bias is None else _f32c(row_bias, "row_bias")),
+                                    _f32c(scale, "scale").data_ptr(), _f32c(qv, "qv").data_ptr(), P, int(n_bits),
+                                    _f32c(mant37, "mant37").data_ptr(), float(shift), int(bool(clamp_u)), float(sa_mul),
+                                    float(norm), ws.data_ptr(), ws_bytes, scores.data_ptr(), _stream())
+    if GEMM_EVENTS is not None:
+        ev1.record()
+        GEMM_EVENTS.append((BF16, M, T, K, P, 1, ev0, ev1))
+    _lib.check(rc, "adalog_score_act_fused")
+    return scores
+
+
 # ------------------------------------------------------------------------------------------------ FPCS pieces
 def topk(scores, k: int):
     scores = _f32c(scores, "scores")

@@ -25,6 +25,9 @@ from ..quantizers.logarithm import ShiftAdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
 GELU_SHIFT = 0.16997124254703522      # -min(gelu(x)), reference linear.py:749
+GELU_SHIFT32 = float(torch.tensor(GELU_SHIFT, dtype=torch.float32))     # the Parameter's fp32 value
+import os as _os
+FUSED_ACT_SEARCH = _os.environ.get("ADALOG_FUSED_ACT", "1") != "0"      # A/B switch: 0 = pack + streaming GEMM (round 1)
 MAX_PACK_BYTES = 6 << 30              # candidates are scored in chunks when a packed operand would exceed this
 
 
@@ -465,6 +468,14 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
                             shift=aq.shift.data, clamp_u=True)
         return BF16, xp, Strided(aq.scale.data.view(-1)), self._ts32(), aq.shift.data
 
+    def _log2_x(self):
+        """log2(raw_input + shift), once per captured tensor (input of the fused activation search)."""
+        key = (self.raw_input.data_ptr(), self.raw_input._version)
+        if getattr(self, "_lx_key", None) != key:
+            self._lx = backend.get().log2_shift(self._x2(), GELU_SHIFT32)
+            self._lx_key = key
+        return self._lx
+
     def _score_scale_logbase(self, wp, bias_fold, scale, qv):
         """linear.py:816-848 / 856-890 / 898-931 -> scores [P, 1] for per-candidate (scale_p, q_p); transposed like
         _score_a (rows = output channels, columns = (token, candidate))."""
@@ -474,6 +485,13 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         x3 = self._x2().unsqueeze(0)
         M = x3.shape[1]
         P = scale.shape[0]
+        norm = 1.0 / (self._tokens_per_image() * self.out_features)
+        if FUSED_ACT_SEARCH and hasattr(be, "score_act_fused") and \
+                be.score_act_fused_ok(self.out_features, M, self.in_features, wp.shape[-1], P, aq.n_bits):
+            # quantise-in-the-loader kernel: the [M*P, K] candidate operand is never written (gemm_fused.hip)
+            return be.score_act_fused(wp, x3[0], self._log2_x(), self.raw_out.reshape(-1, self.out_features),
+                                      self.w_quantizer.scale.data.view(-1), bias_fold, scale.reshape(-1), qv.reshape(-1),
+                                      aq.n_bits, self._mant37(dev), float(GELU_SHIFT32), True, self._ts32(), norm)
         out = []
         chunk = self._cand_chunk(M, pad_k(self.in_features, BF16) * 2)
         for s in range(0, P, chunk):
@@ -534,6 +552,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
+        self._lx = self._lx_key = None
 
     def reparam_bias(self):
         """linear.py:999-1006: bias += (-shift * 1^T) . q_w(W)^T, then the quantiser stops subtracting the shift."""

@@ -125,6 +125,29 @@ int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int
  * to pass as `workspace` (0: not needed; a NULL / short workspace falls back to the one-pass kernels). */
 int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, int cand_inner);
 
+/* ---- K11 fused  post-GELU activation-candidate search with the AdaLog quantisation inside the GEMM's loader
+ *                                               reference linear.py:816-848, :856-890, :898-931 (one scoring call)
+ * scores[p] = -norm * sum_{t < T, o < M} ( (ref[t][o] - row_bias[o]) - row_scale[o] * (scale[p] * sa_mul) *
+ *                                         sum_k Wp[o][k] * m_p(x[t][k]) )^2            for the P = 128 candidates (scale[p], qv[p]),
+ * m_p(x) = integer-numerator form of the search-time AdaLog value (linear.py:831-836):
+ *          k = rne(-log2(clamp((x + shift) / scale[p], 1e-15, 1)) * 37 / qv[p]);  0 if k >= 2^n_bits;
+ *          else 2^-floor(k qv / 37) * mant37[(k qv) mod 37].
+ * Same result as adalog_pack_adalog_bf16(c_inner) + adalog_gemm_score + adalog_finish_scores (bins are exact: near-ties
+ * of the fast evaluation are re-evaluated with the IEEE divide / correctly rounded log2 pipeline and the accumulators
+ * corrected), but the [T*P][K] candidate operand is never written: HBM traffic = Lx + ref + Wp.
+ *   Wp: bf16 image of the quantised weight, [M][Kp] (adalog_pack_uniform, out_dtype 1);  x: [T][K] fp32;
+ *   Lx = adalog_log2_shift(x, shift): [T][K] fp32, correctly rounded log2(x + shift), -inf where x + shift <= 0;
+ *   ref: raw_out [T][M];  workspace: adalog_score_act_fused_workspace_bytes() bytes, 8-byte aligned.
+ * adalog_score_act_fused_ok: 1 when the shape is taken (P = 128, n_bits <= 6, >= 6 K-steps of 32, LDS budget), else the
+ * caller uses the packed path. */
+int adalog_log2_shift(const float* x, float* out, int64_t n, float shift, void* stream);
+int adalog_score_act_fused_ok(int M, int64_t T, int K, int64_t Kp, int P, int n_bits);
+int64_t adalog_score_act_fused_workspace_bytes(void);
+int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const float* x, const float* Lx, int64_t T, int K,
+                           const float* ref, const float* row_scale, const float* row_bias, const float* scale,
+                           const float* qv, int P, int n_bits, const float* mant37, float shift, int clamp_u, float sa_mul,
+                           double norm, void* workspace, int64_t workspace_bytes, float* scores, void* stream);
+
 /* ---- K16  FPCS driver pieces                 reference linear.py:483-523, matmul.py:243-262, conv.py:292-311
  * adalog_topk: idx[j][col] = candidate with the j-th best score of column col, j < k; order (score desc, index asc),
  *   i.e. torch.topk(sorted=True) with ties made deterministic.  scores: [P][cols], P <= 256.

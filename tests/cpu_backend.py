@@ -258,7 +258,7 @@ class ShardedSelect:
                 if p == 0 and self.positive:
                     cq = torch.ceil(torch.tensor(float(total), dtype=torch.float32) * self.qfrac[r % self.R])
                     rk = int(cq) - 1
-                    self.remaining[s, r] = -1 if total == 0 else max(rk, 0)
+                    self.remaining[s, r] = -1 if (total == 0 or rk >= total) else max(rk, 0)   # one past the positives -> NaN -> 0
                 rem = int(self.remaining[s, r])
                 if rem >= 0:
                     cum = torch.cumsum(h[s, r], 0)

@@ -747,3 +747,69 @@ def test_topk_next_matches_two_kernels(ops):
         a = ops.fpcs_next(scale.to(DEV), zp.to(DEV), None, idx1, 1, 0, None, None, None)
         b = ops.topk_next(scores.to(DEV), scale.to(DEV), zp.to(DEV), None, 1, 0, None, None, None)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] is None and b[2] is None
+
+
+# ------------------------------------------------------------------------------------------------ fused activation search
+def _postgelu_layer(I, Oc, T, N, bits, seed, tie_frac=0.0, const_x=False):
+    from adalog_amd import quant_layers as Q
+    g = torch.Generator().manual_seed(seed)
+    x = torch.nn.functional.gelu(2.0 * torch.randn(N, T, I, generator=g))
+    if const_x:
+        x = torch.full((N, T, I), 0.731)
+    W = torch.randn(Oc, I, generator=g) * 0.03
+    b = torch.randn(Oc, generator=g) * 0.1
+    lay = Q.PostGeluLogBasedBatchingQuantLinear(I, Oc, True, "raw", bits, bits, calib_batch_size=N, search_round=1,
+                                                eq_n=128, n_V=1, quantizer="adalog", fpcs=True, steps=6).to(DEV)
+    lay.weight.data.copy_(W)
+    lay.bias.data.copy_(b)
+    shift = float(torch.tensor(0.16997124254703522, dtype=torch.float32))
+    # candidates as activation_fpcs builds them: 16 scales x 8 bases
+    hi = float(x.max()) + shift
+    scs = (torch.linspace(0.55 * hi, hi, 16)).repeat(8)
+    qs = torch.tensor([13., 23., 31., 37., 45., 60., 90., 137.]).repeat_interleave(16)
+    if tie_frac > 0:                                   # plant values ON rounding ties of random (candidate, bin) pairs
+        n = int(tie_frac * x.numel())
+        idx = torch.randint(0, x.numel(), (n,), generator=g)
+        pc = torch.randint(0, 128, (n,), generator=g)
+        kb = torch.randint(0, 2 ** bits - 1, (n,), generator=g).float() + 0.5
+        xs = scs[pc].double() * torch.pow(torch.tensor(2.0, dtype=torch.float64), -(kb.double() * qs[pc].double() / 37.0))
+        x.view(-1)[idx] = (xs - shift).float()
+    lay.raw_input = x.to(DEV)
+    lay.raw_out = torch.nn.functional.linear(x, W, b).to(DEV)
+    lay.w_quantizer.scale.data.fill_(float(W.abs().max()) / 7.0)
+    lay.w_quantizer.zero_point.data.fill_(float(2 ** (bits - 1)))
+    lay.w_quantizer.inited = True
+    return lay, scs.view(-1, 1).contiguous().to(DEV), qs.view(-1, 1).contiguous().to(DEV)
+
+
+@pytest.mark.parametrize("I,Oc,T,N,bits,tie,const", [
+    (1536, 384, 197, 4, 4, 0.0, False),      # deit_small fc2 (12 row blocks, one row tile)
+    (1536, 384, 197, 3, 4, 0.05, False),     # ties planted: queue, exact path and the rank-1 fix-ups all run; odd token count
+    (768, 192, 50, 2, 3, 0.05, False),       # deit_tiny (6 row blocks)
+    (512, 128, 49, 8, 3, 0.02, False),       # swin stage 0 (4 row blocks)
+    (1024, 256, 33, 3, 6, 0.02, False),      # 6 bit: 66-row LUT, 8 row blocks
+    (3072, 768, 41, 2, 4, 0.02, False),      # vit_base: two row tiles of 384
+    (200, 200, 37, 3, 4, 0.05, False),       # ragged: K and M not multiples of 32
+    (256, 96, 31, 2, 4, 0.0, True),          # constant input: every lane ties with the same candidates (queue flood)
+])
+def test_score_act_fused_matches_packed_path(I, Oc, T, N, bits, tie, const):
+    """gemm_fused.hip against pack_adalog + gemm_score (itself pinned to the reference's traces and to the oracle)."""
+    from adalog_amd.quant_layers import linear as LM
+    from adalog_amd.ops import BF16
+    be = ops
+    lay, scs, qs = _postgelu_layer(I, Oc, T, N, bits, 1234 + I + T, tie, const)
+    aq = lay.a_quantizer
+    with torch.no_grad():
+        wp, rowsum = lay._pack_w_fixed(BF16, want_rowsum=True)
+        fold = be.shift_fold(rowsum.view(1, -1), lay.w_quantizer.scale.data.view(1, -1), aq.shift.data, lay.bias.data).view(-1)
+        assert be.score_act_fused_ok(Oc, N * T, I, wp.shape[-1], 128, bits)
+        LM.FUSED_ACT_SEARCH = False
+        try:
+            ref = lay._score_scale_logbase(wp, fold, scs, qs)
+        finally:
+            LM.FUSED_ACT_SEARCH = True
+        got = lay._score_scale_logbase(wp, fold, scs, qs)
+        got2 = lay._score_scale_logbase(wp, fold, scs, qs)
+    assert torch.equal(got, got2)                                     # bit-reproducible
+    err = ((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
+    assert err <= 2e-6, err
