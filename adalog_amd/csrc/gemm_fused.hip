@@ -5,8 +5,8 @@
 //   out_sim        = F.linear(x_sim, q_w(W), b)          ->  -(raw_out - out_sim)^2  ->  mean / sum  ->  scores [P]
 // by ONE kernel that never materialises the candidate operand: round 1 wrote it to HBM as bf16 (2.5 GB per call for
 // deit_small fc2: k_pack_adalog_fast 0.4 ms) and read it back in the scoring GEMM (0.99 ms, 2.7 GB: 55x the
-// algorithmic bytes).  Here the only HBM streams are log2(x + shift) (fp32, 38.7 MB, read once), raw_out (9.7 MB) and the
-// bf16 weight image (1.2 MB, L2-resident).
+// algorithmic bytes).  Here the only HBM streams are x and log2(x + shift) (fp32, 2 x 38.7 MB, read once), raw_out
+// (9.7 MB) and the bf16 weight image (1.2 MB, L2-resident).
 //
 // Evaluated transposed, like the streaming kernel's activation searches:  D[o, (t, p)] = sum_k Wq[o, k] * v_p(x[t, k]),
 // GEMM rows = output channels, GEMM columns = (token, candidate).  One workgroup = 4 waves, ONE PER SIMD (512 registers
@@ -19,17 +19,21 @@
 //         value = LUT[(bits(t) << 9) + lane const]   (ds_read_b32: dword table [bin][candidate], bank = candidate: no
 //         conflicts);  two values pack into one dword;  max3 over |d| flags near-ties          -- ~7 VALU + 1 LDS read;
 //     L = log2(x + shift) is precomputed once per layer (adalog_log2_shift, correctly rounded) and reaches the wave through
-//     LDS (one 256-byte DMA per K-step and wave, broadcast reads): no transcendental runs in this kernel;
-//   * EXACT bins, deferred: the fast kf is within ~2e-5 of the reference's fp32 pipeline  x/s -> clamp -> log2 -> *37 -> /q
-//     (error budget in DESIGN.md).  A lane whose |d| lies within 1e-4 of a rounding tie pushes (k, candidate, fast bin)
-//     into its wave's LDS queue -- ~12 instructions in a cold block.  At the end of the tile the wave resolves the queue
-//     64 events at a time: exact pipeline (IEEE divide, correctly rounded log2 through fp64: common.h's rule), and where
-//     the exact bin differs from the fast one (~1e-5 of element-candidates) the two lanes that own the candidate's column
-//     apply the rank-1 correction  acc[o] += Wq[o, k] * (v_exact - v_fast)  to their accumulators.  The scores are
-//     those of the exact bins; nothing heavy sits in the MFMA loop;
-//   * the weight tile (32 * NRB rows x 64 bytes per K-step) streams through a 4-stage LDS-DMA ring shared by the four
-//     waves (buffer_load ... lds, swizzled source slots, counted vmcnt + one barrier per K-step) -- 16 B/clk/CU at the
-//     matrix pipe's full rate; an A fragment read feeds two MFMAs;
+//     LDS together with x (one 256-byte DMA each per K-step and wave, broadcast reads): no transcendental, no division
+//     and no fp64 in this kernel;
+//   * EXACT bins through a THRESHOLD TABLE.  The reference's fp32 pipeline  xs = x + shift;  u = clamp(xs / s, 1e-15, 1);
+//     k = rne(fl(fl(-log2(u) * 37) / q))  is a monotone non-increasing step function of xs for a fixed candidate (every
+//     step is a correctly rounded monotone operation), so it is fully described by its break points: thr[b][p] = the
+//     smallest float xs with k <= b.  adalog_tie_thresholds finds them per scoring call by bisection over the float
+//     ordering with the exact pipeline (IEEE divide, correctly rounded log2 through fp64: common.h's rule) -- 128 x 2^bits
+//     searches of 31 steps, a few microseconds.  The fast kf above is within ~2e-5 of that pipeline (error budget in
+//     DESIGN.md); when a chunk of 8 element-candidates holds one within 1e-4 of a rounding tie, a cold block re-derives the
+//     chunk's bins as  fast bin + [xs < thr[bin]] - [xs >= thr[bin - 1]]  (two LDS reads and two compares) and re-reads
+//     the LUT.  The operand is therefore bit-identical to what k_pack_adalog_fast (operand.hip) writes;
+//   * the weight tile (32 * NRB rows x 64 bytes per K-step) streams through an LDS-DMA ring shared by the four waves
+//     (buffer_load ... lds, swizzled source slots, counted vmcnt + one barrier per K-step) -- 16 B/clk/CU at the matrix
+//     pipe's full rate; an A fragment read feeds two MFMAs.  The ring and the fragment generation run ahead across tile
+//     boundaries (persistent workgroups);
 //   * epilogue in registers: e = (ref - row_bias) - D * (s_p * ts) * s_w[o], the lane adds e^2 over its rows, lanes l and
 //     l + 32 combine, per-wave fp64 running sums per candidate; one [workgroup][128] fp64 row leaves the kernel and a
 //     fixed-order finish turns the rows into scores (bit-reproducible).
@@ -42,34 +46,34 @@ namespace {
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 typedef void __attribute__((address_space(3)))* las_ptr;
 typedef const uint32_t __attribute__((address_space(3)))* lds_u32p;
+typedef const float __attribute__((address_space(3)))* lds_f32p;
 
 struct FusedArgs {
     const uint8_t* W;          // [M][Kb] bf16 image of q_w(W) - z (integers), rows zero-padded to Kb bytes
     const float* L;            // [T][K]  log2(x + shift)  (-inf where x + shift <= 0)
-    const float* x;            // [T][K]  the captured activation (exact path only)
+    const float* x;            // [T][K]  the captured activation
     const float* ref;          // [T][M]  raw_out
     const float* row_scale;    // [M]     weight scale s_w[o]
     const float* row_bias;     // [M]     bias with the -shift term folded in (may be null)
     const float* scale;        // [128]   candidate scales s_p
     const float* qv;           // [128]   candidate bases q_p (as floats)
     const float* mant;         // [37]    integer numerators of the search-time mantissa table (linear.py:750-752)
+    const float* thr;          // [levels2][128] break points of the exact pipeline (k_tie_thresholds)
     double* wg_acc;            // [gridDim.x][128]
     int M, T, K;
     int Kb;                    // row pitch of W in bytes (multiple of 128)
     int levels2;               // 2^bits
-    int clamp_u;
     int n_rt;                  // row tiles of 32 * NRB rows
-    int nk;                    // 64-byte K-steps (even: Kb is a multiple of 128)
+    int nk;                    // 64-byte K-steps
     float shift, sa_mul;
 };
 
-constexpr int FNS = 4;                       // ring stages
-constexpr int QCAP = 1024;                   // tie-queue entries per wave (a chunk can push 512)
 constexpr float MAGIC = 12582912.0f;         // 1.5 * 2^23: fl32(kf + MAGIC) carries rne(kf) in its low mantissa bits
 constexpr unsigned MAGIC_BITS = 0x4B400000u;
-constexpr float TIE = 0.4999f;               // |kf - rne(kf)| above this: the exact pipeline decides
+constexpr float TIE = 0.4999f;               // |kf - rne(kf)| above this: the threshold table decides
 
 // Fragment / parameter reads through __restrict__ helpers: the loads carry alias scopes, so the waitcnt pass does not
 // order them behind the (untagged) in-flight LDS-DMA with a vmcnt(0) -- the counted vmcnt before each barrier does that.
@@ -79,8 +83,6 @@ __device__ __forceinline__ uint4 lds_frag(const uint8_t* __restrict__ stage, int
 __device__ __forceinline__ float4 lds_f4(const uint8_t* __restrict__ base, int off) {
     return *reinterpret_cast<const float4*>(base + off);
 }
-
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v8bf frag8(const uint32_t (&d)[4]) {
     const u4v v = {d[0], d[1], d[2], d[3]};
     return __builtin_bit_cast(v8bf, v);
@@ -88,40 +90,68 @@ __device__ __forceinline__ v8bf frag8(const uint32_t (&d)[4]) {
 
 // The compiler selects ONE form of MFMA per function (accumulators in AGPRs when the wave may use 512 registers), so it
 // cannot keep more than 256 accumulator registers without copying tiles in and out around every MFMA.  Hand-placed
-// classes: the first NA accumulator tiles live in AGPRs ("a"), the rest in VGPRs ("v").
-#define MFMA_BF16_A(ACC, A, B) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+// classes: the tiles of the first NA row blocks use the compiler's form (AGPRs), the rest an asm form with VGPR accumulators.
 #define MFMA_BF16_V(ACC, A, B) asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
 template <int NRB>
 __device__ __forceinline__ void mfma_tile(v16f& acc, int rb, const v8bf& a, const v8bf& b) {
     constexpr int NA = NRB * 2 <= 16 ? NRB : 8;          // row blocks whose two tiles sit in AGPRs (16 tiles = 256 registers)
-    if (rb < NA) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);   // compiler form: AGPR accumulators
+    if (rb < NA) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
     else MFMA_BF16_V(acc, a, b);
 }
 
-template <int NRB>
+// the reference's pipeline for one value (clamped form, linear.py:829-833): bin in [0, levels2] (levels2 = masked)
+__device__ __forceinline__ float exact_kc(float xs, float s, float qf, int levels2) {
+    float ue = xs / s;
+    ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
+    const float le = (float)log2((double)ue);            // correctly rounded log2 (common.h: adalog_k)
+    const float t = (-le) * 37.0f / qf;
+    const float kk = rintf(t);
+    return (kk == kk) ? fminf(fmaxf(kk, 0.0f), (float)levels2) : (float)levels2;
+}
+
+// thr[b][p] = smallest positive float xs whose bin is <= b (the bin never increases with xs); -inf when even the clamped
+// end of the range (u = 1e-15) stays at or below b.  One thread per (bin boundary, candidate), bisection over float bits.
+__global__ __launch_bounds__(128) void k_tie_thresholds(const float* __restrict__ scale, const float* __restrict__ qv,
+                                                        int levels2, float* __restrict__ thr) {
+    const int b = blockIdx.x, pc = threadIdx.x;
+    const float s = scale[pc], qf = qv[pc];
+    unsigned lo = 0x00800000u, hi = 0x7F7FFFFFu;         // FLT_MIN .. FLT_MAX: bin(lo) is the largest, bin(hi) = 0
+    float out;
+    if (exact_kc(__uint_as_float(lo), s, qf, levels2) <= (float)b) {
+        out = -__builtin_inff();
+    } else {
+        while (hi - lo > 1u) {
+            const unsigned mid = lo + ((hi - lo) >> 1);
+            if (exact_kc(__uint_as_float(mid), s, qf, levels2) <= (float)b) hi = mid; else lo = mid;
+        }
+        out = __uint_as_float(hi);
+    }
+    thr[b * 128 + pc] = out;
+}
+
+template <int NRB, int FNS>
 __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int AT = NRB * 2048;               // weight tile bytes per stage (32 * NRB rows x 64 B)
-    constexpr int STG = AT + 1024;               // + 4 x 256 B of log2 values (one 64-float run per wave)
     constexpr int RQ = NRB / 2;                  // weight DMA requests per wave per K-step (16 rows x 64 B each)
-    constexpr int RW = RQ + 1;                   // + the wave's log2 request
+    constexpr int RW = RQ + 2;                   // + the wave's x and log2 requests
     constexpr int ROWS = 32 * NRB;
+    constexpr int XS = FNS + 1;                  // slots of the x / log2 ring (read one step earlier AND during the step)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t* ring = smem;                                                   // FNS * STG
-    uint32_t* s_lut = reinterpret_cast<uint32_t*>(smem + FNS * STG);        // [levels2 + 2][128] bf16 bits (low half)
+    uint8_t* ring = smem;                                                   // FNS * AT
+    uint8_t* xring = ring + FNS * AT;                                       // XS * 4 waves * {256 B x, 256 B log2}
+    uint32_t* s_lut = reinterpret_cast<uint32_t*>(xring + XS * 2048);       // [levels2 + 2][128] bf16 bits (low half)
     const int lut_rows = p.levels2 + 2;
-    float4* s_par = reinterpret_cast<float4*>(s_lut + lut_rows * 128);      // [128] {-37/q, log2(s)*37/q, hi, s * sa_mul}
-    float2* s_sq = reinterpret_cast<float2*>(s_par + 128);                  // [128] {s, q}           (exact path)
-    float* s_refb = reinterpret_cast<float*>(s_sq + 128);                   // [2][ROWS] ref - row_bias
+    float* s_thr = reinterpret_cast<float*>(s_lut + lut_rows * 128);        // [levels2][128]
+    float4* s_par = reinterpret_cast<float4*>(s_thr + p.levels2 * 128);     // [128] {-37/q, log2(s)*37/q, hi, s * sa_mul}
+    float* s_refb = reinterpret_cast<float*>(s_par + 128);                  // [2][ROWS] ref - row_bias
     float* s_rs = s_refb + 2 * ROWS;                                        // [ROWS]    row scale (0 past M)
     double* s_fin = reinterpret_cast<double*>(s_rs + ROWS);                 // [4][64]
-    uint32_t* s_queue = reinterpret_cast<uint32_t*>(s_fin + 256);           // [4][QCAP]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int frow = lane & 31, fkg = lane >> 5;
     const int wtok = w >> 1, cbp = w & 1;
-    uint32_t* myq = s_queue + w * QCAP;
 
     // ---- per-launch tables
     for (int e = tid; e < lut_rows * 128; e += 256) {
@@ -131,18 +161,17 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
         const float v = (bin >= p.levels2 || t > 100) ? 0.0f : ldexpf(p.mant[j], -t);
         s_lut[e] = __float_as_uint(v) >> 16;                                // exact: <= 8 significant bits
     }
-    const float lo = p.clamp_u ? 0.0f : -0.25f;
+    for (int e = tid; e < p.levels2 * 128; e += 256) s_thr[e] = p.thr[e];
     const float top = (float)p.levels2 + 0.75f;                             // rounds to 2L + 1: a zero entry
     if (tid < 128) {
         const float s = p.scale[tid], qf = p.qv[tid];
         const float rq37 = 37.0f / qf;
         const float NL15 = 49.828921f;                                      // -fl32(log2(1e-15f))
-        s_par[tid] = make_float4(-rq37, __log2f(s) * rq37, p.clamp_u ? fminf(NL15 * rq37, top) : top, s * p.sa_mul);
-        s_sq[tid] = make_float2(s, qf);
+        s_par[tid] = make_float4(-rq37, __log2f(s) * rq37, fminf(NL15 * rq37, top), s * p.sa_mul);
     }
     __syncthreads();
     float ca[2], cc[2], chi[2], calpha[2];
-    unsigned lutc[2];
+    unsigned lutc[2], thrc[2];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const int c = 64 * cbp + 32 * cb + frow;
@@ -150,6 +179,7 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
         ca[cb] = pr.x; cc[cb] = pr.y; chi[cb] = pr.z; calpha[cb] = pr.w;
         // byte address of LUT[bin][c] = lut_base + bin * 512 + c * 4, with bin = bits(t) - MAGIC_BITS folded in (mod 2^32)
         lutc[cb] = (unsigned)(uintptr_t)(lds_u32p)s_lut + (unsigned)c * 4u - (MAGIC_BITS << 9);
+        thrc[cb] = (unsigned)(uintptr_t)(lds_f32p)s_thr + (unsigned)c * 4u;
     }
 
     // ---- tiles: (token pair, row tile), row tile fastest; static stride over the persistent workgroups
@@ -159,10 +189,10 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
     const int nk = p.nk;
     if (bid >= ntile) return;
 
-    // ---- issue cursors.  Weights run FNS - 1 steps ahead of the compute cursor; the log2 run of step n is consumed one
-    // step earlier than the weights of step n (the B fragments of step n are produced while step n - 1 multiplies), so its
-    // cursor runs one step further ahead and its request travels with the weights of step n - 1.  A cursor is
-    // (token pair, row tile, K-step); all of it is wave-uniform and advances without branches.
+    // ---- issue cursors.  Weights run FNS - 1 steps ahead of the compute cursor; the x / log2 runs of step n are first
+    // consumed half a step earlier than its weights (the B fragments of a K half are produced while the previous half
+    // multiplies), so their cursor runs one step further ahead and their requests travel with the weights of step n - 1.
+    // A cursor is (token pair, row tile, K-step); all of it is wave-uniform and advances without branches.
     const int lrow = lane >> 2, lslot16 = ((lane & 3) ^ ((lane >> 4) & 3)) << 4;
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, p.M * p.Kb, 0x00020000);
     const unsigned d_pair = nwg / (unsigned)p.n_rt, d_rt = nwg - d_pair * (unsigned)p.n_rt;
@@ -180,15 +210,18 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
     };
     Cur ca_ = cur_init(), cl_ = cur_init();
     const int vl = (wtok * p.K + lane) * 4;          // the wave's token: 64 floats from the step's k0 (32 are used)
-    auto issue_l = [&](int slot) __attribute__((always_inline)) {
+    auto issue_x = [&](int slot) __attribute__((always_inline)) {
         const int tok0 = (int)cl_.pair * 2;
-        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.L + (int64_t)tok0 * p.K), 0,
-                                                                             min(2, p.T - tok0) * p.K * 4, 0x00020000);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (las_ptr)(ring + slot * STG + AT + w * 256), 4, vl, cl_.k * 128, 0, 0);
+        const int nrec = min(2, p.T - tok0) * p.K * 4;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)tok0 * p.K), 0, nrec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc((void*)(p.L + (int64_t)tok0 * p.K), 0, nrec, 0x00020000);
+        uint8_t* dst = xring + slot * 2048 + w * 512;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (las_ptr)dst, 4, vl, cl_.k * 128, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (las_ptr)(dst + 256), 4, vl, cl_.k * 128, 0, 0);
         cur_step(cl_);
     };
     auto issue_a = [&](int slot) __attribute__((always_inline)) {
-        uint8_t* st_ = ring + slot * STG;
+        uint8_t* st_ = ring + slot * AT;
         const int row0 = (int)ca_.rt * ROWS + w * 16 + lrow;
 #pragma unroll
         for (int q = 0; q < RQ; ++q) {
@@ -197,16 +230,14 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
         }
         cur_step(ca_);
     };
-    issue_l(0);                                      // log2 run of global step 0
+    issue_x(0);                                      // x / log2 runs of global step 0
 #pragma unroll
-    for (int s0 = 0; s0 < FNS - 1; ++s0) { issue_a(s0); issue_l((s0 + 1) % FNS); }
+    for (int s0 = 0; s0 < FNS - 1; ++s0) { issue_a(s0); issue_x(s0 + 1); }
 
     v16f acc[NRB][2];
-    uint32_t bA[2][2][4], bB[2][2][4];               // B fragments [candidate block][K half][dword]
+    uint32_t bA[2][4], bB[2][4];                     // B fragments of one K half [candidate block][dword]
     double run[2] = {0.0, 0.0};
-    int qn = 0;                                      // tie-queue fill (wave-uniform)
-    int st = 0;                                      // ring slot of the current global step
-    int tok_abs = 0, m0 = 0;                         // this wave's token and the row-tile origin of the current tile
+    int st = 0, sx = 0;                              // ring slots of the current global step (weights; x / log2)
 
     // ---- B fragments of one (candidate block, K half) chunk: 8 element-candidates of this lane.
     // Returns max |kf - rne(kf)| over the chunk (the tie detector).
@@ -216,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
         float dm = 0.0f;
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
-            const float k0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(lv[e], ca[cb], cc[cb]), lo, chi[cb]);
-            const float k1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(lv[e + 1], ca[cb], cc[cb]), lo, chi[cb]);
+            const float k0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(lv[e], ca[cb], cc[cb]), 0.0f, chi[cb]);
+            const float k1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(lv[e + 1], ca[cb], cc[cb]), 0.0f, chi[cb]);
             const float t0 = k0 + MAGIC, t1 = k1 + MAGIC;
             const float d0 = k0 - (t0 - MAGIC), d1 = k1 - (t1 - MAGIC);
             dm = fmaxf(fmaxf(dm, fabsf(d0)), fabsf(d1));                     // v_max3_f32 with |.| modifiers
@@ -229,164 +260,125 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
         return dm;
     };
 
-    // ---- rank-1 correction of the accumulator column of candidate (cb, fr):  acc[o] += Wq[o, kabs] * (v_exact - v_fast),
-    // as two MFMAs per row block with one live K slot: A = the weight column (lane (row, K group 0), element 0),
-    // B = +v_exact / -v_fast in the owner column (both exact in bf16; their difference is not)
-    auto apply = [&](int kabs, int cb, int fr, unsigned ve_bits, unsigned vf_bits) __attribute__((always_inline)) {
-        const bool own = frow == fr && fkg == 0;
-        const u4v b1 = {own ? ve_bits : 0u, 0u, 0u, 0u}, b2 = {own ? (vf_bits ^ 0x8000u) : 0u, 0u, 0u, 0u};
-        const uint16_t* wcol = reinterpret_cast<const uint16_t*>(p.W) + kabs;
-#pragma unroll
-        for (int rb = 0; rb < NRB; ++rb) {
-            const int row = m0 + rb * 32 + frow;
-            const unsigned wv = (fkg == 0 && row < p.M) ? (unsigned)wcol[(int64_t)row * (p.Kb >> 1)] : 0u;
-            const u4v a = {wv, 0u, 0u, 0u};
-            if (cb == 0) {
-                mfma_tile<NRB>(acc[rb][0], rb, __builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b1));
-                mfma_tile<NRB>(acc[rb][0], rb, __builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b2));
-            } else {
-                mfma_tile<NRB>(acc[rb][1], rb, __builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b1));
-                mfma_tile<NRB>(acc[rb][1], rb, __builtin_bit_cast(v8bf, a), __builtin_bit_cast(v8bf, b2));
-            }
-        }
-    };
-
-    // ---- resolve the queued near-ties of the current tile, 64 at a time: exact pipeline, fix-up where it differs
-    auto resolve = [&]() __attribute__((always_inline)) {
-        for (int base = 0; base < qn; base += 64) {
-            const int i = base + lane;
-            const bool act = i < qn;
-            const uint32_t rec = act ? myq[i] : 0u;
-            const int kabs = rec & 0xFFFF, cbq = (rec >> 16) & 1, fr = (rec >> 17) & 31, fb = rec >> 24;
-            const int c = 64 * cbp + 32 * cbq + fr;
-            float kk = (float)fb;
-            if (act) {
-                const float xs = p.x[(int64_t)tok_abs * p.K + min(kabs, p.K - 1)] + p.shift;
-                const float2 sq = s_sq[c];
-                float ue = xs / sq.x;
-                if (p.clamp_u) ue = fminf(fmaxf(ue, 1e-15f), 1.0f);
-                const float le = (float)log2((double)ue);                    // correctly rounded log2 (common.h: adalog_k)
-                const float t = (-le) * 37.0f / sq.y;
-                kk = rintf(t);
-                kk = (kk == kk) ? fminf(fmaxf(kk, 0.0f), (float)(p.levels2 + 1)) : (float)(p.levels2 + 1);
-            }
-            const uint32_t ve = s_lut[(int)kk * 128 + c], vf = s_lut[fb * 128 + c];
-            unsigned long long mm = __ballot(act && ve != vf && kabs < p.K);
-            while (mm) {                                                      // ~1e-5 of element-candidates
-                const int j = __ffsll(mm) - 1;
-                mm &= mm - 1;
-                const uint32_t rj = __builtin_amdgcn_readlane(rec, j);
-                apply(rj & 0xFFFF, (rj >> 16) & 1, (rj >> 17) & 31, __builtin_amdgcn_readlane(ve, j), __builtin_amdgcn_readlane(vf, j));
-            }
-        }
-        qn = 0;
-    };
-
-    // ---- queue the near-ties of a chunk (cold): recompute the 8 fast values, push (k, candidate, fast bin) per hit
-    auto push_chunk = [&](const float4& l0, const float4& l1, int cb, int kbase) __attribute__((always_inline)) {
+    // ---- a chunk with a near-tie (cold): every bin of the chunk from the threshold table.  The fast bin f is within one of
+    // the exact one, which is  f + [xs < thr[f]] - [xs >= thr[f - 1]]  (bins count the break points above xs).
+    auto fix_chunk = [&](const float4& l0, const float4& l1, const float4& x0, const float4& x1, int cb, uint32_t (&out)[4])
+        __attribute__((always_inline)) {
         const float lv[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        uint32_t v[8];
+        const int L2 = p.levels2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float kf = __builtin_amdgcn_fmed3f(__builtin_fmaf(lv[e], ca[cb], cc[cb]), lo, chi[cb]);
-            const float t = kf + MAGIC;
-            const bool f = fabsf(kf - (t - MAGIC)) > TIE;
-            const unsigned long long m = __ballot(f);
-            if (m) {
-                const int idx = qn + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                if (f) myq[idx] = (unsigned)(kbase + e) | ((unsigned)cb << 16) | ((unsigned)frow << 17) | ((__float_as_uint(t) & 0xFFu) << 24);
-                qn += (int)__popcll(m);
-            }
+            const float kf = __builtin_amdgcn_fmed3f(__builtin_fmaf(lv[e], ca[cb], cc[cb]), 0.0f, chi[cb]);
+            const int f = min((int)(__float_as_uint(kf + MAGIC) & 0xFFu), L2);
+            const float xs = xv[e] + p.shift;
+            const float tu = *(lds_f32p)(uintptr_t)(thrc[cb] + (unsigned)min(f, L2 - 1) * 512u);
+            const float td = *(lds_f32p)(uintptr_t)(thrc[cb] + (unsigned)max(f - 1, 0) * 512u);
+            const int up = (f < L2 && xs < tu) ? 1 : 0, dn = (f > 0 && !(xs < td)) ? 1 : 0;
+            v[e] = s_lut[(f + up - dn) * 128 + 64 * cbp + 32 * cb + frow];
         }
-        if (qn > QCAP - 512) resolve();                                       // room for a whole chunk at the next push
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[i] = v[2 * i] | (v[2 * i + 1] << 16);
     };
 
-    // ---- one 64-byte K-step: MFMAs of step n from BC, B fragments of step n + 1 into BN (GEN).  Four groups, each =
-    // one chunk of generation + (half the row blocks of one K half) x 2 candidate blocks = NRB MFMAs; a scheduling
-    // barrier per group keeps the fragment look-ahead (and with it the register pressure) to one group.
-#define FUSED_STEP(BC, BN, GEN, KT)                                                                               \
+#if defined(FUSED_IGLP)
+#define FUSED_SCHED_HINT __builtin_amdgcn_iglp_opt(FUSED_IGLP);
+#else
+#define FUSED_SCHED_HINT
+#endif
+    // ---- half a K-step: 2 groups, each = one chunk of the NEXT half's B fragments (BN) + NRB MFMAs of this half (BC);
+    // a scheduling barrier per group keeps the fragment look-ahead (and the register pressure) to one group.
+    // XN / LN: the x / log2 runs the next half reads (8 floats per lane at element offset EO)
+#define FUSED_HALF(H, BC, BN, XN, EO)                                                                             \
     do {                                                                                                          \
-        if (RW == 7) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");                                            \
-        else if (RW == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                                       \
-        else if (RW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                        \
-        else if (RW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                        \
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                     \
-        __builtin_amdgcn_s_barrier();                                                                             \
-        asm volatile("" ::: "memory");                                                                            \
-        const uint8_t* As_ = ring + st * STG;                                                                     \
-        const int stn_ = st == FNS - 1 ? 0 : st + 1;                                                              \
-        const uint8_t* Ls_ = ring + stn_ * STG + AT + w * 256;                                                    \
-        issue_a(st == 0 ? FNS - 1 : st - 1);                                                                      \
-        issue_l(st);                                                                                              \
-        float4 l0_ = make_float4(0.f, 0.f, 0.f, 0.f), l1_ = l0_;                                                  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
-            const int h_ = j >> 1, cbg_ = j & 1;                                                                  \
-            float dm_ = 0.0f;                                                                                     \
-            if (GEN) {                                                                                            \
-                if (cbg_ == 0) { l0_ = lds_f4(Ls_, (16 * h_ + 8 * fkg) * 4); l1_ = lds_f4(Ls_, (16 * h_ + 8 * fkg) * 4 + 16); } \
-                dm_ = gen_chunk(l0_, l1_, cbg_, BN[cbg_][h_]);                                                    \
-            }                                                                                                     \
+        const float4 l0_ = lds_f4((XN), 256 + ((EO) + 8 * fkg) * 4), l1_ = lds_f4((XN), 256 + ((EO) + 8 * fkg) * 4 + 16); \
+        _Pragma("unroll") for (int cbg_ = 0; cbg_ < 2; ++cbg_) {                                                  \
+            const float dm_ = gen_chunk(l0_, l1_, cbg_, BN[cbg_]);                                                \
             _Pragma("unroll") for (int r2 = 0; r2 < NRB / 2; ++r2) {                                              \
                 const int rb = cbg_ * (NRB / 2) + r2;                                                             \
-                const uint4 a_ = lds_frag(As_, (rb * 32 + frow) * 64 + (((2 * h_ + fkg) ^ ((frow >> 2) & 3)) << 4)); \
-                mfma_tile<NRB>(acc[rb][0], rb, __builtin_bit_cast(v8bf, a_), frag8(BC[0][h_]));                   \
-                mfma_tile<NRB>(acc[rb][1], rb, __builtin_bit_cast(v8bf, a_), frag8(BC[1][h_]));                   \
+                const uint4 a_ = lds_frag(As_, (rb * 32 + frow) * 64 + (((2 * (H) + fkg) ^ ((frow >> 2) & 3)) << 4)); \
+                mfma_tile<NRB>(acc[rb][0], rb, __builtin_bit_cast(v8bf, a_), frag8(BC[0]));                       \
+                mfma_tile<NRB>(acc[rb][1], rb, __builtin_bit_cast(v8bf, a_), frag8(BC[1]));                       \
             }                                                                                                     \
+            FUSED_SCHED_HINT                                                                                      \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            if (GEN && __builtin_expect(__any(dm_ > TIE), 0)) push_chunk(l0_, l1_, cbg_, ((KT) + 1) * 32 + 16 * h_ + 8 * fkg); \
+            if (__builtin_expect(__any(dm_ > TIE), 0)) {                                                          \
+                const float4 x0_ = lds_f4((XN), ((EO) + 8 * fkg) * 4), x1_ = lds_f4((XN), ((EO) + 8 * fkg) * 4 + 16); \
+                fix_chunk(l0_, l1_, x0_, x1_, cbg_, BN[cbg_]);                                                    \
+            }                                                                                                     \
         }                                                                                                         \
-        st = stn_;                                                                                                \
     } while (0)
 
-    Cur cc_ = cur_init();                            // compute cursor (tile granularity)
-    for (; cc_.tile < ntile; cc_.tile += nwg) {
-        const unsigned pair = cc_.tile / (unsigned)p.n_rt;
-        m0 = (int)(cc_.tile - pair * (unsigned)p.n_rt) * ROWS;
+    // B fragments of the very first half (the runs of global step 0 were issued first)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint8_t* X0 = xring + w * 512;
+        const float4 l0_ = lds_f4(X0, 256 + 8 * fkg * 4), l1_ = lds_f4(X0, 256 + 8 * fkg * 4 + 16);
+        const float4 x0_ = lds_f4(X0, 8 * fkg * 4), x1_ = lds_f4(X0, 8 * fkg * 4 + 16);
+#pragma unroll
+        for (int cbg_ = 0; cbg_ < 2; ++cbg_) {
+            const float dm_ = gen_chunk(l0_, l1_, cbg_, bA[cbg_]);
+            if (__any(dm_ > TIE)) fix_chunk(l0_, l1_, x0_, x1_, cbg_, bA[cbg_]);
+        }
+    }
+
+    for (unsigned tile = bid; tile < ntile; tile += nwg) {
+        const unsigned pair = tile / (unsigned)p.n_rt;
+        const int m0 = (int)(tile - pair * (unsigned)p.n_rt) * ROWS;
         const int tok0 = (int)pair * 2;
-        tok_abs = min(tok0 + wtok, p.T - 1);
         const bool tok_ok = tok0 + wtok < p.T;
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[rb][0][r] = 0.0f; acc[rb][1][r] = 0.0f; }
-        // epilogue operands: plain loads now, staged into LDS after the second step's barrier
-        constexpr int EU = (2 * ROWS + 255) / 256, RU = (ROWS + 255) / 256;
-        float e_ref[EU], e_rs[RU];
-#pragma unroll
-        for (int u = 0; u < EU; ++u) {
-            const int e = tid + u * 256, ts_ = e >= ROWS ? 1 : 0, r = e - ts_ * ROWS;
-            const int row = m0 + r, tk = tok0 + ts_;
-            const bool ok = e < 2 * ROWS && row < p.M && tk < p.T;
-            e_ref[u] = ok ? p.ref[(int64_t)tk * p.M + row] - (p.row_bias ? p.row_bias[row] : 0.0f) : 0.0f;
-        }
-#pragma unroll
-        for (int u = 0; u < RU; ++u) {
-            const int r = tid + u * 256, row = m0 + r;
-            e_rs[u] = (r < ROWS && row < p.M) ? p.row_scale[row] : 0.0f;
-        }
-        // B fragments of the tile's first step (its log2 run travelled with the previous tile's last weights)
+        // epilogue operands of this tile: loaded and staged here (the barrier orders the stores behind the previous
+        // tile's epilogue reads of every wave; the vmcnt(0) costs one ring refill per tile of nk steps)
         {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // once per tile: also covers the very first step
-            const uint8_t* Ls0 = ring + st * STG + AT + w * 256;
+            constexpr int EU = (2 * ROWS + 255) / 256, RU = (ROWS + 255) / 256;
+            float e_ref[EU], e_rs[RU];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int h_ = j >> 1, cbg_ = j & 1;
-                const float4 l0_ = lds_f4(Ls0, (16 * h_ + 8 * fkg) * 4), l1_ = lds_f4(Ls0, (16 * h_ + 8 * fkg) * 4 + 16);
-                const float dm_ = gen_chunk(l0_, l1_, cbg_, bA[cbg_][h_]);
-                if (__builtin_expect(__any(dm_ > TIE), 0)) push_chunk(l0_, l1_, cbg_, 16 * h_ + 8 * fkg);
+            for (int u = 0; u < EU; ++u) {
+                const int e = tid + u * 256, ts_ = e >= ROWS ? 1 : 0, r = e - ts_ * ROWS;
+                const int row = m0 + r, tk = tok0 + ts_;
+                const bool ok = e < 2 * ROWS && row < p.M && tk < p.T;
+                e_ref[u] = ok ? p.ref[(int64_t)tk * p.M + row] - (p.row_bias ? p.row_bias[row] : 0.0f) : 0.0f;
             }
-        }
-        for (int kt = 0; kt < nk; kt += 2) {
-            FUSED_STEP(bA, bB, true, kt);
-            if (kt == 2) {                                          // stage the epilogue operands (read after >= 1 more barrier)
 #pragma unroll
-                for (int u = 0; u < EU; ++u) if (tid + u * 256 < 2 * ROWS) s_refb[tid + u * 256] = e_ref[u];
-#pragma unroll
-                for (int u = 0; u < RU; ++u) if (tid + u * 256 < ROWS) s_rs[tid + u * 256] = e_rs[u];
+            for (int u = 0; u < RU; ++u) {
+                const int r = tid + u * 256, row = m0 + r;
+                e_rs[u] = (r < ROWS && row < p.M) ? p.row_scale[row] : 0.0f;
             }
-            if (kt + 2 < nk) FUSED_STEP(bB, bA, true, kt + 1);
-            else FUSED_STEP(bB, bA, false, kt + 1);
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int u = 0; u < EU; ++u) if (tid + u * 256 < 2 * ROWS) s_refb[tid + u * 256] = e_ref[u];
+#pragma unroll
+            for (int u = 0; u < RU; ++u) if (tid + u * 256 < ROWS) s_rs[tid + u * 256] = e_rs[u];
         }
-        if (qn) resolve();
+        for (int kt = 0; kt < nk; ++kt) {
+            // this step's weights (and the x / log2 runs of the next) have landed once only the newest FNS - 2 batches of
+            // this wave are outstanding
+            if ((FNS - 2) * RW == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if ((FNS - 2) * RW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if ((FNS - 2) * RW == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if ((FNS - 2) * RW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if ((FNS - 2) * RW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if ((FNS - 2) * RW == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else if ((FNS - 2) * RW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint8_t* As_ = ring + st * AT;
+            const int sxn = sx == XS - 1 ? 0 : sx + 1;
+            const uint8_t* Xc_ = xring + sx * 2048 + w * 512;       // runs of this step (second half still to be produced)
+            const uint8_t* Xn_ = xring + sxn * 2048 + w * 512;      // runs of the next step
+            issue_a(st == 0 ? FNS - 1 : st - 1);
+            issue_x(sx == 0 ? XS - 1 : sx - 1);                     // step n + FNS -> the slot step n - 1 has left
+            FUSED_HALF(0, bA, bB, Xc_, 16);
+            FUSED_HALF(1, bB, bA, Xn_, 0);
+            st = st == FNS - 1 ? 0 : st + 1;
+            sx = sxn;
+        }
         // ---- epilogue (one row block at a time: the scheduling barrier keeps the staged reads from being hoisted)
         float s0 = 0.0f, s1 = 0.0f;
         const uint8_t* rb_ = reinterpret_cast<const uint8_t*>(s_refb + wtok * ROWS);
@@ -412,13 +404,136 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
         s1 += __shfl_xor(s1, 32);
         if (tok_ok) { run[0] += (double)s0; run[1] += (double)s1; }
     }
-#undef FUSED_STEP
+#undef FUSED_HALF
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead requests before the LDS is released
     if (fkg == 0) { s_fin[w * 64 + frow] = run[0]; s_fin[w * 64 + 32 + frow] = run[1]; }
     __syncthreads();
     if (tid < 128) {
         const int cw = tid >> 6, wi = tid & 63;
         p.wg_acc[(int64_t)bid * 128 + tid] = s_fin[cw * 64 + wi] + s_fin[(2 + cw) * 64 + wi];
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------- hand-scheduled form
+// Same algorithm, same LDS tables, same results as k_act_fused<12, 4>; the persistent loop (DMA ring, fragment generation,
+// MFMA stream, threshold fix-ups, epilogue) is the generated asm of tools/gen_fused_asm.py (fused_loop_nrb12.inc):
+// 24 accumulator tiles per wave (16 in AGPRs, 8 in v128..v255), A fragments read two row blocks ahead, ~6 generation
+// instructions per MFMA.  The HIP part builds the tables, passes the scalars through an LDS config array (the block
+// clobbers every VGPR / AGPR and s8..s99) and writes the workgroup's row of sums.
+#define FUSED_ASM_CLOBBERS \
+    "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", \
+    "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", \
+    "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", \
+    "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", \
+    "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", \
+    "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", \
+    "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", \
+    "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", \
+    "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
+    "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", \
+    "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", \
+    "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", \
+    "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", \
+    "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", \
+    "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", \
+    "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", \
+    "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", \
+    "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", \
+    "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", \
+    "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", \
+    "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", \
+    "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", \
+    "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", \
+    "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", \
+    "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", \
+    "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", \
+    "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", \
+    "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", \
+    "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", \
+    "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", \
+    "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", \
+    "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", \
+    "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", \
+    "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "s8", "s9", "s10", "s11", \
+    "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", \
+    "s28", "s29", "s30", "s31", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", \
+    "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", \
+    "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", \
+    "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", \
+    "s99", "vcc", "scc", "m0", "memory"
+
+__global__ __launch_bounds__(256, 1) void k_act_fused_asm12(FusedArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NRB = 12, FNS = 4, AT = NRB * 2048, ROWS = 32 * NRB, XS = FNS + 1;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    int* s_cfg = reinterpret_cast<int*>(smem);                              // 64 dwords (tools/gen_fused_asm.py: CFG)
+    uint8_t* ring = smem + 256;                                             // FNS * AT
+    uint8_t* xring = ring + FNS * AT;                                       // XS * 4 waves * {256 B x, 256 B log2}
+    uint32_t* s_lut = reinterpret_cast<uint32_t*>(xring + XS * 2048);       // [levels2 + 2][128] bf16 bits (low half)
+    const int lut_rows = p.levels2 + 2;
+    float* s_thr = reinterpret_cast<float*>(s_lut + lut_rows * 128);        // [levels2][128]
+    float4* s_par = reinterpret_cast<float4*>(s_thr + p.levels2 * 128);     // [128] {-37/q, log2(s)*37/q, hi, s * sa_mul}
+    float* s_refb = reinterpret_cast<float*>(s_par + 128);                  // [2][ROWS]
+    float* s_rs = s_refb + 2 * ROWS;                                        // [ROWS]
+    double* s_fin = reinterpret_cast<double*>(s_rs + ROWS);                 // [4][64]
+    const int tid = threadIdx.x;
+    for (int e = tid; e < lut_rows * 128; e += 256) {
+        const int bin = e >> 7, c = e & 127;
+        const int kq = bin * (int)p.qv[c];
+        const int t = kq / ADALOG_R, j = kq - t * ADALOG_R;
+        const float v = (bin >= p.levels2 || t > 100) ? 0.0f : ldexpf(p.mant[j], -t);
+        s_lut[e] = __float_as_uint(v) >> 16;
+    }
+    for (int e = tid; e < p.levels2 * 128; e += 256) s_thr[e] = p.thr[e];
+    if (tid < 128) {
+        const float s = p.scale[tid], qf = p.qv[tid];
+        const float rq37 = 37.0f / qf;
+        const float top = (float)p.levels2 + 0.75f, NL15 = 49.828921f;
+        s_par[tid] = make_float4(-rq37, __log2f(s) * rq37, fminf(NL15 * rq37, top), s * p.sa_mul);
+    }
+    const unsigned ntile = ((unsigned)(p.T + 1) >> 1) * (unsigned)p.n_rt;
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    if (tid < 64) {
+        auto lds_off = [](const void* q) { return (int)(uintptr_t)(const __attribute__((address_space(3))) void*)q; };
+        const uint64_t pw = (uint64_t)p.W, px = (uint64_t)p.x, pl = (uint64_t)p.L, pr = (uint64_t)p.ref, ps = (uint64_t)p.row_scale,
+                       pb = (uint64_t)p.row_bias;
+        // near-tie zone of the fast bin: twice the error bound of the fast value against the reference's fp32 pipeline
+        // (8.6e-6 for <= 4 bit, 2e-5 for 6 bit)
+        const float tie = p.levels2 <= 16 ? 0.499975f : 0.49995f;
+        const int vals[37] = {(int)pw, (int)(pw >> 32), (int)px, (int)(px >> 32), (int)pl, (int)(pl >> 32), (int)pr, (int)(pr >> 32),
+                              (int)ps, (int)(ps >> 32), (int)pb, (int)(pb >> 32), p.M, p.T, p.K, p.Kb, p.nk, p.n_rt, (int)ntile,
+                              (int)nwg, (int)bid, p.levels2, __float_as_int(p.shift), 0 /* w: per wave below */,
+                              lds_off(ring), lds_off(xring), lds_off(s_lut), lds_off(s_thr), lds_off(s_par), lds_off(s_refb),
+                              lds_off(s_rs), lds_off(s_fin), (int)(nwg / (unsigned)p.n_rt), (int)(nwg % (unsigned)p.n_rt),
+                              (int)(bid / (unsigned)p.n_rt), (int)(bid % (unsigned)p.n_rt), __float_as_int(tie)};
+        int val = 0;
+#pragma unroll
+        for (int i = 0; i < 37; ++i) val = tid == i ? vals[i] : val;
+        s_cfg[tid] = val;
+    }
+    __syncthreads();
+    if (bid < ntile) {
+        const int cfg = (int)(uintptr_t)(const __attribute__((address_space(3))) void*)s_cfg;
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+        asm volatile(
+            "s_mov_b32 s63, %[wv]\n\t"          // CFG slot 'w' (s63) is wave-specific: overwritten after the config load below
+            "s_mov_b32 s39, s63\n\t"
+#include "fused_loop_nrb12.inc"
+            :
+            : [cfg] "s"(cfg), [wv] "s"(w)
+            : FUSED_ASM_CLOBBERS);
+    }
+    __syncthreads();
+    const int t2 = threadIdx.x;
+#if defined(FUSED_DEBUG)
+    if (t2 < 64 && bid == FUSED_DEBUG) reinterpret_cast<int*>(p.wg_acc)[t2] = reinterpret_cast<const int*>(s_fin)[t2];
+    return;
+#endif
+    if (t2 < 128 && bid < ntile) {
+        const int cw = t2 >> 6, wi = t2 & 63;
+        p.wg_acc[(int64_t)bid * 128 + t2] = s_fin[cw * 64 + wi] + s_fin[(2 + cw) * 64 + wi];
     }
 #endif
 }
@@ -475,9 +590,12 @@ static int pick_nrb(int M) {
     return best;
 }
 
-static size_t fused_lds_bytes(int nrb, int levels2) {
-    return (size_t)FNS * (nrb * 2048 + 1024) + (size_t)(levels2 + 2) * 512 + 128 * 16 + 128 * 8 + (size_t)3 * 32 * nrb * 4 +
-           256 * 8 + (size_t)4 * QCAP * 4;
+static size_t fused_lds_bytes(int nrb, int fns, int levels2) {
+    return (size_t)fns * nrb * 2048 + (size_t)(fns + 1) * 2048 + (size_t)(levels2 + 2) * 512 + (size_t)levels2 * 512 + 128 * 16 +
+           (size_t)3 * 32 * nrb * 4 + 256 * 8;
+}
+static int pick_fns(int nrb, int levels2) {
+    return fused_lds_bytes(nrb, 4, levels2) <= 160 * 1024 ? 4 : 3;
 }
 
 }  // namespace
@@ -493,12 +611,14 @@ extern "C" int adalog_log2_shift(const float* x, float* out, int64_t n, float sh
 // 1 when adalog_score_act_fused takes this shape (else the caller packs the candidate operand and uses adalog_gemm_score)
 extern "C" int adalog_score_act_fused_ok(int M, int64_t T, int K, int64_t Kp, int P, int n_bits) {
     if (P != 128 || n_bits < 2 || n_bits > 6 || M < 1 || T < 1 || K < 1) return 0;
-    if (Kp < K || (Kp * 2) % 128 != 0 || Kp / 32 < 6 || Kp >= 65536) return 0;     // >= 6 K-steps; k fits the queue record
+    if (Kp < K || (Kp * 2) % 64 != 0 || Kp / 32 < 6) return 0;                       // >= 6 K-steps of 32 elements
     if ((int64_t)M * Kp * 2 >= ((int64_t)1 << 31) || T >= ((int64_t)1 << 30)) return 0;
-    return fused_lds_bytes(pick_nrb(M), 1 << n_bits) <= 160 * 1024 ? 1 : 0;
+    const int nrb = pick_nrb(M);
+    return fused_lds_bytes(nrb, pick_fns(nrb, 1 << n_bits), 1 << n_bits) <= 160 * 1024 ? 1 : 0;
 }
 
-extern "C" int64_t adalog_score_act_fused_workspace_bytes(void) { return (int64_t)fused_cus() * 128 * 8; }
+// [workgroups][128] fp64 partial sums, then the [2^6][128] fp32 threshold table
+extern "C" int64_t adalog_score_act_fused_workspace_bytes(void) { return (int64_t)fused_cus() * 128 * 8 + 64 * 128 * 4; }
 
 // scores[p] = -norm * sum_{t, o} ( (ref[t, o] - row_bias[o]) - s_w[o] * (s_p * sa_mul) * sum_k Wq[o, k] * m_p(x[t, k]) )^2
 // for the 128 AdaLog candidates (s_p, q_p); m_p = integer-numerator form of the search-time AdaLog value
@@ -511,33 +631,50 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
                                       void* stream) {
     ADALOG_ARG_CHECK(Wp && x && Lx && ref && row_scale && scale && qv && mant37 && workspace && scores, "score_act_fused: null pointer");
     ADALOG_ARG_CHECK(adalog_score_act_fused_ok(M, T, K, Kp, P, n_bits), "score_act_fused: shape not supported (ask adalog_score_act_fused_ok first)");
+    ADALOG_ARG_CHECK(clamp_u, "score_act_fused: only the clamped form (post-GELU searches, linear.py:829) is implemented");
     ADALOG_ARG_CHECK(workspace_bytes >= adalog_score_act_fused_workspace_bytes() && ((uintptr_t)workspace & 7) == 0,
                      "score_act_fused: workspace too small or misaligned");
     FusedArgs a{};
     a.W = (const uint8_t*)Wp; a.L = Lx; a.x = x; a.ref = ref; a.row_scale = row_scale; a.row_bias = row_bias;
     a.scale = scale; a.qv = qv; a.mant = mant37; a.wg_acc = (double*)workspace;
-    a.M = M; a.T = (int)T; a.K = K; a.Kb = (int)(Kp * 2); a.levels2 = 1 << n_bits; a.clamp_u = clamp_u;
+    a.M = M; a.T = (int)T; a.K = K; a.Kb = (int)(Kp * 2); a.levels2 = 1 << n_bits;
     a.nk = (int)(Kp * 2 / 64); a.shift = shift; a.sa_mul = sa_mul;
+    float* thr = reinterpret_cast<float*>((uint8_t*)workspace + (size_t)fused_cus() * 128 * 8);
+    a.thr = thr;
     const int nrb = pick_nrb(M);
+    const int fns = pick_fns(nrb, a.levels2);
     a.n_rt = (M + 32 * nrb - 1) / (32 * nrb);
     const int64_t ntile = ((T + 1) / 2) * a.n_rt;
     const int nwg = (int)(ntile < fused_cus() ? ntile : fused_cus());
-    const size_t shm = fused_lds_bytes(nrb, a.levels2);
+    const size_t shm = fused_lds_bytes(nrb, fns, a.levels2);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH_FUSED(NRBV)                                                                                     \
+    hipLaunchKernelGGL(k_tie_thresholds, dim3((unsigned)a.levels2), dim3(128), 0, st, scale, qv, a.levels2, thr);
+    ADALOG_LAUNCH_CHECK("adalog_score_act_fused (thresholds)");
+#define LAUNCH_FUSED(NRBV, FNSV)                                                                               \
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
         if (!attr_set) {                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_act_fused<NRBV>),                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_act_fused<NRBV, FNSV>),                 \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
             attr_set = true;                                                                                   \
         }                                                                                                      \
-        hipLaunchKernelGGL((k_act_fused<NRBV>), dim3((unsigned)nwg), dim3(256), shm, st, a);                   \
+        hipLaunchKernelGGL((k_act_fused<NRBV, FNSV>), dim3((unsigned)nwg), dim3(256), shm, st, a);             \
     } while (0)
-    if (nrb == 12) LAUNCH_FUSED(12);
-    else if (nrb == 8) LAUNCH_FUSED(8);
-    else if (nrb == 6) LAUNCH_FUSED(6);
-    else LAUNCH_FUSED(4);
+#define LAUNCH_FUSED_N(NRBV) do { if (fns == 4) LAUNCH_FUSED(NRBV, 4); else LAUNCH_FUSED(NRBV, 3); } while (0)
+    static const int use_asm = getenv("ADALOG_FUSED_ASM") ? atoi(getenv("ADALOG_FUSED_ASM")) : 1;
+    const size_t shm_asm = 256 + shm;
+    if (nrb == 12 && fns == 4 && use_asm && shm_asm <= 160 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_act_fused_asm12), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_act_fused_asm12, dim3((unsigned)nwg), dim3(256), shm_asm, st, a);
+    } else if (nrb == 12) LAUNCH_FUSED_N(12);
+    else if (nrb == 8) LAUNCH_FUSED_N(8);
+    else if (nrb == 6) LAUNCH_FUSED_N(6);
+    else LAUNCH_FUSED_N(4);
+#undef LAUNCH_FUSED_N
 #undef LAUNCH_FUSED
     ADALOG_LAUNCH_CHECK("adalog_score_act_fused");
     hipLaunchKernelGGL(k_fused_finish, dim3(128), dim3(64), 0, st, (const double*)workspace, nwg, norm, scores);

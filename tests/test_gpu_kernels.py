@@ -796,7 +796,8 @@ def test_score_act_fused_matches_packed_path(I, Oc, T, N, bits, tie, const):
     """gemm_fused.hip against pack_adalog + gemm_score (itself pinned to the reference's traces and to the oracle)."""
     from adalog_amd.quant_layers import linear as LM
     from adalog_amd.ops import BF16
-    be = ops
+    from adalog_amd import backend
+    be = backend.get()
     lay, scs, qs = _postgelu_layer(I, Oc, T, N, bits, 1234 + I + T, tie, const)
     aq = lay.a_quantizer
     with torch.no_grad():
