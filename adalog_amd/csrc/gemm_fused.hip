@@ -458,11 +458,11 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
     "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", \
     "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "s8", "s9", "s10", "s11", \
     "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", \
-    "s28", "s29", "s30", "s31", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", \
-    "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", \
-    "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", \
-    "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", \
-    "s99", "vcc", "scc", "m0", "memory"
+    "s28", "s29", "s30", "s31", "s34", "s35", "s36", "s37", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", \
+    "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", \
+    "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
+    "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", \
+    "s95", "s96", "s97", "s98", "s99", "vcc", "scc", "m0", "memory"
 
 __global__ __launch_bounds__(256, 1) void k_act_fused_asm12(FusedArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -25,6 +25,8 @@ ROWS = 32 * NRB
 NA = 8            # row blocks whose tiles live in AGPRs (2 tiles each)
 MAGIC = 0x4B400000
 TIE_BITS = 0x3EFFF2E5   # 0.4999f
+PACKED = bool(os.environ.get("FUSED_PACKED"))     # v_pk_fma/add_f32 for the pairwise arithmetic: measured 22 % SLOWER beside MFMAs
+SM = 34                                            # s[36:37] = {MAGIC, -}, s[38:39] = {-MAGIC, -} (packed-add constants)
 
 # ---------------------------------------------------------------- config array in LDS (dword indices), written by the kernel
 CFG = ["pW_lo", "pW_hi", "pX_lo", "pX_hi", "pL_lo", "pL_hi", "pRef_lo", "pRef_hi", "pRs_lo", "pRs_hi", "pRb_lo", "pRb_hi",
@@ -193,6 +195,8 @@ def lane_setup(A):
     A.e(f"s_mov_b32 s{S['rW'] + 3}, 0x00020000")
     A.e(f"s_mov_b32 s{S['rX'] + 3}, 0x00020000")
     A.e(f"s_mov_b32 s{S['rL'] + 3}, 0x00020000")
+    A.e(f"s_mov_b32 s{SM}, 0x{MAGIC:08x}")
+    A.e(f"s_mov_b32 s{SM + 2}, 0x{(MAGIC ^ 0x80000000):08x}")
 
 
 def set_x_rsrc(A):
@@ -278,6 +282,9 @@ def issue_a(A, slot_setup):
             A.e(f"s_mov_b32 m0, {t(6)}")
         else:
             A.e(f"s_add_i32 m0, {t(6)}, {q * 4096}")
+        if os.environ.get("FUSED_NODMA") and q > 0:
+            A.e(f"buffer_load_dword {v('XDMA')}, s[{S['rX']}:{S['rX'] + 3}], {t(7)} offen lds")   # keeps the vmcnt bookkeeping, moves 256 B
+            continue
         A.e(f"buffer_load_dwordx4 v{V['DMA'] + q}, s[{S['rW']}:{S['rW'] + 3}], {t(7)} offen lds")
     cursor_step(A, "a", set_a_rows)
 
@@ -319,22 +326,37 @@ def gen_pair_ops(cb, e, set_, val0, dm_first):
     g = V["GT"] + 8 * set_
     k0, k1, t0, t1, d0, d1, a0, a1 = (f"v{g + i}" for i in range(8))
     dm = v("DM", cb)
-    ops = [
-        f"v_fma_f32 {k0}, {v('LV', e)}, {ca}, {cc}",
-        f"v_fma_f32 {k1}, {v('LV', e + 1)}, {ca}, {cc}",
-        f"v_med3_f32 {k0}, {k0}, 0, {chi}",
-        f"v_med3_f32 {k1}, {k1}, 0, {chi}",
-        f"v_add_f32 {t0}, 0x{MAGIC:08x}, {k0}",
-        f"v_add_f32 {t1}, 0x{MAGIC:08x}, {k1}",
-        f"v_lshl_add_u32 {a0}, {t0}, 9, {lutc}",
-        f"v_lshl_add_u32 {a1}, {t1}, 9, {lutc}",
-        ("ds", f"ds_read_b32 v{V['VAL'] + val0}, {a0}", f"val{val0}"),
-        ("ds", f"ds_read_b32 v{V['VAL'] + val0 + 1}, {a1}", f"val{val0 + 1}"),
-        f"v_add_f32 {d0}, 0x{(MAGIC ^ 0x80000000):08x}, {t0}",
-        f"v_add_f32 {d1}, 0x{(MAGIC ^ 0x80000000):08x}, {t1}",
-        f"v_sub_f32 {d0}, {k0}, {d0}",
-        f"v_sub_f32 {d1}, {k1}, {d1}",
-    ]
+    lut0 = ("ds", f"ds_read_b32 v{V['VAL'] + val0}, {a0}", f"val{val0}") if not os.environ.get("FUSED_NOLUT") else f"v_mov_b32 v{V['VAL'] + val0}, {a0}"
+    lut1 = ("ds", f"ds_read_b32 v{V['VAL'] + val0 + 1}, {a1}", f"val{val0 + 1}") if not os.environ.get("FUSED_NOLUT") else f"v_mov_b32 v{V['VAL'] + val0 + 1}, {a1}"
+    if PACKED:
+        pa = V[par]
+        ops = [
+            f"v_pk_fma_f32 v[{g}:{g + 1}], v[{V['LV'] + e}:{V['LV'] + e + 1}], v[{pa}:{pa + 1}], v[{pa}:{pa + 1}] op_sel:[0,0,1] op_sel_hi:[1,0,1]",
+            f"v_med3_f32 {k0}, {k0}, 0, {chi}",
+            f"v_med3_f32 {k1}, {k1}, 0, {chi}",
+            f"v_pk_add_f32 v[{g + 2}:{g + 3}], v[{g}:{g + 1}], s[{SM}:{SM + 1}] op_sel_hi:[1,0]",
+            f"v_lshl_add_u32 {a0}, {t0}, 9, {lutc}",
+            f"v_lshl_add_u32 {a1}, {t1}, 9, {lutc}",
+            lut0, lut1,
+            f"v_pk_add_f32 v[{g + 4}:{g + 5}], v[{g + 2}:{g + 3}], s[{SM + 2}:{SM + 3}] op_sel_hi:[1,0]",
+            f"v_pk_add_f32 v[{g + 4}:{g + 5}], v[{g}:{g + 1}], v[{g + 4}:{g + 5}] neg_lo:[0,1] neg_hi:[0,1]",
+        ]
+    else:
+        ops = [
+            f"v_fma_f32 {k0}, {v('LV', e)}, {ca}, {cc}",
+            f"v_fma_f32 {k1}, {v('LV', e + 1)}, {ca}, {cc}",
+            f"v_med3_f32 {k0}, {k0}, 0, {chi}",
+            f"v_med3_f32 {k1}, {k1}, 0, {chi}",
+            f"v_add_f32 {t0}, 0x{MAGIC:08x}, {k0}",
+            f"v_add_f32 {t1}, 0x{MAGIC:08x}, {k1}",
+            f"v_lshl_add_u32 {a0}, {t0}, 9, {lutc}",
+            f"v_lshl_add_u32 {a1}, {t1}, 9, {lutc}",
+            lut0, lut1,
+            f"v_add_f32 {d0}, 0x{(MAGIC ^ 0x80000000):08x}, {t0}",
+            f"v_add_f32 {d1}, 0x{(MAGIC ^ 0x80000000):08x}, {t1}",
+            f"v_sub_f32 {d0}, {k0}, {d0}",
+            f"v_sub_f32 {d1}, {k1}, {d1}",
+        ]
     if dm_first:
         ops.append(f"v_max_f32 {dm}, abs({d0}), abs({d1})")
     else:
@@ -494,11 +516,14 @@ def unit(A, h, bc, bn, xs_vgpr, eo, cold_blocks):
             a_read(rb + 3)
         A.wait(f"a{rb}")
         for cb in range(2):
-            A.e(f"v_mfma_f32_32x32x16_bf16 {acc(rb, cb)}, {abuf(rb)}, v[{V[bc] + 4 * cb}:{V[bc] + 4 * cb + 3}], {acc(rb, cb)}")
+            if not os.environ.get("FUSED_NOMFMA"):
+                A.e(f"v_mfma_f32_32x32x16_bf16 {acc(rb, cb)}, {abuf(rb)}, v[{V[bc] + 4 * cb}:{V[bc] + 4 * cb + 3}], {acc(rb, cb)}")
             emit_fill(per)
     emit_fill(nf)
     # ---- near-tie checks of the two chunks (cold blocks follow the loop)
     for cb in range(2):
+        if os.environ.get("FUSED_NOCOLD"):
+            continue
         lab = A.new("Lcold")
         A.e(f"v_cmp_lt_f32 vcc, {t(11)}, {v('DM', cb)}")
         A.e(f"s_cbranch_vccnz {lab}_%=")
@@ -733,7 +758,8 @@ def program():
     A.label("Lstep")
     cold = []
     A.e(f"s_waitcnt vmcnt({(FNS - 2) * (NRB // 2 + 2)})")
-    A.e("s_barrier")
+    if not os.environ.get("FUSED_NOBAR"):
+        A.e("s_barrier")
     # ring addresses of this step
     A.e(f"s_mul_i32 {t(0)}, {s('stA')}, {AT}")
     A.e(f"s_add_i32 {t(0)}, {t(0)}, {s('oRing')}")
