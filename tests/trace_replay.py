@@ -6,7 +6,13 @@ candidates and the parameters in force to the product layer's ``_score_*`` metho
 ``-m gpu``, the executable specs of tests/cpu_backend.py in the CPU tier) and the result is compared with the
 reference's own ``trace_NNN_scores``:
 
-  * score vectors: max relative error <= SCORE_RTOL (1e-4; the north-star bar for fp32 tensors is 1e-3);
+  * score vectors: max relative error <= SCORE_RTOL (1e-4; the north-star bar for fp32 tensors is 1e-3), or -- for the
+    near-optimal candidates of 6-bit searches, whose score is a residual ~4^-bits of the signal, so that the fp32
+    rounding of `raw_out - out_sim` (reference and product alike) is a larger FRACTION of it -- an absolute error below
+    NOISE_C * sqrt(|score| * E), E = the same normalised sum over the REFERENCE tensor (raw_out, W or x) squared: the
+    first-order fp32 noise of sum(e^2) is 2 sum(e d), |d| ~ u |out|, i.e. ~ u sqrt(sum e^2) sqrt(sum out^2).  Observed on
+    MI355X: <= 5.6e-6 in these units for every Linear trace at 3, 4 AND 6 bit (the same constant, which is what the model
+    predicts), <= 2e-7 for the attention / conv traces; NOISE_C = 1e-5.  At 4 bit this is below SCORE_RTOL anyway;
   * top-k sets: the product's deterministic top-k of ITS scores must equal the reference's ``trace_NNN_idx`` as a set per
     column, except for members whose REFERENCE scores lie within TIE_RTOL (1e-5 relative) of the k-th best reference
     score -- exact and near ties are structural in FPCS and torch.topk's order among them is unspecified.
@@ -25,6 +31,7 @@ from adalog_amd.ops import BF16, Strided
 from oracle import adalog_oracle as O
 
 SCORE_RTOL = 1e-4
+NOISE_C = 1e-5              # absolute score error allowed: NOISE_C * sqrt(|score| * energy of the reference tensor)
 TIE_RTOL = 1e-5
 NOISE_FLIP_FRAC = 2e-3
 
@@ -38,11 +45,12 @@ class Replay:
 
     def __init__(self, g, prefix="trace"):
         self.g, self.prefix, self.n = g, prefix, 0
-        self.max_err, self.flips, self.noise_flips, self.members, self.max_gap = 0.0, 0, 0, 0, 0.0
+        self.max_err, self.flips, self.noise_flips, self.members, self.max_gap, self.max_nrm = 0.0, 0, 0, 0, 0.0, 0.0
 
-    def check(self, got, cand_axis0: bool):
+    def check(self, got, cand_axis0: bool, energy=None):
         """``got``: product scores [P, cols] (any device).  cand_axis0: golden arrays carry the candidate axis first
-        (weights / matmul / conv) or last (activations)."""
+        (weights / matmul / conv) or last (activations).  ``energy``: [cols] (or scalar) normalised sum of squares of
+        the tensor the scores measure the distance to."""
         g, i = self.g, self.n
         ref = t(g[f"{self.prefix}_{i:03d}_scores"]).float()
         idx = t(g[f"{self.prefix}_{i:03d}_idx"]).long()
@@ -53,9 +61,15 @@ class Replay:
         else:
             ref, idx = ref.reshape(-1, P).t(), idx.reshape(-1, k).t()
         mine = got.detach().float().cpu().reshape(ref.shape)
-        err = ((mine - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
-        assert err <= SCORE_RTOL, f"{self.prefix} call {i}: score rel err {err:.3e} > {SCORE_RTOL}"
+        rel = (mine - ref).abs() / ref.abs().clamp_min(1e-30)
+        en = torch.as_tensor(1.0 if energy is None else energy).detach().float().cpu().reshape(1, -1)
+        nrm = (mine - ref).abs() / (ref.abs() * en).sqrt().clamp_min(1e-30)
+        bad = (rel > SCORE_RTOL) & ((nrm > NOISE_C) | (energy is None))
+        assert not bool(bad.any()), f"{self.prefix} call {i}: score rel err {rel[bad].max().item():.3e} (in units of " \
+                                    f"sqrt(score * energy): {nrm[bad].max().item():.3e})"
+        err = rel.max().item()
         self.max_err = max(self.max_err, err)
+        self.max_nrm = max(self.max_nrm, nrm.max().item())
         my_idx = backend.get().topk(got.detach().float().contiguous(), k).long().cpu()          # [k, cols]
         kth = ref.topk(k, dim=0).values[-1]                                           # k-th best reference score
         for c in range(ref.shape[1]):
@@ -76,8 +90,8 @@ class Replay:
     def done(self):
         assert self.n == int(self.g[f"{self.prefix}_n"]), (self.n, int(self.g[f"{self.prefix}_n"]))
         assert self.noise_flips <= NOISE_FLIP_FRAC * self.members, (self.noise_flips, self.members, self.max_gap)
-        return {"calls": self.n, "max_rel_err": self.max_err, "tie_flips": self.flips, "noise_flips": self.noise_flips,
-                "max_noise_gap": self.max_gap, "members": self.members}
+        return {"calls": self.n, "max_rel_err": self.max_err, "max_err_noise_units": self.max_nrm, "tie_flips": self.flips,
+                "noise_flips": self.noise_flips, "max_noise_gap": self.max_gap, "members": self.members}
 
 
 def _set_uniform(q, scale, zp):
@@ -98,22 +112,34 @@ def _pl(a, dev):
 
 
 # ------------------------------------------------------------------------------------------------ Linear
+def _energies(lay):
+    """normalised sums of squares matching the four Linear score kinds (same reductions as the scores)"""
+    ro, x, W = lay.raw_out.float(), lay.raw_input.float(), lay.weight.data.float()
+    O = ro.shape[-1]
+    rb = ro.reshape(ro.shape[0], -1, O)
+    xb = x.reshape(x.shape[0], -1, x.shape[-1])
+    return {"w_out": (rb ** 2).mean(1).sum(0), "a_out": (rb ** 2).mean((1, 2)).sum(0), "w_self": (W ** 2).mean(1),
+            "a_self": (xb ** 2).mean((1, 2)).sum(0), "a_self_cw": (xb ** 2).mean(1).sum(0)}
+
+
 def _linear_observer(lay, rp, dev):
+    en = _energies(lay)
+
     def obs(kind, p, a, b, s):
         if kind == "w_self":
-            rp.check(lay._score_w_self(_pc(a, dev), _pc(b, dev)), True)
+            rp.check(lay._score_w_self(_pc(a, dev), _pc(b, dev)), True, en["w_self"])
         elif kind == "a_self":
-            rp.check(lay._score_a_self(_pl(a, dev), _pl(b, dev)), False)
+            rp.check(lay._score_a_self(_pl(a, dev), _pl(b, dev)), False, en["a_self"])
         elif kind == "w_out":
             _set_uniform(lay.a_quantizer, p.a_scale, p.a_zp)
             lay.w_quantizer._zp_on_grid = True
-            rp.check(lay._score_w(lay._pack_x_fixed(), _pc(a, dev), _pc(b, dev)), True)
+            rp.check(lay._score_w(lay._pack_x_fixed(), _pc(a, dev), _pc(b, dev)), True, en["w_out"])
         elif kind == "a_out":
             _set_uniform(lay.w_quantizer, p.w_scale, p.w_zp)
             dt = lay._int_dt(lay.raw_input.numel() // lay.in_features)
             wp = lay._pack_w_fixed(dt)
             wp.int_dt = dt
-            rp.check(lay._score_a(wp, _pl(a, dev), _pl(b, dev)), False)
+            rp.check(lay._score_a(wp, _pl(a, dev), _pl(b, dev)), False, en["a_out"])
         else:
             raise AssertionError(kind)
     return obs
@@ -149,7 +175,7 @@ def replay_channelwise(golden, bits, device="cpu"):
 
     def obs(kind, p, a, b_, s):
         assert kind == "a_self_cw"
-        rp.check(lay._score_a_self(_pl(a, dev), _pl(b_, dev)), False)
+        rp.check(lay._score_a_self(_pl(a, dev), _pl(b_, dev)), False, _energies(lay)["a_self_cw"])
     with torch.no_grad():
         s, z = O.search_linear_channelwise(x, ab, batch=cbs, observer=obs)
     out = rp.done()
@@ -166,6 +192,7 @@ def replay_channelwise(golden, bits, device="cpu"):
         O.search_linear(W2, b2, x2, ro, wb, ab, n_V=n_V, batch=cbs, observer=_linear_observer(lay2, rp2, dev))
     out2 = rp2.done()
     return {"calls": out["calls"] + out2["calls"], "max_rel_err": max(out["max_rel_err"], out2["max_rel_err"]),
+            "max_err_noise_units": max(out["max_err_noise_units"], out2["max_err_noise_units"]),
             "tie_flips": out["tie_flips"] + out2["tie_flips"], "noise_flips": out["noise_flips"] + out2["noise_flips"],
             "max_noise_gap": max(out["max_noise_gap"], out2["max_noise_gap"]), "members": out["members"] + out2["members"]}
 
@@ -186,20 +213,21 @@ def replay_postgelu(golden, bits, device="cpu"):
 
     def obs(kind, p, a, b_, s):
         aq = lay.a_quantizer
+        en = _energies(lay)
         if kind == "w_self":
-            rp.check(lay._score_w_self(_pc(a, dev), _pc(b_, dev)), True)
+            rp.check(lay._score_w_self(_pc(a, dev), _pc(b_, dev)), True, en["w_self"])
         elif kind == "a_logbase":
             _set_uniform(lay.w_quantizer, p.w_scale, p.w_zp)
             wp, rowsum = lay._pack_w_fixed(BF16, want_rowsum=True)
             fold = be.shift_fold(rowsum.view(1, -1), lay.w_quantizer.scale.data.view(1, -1), aq.shift.data,
                                  lay.bias.data).view(-1)
-            rp.check(lay._score_scale_logbase(wp, fold, _pl(a, dev), _pl(b_, dev)), False)
+            rp.check(lay._score_scale_logbase(wp, fold, _pl(a, dev), _pl(b_, dev)), False, en["a_out"])
         elif kind == "w_out":
             aq.scale.data.copy_(p.a_scale.reshape(aq.scale.shape).to(dev))
             aq.q.data.fill_(int(p.a_q))
             aq.inited = True
             lay._q_host = int(p.a_q)
-            rp.check(lay._score_w(lay._pack_x_fixed(), _pc(a, dev), _pc(b_, dev)), True)
+            rp.check(lay._score_w(lay._pack_x_fixed(), _pc(a, dev), _pc(b_, dev)), True, en["w_out"])
         else:
             raise AssertionError(kind)
     with torch.no_grad():
@@ -229,14 +257,16 @@ def replay_matmul(golden, bits, device="cpu"):
     lay._initialize_calib_parameters()
     rp = Replay(g)
 
+    en_h = (ro.float() ** 2).mean((2, 3)).sum(0)                          # [H]
+
     def obs(kind, p, a, b_, s):
         dt = _mm_dt(lay)
         if kind == "A":
             _set_uniform(lay.B_quantizer, p.B_scale, p.B_zp)
-            rp.check(lay._score("A", lay._pack_fixed("B", dt), _pc(a, dev), _pc(b_, dev), dt), True)
+            rp.check(lay._score("A", lay._pack_fixed("B", dt), _pc(a, dev), _pc(b_, dev), dt), True, en_h)
         elif kind == "B":
             _set_uniform(lay.A_quantizer, p.A_scale, p.A_zp)
-            rp.check(lay._score("B", lay._pack_fixed("A", dt), _pc(a, dev), _pc(b_, dev), dt), True)
+            rp.check(lay._score("B", lay._pack_fixed("A", dt), _pc(a, dev), _pc(b_, dev), dt), True, en_h)
         else:
             raise AssertionError(kind)
     with torch.no_grad():
@@ -257,20 +287,22 @@ def replay_postsoftmax(golden, bits, device="cpu"):
     lay._initialize_calib_parameters()
     rp = Replay(g)
 
+    en_h = (ro.float() ** 2).mean((2, 3)).sum(0)                          # [H]
+
     def obs(kind, p, a, b_, s):
         aq = lay.A_quantizer
         if kind == "A_logbase":
             _set_uniform(lay.B_quantizer, p.B_scale, p.B_zp)
             q_all, sc = lay._score_A_log_base()
             assert torch.equal(q_all.cpu().long().view(-1), b_.view(-1))
-            rp.check(sc, True)
+            rp.check(sc, True, en_h.mean())
         elif kind == "B":
             aq.q.data.fill_(int(p.A_q))
             lay._q_host = int(p.A_q)
             qv = search.const_tensor([float(p.A_q)], dev)
             ap = lay._pack_A_adalog(lay._a3(lay.raw_input[0]), qv, aq.scale.data.view(-1), 1, True, k_align=lay._kalign())
             rp.check(lay._score("B", ap, _pc(a, dev), _pc(b_, dev), BF16, fixed_sa=Strided(aq.scale.data.view(-1)),
-                                sa_mul=lay._ts32()), True)
+                                sa_mul=lay._ts32()), True, en_h)
         else:
             raise AssertionError(kind)
     with torch.no_grad():
@@ -299,7 +331,7 @@ def replay_conv(golden, bits, device="cpu"):
 
     def obs(kind, p, a, b_, s):
         assert kind == "w_out"
-        rp.check(lay._score_w(xp, ref, M, gh * gw, _pc(a, dev), _pc(b_, dev)), True)
+        rp.check(lay._score_w(xp, ref, M, gh * gw, _pc(a, dev), _pc(b_, dev)), True, (ro.float() ** 2).mean((2, 3)).sum(0))
     with torch.no_grad():
         O.search_conv(W, b, x, ro, wb, (k, k), batch=cbs, observer=obs)
     return rp.done()
