@@ -16,6 +16,7 @@ p, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     "adalog_abi_version": (i32, []),
     "adalog_last_error": (C.c_char_p, []),
+    "adalog_last_kernel": (C.c_char_p, []),
     "adalog_uniform_fake_quant_f32": (i32, [p, p, p, i64, p, p, i64, i64, i32, i32, p]),
     "adalog_log_fake_quant_f32": (i32, [p, p, p, i64, p, p, p, p, i32, p, i32, i32, p]),
     "adalog_pack_uniform": (i32, [p, i64, i64, i64, i64, i64, i64, p, p, i64, i64, i64, i64, i64, i32, i32, p, i64, p, i32, p]),

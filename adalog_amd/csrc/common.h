@@ -10,6 +10,7 @@
 
 extern "C" void adalog_set_error(const char* where, hipError_t e);
 extern "C" void adalog_set_error_msg(const char* msg);
+extern "C" void adalog_note_kernel(const char* name);
 
 #define ADALOG_LAUNCH_CHECK(name)                                   \
     do {                                                            \

@@ -658,6 +658,7 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
             attr_set = true;                                                                                   \
         }                                                                                                      \
+        adalog_note_kernel("k_act_fused<bf16>");                                                             \
         hipLaunchKernelGGL((k_act_fused<NRBV, FNSV>), dim3((unsigned)nwg), dim3(256), shm, st, a);             \
     } while (0)
 #define LAUNCH_FUSED_N(NRBV) do { if (fns == 4) LAUNCH_FUSED(NRBV, 4); else LAUNCH_FUSED(NRBV, 3); } while (0)
@@ -669,6 +670,7 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_act_fused_asm12), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
+        adalog_note_kernel("k_act_fused_asm12<bf16>");
         hipLaunchKernelGGL(k_act_fused_asm12, dim3((unsigned)nwg), dim3(256), shm_asm, st, a);
     } else if (nrb == 12) LAUNCH_FUSED_N(12);
     else if (nrb == 8) LAUNCH_FUSED_N(8);

@@ -2174,6 +2174,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
+            adalog_note_kernel(DTV == 3 ? "k_gemm_slab<fp8>" : "k_gemm_slab<i8>");                                 \
             hipLaunchKernelGGL((k_gemm_slab<NREFV, ROWSV, DTV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);   \
         } while (0)
 #define LAUNCH_SLAB_DT(DTV)                                                                                       \
@@ -2199,6 +2200,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
+            adalog_note_kernel(DTV == 3 ? "k_gemm_grp<fp8>" : "k_gemm_grp<i8>");                                   \
             hipLaunchKernelGGL((k_gemm_grp<NJV, DTV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);             \
         } while (0)
         if (dtype == 3) { if (ref_div == 64) LAUNCH_GRP(2, 3); else if (ref_div == 128) LAUNCH_GRP(4, 3); else LAUNCH_GRP(8, 3); }
@@ -2219,6 +2221,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
+            adalog_note_kernel("k_gemm_grpk<bf16>");                                                              \
             hipLaunchKernelGGL((k_gemm_grpk<NJV, 7>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);              \
         } while (0)
         if (ref_div == 64) LAUNCH_GRPK(2); else if (ref_div == 128) LAUNCH_GRPK(4); else LAUNCH_GRPK(8);
@@ -2241,6 +2244,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (NSV == 4 ? 128 : 80) * 1024); \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
+            adalog_note_kernel(DT == 0 ? "k_gemm_stream<i8>" : DT == 1 ? "k_gemm_stream<bf16>" : DT == 2 ? "k_gemm_stream<f32>" : "k_gemm_stream<fp8>"); \
             hipLaunchKernelGGL((k_gemm_stream<DT, RIV, NWV, NSV>), pgrid, dim3(64 * NWV), shm, st, p);            \
         } while (0)
 #define LAUNCH_STREAM_DT(DT)                                                                                      \
@@ -2262,6 +2266,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
+            adalog_note_kernel("k_gemm_cand_glds");                                                               \
             hipLaunchKernelGGL((k_gemm_cand_glds<DT, TMV>), grid, dim3(512), shm, st, p);                         \
         } while (0)
         if (dtype == 0) { if (L.tm == 2) LAUNCH_GLDS(0, 2); else LAUNCH_GLDS(0, 1); }
@@ -2278,6 +2283,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);                       \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
+            adalog_note_kernel("k_gemm_cand");                                                                    \
             hipLaunchKernelGGL((k_gemm_cand<DT, TMV, ST>), grid, dim3(512), shm, st, p);                          \
         } while (0)
 #define LAUNCH_BIG_TM(DT, ST)                                                                                     \
@@ -2297,6 +2303,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         dim3 block(256);
 #define LAUNCH(DT)                                                                                   \
         do {                                                                                         \
+            adalog_note_kernel("k_gemm_score");                                                      \
             if (out) hipLaunchKernelGGL((k_gemm_score<DT, true>), grid, block, 0, st, p);            \
             else hipLaunchKernelGGL((k_gemm_score<DT, false>), grid, block, 0, st, p);               \
         } while (0)

@@ -217,7 +217,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
                                partial.data_ptr(), n_part, None, 0, 0, 0, int(order), reduce_cols, _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
-        GEMM_EVENTS.append((dtype, M, N, k_valid, C, G, ev0, ev1))      # k_valid: the un-padded K of the packed operands
+        GEMM_EVENTS.append((dtype, M, N, k_valid, C, G, ev0, ev1, lib.adalog_last_kernel().decode()))   # k_valid: un-padded K
     _lib.check(rc, "adalog_gemm_score")
     cols = (gmod if keep_h else 1) * (N if keep_n else 1)
     scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
@@ -289,7 +289,7 @@ def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: i
                                     float(norm), ws.data_ptr(), ws_bytes, scores.data_ptr(), _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
-        GEMM_EVENTS.append((BF16, M, T, K, P, 1, ev0, ev1))
+        GEMM_EVENTS.append((BF16, M, T, K, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
     _lib.check(rc, "adalog_score_act_fused")
     return scores
 

@@ -36,8 +36,10 @@ class QuantCalibrator:
         self.calib_loader = calib_loader
         self.capture = capture
         self.verbose = verbose
-        self.timings = {}                    # module name -> seconds spent in hyperparameter_searching (+ reparam)
+        self.timings = {}                    # module name -> HOST seconds enqueueing hyperparameter_searching (+ reparam)
         self.capture_seconds = 0.0
+        self._events = {}                    # module name -> (start, end) device events around its search (+ reparam)
+        self._capture_events = []
 
     # hooks keep the reference's names (calibrator.py:14-28); tensors stay on the device
     def single_input_forward_hook(self, module, inp, outp):
@@ -68,6 +70,7 @@ class QuantCalibrator:
         """One pass over the calibration set recording inputs/outputs of every module in ``group``."""
         t0 = time.perf_counter()
         device = next(self.model.parameters()).device
+        cev = self._event_pair(device)
         hooks = []
         last = group[-1][1]
         for _, module in group:
@@ -96,6 +99,32 @@ class QuantCalibrator:
                 module.raw_input = [torch.cat(t, dim=0) for t in module.tmp_input]
             module.tmp_input = module.tmp_out = None
         self.capture_seconds += time.perf_counter() - t0
+        if cev is not None:
+            cev[1].record()
+            self._capture_events.append(cev)
+
+    @staticmethod
+    def _event_pair(device):
+        """(start, end) events on the current stream, start already recorded; None off-GPU"""
+        if torch.device(device).type != "cuda":
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+
+    def fpcs_seconds(self):
+        """DEVICE seconds per module: events on the search stream around hyperparameter_searching (+ reparam), i.e. the
+        reference's `FPCS wall-clock = sum over modules` without the host running ahead.  Synchronises."""
+        if not self._events:
+            return {}
+        torch.cuda.synchronize()
+        return {n: a.elapsed_time(b) * 1e-3 for n, (a, b) in self._events.items()}
+
+    def capture_device_seconds(self):
+        if not self._capture_events:
+            return 0.0
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self._capture_events) * 1e-3
 
     def batching_quant_calib(self):
         pending = self._pending()
@@ -110,10 +139,14 @@ class QuantCalibrator:
             self._capture(group)
             for name, module in group:
                 t0 = time.perf_counter()
+                ev = self._event_pair(next(self.model.parameters()).device)
                 with torch.no_grad():
                     module.hyperparameter_searching()
                     if hasattr(module, 'prev_layer') and module.prev_layer is not None:
                         module.reparam()
+                if ev is not None:
+                    ev[1].record()
+                    self._events[name] = ev
                 self.timings[name] = time.perf_counter() - t0      # host-side enqueue time; the stream runs behind
                 if self.verbose:
                     print(f"calibrated {name}")

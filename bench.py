@@ -9,8 +9,11 @@ BASELINE.json configs[1]: deit_small, W4A4 (configs/4bit.py), 32 synthetic 224x2
 (weak scaling: the global calibration set is 32*N images sharded by rank, scores all-reduced over RCCL).
 Inputs (images, random-init weights) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
   value      = calibration images per second, whole job  (= 32*N*K / wall, wall = max over ranks)
-  roofline   = the dominant kernel (k_gemm_stream, int8 MFMA): algorithmic ops of its launches / their summed duration,
-               measured live with events on the launch stream during the timed steps
+  roofline   = the dominant scoring kernel (largest summed launch time; the library reports which kernel each launch used):
+               algorithmic flops of its launches / their summed duration, measured live with events on the launch stream
+               during the timed steps; config.scoring_kernels lists every kernel the same way
+  hbm_kernels = the HBM-class kernels of the path (fake-quant, self-MSE scoring, quantile, packing) against 8 TB/s
+  brecq      = BRECQ iterations per second on one block (bounded sample)
   cpu_baseline = the CPU oracle (a port of the reference's algorithm, oracle/) timed on the host cores on a bounded
                sample of the same workload and scaled to images/s with the work model of BASELINE.md section 2
 """
@@ -40,8 +43,9 @@ def load_cfg(bits):
 
 
 class GemmProfiler:
-    """Collects the event pairs adalog_amd.ops records around every scoring-GEMM launch (on the launch stream) together
-    with the true (un-padded) K of the packed operands, so that ALGORITHMIC flops = 2*M*N*K*C*G are divided by kernel time."""
+    """Collects the event pairs adalog_amd.ops records around every scoring launch (on the launch stream) together with
+    the true (un-padded) K of the operands and the name of the kernel the library picked (adalog_last_kernel), so that
+    ALGORITHMIC flops = 2*M*N*K*C*G are divided by kernel time, per kernel."""
 
     def __init__(self, ops):
         self.ops = ops
@@ -52,62 +56,137 @@ class GemmProfiler:
     def stop(self):
         ev, self.ops.GEMM_EVENTS = self.ops.GEMM_EVENTS, None
         torch.cuda.synchronize()
-        by, shapes = {}, {}
-        for dt, M, N, K, C, G, s, e in ev:
+        by, shapes, kern = {}, {}, {}
+        for dt, M, N, K, C, G, s, e, name in ev:
             ms = s.elapsed_time(e)
-            for d, key in ((by, dt), (shapes, (dt, M, N, K, C, G))):
+            for d, key in ((by, dt), (shapes, (dt, M, N, K, C, G, name)), (kern, (name, dt))):
                 b = d.setdefault(key, [0.0, 0.0, 0])
                 b[0] += 2.0 * M * N * K * C * G
                 b[1] += ms
                 b[2] += 1
-        self.shapes = shapes
+        self.shapes, self.kernels = shapes, kern
         return by
 
     def top_shapes(self, steps, n=14):
         """Per-shape totals (rows x columns x K, candidates, groups), largest time first."""
         rows = sorted(self.shapes.items(), key=lambda kv: -kv[1][1])[:n]
-        return [{"dtype": DT_NAME[k[0]], "M": k[1], "N": k[2], "K": k[3], "cands": k[4], "groups": k[5],
+        return [{"kernel": k[6], "dtype": DT_NAME[k[0]], "M": k[1], "N": k[2], "K": k[3], "cands": k[4], "groups": k[5],
                  "launches_per_step": v[2] / steps, "ms_per_step": round(v[1] / steps, 2),
                  "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in rows]
 
+    def by_kernel(self, steps):
+        rows = sorted(self.kernels.items(), key=lambda kv: -kv[1][1])
+        return [{"kernel": k[0], "dtype": DT_NAME[k[1]], "launches_per_step": v[2] / steps, "ms_per_step": round(v[1] / steps, 2),
+                 "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1), "frac_of_peak": round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_TOPS[k[1]], 3)}
+                for k, v in rows]
 
-# scoring-GEMM kernels by operand type: the roofline object covers every launch of the dominant type
-KERNELS = {0: "k_gemm_slab + k_gemm_stream<i8> + k_gemm_grp<i8>", 1: "k_gemm_stream<bf16> + k_gemm_grpk<bf16>", 2: "k_gemm_stream<f32>",
-           3: "k_gemm_grp<fp8> + k_gemm_stream<fp8>"}
 
-
-def pmc_traffic(dom):
-    """HBM bytes per launch of the dominant scoring-GEMM dtype, from the committed PMC passes over this same workload
-    (tools/pmc_bench.sh -> profiles/r01_pmc_bench_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE,
-    averaged over every dispatch of one calibration step).  None when the summary is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_bench_traffic.json")
+def pmc_traffic(kernel, workload_is_default):
+    """HBM bytes per launch of `kernel`, REPLAYED from the committed PMC passes of this same command
+    (tools/pmc_bench.sh -> profiles/r02_pmc_bench_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged
+    over every dispatch of one calibration step).  None for any other workload or when the summary is absent."""
+    if not workload_is_default:
+        return None
+    path = os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")
     try:
         with open(path) as f:
             rows = json.load(f)
     except OSError:
         return None
-    def dtype_of(name):
-        # k_gemm_stream<DT, RI, NW, NS>; k_gemm_slab<NREF, ROWS, DT>; k_gemm_grp<NJ, DT>; k_gemm_grpk<NJ, NK> is bf16
-        try:
-            args = name[name.index("<") + 1:name.index(">")].split(",")
-            if name.startswith("k_gemm_stream<"):
-                return int(args[0])
-            if name.startswith("k_gemm_slab<"):
-                return int(args[2])
-            if name.startswith("k_gemm_grp<"):
-                return int(args[1])
-            if name.startswith("k_gemm_grpk<"):
-                return 1
-        except (ValueError, IndexError):
-            pass
-        return None
-
+    base = kernel.split("<")[0]
     tot, n = 0.0, 0
     for name, v in rows.items():
-        if dtype_of(name) == dom and v.get("hbm_read_bytes_per_launch") is not None:
+        if name.startswith(base) and v.get("hbm_read_bytes_per_launch") is not None:
             tot += (v["hbm_read_bytes_per_launch"] + (v.get("hbm_write_bytes_per_launch") or 0.0)) * v["launches"]
             n += v["launches"]
     return tot / n if n else None
+
+
+def hbm_kernels(ops, dev):
+    """Class-E (HBM-bound) kernels of the path at the deit_small / 32-image layer shapes: algorithmic bytes
+    over the median event time, against 8 TB/s."""
+    def timeit(fn, reps=5):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b))
+        return sorted(ts)[len(ts) // 2]
+    g = torch.Generator().manual_seed(3)
+    M = 32 * 197
+    out = []
+    x = torch.randn(M, 1536, generator=g).to(dev)                          # fc2 input sized tensor (38.7 MB)
+    xg = torch.nn.functional.gelu(x)
+    sc1, zp1 = torch.tensor([0.21], device=dev), torch.tensor([7.0], device=dev)
+    P = 128
+    cs = (torch.rand(P, 1, generator=g) * 0.2 + 0.1).to(dev)
+    cz = torch.randint(4, 12, (P, 1), generator=g).float().to(dev)
+    W = (torch.randn(1536, 384, generator=g) * 0.05).to(dev)
+    csw = (torch.rand(P, 1536, generator=g) * 0.01 + 0.005).to(dev)
+    czw = torch.randint(4, 12, (P, 1536), generator=g).float().to(dev)
+    q = torch.tensor([37], dtype=torch.int64, device=dev)
+    from adalog_amd.quantizers.logarithm import AdaLogQuantizer
+    t1, t2 = AdaLogQuantizer.make_tables(37, 8)                             # 4 bit: n_levels = 8, 16-entry tables
+    t1, t2 = t1.to(dev), t2.to(dev)
+    shift = torch.tensor([0.17], device=dev)
+    x384 = x[:, :384].contiguous().unsqueeze(0)
+    nb = x.numel() * 4
+    rows = [
+        ("k_uniform_rows (K1 uniform fake-quant, fp32 in/out)", 2 * nb, lambda: ops.uniform_fake_quant(x, sc1, zp1, 4)),
+        ("k_adalog (K2/K3 shifted AdaLog fake-quant)", 2 * nb,
+         lambda: ops.log_fake_quant(xg, sc1, q, t1, t2, 4, shift=shift, sub_shift=True)),
+        ("k_score_a_self (K10, 128 candidates, x read once)", nb, lambda: ops.score_a_self(x, cs, cz, False, 4, 1.0)),
+        ("k_score_w_self (K9, 128 candidates)", W.numel() * 4, lambda: ops.score_w_self(W, csw, czw, 4)),
+        ("k_sel_hist/pick (K5 quantile, 4 radix passes)", 4 * nb, lambda: ops.quantile_rows(x.view(1, -1), [0.9, 1.0, 0.1, 0.0], 1)),
+        ("k_log2_shift (input of the fused search, once per layer)", 2 * nb, lambda: ops.log2_shift(xg, 0.17)),
+        ("k_pack_uniform_i8_fast (128 candidates -> int8 operand)", x384.numel() * 4 + x384.numel() * P,
+         lambda: ops.pack_uniform(x384, cs, cz, P, 1, 1, 0, 0, 4, ops.I8, c_inner=True)),
+    ]
+    for name, nbytes, fn in rows:
+        try:
+            ms = timeit(fn)
+            out.append({"kernel": name, "algorithmic_bytes": int(nbytes), "ms": round(ms, 4), "achieved_GBps": round(nbytes / ms / 1e6, 1),
+                        "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000.0, 3)})
+        except Exception as ex:                                   # a micro-benchmark must never take the headline down
+            out.append({"kernel": name, "error": repr(ex)[:200]})
+    return out
+
+
+def brecq_rate(model_name, bits, dev, iters=120):
+    """BRECQ (utils/block_recon.py:84-137) iterations per second on blocks.0 of the benchmarked model: a bounded sample
+    (the reference runs 20 000 iterations per block); wall time for one block and the whole model follow by scaling."""
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import create_model
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    cfg = load_cfg(bits)
+    torch.manual_seed(5)
+    base = create_model(model_name).eval()
+    full = copy.deepcopy(base).to(dev).eval()
+    model = wrap_modules_in_net(base, cfg, reparam=True).to(dev)
+    imgs = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(dev)
+    QuantCalibrator(model, [(imgs, None)], capture="block").batching_quant_calib()
+    model = wrap_reparamed_modules_in_net(model)
+    for m in model.modules():
+        if hasattr(m, "reparam_bias"):
+            m.reparam_bias()
+    opt = torch.randn(64, 3, 224, 224, generator=torch.Generator().manual_seed(6)).to(dev)
+    rec = BlockReconstructor(model, full, [(opt[:32], None), (opt[32:], None)])
+    name = "blocks.0"
+    block, fblock = rec.blocks[name], rec.full_blocks[name]
+    rec.init_block_raw_data(block, fblock, name, dev)
+    rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=10)          # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=iters)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nblk = len(rec.blocks)
+    return {"iters_per_s": round(iters / dt, 1), "ms_per_iter": round(dt / iters * 1e3, 3), "block": name, "batch": 32,
+            "sample_iters": iters, "blocks_in_model": nblk,
+            "extrapolated_s_per_block_20000_iters": round(20000 * dt / iters, 1),
+            "extrapolated_s_whole_model": round(20000 * dt / iters * nblk, 1)}
 
 
 def _cpu_sample(threads, n_cand, min_seconds=0.0):
@@ -250,8 +329,12 @@ def main():
 
     prof = GemmProfiler(ops)
 
+    cals = []
+
     def one_step(model):
-        QuantCalibrator(model, loader, capture="block").batching_quant_calib()
+        cal = QuantCalibrator(model, loader, capture="block")
+        cal.batching_quant_calib()
+        cals.append(cal)
 
     models = [copy.deepcopy(base) for _ in range(args.warmup + args.steps)]
     for i in range(args.warmup):
@@ -277,15 +360,20 @@ def main():
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         value = cfg.calib_size * args.steps / wall
-        dom = max(by, key=lambda d: by[d][1]) if by else 0
-        fl, ms, n = by.get(dom, (0.0, 1.0, 1))
+        # the dominant KERNEL (largest summed launch time over the timed steps) carries the roofline object
+        (dom_name, dom), (fl, ms, n) = max(prof.kernels.items(), key=lambda kv: kv[1][1]) if prof.kernels else (("", 0), (0.0, 1.0, 1))
         achieved = fl / (ms * 1e-3) / 1e12
         gemm_ms_total = sum(v[1] for v in by.values())
+        timed = cals[args.warmup:]
+        fpcs = [sum(c.fpcs_seconds().values()) for c in timed]
+        capt = [c.capture_device_seconds() for c in timed]
+        default_workload = (args.model == "deit_small" and args.bits == 4 and args.images_per_gpu == 32 and world == 1
+                            and args.depth is None)
         result = {
             "metric": "calib_images_per_sec", "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if args.images_total is not None else "weak",
-            "vs_baseline": None, "dtype": "i8" if dom == 0 else DT_NAME[dom], "data": "synthetic",
+            "vs_baseline": None, "dtype": DT_NAME[dom], "data": "synthetic",
             "config": {"workload": f"{args.model} W{cfg.w_bit}A{cfg.a_bit} --calibrate, {args.images_per_gpu} calib images "
                                    f"per GPU ({cfg.calib_size} total), eq_n=128, 3 rounds, FPCS 6 steps",
                        "calib_wall_s_per_step": wall / args.steps,
@@ -293,14 +381,26 @@ def main():
                        "scoring_gemm_by_dtype": {DT_NAME[d]: {"launches_per_step": v[2] / args.steps,
                                                               "ms_per_step": v[1] / args.steps,
                                                               "tflops": v[0] / (v[1] * 1e-3) / 1e12} for d, v in by.items()},
+                       "scoring_kernels": prof.by_kernel(args.steps),
                        "scoring_gemm_top_shapes": prof.top_shapes(args.steps),
+                       "fpcs_seconds_per_step": sum(fpcs) / max(len(fpcs), 1),
+                       "capture_seconds_per_step": sum(capt) / max(len(capt), 1),
+                       "fpcs_note": "device events on the search stream around every module's hyperparameter_searching (+ reparam), "
+                                    "summed over the modules (rank 0); capture = the FP forward passes that record the activations",
                        "depth_override": args.depth},
-            "roofline": {"bound": "mfma", "kernel": KERNELS[dom], "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],
-                         "traffic": pmc_traffic(dom),
+                         "traffic": pmc_traffic(dom_name, default_workload),
+                         "traffic_note": "replayed from profiles/r02_pmc_bench_traffic.json (rocprofv3 --pmc passes of this same "
+                                         "command); null for any other workload",
                          "launches": n, "avg_launch_ms": ms / max(n, 1)},
         }
         if not args.no_cpu_baseline and world == 1:
+            result["hbm_kernels"] = hbm_kernels(ops, dev)
+            try:
+                result["brecq"] = brecq_rate(args.model, args.bits, dev)
+            except Exception as ex:
+                result["brecq"] = {"error": repr(ex)[:300]}
             result["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
         print(json.dumps(result))
     if world > 1:

@@ -22,6 +22,8 @@ extern "C" {
 
 int adalog_abi_version(void);
 const char* adalog_last_error(void);
+/* measurement aid: name of the scoring kernel the last adalog_gemm_score / adalog_score_act_fused call of this thread launched */
+const char* adalog_last_kernel(void);
 
 /* ---- K1  UniformQuantizer.forward, eval form                      reference quantizers/uniform.py:25-36
  * y = (clamp(rne(x/s) + rne(zp), 0, 2L-1) - rne(zp)) * s   (asymmetric), or clamp(rne(x/s), -L, L-1) * s (symmetric).
