@@ -176,7 +176,8 @@ def brecq_rate(model_name, bits, dev, iters=120):
     name = "blocks.0"
     block, fblock = rec.blocks[name], rec.full_blocks[name]
     rec.init_block_raw_data(block, fblock, name, dev)
-    rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=10)          # warm-up
+    rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=10)          # warm-up (releases the block data)
+    rec.init_block_raw_data(block, fblock, name, dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=iters)

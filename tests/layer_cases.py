@@ -347,3 +347,67 @@ def case_brecq_reconstruct(device="cpu", iters=60):
     w3 = lin.weight.data.view(lin.n_V, lin.crb_rows, lin.in_features)
     grid = w3 / lin.w_quantizer.scale.data
     assert (grid - grid.round()).abs().max().item() < 1e-3            # committed to the integer grid
+
+
+def case_brecq_converges(device="cuda", iters=20000, images=256):
+    """BRECQ as the reference runs it (block_recon.py:84-137: 20 000 Adam iterations of batch 32 per block, rounding
+    regulariser after the 20 % warm-up, b: 20 -> 2, hard rounding committed at the end) on the transformer block of a
+    depth-1 deit_small at W4A4: the block's reconstruction error against the FP block, over the optimisation images,
+    must be LOWER after the reconstruction (learned rounding + tuned activation scales) than before it (nearest rounding,
+    calibrated scales).  Returns the numbers for the log."""
+    DEV[0] = torch.device(device)
+    import copy
+    import importlib.util
+    import os
+    import time
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import create_model
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cfg4c", os.path.join(root, "configs", "4bit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = mod.Config()
+    torch.manual_seed(5)
+    base = create_model("deit_small", depth=1).eval()
+    for p_ in base.parameters():                                   # random-init weights: give the activations some spread
+        p_.data.mul_(4.0)
+    full = copy.deepcopy(base).to(DEV[0]).eval()
+    model = wrap_modules_in_net(base, cfg, reparam=True).to(DEV[0])
+    g = torch.Generator().manual_seed(5)
+    calib = torch.randn(32, 3, 224, 224, generator=g).to(DEV[0])
+    QuantCalibrator(model, [(calib, None)], capture="block").batching_quant_calib()
+    model = wrap_reparamed_modules_in_net(model)
+    for m in model.modules():
+        if hasattr(m, "reparam_bias"):
+            m.reparam_bias()
+    opt = torch.randn(images, 3, 224, 224, generator=g).to(DEV[0])
+    loader = [(opt[i:i + 32], None) for i in range(0, images, 32)]
+    rec = BlockReconstructor(model, full, loader)
+    name = "blocks.0"
+    block, fblock = rec.blocks[name], rec.full_blocks[name]
+    rec.init_block_raw_data(block, fblock, name, DEV[0])
+    xin, tgt = block.raw_input.clone(), block.raw_out.clone()
+
+    def block_err():
+        rec.set_block_mode(block, "quant_forward")
+        with torch.no_grad():
+            e = sum(((block(xin[i:i + 32]) - tgt[i:i + 32]) ** 2).sum().item() for i in range(0, images, 32)) / tgt.numel()
+        rec.set_block_mode(block, "raw")
+        return e
+    e0 = block_err()
+    torch.cuda.synchronize() if DEV[0].type == "cuda" else None
+    t0 = time.perf_counter()
+    rec.reconstruct_single_block(name, block, DEV[0], quant_act=True, iters=iters)
+    torch.cuda.synchronize() if DEV[0].type == "cuda" else None
+    dt = time.perf_counter() - t0
+    # commit the hard rounding exactly as reconstruct_model does (block_recon.py:151-157)
+    from adalog_amd.quantizers.adaround import AdaRoundQuantizer
+    for m in block.modules():
+        if hasattr(m, "w_quantizer") and isinstance(m.w_quantizer, AdaRoundQuantizer):
+            m.weight.data.copy_(m.w_quantizer.get_hard_value(m.weight.data))
+            del m.w_quantizer.alpha
+            m.w_quantizer.round_mode = "nearest"
+    e1 = block_err()
+    return {"mse_before": e0, "mse_after": e1, "iters": iters, "seconds": dt, "iters_per_s": iters / dt}

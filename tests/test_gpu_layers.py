@@ -116,3 +116,18 @@ def test_brecq_toy_forward_backward(golden):
 
 def test_brecq_reconstruct_model():
     LC.case_brecq_reconstruct(DEV, iters=200)
+
+
+def test_brecq_block_converges_at_reference_length():
+    """The reference's 20 000 iterations on one deit_small block: reconstruction error after < before."""
+    import json
+    import os
+    r = LC.case_brecq_converges(DEV, iters=20000, images=256)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "brecq_convergence.json"), "w") as f:
+            json.dump(r, f)
+    except OSError:
+        pass
+    assert r["mse_after"] < r["mse_before"], r
