@@ -10,7 +10,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from . import _lib
+from . import _lib, _torch_ops
 
 I8, BF16, F32, FP8 = 0, 1, 2, 3        # FP8: e4m3 bytes holding q - z of <= 4-bit layers exactly (same MFMA rate as int8)
 # bench.py sets this to a list to time the scoring GEMM launches: (dtype, M, N, Kp, C, G, A.data_ptr(), start, end) with
@@ -67,6 +67,8 @@ def uniform_fake_quant(x, scale, zero_point, n_bits: int, sym: bool = False, wan
     scale = _f32c(scale, "scale")
     zp = None if sym else _f32c(zero_point, "zero_point")
     n_ch, inner = broadcast_layout(x.shape, scale.shape)
+    if want_y and not want_bins and _torch_ops.available():          # level 1: the registered PyTorch custom op
+        return torch.ops.adalog.uniform_fake_quant(x, scale, zp, n_ch, inner, int(n_bits), bool(sym))
     y = torch.empty_like(x) if want_y else None
     bins = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_bins else None
     lib = _lib.load()
@@ -84,6 +86,9 @@ def log_fake_quant(x, scale, q, table1, table2, n_bits: int, shift=None, sub_shi
         raise ValueError("AdaLog quantisers are per-tensor (scale must have one element)")
     if q.dtype != torch.int64 or not q.is_cuda:
         raise TypeError("q must be an int64 tensor on the device (the quantiser's buffer)")
+    if want_y and not want_bins and not train_form and _torch_ops.available():
+        return torch.ops.adalog.log_fake_quant(x, scale, q, _f32c(table1, "table1"), _f32c(table2, "table2"), int(n_bits),
+                                               None if shift is None else _f32c(shift, "shift"), bool(sub_shift))
     y = torch.empty_like(x) if want_y else None
     bins = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_bins else None
     lib = _lib.load()
@@ -254,6 +259,8 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
 def log2_shift(x, shift: float):
     """log2(x + shift), correctly rounded, -inf where x + shift <= 0 (input of score_act_fused; once per layer)."""
     x = _f32c(x, "x")
+    if _torch_ops.available():
+        return torch.ops.adalog.log2_shift(x, float(shift))
     out = torch.empty_like(x)
     rc = _lib.load().adalog_log2_shift(x.data_ptr(), out.data_ptr(), x.numel(), float(shift), _stream())
     _lib.check(rc, "adalog_log2_shift")
@@ -275,6 +282,11 @@ def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: i
     P = scale.numel()
     assert wp.dtype == torch.bfloat16 and wp.is_contiguous() and ref2.shape == (T, M)
     x2, lx2, ref2 = _f32c(x2, "x"), _f32c(lx2, "log2 x"), _f32c(ref2, "ref")
+    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
+        return torch.ops.adalog.score_act_fused(wp, x2, lx2, ref2, _f32c(row_scale, "row_scale"),
+                                                None if row_bias is None else _f32c(row_bias, "row_bias"),
+                                                _f32c(scale, "scale"), _f32c(qv, "qv"), int(n_bits), _f32c(mant37, "mant37"),
+                                                float(shift), bool(clamp_u), float(sa_mul), float(norm))
     ws_bytes = lib.adalog_score_act_fused_workspace_bytes()
     ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x2.device)
     scores = torch.empty((P, 1), dtype=torch.float32, device=x2.device)
@@ -298,6 +310,8 @@ def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: i
 def topk(scores, k: int):
     scores = _f32c(scores, "scores")
     P, cols = scores.shape
+    if _torch_ops.available():
+        return torch.ops.adalog.topk(scores, int(k))
     idx = torch.empty((k, cols), dtype=torch.int32, device=scores.device)
     rc = _lib.load().adalog_topk(scores.data_ptr(), P, cols, int(k), idx.data_ptr(), _stream())
     _lib.check(rc, "adalog_topk")

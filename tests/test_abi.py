@@ -48,3 +48,20 @@ def test_product_package_never_imports_oracle():
     out = subprocess.run(["grep", "-rIl", "-E", r"(^|[^_a-zA-Z])oracle", os.path.join(ROOT, "adalog_amd"),
                           "--include=*.py", "--include=*.hip", "--include=*.h"], capture_output=True, text=True).stdout
     assert out.strip() == "", f"product files mention the oracle: {out}"
+
+
+def test_torch_ops_registered_hip_only():
+    """torch.ops.adalog.* (north_star: 'through PyTorch-ROCm custom ops'): the TORCH_LIBRARY registration loads, declares the
+    expected schemas and has NO CPU kernel (calling it with CPU tensors is an error, not a fallback)."""
+    import torch
+    from adalog_amd import _torch_ops
+    if not os.path.exists(_torch_ops.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    assert _torch_ops.available()
+    for name in _torch_ops.OPS:
+        assert hasattr(torch.ops.adalog, name), name
+    with pytest.raises(NotImplementedError):
+        torch.ops.adalog.topk(torch.zeros(4, 3), 2)
+    with pytest.raises(NotImplementedError):
+        torch.ops.adalog.uniform_fake_quant(torch.zeros(4), torch.ones(1), torch.zeros(1), 1, 4, 4, False)

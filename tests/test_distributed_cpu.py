@@ -106,3 +106,67 @@ def test_shard_slice_and_gather_single_process():
     assert parallel.shard_slice(32) == (0, 32)
     x = torch.arange(6.0).view(3, 2)
     assert parallel.gather_images(x) is x and parallel.all_reduce_sum(x) is x
+
+
+def _brecq_worker(rank, world, port, outdir):
+    """BRECQ data parallelism: every rank trains the same block on its own shard of the block inputs; the
+    gradients of alpha / activation scales are all-reduced (mean) each iteration, so the ranks' parameters stay identical."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from adalog_amd import backend, quant_layers as Q
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    from tests import cpu_backend
+    torch.set_num_threads(2)
+    backend.set_backend(cpu_backend)
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "brecq_toy.npz"))
+    I, Hd = 16, 32
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            kw = dict(mode="raw", w_bit=4, a_bit=4, calib_batch_size=4, search_round=1, eq_n=128, fpcs=True, steps=2)
+            self.fc1 = Q.AsymmetricallyBatchingQuantLinear(I, Hd, True, n_V=1, **kw)
+            self.fc2 = Q.PostGeluLogBasedBatchingQuantLinear(Hd, I, True, n_V=1, quantizer="adalog", **kw)
+
+        def forward(self, x):
+            return x + self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+    blk = Blk().eval()
+    sd = {k[4:].replace("__", "."): torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("cal_") and "matmul1" not in k}
+    blk.load_state_dict(sd, strict=False)
+    for m in blk.modules():
+        if hasattr(m, "mode"):
+            m.calibrated = True
+            m.a_quantizer.inited = m.w_quantizer.inited = True
+    gen = torch.Generator().manual_seed(99)
+    x = torch.randn(16, 5, I, generator=gen)
+    with torch.no_grad():
+        y = blk(x)                                                 # FP targets (mode 'raw')
+    per = 16 // world
+    blk.raw_input, blk.raw_out = x[rank * per:(rank + 1) * per].clone(), y[rank * per:(rank + 1) * per].clone()
+    rec = object.__new__(BlockReconstructor)
+    rec.reconstruct_single_block("blk", blk, torch.device("cpu"), batch_size=8, iters=12, quant_act=True)
+    out = {"alpha1": blk.fc1.w_quantizer.alpha.data.clone(), "alpha2": blk.fc2.w_quantizer.alpha.data.clone(),
+           "s1": blk.fc1.a_quantizer.scale.data.clone(), "s2": blk.fc2.a_quantizer.scale.data.clone()}
+    torch.save(out, os.path.join(outdir, f"brecq_rank{rank}_of{world}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_brecq_gradient_all_reduce_keeps_ranks_in_lock_step():
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_brecq_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(d, "brecq_rank0_of2.pt")), torch.load(os.path.join(d, "brecq_rank1_of2.pt"))
+        mp.spawn(_brecq_worker, args=(1, _free_port(), d), nprocs=1, join=True)
+        single = torch.load(os.path.join(d, "brecq_rank0_of1.pt"))
+    for k in r0:
+        assert torch.equal(r0[k], r1[k]), f"ranks diverged on {k}: the gradients were not all-reduced"
+    # the ranks saw different samples than the single process, so the parameters moved differently -- but they did move
+    assert not torch.equal(r0["alpha1"], single["alpha1"])
+    init = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "brecq_toy.npz"))["alpha_fc1"])
+    assert (r0["alpha1"] - init).abs().max().item() > 1e-4

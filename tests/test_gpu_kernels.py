@@ -814,3 +814,21 @@ def test_score_act_fused_matches_packed_path(I, Oc, T, N, bits, tie, const):
     assert torch.equal(got, got2)                                     # bit-reproducible
     err = ((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
     assert err <= 2e-6, err
+
+
+def test_torch_ops_route_matches_c_abi():
+    """torch.ops.adalog.* (TORCH_LIBRARY shims) give bit-identical results to the ctypes route of the same C ABI, and
+    adalog_amd.ops goes through them when the extension is built."""
+    from adalog_amd import _torch_ops, ops as OPS
+    assert _torch_ops.available(), "libadalog_torch.so not built (python adalog_amd/csrc/build_torch_ops.py)"
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(64, 197, 96, generator=g).to(DEV)
+    s = torch.rand(96, generator=g).to(DEV) * 0.1 + 0.05
+    z = torch.randint(3, 12, (96,), generator=g).float().to(DEV)
+    y_t = torch.ops.adalog.uniform_fake_quant(x, s, z, 96, 1, 4, False)
+    y_c, _ = OPS.uniform_fake_quant(x, s, z, 4, want_bins=True)            # want_bins forces the ctypes route
+    assert torch.equal(y_t, y_c) and torch.equal(OPS.uniform_fake_quant(x, s, z, 4), y_c)
+    sc = torch.rand(128, 1, generator=g).to(DEV)
+    assert torch.equal(torch.ops.adalog.topk(sc, 16), OPS.topk(sc, 16))
+    xg = torch.nn.functional.gelu(x)
+    assert torch.equal(torch.ops.adalog.log2_shift(xg, 0.17), OPS.log2_shift(xg, 0.17))
