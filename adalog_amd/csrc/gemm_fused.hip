@@ -464,79 +464,51 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
     "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", \
     "s95", "s96", "s97", "s98", "s99", "vcc", "scc", "m0", "memory"
 
-__global__ __launch_bounds__(256, 1) void k_act_fused_asm12(FusedArgs p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NRB = 12, FNS = 4, AT = NRB * 2048, ROWS = 32 * NRB, XS = FNS + 1;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    int* s_cfg = reinterpret_cast<int*>(smem);                              // 64 dwords (tools/gen_fused_asm.py: CFG)
-    uint8_t* ring = smem + 256;                                             // FNS * AT
-    uint8_t* xring = ring + FNS * AT;                                       // XS * 4 waves * {256 B x, 256 B log2}
-    uint32_t* s_lut = reinterpret_cast<uint32_t*>(xring + XS * 2048);       // [levels2 + 2][128] bf16 bits (low half)
-    const int lut_rows = p.levels2 + 2;
-    float* s_thr = reinterpret_cast<float*>(s_lut + lut_rows * 128);        // [levels2][128]
-    float4* s_par = reinterpret_cast<float4*>(s_thr + p.levels2 * 128);     // [128] {-37/q, log2(s)*37/q, hi, s * sa_mul}
-    float* s_refb = reinterpret_cast<float*>(s_par + 128);                  // [2][ROWS]
-    float* s_rs = s_refb + 2 * ROWS;                                        // [ROWS]
-    double* s_fin = reinterpret_cast<double*>(s_rs + ROWS);                 // [4][64]
-    const int tid = threadIdx.x;
-    for (int e = tid; e < lut_rows * 128; e += 256) {
-        const int bin = e >> 7, c = e & 127;
-        const int kq = bin * (int)p.qv[c];
-        const int t = kq / ADALOG_R, j = kq - t * ADALOG_R;
-        const float v = (bin >= p.levels2 || t > 100) ? 0.0f : ldexpf(p.mant[j], -t);
-        s_lut[e] = __float_as_uint(v) >> 16;
-    }
-    for (int e = tid; e < p.levels2 * 128; e += 256) s_thr[e] = p.thr[e];
-    if (tid < 128) {
-        const float s = p.scale[tid], qf = p.qv[tid];
-        const float rq37 = 37.0f / qf;
-        const float top = (float)p.levels2 + 0.75f, NL15 = 49.828921f;
-        s_par[tid] = make_float4(-rq37, __log2f(s) * rq37, fminf(NL15 * rq37, top), s * p.sa_mul);
-    }
-    const unsigned ntile = ((unsigned)(p.T + 1) >> 1) * (unsigned)p.n_rt;
-    const unsigned nwg = gridDim.x, bid = blockIdx.x;
-    if (tid < 64) {
-        auto lds_off = [](const void* q) { return (int)(uintptr_t)(const __attribute__((address_space(3))) void*)q; };
-        const uint64_t pw = (uint64_t)p.W, px = (uint64_t)p.x, pl = (uint64_t)p.L, pr = (uint64_t)p.ref, ps = (uint64_t)p.row_scale,
-                       pb = (uint64_t)p.row_bias;
-        // near-tie zone of the fast bin: twice the error bound of the fast value against the reference's fp32 pipeline
-        // (8.6e-6 for <= 4 bit, 2e-5 for 6 bit)
-        const float tie = p.levels2 <= 16 ? 0.499975f : 0.49995f;
-        const int vals[37] = {(int)pw, (int)(pw >> 32), (int)px, (int)(px >> 32), (int)pl, (int)(pl >> 32), (int)pr, (int)(pr >> 32),
-                              (int)ps, (int)(ps >> 32), (int)pb, (int)(pb >> 32), p.M, p.T, p.K, p.Kb, p.nk, p.n_rt, (int)ntile,
-                              (int)nwg, (int)bid, p.levels2, __float_as_int(p.shift), 0 /* w: per wave below */,
-                              lds_off(ring), lds_off(xring), lds_off(s_lut), lds_off(s_thr), lds_off(s_par), lds_off(s_refb),
-                              lds_off(s_rs), lds_off(s_fin), (int)(nwg / (unsigned)p.n_rt), (int)(nwg % (unsigned)p.n_rt),
-                              (int)(bid / (unsigned)p.n_rt), (int)(bid % (unsigned)p.n_rt), __float_as_int(tie)};
-        int val = 0;
-#pragma unroll
-        for (int i = 0; i < 37; ++i) val = tid == i ? vals[i] : val;
-        s_cfg[tid] = val;
-    }
-    __syncthreads();
-    if (bid < ntile) {
-        const int cfg = (int)(uintptr_t)(const __attribute__((address_space(3))) void*)s_cfg;
-        const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-        asm volatile(
-            "s_mov_b32 s63, %[wv]\n\t"          // CFG slot 'w' (s63) is wave-specific: overwritten after the config load below
-            "s_mov_b32 s39, s63\n\t"
-#include "fused_loop_nrb12.inc"
-            :
-            : [cfg] "s"(cfg), [wv] "s"(w)
-            : FUSED_ASM_CLOBBERS);
-    }
-    __syncthreads();
-    const int t2 = threadIdx.x;
-#if defined(FUSED_DEBUG)
-    if (t2 < 64 && bid == FUSED_DEBUG) reinterpret_cast<int*>(p.wg_acc)[t2] = reinterpret_cast<const int*>(s_fin)[t2];
-    return;
-#endif
-    if (t2 < 128 && bid < ntile) {
-        const int cw = t2 >> 6, wi = t2 & 63;
-        p.wg_acc[(int64_t)bid * 128 + t2] = s_fin[cw * 64 + wi] + s_fin[(2 + cw) * 64 + wi];
-    }
-#endif
-}
+#define KNAME k_act_fused_asm_12_4
+#define KNRB 12
+#define KFNS 4
+#define KINC "fused_loop_nrb12_s4.inc"
+#include "fused_asm_kernel.inc"
+#undef KNAME
+#undef KNRB
+#undef KFNS
+#undef KINC
+#define KNAME k_act_fused_asm_12_3
+#define KNRB 12
+#define KFNS 3
+#define KINC "fused_loop_nrb12_s3.inc"
+#include "fused_asm_kernel.inc"
+#undef KNAME
+#undef KNRB
+#undef KFNS
+#undef KINC
+#define KNAME k_act_fused_asm_8_4
+#define KNRB 8
+#define KFNS 4
+#define KINC "fused_loop_nrb8_s4.inc"
+#include "fused_asm_kernel.inc"
+#undef KNAME
+#undef KNRB
+#undef KFNS
+#undef KINC
+#define KNAME k_act_fused_asm_6_4
+#define KNRB 6
+#define KFNS 4
+#define KINC "fused_loop_nrb6_s4.inc"
+#include "fused_asm_kernel.inc"
+#undef KNAME
+#undef KNRB
+#undef KFNS
+#undef KINC
+#define KNAME k_act_fused_asm_4_4
+#define KNRB 4
+#define KFNS 4
+#define KINC "fused_loop_nrb4_s4.inc"
+#include "fused_asm_kernel.inc"
+#undef KNAME
+#undef KNRB
+#undef KFNS
+#undef KINC
 
 // L = log2(x + shift), correctly rounded (fp64 log2 rounded once): -inf where x + shift <= 0 (the u-clamp / the bin mask
 // then take over, exactly as for log2 of a non-positive number in k_pack_adalog_fast)
@@ -664,18 +636,27 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
 #define LAUNCH_FUSED_N(NRBV) do { if (fns == 4) LAUNCH_FUSED(NRBV, 4); else LAUNCH_FUSED(NRBV, 3); } while (0)
     static const int use_asm = getenv("ADALOG_FUSED_ASM") ? atoi(getenv("ADALOG_FUSED_ASM")) : 1;
     const size_t shm_asm = 256 + shm;
-    if (nrb == 12 && fns == 4 && use_asm && shm_asm <= 160 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_act_fused_asm12), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        adalog_note_kernel("k_act_fused_asm12<bf16>");
-        hipLaunchKernelGGL(k_act_fused_asm12, dim3((unsigned)nwg), dim3(256), shm_asm, st, a);
+#define LAUNCH_ASM(KERNEL, TAG)                                                                                 \
+    do {                                                                                                       \
+        static bool attr_set = false;                                                                          \
+        if (!attr_set) {                                                                                       \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr_set = true;                                                                                   \
+        }                                                                                                      \
+        adalog_note_kernel(TAG);                                                                               \
+        hipLaunchKernelGGL(KERNEL, dim3((unsigned)nwg), dim3(256), shm_asm, st, a);                            \
+    } while (0)
+    if (use_asm && shm_asm <= 160 * 1024) {
+        if (nrb == 12 && fns == 4) LAUNCH_ASM(k_act_fused_asm_12_4, "k_act_fused_asm<12,4,bf16>");
+        else if (nrb == 12) LAUNCH_ASM(k_act_fused_asm_12_3, "k_act_fused_asm<12,3,bf16>");
+        else if (nrb == 8) LAUNCH_ASM(k_act_fused_asm_8_4, "k_act_fused_asm<8,4,bf16>");
+        else if (nrb == 6) LAUNCH_ASM(k_act_fused_asm_6_4, "k_act_fused_asm<6,4,bf16>");
+        else LAUNCH_ASM(k_act_fused_asm_4_4, "k_act_fused_asm<4,4,bf16>");
     } else if (nrb == 12) LAUNCH_FUSED_N(12);
     else if (nrb == 8) LAUNCH_FUSED_N(8);
     else if (nrb == 6) LAUNCH_FUSED_N(6);
     else LAUNCH_FUSED_N(4);
+#undef LAUNCH_ASM
 #undef LAUNCH_FUSED_N
 #undef LAUNCH_FUSED
     ADALOG_LAUNCH_CHECK("adalog_score_act_fused");

@@ -24,6 +24,16 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _top(name, *args):
+    """call torch.ops.adalog.<name>; C-ABI failures surface as AdalogHipError, like on the ctypes route"""
+    try:
+        return getattr(torch.ops.adalog, name)(*args)
+    except RuntimeError as e:
+        if "adalog::" in str(e):
+            raise _lib.AdalogHipError(str(e)) from e
+        raise
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -68,7 +78,7 @@ def uniform_fake_quant(x, scale, zero_point, n_bits: int, sym: bool = False, wan
     zp = None if sym else _f32c(zero_point, "zero_point")
     n_ch, inner = broadcast_layout(x.shape, scale.shape)
     if want_y and not want_bins and _torch_ops.available():          # level 1: the registered PyTorch custom op
-        return torch.ops.adalog.uniform_fake_quant(x, scale, zp, n_ch, inner, int(n_bits), bool(sym))
+        return _top("uniform_fake_quant", x, scale, zp, n_ch, inner, int(n_bits), bool(sym))
     y = torch.empty_like(x) if want_y else None
     bins = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_bins else None
     lib = _lib.load()
@@ -87,8 +97,8 @@ def log_fake_quant(x, scale, q, table1, table2, n_bits: int, shift=None, sub_shi
     if q.dtype != torch.int64 or not q.is_cuda:
         raise TypeError("q must be an int64 tensor on the device (the quantiser's buffer)")
     if want_y and not want_bins and not train_form and _torch_ops.available():
-        return torch.ops.adalog.log_fake_quant(x, scale, q, _f32c(table1, "table1"), _f32c(table2, "table2"), int(n_bits),
-                                               None if shift is None else _f32c(shift, "shift"), bool(sub_shift))
+        return _top("log_fake_quant", x, scale, q, _f32c(table1, "table1"), _f32c(table2, "table2"), int(n_bits),
+                    None if shift is None else _f32c(shift, "shift"), bool(sub_shift))
     y = torch.empty_like(x) if want_y else None
     bins = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_bins else None
     lib = _lib.load()
@@ -260,7 +270,7 @@ def log2_shift(x, shift: float):
     """log2(x + shift), correctly rounded, -inf where x + shift <= 0 (input of score_act_fused; once per layer)."""
     x = _f32c(x, "x")
     if _torch_ops.available():
-        return torch.ops.adalog.log2_shift(x, float(shift))
+        return _top("log2_shift", x, float(shift))
     out = torch.empty_like(x)
     rc = _lib.load().adalog_log2_shift(x.data_ptr(), out.data_ptr(), x.numel(), float(shift), _stream())
     _lib.check(rc, "adalog_log2_shift")
@@ -283,10 +293,9 @@ def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: i
     assert wp.dtype == torch.bfloat16 and wp.is_contiguous() and ref2.shape == (T, M)
     x2, lx2, ref2 = _f32c(x2, "x"), _f32c(lx2, "log2 x"), _f32c(ref2, "ref")
     if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
-        return torch.ops.adalog.score_act_fused(wp, x2, lx2, ref2, _f32c(row_scale, "row_scale"),
-                                                None if row_bias is None else _f32c(row_bias, "row_bias"),
-                                                _f32c(scale, "scale"), _f32c(qv, "qv"), int(n_bits), _f32c(mant37, "mant37"),
-                                                float(shift), bool(clamp_u), float(sa_mul), float(norm))
+        return _top("score_act_fused", wp, x2, lx2, ref2, _f32c(row_scale, "row_scale"),
+                    None if row_bias is None else _f32c(row_bias, "row_bias"), _f32c(scale, "scale"), _f32c(qv, "qv"),
+                    int(n_bits), _f32c(mant37, "mant37"), float(shift), bool(clamp_u), float(sa_mul), float(norm))
     ws_bytes = lib.adalog_score_act_fused_workspace_bytes()
     ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x2.device)
     scores = torch.empty((P, 1), dtype=torch.float32, device=x2.device)
@@ -311,7 +320,7 @@ def topk(scores, k: int):
     scores = _f32c(scores, "scores")
     P, cols = scores.shape
     if _torch_ops.available():
-        return torch.ops.adalog.topk(scores, int(k))
+        return _top("topk", scores, int(k))
     idx = torch.empty((k, cols), dtype=torch.int32, device=scores.device)
     rc = _lib.load().adalog_topk(scores.data_ptr(), P, cols, int(k), idx.data_ptr(), _stream())
     _lib.check(rc, "adalog_topk")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generator of the hand-scheduled CDNA4 (gfx950) main loop of the fused activation-search kernel (gemm_fused.hip).
 
-    python tools/gen_fused_asm.py            -> adalog_amd/csrc/fused_loop_nrb12.inc  (+ .lst, a plain listing)
+    FUSED_NRB=12 FUSED_FNS=4 python tools/gen_fused_asm.py   -> adalog_amd/csrc/fused_loop_nrb12_s4.inc  (+ .lst, a listing)
+    tools/gen_fused_asm_all.sh                               -> the five variants the library ships
 
 Why a generator: the compiler keeps at most 256 accumulator registers per wave (one MFMA form per function), reads every
 A fragment right in front of its MFMAs (exposed LDS latency) and cannot be steered into interleaving the fragment
@@ -17,12 +18,12 @@ See gemm_fused.hip for the algorithm; names here follow it.
 import os
 import sys
 
-NRB = 12          # row blocks of 32 output channels per tile
-FNS = 4           # weight-ring stages
+NRB = int(os.environ.get("FUSED_NRB", "12"))      # row blocks of 32 output channels per tile (12, 8, 6 or 4)
+FNS = int(os.environ.get("FUSED_FNS", "4"))       # weight-ring stages (3 where the 6-bit tables need the LDS)
 XS = FNS + 1      # x / log2 ring slots
 AT = NRB * 2048   # weight tile bytes per stage
 ROWS = 32 * NRB
-NA = 8            # row blocks whose tiles live in AGPRs (2 tiles each)
+NA = min(NRB, 8)  # row blocks whose tiles live in AGPRs (2 tiles each); the rest sit in v128..
 MAGIC = 0x4B400000
 TIE_BITS = 0x3EFFF2E5   # 0.4999f
 PACKED = bool(os.environ.get("FUSED_PACKED"))     # v_pk_fma/add_f32 for the pairwise arithmetic: measured 22 % SLOWER beside MFMAs
@@ -908,7 +909,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     A = program()
     A.lines = hazard_pass(A.lines)
-    out = os.path.join(root, "adalog_amd", "csrc", f"fused_loop_nrb{NRB}.inc")
+    out = os.path.join(root, "adalog_amd", "csrc", f"fused_loop_nrb{NRB}_s{FNS}.inc")
     with open(out, "w") as f:
         f.write(f"// GENERATED by tools/gen_fused_asm.py (NRB = {NRB}, FNS = {FNS}) -- do not edit.\n")
         f.write(f"// Config array (dword index): {', '.join(f'{i}={n}' for i, n in enumerate(CFG))}\n")
