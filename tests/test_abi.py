@@ -65,3 +65,25 @@ def test_torch_ops_registered_hip_only():
         torch.ops.adalog.topk(torch.zeros(4, 3), 2)
     with pytest.raises(NotImplementedError):
         torch.ops.adalog.uniform_fake_quant(torch.zeros(4), torch.ones(1), torch.zeros(1), 1, 4, 4, False)
+
+
+def test_generated_asm_is_up_to_date(tmp_path):
+    """The hand-scheduled loops of gemm_fused.hip are generated text (tools/gen_fused_asm.py); the committed .inc files
+    must be what the generator emits today (edit the generator, run tools/gen_fused_asm_all.sh, commit both)."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    for nrb, fns in ((12, 4), (12, 3), (8, 4), (6, 4), (4, 4)):
+        os.environ["FUSED_NRB"], os.environ["FUSED_FNS"] = str(nrb), str(fns)
+        for k in ("FUSED_STAGE", "FUSED_SUB", "FUSED_VAR", "FUSED_DEBUG", "FUSED_NOCOLD", "FUSED_NOLUT", "FUSED_NOBAR", "FUSED_NODMA",
+                  "FUSED_NOMFMA", "FUSED_PACKED"):
+            os.environ.pop(k, None)
+        import gen_fused_asm as G
+        G = importlib.reload(G)
+        lines = G.hazard_pass(G.program().lines)
+        want = ['"' + ln + '\\n\\t"' for ln in lines if not ln.startswith(";")]
+        have = [ln.rstrip("\n") for ln in open(os.path.join(ROOT, "adalog_amd", "csrc", f"fused_loop_nrb{nrb}_s{fns}.inc"))
+                if ln.startswith('"')]
+        assert have == want, f"fused_loop_nrb{nrb}_s{fns}.inc is stale: run tools/gen_fused_asm_all.sh"
+    os.environ.pop("FUSED_NRB", None)
+    os.environ.pop("FUSED_FNS", None)
