@@ -7,6 +7,9 @@
 // parameter gradients reduced deterministically (per-block partials, then a fixed-order fp64 finish).
 #include "common.h"
 
+#include <atomic>
+#include <mutex>
+
 namespace {
 
 __device__ __forceinline__ float block_sum(float v, float* sm) {
@@ -20,35 +23,102 @@ __device__ __forceinline__ float block_sum(float v, float* sm) {
     return r;
 }
 
-// x viewed [rows][inner], channel = row % n_ch (per-tensor: rows = 1).  part_* : [rows][gridDim.x]
+// "Last block finishes" reductions.  Every block leaves an fp32 partial and takes a ticket; the block that draws the
+// last ticket sums the partials in fp64 in a fixed order.  The partials and the ticket are device-scope atomics (they go
+// straight to the coherence point, across the eight XCDs' L2s), ordered by a wait on the store: no L2 write-back, which
+// a device-scope fence in every block would cost (measured: 3x the kernel time).
+__device__ __forceinline__ void store_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Call after thread 0 issued its store_agent()s.  True in exactly one block; that block puts the counter back to zero.
+__device__ __forceinline__ bool last_block_arrives(unsigned int* counter, unsigned total) {
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the partial stores are acknowledged before the ticket
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == total - 1) ? 1 : 0;
+        if (is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return is_last != 0;
+}
+
+// fixed-order fp64 sum of part[0..count) by the 256 threads of one block (the same order whichever block runs it)
+__device__ __forceinline__ float block_total_f64(const float* part, int64_t count, double* smd, double mul = 1.0) {
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < count; i += 256) acc += (double)load_agent(part + i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) smd[w] = acc;
+    __syncthreads();
+    return (float)(((smd[0] + smd[1]) + (smd[2] + smd[3])) * mul);
+}
+
+__device__ __forceinline__ void uniform_bwd_one(float xv, float g, float s, float z, float qmin, float qmax, float& gxo,
+                                                float& as, float& az) {
+    const float r = xv / s;
+    const float t = rintf(r) + z;
+    const bool inside = (t >= qmin) && (t <= qmax);
+    const float q = fminf(fmaxf(t, qmin), qmax);
+    gxo = inside ? g : 0.0f;
+    as += g * ((q - z) - (inside ? r : 0.0f));
+    az += inside ? 0.0f : -g * s;
+}
+
+// x viewed [rows][inner], channel = row % n_ch (per-tensor: rows = 1).  part_* : [rows][gridDim.x].
+// counter != null (per-tensor form only): the last block to finish reduces the partials into gscale / gzp itself.
 __global__ __launch_bounds__(256) void k_uniform_bwd(const float* __restrict__ gy, const float* __restrict__ x,
                                                      float* __restrict__ gx, int64_t rows, int64_t inner,
                                                      const float* __restrict__ scale, const float* __restrict__ zp,
                                                      int64_t n_ch, float qmin, float qmax, float* __restrict__ part_s,
-                                                     float* __restrict__ part_z) {
+                                                     float* __restrict__ part_z, unsigned int* counter,
+                                                     float* __restrict__ gscale, float* __restrict__ gzp) {
     __shared__ float sm[4];
+    __shared__ double smd[4];
+    const bool vec = (inner & 3) == 0;
     for (int64_t row = blockIdx.y; row < rows; row += gridDim.y) {
         const int64_t ch = row % n_ch;
         const float s = scale[ch];
         const float z = zp ? rintf(zp[ch]) : 0.0f;
         float as = 0.0f, az = 0.0f;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += (int64_t)gridDim.x * blockDim.x) {
-            const int64_t o = row * inner + i;
-            const float xv = x[o], g = gy[o];
-            const float t = rintf(xv / s) + z;
-            const bool inside = (t >= qmin) && (t <= qmax);
-            const float q = fminf(fmaxf(t, qmin), qmax);
-            if (gx) gx[o] = inside ? g : 0.0f;
-            as += g * ((q - z) - (inside ? xv / s : 0.0f));
-            az += inside ? 0.0f : -g * s;
+        if (vec) {
+            const float4* x4 = reinterpret_cast<const float4*>(x + row * inner);
+            const float4* g4 = reinterpret_cast<const float4*>(gy + row * inner);
+            float4* o4 = gx ? reinterpret_cast<float4*>(gx + row * inner) : nullptr;
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (inner >> 2); i += (int64_t)gridDim.x * blockDim.x) {
+                const float4 xv = x4[i], g = g4[i];
+                float4 o;
+                uniform_bwd_one(xv.x, g.x, s, z, qmin, qmax, o.x, as, az);
+                uniform_bwd_one(xv.y, g.y, s, z, qmin, qmax, o.y, as, az);
+                uniform_bwd_one(xv.z, g.z, s, z, qmin, qmax, o.z, as, az);
+                uniform_bwd_one(xv.w, g.w, s, z, qmin, qmax, o.w, as, az);
+                if (o4) o4[i] = o;
+            }
+        } else {
+            for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += (int64_t)gridDim.x * blockDim.x) {
+                const int64_t o = row * inner + i;
+                float go;
+                uniform_bwd_one(x[o], gy[o], s, z, qmin, qmax, go, as, az);
+                if (gx) gx[o] = go;
+            }
         }
         if (part_s) {
             const float ts = block_sum(as, sm), tz = block_sum(az, sm);
             if (threadIdx.x == 0) {
-                part_s[row * gridDim.x + blockIdx.x] = ts;
-                if (part_z) part_z[row * gridDim.x + blockIdx.x] = tz;
+                store_agent(part_s + row * gridDim.x + blockIdx.x, ts);
+                if (part_z) store_agent(part_z + row * gridDim.x + blockIdx.x, tz);
             }
         }
+    }
+    if (counter && part_s && last_block_arrives(counter, gridDim.x * gridDim.y)) {
+        const int64_t cnt = rows * gridDim.x;
+        if (gscale) { const float v = block_total_f64(part_s, cnt, smd); if (threadIdx.x == 0) gscale[0] = v; }
+        if (gzp && part_z) { const float v = block_total_f64(part_z, cnt, smd); if (threadIdx.x == 0) gzp[0] = v; }
     }
 }
 
@@ -72,8 +142,10 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
                                                     const float* __restrict__ y, float* __restrict__ gx, int64_t n,
                                                     const float* __restrict__ scale, const int64_t* __restrict__ q,
                                                     int levels2, const float* __restrict__ shift, int sub_shift,
-                                                    float* __restrict__ part_s) {
+                                                    float* __restrict__ part_s, unsigned int* counter,
+                                                    float* __restrict__ gscale) {
     __shared__ float sm[4];
+    __shared__ double smd[4];
     const float s = scale[0], qf = (float)q[0];
     const float sh = shift ? shift[0] : 0.0f;
     float as = 0.0f;
@@ -93,7 +165,11 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
     }
     if (part_s) {
         const float ts = block_sum(as, sm);
-        if (threadIdx.x == 0) part_s[blockIdx.x] = ts;
+        if (threadIdx.x == 0) store_agent(part_s + blockIdx.x, ts);
+        if (last_block_arrives(counter, gridDim.x)) {
+            const float v = block_total_f64(part_s, gridDim.x, smd);
+            if (threadIdx.x == 0) gscale[0] = v;
+        }
     }
 }
 
@@ -131,8 +207,11 @@ __global__ __launch_bounds__(256) void k_adaround(const float* __restrict__ w, c
 // round loss value (block partials) and, when galpha != null, galpha[i] += gscale * d/d alpha
 __global__ __launch_bounds__(256) void k_round_loss(const float* __restrict__ alpha, int64_t n, float b,
                                                     const float* __restrict__ b_dev, float* __restrict__ part,
-                                                    float* __restrict__ galpha, float gscale) {
+                                                    float* __restrict__ galpha, float gscale, const float* __restrict__ gmul,
+                                                    int overwrite, unsigned int* counter, float* __restrict__ loss) {
     __shared__ float sm[4];
+    __shared__ double smd[4];
+    if (gmul) gscale *= gmul[0];             // upstream gradient of the (scalar) loss, read on the device
     if (b_dev) b = b_dev[0];                 // exponent read on the device: lets a captured HIP graph follow the decaying b
     float acc = 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -144,13 +223,113 @@ __global__ __launch_bounds__(256) void k_round_loss(const float* __restrict__ al
         if (galpha) {
             const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
             const float dl = ad > 0.0f ? -b * powf(ad, b - 1.0f) * sgn * 2.0f * dh : 0.0f;
-            galpha[i] += gscale * dl;
+            galpha[i] = overwrite ? gscale * dl : galpha[i] + gscale * dl;
         }
     }
     if (part) {
         const float t = block_sum(acc, sm);
-        if (threadIdx.x == 0) part[blockIdx.x] = t;
+        if (threadIdx.x == 0) store_agent(part + blockIdx.x, t);
+        if (last_block_arrives(counter, gridDim.x)) {
+            const float v = block_total_f64(part, gridDim.x, smd);
+            if (threadIdx.x == 0) loss[0] = v;
+        }
     }
+}
+
+// The rounding regulariser of a whole block in one launch: up to RL_MAX alpha tensors, value and gradient together.
+constexpr int RL_MAX = 16;
+struct RoundLossMulti {
+    const float* alpha[RL_MAX];
+    float* grad[RL_MAX];
+    int64_t n[RL_MAX];
+    int first_block[RL_MAX + 1];          // tensor t owns blocks [first_block[t], first_block[t+1])
+    int count;
+};
+
+__global__ __launch_bounds__(256) void k_round_loss_multi(RoundLossMulti a, float b, const float* __restrict__ b_dev,
+                                                          float weight, float* __restrict__ part, unsigned int* counter,
+                                                          float* __restrict__ loss) {
+    __shared__ float sm[4];
+    __shared__ double smd[4];
+    if (b_dev) b = b_dev[0];
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
+    const float* __restrict__ al = a.alpha[t];
+    float* __restrict__ gr = a.grad[t];
+    const int64_t n = a.n[t];
+    const int nblk = a.first_block[t + 1] - a.first_block[t];
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)(blockIdx.x - a.first_block[t]) * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) {
+        float dh;
+        const float h = soft_h(al[i], dh);
+        const float d = 2.0f * (h - 0.5f);
+        const float ad = fabsf(d);
+        const float pm1 = ad > 0.0f ? powf(ad, b - 1.0f) : 0.0f;
+        acc += 1.0f - pm1 * ad;
+        const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        gr[i] = weight * (-b * pm1 * sgn * 2.0f * dh);
+    }
+    const float ts = block_sum(acc, sm);
+    if (threadIdx.x == 0) store_agent(part + blockIdx.x, ts);
+    if (last_block_arrives(counter, gridDim.x)) {
+        const float v = block_total_f64(part, gridDim.x, smd, (double)weight);
+        if (threadIdx.x == 0) loss[0] = v;
+    }
+}
+
+// reconstruction loss  scale * sum_i (pred_i - tgt_i)^2  (block_recon.py:186-199 with p = 2) and its gradient
+__global__ __launch_bounds__(256) void k_rec_loss(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t n,
+                                                  float scale, float* __restrict__ part, unsigned int* counter,
+                                                  float* __restrict__ loss) {
+    __shared__ float sm[4];
+    __shared__ double smd[4];
+    float acc = 0.0f;
+    const int64_t n4 = n >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(pred);
+    const float4* t4 = reinterpret_cast<const float4*>(tgt);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = p4[i], b = t4[i];
+        const float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+        acc += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const float d = pred[(n4 << 2) + threadIdx.x] - tgt[(n4 << 2) + threadIdx.x];
+        acc += d * d;
+    }
+    const float t = block_sum(acc, sm);
+    if (threadIdx.x == 0) store_agent(part + blockIdx.x, t);
+    if (last_block_arrives(counter, gridDim.x)) {
+        const float v = block_total_f64(part, gridDim.x, smd, (double)scale);
+        if (threadIdx.x == 0) loss[0] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rec_loss_bwd(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t n,
+                                                      float scale2, const float* __restrict__ gmul, float* __restrict__ gpred) {
+    const float f = scale2 * gmul[0];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        gpred[i] = (pred[i] - tgt[i]) * f;
+}
+
+// Ticket counters for the "last block finishes" reductions: a ring of zeroed device words, one handed to each launch
+// (the last block puts its word back to zero).  Launches that overlap in time hold different slots as long as fewer
+// than RING of them are in flight.
+constexpr int RING = 1024;
+unsigned int* ticket_slot() {
+    static unsigned int* ring = nullptr;
+    static std::atomic<unsigned> next{0};
+    static std::mutex mu;
+    if (!ring) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!ring) {
+            unsigned int* p = nullptr;
+            if (hipMalloc(&p, RING * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, RING * sizeof(unsigned int)) != hipSuccess
+                || hipDeviceSynchronize() != hipSuccess)
+                return nullptr;
+            ring = p;
+        }
+    }
+    return ring + (next.fetch_add(1) % RING);
 }
 
 inline int grid1(int64_t n, int cap = 2048) {
@@ -162,9 +341,15 @@ inline int grid1(int64_t n, int cap = 2048) {
 
 }  // namespace
 
+// x blocks per row of the [rows][inner] view: enough blocks in total to fill the chip, at least 2048 elements per block
 extern "C" int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, int64_t inner) {
     (void)n_channels;
-    return grid1(inner, 64);
+    const int64_t rows = inner > 0 ? n / inner : 1;
+    const int64_t want = rows >= 4096 ? 1 : (4096 + rows - 1) / rows;      // blocks per row so that rows * nb >= 4096
+    int64_t nb = (inner + 2047) / 2048;
+    if (nb > want) nb = want;
+    if (nb < 1) nb = 1;
+    return (int)nb;
 }
 
 // gscale / gzp: [n_channels] (each optional).  workspace: 2 * rows * adalog_uniform_fq_backward_blocks floats.
@@ -178,17 +363,22 @@ extern "C" int adalog_uniform_fq_backward(const float* gy, const float* x, float
     const float L = (float)(1 << (n_bits - 1));
     const float qmin = symmetric ? -L : 0.0f, qmax = symmetric ? L - 1.0f : 2.0f * L - 1.0f;
     const int64_t rows = n / inner;
-    const int nb = grid1(inner, 64);
+    const int nb = adalog_uniform_fq_backward_blocks(n, n_channels, inner);
     int gy_ = (int)(rows < 4096 ? rows : 4096);
     hipStream_t st = (hipStream_t)stream;
     float* ps = (gscale || gzp) ? workspace : nullptr;
     float* pz = (gzp && !symmetric) ? workspace + rows * nb : nullptr;
+    // per-tensor parameters: the kernel's last block reduces the partials itself (no finish launches)
+    unsigned int* ticket = (ps && n_channels == 1) ? ticket_slot() : nullptr;
+    ADALOG_ARG_CHECK(!(ps && n_channels == 1) || ticket, "uniform_fq_backward: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_uniform_bwd, dim3(nb, gy_), dim3(256), 0, st, gy, x, gx, rows, inner, scale,
-                       symmetric ? nullptr : zero_point, n_channels, qmin, qmax, ps, pz);
+                       symmetric ? nullptr : zero_point, n_channels, qmin, qmax, ps, pz, ticket, gscale, gzp);
     ADALOG_LAUNCH_CHECK("adalog_uniform_fq_backward");
-    if (gscale) hipLaunchKernelGGL(k_param_grad_finish, dim3((unsigned)n_channels), dim3(64), 0, st, ps, rows, nb, n_channels, gscale);
-    if (pz) hipLaunchKernelGGL(k_param_grad_finish, dim3((unsigned)n_channels), dim3(64), 0, st, pz, rows, nb, n_channels, gzp);
-    ADALOG_LAUNCH_CHECK("adalog_uniform_fq_backward/finish");
+    if (!ticket) {
+        if (gscale) hipLaunchKernelGGL(k_param_grad_finish, dim3((unsigned)n_channels), dim3(64), 0, st, ps, rows, nb, n_channels, gscale);
+        if (pz) hipLaunchKernelGGL(k_param_grad_finish, dim3((unsigned)n_channels), dim3(64), 0, st, pz, rows, nb, n_channels, gzp);
+        ADALOG_LAUNCH_CHECK("adalog_uniform_fq_backward/finish");
+    }
     return 0;
 }
 
@@ -201,11 +391,11 @@ extern "C" int adalog_log_fq_backward(const float* gy, const float* x, const flo
     ADALOG_ARG_CHECK(!gscale || workspace, "log_fq_backward: the scale gradient needs a workspace");
     const int nb = grid1(n, 1024);
     hipStream_t st = (hipStream_t)stream;
+    unsigned int* ticket = gscale ? ticket_slot() : nullptr;
+    ADALOG_ARG_CHECK(!gscale || ticket, "log_fq_backward: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_adalog_bwd, dim3(nb), dim3(256), 0, st, gy, x, y, gx, n, scale, q, 1 << n_bits, shift, sub_shift,
-                       gscale ? workspace : nullptr);
+                       gscale ? workspace : nullptr, ticket, gscale);
     ADALOG_LAUNCH_CHECK("adalog_log_fq_backward");
-    if (gscale) hipLaunchKernelGGL(k_param_grad_finish, dim3(1), dim3(64), 0, st, workspace, (int64_t)1, nb, (int64_t)1, gscale);
-    ADALOG_LAUNCH_CHECK("adalog_log_fq_backward/finish");
     return 0;
 }
 
@@ -220,15 +410,75 @@ extern "C" int adalog_adaround(const float* w, const float* alpha, const float* 
     return 0;
 }
 
-// loss[0] = sum_i (1 - |2 h(alpha_i) - 1|^b); if galpha: galpha += gscale * dloss/dalpha.  workspace: 1024 floats
+// loss[0] = sum_i (1 - |2 h(alpha_i) - 1|^b) (when loss != null).  When galpha != null, with
+// g_i = gscale * (gmul ? gmul[0] : 1) * dloss/dalpha_i:  galpha[i] = g_i (overwrite) or galpha[i] += g_i.
+// workspace: 1024 floats (needed for the loss value only)
 extern "C" int adalog_round_loss(const float* alpha, int64_t n, float b, const float* b_dev, float* loss, float* galpha,
-                                 float gscale, float* workspace, void* stream) {
+                                 float gscale, const float* gmul, int overwrite, float* workspace, void* stream) {
     ADALOG_ARG_CHECK(alpha && n >= 1 && (loss == nullptr || workspace), "round_loss: bad arguments");
     const int nb = grid1(n, 1024);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_round_loss, dim3(nb), dim3(256), 0, st, alpha, n, b, b_dev, loss ? workspace : nullptr, galpha, gscale);
+    unsigned int* ticket = loss ? ticket_slot() : nullptr;
+    ADALOG_ARG_CHECK(!loss || ticket, "round_loss: cannot allocate the ticket counters");
+    hipLaunchKernelGGL(k_round_loss, dim3(nb), dim3(256), 0, st, alpha, n, b, b_dev, loss ? workspace : nullptr, galpha, gscale,
+                       gmul, overwrite, ticket, loss);
     ADALOG_LAUNCH_CHECK("adalog_round_loss");
-    if (loss) hipLaunchKernelGGL(k_param_grad_finish, dim3(1), dim3(64), 0, st, workspace, (int64_t)1, nb, (int64_t)1, loss);
-    ADALOG_LAUNCH_CHECK("adalog_round_loss/finish");
+    return 0;
+}
+
+// loss[0] = scale * sum (pred - tgt)^2   (LossFunction.lp_loss with p = 2, utils/block_recon.py:186-199; the caller folds
+// the 1/(batch*channels) of .sum(1).mean() and the /10 into `scale`).  workspace: 2048 floats.
+extern "C" int adalog_rec_loss(const float* pred, const float* tgt, int64_t n, float scale, float* loss, float* workspace,
+                               void* stream) {
+    ADALOG_ARG_CHECK(pred && tgt && loss && workspace && n >= 1, "rec_loss: bad arguments");
+    ADALOG_ARG_CHECK((((uintptr_t)pred | (uintptr_t)tgt) & 15) == 0, "rec_loss: pred / tgt must be 16-byte aligned");
+    unsigned int* ticket = ticket_slot();
+    ADALOG_ARG_CHECK(ticket, "rec_loss: cannot allocate the ticket counters");
+    hipLaunchKernelGGL(k_rec_loss, dim3(grid1(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, pred, tgt, n, scale, workspace,
+                       ticket, loss);
+    ADALOG_LAUNCH_CHECK("adalog_rec_loss");
+    return 0;
+}
+
+// gpred = 2 * scale * gmul[0] * (pred - tgt);  gmul: device fp32 [1], the upstream gradient of the scalar loss
+extern "C" int adalog_rec_loss_backward(const float* pred, const float* tgt, int64_t n, float scale, const float* gmul,
+                                        float* gpred, void* stream) {
+    ADALOG_ARG_CHECK(pred && tgt && gmul && gpred && n >= 1, "rec_loss_backward: bad arguments");
+    hipLaunchKernelGGL(k_rec_loss_bwd, dim3(grid1(n, 4096)), dim3(256), 0, (hipStream_t)stream, pred, tgt, n, 2.0f * scale, gmul,
+                       gpred);
+    ADALOG_LAUNCH_CHECK("adalog_rec_loss_backward");
+    return 0;
+}
+
+// loss[0] = weight * sum over the `count` (<= 16) alpha tensors of sum_i (1 - |2 h(alpha_i) - 1|^b)  and
+// grads[t][i] = weight * d/d alpha_t[i] of it, in one launch (LossFunction.__call__'s loop over the block's AdaRound
+// quantisers, utils/block_recon.py:205-210).  alphas / grads / ns: HOST arrays of device pointers / lengths.
+// workspace: adalog_round_loss_multi_workspace(ns, count) floats.
+extern "C" int64_t adalog_round_loss_multi_workspace(const int64_t* ns, int count) {
+    int64_t blocks = 0;
+    for (int t = 0; t < count; ++t) blocks += grid1(ns[t], 256);
+    return blocks;
+}
+
+extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const* grads, const int64_t* ns, int count, float b,
+                                       const float* b_dev, float weight, float* loss, float* workspace, void* stream) {
+    ADALOG_ARG_CHECK(alphas && grads && ns && loss && workspace && count >= 1 && count <= RL_MAX, "round_loss_multi: bad arguments");
+    RoundLossMulti a;
+    int blocks = 0;
+    for (int t = 0; t < count; ++t) {
+        ADALOG_ARG_CHECK(alphas[t] && grads[t] && ns[t] >= 1, "round_loss_multi: bad tensor");
+        a.alpha[t] = alphas[t];
+        a.grad[t] = grads[t];
+        a.n[t] = ns[t];
+        a.first_block[t] = blocks;
+        blocks += grid1(ns[t], 256);
+    }
+    a.first_block[count] = blocks;
+    a.count = count;
+    unsigned int* ticket = ticket_slot();
+    ADALOG_ARG_CHECK(ticket, "round_loss_multi: cannot allocate the ticket counters");
+    hipLaunchKernelGGL(k_round_loss_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, b_dev, weight, workspace, ticket,
+                       loss);
+    ADALOG_LAUNCH_CHECK("adalog_round_loss_multi");
     return 0;
 }

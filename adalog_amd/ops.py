@@ -574,14 +574,59 @@ def adaround(w2, alpha2, scale, zero_point, n_bits: int, soft: bool, gy=None):
     return out
 
 
-def round_loss(alpha, b, galpha=None, gscale: float = 1.0, want_loss: bool = True):
-    """``b``: python float, or a device fp32 tensor of one element (read by the kernel: HIP-graph friendly)."""
+def round_loss(alpha, b, galpha=None, gscale: float = 1.0, want_loss: bool = True, gmul=None, overwrite: bool = False):
+    """``b``: python float, or a device fp32 tensor of one element (read by the kernel: HIP-graph friendly).
+    ``galpha`` (optional) receives gscale * gmul * d/d alpha: added to it, or written over it (``overwrite``);
+    ``gmul``: optional one-element device tensor (the upstream gradient of the scalar loss)."""
     alpha = _f32c(alpha, "alpha")
     loss = torch.empty(1, dtype=torch.float32, device=alpha.device) if want_loss else None
-    ws = torch.empty(1024, dtype=torch.float32, device=alpha.device)
+    ws = torch.empty(1024, dtype=torch.float32, device=alpha.device) if want_loss else None
     b_dev = _f32c(b, "b") if torch.is_tensor(b) else None
     rc = _lib.load().adalog_round_loss(alpha.data_ptr(), alpha.numel(), 0.0 if b_dev is not None else float(b), _ptr(b_dev),
                                       _ptr(loss), _ptr(galpha), float(gscale),
-                                      ws.data_ptr(), _stream())
+                                      _ptr(None if gmul is None else _f32c(gmul, "gmul")), int(bool(overwrite)),
+                                      _ptr(ws), _stream())
     _lib.check(rc, "adalog_round_loss")
     return loss
+
+
+def rec_loss(pred, tgt, scale: float):
+    """scale * sum (pred - tgt)^2 as a one-element tensor (LossFunction.lp_loss, p = 2; block_recon.py:186-199)."""
+    pred, tgt = _f32c(pred, "pred"), _f32c(tgt, "tgt")
+    if pred.shape != tgt.shape:
+        raise _lib.AdalogHipError("rec_loss: pred and tgt differ in shape")
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    ws = torch.empty(2048, dtype=torch.float32, device=pred.device)
+    rc = _lib.load().adalog_rec_loss(pred.data_ptr(), tgt.data_ptr(), pred.numel(), float(scale), loss.data_ptr(), ws.data_ptr(),
+                                    _stream())
+    _lib.check(rc, "adalog_rec_loss")
+    return loss
+
+
+def rec_loss_backward(pred, tgt, scale: float, gmul):
+    pred, tgt = _f32c(pred, "pred"), _f32c(tgt, "tgt")
+    gp = torch.empty_like(pred)
+    rc = _lib.load().adalog_rec_loss_backward(pred.data_ptr(), tgt.data_ptr(), pred.numel(), float(scale),
+                                             _f32c(gmul, "gmul").data_ptr(), gp.data_ptr(), _stream())
+    _lib.check(rc, "adalog_rec_loss_backward")
+    return gp
+
+
+def round_loss_multi(alphas, b, weight: float):
+    """weight * sum_t sum(1 - |2h(alpha_t)-1|^b) and its gradients, one launch for all tensors of a block.
+    Returns (loss [1], [grad_t])."""
+    import ctypes
+    alphas = [_f32c(a, "alpha") for a in alphas]
+    n = len(alphas)
+    grads = [torch.empty_like(a) for a in alphas]
+    PA, NA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    ap, gp, ns = PA(*[a.data_ptr() for a in alphas]), PA(*[g_.data_ptr() for g_ in grads]), NA(*[a.numel() for a in alphas])
+    lib = _lib.load()
+    dev = alphas[0].device
+    ws = torch.empty(int(lib.adalog_round_loss_multi_workspace(ns, n)), dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    b_dev = _f32c(b, "b") if torch.is_tensor(b) else None
+    rc = lib.adalog_round_loss_multi(ap, gp, ns, n, 0.0 if b_dev is not None else float(b), _ptr(b_dev), float(weight),
+                                     loss.data_ptr(), ws.data_ptr(), _stream())
+    _lib.check(rc, "adalog_round_loss_multi")
+    return loss, grads

@@ -35,9 +35,9 @@ class _RoundLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (alpha,) = ctx.saved_tensors
-        ga = torch.zeros_like(alpha)
-        backend.get().round_loss(alpha, ctx.b, galpha=ga, gscale=1.0, want_loss=False)
-        return ga * g, None
+        ga = torch.empty_like(alpha)
+        backend.get().round_loss(alpha, ctx.b, galpha=ga, gscale=1.0, want_loss=False, gmul=g.reshape(1), overwrite=True)
+        return ga, None
 
 
 class AdaRoundQuantizer(nn.Module):

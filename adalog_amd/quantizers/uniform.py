@@ -21,6 +21,7 @@ class _UniformSTE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, zero_point, n_bits, sym):
         be = backend.get()
+        x = x.contiguous()                               # saved in the layout the backward kernel reads (one copy, not two)
         if sym:
             y = be.uniform_fake_quant(x, scale, None, n_bits, sym=True)
             ctx.save_for_backward(x, scale, None)

@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from .. import parallel
+from .. import backend, parallel
 from ..quant_layers import MinMaxQuantConv2d, MinMaxQuantLinear, MinMaxQuantMatMul
 from ..quantizers.adaround import AdaRoundQuantizer
 from .calibrator import QuantCalibrator
@@ -117,6 +117,8 @@ class BlockReconstructor(QuantCalibrator):
                      and n_local >= local_bs and iters > 8)
         full_graph = use_graph and ws == 1
         okw = dict(capturable=True) if full_graph else {}
+        if torch.device(device).type == 'cuda':
+            okw['fused'] = True                          # one kernel per optimiser step instead of six foreach passes
         w_optimizer = torch.optim.Adam(w_params, **okw)
         a_lr = torch.tensor(lr, dtype=torch.float32, device=device) if full_graph else lr
         a_optimizer = torch.optim.Adam(a_params, lr=a_lr, **okw) if len(a_params) != 0 else None
@@ -126,6 +128,21 @@ class BlockReconstructor(QuantCalibrator):
                                  rec_loss='mse' if 'head' not in name else 'kl_div', b_range=b_range, decay_start=0,
                                  warmup=warmup, p=p)
         gen = torch.Generator().manual_seed(1234 + parallel.rank())
+        # Only alpha and the activation scales are optimised (block_recon.py:97-108).  The reference leaves every other
+        # parameter of the block with requires_grad=True and autograd fills their .grad each iteration (bias sums,
+        # LayerNorm gamma/beta, ~40 accumulations) although nothing reads them; freezing them for the duration of the
+        # reconstruction changes no trained value and drops those kernels.
+        trained = {id(prm) for prm in w_params + a_params}
+        frozen = [prm for prm in block.parameters() if prm.requires_grad and id(prm) not in trained]
+        for prm in frozen:
+            prm.requires_grad_(False)
+        # ADALOG_BRECQ_FAST_MM=1: the block's plain GEMMs (linear / bmm, forward and both backward products) use hipBLASLt's
+        # "fast fp32" mode (bf16 three-term split products, relative error 4e-6 against 4e-7).  Measured on a deit_small
+        # block it is worth 4 % of the iteration (some shapes get slower kernels), so the default stays plain fp32.
+        fast_mm = torch.device(device).type == 'cuda' and os.environ.get("ADALOG_BRECQ_FAST_MM", "0") == "1"
+        prev_tf32 = torch.backends.cuda.matmul.allow_tf32
+        if fast_mm:
+            torch.backends.cuda.matmul.allow_tf32 = True
         graph, static_inp, static_out, static_rec, static_rnd = None, None, None, None, None
         b_dev = rw_dev = None
         params = w_params + a_params
@@ -191,6 +208,9 @@ class BlockReconstructor(QuantCalibrator):
                 a_scheduler.step()
             loss_func.log(static_rec, static_rnd)
         graph = None
+        torch.backends.cuda.matmul.allow_tf32 = prev_tf32
+        for prm in frozen:
+            prm.requires_grad_(True)
         for _, module in block.named_modules():
             if hasattr(module, 'w_quantizer'):
                 module.w_quantizer.soft_targets = False
@@ -220,6 +240,36 @@ class BlockReconstructor(QuantCalibrator):
                 module.w_quantizer.round_mode = "nearest"
 
 
+class _RecLossFn(torch.autograd.Function):
+    """scale * sum (pred - tgt)^2 in one kernel each way (lp_loss with p = 2 is six ATen passes forward, six back)."""
+
+    @staticmethod
+    def forward(ctx, pred, tgt, scale):
+        ctx.save_for_backward(pred, tgt)
+        ctx.scale = scale
+        return backend.get().rec_loss(pred, tgt, scale).view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt = ctx.saved_tensors
+        return backend.get().rec_loss_backward(pred, tgt, ctx.scale, g.reshape(1)), None, None
+
+
+class _RoundLossAllFn(torch.autograd.Function):
+    """weight * sum over the block's AdaRound quantisers of sum(1 - |2h-1|^b): value and gradients in ONE launch
+    (csrc/brecq.hip k_round_loss_multi); the reference builds ~10 autograd nodes per quantiser."""
+
+    @staticmethod
+    def forward(ctx, b, weight, *alphas):
+        loss, grads = backend.get().round_loss_multi(alphas, b, weight)
+        ctx.save_for_backward(*grads)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
+
+
 class LossFunction:
     """block_recon.py:160-218."""
 
@@ -239,14 +289,19 @@ class LossFunction:
         self.last = (0.0, 0.0, 0.0)
 
     @staticmethod
-    def lp_loss(pred, tgt, p=2.0, reduction='none'):
+    def lp_loss(pred, tgt, p=2.0, reduction='none', scale=1.0):
+        """``scale`` multiplies the result (rec_term passes its /10 here so that the fused kernel absorbs it)."""
         if reduction == 'none':
-            return (pred - tgt).abs().pow(p).sum(1).mean()
-        return (pred - tgt).abs().pow(p).mean()
+            if p == 2.0 and pred.dim() >= 2 and pred.shape == tgt.shape and pred.is_contiguous() and tgt.is_contiguous() \
+                    and pred.dtype == torch.float32 and pred.requires_grad and not tgt.requires_grad:   # a BRECQ iteration
+                # .sum(1).mean() = sum over everything / (numel / size(1))
+                return _RecLossFn.apply(pred, tgt, scale * float(pred.size(1)) / float(pred.numel()))
+            return (pred - tgt).abs().pow(p).sum(1).mean() * scale
+        return (pred - tgt).abs().pow(p).mean() * scale
 
     def rec_term(self, pred, tgt):
         if self.rec_loss == 'mse':
-            return self.lp_loss(pred, tgt, p=self.p) / 10
+            return self.lp_loss(pred, tgt, p=self.p, scale=0.1)
         if self.rec_loss == 'kl_div':
             return F.kl_div(F.log_softmax(pred, dim=-1), F.softmax(tgt, dim=-1).detach(), reduction="batchmean")
         raise ValueError('Not supported reconstruction loss function: {}'.format(self.rec_loss))
@@ -264,6 +319,10 @@ class LossFunction:
 
     def round_sum(self, b):
         """weight * sum over the block's AdaRound quantisers of sum(1 - |2h-1|^b); b: float or one-element device tensor."""
+        alphas = [module.w_quantizer.alpha for _, module in self.block.named_modules()
+                  if hasattr(module, 'w_quantizer') and isinstance(module.w_quantizer, AdaRoundQuantizer)]
+        if 1 <= len(alphas) <= 16 and all(a.dtype == torch.float32 for a in alphas):
+            return _RoundLossAllFn.apply(b, float(self.weight), *alphas)
         round_loss = 0
         for _, module in self.block.named_modules():
             if hasattr(module, 'w_quantizer') and isinstance(module.w_quantizer, AdaRoundQuantizer):

@@ -64,7 +64,7 @@ class Attention(nn.Module):
         B, N, C = x.shape
         x = self.qkv(x)
         qkv = x.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv[0], qkv[1], qkv[2]
+        q, k, v = qkv.unbind(0)                    # one backward node (a stack) instead of three zero-filled selects
         q, k = self.q_norm(q), self.k_norm(k)
         attn = self.matmul1(q, k.transpose(-2, -1)) * self.scale
         attn = attn.softmax(dim=-1)
@@ -218,7 +218,7 @@ class WindowAttention(nn.Module):
         B_, N, C = x.shape
         x = self.qkv(x)
         qkv = x.reshape(B_, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv[0], qkv[1], qkv[2]
+        q, k, v = qkv.unbind(0)                    # one backward node (a stack) instead of three zero-filled selects
         q = q * self.scale
         attn = self.matmul1(q, k.transpose(-2, -1))
         attn = attn + self._get_rel_pos_bias()

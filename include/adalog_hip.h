@@ -232,9 +232,12 @@ int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, 
  * adalog_adaround: forward (backward = 0): out = (clamp(floor(w/s) + h + zp, 0, 2L-1) - zp) * s with
  *   h = clamp(sigmoid(alpha)*1.2 - 0.1, 0, 1) (soft) or [alpha >= 0] (hard)   (reference quantizers/adaround.py:43-60);
  *   backward = 1: out = d loss / d alpha = gy * s * h'(alpha) * [inside clamp].  w/alpha: [rows][inner], scale/zp: [rows].
- * adalog_round_loss: loss[0] = sum (1 - |2h(alpha)-1|^b)  and, if galpha, galpha += gscale * d/d alpha
- *   (reference utils/block_recon.py:205-210).  b_dev (optional, device fp32 [1]) overrides b: the exponent is then read
- *   on the device, so a captured HIP graph of a BRECQ iteration follows the decaying b.  workspace: 1024 floats. */
+ * adalog_round_loss: loss[0] = sum (1 - |2h(alpha)-1|^b)  and, if galpha, with g = gscale * (gmul ? gmul[0] : 1) * d/d alpha:
+ *   galpha = g (overwrite != 0) or galpha += g   (reference utils/block_recon.py:205-210).  gmul (optional, device fp32
+ *   [1]) is the upstream gradient of the scalar loss.  b_dev (optional, device fp32 [1]) overrides b: the exponent is then
+ *   read on the device, so a captured HIP graph of a BRECQ iteration follows the decaying b.  workspace: 1024 floats.
+ * The per-tensor parameter gradients and the loss value are reduced inside the producing kernel: every block leaves an
+ *   fp32 partial, and the last block to arrive (device ticket counter) sums them in fp64 in a fixed order. */
 int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, int64_t inner);
 int adalog_uniform_fq_backward(const float* gy, const float* x, float* gx, int64_t n, const float* scale,
                                const float* zero_point, int64_t n_channels, int64_t inner, int n_bits, int symmetric,
@@ -245,7 +248,20 @@ int adalog_log_fq_backward(const float* gy, const float* x, const float* y, floa
 int adalog_adaround(const float* w, const float* alpha, const float* gy, float* out, int64_t rows, int64_t inner,
                     const float* scale, const float* zero_point, int n_bits, int soft, int backward, void* stream);
 int adalog_round_loss(const float* alpha, int64_t n, float b, const float* b_dev, float* loss, float* galpha, float gscale,
-                      float* workspace, void* stream);
+                      const float* gmul, int overwrite, float* workspace, void* stream);
+/* The regulariser of a whole block in one launch: loss[0] = weight * sum_t sum_i (1 - |2h(alpha_t[i])-1|^b) over `count`
+ *   (<= 16) tensors and grads[t][i] = weight * d/d alpha_t[i] (the loop of reference utils/block_recon.py:205-210).
+ *   alphas / grads / ns are HOST arrays (device pointers / element counts).  workspace:
+ *   adalog_round_loss_multi_workspace(ns, count) floats. */
+int64_t adalog_round_loss_multi_workspace(const int64_t* ns, int count);
+int adalog_round_loss_multi(const float* const* alphas, float* const* grads, const int64_t* ns, int count, float b,
+                            const float* b_dev, float weight, float* loss, float* workspace, void* stream);
+/* Reconstruction loss of a BRECQ iteration, LossFunction.lp_loss with p = 2 (reference utils/block_recon.py:186-199):
+ *   loss[0] = scale * sum (pred - tgt)^2, the caller folding 1/(batch*channels) of `.sum(1).mean()` and the /10 into scale;
+ *   backward: gpred = 2 * scale * gmul[0] * (pred - tgt).  workspace: 2048 floats. */
+int adalog_rec_loss(const float* pred, const float* tgt, int64_t n, float scale, float* loss, float* workspace, void* stream);
+int adalog_rec_loss_backward(const float* pred, const float* tgt, int64_t n, float scale, const float* gmul, float* gpred,
+                             void* stream);
 
 #ifdef __cplusplus
 }

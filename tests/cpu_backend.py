@@ -366,10 +366,32 @@ def adaround(w2, alpha2, scale, zero_point, n_bits, soft, gy=None):
 
 
 @torch.enable_grad()
-def round_loss(alpha, b, galpha=None, gscale=1.0, want_loss=True):
+def round_loss(alpha, b, galpha=None, gscale=1.0, want_loss=True, gmul=None, overwrite=False):
     a = alpha.detach().clone().requires_grad_(True)
     h = torch.clamp(torch.sigmoid(a) * 1.2 - 0.1, 0, 1)
     loss = (1 - ((h - .5).abs() * 2).pow(b)).sum()
     if galpha is not None:
-        galpha += gscale * torch.autograd.grad(loss, a)[0]
+        g = gscale * torch.autograd.grad(loss, a)[0] * (1.0 if gmul is None else gmul.reshape(()))
+        if overwrite:
+            galpha.copy_(g)
+        else:
+            galpha += g
     return loss.detach().view(1) if want_loss else None
+
+
+def rec_loss(pred, tgt, scale):
+    return (((pred - tgt) ** 2).sum() * scale).view(1)
+
+
+def rec_loss_backward(pred, tgt, scale, gmul):
+    return (pred - tgt) * (2.0 * scale * gmul.reshape(()))
+
+
+def round_loss_multi(alphas, b, weight):
+    bb = float(b.reshape(()).item()) if torch.is_tensor(b) else float(b)
+    total, grads = 0.0, []
+    for al in alphas:
+        g_ = torch.zeros_like(al)
+        total = total + round_loss(al, bb, galpha=g_, gscale=weight)
+        grads.append(g_)
+    return (total * weight).view(1), grads

@@ -509,6 +509,15 @@ def test_adaround_and_round_loss(ops):
         l = ops.round_loss(alpha.to(DEV), b, galpha=ga, gscale=0.5)
         torch.testing.assert_close(l.cpu(), l_ref, rtol=1e-4, atol=1e-3)
         torch.testing.assert_close(ga.cpu(), ga_ref, rtol=1e-3, atol=1e-5)
+        # the form the autograd node uses: upstream gradient read on the device, gradient written (not accumulated)
+        ga2 = torch.full_like(alpha, 7.0).to(DEV)
+        assert ops.round_loss(alpha.to(DEV), b, galpha=ga2, gscale=1.0, want_loss=False, gmul=torch.tensor([0.5]).to(DEV),
+                              overwrite=True) is None
+        torch.testing.assert_close(ga2.cpu(), ga_ref, rtol=1e-3, atol=1e-5)
+    # many launches back to back reuse the ticket counters: every value must stay the same
+    big = torch.randn(300_000, generator=gen).to(DEV)
+    vals = torch.stack([ops.round_loss(big, 4.0) for _ in range(2100)])
+    assert torch.equal(vals, vals[0].expand_as(vals))
 
 
 @pytest.mark.parametrize("dtype", ["i8", "bf16"])
@@ -832,3 +841,33 @@ def test_torch_ops_route_matches_c_abi():
     assert torch.equal(torch.ops.adalog.topk(sc, 16), OPS.topk(sc, 16))
     xg = torch.nn.functional.gelu(x)
     assert torch.equal(torch.ops.adalog.log2_shift(xg, 0.17), OPS.log2_shift(xg, 0.17))
+
+
+@pytest.mark.parametrize("shape", [(4, 7, 33), (32, 197, 384), (3, 5)])
+def test_rec_loss_forward_backward(ops, shape):
+    """Fused BRECQ reconstruction loss (lp_loss, p = 2) against the ATen composition the reference runs."""
+    gen = g(77)
+    pred = torch.randn(*shape, generator=gen)
+    tgt = pred + 0.1 * torch.randn(*shape, generator=gen)
+    scale = 0.1 * shape[1] / pred.numel()
+    p_ref = pred.clone().requires_grad_(True)
+    l_ref = (p_ref - tgt).abs().pow(2.0).sum(1).mean() / 10
+    l_ref.backward()
+    l = ops.rec_loss(pred.to(DEV), tgt.to(DEV), scale)
+    torch.testing.assert_close(l.cpu().view(()), l_ref.detach(), rtol=2e-6, atol=0)
+    gp = ops.rec_loss_backward(pred.to(DEV), tgt.to(DEV), scale, torch.tensor([1.0]).to(DEV))
+    torch.testing.assert_close(gp.cpu(), p_ref.grad, rtol=1e-5, atol=1e-9)
+
+
+def test_round_loss_multi_matches_per_tensor(ops):
+    """One launch for all of a block's alpha tensors == the per-tensor kernel, value and gradients."""
+    gen = g(78)
+    alphas = [torch.randn(n, generator=gen) * 2 for n in (147456, 1152 * 384, 5, 384 * 1536 + 3)]
+    for b in (20.0, 7.3, 2.0):
+        l_ref, g_ref = CB.round_loss_multi(alphas, b, 0.01)
+        loss, grads = ops.round_loss_multi([a.to(DEV) for a in alphas], b, 0.01)
+        torch.testing.assert_close(loss.cpu(), l_ref, rtol=1e-5, atol=1e-4)
+        for gg, gr in zip(grads, g_ref):
+            torch.testing.assert_close(gg.cpu(), gr, rtol=1e-3, atol=1e-7)
+    loss_b, _ = ops.round_loss_multi([a.to(DEV) for a in alphas], torch.tensor([2.0]).to(DEV), 0.01)    # exponent on the device
+    torch.testing.assert_close(loss_b, loss)
