@@ -148,20 +148,23 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
     __shared__ double smd[4];
     const float s = scale[0], qf = (float)q[0];
     const float sh = shift ? shift[0] : 0.0f;
+    const float inv_s = 1.0f / s, rq37 = 37.0f / qf, q37 = qf / 37.0f, kmax = (float)(levels2 - 1);
     float as = 0.0f;
+    // k is the forward's bin (same exact-with-fallback evaluation); the gradient factors use reciprocals: they are smooth
+    // in their inputs, so a last-ulp difference from the IEEE quotients moves the gradient by ~1e-7 relative.
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float xs = shift ? x[i] + sh : x[i];
         const float ur = xs / s;
         const bool iu = (ur >= 1e-15f) && (ur <= 1.0f);
         const float u = fminf(fmaxf(ur, 1e-15f), 1.0f);
-        const float k = adalog_k(u, qf);
-        const bool ik = (k >= 0.0f) && (k <= (float)(levels2 - 1));
+        const float k = adalog_k_fast(u, 1.0f, 1.0f, qf, rq37, false);
+        const bool ik = (k >= 0.0f) && (k <= kmax);
         // y before the "- shift", recomputed from k (adding the shift back to the stored output would cancel small y)
-        const float yv = (k < (float)levels2) ? exp2f(-1.0f * fminf(fmaxf(k, 0.0f), (float)(levels2 - 1)) * qf / 37.0f) * s : 0.0f;
+        const float yv = (k <= kmax) ? __builtin_amdgcn_exp2f(-fminf(fmaxf(k, 0.0f), kmax) * q37) * s : 0.0f;
         const float g = gy[i];
-        const float dydx = (iu && ik) ? yv / (u * s) : 0.0f;
+        const float dydx = (iu && ik) ? yv * __builtin_amdgcn_rcpf(u * s) : 0.0f;
         if (gx) gx[i] = g * dydx;
-        as += g * (yv / s - dydx * xs / s);
+        as += g * inv_s * (yv - dydx * xs);
     }
     if (part_s) {
         const float ts = block_sum(as, sm);

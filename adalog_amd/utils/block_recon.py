@@ -107,14 +107,14 @@ class BlockReconstructor(QuantCalibrator):
         ws = parallel.world_size()
         local_bs = max(1, batch_size // ws)
         n_local = block.raw_input.size(0)
-        # One iteration is ~175 kernel launches (2.6 ms of GPU time, 4.1 ms wall on MI355X for a deit_small block).
-        # ADALOG_BRECQ_GRAPH=1 captures the iteration once in a HIP graph over static batch buffers and replays it: forward,
-        # reconstruction loss, rounding regulariser (its exponent b and on/off weight live in device scalars), backward
-        # and -- single process -- both Adam steps (capturable); with several ranks the gradient all-reduce and the
-        # optimiser steps stay eager.  Measured gain: 3 % (4.13 -> 4.00 ms): the replay pays a per-node cost close to an
-        # eager launch, so the lever is fewer and larger kernels, not the launch path -- hence opt-in.
-        use_graph = (torch.device(device).type == 'cuda' and os.environ.get("ADALOG_BRECQ_GRAPH", "0") == "1"
-                     and n_local >= local_bs and iters > 8)
+        # One iteration is ~85 kernel launches (1.7 ms of GPU time on MI355X for a deit_small block, 58 % of it the fp32
+        # GEMMs), issued eagerly in 2.0 ms.  The iteration is captured once in a HIP graph over static batch buffers and
+        # replayed: forward, reconstruction loss, rounding regulariser (its exponent b and on/off weight live in device
+        # scalars), backward and -- single process -- both Adam steps (capturable).  20 000 iterations of the block:
+        # 496 it/s eager, 568 it/s replayed, same reached error.  With several ranks the gradient all-reduce and the
+        # optimiser steps stay eager and the graph is opt-in (ADALOG_BRECQ_GRAPH=1); ADALOG_BRECQ_GRAPH=0 forces eager.
+        want_graph = os.environ.get("ADALOG_BRECQ_GRAPH", "1" if ws == 1 else "0") == "1"
+        use_graph = (torch.device(device).type == 'cuda' and want_graph and n_local >= local_bs and iters > 8)
         full_graph = use_graph and ws == 1
         okw = dict(capturable=True) if full_graph else {}
         if torch.device(device).type == 'cuda':

@@ -153,9 +153,10 @@ def hbm_kernels(ops, dev):
     return out
 
 
-def brecq_rate(model_name, bits, dev, iters=120):
+def brecq_rate(model_name, bits, dev, iters=2000):
     """BRECQ (utils/block_recon.py:84-137) iterations per second on blocks.0 of the benchmarked model: a bounded sample
-    (the reference runs 20 000 iterations per block); wall time for one block and the whole model follow by scaling."""
+    (the reference runs 20 000 iterations per block) with the reference's schedule in proportion (first 20 % without the
+    rounding regulariser); wall time for one block and the whole model follow by scaling."""
     from adalog_amd.utils.block_recon import BlockReconstructor
     from adalog_amd.utils.calibrator import QuantCalibrator
     from adalog_amd.utils.models import create_model
@@ -176,7 +177,7 @@ def brecq_rate(model_name, bits, dev, iters=120):
     name = "blocks.0"
     block, fblock = rec.blocks[name], rec.full_blocks[name]
     rec.init_block_raw_data(block, fblock, name, dev)
-    rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=10)          # warm-up (releases the block data)
+    rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=100)         # warm-up (releases the block data)
     rec.init_block_raw_data(block, fblock, name, dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
