@@ -27,7 +27,7 @@ SIGNATURES = {
     "adalog_gemm_score_layout": (i64, [i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, p, p, p]),
     "adalog_log2_shift": (i32, [p, p, i64, f32, p]),
     "adalog_score_act_fused_ok": (i32, [i32, i64, i32, i64, i32, i32]),
-    "adalog_score_act_fused_workspace_bytes": (i64, []),
+    "adalog_score_act_fused_workspace_bytes": (i64, [i64, i64]),
     "adalog_score_act_fused": (i32, [p, i32, i64, p, p, i64, i32, p, p, p, p, p, i32, i32, p, f32, i32, f32, f64, p, i64, p, p]),
     "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p, i64, p]),
     "adalog_finish_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),

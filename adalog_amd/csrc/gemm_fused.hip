@@ -62,12 +62,14 @@ struct FusedArgs {
     const float* qv;           // [128]   candidate bases q_p (as floats)
     const float* mant;         // [37]    integer numerators of the search-time mantissa table (linear.py:750-752)
     const float* thr;          // [levels2][128] break points of the exact pipeline (k_tie_thresholds)
+    const uint8_t* flags;      // [T][fpitch] near-tie flags of the hand-scheduled form (k_tie_flags); null for the compiler form
     double* wg_acc;            // [gridDim.x][128]
     int M, T, K;
     int Kb;                    // row pitch of W in bytes (multiple of 128)
     int levels2;               // 2^bits
     int n_rt;                  // row tiles of 32 * NRB rows
     int nk;                    // 64-byte K-steps
+    int fpitch;                // bytes per token row of `flags`
     float shift, sa_mul;
 };
 
@@ -127,6 +129,58 @@ __global__ __launch_bounds__(128) void k_tie_thresholds(const float* __restrict_
         out = __uint_as_float(hi);
     }
     thr[b * 128 + pc] = out;
+}
+
+// Near-tie flags for the hand-scheduled form.  The main loop generates the B fragments of one K half (16 k) per "unit":
+// half-step j = 2 * step + half of a token.  nib(j) has bit blk (0..3) set when any of the 16 x 32 element-candidates of
+// candidate block blk (candidates 32 blk .. 32 blk + 31) lies within the near-tie zone of its fast bin -- evaluated with
+// exactly the fast arithmetic of the main loop (same fma / clamp / round), so the main loop needs no detection of its own.
+// Row of token t (fpitch bytes):  byte n < nk : nib(2n + 1) | nib(2n + 2) << 4  (the two units of main-loop step n;
+// nib(2 nk) = 0, patched in the kernel with the next tile's first nibble);  byte nk : nib(0).
+// One wave per token; a lane owns candidates lane and lane + 64; the log2 values arrive as scalar loads.
+__global__ __launch_bounds__(256) void k_tie_flags(const float* __restrict__ L, const float* __restrict__ scale,
+                                                   const float* __restrict__ qv, int levels2, int T, int K, int nk, int fpitch,
+                                                   float tie, uint8_t* __restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float pa[2], pc[2], ph[2];
+#pragma unroll
+    for (int sidx = 0; sidx < 2; ++sidx) {
+        const float s = scale[lane + 64 * sidx], qf = qv[lane + 64 * sidx];
+        const float rq37 = 37.0f / qf;
+        const float top = (float)levels2 + 0.75f, NL15 = 49.828921f;
+        pa[sidx] = -rq37; pc[sidx] = __log2f(s) * rq37; ph[sidx] = fminf(NL15 * rq37, top);      // as s_par in the main kernels
+    }
+    for (int tok = blockIdx.x * 4 + w; tok < T; tok += gridDim.x * 4) {
+        const float* __restrict__ Lr = L + (int64_t)tok * K;
+        uint8_t* __restrict__ row = flags + (int64_t)tok * fpitch;
+        unsigned prev_odd = 0;
+        for (int n = 0; n < nk; ++n) {
+            unsigned nib[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float dm0 = 0.0f, dm1 = 0.0f;
+                const int k0 = n * 32 + h * 16;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float l = (k0 + e < K) ? Lr[k0 + e] : 0.0f;
+                    const float kf0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(l, pa[0], pc[0]), 0.0f, ph[0]);
+                    const float kf1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(l, pa[1], pc[1]), 0.0f, ph[1]);
+                    dm0 = fmaxf(dm0, fabsf(kf0 - __builtin_rintf(kf0)));
+                    dm1 = fmaxf(dm1, fabsf(kf1 - __builtin_rintf(kf1)));
+                }
+                const unsigned long long m0 = __ballot(dm0 > tie), m1 = __ballot(dm1 > tie);
+                nib[h] = ((unsigned)m0 != 0u ? 1u : 0u) | ((unsigned)(m0 >> 32) != 0u ? 2u : 0u) |
+                         ((unsigned)m1 != 0u ? 4u : 0u) | ((unsigned)(m1 >> 32) != 0u ? 8u : 0u);
+            }
+            if (lane == 0) {
+                if (n == 0) row[nk] = (uint8_t)nib[0];
+                else row[n - 1] = (uint8_t)(prev_odd | (nib[0] << 4));
+            }
+            prev_odd = nib[1];
+        }
+        if (lane == 0) row[nk - 1] = (uint8_t)prev_odd;
+    }
 }
 
 template <int NRB, int FNS>
@@ -592,8 +646,12 @@ extern "C" int adalog_score_act_fused_ok(int M, int64_t T, int K, int64_t Kp, in
     return fused_lds_bytes(nrb, pick_fns(nrb, 1 << n_bits), 1 << n_bits) <= 160 * 1024 ? 1 : 0;
 }
 
-// [workgroups][128] fp64 partial sums, then the [2^6][128] fp32 threshold table
-extern "C" int64_t adalog_score_act_fused_workspace_bytes(void) { return (int64_t)fused_cus() * 128 * 8 + 64 * 128 * 4; }
+static int64_t fused_flag_pitch(int64_t Kp) { return ((Kp * 2 / 64 + 1) + 3) & ~(int64_t)3; }
+
+// [workgroups][128] fp64 partial sums, the [2^6][128] fp32 threshold table, then the [T][pitch] near-tie flag bytes
+extern "C" int64_t adalog_score_act_fused_workspace_bytes(int64_t T, int64_t Kp) {
+    return (int64_t)fused_cus() * 128 * 8 + 64 * 128 * 4 + T * fused_flag_pitch(Kp) + 64;
+}
 
 // scores[p] = -norm * sum_{t, o} ( (ref[t, o] - row_bias[o]) - s_w[o] * (s_p * sa_mul) * sum_k Wq[o, k] * m_p(x[t, k]) )^2
 // for the 128 AdaLog candidates (s_p, q_p); m_p = integer-numerator form of the search-time AdaLog value
@@ -607,7 +665,7 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
     ADALOG_ARG_CHECK(Wp && x && Lx && ref && row_scale && scale && qv && mant37 && workspace && scores, "score_act_fused: null pointer");
     ADALOG_ARG_CHECK(adalog_score_act_fused_ok(M, T, K, Kp, P, n_bits), "score_act_fused: shape not supported (ask adalog_score_act_fused_ok first)");
     ADALOG_ARG_CHECK(clamp_u, "score_act_fused: only the clamped form (post-GELU searches, linear.py:829) is implemented");
-    ADALOG_ARG_CHECK(workspace_bytes >= adalog_score_act_fused_workspace_bytes() && ((uintptr_t)workspace & 7) == 0,
+    ADALOG_ARG_CHECK(workspace_bytes >= adalog_score_act_fused_workspace_bytes(T, Kp) && ((uintptr_t)workspace & 7) == 0,
                      "score_act_fused: workspace too small or misaligned");
     FusedArgs a{};
     a.W = (const uint8_t*)Wp; a.L = Lx; a.x = x; a.ref = ref; a.row_scale = row_scale; a.row_bias = row_bias;
@@ -616,6 +674,8 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
     a.nk = (int)(Kp * 2 / 64); a.shift = shift; a.sa_mul = sa_mul;
     float* thr = reinterpret_cast<float*>((uint8_t*)workspace + (size_t)fused_cus() * 128 * 8);
     a.thr = thr;
+    uint8_t* flags = reinterpret_cast<uint8_t*>(thr + 64 * 128);
+    a.fpitch = (int)fused_flag_pitch(Kp);
     const int nrb = pick_nrb(M);
     const int fns = pick_fns(nrb, a.levels2);
     a.n_rt = (M + 32 * nrb - 1) / (32 * nrb);
@@ -639,6 +699,15 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
 #define LAUNCH_FUSED_N(NRBV) do { if (fns == 4) LAUNCH_FUSED(NRBV, 4); else LAUNCH_FUSED(NRBV, 3); } while (0)
     static const int use_asm = getenv("ADALOG_FUSED_ASM") ? atoi(getenv("ADALOG_FUSED_ASM")) : 1;
     const size_t shm_asm = 256 + shm;
+    if (use_asm && shm_asm <= 160 * 1024) {
+        // near-tie flags of this call's candidates (the hand-scheduled loop has no detection of its own)
+        const float tie = a.levels2 <= 16 ? 0.499975f : 0.49995f;
+        const int tb = (int)((T + 3) / 4);
+        a.flags = flags;
+        hipLaunchKernelGGL(k_tie_flags, dim3((unsigned)(tb < 4096 ? tb : 4096)), dim3(256), 0, st, Lx, scale, qv, a.levels2, (int)T, K,
+                           a.nk, a.fpitch, tie, flags);
+        ADALOG_LAUNCH_CHECK("adalog_score_act_fused (near-tie flags)");
+    }
 #define LAUNCH_ASM(KERNEL, TAG)                                                                                 \
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \

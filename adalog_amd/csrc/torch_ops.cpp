@@ -22,7 +22,7 @@ int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n
                               int train_form, void* stream);
 int adalog_log2_shift(const float* x, float* out, int64_t n, float shift, void* stream);
 int adalog_score_act_fused_ok(int M, int64_t T, int K, int64_t Kp, int P, int n_bits);
-int64_t adalog_score_act_fused_workspace_bytes(void);
+int64_t adalog_score_act_fused_workspace_bytes(int64_t T, int64_t Kp);
 int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const float* x, const float* Lx, int64_t T, int K,
                            const float* ref, const float* row_scale, const float* row_bias, const float* scale,
                            const float* qv, int P, int n_bits, const float* mant37, float shift, int clamp_u, float sa_mul,
@@ -80,8 +80,8 @@ at::Tensor score_act_fused(const at::Tensor& wp, const at::Tensor& x2, const at:
     TORCH_CHECK(wp.is_cuda() && wp.scalar_type() == at::kBFloat16 && wp.is_contiguous(), "wp: expected a contiguous bf16 HIP tensor");
     const int64_t M = wp.size(-2), Kp = wp.size(-1), T = x2.size(0), K = x2.size(1), P = scale.numel();
     TORCH_CHECK(adalog_score_act_fused_ok((int)M, T, (int)K, Kp, (int)P, (int)n_bits), "adalog::score_act_fused: shape not supported");
-    const int64_t wsb = adalog_score_act_fused_workspace_bytes();
-    at::Tensor ws = at::empty({wsb / 8}, x2.options().dtype(at::kDouble));
+    const int64_t wsb = adalog_score_act_fused_workspace_bytes(T, Kp);
+    at::Tensor ws = at::empty({(wsb + 7) / 8}, x2.options().dtype(at::kDouble));
     at::Tensor scores = at::empty({P, 1}, x2.options());
     check(adalog_score_act_fused(wp.data_ptr(), (int)M, Kp, fptr(x2, "x"), fptr(lx2, "log2 x"), T, (int)K, fptr(ref2, "ref"),
                                  fptr(row_scale, "row_scale"), row_bias.has_value() ? fptr(*row_bias, "row_bias") : nullptr,

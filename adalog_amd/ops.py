@@ -296,8 +296,8 @@ def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: i
         return _top("score_act_fused", wp, x2, lx2, ref2, _f32c(row_scale, "row_scale"),
                     None if row_bias is None else _f32c(row_bias, "row_bias"), _f32c(scale, "scale"), _f32c(qv, "qv"),
                     int(n_bits), _f32c(mant37, "mant37"), float(shift), bool(clamp_u), float(sa_mul), float(norm))
-    ws_bytes = lib.adalog_score_act_fused_workspace_bytes()
-    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x2.device)
+    ws_bytes = lib.adalog_score_act_fused_workspace_bytes(T, Kp)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x2.device)
     scores = torch.empty((P, 1), dtype=torch.float32, device=x2.device)
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -139,12 +139,13 @@ int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, i
  * corrected), but the [T*P][K] candidate operand is never written: HBM traffic = Lx + ref + Wp.
  *   Wp: bf16 image of the quantised weight, [M][Kp] (adalog_pack_uniform, out_dtype 1);  x: [T][K] fp32;
  *   Lx = adalog_log2_shift(x, shift): [T][K] fp32, correctly rounded log2(x + shift), -inf where x + shift <= 0;
- *   ref: raw_out [T][M];  workspace: adalog_score_act_fused_workspace_bytes() bytes, 8-byte aligned.
+ *   ref: raw_out [T][M];  workspace: adalog_score_act_fused_workspace_bytes(T, Kp) bytes, 8-byte aligned (partial sums,
+ *   the threshold table, and one near-tie flag byte per token and K-step written by a pre-pass over Lx).
  * adalog_score_act_fused_ok: 1 when the shape is taken (P = 128, n_bits <= 6, >= 6 K-steps of 32, LDS budget), else the
  * caller uses the packed path. */
 int adalog_log2_shift(const float* x, float* out, int64_t n, float shift, void* stream);
 int adalog_score_act_fused_ok(int M, int64_t T, int K, int64_t Kp, int P, int n_bits);
-int64_t adalog_score_act_fused_workspace_bytes(void);
+int64_t adalog_score_act_fused_workspace_bytes(int64_t T, int64_t Kp);
 int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const float* x, const float* Lx, int64_t T, int K,
                            const float* ref, const float* row_scale, const float* row_bias, const float* scale,
                            const float* qv, int P, int n_bits, const float* mant37, float shift, int clamp_u, float sa_mul,

@@ -26,19 +26,20 @@ ROWS = 32 * NRB
 NA = min(NRB, 8)  # row blocks whose tiles live in AGPRs (2 tiles each); the rest sit in v128..
 MAGIC = 0x4B400000
 TIE_BITS = 0x3EFFF2E5   # 0.4999f
-PACKED = bool(os.environ.get("FUSED_PACKED"))     # v_pk_fma/add_f32 for the pairwise arithmetic: measured 22 % SLOWER beside MFMAs
-SM = 34                                            # s[36:37] = {MAGIC, -}, s[38:39] = {-MAGIC, -} (packed-add constants)
+# (v_pk_fma/add_f32 for the pairwise arithmetic was measured 22 % SLOWER beside the MFMAs: not generated any more)
 
 # ---------------------------------------------------------------- config array in LDS (dword indices), written by the kernel
 CFG = ["pW_lo", "pW_hi", "pX_lo", "pX_hi", "pL_lo", "pL_hi", "pRef_lo", "pRef_hi", "pRs_lo", "pRs_hi", "pRb_lo", "pRb_hi",
        "M", "T", "K", "Kb", "nk", "n_rt", "ntile", "nwg", "bid", "L2", "shift", "w",
-       "oRing", "oXr", "oLut", "oThr", "oPar", "oRefb", "oRs", "oFin", "dpair", "drt", "pair0", "rt0", "tie"]
+       "oRing", "oXr", "oLut", "oThr", "oPar", "oRefb", "oRs", "oFin", "dpair", "drt", "pair0", "rt0", "tie",
+       "pF_lo", "pF_hi", "fpitch"]
 S = {n: 40 + i for i, n in enumerate(CFG)}          # s40 .. s75
 S["tie"] = 27                                        # = t(19)'s old home is s27: see below (TIE lives in s19)
 S.update(rW=76, rX=80, rL=84,                        # buffer resources (4 SGPRs each)
          a_tile=88, a_pair=89, a_rt=90, a_k=91, l_tile=92, l_pair=93, l_rt=94, l_k=95,
          c_tile=96, kt=97, stA=98, stX=99, c_pair=30, c_rt=31)
 S["tie"] = 19                                        # t(11): the near-tie threshold, loaded from the config
+S.update(pF_lo=34, pF_hi=35, fpitch=36, sh2=37)      # near-tie flag rows (k_tie_flags); sh2 = 2 * (w & 1)
 T0 = 8                                               # s8 .. s31: temporaries
 
 
@@ -57,7 +58,7 @@ def t2(i):
 # ---------------------------------------------------------------- VGPR map
 V = dict(LANE=0, FROW=1, FKG=2, TMP=3, PAR0=4, PAR1=8, LUTC0=12, LUTC1=13, THRC0=14, THRC1=15, AOFF0=16, AOFF1=17, AS0=18, AS1=19,
          XOFF=20, XSC=21, XSN=22, XDMA=23, DMA=24, EPI=30, EPR=31, XORA=32, LUTB0=33, LUTB1=34, ZERO=35, RUN0=36, RUN1=38,
-         BA=40, BB=48, LV=56, ABUF=64, VAL=84, GT=100, DM=116, TOKOK=118, XV=120, E0=64, )
+         BA=40, BB=48, LV=56, ABUF=64, VAL=84, GT=100, FLGC=116, FLGN=117, XV=120, E0=64, )
 CA, CC, CHI, AL = 0, 1, 2, 3
 
 
@@ -196,8 +197,10 @@ def lane_setup(A):
     A.e(f"s_mov_b32 s{S['rW'] + 3}, 0x00020000")
     A.e(f"s_mov_b32 s{S['rX'] + 3}, 0x00020000")
     A.e(f"s_mov_b32 s{S['rL'] + 3}, 0x00020000")
-    A.e(f"s_mov_b32 s{SM}, 0x{MAGIC:08x}")
-    A.e(f"s_mov_b32 s{SM + 2}, 0x{(MAGIC ^ 0x80000000):08x}")
+    A.e(f"s_and_b32 {s('sh2')}, {s('w')}, 1")
+    A.e(f"s_lshl_b32 {s('sh2')}, {s('sh2')}, 1")
+    A.e(f"v_mov_b32 {v('FLGC')}, 0")
+    A.e(f"v_mov_b32 {v('FLGN')}, 0")
 
 
 def set_x_rsrc(A):
@@ -318,51 +321,27 @@ def a_slot_base(slot_reg_or_const):
 
 
 # ---------------------------------------------------------------- fragment generation (one pair of element-candidates)
-def gen_pair_ops(cb, e, set_, val0, dm_first):
+def gen_pair_ops(cb, e, set_, val0):
     """instruction list (strings or ('ds', text, tag)) producing LUT reads of elements e, e+1 of candidate block cb
-    from the log2 values LV[e], LV[e+1]; results land in VAL+val0, VAL+val0+1"""
+    from the log2 values LV[e], LV[e+1]; results land in VAL+val0, VAL+val0+1.  (Near-ties: k_tie_flags' bits.)"""
     par = "PAR0" if cb == 0 else "PAR1"
     ca, cc, chi = v(par, CA), v(par, CC), v(par, CHI)
     lutc = v("LUTC0" if cb == 0 else "LUTC1")
-    g = V["GT"] + 8 * set_
-    k0, k1, t0, t1, d0, d1, a0, a1 = (f"v{g + i}" for i in range(8))
-    dm = v("DM", cb)
+    g = V["GT"] + 4 * set_
+    k0, k1, a0, a1 = (f"v{g + i}" for i in range(4))
     lut0 = ("ds", f"ds_read_b32 v{V['VAL'] + val0}, {a0}", f"val{val0}") if not os.environ.get("FUSED_NOLUT") else f"v_mov_b32 v{V['VAL'] + val0}, {a0}"
     lut1 = ("ds", f"ds_read_b32 v{V['VAL'] + val0 + 1}, {a1}", f"val{val0 + 1}") if not os.environ.get("FUSED_NOLUT") else f"v_mov_b32 v{V['VAL'] + val0 + 1}, {a1}"
-    if PACKED:
-        pa = V[par]
-        ops = [
-            f"v_pk_fma_f32 v[{g}:{g + 1}], v[{V['LV'] + e}:{V['LV'] + e + 1}], v[{pa}:{pa + 1}], v[{pa}:{pa + 1}] op_sel:[0,0,1] op_sel_hi:[1,0,1]",
-            f"v_med3_f32 {k0}, {k0}, 0, {chi}",
-            f"v_med3_f32 {k1}, {k1}, 0, {chi}",
-            f"v_pk_add_f32 v[{g + 2}:{g + 3}], v[{g}:{g + 1}], s[{SM}:{SM + 1}] op_sel_hi:[1,0]",
-            f"v_lshl_add_u32 {a0}, {t0}, 9, {lutc}",
-            f"v_lshl_add_u32 {a1}, {t1}, 9, {lutc}",
-            lut0, lut1,
-            f"v_pk_add_f32 v[{g + 4}:{g + 5}], v[{g + 2}:{g + 3}], s[{SM + 2}:{SM + 3}] op_sel_hi:[1,0]",
-            f"v_pk_add_f32 v[{g + 4}:{g + 5}], v[{g}:{g + 1}], v[{g + 4}:{g + 5}] neg_lo:[0,1] neg_hi:[0,1]",
-        ]
-    else:
-        ops = [
-            f"v_fma_f32 {k0}, {v('LV', e)}, {ca}, {cc}",
-            f"v_fma_f32 {k1}, {v('LV', e + 1)}, {ca}, {cc}",
-            f"v_med3_f32 {k0}, {k0}, 0, {chi}",
-            f"v_med3_f32 {k1}, {k1}, 0, {chi}",
-            f"v_add_f32 {t0}, 0x{MAGIC:08x}, {k0}",
-            f"v_add_f32 {t1}, 0x{MAGIC:08x}, {k1}",
-            f"v_lshl_add_u32 {a0}, {t0}, 9, {lutc}",
-            f"v_lshl_add_u32 {a1}, {t1}, 9, {lutc}",
-            lut0, lut1,
-            f"v_add_f32 {d0}, 0x{(MAGIC ^ 0x80000000):08x}, {t0}",
-            f"v_add_f32 {d1}, 0x{(MAGIC ^ 0x80000000):08x}, {t1}",
-            f"v_sub_f32 {d0}, {k0}, {d0}",
-            f"v_sub_f32 {d1}, {k1}, {d1}",
-        ]
-    if dm_first:
-        ops.append(f"v_max_f32 {dm}, abs({d0}), abs({d1})")
-    else:
-        ops.append(f"v_max3_f32 {dm}, abs({d0}), abs({d1}), {dm}")
-    return ops
+    return [
+        f"v_fma_f32 {k0}, {v('LV', e)}, {ca}, {cc}",
+        f"v_fma_f32 {k1}, {v('LV', e + 1)}, {ca}, {cc}",
+        f"v_med3_f32 {k0}, {k0}, 0, {chi}",
+        f"v_med3_f32 {k1}, {k1}, 0, {chi}",
+        f"v_add_f32 {k0}, 0x{MAGIC:08x}, {k0}",
+        f"v_add_f32 {k1}, 0x{MAGIC:08x}, {k1}",
+        f"v_lshl_add_u32 {a0}, {k0}, 9, {lutc}",
+        f"v_lshl_add_u32 {a1}, {k1}, 9, {lutc}",
+        lut0, lut1,
+    ]
 
 
 def pack_op(bn, cb, i, val0):
@@ -432,6 +411,87 @@ def fix_chunk(A, cb, bn, xsrc_vgpr, eo):
     A.drain()
 
 
+PROF = bool(os.environ.get("FUSED_PROF"))          # phase timers (s_memtime) instead of results: see tools/lab/prof_fused.py
+PV = dict(P0=118, P1=119, P2=35, P3=3)              # cycles: barrier wait / unit 0 / unit 1 / everything between steps
+
+
+def stamp(A, which):
+    """profiling build: add the cycles since the previous stamp to counter `which`"""
+    if not PROF:
+        return
+    A.drain()
+    A.e(f"s_memtime s[{T0 + 14}:{T0 + 15}]")
+    A.e("s_waitcnt lgkmcnt(0)")
+    A.e(f"s_sub_i32 {t(13)}, {t(14)}, {t(18)}")
+    A.e(f"s_mov_b32 {t(18)}, {t(14)}")
+    A.e(f"v_add_u32 v{PV[which]}, {t(13)}, v{PV[which]}")
+
+
+def load_flag_row(A, pair_sgpr):
+    """FLGN <- the near-tie flag row of token 2 * pair + (w >> 1) (dword j in lane j; zeros past T).  Issues one VMEM load."""
+    lab = A.new("Lnofl")
+    A.e(f"v_mov_b32 {v('FLGN')}, 0")
+    A.e(f"s_lshl_b32 {t(0)}, {pair_sgpr}, 1")
+    A.e(f"s_lshr_b32 {t(1)}, {s('w')}, 1")
+    A.e(f"s_add_i32 {t(0)}, {t(0)}, {t(1)}")                        # token
+    A.e(f"s_cmp_ge_i32 {t(0)}, {s('T')}")
+    A.e(f"s_cbranch_scc1 {lab}_%=")
+    A.e(f"s_mul_hi_u32 {t(3)}, {t(0)}, {s('fpitch')}")
+    A.e(f"s_mul_i32 {t(2)}, {t(0)}, {s('fpitch')}")
+    A.e(f"s_add_u32 {t(2)}, {t(2)}, {s('pF_lo')}")
+    A.e(f"s_addc_u32 {t(3)}, {t(3)}, {s('pF_hi')}")
+    A.e(f"s_lshr_b32 {t(4)}, {s('fpitch')}, 2")                     # dwords per row
+    A.e(f"v_lshlrev_b32 v60, 2, {v('LANE')}")
+    A.e(f"v_cmp_gt_u32 vcc, {t(4)}, {v('LANE')}")
+    A.e(f"s_and_saveexec_b64 {t2(16)}, vcc")
+    A.e(f"global_load_dword {v('FLGN')}, v60, {t2(2)}")
+    A.e(f"s_mov_b64 exec, {t2(16)}")
+    A.label(lab)
+
+
+def first_nibble(A, reg, dst):
+    """dst = nib(0) of the row in VGPR `reg` (byte nk), shifted right by 2 * (w & 1): bit cb = candidate block cb of this wave"""
+    A.e(f"s_lshr_b32 {t(0)}, {s('nk')}, 2")
+    A.e(f"v_readlane_b32 {dst}, {v(reg)}, {t(0)}")
+    A.e(f"s_and_b32 {t(1)}, {s('nk')}, 3")
+    A.e(f"s_lshl_b32 {t(1)}, {t(1)}, 3")
+    A.e(f"s_lshr_b32 {dst}, {dst}, {t(1)}")
+    A.e(f"s_and_b32 {dst}, {dst}, 15")
+    A.e(f"s_lshr_b32 {dst}, {dst}, {s('sh2')}")
+
+
+def rotate_flags(A):
+    """after the next tile's row arrived in FLGN (and the current one sits in FLGC): put the next tile's nib(0) into the
+    high nibble of the current row's last byte (the unit that runs ahead into the next tile tests it)"""
+    A.e(f"s_lshr_b32 {t(0)}, {s('nk')}, 2")
+    A.e(f"v_readlane_b32 {t(1)}, {v('FLGN')}, {t(0)}")
+    A.e(f"s_and_b32 {t(2)}, {s('nk')}, 3")
+    A.e(f"s_lshl_b32 {t(2)}, {t(2)}, 3")
+    A.e(f"s_lshr_b32 {t(1)}, {t(1)}, {t(2)}")
+    A.e(f"s_and_b32 {t(1)}, {t(1)}, 15")                            # nib(0) of the next tile's token
+    A.e(f"s_sub_i32 {t(3)}, {s('nk')}, 1")
+    A.e(f"s_and_b32 {t(4)}, {t(3)}, 3")
+    A.e(f"s_lshl_b32 {t(4)}, {t(4)}, 3")
+    A.e(f"s_add_i32 {t(4)}, {t(4)}, 4")
+    A.e(f"s_lshl_b32 {t(1)}, {t(1)}, {t(4)}")
+    A.e(f"s_lshr_b32 {t(3)}, {t(3)}, 2")
+    A.e(f"v_mov_b32 v60, {t(1)}")
+    A.e(f"v_cmp_eq_u32 vcc, {t(3)}, {v('LANE')}")
+    A.e("v_cndmask_b32 v60, 0, v60, vcc")
+    A.e(f"v_or_b32 {v('FLGC')}, {v('FLGC')}, v60")
+
+
+def step_flags(A):
+    """t(20) = flag byte of this K-step (k_tie_flags layout) >> 2 * (w & 1): bits cb = unit 0, bits 4 + cb = unit 1"""
+    A.e(f"s_sub_i32 {t(12)}, {s('nk')}, {s('kt')}")                # step index
+    A.e(f"s_lshr_b32 {t(13)}, {t(12)}, 2")
+    A.e(f"v_readlane_b32 {t(20)}, {v('FLGC')}, {t(13)}")
+    A.e(f"s_and_b32 {t(12)}, {t(12)}, 3")
+    A.e(f"s_lshl_b32 {t(12)}, {t(12)}, 3")
+    A.e(f"s_lshr_b32 {t(20)}, {t(20)}, {t(12)}")
+    A.e(f"s_lshr_b32 {t(20)}, {t(20)}, {s('sh2')}")
+
+
 def gen_only(A, bn, xs_vgpr, eo):
     """un-overlapped generation of one K half into bn (used once, before the first step)"""
     A.ds(f"ds_read_b128 {vr('LV', 0, 4)}, {xs_vgpr} offset:{256 + eo * 4}", "l0")
@@ -439,7 +499,7 @@ def gen_only(A, bn, xs_vgpr, eo):
     A.drain()
     for cb in range(2):
         for pi in range(4):
-            for op in gen_pair_ops(cb, 2 * pi, pi & 1, 8 * cb + 2 * pi, pi == 0):
+            for op in gen_pair_ops(cb, 2 * pi, pi & 3, 8 * cb + 2 * pi):
                 if isinstance(op, tuple):
                     A.ds(op[1], op[2])
                 else:
@@ -447,10 +507,11 @@ def gen_only(A, bn, xs_vgpr, eo):
         A.drain()
         for i in range(4):
             A.e(pack_op(bn, cb, i, 8 * cb + 2 * i)[1])
+    first_nibble(A, "FLGN", t(20))                                # nib(0) of the first tile's token, >> 2 * (w & 1)
     for cb in range(2):
         lab = A.new("Lfix")
-        A.e(f"v_cmp_lt_f32 vcc, {t(11)}, {v('DM', cb)}")
-        A.e(f"s_cbranch_vccz {lab}_%=")
+        A.e(f"s_bitcmp0_b32 {t(20)}, {cb}")
+        A.e(f"s_cbranch_scc1 {lab}_%=")
         fix_chunk(A, cb, bn, xs_vgpr, eo)
         A.label(lab)
 
@@ -466,7 +527,7 @@ def unit(A, h, bc, bn, xs_vgpr, eo, cold_blocks):
     pend_packs = []
     for cb in range(2):
         for pi in range(4):
-            ops = gen_pair_ops(cb, 2 * pi, pi & 1, 8 * cb + 2 * pi, pi == 0)
+            ops = gen_pair_ops(cb, 2 * pi, pi & 3, 8 * cb + 2 * pi)
             if cb == 0 and pi == 0:
                 ops.insert(0, ("waitfor", "l1"))
             fill.extend(ops)
@@ -526,8 +587,8 @@ def unit(A, h, bc, bn, xs_vgpr, eo, cold_blocks):
         if os.environ.get("FUSED_NOCOLD"):
             continue
         lab = A.new("Lcold")
-        A.e(f"v_cmp_lt_f32 vcc, {t(11)}, {v('DM', cb)}")
-        A.e(f"s_cbranch_vccnz {lab}_%=")
+        A.e(f"s_bitcmp1_b32 {t(20)}, {4 * h + cb}")                 # k_tie_flags: unit h of this step, candidate block cb
+        A.e(f"s_cbranch_scc1 {lab}_%=")
         A.label(lab + "r")
         cold_blocks.append((lab, cb, bn, xs_vgpr, eo, list(A.fifo)))
 
@@ -589,6 +650,14 @@ def epilogue(A):
 
 def tile_setup(A):
     """epilogue operands of the compute tile -> LDS; accumulators zeroed.  Uses the compute cursor (c_tile)."""
+    A.c("tile: near-tie flag rows (this tile's = the one fetched during the previous tile; fetch the next tile's)")
+    A.e(f"v_mov_b32 {v('FLGC')}, {v('FLGN')}")
+    A.e(f"s_add_i32 {t(5)}, {s('c_pair')}, {s('dpair')}")
+    A.e(f"s_add_i32 {t(6)}, {s('c_rt')}, {s('drt')}")
+    A.e(f"s_cmp_ge_u32 {t(6)}, {s('n_rt')}")
+    A.e(f"s_cselect_b32 {t(6)}, 1, 0")
+    A.e(f"s_add_i32 {t(5)}, {t(5)}, {t(6)}")                        # token pair of the next tile of this workgroup
+    load_flag_row(A, t(5))
     A.c("tile: m0, tok0, staging of ref - row_bias and row_scale, zero accumulators")
     # (pair, rt) of the compute tile are kept incrementally (c_pair, c_rt), like the issue cursors
     A.e(f"s_mov_b32 {t(0)}, {s('c_pair')}")
@@ -714,6 +783,7 @@ def tile_setup(A):
     for r in range(128, 128 + 16 * 2 * (NRB - NA)):
         A.e(f"v_mov_b32 v{r}, 0")
     A.e("s_nop 4")
+    rotate_flags(A)
 
 
 SUB = int(os.environ.get("FUSED_SUB", "99"))            # debugging of tile_setup: 0 no loads, 1 ref, 2 + row_bias, 3 + row_scale
@@ -737,6 +807,7 @@ def program():
     A.e(f"s_mov_b32 {s('c_rt')}, {s('rt0')}")
     set_x_rsrc(A)
     set_a_rows(A)
+    load_flag_row(A, s('pair0'))                                    # first tile's near-tie flags (waited with the first DMAs)
     A.c("prologue: x/log2 of step 0, then weights of steps 0..FNS-2 with the x/log2 of the following step")
     issue_x(A, x_slot_base(0))
     for s0 in range(FNS - 1):
@@ -751,16 +822,24 @@ def program():
     if STAGE <= 2:
         A.e("s_branch Lend_%=")
 
+    if PROF:
+        for r in PV.values():
+            A.e(f"v_mov_b32 v{r}, 0")
+        A.e(f"s_memtime s[{T0 + 14}:{T0 + 15}]")
+        A.e("s_waitcnt lgkmcnt(0)")
+        A.e(f"s_mov_b32 {t(18)}, {t(14)}")
     A.label("Ltile")
     tile_setup(A)
     if STAGE <= 3:
         A.e("s_branch Lend_%=")
     A.e(f"s_mov_b32 {s('kt')}, {s('nk')}")
     A.label("Lstep")
+    stamp(A, "P3")
     cold = []
     A.e(f"s_waitcnt vmcnt({(FNS - 2) * (NRB // 2 + 2)})")
     if not os.environ.get("FUSED_NOBAR"):
         A.e("s_barrier")
+    stamp(A, "P0")
     # ring addresses of this step
     A.e(f"s_mul_i32 {t(0)}, {s('stA')}, {AT}")
     A.e(f"s_add_i32 {t(0)}, {t(0)}, {s('oRing')}")
@@ -774,6 +853,7 @@ def program():
     A.e(f"s_lshl_b32 {t(3)}, {t(2)}, 11")
     A.e(f"v_add_u32 {v('XSN')}, {t(3)}, {v('XOFF')}")
     A.e(f"s_mov_b32 {t(19)}, {t(2)}")                              # keep the next x slot
+    step_flags(A)
     # DMA for step n + FNS - 1 (weights -> the slot step n - 1 used) and n + FNS (x/log2 -> the x slot step n - 1 used)
     A.e(f"s_add_i32 {t(4)}, {s('stA')}, {FNS - 1}")
     A.e(f"s_cmp_ge_u32 {t(4)}, {FNS}")
@@ -786,8 +866,10 @@ def program():
     A.e(f"s_sub_i32 {t(4)}, {t(4)}, {t(5)}")
     issue_x(A, x_slot_base(t(4)))
     unit(A, 0, "BA", "BB", v("XSC"), 16, cold)
+    stamp(A, "P1")
     unit(A, 1, "BB", "BA", v("XSN"), 0, cold)
     A.drain()
+    stamp(A, "P2")
     # advance the ring slots
     A.e(f"s_add_i32 {s('stA')}, {s('stA')}, 1")
     A.e(f"s_cmp_eq_u32 {s('stA')}, {FNS}")
@@ -834,6 +916,12 @@ def program():
         A.e("s_branch Ldbgend_%=")
     A.c("per-lane sums -> s_fin[w][64] (lanes 0..31 hold the candidates of both blocks)")
     A.e("s_waitcnt vmcnt(0)")
+    if PROF:
+        A.e(f"v_cmp_gt_u32 vcc, 16, {v('FROW')}")
+        A.e(f"v_cndmask_b32 v60, v{PV['P2']}, v{PV['P0']}, vcc")
+        A.e(f"v_cndmask_b32 v61, v{PV['P3']}, v{PV['P1']}, vcc")
+        A.e(f"v_cvt_f64_u32 v[{V['RUN0']}:{V['RUN0'] + 1}], v60")
+        A.e(f"v_cvt_f64_u32 v[{V['RUN1']}:{V['RUN1'] + 1}], v61")
     A.e(f"s_lshl_b32 {t(0)}, {s('w')}, 9")
     A.e(f"s_add_i32 {t(0)}, {t(0)}, {s('oFin')}")
     A.e(f"v_lshl_add_u32 v60, {v('FROW')}, 3, {t(0)}")

@@ -15,7 +15,7 @@ with torch.no_grad():
     fold = be.shift_fold(rowsum.view(1, -1), lay.w_quantizer.scale.data.view(1, -1), aq.shift.data, lay.bias.data).view(-1)
     x2 = lay._x2(); lx = lay._log2_x(); ref = lay.raw_out.reshape(-1, 384)
     lib = _lib.load()
-    nb = lib.adalog_score_act_fused_workspace_bytes()
+    nb = lib.adalog_score_act_fused_workspace_bytes(T, Kp)
     ws = torch.zeros(nb // 8, dtype=torch.float64, device="cuda")
     scores = torch.empty(128, device="cuda")
     rs = lay.w_quantizer.scale.data.view(-1).contiguous()
