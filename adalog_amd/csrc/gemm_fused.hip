@@ -62,14 +62,12 @@ struct FusedArgs {
     const float* qv;           // [128]   candidate bases q_p (as floats)
     const float* mant;         // [37]    integer numerators of the search-time mantissa table (linear.py:750-752)
     const float* thr;          // [levels2][128] break points of the exact pipeline (k_tie_thresholds)
-    const uint8_t* flags;      // [T][fpitch] near-tie flags of the hand-scheduled form (k_tie_flags); null for the compiler form
     double* wg_acc;            // [gridDim.x][128]
     int M, T, K;
     int Kb;                    // row pitch of W in bytes (multiple of 128)
     int levels2;               // 2^bits
     int n_rt;                  // row tiles of 32 * NRB rows
     int nk;                    // 64-byte K-steps
-    int fpitch;                // bytes per token row of `flags`
     float shift, sa_mul;
 };
 
@@ -129,58 +127,6 @@ __global__ __launch_bounds__(128) void k_tie_thresholds(const float* __restrict_
         out = __uint_as_float(hi);
     }
     thr[b * 128 + pc] = out;
-}
-
-// Near-tie flags for the hand-scheduled form.  The main loop generates the B fragments of one K half (16 k) per "unit":
-// half-step j = 2 * step + half of a token.  nib(j) has bit blk (0..3) set when any of the 16 x 32 element-candidates of
-// candidate block blk (candidates 32 blk .. 32 blk + 31) lies within the near-tie zone of its fast bin -- evaluated with
-// exactly the fast arithmetic of the main loop (same fma / clamp / round), so the main loop needs no detection of its own.
-// Row of token t (fpitch bytes):  byte n < nk : nib(2n + 1) | nib(2n + 2) << 4  (the two units of main-loop step n;
-// nib(2 nk) = 0, patched in the kernel with the next tile's first nibble);  byte nk : nib(0).
-// One wave per token; a lane owns candidates lane and lane + 64; the log2 values arrive as scalar loads.
-__global__ __launch_bounds__(256) void k_tie_flags(const float* __restrict__ L, const float* __restrict__ scale,
-                                                   const float* __restrict__ qv, int levels2, int T, int K, int nk, int fpitch,
-                                                   float tie, uint8_t* __restrict__ flags) {
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float pa[2], pc[2], ph[2];
-#pragma unroll
-    for (int sidx = 0; sidx < 2; ++sidx) {
-        const float s = scale[lane + 64 * sidx], qf = qv[lane + 64 * sidx];
-        const float rq37 = 37.0f / qf;
-        const float top = (float)levels2 + 0.75f, NL15 = 49.828921f;
-        pa[sidx] = -rq37; pc[sidx] = __log2f(s) * rq37; ph[sidx] = fminf(NL15 * rq37, top);      // as s_par in the main kernels
-    }
-    for (int tok = blockIdx.x * 4 + w; tok < T; tok += gridDim.x * 4) {
-        const float* __restrict__ Lr = L + (int64_t)tok * K;
-        uint8_t* __restrict__ row = flags + (int64_t)tok * fpitch;
-        unsigned prev_odd = 0;
-        for (int n = 0; n < nk; ++n) {
-            unsigned nib[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                float dm0 = 0.0f, dm1 = 0.0f;
-                const int k0 = n * 32 + h * 16;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float l = (k0 + e < K) ? Lr[k0 + e] : 0.0f;
-                    const float kf0 = __builtin_amdgcn_fmed3f(__builtin_fmaf(l, pa[0], pc[0]), 0.0f, ph[0]);
-                    const float kf1 = __builtin_amdgcn_fmed3f(__builtin_fmaf(l, pa[1], pc[1]), 0.0f, ph[1]);
-                    dm0 = fmaxf(dm0, fabsf(kf0 - __builtin_rintf(kf0)));
-                    dm1 = fmaxf(dm1, fabsf(kf1 - __builtin_rintf(kf1)));
-                }
-                const unsigned long long m0 = __ballot(dm0 > tie), m1 = __ballot(dm1 > tie);
-                nib[h] = ((unsigned)m0 != 0u ? 1u : 0u) | ((unsigned)(m0 >> 32) != 0u ? 2u : 0u) |
-                         ((unsigned)m1 != 0u ? 4u : 0u) | ((unsigned)(m1 >> 32) != 0u ? 8u : 0u);
-            }
-            if (lane == 0) {
-                if (n == 0) row[nk] = (uint8_t)nib[0];
-                else row[n - 1] = (uint8_t)(prev_odd | (nib[0] << 4));
-            }
-            prev_odd = nib[1];
-        }
-        if (lane == 0) row[nk - 1] = (uint8_t)prev_odd;
-    }
 }
 
 template <int NRB, int FNS>
@@ -470,11 +416,12 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------- hand-scheduled form
-// Same algorithm, same LDS tables, same results as k_act_fused<12, 4>; the persistent loop (DMA ring, fragment generation,
-// MFMA stream, threshold fix-ups, epilogue) is the generated asm of tools/gen_fused_asm.py (fused_loop_nrb12.inc):
-// 24 accumulator tiles per wave (16 in AGPRs, 8 in v128..v255), A fragments read two row blocks ahead, ~6 generation
-// instructions per MFMA.  The HIP part builds the tables, passes the scalars through an LDS config array (the block
-// clobbers every VGPR / AGPR and s8..s99) and writes the workgroup's row of sums.
+// Same algorithm, same LDS tables, same results as k_act_fused<NRB, FNS>; the persistent loop (DMA ring, fragment
+// generation, MFMA stream, threshold fix-ups, epilogue) is the generated asm of tools/gen_fused_asm.py
+// (fused_loop_nrb*.inc): EIGHT waves per workgroup, two per SIMD (256 registers each: accumulator tiles in a0..a127
+// and v64..v127, 64 working VGPRs), wave = (token of the pair, candidate block of 32); see the generator's header for the machine model behind
+// that shape.  The HIP part builds the tables, passes the scalars through an LDS config array (the block clobbers
+// v0..v127, a0..a127 and s8..s99) and writes the workgroup's row of sums.
 #define FUSED_ASM_CLOBBERS \
     "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", \
     "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", \
@@ -484,39 +431,21 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
     "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", \
     "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", \
     "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", \
-    "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", \
-    "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", \
-    "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", \
-    "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", \
-    "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", \
-    "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", \
-    "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", \
-    "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", \
-    "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", \
-    "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", \
-    "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", \
-    "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", \
-    "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", \
-    "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", \
-    "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", \
-    "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", \
-    "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", \
-    "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", \
-    "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", \
-    "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", \
-    "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
-    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", \
-    "a190", "a191", "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", \
-    "a204", "a205", "a206", "a207", "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", \
-    "a218", "a219", "a220", "a221", "a222", "a223", "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", \
-    "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", "a240", "a241", "a242", "a243", "a244", "a245", \
-    "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255", "s8", "s9", "s10", "s11", \
-    "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", \
-    "s28", "s29", "s30", "s31", "s34", "s35", "s36", "s37", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", \
-    "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", \
-    "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", \
-    "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", \
-    "s95", "s96", "s97", "s98", "s99", "vcc", "scc", "m0", "memory"
+    "v125", "v126", "v127", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", \
+    "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", \
+    "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", \
+    "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", \
+    "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", \
+    "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", \
+    "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", \
+    "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", \
+    "a122", "a123", "a124", "a125", "a126", "a127", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", \
+    "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s34", \
+    "s35", "s36", "s37", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", \
+    "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", \
+    "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", \
+    "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99", \
+    "vcc", "scc", "m0", "memory"
 
 #define KNAME k_act_fused_asm_12_4
 #define KNRB 12
@@ -540,15 +469,6 @@ __global__ __launch_bounds__(256, 1) void k_act_fused(FusedArgs p) {
 #define KNRB 8
 #define KFNS 4
 #define KINC "fused_loop_nrb8_s4.inc"
-#include "fused_asm_kernel.inc"
-#undef KNAME
-#undef KNRB
-#undef KFNS
-#undef KINC
-#define KNAME k_act_fused_asm_6_4
-#define KNRB 6
-#define KFNS 4
-#define KINC "fused_loop_nrb6_s4.inc"
 #include "fused_asm_kernel.inc"
 #undef KNAME
 #undef KNRB
@@ -604,11 +524,19 @@ static int fused_cus() {
     return n_cu;
 }
 
+static bool fused_use_asm() {
+    static const int use_asm = getenv("ADALOG_FUSED_ASM") ? atoi(getenv("ADALOG_FUSED_ASM")) : 1;
+    return use_asm != 0;
+}
+
+// row blocks per tile: least padding of M; the hand-scheduled loops exist for 12, 8 and 4 (its eight waves split the
+// weight requests four ways), the compiler form also for 6
 static int pick_nrb(int M) {
     const int cand[4] = {12, 8, 6, 4};
     int best = 12;
     int64_t best_pad = -1;
     for (int i = 0; i < 4; ++i) {
+        if (cand[i] == 6 && fused_use_asm()) continue;
         const int rows = 32 * cand[i];
         const int64_t pad = (int64_t)((M + rows - 1) / rows) * rows;
         if (best_pad < 0 || pad < best_pad) { best_pad = pad; best = cand[i]; }
@@ -646,11 +574,10 @@ extern "C" int adalog_score_act_fused_ok(int M, int64_t T, int K, int64_t Kp, in
     return fused_lds_bytes(nrb, pick_fns(nrb, 1 << n_bits), 1 << n_bits) <= 160 * 1024 ? 1 : 0;
 }
 
-static int64_t fused_flag_pitch(int64_t Kp) { return ((Kp * 2 / 64 + 1) + 3) & ~(int64_t)3; }
-
-// [workgroups][128] fp64 partial sums, the [2^6][128] fp32 threshold table, then the [T][pitch] near-tie flag bytes
+// [workgroups][128] fp64 partial sums, then the [2^6][128] fp32 threshold table (T, Kp: the call's shape; reserved)
 extern "C" int64_t adalog_score_act_fused_workspace_bytes(int64_t T, int64_t Kp) {
-    return (int64_t)fused_cus() * 128 * 8 + 64 * 128 * 4 + T * fused_flag_pitch(Kp) + 64;
+    (void)T; (void)Kp;
+    return (int64_t)fused_cus() * 128 * 8 + 64 * 128 * 4;
 }
 
 // scores[p] = -norm * sum_{t, o} ( (ref[t, o] - row_bias[o]) - s_w[o] * (s_p * sa_mul) * sum_k Wq[o, k] * m_p(x[t, k]) )^2
@@ -674,8 +601,6 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
     a.nk = (int)(Kp * 2 / 64); a.shift = shift; a.sa_mul = sa_mul;
     float* thr = reinterpret_cast<float*>((uint8_t*)workspace + (size_t)fused_cus() * 128 * 8);
     a.thr = thr;
-    uint8_t* flags = reinterpret_cast<uint8_t*>(thr + 64 * 128);
-    a.fpitch = (int)fused_flag_pitch(Kp);
     const int nrb = pick_nrb(M);
     const int fns = pick_fns(nrb, a.levels2);
     a.n_rt = (M + 32 * nrb - 1) / (32 * nrb);
@@ -697,17 +622,8 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
         hipLaunchKernelGGL((k_act_fused<NRBV, FNSV>), dim3((unsigned)nwg), dim3(256), shm, st, a);             \
     } while (0)
 #define LAUNCH_FUSED_N(NRBV) do { if (fns == 4) LAUNCH_FUSED(NRBV, 4); else LAUNCH_FUSED(NRBV, 3); } while (0)
-    static const int use_asm = getenv("ADALOG_FUSED_ASM") ? atoi(getenv("ADALOG_FUSED_ASM")) : 1;
+    const bool use_asm = fused_use_asm();
     const size_t shm_asm = 256 + shm;
-    if (use_asm && shm_asm <= 160 * 1024) {
-        // near-tie flags of this call's candidates (the hand-scheduled loop has no detection of its own)
-        const float tie = a.levels2 <= 16 ? 0.499975f : 0.49995f;
-        const int tb = (int)((T + 3) / 4);
-        a.flags = flags;
-        hipLaunchKernelGGL(k_tie_flags, dim3((unsigned)(tb < 4096 ? tb : 4096)), dim3(256), 0, st, Lx, scale, qv, a.levels2, (int)T, K,
-                           a.nk, a.fpitch, tie, flags);
-        ADALOG_LAUNCH_CHECK("adalog_score_act_fused (near-tie flags)");
-    }
 #define LAUNCH_ASM(KERNEL, TAG)                                                                                 \
     do {                                                                                                       \
         static bool attr_set = false;                                                                          \
@@ -716,13 +632,12 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
             attr_set = true;                                                                                   \
         }                                                                                                      \
         adalog_note_kernel(TAG);                                                                               \
-        hipLaunchKernelGGL(KERNEL, dim3((unsigned)nwg), dim3(256), shm_asm, st, a);                            \
+        hipLaunchKernelGGL(KERNEL, dim3((unsigned)nwg), dim3(512), shm_asm, st, a);                            \
     } while (0)
     if (use_asm && shm_asm <= 160 * 1024) {
         if (nrb == 12 && fns == 4) LAUNCH_ASM(k_act_fused_asm_12_4, "k_act_fused_asm<12,4,bf16>");
         else if (nrb == 12) LAUNCH_ASM(k_act_fused_asm_12_3, "k_act_fused_asm<12,3,bf16>");
         else if (nrb == 8) LAUNCH_ASM(k_act_fused_asm_8_4, "k_act_fused_asm<8,4,bf16>");
-        else if (nrb == 6) LAUNCH_ASM(k_act_fused_asm_6_4, "k_act_fused_asm<6,4,bf16>");
         else LAUNCH_ASM(k_act_fused_asm_4_4, "k_act_fused_asm<4,4,bf16>");
     } else if (nrb == 12) LAUNCH_FUSED_N(12);
     else if (nrb == 8) LAUNCH_FUSED_N(8);

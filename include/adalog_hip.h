@@ -139,8 +139,8 @@ int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, i
  * corrected), but the [T*P][K] candidate operand is never written: HBM traffic = Lx + ref + Wp.
  *   Wp: bf16 image of the quantised weight, [M][Kp] (adalog_pack_uniform, out_dtype 1);  x: [T][K] fp32;
  *   Lx = adalog_log2_shift(x, shift): [T][K] fp32, correctly rounded log2(x + shift), -inf where x + shift <= 0;
- *   ref: raw_out [T][M];  workspace: adalog_score_act_fused_workspace_bytes(T, Kp) bytes, 8-byte aligned (partial sums,
- *   the threshold table, and one near-tie flag byte per token and K-step written by a pre-pass over Lx).
+ *   ref: raw_out [T][M];  workspace: adalog_score_act_fused_workspace_bytes(T, Kp) bytes, 8-byte aligned (partial sums and
+ *   the threshold table).
  * adalog_score_act_fused_ok: 1 when the shape is taken (P = 128, n_bits <= 6, >= 6 K-steps of 32, LDS budget), else the
  * caller uses the packed path. */
 int adalog_log2_shift(const float* x, float* out, int64_t n, float shift, void* stream);

@@ -2,45 +2,58 @@
 """Generator of the hand-scheduled CDNA4 (gfx950) main loop of the fused activation-search kernel (gemm_fused.hip).
 
     FUSED_NRB=12 FUSED_FNS=4 python tools/gen_fused_asm.py   -> adalog_amd/csrc/fused_loop_nrb12_s4.inc  (+ .lst, a listing)
-    tools/gen_fused_asm_all.sh                               -> the five variants the library ships
+    tools/gen_fused_asm_all.sh                               -> the variants the library ships
 
-Why a generator: the compiler keeps at most 256 accumulator registers per wave (one MFMA form per function), reads every
-A fragment right in front of its MFMAs (exposed LDS latency) and cannot be steered into interleaving the fragment
-generation with the matrix stream.  Here every register is placed by hand -- 16 accumulator tiles in AGPRs, 8 in
-v128..v255, everything else below v128 -- and the issue order of one K-step is laid out explicitly: per MFMA about seven
-other instructions (VALU of the fragment generation, LUT / fragment reads two MFMA pairs ahead, DMA requests), with
-counted s_waitcnt lgkmcnt from a model of the in-order LDS queue.
+Why a generator: the loop needs every register placed by hand and the issue order of a K-step laid out explicitly (the
+compiler reads each A fragment right in front of its MFMA and cannot be steered into interleaving the fragment
+generation with the matrix stream).
 
-The text is one inline-asm block (all VGPRs / AGPRs and s8..s99 clobbered); the HIP kernel around it builds the LDS
+Machine model the layout follows (tools/lab/overlap_probe: measured on MI355X):
+  * v_mfma_f32_32x32x16_bf16 keeps the SIMD's vector issue port for 16 of its 32 cycles, for EVERY wave of the SIMD: per
+    MFMA only ~4 VALU instructions (4 cycles each) are free, a second wave does not add VALU throughput;
+  * an LDS instruction costs the issuing wave ~6 cycles; with two waves on the SIMD about half of that overlaps;
+  * a single wave per SIMD exposes every LDS round trip, the barrier skew and the near-tie blocks of any one wave to
+    the whole workgroup (round-2 first form: 4 waves x 24 tiles, ~900 of 3100 cycles per K-step were such stalls).
+Hence EIGHT waves per workgroup, two per SIMD, 256 registers each: wave w owns token (w >> 2) of the tile's pair and
+candidate block (w & 3): NRB accumulator tiles of 32 x 32 (eight in a0..a127, four in v64..v127: the compiler splits a
+256-register wave 128 + 128) and 64 VGPRs for everything else.  Per K-step and wave: 2 x NRB MFMAs, the 16 element-candidates of its B fragments per K half
+(fma, med3, add, shift-add, LUT read, three more VALU for the near-tie test; two values pack into a dword), 2 x NRB
+A-fragment reads three row blocks ahead,
+NRB / 4 + 1 LDS-DMA requests, counted s_waitcnt from a model of the in-order LDS queue, one barrier.
+
+Near-ties: each generated element adds |kf - rne(kf)| to a running maximum (3 more VALU per element); one compare per
+unit branches to a cold block that re-derives the chunk's bins from the threshold table.  (A pre-pass that marked the
+near-tie chunks per token and K half, leaving the loop without detection, was measured: loop 0.82 ms + pre-pass 0.17 ms
+against 0.89 ms with the detection inside -- the loop is bound by latency, not by its VALU count.)
+
+The text is one inline-asm block (v0..v127, a0..a127 and s8..s99 clobbered); the HIP kernel around it builds the LDS
 tables, hands the scalars over through an LDS config array and turns the per-lane sums into the workgroup's output row.
 See gemm_fused.hip for the algorithm; names here follow it.
 """
 import os
-import sys
+import re
 
-NRB = int(os.environ.get("FUSED_NRB", "12"))      # row blocks of 32 output channels per tile (12, 8, 6 or 4)
+NRB = int(os.environ.get("FUSED_NRB", "12"))      # row blocks of 32 output channels per tile (12, 8 or 4)
 FNS = int(os.environ.get("FUSED_FNS", "4"))       # weight-ring stages (3 where the 6-bit tables need the LDS)
+NW = 8            # waves per workgroup
 XS = FNS + 1      # x / log2 ring slots
+XSLOT = 2048      # bytes reserved per x-ring slot (512 used: [token][x 128 B | log2 128 B])
 AT = NRB * 2048   # weight tile bytes per stage
 ROWS = 32 * NRB
-NA = min(NRB, 8)  # row blocks whose tiles live in AGPRs (2 tiles each); the rest sit in v128..
+RQ = NRB // 4     # weight DMA requests (16 rows x 64 B) per wave and K-step
+assert NRB % 4 == 0 and NRB <= 12
 MAGIC = 0x4B400000
-TIE_BITS = 0x3EFFF2E5   # 0.4999f
-# (v_pk_fma/add_f32 for the pairwise arithmetic was measured 22 % SLOWER beside the MFMAs: not generated any more)
 
 # ---------------------------------------------------------------- config array in LDS (dword indices), written by the kernel
 CFG = ["pW_lo", "pW_hi", "pX_lo", "pX_hi", "pL_lo", "pL_hi", "pRef_lo", "pRef_hi", "pRs_lo", "pRs_hi", "pRb_lo", "pRb_hi",
        "M", "T", "K", "Kb", "nk", "n_rt", "ntile", "nwg", "bid", "L2", "shift", "w",
-       "oRing", "oXr", "oLut", "oThr", "oPar", "oRefb", "oRs", "oFin", "dpair", "drt", "pair0", "rt0", "tie",
-       "pF_lo", "pF_hi", "fpitch"]
-S = {n: 40 + i for i, n in enumerate(CFG)}          # s40 .. s75
-S["tie"] = 27                                        # = t(19)'s old home is s27: see below (TIE lives in s19)
-S.update(rW=76, rX=80, rL=84,                        # buffer resources (4 SGPRs each)
+       "oRing", "oXr", "oLut", "oThr", "oPar", "oRefb", "oRs", "oFin", "dpair", "drt", "pair0", "rt0", "tie"]
+S = {n: 40 + i for i, n in enumerate(CFG)}          # s40 .. s75 (+ overrides below)
+S.update(tie=19, cblk=37)
+S.update(rW=76, rX=80, xw=84, aw=85,                 # buffer resources (4 SGPRs each); per-wave ring offsets
          a_tile=88, a_pair=89, a_rt=90, a_k=91, l_tile=92, l_pair=93, l_rt=94, l_k=95,
          c_tile=96, kt=97, stA=98, stX=99, c_pair=30, c_rt=31)
-S["tie"] = 19                                        # t(11): the near-tie threshold, loaded from the config
-S.update(pF_lo=34, pF_hi=35, fpitch=36, sh2=37)      # near-tie flag rows (k_tie_flags); sh2 = 2 * (w & 1)
-T0 = 8                                               # s8 .. s31: temporaries
+T0 = 8                                               # s8 .. s29: temporaries (s30, s31: compute cursor)
 
 
 def s(name):
@@ -55,10 +68,10 @@ def t2(i):
     return f"s[{T0 + i}:{T0 + i + 1}]"
 
 
-# ---------------------------------------------------------------- VGPR map
-V = dict(LANE=0, FROW=1, FKG=2, TMP=3, PAR0=4, PAR1=8, LUTC0=12, LUTC1=13, THRC0=14, THRC1=15, AOFF0=16, AOFF1=17, AS0=18, AS1=19,
-         XOFF=20, XSC=21, XSN=22, XDMA=23, DMA=24, EPI=30, EPR=31, XORA=32, LUTB0=33, LUTB1=34, ZERO=35, RUN0=36, RUN1=38,
-         BA=40, BB=48, LV=56, ABUF=64, VAL=84, GT=100, FLGC=116, FLGN=117, XV=120, E0=64, )
+# ---------------------------------------------------------------- VGPR map (64 registers)
+V = dict(LANE=0, FROW=1, FKG=2, PAR=4, LUTC=8, THRC=9, LUTB=10, AOFF0=11, AOFF1=12, AS0=13, AS1=14, XOFF=15, XSC=16, XSN=17,
+         XDMA=18, DMA=19, DX=22, DM=23, RUN=24, BA=26, BB=30, LV=34, ABUF=42, VAL=58, GT=62,
+         TV=42)      # TV: 16 scratch registers shared with the A buffers (dead outside the MFMA stream)
 CA, CC, CHI, AL = 0, 1, 2, 3
 
 
@@ -71,20 +84,15 @@ def vr(name, off, n):
     return f"v[{a}:{a + n - 1}]"
 
 
-def acc(rb, cb):
-    """register operand of accumulator tile (rb, cb)"""
-    tix = rb * 2 + cb
+NA = min(NRB, 8)   # accumulator tiles in AGPRs (a0..a127); the compiler splits a 256-register wave 128 + 128, so tiles
+                   # 8..11 live in v64..v127
+
+
+def acc(rb):
     if rb < NA:
-        return f"a[{16 * tix}:{16 * tix + 15}]"
-    b = 128 + 16 * (tix - 2 * NA)
+        return f"a[{16 * rb}:{16 * rb + 15}]"
+    b = 64 + 16 * (rb - NA)
     return f"v[{b}:{b + 15}]"
-
-
-def acc_elem(rb, cb, i):
-    tix = rb * 2 + cb
-    if rb < NA:
-        return ("a", 16 * tix + i)
-    return ("v", 128 + 16 * (tix - 2 * NA) + i)
 
 
 class Asm:
@@ -143,52 +151,47 @@ def cfg_load(A):
 
 
 def lane_setup(A):
-    A.c("lane geometry")
+    A.c("lane geometry: wave w = (token w >> 2 of the pair, candidate block w & 3); lane = (frow = candidate, fkg = k group)")
     A.e(f"v_and_b32 {v('FROW')}, 31, {v('LANE')}")
     A.e(f"v_lshrrev_b32 {v('FKG')}, 5, {v('LANE')}")
-    A.e(f"v_mov_b32 {v('ZERO')}, 0")
-    A.e(f"s_lshr_b32 {t(0)}, {s('w')}, 1")                       # wtok
-    A.e(f"s_and_b32 {t(1)}, {s('w')}, 1")                        # cbp
-    # candidate index c0 = 64*cbp + frow ; c1 = c0 + 32
-    A.e(f"s_lshl_b32 {t(2)}, {t(1)}, 6")
-    A.e(f"v_add_u32 v3, {t(2)}, {v('FROW')}")                    # c0
+    A.e(f"s_lshr_b32 {t(0)}, {s('w')}, 2")                       # wtok
+    A.e(f"s_and_b32 {s('cblk')}, {s('w')}, 3")
+    A.e(f"s_lshl_b32 {t(2)}, {s('cblk')}, 5")
+    A.e(f"v_add_u32 v3, {t(2)}, {v('FROW')}")                    # candidate index c
     # parameters {-37/q, log2(s)*37/q, hi, s*sa_mul}: float4 at oPar + c*16
-    A.e(f"v_lshl_add_u32 v60, v3, 4, {s('oPar')}")
-    A.ds(f"ds_read_b128 {vr('PAR0', 0, 4)}, v60", "p0")
-    A.ds(f"ds_read_b128 {vr('PAR1', 0, 4)}, v60 offset:512", "p1")
+    A.e(f"v_lshl_add_u32 {v('TV')}, v3, 4, {s('oPar')}")
+    A.ds(f"ds_read_b128 {vr('PAR', 0, 4)}, {v('TV')}", "p0")
     # LUT / threshold lane bases
-    A.e(f"v_lshl_add_u32 {v('LUTB0')}, v3, 2, {s('oLut')}")
-    A.e(f"v_add_u32 {v('LUTB1')}, 128, {v('LUTB0')}")
+    A.e(f"v_lshl_add_u32 {v('LUTB')}, v3, 2, {s('oLut')}")
     A.e(f"s_mov_b32 {t(3)}, 0x{(-(MAGIC << 9)) & 0xFFFFFFFF:08x}")
-    A.e(f"v_add_u32 {v('LUTC0')}, {t(3)}, {v('LUTB0')}")
-    A.e(f"v_add_u32 {v('LUTC1')}, {t(3)}, {v('LUTB1')}")
-    A.e(f"v_lshl_add_u32 {v('THRC0')}, v3, 2, {s('oThr')}")
-    A.e(f"v_add_u32 {v('THRC1')}, 128, {v('THRC0')}")
+    A.e(f"v_add_u32 {v('LUTC')}, {t(3)}, {v('LUTB')}")
+    A.e(f"v_lshl_add_u32 {v('THRC')}, v3, 2, {s('oThr')}")
     # A fragment lane offsets: frow*64 + (((2h + fkg) ^ ((frow >> 2) & 3)) << 4)
-    A.e(f"v_lshrrev_b32 v60, 2, {v('FROW')}")
-    A.e("v_and_b32 v60, 3, v60")                                   # sw
-    A.e(f"v_xor_b32 v61, {v('FKG')}, v60")                         # h = 0: fkg ^ sw
-    A.e(f"v_lshlrev_b32 v62, 6, {v('FROW')}")
-    A.e(f"v_lshl_add_u32 {v('AOFF0')}, v61, 4, v62")
-    A.e("v_xor_b32 v61, 2, v61")                                   # h = 1: (2 + fkg) ^ sw = (fkg ^ sw) ^ 2
-    A.e(f"v_lshl_add_u32 {v('AOFF1')}, v61, 4, v62")
-    # x / log2 read offset inside the wave's 512-byte slot part: fkg * 32 bytes (+256 for log2)
-    A.e(f"s_lshl_b32 {t(4)}, {s('w')}, 9")
-    A.e(f"s_add_i32 {t(4)}, {t(4)}, {s('oXr')}")
-    A.e(f"v_lshl_add_u32 {v('XOFF')}, {v('FKG')}, 5, {t(4)}")
-    # x / log2 DMA voffset: (wtok * K + lane) * 4
+    A.e(f"v_lshrrev_b32 {v('TV', 1)}, 2, {v('FROW')}")
+    A.e(f"v_and_b32 {v('TV', 1)}, 3, {v('TV', 1)}")               # sw
+    A.e(f"v_xor_b32 {v('TV', 2)}, {v('FKG')}, {v('TV', 1)}")      # h = 0: fkg ^ sw
+    A.e(f"v_lshlrev_b32 {v('TV', 3)}, 6, {v('FROW')}")
+    A.e(f"v_lshl_add_u32 {v('AOFF0')}, {v('TV', 2)}, 4, {v('TV', 3)}")
+    A.e(f"v_xor_b32 {v('TV', 2)}, 2, {v('TV', 2)}")               # h = 1: (2 + fkg) ^ sw = (fkg ^ sw) ^ 2
+    A.e(f"v_lshl_add_u32 {v('AOFF1')}, {v('TV', 2)}, 4, {v('TV', 3)}")
+    # ring offsets of this wave: x slot part (token, array, half) and weight requests
+    A.e(f"s_lshl_b32 {s('xw')}, {t(0)}, 8")                       # wtok * 256
+    A.e(f"s_lshl_b32 {t(4)}, {s('cblk')}, 6")                     # (array, half) = cblk: 64 bytes each
+    A.e(f"s_add_i32 {t(4)}, {t(4)}, {s('xw')}")
+    A.e(f"s_mul_i32 {s('aw')}, {s('w')}, {RQ * 1024}")
+    # x / log2 read offset inside a slot: token part + fkg * 32 bytes (log2 run at +128)
+    A.e(f"s_add_i32 {t(5)}, {s('xw')}, {s('oXr')}")
+    A.e(f"v_lshl_add_u32 {v('XOFF')}, {v('FKG')}, 5, {t(5)}")
+    A.e(f"s_mov_b32 {s('xw')}, {t(4)}")                           # xw = DMA destination part of this wave inside a slot
+    # x / log2 DMA voffset: (wtok * K + half * 16 + lane) * 4   (lanes 0..15 only)
     A.e(f"s_mul_i32 {t(5)}, {t(0)}, {s('K')}")
-    A.e(f"v_add_u32 v60, {t(5)}, {v('LANE')}")
-    A.e(f"v_lshlrev_b32 {v('XDMA')}, 2, v60")
-    # epilogue read bases: refb + wtok*ROWS*4 + fkg*16 ; rs + fkg*16
-    A.e(f"s_mul_i32 {t(5)}, {t(0)}, {ROWS * 4}")
-    A.e(f"s_add_i32 {t(5)}, {t(5)}, {s('oRefb')}")
-    A.e(f"v_lshl_add_u32 {v('EPI')}, {v('FKG')}, 4, {t(5)}")
-    A.e(f"v_lshl_add_u32 {v('EPR')}, {v('FKG')}, 4, {s('oRs')}")
-    A.e(f"v_xor_b32 v60, 32, {v('LANE')}")
-    A.e(f"v_lshlrev_b32 {v('XORA')}, 2, v60")
-    for r in range(4):
-        A.e(f"v_mov_b32 v{V['RUN0'] + r}, 0")
+    A.e(f"s_and_b32 {t(6)}, {s('cblk')}, 1")
+    A.e(f"s_lshl_b32 {t(6)}, {t(6)}, 4")
+    A.e(f"s_add_i32 {t(5)}, {t(5)}, {t(6)}")
+    A.e(f"v_add_u32 {v('TV', 1)}, {t(5)}, {v('LANE')}")
+    A.e(f"v_lshlrev_b32 {v('XDMA')}, 2, {v('TV', 1)}")
+    A.e(f"v_mov_b32 {v('RUN')}, 0")
+    A.e(f"v_mov_b32 {v('RUN', 1)}, 0")
     A.drain()
     # buffer resources: W {ptr, 0 stride, M*Kb records, 0x00020000}
     A.e(f"s_mov_b32 s{S['rW']}, {s('pW_lo')}")
@@ -196,51 +199,46 @@ def lane_setup(A):
     A.e(f"s_mul_i32 s{S['rW'] + 2}, {s('M')}, {s('Kb')}")
     A.e(f"s_mov_b32 s{S['rW'] + 3}, 0x00020000")
     A.e(f"s_mov_b32 s{S['rX'] + 3}, 0x00020000")
-    A.e(f"s_mov_b32 s{S['rL'] + 3}, 0x00020000")
-    A.e(f"s_and_b32 {s('sh2')}, {s('w')}, 1")
-    A.e(f"s_lshl_b32 {s('sh2')}, {s('sh2')}, 1")
-    A.e(f"v_mov_b32 {v('FLGC')}, 0")
-    A.e(f"v_mov_b32 {v('FLGN')}, 0")
 
 
 def set_x_rsrc(A):
-    """x / log2 resources of the L cursor's token pair: base + tok0*K*4, records = min(2, T - tok0)*K*4"""
+    """resource of this wave's run (x or log2: bit 1 of cblk) for the L cursor's token pair: base + tok0*K*4,
+    records = min(2, T - tok0)*K*4"""
     A.e(f"s_lshl_b32 {t(0)}, {s('l_pair')}, 1")                    # tok0
     A.e(f"s_mul_i32 {t(2)}, {t(0)}, {s('K')}")
     A.e(f"s_mul_hi_u32 {t(3)}, {t(0)}, {s('K')}")
     A.e(f"s_lshl_b64 {t2(2)}, {t2(2)}, 2")                         # byte offset (64 bit)
-    A.e(f"s_add_u32 s{S['rX']}, {s('pX_lo')}, {t(2)}")
-    A.e(f"s_addc_u32 {t(4)}, {s('pX_hi')}, {t(3)}")
+    A.e(f"s_bitcmp1_b32 {s('cblk')}, 1")
+    A.e(f"s_cselect_b32 {t(4)}, {s('pL_lo')}, {s('pX_lo')}")
+    A.e(f"s_cselect_b32 {t(5)}, {s('pL_hi')}, {s('pX_hi')}")
+    A.e(f"s_add_u32 s{S['rX']}, {t(4)}, {t(2)}")
+    A.e(f"s_addc_u32 {t(4)}, {t(5)}, {t(3)}")
     A.e(f"s_and_b32 s{S['rX'] + 1}, {t(4)}, 0xffff")
-    A.e(f"s_add_u32 s{S['rL']}, {s('pL_lo')}, {t(2)}")
-    A.e(f"s_addc_u32 {t(4)}, {s('pL_hi')}, {t(3)}")
-    A.e(f"s_and_b32 s{S['rL'] + 1}, {t(4)}, 0xffff")
     A.e(f"s_sub_i32 {t(4)}, {s('T')}, {t(0)}")
     A.e(f"s_min_i32 {t(4)}, {t(4)}, 2")
     A.e(f"s_mul_i32 {t(4)}, {t(4)}, {s('K')}")
-    A.e(f"s_lshl_b32 {t(4)}, {t(4)}, 2")
-    A.e(f"s_mov_b32 s{S['rX'] + 2}, {t(4)}")
-    A.e(f"s_mov_b32 s{S['rL'] + 2}, {t(4)}")
+    A.e(f"s_lshl_b32 s{S['rX'] + 2}, {t(4)}, 2")
 
 
 def set_a_rows(A):
-    """weight DMA voffsets of the A cursor's row tile: min(rt*ROWS + (w + 4q)*16 + lrow, M-1) * Kb + lslot16"""
-    A.e(f"v_lshrrev_b32 v60, 2, {v('LANE')}")                      # lrow
-    A.e(f"v_and_b32 v61, 3, {v('LANE')}")
-    A.e(f"v_lshrrev_b32 v62, 4, {v('LANE')}")
-    A.e("v_and_b32 v62, 3, v62")
-    A.e("v_xor_b32 v61, v61, v62")
-    A.e("v_lshlrev_b32 v61, 4, v61")                               # lslot16
+    """weight DMA voffsets of the A cursor's row tile: min(rt*ROWS + (w*RQ + q)*16 + lrow, M-1) * Kb + lslot16"""
+    a, b, c = v('VAL', 0), v('VAL', 1), v('VAL', 2)              # (runs at a step's top: the A buffers already receive fragments)
+    A.e(f"v_lshrrev_b32 {a}, 2, {v('LANE')}")                      # lrow
+    A.e(f"v_and_b32 {b}, 3, {v('LANE')}")
+    A.e(f"v_lshrrev_b32 {c}, 4, {v('LANE')}")
+    A.e(f"v_and_b32 {c}, 3, {c}")
+    A.e(f"v_xor_b32 {b}, {b}, {c}")
+    A.e(f"v_lshlrev_b32 {b}, 4, {b}")                              # lslot16
     A.e(f"s_mul_i32 {t(0)}, {s('a_rt')}, {ROWS}")
-    A.e(f"s_lshl_b32 {t(1)}, {s('w')}, 4")
+    A.e(f"s_mul_i32 {t(1)}, {s('w')}, {RQ * 16}")
     A.e(f"s_add_i32 {t(0)}, {t(0)}, {t(1)}")
-    A.e(f"v_add_u32 v60, {t(0)}, v60")                             # row of q = 0
+    A.e(f"v_add_u32 {a}, {t(0)}, {a}")                             # row of q = 0
     A.e(f"s_sub_i32 {t(2)}, {s('M')}, 1")
-    for q in range(NRB // 2):
-        A.e(f"v_add_u32 v62, {64 * q}, v60")
-        A.e(f"v_min_i32 v62, {t(2)}, v62")
-        A.e(f"v_mul_lo_u32 v62, v62, {s('Kb')}")
-        A.e(f"v_add_u32 v{V['DMA'] + q}, v62, v61")
+    for q in range(RQ):
+        A.e(f"v_add_u32 {c}, {16 * q}, {a}")
+        A.e(f"v_min_i32 {c}, {t(2)}, {c}")
+        A.e(f"v_mul_lo_u32 {c}, {c}, {s('Kb')}")
+        A.e(f"v_add_u32 v{V['DMA'] + q}, {c}, {b}")
 
 
 def cursor_step(A, pre, on_wrap):
@@ -266,279 +264,175 @@ def cursor_step(A, pre, on_wrap):
     A.label(lab)
 
 
-def issue_x(A, slot_sgpr_expr_setup):
-    """x and log2 runs of the L cursor's step into x-ring slot (SGPR t(6) holds the slot's byte base for this wave)"""
-    slot_sgpr_expr_setup(A)
+def issue_x(A, slot):
+    """this wave's 64 bytes (16 lanes) of the L cursor's step into x-ring slot `slot` (int or SGPR name)"""
+    if isinstance(slot, int):
+        A.e(f"s_add_i32 {t(6)}, {s('xw')}, {slot * XSLOT}")
+    else:
+        A.e(f"s_mul_i32 {t(6)}, {slot}, {XSLOT}")
+        A.e(f"s_add_i32 {t(6)}, {t(6)}, {s('xw')}")
+    A.e(f"s_add_i32 m0, {t(6)}, {s('oXr')}")
     A.e(f"s_lshl_b32 {t(7)}, {s('l_k')}, 7")                       # k * 128 bytes
-    A.e(f"s_mov_b32 m0, {t(6)}")
+    A.e(f"s_mov_b64 {t2(16)}, exec")
+    A.e("s_mov_b64 exec, 0xffff")
     A.e(f"buffer_load_dword {v('XDMA')}, s[{S['rX']}:{S['rX'] + 3}], {t(7)} offen lds")
-    A.e(f"s_add_i32 m0, {t(6)}, 256")
-    A.e(f"buffer_load_dword {v('XDMA')}, s[{S['rL']}:{S['rL'] + 3}], {t(7)} offen lds")
+    A.e(f"s_mov_b64 exec, {t2(16)}")
     cursor_step(A, "l", set_x_rsrc)
 
 
-def issue_a(A, slot_setup):
-    """weight tile of the A cursor's step: NRB/2 requests of 16 rows x 64 B by this wave (t(6) = slot base + w*1024)"""
-    slot_setup(A)
+def issue_a(A, slot):
+    """weight tile of the A cursor's step: RQ requests of 16 rows x 64 B by this wave"""
+    if isinstance(slot, int):
+        A.e(f"s_add_i32 {t(6)}, {s('aw')}, {slot * AT}")
+    else:
+        A.e(f"s_mul_i32 {t(6)}, {slot}, {AT}")
+        A.e(f"s_add_i32 {t(6)}, {t(6)}, {s('aw')}")
+    A.e(f"s_add_i32 {t(6)}, {t(6)}, {s('oRing')}")
     A.e(f"s_lshl_b32 {t(7)}, {s('a_k')}, 6")                       # k * 64 bytes
-    for q in range(NRB // 2):
+    for q in range(RQ):
         if q == 0:
             A.e(f"s_mov_b32 m0, {t(6)}")
         else:
-            A.e(f"s_add_i32 m0, {t(6)}, {q * 4096}")
-        if os.environ.get("FUSED_NODMA") and q > 0:
-            A.e(f"buffer_load_dword {v('XDMA')}, s[{S['rX']}:{S['rX'] + 3}], {t(7)} offen lds")   # keeps the vmcnt bookkeeping, moves 256 B
-            continue
+            A.e(f"s_add_i32 m0, {t(6)}, {q * 1024}")
         A.e(f"buffer_load_dwordx4 v{V['DMA'] + q}, s[{S['rW']}:{S['rW'] + 3}], {t(7)} offen lds")
     cursor_step(A, "a", set_a_rows)
 
 
-def x_slot_base(slot_reg_or_const):
-    def f(A):
-        # t(6) = oXr + slot*2048 + w*512
-        if isinstance(slot_reg_or_const, int):
-            A.e(f"s_lshl_b32 {t(6)}, {s('w')}, 9")
-            A.e(f"s_add_i32 {t(6)}, {t(6)}, {slot_reg_or_const * 2048}")
-        else:
-            A.e(f"s_lshl_b32 {t(6)}, {slot_reg_or_const}, 11")
-            A.e(f"s_lshl_b32 {t(8)}, {s('w')}, 9")
-            A.e(f"s_add_i32 {t(6)}, {t(6)}, {t(8)}")
-        A.e(f"s_add_i32 {t(6)}, {t(6)}, {s('oXr')}")
-    return f
-
-
-def a_slot_base(slot_reg_or_const):
-    def f(A):
-        if isinstance(slot_reg_or_const, int):
-            A.e(f"s_lshl_b32 {t(6)}, {s('w')}, 10")
-            A.e(f"s_add_i32 {t(6)}, {t(6)}, {slot_reg_or_const * AT}")
-        else:
-            A.e(f"s_mul_i32 {t(6)}, {slot_reg_or_const}, {AT}")
-            A.e(f"s_lshl_b32 {t(8)}, {s('w')}, 10")
-            A.e(f"s_add_i32 {t(6)}, {t(6)}, {t(8)}")
-        A.e(f"s_add_i32 {t(6)}, {t(6)}, {s('oRing')}")
-    return f
-
-
 # ---------------------------------------------------------------- fragment generation (one pair of element-candidates)
-def gen_pair_ops(cb, e, set_, val0):
-    """instruction list (strings or ('ds', text, tag)) producing LUT reads of elements e, e+1 of candidate block cb
-    from the log2 values LV[e], LV[e+1]; results land in VAL+val0, VAL+val0+1.  (Near-ties: k_tie_flags' bits.)"""
-    par = "PAR0" if cb == 0 else "PAR1"
-    ca, cc, chi = v(par, CA), v(par, CC), v(par, CHI)
-    lutc = v("LUTC0" if cb == 0 else "LUTC1")
-    g = V["GT"] + 4 * set_
-    k0, k1, a0, a1 = (f"v{g + i}" for i in range(4))
-    lut0 = ("ds", f"ds_read_b32 v{V['VAL'] + val0}, {a0}", f"val{val0}") if not os.environ.get("FUSED_NOLUT") else f"v_mov_b32 v{V['VAL'] + val0}, {a0}"
-    lut1 = ("ds", f"ds_read_b32 v{V['VAL'] + val0 + 1}, {a1}", f"val{val0 + 1}") if not os.environ.get("FUSED_NOLUT") else f"v_mov_b32 v{V['VAL'] + val0 + 1}, {a1}"
-    return [
-        f"v_fma_f32 {k0}, {v('LV', e)}, {ca}, {cc}",
-        f"v_fma_f32 {k1}, {v('LV', e + 1)}, {ca}, {cc}",
-        f"v_med3_f32 {k0}, {k0}, 0, {chi}",
-        f"v_med3_f32 {k1}, {k1}, 0, {chi}",
-        f"v_add_f32 {k0}, 0x{MAGIC:08x}, {k0}",
-        f"v_add_f32 {k1}, 0x{MAGIC:08x}, {k1}",
-        f"v_lshl_add_u32 {a0}, {k0}, 9, {lutc}",
-        f"v_lshl_add_u32 {a1}, {k1}, 9, {lutc}",
-        lut0, lut1,
-    ]
+def gen_pair_ops(e, val0, first):
+    """instruction list (strings or ('ds', text, tag)): LUT reads of elements e, e+1 from the log2 values LV[e], LV[e+1]
+    (the 16-bit values land in VAL[val0], VAL[val0 + 1]) and |kf - rne(kf)| folded into the unit's running maximum DM"""
+    ca, cc, chi = v('PAR', CA), v('PAR', CC), v('PAR', CHI)
+    k, tt, x, dm = v('GT', 0), v('GT', 1), v('DX'), v('DM')
+    ops = []
+    for j in range(2):
+        ops += [
+            f"v_fma_f32 {k}, {v('LV', e + j)}, {ca}, {cc}",
+            f"v_med3_f32 {k}, {k}, 0, {chi}",
+            f"v_add_f32 {tt}, 0x{MAGIC:08x}, {k}",
+            f"v_add_f32 {x}, 0x{(MAGIC ^ 0x80000000):08x}, {tt}",
+            f"v_sub_f32 {x}, {k}, {x}",
+            (f"v_max_f32 {dm}, abs({x}), abs({x})" if (first and j == 0) else f"v_max_f32 {dm}, abs({x}), {dm}"),
+            f"v_lshl_add_u32 {tt}, {tt}, 9, {v('LUTC')}",
+            ("ds", f"ds_read_b32 {v('VAL', val0 + j)}, {tt}", f"val{val0 + j}"),
+        ]
+    return ops
 
 
-def pack_op(bn, cb, i, val0):
-    """dword i of B fragment (cb) from VAL[val0], VAL[val0+1]"""
-    return ("pack", f"v_lshl_or_b32 v{V[bn] + 4 * cb + i}, v{V['VAL'] + val0 + 1}, 16, v{V['VAL'] + val0}", (f"val{val0}", f"val{val0 + 1}"))
+def pack_op(bn, i, val0):
+    """dword i of B fragment bn from VAL[val0], VAL[val0+1]"""
+    return ("pack", f"v_lshl_or_b32 v{V[bn] + i}, {v('VAL', val0 + 1)}, 16, {v('VAL', val0)}", (f"val{val0}", f"val{val0 + 1}"))
 
 
-def fix_chunk(A, cb, bn, xsrc_vgpr, eo):
-    """cold block: a chunk (cb) holding a near-tie.  Per element: is any lane within the zone?  (~1.3 % each) -- if so the
-    element's bins come from the threshold table for every lane (exact wherever the fast bin is within one of it) and the
-    16-bit value is patched into B fragment bn[cb].  LV holds the chunk's log2 values; x is read from the x run."""
-    par = "PAR0" if cb == 0 else "PAR1"
-    ca, cc, chi = v(par, CA), v(par, CC), v(par, CHI)
-    thrc = v("THRC0" if cb == 0 else "THRC1")
-    lutb = v("LUTB0" if cb == 0 else "LUTB1")
+def fix_chunk(A, bn, xsrc_vgpr, eo):
+    """cold block: the wave's chunk holds a near-tie.  Per element: is any lane within the zone?  (~1.3 % each) -- if so
+    the element's bins come from the threshold table for every lane (exact wherever the fast bin is within one of it) and
+    the 16-bit value is patched into B fragment bn.  LV holds the chunk's log2 values; x is read from the x run.
+    Works in VAL0..3 and GT0..1 only: the A buffers may hold fragments read ahead for the next unit."""
+    ca, cc, chi = v('PAR', CA), v('PAR', CC), v('PAR', CHI)
+    ra, rb_, rc, rd, re_, rf = v('VAL', 0), v('VAL', 1), v('VAL', 2), v('VAL', 3), v('GT', 0), v('GT', 1)
     A.drain()
-    A.ds(f"ds_read_b128 {vr('XV', 0, 4)}, {xsrc_vgpr} offset:{eo * 4}", "x0")
-    A.ds(f"ds_read_b128 {vr('XV', 4, 4)}, {xsrc_vgpr} offset:{eo * 4 + 16}", "x1")
     A.e(f"s_sub_i32 {t(10)}, {s('L2')}, 1")
-    g = V["GT"]
     for e in range(8):
-        kf, tt, dd, f_, xs, i0, i1, tu = (f"v{g + i}" for i in range(8))
-        td, u_, d_ = (f"v{g + 8 + i}" for i in range(3))
         skip = A.new("Lfe")
-        A.e(f"v_fma_f32 {kf}, {v('LV', e)}, {ca}, {cc}")
-        A.e(f"v_med3_f32 {kf}, {kf}, 0, {chi}")
-        A.e(f"v_add_f32 {tt}, 0x{MAGIC:08x}, {kf}")
-        A.e(f"v_add_f32 {dd}, 0x{(MAGIC ^ 0x80000000):08x}, {tt}")
-        A.e(f"v_sub_f32 {dd}, {kf}, {dd}")
-        A.e(f"v_cmp_lt_f32 vcc, {s('tie')}, abs({dd})")
+        A.e(f"v_fma_f32 {ra}, {v('LV', e)}, {ca}, {cc}")
+        A.e(f"v_med3_f32 {ra}, {ra}, 0, {chi}")                    # kf
+        A.e(f"v_add_f32 {rb_}, 0x{MAGIC:08x}, {ra}")               # t
+        A.e(f"v_add_f32 {rc}, 0x{(MAGIC ^ 0x80000000):08x}, {rb_}")
+        A.e(f"v_sub_f32 {rc}, {ra}, {rc}")                         # d
+        A.e(f"v_cmp_lt_f32 vcc, {s('tie')}, abs({rc})")
         A.e(f"s_cbranch_vccz {skip}_%=")
-        saved = list(A.fifo)
-        A.e(f"v_and_b32 {f_}, 0xff, {tt}")
-        A.e(f"v_min_u32 {f_}, {s('L2')}, {f_}")                    # fast bin, clamped to 2^bits (= masked)
-        A.e(f"v_min_u32 {i0}, {t(10)}, {f_}")
-        A.e(f"v_lshl_add_u32 {i0}, {i0}, 9, {thrc}")
-        A.e(f"v_subrev_u32 {i1}, 1, {f_}")
-        A.e(f"v_max_i32 {i1}, 0, {i1}")
-        A.e(f"v_lshl_add_u32 {i1}, {i1}, 9, {thrc}")
-        A.ds(f"ds_read_b32 {tu}, {i0}", "tu")
-        A.ds(f"ds_read_b32 {td}, {i1}", "td")
-        A.drain()                                                  # (also covers the x reads)
-        A.e(f"v_add_f32 {xs}, {s('shift')}, {v('XV', e)}")
-        A.e(f"v_cmp_lt_f32 {t2(12)}, {xs}, {tu}")                  # xs < thr[f]
-        A.e(f"v_cmp_lt_u32 {t2(14)}, {f_}, {s('L2')}")             # f < 2^bits
-        A.e(f"s_and_b64 {t2(12)}, {t2(12)}, {t2(14)}")
-        A.e(f"v_cndmask_b32 {u_}, 0, 1, {t2(12)}")
-        A.e(f"v_cmp_nlt_f32 {t2(12)}, {xs}, {td}")                 # !(xs < thr[f-1])
-        A.e(f"v_cmp_lt_u32 {t2(14)}, 0, {f_}")                     # f > 0
-        A.e(f"s_and_b64 {t2(12)}, {t2(12)}, {t2(14)}")
-        A.e(f"v_cndmask_b32 {d_}, 0, 1, {t2(12)}")
-        A.e(f"v_add_u32 {f_}, {f_}, {u_}")
-        A.e(f"v_sub_u32 {f_}, {f_}, {d_}")
-        A.e(f"v_lshl_add_u32 {f_}, {f_}, 9, {lutb}")
-        A.ds(f"ds_read_b32 {tu}, {f_}", "fx")
+        A.ds(f"ds_read_b32 {rf}, {xsrc_vgpr} offset:{(eo + e) * 4}", "xe")
+        A.e(f"v_and_b32 {ra}, 0xff, {rb_}")
+        A.e(f"v_min_u32 {ra}, {s('L2')}, {ra}")                    # f: fast bin, clamped to 2^bits (= masked)
+        A.e(f"v_min_u32 {rb_}, {t(10)}, {ra}")
+        A.e(f"v_lshl_add_u32 {rb_}, {rb_}, 9, {v('THRC')}")
+        A.e(f"v_subrev_u32 {rc}, 1, {ra}")
+        A.e(f"v_max_i32 {rc}, 0, {rc}")
+        A.e(f"v_lshl_add_u32 {rc}, {rc}, 9, {v('THRC')}")
+        A.ds(f"ds_read_b32 {rd}, {rb_}", "tu")                     # thr[f]
+        A.ds(f"ds_read_b32 {re_}, {rc}", "td")                     # thr[f - 1]
         A.drain()
-        bdw = f"v{V[bn] + 4 * cb + e // 2}"
+        A.e(f"v_add_f32 {rf}, {s('shift')}, {rf}")                 # xs
+        A.e(f"v_cmp_lt_f32 {t2(12)}, {rf}, {rd}")                  # xs < thr[f]
+        A.e(f"v_cmp_lt_u32 {t2(14)}, {ra}, {s('L2')}")             # f < 2^bits
+        A.e(f"s_and_b64 {t2(12)}, {t2(12)}, {t2(14)}")
+        A.e(f"v_cndmask_b32 {rb_}, 0, 1, {t2(12)}")
+        A.e(f"v_add_u32 {rb_}, {ra}, {rb_}")
+        A.e(f"v_cmp_nlt_f32 {t2(12)}, {rf}, {re_}")                # !(xs < thr[f-1])
+        A.e(f"v_cmp_lt_u32 {t2(14)}, 0, {ra}")                     # f > 0
+        A.e(f"s_and_b64 {t2(12)}, {t2(12)}, {t2(14)}")
+        A.e(f"v_cndmask_b32 {rc}, 0, 1, {t2(12)}")
+        A.e(f"v_sub_u32 {rb_}, {rb_}, {rc}")
+        A.e(f"v_lshl_add_u32 {rb_}, {rb_}, 9, {v('LUTB')}")
+        A.ds(f"ds_read_b32 {rd}, {rb_}", "fx")
+        A.drain()
+        bdw = f"v{V[bn] + e // 2}"
         if e % 2 == 0:
             A.e(f"v_and_b32 {bdw}, 0xffff0000, {bdw}")
-            A.e(f"v_or_b32 {bdw}, {bdw}, {tu}")
+            A.e(f"v_or_b32 {bdw}, {bdw}, {rd}")
         else:
             A.e(f"v_and_b32 {bdw}, 0xffff, {bdw}")
-            A.e(f"v_lshl_or_b32 {bdw}, {tu}, 16, {bdw}")
+            A.e(f"v_lshl_or_b32 {bdw}, {rd}, 16, {bdw}")
         A.label(skip)
-        A.fifo = saved if e == 0 and False else A.fifo             # after a taken element nothing is outstanding; if every
-        # element is skipped the x reads are still in flight: harmless (XV is only read inside taken elements, behind a drain)
-    A.drain()
-
-
-PROF = bool(os.environ.get("FUSED_PROF"))          # phase timers (s_memtime) instead of results: see tools/lab/prof_fused.py
-PV = dict(P0=118, P1=119, P2=35, P3=3)              # cycles: barrier wait / unit 0 / unit 1 / everything between steps
-
-
-def stamp(A, which):
-    """profiling build: add the cycles since the previous stamp to counter `which`"""
-    if not PROF:
-        return
-    A.drain()
-    A.e(f"s_memtime s[{T0 + 14}:{T0 + 15}]")
-    A.e("s_waitcnt lgkmcnt(0)")
-    A.e(f"s_sub_i32 {t(13)}, {t(14)}, {t(18)}")
-    A.e(f"s_mov_b32 {t(18)}, {t(14)}")
-    A.e(f"v_add_u32 v{PV[which]}, {t(13)}, v{PV[which]}")
-
-
-def load_flag_row(A, pair_sgpr):
-    """FLGN <- the near-tie flag row of token 2 * pair + (w >> 1) (dword j in lane j; zeros past T).  Issues one VMEM load."""
-    lab = A.new("Lnofl")
-    A.e(f"v_mov_b32 {v('FLGN')}, 0")
-    A.e(f"s_lshl_b32 {t(0)}, {pair_sgpr}, 1")
-    A.e(f"s_lshr_b32 {t(1)}, {s('w')}, 1")
-    A.e(f"s_add_i32 {t(0)}, {t(0)}, {t(1)}")                        # token
-    A.e(f"s_cmp_ge_i32 {t(0)}, {s('T')}")
-    A.e(f"s_cbranch_scc1 {lab}_%=")
-    A.e(f"s_mul_hi_u32 {t(3)}, {t(0)}, {s('fpitch')}")
-    A.e(f"s_mul_i32 {t(2)}, {t(0)}, {s('fpitch')}")
-    A.e(f"s_add_u32 {t(2)}, {t(2)}, {s('pF_lo')}")
-    A.e(f"s_addc_u32 {t(3)}, {t(3)}, {s('pF_hi')}")
-    A.e(f"s_lshr_b32 {t(4)}, {s('fpitch')}, 2")                     # dwords per row
-    A.e(f"v_lshlrev_b32 v60, 2, {v('LANE')}")
-    A.e(f"v_cmp_gt_u32 vcc, {t(4)}, {v('LANE')}")
-    A.e(f"s_and_saveexec_b64 {t2(16)}, vcc")
-    A.e(f"global_load_dword {v('FLGN')}, v60, {t2(2)}")
-    A.e(f"s_mov_b64 exec, {t2(16)}")
-    A.label(lab)
-
-
-def first_nibble(A, reg, dst):
-    """dst = nib(0) of the row in VGPR `reg` (byte nk), shifted right by 2 * (w & 1): bit cb = candidate block cb of this wave"""
-    A.e(f"s_lshr_b32 {t(0)}, {s('nk')}, 2")
-    A.e(f"v_readlane_b32 {dst}, {v(reg)}, {t(0)}")
-    A.e(f"s_and_b32 {t(1)}, {s('nk')}, 3")
-    A.e(f"s_lshl_b32 {t(1)}, {t(1)}, 3")
-    A.e(f"s_lshr_b32 {dst}, {dst}, {t(1)}")
-    A.e(f"s_and_b32 {dst}, {dst}, 15")
-    A.e(f"s_lshr_b32 {dst}, {dst}, {s('sh2')}")
-
-
-def rotate_flags(A):
-    """after the next tile's row arrived in FLGN (and the current one sits in FLGC): put the next tile's nib(0) into the
-    high nibble of the current row's last byte (the unit that runs ahead into the next tile tests it)"""
-    A.e(f"s_lshr_b32 {t(0)}, {s('nk')}, 2")
-    A.e(f"v_readlane_b32 {t(1)}, {v('FLGN')}, {t(0)}")
-    A.e(f"s_and_b32 {t(2)}, {s('nk')}, 3")
-    A.e(f"s_lshl_b32 {t(2)}, {t(2)}, 3")
-    A.e(f"s_lshr_b32 {t(1)}, {t(1)}, {t(2)}")
-    A.e(f"s_and_b32 {t(1)}, {t(1)}, 15")                            # nib(0) of the next tile's token
-    A.e(f"s_sub_i32 {t(3)}, {s('nk')}, 1")
-    A.e(f"s_and_b32 {t(4)}, {t(3)}, 3")
-    A.e(f"s_lshl_b32 {t(4)}, {t(4)}, 3")
-    A.e(f"s_add_i32 {t(4)}, {t(4)}, 4")
-    A.e(f"s_lshl_b32 {t(1)}, {t(1)}, {t(4)}")
-    A.e(f"s_lshr_b32 {t(3)}, {t(3)}, 2")
-    A.e(f"v_mov_b32 v60, {t(1)}")
-    A.e(f"v_cmp_eq_u32 vcc, {t(3)}, {v('LANE')}")
-    A.e("v_cndmask_b32 v60, 0, v60, vcc")
-    A.e(f"v_or_b32 {v('FLGC')}, {v('FLGC')}, v60")
-
-
-def step_flags(A):
-    """t(20) = flag byte of this K-step (k_tie_flags layout) >> 2 * (w & 1): bits cb = unit 0, bits 4 + cb = unit 1"""
-    A.e(f"s_sub_i32 {t(12)}, {s('nk')}, {s('kt')}")                # step index
-    A.e(f"s_lshr_b32 {t(13)}, {t(12)}, 2")
-    A.e(f"v_readlane_b32 {t(20)}, {v('FLGC')}, {t(13)}")
-    A.e(f"s_and_b32 {t(12)}, {t(12)}, 3")
-    A.e(f"s_lshl_b32 {t(12)}, {t(12)}, 3")
-    A.e(f"s_lshr_b32 {t(20)}, {t(20)}, {t(12)}")
-    A.e(f"s_lshr_b32 {t(20)}, {t(20)}, {s('sh2')}")
 
 
 def gen_only(A, bn, xs_vgpr, eo):
     """un-overlapped generation of one K half into bn (used once, before the first step)"""
-    A.ds(f"ds_read_b128 {vr('LV', 0, 4)}, {xs_vgpr} offset:{256 + eo * 4}", "l0")
-    A.ds(f"ds_read_b128 {vr('LV', 4, 4)}, {xs_vgpr} offset:{256 + eo * 4 + 16}", "l1")
+    A.ds(f"ds_read_b128 {vr('LV', 0, 4)}, {xs_vgpr} offset:{128 + eo * 4}", "l0")
+    A.ds(f"ds_read_b128 {vr('LV', 4, 4)}, {xs_vgpr} offset:{128 + eo * 4 + 16}", "l1")
     A.drain()
-    for cb in range(2):
-        for pi in range(4):
-            for op in gen_pair_ops(cb, 2 * pi, pi & 3, 8 * cb + 2 * pi):
-                if isinstance(op, tuple):
-                    A.ds(op[1], op[2])
-                else:
-                    A.e(op)
+    for pi in range(4):
+        for op in gen_pair_ops(2 * pi, 2 * (pi & 1), pi == 0):
+            if isinstance(op, tuple):
+                A.ds(op[1], op[2])
+            else:
+                A.e(op)
         A.drain()
-        for i in range(4):
-            A.e(pack_op(bn, cb, i, 8 * cb + 2 * i)[1])
-    first_nibble(A, "FLGN", t(20))                                # nib(0) of the first tile's token, >> 2 * (w & 1)
-    for cb in range(2):
-        lab = A.new("Lfix")
-        A.e(f"s_bitcmp0_b32 {t(20)}, {cb}")
-        A.e(f"s_cbranch_scc1 {lab}_%=")
-        fix_chunk(A, cb, bn, xs_vgpr, eo)
-        A.label(lab)
+        A.e(pack_op(bn, pi, 2 * (pi & 1))[1])
+    lab = A.new("Lfix")
+    A.e(f"v_cmp_lt_f32 vcc, {s('tie')}, {v('DM')}")
+    A.e(f"s_cbranch_vccz {lab}_%=")
+    fix_chunk(A, bn, xs_vgpr, eo)
+    A.label(lab)
 
 
-def unit(A, h, bc, bn, xs_vgpr, eo, cold_blocks):
-    """half a K-step: 2*NRB MFMAs of K half h from B fragments bc, interleaved with the generation of the next half's
-    fragments (bn) from the x / log2 run at xs_vgpr (+eo elements).  Appends (label, emitter) cold blocks."""
-    aoff = v("AS0" if h == 0 else "AS1")
-    # ---- the filler stream, in issue order
+def abuf(h, rb):
+    b = V['ABUF'] + 4 * ((h * NRB + rb) % 4)
+    return f"v[{b}:{b + 3}]"
+
+
+def a_read(A, h, rb):
+    A.ds(f"ds_read_b128 {abuf(h, rb)}, {v('AS0' if h == 0 else 'AS1')} offset:{rb * 2048}", f"a{h}_{rb}")
+
+
+def unit_begin(A, h, xs_vgpr, eo, a_ahead):
+    """the log2 values of the chunk this unit generates (and, when nothing was read ahead, its first A fragments)"""
+    A.ds(f"ds_read_b128 {vr('LV', 0, 4)}, {xs_vgpr} offset:{128 + eo * 4}", f"l{h}_0")
+    A.ds(f"ds_read_b128 {vr('LV', 4, 4)}, {xs_vgpr} offset:{128 + eo * 4 + 16}", f"l{h}_1")
+    if not a_ahead:
+        for rb in range(min(3, NRB)):
+            a_read(A, h, rb)
+
+
+def unit(A, h, bc, bn, xs_vgpr, eo, cold_blocks, first_fill_rb):
+    """half a K-step: NRB MFMAs of K half h from B fragment bc, interleaved with the generation of the next half's
+    fragment (bn) from the log2 values unit_begin requested.  A fragments run three row blocks ahead, across the boundary
+    between the two units of a step (same ring slot).  Appends a cold block descriptor."""
     fill = []
-    fill.append(("ds", f"ds_read_b128 {vr('LV', 0, 4)}, {xs_vgpr} offset:{256 + eo * 4}", "l0"))
-    fill.append(("ds", f"ds_read_b128 {vr('LV', 4, 4)}, {xs_vgpr} offset:{256 + eo * 4 + 16}", "l1"))
-    pend_packs = []
-    for cb in range(2):
-        for pi in range(4):
-            ops = gen_pair_ops(cb, 2 * pi, pi & 3, 8 * cb + 2 * pi)
-            if cb == 0 and pi == 0:
-                ops.insert(0, ("waitfor", "l1"))
-            fill.extend(ops)
-            # pack the pair generated two pairs ago (its LUT reads have had time to return)
-            pend_packs.append(pack_op(bn, cb, pi, 8 * cb + 2 * pi))
-            if len(pend_packs) > 3:
-                fill.append(pend_packs.pop(0))
-    fill.extend(pend_packs)
-    # ---- MFMA stream with the A fragment reads three row blocks ahead (four rotating buffers)
+    for pi in range(4):
+        ops = gen_pair_ops(2 * pi, 2 * (pi & 1), pi == 0)
+        if pi >= 2:
+            # pair pi - 2 is packed right before this pair's LUT reads reuse its VAL registers: a full pair (and the MFMAs
+            # in between) after its own reads were issued
+            ops.insert(7, pack_op(bn, pi - 2, 2 * (pi & 1)))
+        if pi == 0:
+            ops.insert(0, ("waitfor", f"l{h}_0"))
+        if pi == 2:
+            ops.insert(0, ("waitfor", f"l{h}_1"))
+        fill.extend(ops)
+    tail = [pack_op(bn, 2, 0), pack_op(bn, 3, 2)]                   # after the last MFMA: their reads went out two MFMAs earlier
     nf = len(fill)
-    n_mfma = 2 * NRB
     fi = 0
 
     def emit_fill(k):
@@ -560,37 +454,29 @@ def unit(A, h, bc, bn, xs_vgpr, eo, cold_blocks):
             else:
                 A.e(op)
 
-    def abuf(rb):
-        b = V['ABUF'] + 4 * (rb % 4)
-        return f"v[{b}:{b + 3}]"
-
-    def a_read(rb):
-        A.ds(f"ds_read_b128 {abuf(rb)}, {aoff} offset:{rb * 2048}", f"a{rb}")
-
-    emit_fill(2)                                                   # the two log2 reads go first
-    a_read(0)
-    a_read(1)
-    a_read(2)
-    emit_fill(14)                                                  # first pair's arithmetic covers the fragment latency
-    per = (nf - fi + n_mfma - 1) // n_mfma
+    n_slots = max(1, NRB - 1 - first_fill_rb)                      # the generation ends one MFMA before the unit does
+    per = (nf + n_slots - 1) // n_slots
     for rb in range(NRB):
-        if rb + 3 < NRB:
-            a_read(rb + 3)
-        A.wait(f"a{rb}")
-        for cb in range(2):
-            if not os.environ.get("FUSED_NOMFMA"):
-                A.e(f"v_mfma_f32_32x32x16_bf16 {acc(rb, cb)}, {abuf(rb)}, v[{V[bc] + 4 * cb}:{V[bc] + 4 * cb + 3}], {acc(rb, cb)}")
+        nxt = rb + 3
+        if nxt < NRB:
+            a_read(A, h, nxt)
+        elif h == 0 and nxt - NRB < min(3, NRB):
+            a_read(A, 1, nxt - NRB)                                # the second unit's first fragments (same ring slot)
+        A.wait(f"a{h}_{rb}")
+        if not os.environ.get("FUSED_NOMFMA"):
+            A.e(f"v_mfma_f32_32x32x16_bf16 {acc(rb)}, {abuf(h, rb)}, v[{V[bc]}:{V[bc] + 3}], {acc(rb)}")
+        if rb >= first_fill_rb:
             emit_fill(per)
     emit_fill(nf)
-    # ---- near-tie checks of the two chunks (cold blocks follow the loop)
-    for cb in range(2):
-        if os.environ.get("FUSED_NOCOLD"):
-            continue
+    fill.extend(tail)
+    nf = len(fill)
+    emit_fill(nf)
+    if not os.environ.get("FUSED_NOCOLD"):
         lab = A.new("Lcold")
-        A.e(f"s_bitcmp1_b32 {t(20)}, {4 * h + cb}")                 # k_tie_flags: unit h of this step, candidate block cb
-        A.e(f"s_cbranch_scc1 {lab}_%=")
+        A.e(f"v_cmp_lt_f32 vcc, {s('tie')}, {v('DM')}")             # any element-candidate of the chunk near a rounding tie?
+        A.e(f"s_cbranch_vccnz {lab}_%=")
         A.label(lab + "r")
-        cold_blocks.append((lab, cb, bn, xs_vgpr, eo, list(A.fifo)))
+        cold_blocks.append((lab, bn, xs_vgpr, eo, list(A.fifo)))
 
 
 def epilogue(A):
@@ -598,82 +484,73 @@ def epilogue(A):
     A.e("s_nop 7")
     A.e("s_nop 7")
     A.e("s_nop 7")                                                 # MFMA results -> VALU reads
-    s0, s1 = "v96", "v97"
+    E0 = V['ABUF']
+    s0 = v('LV', 4)
+    epi, epr, xora = v('LV', 5), v('LV', 6), v('LV', 7)
+    # read bases: refb + wtok*ROWS*4 + fkg*16 ; rs + fkg*16 ; bpermute partner lane ^ 32
+    A.e(f"s_lshr_b32 {t(5)}, {s('w')}, 2")
+    A.e(f"s_mul_i32 {t(5)}, {t(5)}, {ROWS * 4}")
+    A.e(f"s_add_i32 {t(5)}, {t(5)}, {s('oRefb')}")
+    A.e(f"v_lshl_add_u32 {epi}, {v('FKG')}, 4, {t(5)}")
+    A.e(f"v_lshl_add_u32 {epr}, {v('FKG')}, 4, {s('oRs')}")
+    A.e(f"v_xor_b32 {xora}, 32, {v('LANE')}")
+    A.e(f"v_lshlrev_b32 {xora}, 2, {xora}")
     A.e(f"v_mov_b32 {s0}, 0")
-    A.e(f"v_mov_b32 {s1}, 0")
-    idx = 0
-    reads = []
-    for rb in range(NRB):
-        for i4 in range(4):
-            reads.append((rb, i4))
-    # software pipeline: issue the reads of group g+1 before the arithmetic of group g
+    reads = [(rb, i4) for rb in range(NRB) for i4 in range(4)]
+
     def issue(gi):
         rb, i4 = reads[gi]
-        b = V["E0"] + 8 * (gi & 1)
+        b = E0 + 8 * (gi & 1)
         off = (rb * 32 + 8 * i4) * 4
-        A.ds(f"ds_read_b128 v[{b}:{b + 3}], {v('EPI')} offset:{off}", f"rf{gi}")
-        A.ds(f"ds_read_b128 v[{b + 4}:{b + 7}], {v('EPR')} offset:{off}", f"rs{gi}")
+        A.ds(f"ds_read_b128 v[{b}:{b + 3}], {epi} offset:{off}", f"rf{gi}")
+        A.ds(f"ds_read_b128 v[{b + 4}:{b + 7}], {epr} offset:{off}", f"rs{gi}")
     issue(0)
     for gi, (rb, i4) in enumerate(reads):
         if gi + 1 < len(reads):
             issue(gi + 1)
         A.wait(f"rs{gi}")
-        b = V["E0"] + 8 * (gi & 1)
+        b = E0 + 8 * (gi & 1)
         for j in range(4):
-            for cb in range(2):
-                kind, r = acc_elem(rb, cb, 4 * i4 + j)
-                tmp = f"v{80 + 2 * j + cb}"
-                if kind == "a":
-                    A.e(f"v_accvgpr_read_b32 {tmp}, a{r}")
-                    src = tmp
-                else:
-                    src = f"v{r}"
-                A.e(f"v_mul_f32 {tmp}, {src}, {v('PAR0' if cb == 0 else 'PAR1', AL)}")
-                A.e(f"v_fma_f32 {tmp}, -{tmp}, v{b + 4 + j}, v{b + j}")
-                A.e(f"v_fma_f32 {s0 if cb == 0 else s1}, {tmp}, {tmp}, {s0 if cb == 0 else s1}")
+            tmp = v('LV', j)
+            if rb < NA:
+                A.e(f"v_accvgpr_read_b32 {tmp}, a{16 * rb + 4 * i4 + j}")
+                A.e(f"v_mul_f32 {tmp}, {tmp}, {v('PAR', AL)}")
+            else:
+                A.e(f"v_mul_f32 {tmp}, v{64 + 16 * (rb - NA) + 4 * i4 + j}, {v('PAR', AL)}")
+            A.e(f"v_fma_f32 {tmp}, -{tmp}, v{b + 4 + j}, v{b + j}")
+            A.e(f"v_fma_f32 {s0}, {tmp}, {tmp}, {s0}")
     # lanes l and l + 32 hold the two row halves of a candidate
-    A.ds(f"ds_bpermute_b32 v98, {v('XORA')}, {s0}", "bp0")
-    A.ds(f"ds_bpermute_b32 v99, {v('XORA')}, {s1}", "bp1")
+    A.ds(f"ds_bpermute_b32 {v('LV', 0)}, {xora}, {s0}", "bp0")
     A.drain()
-    A.e(f"v_add_f32 {s0}, {s0}, v98")
-    A.e(f"v_add_f32 {s1}, {s1}, v99")
+    A.e(f"v_add_f32 {s0}, {s0}, {v('LV', 0)}")
     # run += (double) s  when this wave's token exists (t(9) = 1)
     lab = A.new("Lnotok")
     A.e(f"s_cmp_eq_u32 {t(9)}, 0")
     A.e(f"s_cbranch_scc1 {lab}_%=")
-    A.e(f"v_cvt_f64_f32 v[100:101], {s0}")
-    A.e(f"v_cvt_f64_f32 v[102:103], {s1}")
-    A.e(f"v_add_f64 v[{V['RUN0']}:{V['RUN0'] + 1}], v[{V['RUN0']}:{V['RUN0'] + 1}], v[100:101]")
-    A.e(f"v_add_f64 v[{V['RUN1']}:{V['RUN1'] + 1}], v[{V['RUN1']}:{V['RUN1'] + 1}], v[102:103]")
+    A.e(f"v_cvt_f64_f32 {vr('LV', 0, 2)}, {s0}")
+    A.e(f"v_add_f64 {vr('RUN', 0, 2)}, {vr('RUN', 0, 2)}, {vr('LV', 0, 2)}")
     A.label(lab)
 
 
 def tile_setup(A):
     """epilogue operands of the compute tile -> LDS; accumulators zeroed.  Uses the compute cursor (c_tile)."""
-    A.c("tile: near-tie flag rows (this tile's = the one fetched during the previous tile; fetch the next tile's)")
-    A.e(f"v_mov_b32 {v('FLGC')}, {v('FLGN')}")
-    A.e(f"s_add_i32 {t(5)}, {s('c_pair')}, {s('dpair')}")
-    A.e(f"s_add_i32 {t(6)}, {s('c_rt')}, {s('drt')}")
-    A.e(f"s_cmp_ge_u32 {t(6)}, {s('n_rt')}")
-    A.e(f"s_cselect_b32 {t(6)}, 1, 0")
-    A.e(f"s_add_i32 {t(5)}, {t(5)}, {t(6)}")                        # token pair of the next tile of this workgroup
-    load_flag_row(A, t(5))
     A.c("tile: m0, tok0, staging of ref - row_bias and row_scale, zero accumulators")
-    # (pair, rt) of the compute tile are kept incrementally (c_pair, c_rt), like the issue cursors
     A.e(f"s_mov_b32 {t(0)}, {s('c_pair')}")
     A.e(f"s_mov_b32 {t(1)}, {s('c_rt')}")
     A.e(f"s_lshl_b32 {t(2)}, {t(0)}, 1")                           # tok0
     A.e(f"s_mul_i32 {t(3)}, {t(1)}, {ROWS}")                       # m0
-    # tok_ok for this wave: tok0 + wtok < T
-    A.e(f"s_lshr_b32 {t(4)}, {s('w')}, 1")
+    A.e(f"s_lshr_b32 {t(4)}, {s('w')}, 2")
     A.e(f"s_add_i32 {t(4)}, {t(4)}, {t(2)}")
     A.e(f"s_cmp_lt_i32 {t(4)}, {s('T')}")
-    A.e(f"s_cselect_b32 {t(9)}, 1, 0")
-    # thread id within the workgroup: tid = w*64 + lane ; staging elements e = tid + u*256
+    A.e(f"s_cselect_b32 {t(9)}, 1, 0")                             # tok_ok for this wave: tok0 + wtok < T
+    NT = 64 * NW
+    tid, e_, ts, r_, row, tk, off, a4 = (v('TV', i) for i in range(8))
     A.e(f"s_lshl_b32 {t(5)}, {s('w')}, 6")
-    A.e(f"v_add_u32 v60, {t(5)}, {v('LANE')}")                     # tid
-    EU = (2 * ROWS + 255) // 256
-    RU = (ROWS + 255) // 256
+    A.e(f"v_add_u32 {tid}, {t(5)}, {v('LANE')}")                   # thread id within the workgroup
+    EU = (2 * ROWS + NT - 1) // NT
+    RU = (ROWS + NT - 1) // NT
+    RF, RBV, RSV = V['TV'] + 8, V['TV'] + 10, V['TV'] + 12         # loaded ref / row_bias / row_scale values (EU, EU, RU <= 2)
+    assert EU <= 2 and RU <= 2
     A.e("s_waitcnt vmcnt(0)")
     A.e(f"s_mul_i32 {t(20)}, {t(2)}, {s('M')}")                    # tok0 * M (64 bit) * 4 + pRef
     A.e(f"s_mul_hi_u32 {t(21)}, {t(2)}, {s('M')}")
@@ -683,110 +560,72 @@ def tile_setup(A):
     A.e(f"s_movk_i32 {t(7)}, {2 * ROWS}")
     A.e(f"s_movk_i32 {t(8)}, {ROWS}")
     for u in range(EU):
-        # e = tid + u*256 ; ts = e >= ROWS ; r = e - ts*ROWS ; row = m0 + r ; tk = tok0 + ts
-        A.e(f"v_add_u32 v61, {u * 256}, v60")
-        A.e(f"v_cmp_le_u32 vcc, {ROWS}, v61")
-        A.e("v_cndmask_b32 v62, 0, 1, vcc")                        # ts
-        A.e(f"v_mul_u32_u24 v63, {ROWS}, v62")
-        A.e("v_sub_u32 v63, v61, v63")                             # r
-        A.e(f"v_add_u32 v64, {t(3)}, v63")                         # row
-        A.e(f"v_add_u32 v65, {t(2)}, v62")                         # tk
+        # e = tid + u*NT ; ts = e >= ROWS ; r = e - ts*ROWS ; row = m0 + r ; tk = tok0 + ts
+        A.e(f"v_add_u32 {e_}, {u * NT}, {tid}")
+        A.e(f"v_cmp_le_u32 vcc, {t(8)}, {e_}")
+        A.e(f"v_cndmask_b32 {ts}, 0, 1, vcc")
+        A.e(f"v_mul_u32_u24 {r_}, {t(8)}, {ts}")
+        A.e(f"v_sub_u32 {r_}, {e_}, {r_}")
+        A.e(f"v_add_u32 {row}, {t(3)}, {r_}")
+        A.e(f"v_add_u32 {tk}, {t(2)}, {ts}")
         # ok = e < 2*ROWS && row < M && tk < T
-        A.e(f"v_cmp_gt_u32 {t2(12)}, {t(7)}, v61")
-        A.e(f"v_cmp_gt_i32 {t2(14)}, {s('M')}, v64")
+        A.e(f"v_cmp_gt_u32 {t2(12)}, {t(7)}, {e_}")
+        A.e(f"v_cmp_gt_i32 {t2(14)}, {s('M')}, {row}")
         A.e(f"s_and_b64 {t2(12)}, {t2(12)}, {t2(14)}")
-        A.e(f"v_cmp_gt_i32 {t2(14)}, {s('T')}, v65")
+        A.e(f"v_cmp_gt_i32 {t2(14)}, {s('T')}, {tk}")
         A.e(f"s_and_b64 {t2(12)}, {t2(12)}, {t2(14)}")
         # ref[(tok0 + ts)*M + row]: 64-bit tile base in s[t20:t21], 32-bit lane offset (ts*M + row)*4
-        A.e(f"v_mul_lo_u32 v66, v62, {s('M')}")
-        A.e("v_add_u32 v66, v66, v64")
-        A.e("v_lshlrev_b32 v66, 2, v66")
-        A.e(f"v_mov_b32 v{70 + u}, 0")
-        A.e(f"v_mov_b32 v{74 + u}, 0")
+        A.e(f"v_mul_lo_u32 {off}, {ts}, {s('M')}")
+        A.e(f"v_add_u32 {off}, {off}, {row}")
+        A.e(f"v_lshlrev_b32 {off}, 2, {off}")
+        A.e(f"v_mov_b32 v{RF + u}, 0")
+        A.e(f"v_mov_b32 v{RBV + u}, 0")
         A.e(f"s_and_saveexec_b64 {t2(16)}, {t2(12)}")
-        if SUB >= 1:
-            var = int(os.environ.get("FUSED_VAR", "0"))
-            if var == 0:
-                A.e(f"global_load_dword v{70 + u}, v66, {t2(20)}")
-            elif var == 1:                                              # constant offset 0
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, {t2(20)}")
-            elif var == 2:                                              # plain 64-bit address of ref[0]
-                A.e(f"v_mov_b32 v66, {s('pRef_lo')}")
-                A.e(f"v_mov_b32 v67, {s('pRef_hi')}")
-                A.e(f"global_load_dword v{70 + u}, v[66:67], off")
-            elif var == 3:                                              # no exec masking around it
-                A.e(f"s_mov_b64 exec, {t2(16)}")
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, {t2(20)}")
-            elif var == 5:                                              # s[28:29] = plain copy of pRef
-                A.e(f"s_mov_b32 {t(20)}, {s('pRef_lo')}")
-                A.e(f"s_mov_b32 {t(21)}, {s('pRef_hi')}")
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, {t2(20)}")
-            elif var == 6:                                              # same through another pair
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, {t2(20)}")
-            elif var == 7:                                              # pRef pair directly
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, s[{S['pRef_lo']}:{S['pRef_hi']}]")
-            elif var == 8:                                              # computed base, long settle time
-                A.e("s_nop 7")
-                A.e("s_nop 7")
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, {t2(20)}")
-            elif var == 10:                                             # pRef + constant inside the tensor
-                A.e(f"s_add_u32 s28, {s('pRef_lo')}, 0x60000")
-                A.e(f"s_addc_u32 s29, {s('pRef_hi')}, 0")
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, s[28:29]")
-            elif var == 11:                                             # computed base but only wave 0 / lane 0 loads
-                A.e(f"s_mov_b64 exec, 1")
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, {t2(20)}")
-            elif var == 4:                                              # read W instead of ref
-                A.e(f"global_load_dword v{70 + u}, {v('ZERO')}, s[{S['pW_lo']}:{S['pW_hi']}]")
-        # row_bias (may be null)
+        A.e(f"global_load_dword v{RF + u}, {off}, {t2(20)}")
         labn = A.new("Lnorb")
         A.e(f"s_or_b32 {t(18)}, {s('pRb_lo')}, {s('pRb_hi')}")
         A.e(f"s_cmp_eq_u32 {t(18)}, 0")
         A.e(f"s_cbranch_scc1 {labn}_%=")
-        A.e("v_lshlrev_b32 v69, 2, v64")
-        if SUB >= 2:
-            A.e(f"global_load_dword v{74 + u}, v69, s[{S['pRb_lo']}:{S['pRb_hi']}]")
+        A.e(f"v_lshlrev_b32 {a4}, 2, {row}")
+        A.e(f"global_load_dword v{RBV + u}, {a4}, s[{S['pRb_lo']}:{S['pRb_hi']}]")
         A.label(labn)
         A.e(f"s_mov_b64 exec, {t2(16)}")
     for u in range(RU):
-        A.e(f"v_add_u32 v61, {u * 256}, v60")                      # r
-        A.e(f"v_add_u32 v64, {t(3)}, v61")                         # row
-        A.e(f"v_cmp_gt_u32 {t2(12)}, {t(8)}, v61")
-        A.e(f"v_cmp_gt_i32 {t2(14)}, {s('M')}, v64")
+        A.e(f"v_add_u32 {e_}, {u * NT}, {tid}")                    # r
+        A.e(f"v_add_u32 {row}, {t(3)}, {e_}")
+        A.e(f"v_cmp_gt_u32 {t2(12)}, {t(8)}, {e_}")
+        A.e(f"v_cmp_gt_i32 {t2(14)}, {s('M')}, {row}")
         A.e(f"s_and_b64 {t2(12)}, {t2(12)}, {t2(14)}")
-        A.e(f"v_mov_b32 v{78 + u}, 0")
-        A.e("v_lshlrev_b32 v69, 2, v64")
+        A.e(f"v_mov_b32 v{RSV + u}, 0")
+        A.e(f"v_lshlrev_b32 {a4}, 2, {row}")
         A.e(f"s_and_saveexec_b64 {t2(16)}, {t2(12)}")
-        if SUB >= 3:
-            A.e(f"global_load_dword v{78 + u}, v69, s[{S['pRs_lo']}:{S['pRs_hi']}]")
+        A.e(f"global_load_dword v{RSV + u}, {a4}, s[{S['pRs_lo']}:{S['pRs_hi']}]")
         A.e(f"s_mov_b64 exec, {t2(16)}")
     A.e("s_waitcnt vmcnt(0)")
     A.e("s_barrier")                                               # every wave is past the previous tile's epilogue reads
     for u in range(EU):
-        A.e(f"v_add_u32 v61, {u * 256}, v60")
-        A.e(f"v_cmp_gt_u32 vcc, {2 * ROWS}, v61")
-        A.e(f"v_sub_f32 v{70 + u}, v{70 + u}, v{74 + u}")
-        A.e(f"v_lshl_add_u32 v62, v61, 2, {s('oRefb')}")
+        A.e(f"v_add_u32 {e_}, {u * NT}, {tid}")
+        A.e(f"v_cmp_gt_u32 vcc, {t(7)}, {e_}")
+        A.e(f"v_sub_f32 v{RF + u}, v{RF + u}, v{RBV + u}")
+        A.e(f"v_lshl_add_u32 {r_}, {e_}, 2, {s('oRefb')}")
         A.e(f"s_and_saveexec_b64 {t2(16)}, vcc")
-        A.e(f"ds_write_b32 v62, v{70 + u}")
+        A.e(f"ds_write_b32 {r_}, v{RF + u}")
         A.e(f"s_mov_b64 exec, {t2(16)}")
     for u in range(RU):
-        A.e(f"v_add_u32 v61, {u * 256}, v60")
-        A.e(f"v_cmp_gt_u32 vcc, {ROWS}, v61")
-        A.e(f"v_lshl_add_u32 v62, v61, 2, {s('oRs')}")
+        A.e(f"v_add_u32 {e_}, {u * NT}, {tid}")
+        A.e(f"v_cmp_gt_u32 vcc, {t(8)}, {e_}")
+        A.e(f"v_lshl_add_u32 {r_}, {e_}, 2, {s('oRs')}")
         A.e(f"s_and_saveexec_b64 {t2(16)}, vcc")
-        A.e(f"ds_write_b32 v62, v{78 + u}")
+        A.e(f"ds_write_b32 {r_}, v{RSV + u}")
         A.e(f"s_mov_b64 exec, {t2(16)}")
     A.c("zero the accumulators")
-    for r in range(16 * 2 * NA):
+    for r in range(16 * NA):
         A.e(f"v_accvgpr_write_b32 a{r}, 0")
-    for r in range(128, 128 + 16 * 2 * (NRB - NA)):
+    for r in range(64, 64 + 16 * (NRB - NA)):
         A.e(f"v_mov_b32 v{r}, 0")
     A.e("s_nop 4")
-    rotate_flags(A)
 
 
-SUB = int(os.environ.get("FUSED_SUB", "99"))            # debugging of tile_setup: 0 no loads, 1 ref, 2 + row_bias, 3 + row_scale
 STAGE = int(os.environ.get("FUSED_STAGE", "99"))      # debugging: stop after a phase (1 setup, 2 prologue, 3 tile setup, 4 one step)
 
 
@@ -796,7 +635,6 @@ def program():
     lane_setup(A)
     if STAGE <= 1:
         A.e("s_branch Lend_%=")
-    # cursors
     for pre in ("a", "l"):
         A.e(f"s_mov_b32 {s(pre + '_tile')}, {s('bid')}")
         A.e(f"s_mov_b32 {s(pre + '_pair')}, {s('pair0')}")
@@ -807,69 +645,60 @@ def program():
     A.e(f"s_mov_b32 {s('c_rt')}, {s('rt0')}")
     set_x_rsrc(A)
     set_a_rows(A)
-    load_flag_row(A, s('pair0'))                                    # first tile's near-tie flags (waited with the first DMAs)
     A.c("prologue: x/log2 of step 0, then weights of steps 0..FNS-2 with the x/log2 of the following step")
-    issue_x(A, x_slot_base(0))
+    issue_x(A, 0)
     for s0 in range(FNS - 1):
-        issue_a(A, a_slot_base(s0))
-        issue_x(A, x_slot_base(s0 + 1))
+        issue_a(A, s0)
+        issue_x(A, s0 + 1)
     A.e(f"s_mov_b32 {s('stA')}, 0")
     A.e(f"s_mov_b32 {s('stX')}, 0")
-    A.c("B fragments of the very first K half")
+    A.c("B fragment of the very first K half")
     A.e("s_waitcnt vmcnt(0)")
+    A.e("s_barrier")                                               # the x / log2 parts of the slot come from four waves
     A.e(f"v_mov_b32 {v('XSC')}, {v('XOFF')}")
     gen_only(A, "BA", v("XSC"), 0)
     if STAGE <= 2:
         A.e("s_branch Lend_%=")
 
-    if PROF:
-        for r in PV.values():
-            A.e(f"v_mov_b32 v{r}, 0")
-        A.e(f"s_memtime s[{T0 + 14}:{T0 + 15}]")
-        A.e("s_waitcnt lgkmcnt(0)")
-        A.e(f"s_mov_b32 {t(18)}, {t(14)}")
     A.label("Ltile")
     tile_setup(A)
     if STAGE <= 3:
         A.e("s_branch Lend_%=")
     A.e(f"s_mov_b32 {s('kt')}, {s('nk')}")
     A.label("Lstep")
-    stamp(A, "P3")
     cold = []
-    A.e(f"s_waitcnt vmcnt({(FNS - 2) * (NRB // 2 + 2)})")
+    A.e(f"s_waitcnt vmcnt({(FNS - 2) * (RQ + 1)})")
     if not os.environ.get("FUSED_NOBAR"):
         A.e("s_barrier")
-    stamp(A, "P0")
     # ring addresses of this step
     A.e(f"s_mul_i32 {t(0)}, {s('stA')}, {AT}")
     A.e(f"s_add_i32 {t(0)}, {t(0)}, {s('oRing')}")
     A.e(f"v_add_u32 {v('AS0')}, {t(0)}, {v('AOFF0')}")
     A.e(f"v_add_u32 {v('AS1')}, {t(0)}, {v('AOFF1')}")
-    A.e(f"s_lshl_b32 {t(1)}, {s('stX')}, 11")
+    A.e(f"s_mul_i32 {t(1)}, {s('stX')}, {XSLOT}")
     A.e(f"v_add_u32 {v('XSC')}, {t(1)}, {v('XOFF')}")
     A.e(f"s_add_i32 {t(2)}, {s('stX')}, 1")
     A.e(f"s_cmp_eq_u32 {t(2)}, {XS}")
     A.e(f"s_cselect_b32 {t(2)}, 0, {t(2)}")                        # next x slot
-    A.e(f"s_lshl_b32 {t(3)}, {t(2)}, 11")
+    A.e(f"s_mul_i32 {t(3)}, {t(2)}, {XSLOT}")
     A.e(f"v_add_u32 {v('XSN')}, {t(3)}, {v('XOFF')}")
     A.e(f"s_mov_b32 {t(19)}, {t(2)}")                              # keep the next x slot
-    step_flags(A)
+    unit_begin(A, 0, v("XSC"), 16, False)                          # this step's first reads fly while the DMA work issues
     # DMA for step n + FNS - 1 (weights -> the slot step n - 1 used) and n + FNS (x/log2 -> the x slot step n - 1 used)
     A.e(f"s_add_i32 {t(4)}, {s('stA')}, {FNS - 1}")
     A.e(f"s_cmp_ge_u32 {t(4)}, {FNS}")
     A.e(f"s_cselect_b32 {t(5)}, {FNS}, 0")
     A.e(f"s_sub_i32 {t(4)}, {t(4)}, {t(5)}")
-    issue_a(A, a_slot_base(t(4)))
+    issue_a(A, t(4))
     A.e(f"s_add_i32 {t(4)}, {s('stX')}, {XS - 1}")
     A.e(f"s_cmp_ge_u32 {t(4)}, {XS}")
     A.e(f"s_cselect_b32 {t(5)}, {XS}, 0")
     A.e(f"s_sub_i32 {t(4)}, {t(4)}, {t(5)}")
-    issue_x(A, x_slot_base(t(4)))
-    unit(A, 0, "BA", "BB", v("XSC"), 16, cold)
-    stamp(A, "P1")
-    unit(A, 1, "BB", "BA", v("XSN"), 0, cold)
+    issue_x(A, t(4))
+    unit(A, 0, "BA", "BB", v("XSC"), 16, cold, 0)
+    unit_begin(A, 1, v("XSN"), 0, True)
+    unit(A, 1, "BB", "BA", v("XSN"), 0, cold, 1)
     A.drain()
-    stamp(A, "P2")
     # advance the ring slots
     A.e(f"s_add_i32 {s('stA')}, {s('stA')}, 1")
     A.e(f"s_cmp_eq_u32 {s('stA')}, {FNS}")
@@ -894,48 +723,24 @@ def program():
     A.e("s_cbranch_scc1 Ltile_%=")
     A.e("s_branch Lend_%=")
     A.c("cold blocks: chunks with a near-tie")
-    for lab, cb, bn, xs_vgpr, eo, fifo in cold:
+    for lab, bn, xs_vgpr, eo, fifo in cold:
         A.label(lab)
         A.fifo = list(fifo)
-        fix_chunk(A, cb, bn, xs_vgpr, eo)
+        fix_chunk(A, bn, xs_vgpr, eo)
         A.e(f"s_branch {lab}r_%=")
     A.label("Lend")
     A.fifo = []
-    if os.environ.get("FUSED_DEBUG"):
-        # dump scalars as raw dwords into s_fin[0..31] (wave 0), read back by the kernel's debug path
-        dbg = [s('pRef_lo'), s('pRef_hi'), t(20), t(21), s('M'), s('T'), t(2), t(3), s('c_tile'), s('n_rt'), s('w'), s('oFin'),
-               s('c_pair'), s('c_rt'), s('pair0'), s('rt0')]
-        A.e("s_waitcnt vmcnt(0)")
-        A.e(f"s_lshl_b32 {t(0)}, {s('w')}, 6")
-        A.e(f"s_add_i32 {t(0)}, {t(0)}, {s('oFin')}")
-        A.e(f"v_mov_b32 v60, {t(0)}")
-        for i, r in enumerate(dbg):
-            A.e(f"v_mov_b32 v61, {r}")
-            A.e(f"ds_write_b32 v60, v61 offset:{4 * i}")
-        A.e("s_waitcnt lgkmcnt(0)")
-        A.e("s_branch Ldbgend_%=")
-    A.c("per-lane sums -> s_fin[w][64] (lanes 0..31 hold the candidates of both blocks)")
+    A.c("per-lane sums -> s_fin[w][32] (lanes 0..31 hold the wave's candidates)")
     A.e("s_waitcnt vmcnt(0)")
-    if PROF:
-        A.e(f"v_cmp_gt_u32 vcc, 16, {v('FROW')}")
-        A.e(f"v_cndmask_b32 v60, v{PV['P2']}, v{PV['P0']}, vcc")
-        A.e(f"v_cndmask_b32 v61, v{PV['P3']}, v{PV['P1']}, vcc")
-        A.e(f"v_cvt_f64_u32 v[{V['RUN0']}:{V['RUN0'] + 1}], v60")
-        A.e(f"v_cvt_f64_u32 v[{V['RUN1']}:{V['RUN1'] + 1}], v61")
-    A.e(f"s_lshl_b32 {t(0)}, {s('w')}, 9")
+    A.e(f"s_lshl_b32 {t(0)}, {s('w')}, 8")
     A.e(f"s_add_i32 {t(0)}, {t(0)}, {s('oFin')}")
-    A.e(f"v_lshl_add_u32 v60, {v('FROW')}, 3, {t(0)}")
+    A.e(f"v_lshl_add_u32 {v('TV')}, {v('FROW')}, 3, {t(0)}")
     A.e(f"v_cmp_eq_u32 vcc, 0, {v('FKG')}")
     A.e(f"s_and_saveexec_b64 {t2(16)}, vcc")
-    A.e(f"ds_write_b64 v60, v[{V['RUN0']}:{V['RUN0'] + 1}]")
-    A.e(f"ds_write_b64 v60, v[{V['RUN1']}:{V['RUN1'] + 1}] offset:256")
+    A.e(f"ds_write_b64 {v('TV')}, {vr('RUN', 0, 2)}")
     A.e(f"s_mov_b64 exec, {t2(16)}")
     A.e("s_waitcnt lgkmcnt(0)")
-    A.label("Ldbgend")
     return A
-
-
-import re
 
 
 def _sgprs(text):
@@ -997,6 +802,9 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     A = program()
     A.lines = hazard_pass(A.lines)
+    used_v = max(int(n) for ln in A.lines if not ln.startswith(";") for n in re.findall(r"(?<![a-z_\d])v\[?(\d+)", ln))
+    used_v2 = max([int(b) for ln in A.lines if not ln.startswith(";") for _, b in re.findall(r"v\[(\d+):(\d+)\]", ln)] + [0])
+    assert max(used_v, used_v2) < 128, f"VGPR budget exceeded: v{max(used_v, used_v2)}"
     out = os.path.join(root, "adalog_amd", "csrc", f"fused_loop_nrb{NRB}_s{FNS}.inc")
     with open(out, "w") as f:
         f.write(f"// GENERATED by tools/gen_fused_asm.py (NRB = {NRB}, FNS = {FNS}) -- do not edit.\n")
@@ -1009,7 +817,7 @@ def main():
     with open(out.replace(".inc", ".lst"), "w") as f:
         f.write("\n".join(A.lines) + "\n")
     n_mfma = sum(1 for l in A.lines if l.startswith("v_mfma"))
-    print(f"{out}: {len(A.lines)} lines, {n_mfma} MFMAs")
+    print(f"{out}: {len(A.lines)} lines, {n_mfma} MFMAs, highest VGPR v{max(used_v, used_v2)}")
 
 
 if __name__ == "__main__":
