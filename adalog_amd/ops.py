@@ -125,6 +125,11 @@ def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr:
     G, R, K, sg, sr, sk = _view3(x3)
     scale, zero_point = _f32c(scale, "scale"), _f32c(zero_point, "zero_point")
     Kp = pad_k(K, dtype, k_align)
+    if _torch_ops.available():
+        out, rowsum = _top("pack_uniform", x3, scale, zero_point, int(C), int(pc), int(gmod), int(pg), int(pr), int(n_bits),
+                           int(dtype), int(Kp), bool(want_rowsum), bool(c_inner))
+        out.k_valid = K
+        return (out, rowsum) if want_rowsum else out
     shape = (1, G, R * C, Kp) if c_inner else (C, G, R, Kp)
     out = torch.empty(shape, dtype=_TORCH_DT[dtype], device=x3.device)
     rowsum = torch.empty((C, G, R), dtype=torch.int32, device=x3.device) if want_rowsum else None
@@ -140,6 +145,11 @@ def pack_adalog(x3, scale, qv, C: int, pc: int, gmod: int, pg: int, n_bits: int,
                 clamp_u: bool = True, c_inner: bool = False, k_align: int = 128):
     G, R, K, sg, sr, sk = _view3(x3)
     Kp = pad_k(K, BF16, k_align)
+    if _torch_ops.available():
+        out = _top("pack_adalog", x3, _f32c(scale, "scale"), _f32c(qv, "qv"), int(C), int(pc), int(gmod), int(pg), int(n_bits),
+                   _f32c(mant37, "mant37"), None if shift is None else _f32c(shift, "shift"), bool(clamp_u), int(Kp), bool(c_inner))
+        out.k_valid = K
+        return out
     out = torch.empty((1, G, R * C, Kp) if c_inner else (C, G, R, Kp), dtype=torch.bfloat16, device=x3.device)
     rc = _lib.load().adalog_pack_adalog_bf16(x3.data_ptr(), G, R, K, sg, sr, sk, _ptr(_f32c(scale, "scale")),
                                             _ptr(_f32c(qv, "qv")), C, pc, gmod, pg, int(n_bits),
@@ -216,6 +226,13 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     sRg = 0 if G == 1 else ref.shape[-1] * ref.shape[-2]
     reduce_cols = 0 if keep_n else 1                    # column axis not kept: the kernel may sum it (per tile / per workgroup)
     k_valid = min(getattr(A, "k_valid", Kp), getattr(B, "k_valid", Kp))
+    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
+        return _top("gemm_score", int(dtype), A, B, int(M), int(N), int(C), int(G), int(gmod), int(k_valid), ref, sa.t, sa.c, sa.g,
+                    float(sa_mul), sb.t, sb.c, sb.g, sb.n, None if bias is None else bias.t, 0 if bias is None else bias.c,
+                    0 if bias is None else bias.g, 0 if bias is None else bias.n, bool(keep_h), bool(keep_n), float(norm),
+                    int(ref_div), int(order), bool(ref_transposed),
+                    None if row_scale is None else _f32c(row_scale, "row_scale"),
+                    None if row_bias is None else _f32c(row_bias, "row_bias"))
     n_part, MT, Npad, mode = _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid, ref_transposed)
     partial = torch.empty((n_part + 1) // 2, dtype=torch.float64, device=A.device).view(torch.float32)   # 8-byte aligned
     if GEMM_EVENTS is not None:
@@ -350,6 +367,13 @@ def topk_next(scores, scale, zp, third, k: int, new_cnt: int, lin, delta, clamp_
     scores, scale = _f32c(scores, "scores"), _f32c(scale, "scale")
     P, cols = scores.shape
     rows = k * new_cnt if new_cnt > 0 else 1
+    if _torch_ops.available():
+        o_s, o_z, o_t = _top("topk_next", scores, scale, zp, third, int(k), int(new_cnt), lin, delta, clamp_min is not None,
+                             float(clamp_min if clamp_min is not None else 0.0))
+        o_z, o_t = (None if zp is None else o_z), (None if third is None else o_t)
+        if new_cnt == 0:
+            return o_s[0], (None if o_z is None else o_z[0]), (None if o_t is None else o_t[0])
+        return o_s, o_z, o_t
     mk = lambda src: None if src is None else torch.empty((rows, cols), dtype=torch.float32, device=scale.device)
     o_s, o_z, o_t = mk(scale), mk(zp), mk(third)
     rc = _lib.load().adalog_topk_next(scores.data_ptr(), P, cols, int(k), scale.data_ptr(), _ptr(zp), _ptr(third),
@@ -380,6 +404,8 @@ def score_w_self(w2, scale, zp, n_bits: int):
     w2 = _f32c(w2, "weight")
     rows, I = w2.shape
     P = scale.shape[0]
+    if _torch_ops.available():
+        return _top("score_w_self", w2, _f32c(scale, "scale"), _f32c(zp, "zp"), int(n_bits))
     scores = torch.empty((P, rows), dtype=torch.float32, device=w2.device)
     rc = _lib.load().adalog_score_w_self(w2.data_ptr(), rows, I, _f32c(scale, "scale").data_ptr(),
                                         _f32c(zp, "zp").data_ptr(), P, int(n_bits), scores.data_ptr(), _stream())
@@ -391,6 +417,8 @@ def score_a_self(x2, scale, zp, channel_wise: bool, n_bits: int, norm: float):
     x2 = _f32c(x2, "x")
     rows, I = x2.shape
     P = scale.shape[0]
+    if _torch_ops.available():
+        return _top("score_a_self", x2, _f32c(scale, "scale"), _f32c(zp, "zp"), bool(channel_wise), int(n_bits), float(norm))
     lib = _lib.load()
     n_part = lib.adalog_score_a_self_partial_elems(rows, I, P)
     partial = torch.empty(n_part, dtype=torch.float32, device=x2.device)
