@@ -105,13 +105,18 @@ def pmc_traffic(kernel, workload_is_default):
 def hbm_kernels(ops, dev):
     """Class-E (HBM-bound) kernels of the path at the deit_small / 32-image layer shapes: algorithmic bytes
     over the median event time, against 8 TB/s."""
-    def timeit(fn, reps=5):
+    def timeit(fn, reps=5, inner=10):
+        """median over `reps` of the time of `inner` back-to-back launches / inner (steady-state rate: one launch between two
+        events is mostly launch latency at these sizes: 77 MB is 10 us at 8 TB/s)"""
         fn(); torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); fn(); b.record(); torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b))
+            a.record()
+            for _ in range(inner):
+                fn()
+            b.record(); torch.cuda.synchronize()
+            ts.append(a.elapsed_time(b) / inner)
         return sorted(ts)[len(ts) // 2]
     g = torch.Generator().manual_seed(3)
     M = 32 * 197
