@@ -122,3 +122,27 @@ def test_block_capture_equals_module_capture_on_hip(bits):
     r = CC.case_capture_equivalence(DEV, bits)
     assert r["scales_off"] <= 0.01 * r["scales"], r                # near-tie flips only
     assert abs(r["mse_block"] / r["mse_module"] - 1.0) <= 0.02, r
+
+
+def test_cli_vit_base_calibrate_and_optimize(tmp_path):
+    """BASELINE config 3 in reduced form: vit_base W4A4 `--calibrate --optimize` through the CLI -- calibration of the
+    768-wide model (two-row-tile fused search, K = 768 int8 searches), then BRECQ over every block (HIP-graph replay,
+    fused kernels) over the config's 1024 optimisation images for a few iterations, checkpoints in the reference's naming, reload of the optimised checkpoint."""
+    out = str(tmp_path / "run3")
+    cmd = [sys.executable, os.path.join(ROOT, "test_quant.py"), "--model", "vit_base", "--config",
+           os.path.join(ROOT, "configs", "4bit.py"), "--calibrate", "--optimize", "--calib-size", "32", "--calib-batch-size", "32",
+           "--optim-iters", "24", "--val-size", "32", "--val-batch-size", "32", "--output-dir", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)     # optim_size = 1024 (configs/4bit.py)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    files = os.listdir(out)
+    assert any(f.startswith("vit_base_w4_a4_s4_calibsize_32") for f in files), files
+    opt = [f for f in files if f.startswith("vit_base_w4_a4_s4_optimsize_")]
+    assert opt, files
+    sd = torch.load(os.path.join(out, opt[0]), map_location="cpu")
+    assert sd["blocks.11.mlp.fc2.w_quantizer.scale"].shape == (1, 768, 1)
+    assert not any(k.endswith("alpha") for k in sd)                           # hard rounding committed (block_recon.py:151-157)
+    cmd2 = [sys.executable, os.path.join(ROOT, "test_quant.py"), "--model", "vit_base", "--config",
+            os.path.join(ROOT, "configs", "4bit.py"), "--load-optimize-checkpoint", os.path.join(out, opt[0]),
+            "--test-optimize-checkpoint", "--val-size", "32", "--val-batch-size", "32", "--output-dir", out]
+    r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
