@@ -78,11 +78,12 @@ static int pick_tm(int M, bool scoring) {
 
 struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff, stream, acc, wgs, slab, slab_U, slab_R; int64_t elems; };
 
-// Wide (one workgroup per CU, 192/256-row tile) form of the streaming kernel: long K only -- 16+ K-steps, where the
-// L2 -> LDS path bounds the main loop and the un-overlapped epilogue is < 10 % of a tile.
+// Wide (one workgroup per CU, 192/256-row tile) form of the streaming kernel: from 8 K-steps on, where the L2 -> LDS path
+// bounds the main loop (measured: K = 768 int8 -- vit_base / deit_base -- 0.39 -> 0.44 of peak, a calibration 4.5 % shorter;
+// K = 512 -- swin stage 2 -- +4 %; below that the un-overlapped epilogue of the larger tile costs more than it saves).
 static int pick_wide(int M, int64_t kvalid_bytes) {
     static const int use_wide = getenv("ADALOG_GEMM_WIDE") ? atoi(getenv("ADALOG_GEMM_WIDE")) : 1;
-    static const int min_k = getenv("ADALOG_GEMM_WIDE_MINK") ? atoi(getenv("ADALOG_GEMM_WIDE_MINK")) : 1024;
+    static const int min_k = getenv("ADALOG_GEMM_WIDE_MINK") ? atoi(getenv("ADALOG_GEMM_WIDE_MINK")) : 512;
     if (!use_wide || kvalid_bytes < min_k || M < 192) return 0;
     const int64_t pad4 = (int64_t)cdiv(M, 256) * 256, pad3 = (int64_t)cdiv(M, 192) * 192, pad2 = (int64_t)cdiv(M, 128) * 128;
     const int ri = pad4 <= pad3 + pad3 / 32 ? 4 : 3;                      // 256 rows unless 192 pads > 3 % less
