@@ -9,8 +9,13 @@
 // (9.7 MB) and the bf16 weight image (1.2 MB, L2-resident).
 //
 // Evaluated transposed, like the streaming kernel's activation searches:  D[o, (t, p)] = sum_k Wq[o, k] * v_p(x[t, k]),
-// GEMM rows = output channels, GEMM columns = (token, candidate).  One workgroup = 4 waves, ONE PER SIMD (512 registers
-// each), tile = (32 * NRB) rows x 2 tokens x 128 candidates:
+// GEMM rows = output channels, GEMM columns = (token, candidate), tile = (32 * NRB) rows x 2 tokens x 128 candidates.
+// Two forms of the same algorithm (same LDS tables, same results):
+//   - the shipped one, k_act_fused_asm_* below: EIGHT waves per workgroup (two per SIMD), wave = (token of the pair,
+//     candidate block of 32), NRB accumulator tiles each, hand-scheduled (tools/gen_fused_asm.py, whose header holds the
+//     measured machine model behind that shape);
+//   - the compiler form k_act_fused<NRB, FNS> (ADALOG_FUSED_ASM=0; 4 waves, one per SIMD, 2 x NRB tiles each), described
+//     in the rest of this comment: it is the readable statement of the algorithm and the first correct implementation.
 //   * wave w owns token (w >> 1) and candidate blocks 2 * (w & 1), 2 * (w & 1) + 1: NRB x 2 accumulator tiles of 32 x 32
 //     (NRB = 12: 384 registers).  A lane IS a candidate column: its (37/q_p, log2(s_p) * 37/q_p, clamp) live in registers;
 //   * the B fragments (candidate operand) are produced in registers, straight into MFMA operand layout: a lane needs 8
