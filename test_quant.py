@@ -8,11 +8,13 @@
 parse args -> import Config from the file path -> CLI overrides -> seed -> build model -> wrap -> calibrate (FPCS) ->
 un-wrap channel-wise layers -> reparam_bias -> save checkpoint -> validate -> [--optimize: BRECQ] -> save.
 
-Differences forced by the environment (no network, no timm, no ImageNet on the build/GPU boxes):
+Differences forced by the environment (no network, no timm / torchvision, no ImageNet on the build/GPU boxes):
   * models come from adalog_amd.utils.models (timm-compatible names); `./checkpoints/vit_raw/<timm name>.bin` is loaded
     when present (test_quant.py:181-182), otherwise seeded random-init weights are used;
   * `--dataset synthetic` (default) draws calibration/validation images from torch.randn with the run's seed and
-    reports *fidelity to the FP model* (top-1 agreement, logit SQNR) instead of ImageNet accuracy.
+    reports *fidelity to the FP model* (top-1 agreement, logit SQNR) instead of ImageNet accuracy;
+  * `--dataset <root>` walks an ImageNet folder tree (train/, val/) with adalog_amd.utils.datasets (PIL + a table of the
+    timm data configs: no torchvision) and reports Prec@1 / Prec@5 through adalog_amd.utils.test_utils.validate.
 The output directory is created when main() runs, not at import time (the reference does it on import, test_quant.py:21-29).
 """
 import argparse
@@ -42,7 +44,7 @@ def get_args_parser():
     parser = argparse.ArgumentParser(add_help=False)
     parser.add_argument("--model", default="deit_small", choices=list(MODEL_ZOO), help="model")
     parser.add_argument('--config', type=str, default="./configs/4bit.py", help="File path to import Config class from")
-    parser.add_argument('--dataset', default="synthetic", help="'synthetic' or a path to ImageNet (needs torchvision)")
+    parser.add_argument('--dataset', default="synthetic", help="'synthetic' or the root of an ImageNet folder tree (train/ and val/)")
     parser.add_argument("--calib-size", default=argparse.SUPPRESS, type=int, help="size of calibration set")
     parser.add_argument("--calib-batch-size", default=argparse.SUPPRESS, type=int, help="batchsize of calibration set")
     parser.add_argument("--val-batch-size", default=200, type=int, help="batchsize of validation set")
@@ -131,6 +133,29 @@ def make_loader(images, batch_size, device, shard=True):
     return [(images[i:i + batch_size], None) for i in range(0, images.shape[0], batch_size)]
 
 
+def imagenet_batches(loader, device, shard=True):
+    """materialises a DataLoader as the list of (images on the device, labels) batches the calibrator / BRECQ walk,
+    keeping this rank's shard of the images when several ranks calibrate together"""
+    xs, ys = zip(*[(x, y) for x, y in loader])
+    x, y = torch.cat(xs), torch.cat(ys)
+    bs = xs[0].shape[0]
+    if shard:
+        lo, hi = parallel.shard_slice(x.shape[0])
+        x, y = x[lo:hi], y[lo:hi]
+    x = x.to(device)
+    return [(x[i:i + bs], y[i:i + bs].to(device)) for i in range(0, x.shape[0], bs)]
+
+
+def validate_dataset(loader, model, full_model, device):
+    """top-1 / top-5 of the quantised model on labelled validation data (reference test_utils.validate) next to the FP model's"""
+    from adalog_amd.utils.test_utils import validate
+    crit = nn.CrossEntropyLoss().to(device)
+    _, q1, q5 = validate(loader, model, crit, device=device)
+    _, f1, f5 = validate(loader, full_model, crit, device=device)
+    logging.info(f" * quantised Prec@1 {q1:.3f} Prec@5 {q5:.3f}   (FP model Prec@1 {f1:.3f} Prec@5 {f5:.3f})")
+    return q1, q5
+
+
 @torch.no_grad()
 def validate_fidelity(loader, model, full_model):
     """Synthetic-data stand-in for test_utils.validate: agreement of the quantised model with the FP model."""
@@ -196,11 +221,17 @@ def main(args):
     full_model = copy.deepcopy(model).to(device).eval()
     model.to(device).eval()
 
-    if args.dataset != "synthetic":
-        raise NotImplementedError("ImageNet loading needs torchvision/timm transforms, which are not available here; "
-                                  "use --dataset synthetic (reference: utils/datasets.py)")
     img_size = 384 if args.model.endswith("384") else 224
-    val_loader = make_loader(synthetic_images(args.val_size, args.seed + 1, img_size), args.val_batch_size, device, shard=False)
+    loader_gen = None
+    if args.dataset != "synthetic":
+        # reference test_quant.py:167-171: ViTImageNetLoaderGenerator(root, val_batch_size, num_workers, kwargs={"model": model})
+        from adalog_amd.utils.datasets import ViTImageNetLoaderGenerator
+        loader_gen = ViTImageNetLoaderGenerator(args.dataset, args.val_batch_size, args.num_workers, kwargs={"model": args.model})
+        val_loader = loader_gen.val_loader()
+        validate_any = lambda m: validate_dataset(val_loader, m, full_model, device)
+    else:
+        val_loader = make_loader(synthetic_images(args.val_size, args.seed + 1, img_size), args.val_batch_size, device, shard=False)
+        validate_any = lambda m: validate_fidelity(val_loader, m, full_model)
 
     reparam = args.load_calibrate_checkpoint is None and args.load_optimize_checkpoint is None
     logging.info('Wraping quantiztion modules (reparam: {}) ...'.format(reparam))
@@ -212,10 +243,14 @@ def main(args):
             logging.info(f"Restoring checkpoint from '{args.load_calibrate_checkpoint}'")
             model = load_model(model, args.load_calibrate_checkpoint, device)
             if args.test_calibrate_checkpoint:
-                validate_fidelity(val_loader, model, full_model)
+                validate_any(model)
         else:
             logging.info("{} - start calibration".format(get_cur_time()))
-            calib_loader = make_loader(synthetic_images(cfg.calib_size, args.seed, img_size), cfg.calib_batch_size, device)
+            if loader_gen is not None:
+                calib_loader = imagenet_batches(loader_gen.calib_loader(num=cfg.calib_size, batch_size=cfg.calib_batch_size,
+                                                                        seed=args.seed), device)
+            else:
+                calib_loader = make_loader(synthetic_images(cfg.calib_size, args.seed, img_size), cfg.calib_batch_size, device)
             t0 = time.perf_counter()
             calibrator = QuantCalibrator(model, calib_loader)
             calibrator.batching_quant_calib()
@@ -230,12 +265,16 @@ def main(args):
                 finish_training(model)
             save_model(model, args, cfg, root_path, mode='calibrate')
             logging.info('Validating after calibration ...')
-            validate_fidelity(val_loader, model, full_model)
+            validate_any(model)
 
     if args.optimize:
         from adalog_amd.utils.block_recon import BlockReconstructor
         logging.info('Building calibrator ...')
-        calib_loader = make_loader(synthetic_images(cfg.optim_size, args.seed, img_size), cfg.optim_batch_size, device)
+        if loader_gen is not None:
+            calib_loader = imagenet_batches(loader_gen.calib_loader(num=cfg.optim_size, batch_size=cfg.optim_batch_size,
+                                                                    seed=args.seed), device)
+        else:
+            calib_loader = make_loader(synthetic_images(cfg.optim_size, args.seed, img_size), cfg.optim_batch_size, device)
         logging.info("{} - start block reconstruction".format(get_cur_time()))
         block_reconstructor = BlockReconstructor(model, full_model, calib_loader)
         block_reconstructor.reconstruct_model(quant_act=cfg.train_act, keep_gpu=cfg.keep_gpu, iters=args.optim_iters)
@@ -246,7 +285,7 @@ def main(args):
         model = load_model(model, args.load_optimize_checkpoint, device)
     if args.optimize or args.test_optimize_checkpoint:
         logging.info('Validating after block reconstruction ...')
-        validate_fidelity(val_loader, model, full_model)
+        validate_any(model)
     logging.info("{} - finished the process.".format(get_cur_time()))
     if world > 1:
         import torch.distributed as dist

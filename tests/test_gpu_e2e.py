@@ -146,3 +146,27 @@ def test_cli_vit_base_calibrate_and_optimize(tmp_path):
             "--test-optimize-checkpoint", "--val-size", "32", "--val-batch-size", "32", "--output-dir", out]
     r2 = subprocess.run(cmd2, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-4000:]
+
+
+def test_cli_dataset_folder_calibrate_and_validate(tmp_path):
+    """`--dataset <ImageNet-style folder>`: the reference's loader / validate path (utils/datasets.py, utils/test_utils.py)
+    on a generated toy folder -- calibration subset drawn from train/, Prec@1 / Prec@5 on val/."""
+    import numpy as np
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    root = tmp_path / "toy_imagenet"
+    for split, per in (("train", 6), ("val", 3)):
+        for ci in range(4):
+            d = root / split / f"n{ci:04d}"
+            d.mkdir(parents=True)
+            for j in range(per):
+                Image.fromarray((rng.rand(70 + 8 * j, 96 - 5 * ci, 3) * 255).astype(np.uint8)).save(d / f"img{j}.jpg")
+    out = str(tmp_path / "run4")
+    cmd = [sys.executable, os.path.join(ROOT, "test_quant.py"), "--model", "deit_tiny", "--config",
+           os.path.join(ROOT, "configs", "4bit.py"), "--dataset", str(root), "--calibrate", "--calib-size", "16",
+           "--calib-batch-size", "8", "--val-batch-size", "4", "--num-workers", "0", "--output-dir", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    text = r.stdout + r.stderr
+    assert "Prec@1" in text and "FP model Prec@1" in text
+    assert os.path.exists(os.path.join(out, "deit_tiny_w4_a4_s4_calibsize_16.pth"))
