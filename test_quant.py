@@ -176,10 +176,15 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
-        if args.device.startswith("cuda"):
+        # RCCL ("nccl") is the product path.  ADALOG_DIST_BACKEND=gloo lets several ranks share ONE GPU (a functional check
+        # of the sharded path on a single-GPU box: the collectives then stage through the host)
+        be_name = os.environ.get("ADALOG_DIST_BACKEND", "nccl")
+        if args.device.startswith("cuda") and be_name == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
+            if args.device.startswith("cuda"):
+                torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
             dist.init_process_group(backend="gloo")
     root_path = args.output_dir or './checkpoints/quant_result/{}'.format(datetime.now().strftime("%Y%m%d_%H%M"))
     if parallel.rank() == 0:
@@ -204,7 +209,8 @@ def main(args):
         logging.info(f"{name}: {value}")
 
     if args.device.startswith('cuda'):
-        device = torch.device('cuda', local_rank if world > 1 else (int(args.device.split(':')[1]) if ':' in args.device else 0))
+        device = torch.device('cuda', (local_rank % max(1, torch.cuda.device_count())) if world > 1
+                              else (int(args.device.split(':')[1]) if ':' in args.device else 0))
         torch.cuda.set_device(device)
     else:
         device = torch.device(args.device)

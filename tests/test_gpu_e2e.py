@@ -170,3 +170,34 @@ def test_cli_dataset_folder_calibrate_and_validate(tmp_path):
     text = r.stdout + r.stderr
     assert "Prec@1" in text and "FP model Prec@1" in text
     assert os.path.exists(os.path.join(out, "deit_tiny_w4_a4_s4_calibsize_16.pth"))
+
+
+def test_cli_swin_base_w3a3_sharded_over_two_ranks(tmp_path):
+    """BASELINE config 4 in reduced form: swin_base W3A3 `--calibrate` with the calibration images SHARDED over the ranks
+    of a torch.distributed.run launch (score all-reduce per search step, quantile statistics all-gathered) -- two ranks
+    sharing this box's one GPU over gloo (RCCL needs one GPU per rank); rank 0 writes the checkpoint."""
+    out = str(tmp_path / "run5")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(ROOT, "test_quant.py"), "--model", "swin_base", "--config",
+           os.path.join(ROOT, "configs", "3bit.py"), "--calibrate", "--calib-size", "32", "--calib-batch-size", "16",
+           "--val-size", "16", "--val-batch-size", "16", "--output-dir", out]
+    env = dict(os.environ, ADALOG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    ckpt = os.path.join(out, "swin_base_w3_a3_s3_calibsize_32.pth")
+    assert os.path.exists(ckpt)
+    sd = torch.load(ckpt, map_location="cpu")
+    assert sd["layers.0.blocks.0.attn.qkv.w_quantizer.scale"].shape == (3, 128, 1)
+    assert "on 2 GPU(s)" in r.stdout + r.stderr
+
+
+def test_cli_deit_base_w3a3_calibrate(tmp_path):
+    """BASELINE config 5's model and bit width on one GPU (its eight-GPU / BRECQ parts are covered by the sharded and the
+    --optimize tests above): deit_base W3A3 --calibrate."""
+    out = str(tmp_path / "run6")
+    cmd = [sys.executable, os.path.join(ROOT, "test_quant.py"), "--model", "deit_base", "--config",
+           os.path.join(ROOT, "configs", "3bit.py"), "--calibrate", "--calib-size", "32", "--calib-batch-size", "32",
+           "--val-size", "32", "--val-batch-size", "32", "--output-dir", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert os.path.exists(os.path.join(out, "deit_base_w3_a3_s3_calibsize_32.pth"))
