@@ -167,50 +167,52 @@ class BlockReconstructor(QuantCalibrator):
             if a_scheduler is not None:
                 a_scheduler.step()
 
-        for it in range(iters):
-            idx = torch.randperm(n_local, generator=gen)[:local_bs].to(block.raw_input.device)
-            if not use_graph or it < 3:                  # eager (and the warm-up iterations before the capture)
-                eager_step(block.raw_input[idx].to(device), block.raw_out[idx].to(device))
-                continue
-            if graph is None:
-                static_inp, static_out = block.raw_input[idx].to(device).clone(), block.raw_out[idx].to(device).clone()
-                b_dev = torch.zeros(1, dtype=torch.float32, device=device)
-                rw_dev = torch.zeros(1, dtype=torch.float32, device=device)
-            else:
-                if block.raw_input.device == static_inp.device:
-                    torch.index_select(block.raw_input, 0, idx, out=static_inp)
-                    torch.index_select(block.raw_out, 0, idx, out=static_out)
-                else:                                        # keep_gpu=False: block data lives on the host
-                    static_inp.copy_(block.raw_input[idx])
-                    static_out.copy_(block.raw_out[idx])
-            active = loss_func.advance()                 # iteration counter, b of this iteration
-            b_dev.fill_(float(loss_func.b))
-            rw_dev.fill_(1.0 if active else 0.0)
-            if graph is None:
-                for prm in params:
-                    prm.grad = None
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    static_rec = loss_func.rec_term(block(static_inp), static_out)
-                    static_rnd = (loss_func.round_sum(b_dev) * rw_dev).sum()
-                    (static_rec + static_rnd).backward()
-                    if full_graph:
-                        optim_steps()
-            graph.replay()                               # grads are overwritten, not accumulated (none existed at capture)
-            if not full_graph:
-                for prm in params:
-                    if prm.grad is not None:
-                        parallel.all_reduce_sum(prm.grad)
-                        prm.grad.div_(ws)
-                optim_steps()
-            if a_scheduler is not None:
-                a_scheduler.step()
-            loss_func.log(static_rec, static_rnd)
-        graph = None
-        torch.backends.cuda.matmul.allow_tf32 = prev_tf32
-        for prm in frozen:
-            prm.requires_grad_(True)
+        try:
+            for it in range(iters):
+                idx = torch.randperm(n_local, generator=gen)[:local_bs].to(block.raw_input.device)
+                if not use_graph or it < 3:                  # eager (and the warm-up iterations before the capture)
+                    eager_step(block.raw_input[idx].to(device), block.raw_out[idx].to(device))
+                    continue
+                if graph is None:
+                    static_inp, static_out = block.raw_input[idx].to(device).clone(), block.raw_out[idx].to(device).clone()
+                    b_dev = torch.zeros(1, dtype=torch.float32, device=device)
+                    rw_dev = torch.zeros(1, dtype=torch.float32, device=device)
+                else:
+                    if block.raw_input.device == static_inp.device:
+                        torch.index_select(block.raw_input, 0, idx, out=static_inp)
+                        torch.index_select(block.raw_out, 0, idx, out=static_out)
+                    else:                                        # keep_gpu=False: block data lives on the host
+                        static_inp.copy_(block.raw_input[idx])
+                        static_out.copy_(block.raw_out[idx])
+                active = loss_func.advance()                 # iteration counter, b of this iteration
+                b_dev.fill_(float(loss_func.b))
+                rw_dev.fill_(1.0 if active else 0.0)
+                if graph is None:
+                    for prm in params:
+                        prm.grad = None
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        static_rec = loss_func.rec_term(block(static_inp), static_out)
+                        static_rnd = (loss_func.round_sum(b_dev) * rw_dev).sum()
+                        (static_rec + static_rnd).backward()
+                        if full_graph:
+                            optim_steps()
+                graph.replay()                               # grads are overwritten, not accumulated (none existed at capture)
+                if not full_graph:
+                    for prm in params:
+                        if prm.grad is not None:
+                            parallel.all_reduce_sum(prm.grad)
+                            prm.grad.div_(ws)
+                    optim_steps()
+                if a_scheduler is not None:
+                    a_scheduler.step()
+                loss_func.log(static_rec, static_rnd)
+        finally:                                         # (also when an iteration raises: leave the block as it was found)
+            graph = None
+            torch.backends.cuda.matmul.allow_tf32 = prev_tf32
+            for prm in frozen:
+                prm.requires_grad_(True)
         for _, module in block.named_modules():
             if hasattr(module, 'w_quantizer'):
                 module.w_quantizer.soft_targets = False
