@@ -144,11 +144,12 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
 }
 
 // Launch-time choice of the group kernel (it shares the streaming kernel's accumulator layout, so the layout query does
-// not need to know): int8 or fp8, one K-step, 5..7 row blocks, many groups, plain column factors.
+// not need to know): int8 or fp8, one K-step, 5..7 row blocks, many groups (up to 16 heads per image: the per-head fp64
+// sums live in LDS), plain column factors.
 static bool grp_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
                    const float* row_scale, int64_t sb_n, int64_t ref_cs) {
     static const int use_grp = getenv("ADALOG_GEMM_GRP") ? atoi(getenv("ADALOG_GEMM_GRP")) : 1;
-    return use_grp && (dtype == 0 || dtype == 3) && kvalid_bytes <= BK3 && M > 128 && M <= 224 && G >= 8 && gmod <= 8 && !bias && !row_scale &&
+    return use_grp && (dtype == 0 || dtype == 3) && kvalid_bytes <= BK3 && M > 128 && M <= 224 && G >= 8 && gmod <= 16 && !bias && !row_scale &&
            sb_n == 0 && (ref_div == 64 || ref_div == 128 || ref_div == 256) && N % ref_div == 0 &&
            (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
 }
@@ -157,7 +158,7 @@ static bool grp_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_
 static bool grpk_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
                     const float* row_scale, int64_t sb_n, int64_t ref_cs) {
     static const int use_grp = getenv("ADALOG_GEMM_GRP") ? atoi(getenv("ADALOG_GEMM_GRP")) : 1;
-    return use_grp && dtype == 1 && kvalid_bytes > 6 * BK3 && kvalid_bytes <= 7 * BK3 && M > 128 && M <= 224 && G >= 8 && gmod <= 8 &&
+    return use_grp && dtype == 1 && kvalid_bytes > 6 * BK3 && kvalid_bytes <= 7 * BK3 && M > 128 && M <= 224 && G >= 8 && gmod <= 16 &&
            !bias && !row_scale && sb_n == 0 && (ref_div == 64 || ref_div == 128 || ref_div == 256) && N % ref_div == 0 &&
            (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
 }
@@ -262,7 +263,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
             static bool attr_set = false;                                                                         \
             if (!attr_set) {                                                                                      \
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_grp<NJV, DTV>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                 \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
             adalog_note_kernel(DTV == 3 ? "k_gemm_grp<fp8>" : "k_gemm_grp<i8>");                                   \
