@@ -294,9 +294,14 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
 #undef LAUNCH_GRPK
     } else if (L.stream && !out) {
         // persistent streaming kernel: two (wide form: one) workgroups per CU walk the tile list
-        {   // m-tiles per L2 group: A rows of one group <= 2 MiB (half of an XCD's L2)
+        {   // m-tiles per group: the group's A rows are re-read once per n-tile (from L2 / the 256 MiB Infinity Cache), the B
+            // tiles stream from HBM once per GROUP -- with the candidate operand at 150..600 MB per launch that stream is
+            // what must not repeat: groups of <= 8 MiB of A rows (2 MiB, half of an XCD's L2, re-read vit_base's fc2
+            // candidates 25 times: 4.16 -> 4.05 s per calibration, 3.99 at 64 MiB; deit_small -- its operand fits the
+            // Infinity Cache -- is indifferent up to 16 MiB and 2 % slower at 64)
+            static const int64_t grp_bytes = getenv("ADALOG_GEMM_GM_BYTES") ? atoll(getenv("ADALOG_GEMM_GM_BYTES")) : ((int64_t)8 << 20);
             const int64_t a_tile = (int64_t)64 * L.tm * p.Kb;
-            int64_t gm = ((int64_t)2 << 20) / a_tile;
+            int64_t gm = grp_bytes / a_tile;
             if (const char* e = getenv("ADALOG_GEMM_GM")) gm = atoi(e);
             p.gm = (int)(gm < 1 ? 1 : gm > L.MT ? L.MT : gm);
         }
