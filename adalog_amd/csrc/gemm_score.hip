@@ -163,6 +163,17 @@ static bool grpk_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64
            (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
 }
 
+// ... and of the window kernel: int8 or fp8, one K-step, at most 64 rows, hundreds of groups or more, at least as many waves as
+// heads per image (every participating wave owns one head).
+static bool win_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
+                   const float* row_scale, int64_t sb_n, int64_t ref_cs, int wgs) {
+    static const int use_win = getenv("ADALOG_GEMM_WIN") ? atoi(getenv("ADALOG_GEMM_WIN")) : 1;
+    const int n_eff = ref_div > 0 ? N / ref_div : 0;
+    return use_win && (dtype == 0 || dtype == 3) && kvalid_bytes <= BK3 && M >= 4 && M <= 64 && G >= 256 && gmod <= 32 && !bias &&
+           !row_scale && sb_n == 0 && (ref_div == 64 || ref_div == 128 || ref_div == 256) && N % ref_div == 0 && n_eff <= 64 &&
+           wgs * 4 >= gmod && ref_cs >= M;
+}
+
 // M, N: GEMM rows / columns (N includes the candidate factor when ref_div > 1).  Outputs the partial-buffer layout
 // [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
 extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype,
@@ -176,6 +187,15 @@ extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod
     return L.elems;
 }
 
+// 1 when a scoring launch of this shape runs on the window kernel, i.e. when int8 / fp8 operands of K <= 32 may be packed
+// with 32-byte rows (half the operand bytes of the 64-byte K-step padding).  C = 1, reduce_cols = 1, transposed reference.
+extern "C" int adalog_gemm_win_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t k_valid) {
+    const int esz = 1;
+    if (!(dtype == 0 || dtype == 3) || k_valid > 32 || ref_div < 1 || N % ref_div != 0) return 0;
+    const Layout L = layout_of(M, N, 1, G, gmod, ref_div, 1, true, k_valid * esz, 32 * esz, true, dtype);
+    return (L.stream && L.acc && win_ok(dtype, M, N, G, gmod, ref_div, k_valid * esz, nullptr, nullptr, 0, M, L.wgs)) ? 1 : 0;
+}
+
 extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
                                  int64_t sBg, int M, int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref,
                                  int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c,
@@ -187,7 +207,8 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 3, "gemm_score: dtype must be 0 (i8), 1 (bf16), 2 (f32) or 3 (fp8 e4m3)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
     const int esz = (dtype == 0 || dtype == 3) ? 1 : dtype == 1 ? 2 : 4;
-    ADALOG_ARG_CHECK((Kp * esz) % BK3 == 0 && Kp > 0, "gemm_score: padded K must be a multiple of 64 bytes");
+    ADALOG_ARG_CHECK(Kp > 0 && ((Kp * esz) % BK3 == 0 || (Kp * esz == 32 && (dtype == 0 || dtype == 3))),
+                     "gemm_score: padded K must be a multiple of 64 bytes (32-byte rows: int8 / fp8, window kernel only)");
     ADALOG_ARG_CHECK((partial != nullptr) == (ref != nullptr), "gemm_score: partial and ref go together");
     ADALOG_ARG_CHECK(partial || out, "gemm_score: nothing to produce");
     ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
@@ -220,6 +241,8 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     static const int use_glds = getenv("ADALOG_GEMM_GLDS") ? atoi(getenv("ADALOG_GEMM_GLDS")) : 1;   // LDS-DMA pipeline (default on)
     ADALOG_ARG_CHECK((Kp * esz) % BK2 == 0 || (L.stream && !out),
                      "gemm_score: rows padded to 64 (not 128) bytes are taken by the streaming search kernel only");
+    ADALOG_ARG_CHECK((Kp * esz) % BK3 == 0 || (L.stream && !out && L.acc && win_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs, L.wgs)),
+                     "gemm_score: 32-byte rows are taken by the window kernel only (adalog_gemm_win_ok)");
     ADALOG_ARG_CHECK(dtype != 3 || (L.stream && !out), "gemm_score: fp8 operands are taken by the streaming search kernel only (ref_div 64/128/256, transposed reference)");
     if (L.slab && !out) {
         // slab kernel: one workgroup per CU, each takes a contiguous range of (slab, unit) pairs
@@ -251,6 +274,25 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         if (dtype == 3) LAUNCH_SLAB_DT(3); else LAUNCH_SLAB_DT(0);
 #undef LAUNCH_SLAB_DT
 #undef LAUNCH_SLAB
+    } else if (L.stream && !out && L.acc && win_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs, L.wgs)) {
+        // window kernel (swin attention searches): a wave per group, same accumulator layout and workgroup count
+        const int n_eff = N / ref_div;
+        const size_t ref_lds = (size_t)4 * n_eff * 64 * 4, acc_lds = (size_t)gmod * 256 * 8;
+        const size_t shm = ref_lds > acc_lds ? ref_lds : acc_lds;
+#define LAUNCH_WIN(NJV, DTV)                                                                                      \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<NJV, DTV>),                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            adalog_note_kernel(DTV == 3 ? "k_gemm_win<fp8>" : "k_gemm_win<i8>");                                   \
+            hipLaunchKernelGGL((k_gemm_win<NJV, DTV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);             \
+        } while (0)
+        if (dtype == 3) { if (ref_div == 64) LAUNCH_WIN(2, 3); else if (ref_div == 128) LAUNCH_WIN(4, 3); else LAUNCH_WIN(8, 3); }
+        else { if (ref_div == 64) LAUNCH_WIN(2, 0); else if (ref_div == 128) LAUNCH_WIN(4, 0); else LAUNCH_WIN(8, 0); }
+#undef LAUNCH_WIN
     } else if (L.stream && !out && L.acc && grp_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs)) {
         // group kernel (q.k^T searches): same accumulator layout and workgroup count as the streaming kernel
         const int NB = N / 32;

@@ -488,8 +488,12 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
     ADALOG_ARG_CHECK(x && scale && zero_point && out, "pack_uniform: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_uniform: bad sizes");
     ADALOG_ARG_CHECK(out_dtype != 3 || n_bits <= 4, "pack_uniform: fp8 output holds q - z exactly only for n_bits <= 4");
-    ADALOG_ARG_CHECK(Kp >= K && (Kp * ((out_dtype == 0 || out_dtype == 3) ? 1 : out_dtype == 1 ? 2 : 4)) % 64 == 0,
-                     "pack_uniform: Kp must cover K and be a multiple of 64 bytes (128 for anything but the search kernel)");
+    {
+        const int64_t row_bytes = Kp * ((out_dtype == 0 || out_dtype == 3) ? 1 : out_dtype == 1 ? 2 : 4);
+        // 32-byte rows: int8 / fp8 operands of K <= 32 for the window kernel only (adalog_gemm_score checks its side)
+        ADALOG_ARG_CHECK(Kp >= K && (row_bytes % 64 == 0 || (row_bytes == 32 && (out_dtype == 0 || out_dtype == 3))),
+                         "pack_uniform: Kp must cover K and be a multiple of 64 bytes (128 for anything but the search kernels)");
+    }
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "pack_uniform: n_bits must be in [2,7] (q - z must fit int8)");
     hipStream_t st = (hipStream_t)stream;
     PackArgs a{};

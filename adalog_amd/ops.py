@@ -262,6 +262,12 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     return scores
 
 
+def gemm_win_ok(dtype: int, M: int, N: int, G: int, gmod: int, ref_div: int, k_valid: int) -> bool:
+    """True when gemm_score (C = 1, candidates innermost, transposed reference, column axis summed) runs this shape on the
+    window kernel: int8 / fp8 operands of K <= 32 may then be packed with 32-byte rows (``k_align=32``)."""
+    return bool(_lib.load().adalog_gemm_win_ok(int(dtype), int(M), int(N) * int(ref_div), int(G), int(gmod), int(ref_div), int(k_valid)))
+
+
 def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, sb: Strided, bias: Optional[Strided],
              sa_mul: float = 1.0):
     """Quantised forward: out[g] = (A[g] . B[g]^T) * sa * sb[n] + bias[n]   -> fp32 [G, M, N]."""

@@ -147,19 +147,27 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         return quantizer.scale.data.view(-1), quantizer.zero_point.data.view(-1)
 
     # ------------------------------------------------------------------ scoring calls
-    def _kalign(self):
+    def _kalign(self, dt=None):
         """Row padding (bytes) of the operands packed for the searches: 64 when every scoring call takes all candidates in one
         launch of the streaming kernel (whose K-step is 64 bytes: q.k^T with head_dim 64 then packs and reads half the
-        bytes), else the general 128."""
+        bytes), else the general 128.  32 for int8 / fp8 operands of K <= 32 that the window kernel takes (swin's
+        49 x 49 x 32 windows: these launches stream 0.8 GB of candidate operand, half of it padding at 64)."""
         G, S, K, Sp = self._dims()
-        whole = self._cand_chunk(G * max(S, Sp) * pad_k(K, BF16, 64) * 2) >= self.eq_n
-        return 64 if whole and self.eq_n in (64, 128, 256) else 128
+        if self.eq_n not in (64, 128, 256):
+            return 128
+        if dt in (I8, FP8) and K <= 32 and self._cand_chunk(G * max(S, Sp) * 32) >= self.eq_n:
+            be, H = backend.get(), self._heads()
+            if be.gemm_win_ok(dt, Sp, S, G, H, self.eq_n, K) and be.gemm_win_ok(dt, S, Sp, G, H, self.eq_n, K):
+                return 32
+        esz = 1 if dt in (I8, FP8) else 2
+        whole = self._cand_chunk(G * max(S, Sp) * pad_k(K, BF16 if esz == 2 else I8, 64) * esz) >= self.eq_n
+        return 64 if whole else 128
 
     def _pack_fixed(self, which, dt=I8):
         be = backend.get()
         H = self._heads()
         A, B = self.raw_input
-        al = self._kalign()
+        al = self._kalign(dt)
         if which == "A":
             s, z = self._q_params(self.A_quantizer)
             return be.pack_uniform(self._a3(A), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.A_quantizer.n_bits, dt, k_align=al)
@@ -183,7 +191,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         bits = self.A_quantizer.n_bits if which == "A" else self.B_quantizer.n_bits
         rows = S if which == "A" else Sp
         esz = 2 if dt == BF16 else 1
-        al = self._kalign()
+        al = self._kalign(dt)
         chunk = self._cand_chunk(G * rows * pad_k(K, dt, al) * esz)
         pg = 1 if H > 1 else 0
         out = []

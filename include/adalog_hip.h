@@ -121,6 +121,10 @@ int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_d
  *   Linear act. search    keep_n=0 -> [P]      (linear.py:415-424, norm = 1/(T*O))
  *   MatMul per head       keep_h=1 -> [P][H]   (matmul.py:154-164, norm = 1/(S*S'))
  *   post-softmax base     none     -> [P]      (matmul.py:345-352, norm = 1/(H*S*S')) */
+/* 1 when a scoring launch of this shape (C = 1, reduce_cols = 1, transposed reference) runs on the window kernel -- many
+ * small groups of <= 64 rows with one K-step, e.g. swin's 49 x 49 x 32 attention windows (reference matmul.py:135-209 on
+ * window attention) -- in which case int8 / fp8 operands of K <= 32 may be packed with 32-byte rows (Kp = 32). */
+int adalog_gemm_win_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t k_valid);
 int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
                          int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes, void* stream);
 /* Scratch for the two-stage form used when cand_inner = 1 and keep_n = 0 (sums of 10^4..10^5 terms per candidate): bytes

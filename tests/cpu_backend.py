@@ -395,3 +395,7 @@ def round_loss_multi(alphas, b, weight):
         total = total + round_loss(al, bb, galpha=g_, gscale=weight)
         grads.append(g_)
     return (total * weight).view(1), grads
+
+
+def gemm_win_ok(dtype, M, N, G, gmod, ref_div, k_valid):
+    return False                                       # the CPU stand-in has one GEMM path: 64-byte rows everywhere
