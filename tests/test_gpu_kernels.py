@@ -657,6 +657,42 @@ def test_gemm_group_kernel(ops, dtype, P):
             assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, G, K, keep_h, rel_err(got.cpu(), want))
 
 
+@pytest.mark.parametrize("dtype", ["i8", "fp8"])
+@pytest.mark.parametrize("P", [64, 128])
+def test_gemm_window_kernel(ops, dtype, P):
+    """Window kernel (attention searches of windowed models: <= 64 rows, one K-step, hundreds of (window, head) groups; a wave
+    per group, 32-byte rows when K <= 32): two / one row blocks, ragged rows and K, head counts that do and do not divide the
+    wave count, head-wise and tensor-wise scores -- against the CPU specification."""
+    gen = g(7400 + P)
+    dt_c, dt_o = {"i8": (CB.I8, ops.I8), "fp8": (CB.FP8, ops.FP8)}[dtype]
+    tdt = {"i8": torch.int8, "fp8": torch.float8_e4m3fn}[dtype]
+    for M, Ncols, G, K, gmod in ((49, 49, 512, 32, 4), (49, 49, 384, 32, 3), (33, 17, 300, 20, 6), (64, 64, 256, 32, 32), (20, 9, 320, 64, 8)):
+        use32 = K <= 32 and ops.gemm_win_ok(dt_o, M, Ncols, G, gmod, P, K)
+        assert ops.gemm_win_ok(dt_o, M, Ncols, G, gmod, P, K) == (K <= 32)          # (the query is about 32-byte rows)
+        Kp = 32 if use32 else CB.pad_k(K, dt_c, 64)
+        A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
+        A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).float().to(tdt)
+        B[..., :K] = torch.randint(-15, 16, (1, G, Ncols * P, K), generator=gen).float().to(tdt)
+        ref = torch.randn(G, Ncols, M, generator=gen) * 3                      # stored [G, N, M] (transposed)
+        sa = torch.rand(gmod, generator=gen) * 0.02 + 0.01
+        sb = torch.rand(P, gmod, generator=gen) * 0.5 + 0.5
+        Ad, Bd = A.to(DEV), B.to(DEV)
+        Ad.k_valid = K; Bd.k_valid = K
+        for keep_h in (True, False):
+            want = CB.gemm_score(dt_c, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa, g=1), CB.Strided(sb, c=gmod, g=1), None,
+                                 keep_h, False, 0.01, sa_mul=0.5, ref_div=P, ref_transposed=True)
+            ops.GEMM_EVENTS = []                                                # (the ctypes route reports the kernel behind a launch)
+            try:
+                got = ops.gemm_score(dt_o, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV), g=1),
+                                     ops.Strided(sb.to(DEV), c=gmod, g=1), None, keep_h, False, 0.01, sa_mul=0.5, ref_div=P,
+                                     order=2, ref_transposed=True)
+                kernel = ops.GEMM_EVENTS[-1][-1]
+            finally:
+                ops.GEMM_EVENTS = None
+            assert kernel.startswith("k_gemm_win"), kernel
+            assert got.shape == want.shape and rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, G, K, keep_h, rel_err(got.cpu(), want))
+
+
 @pytest.mark.parametrize("P", [64, 128, 256])
 def test_gemm_group_kernel_k_steps(ops, P):
     """Group kernel with seven K-steps (softmax.v weight search: bf16, K = 197, 129..224 rows, 64 x P columns per
