@@ -108,11 +108,14 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     L.stream = cand_cols && use_stream && (L.tm <= 2 || L.wide) && (int64_t)(64 * L.tm + BN2) * kb < ((int64_t)1 << 31);
     if (!L.stream && L.wide) { L.wide = 0; L.tm = pick_tm(M, scoring); }
     // Slab kernel: int8 or fp8 storage, one group, 2..6 K-steps (the 256-column slab is <= 96 KiB), whole 32-row units, at least three
-    // units per wave and slab, and a streamed operand that stays in an XCD's L2.
+    // units per wave and slab, and a streamed operand small enough for the caches.
     static const int use_slab = getenv("ADALOG_GEMM_SLAB") ? atoi(getenv("ADALOG_GEMM_SLAB")) : 1;
     static const int slab_min_m = getenv("ADALOG_GEMM_SLAB_MINM") ? atoi(getenv("ADALOG_GEMM_SLAB_MINM")) : 768;
+    // streamed (fixed) operand: every workgroup walks all of it past its resident slab, from L2 or the Infinity Cache (16 MiB:
+    // swin stage 0's 100 352 tokens x 128 B -- those launches ran on the streaming kernel at 0.26 of peak, 0.43 here)
+    static const int64_t slab_max_bytes = getenv("ADALOG_GEMM_SLAB_MAXB") ? atoll(getenv("ADALOG_GEMM_SLAB_MAXB")) : ((int64_t)16 << 20);
     if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && (dtype == 0 || dtype == 3) && G == 1 && kb <= 6 * BK3 && kvalid_bytes > BK3 && M % 32 == 0 && M >= slab_min_m &&
-        (int64_t)M * kb <= ((int64_t)3 << 20) && (int64_t)cdiv(N, BN2) * (M / 32) < ((int64_t)1 << 30)) {
+        (int64_t)M * kb <= slab_max_bytes && (int64_t)cdiv(N, BN2) * (M / 32) < ((int64_t)1 << 30)) {
         L.slab = 1;
         L.slab_U = M / 32;
         L.NT = cdiv(N, BN2);
