@@ -16,3 +16,8 @@ ADALOG_DIST_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 1 --warmup
 for m in deit_tiny vit_base swin_small swin_base; do timeout 300 python bench.py --model $m --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/bench_$m.json 2> gpurun_out/final/bench_$m.err; head -c 200 gpurun_out/final/bench_$m.json; echo; done
 for b in 3 6; do timeout 300 python bench.py --bits $b --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/bench_w${b}.json 2> gpurun_out/final/bench_w${b}.err; head -c 200 gpurun_out/final/bench_w${b}.json; echo; done
 timeout 200 python tools/bench_fused.py > gpurun_out/final/bench_fused.txt 2>&1
+# per-model kernel statistics of the two larger BASELINE models (one warm calibration each)
+for m in vit_base swin_base; do
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_$m -o p -- python3 bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/final/prof_$m.log 2>&1
+  rm -f gpurun_out/final/prof_$m/p_kernel_trace.csv gpurun_out/final/prof_$m/*/p_kernel_trace.csv
+done
