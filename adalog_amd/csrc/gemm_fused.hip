@@ -575,7 +575,8 @@ extern "C" int adalog_score_act_fused_ok(int M, int64_t T, int K, int64_t Kp, in
     const int nrb = pick_nrb(M);
     // the B fragments are regenerated per row tile: beyond two tiles (M > 768) the generation outweighs the operand
     // traffic it saves (measured: swin_base stage 3, 4096 -> 1024, is 13 % faster on the packed path)
-    if ((M + 32 * nrb - 1) / (32 * nrb) > 2) return 0;
+    static const int max_rt = getenv("ADALOG_FUSED_MAX_RT") ? atoi(getenv("ADALOG_FUSED_MAX_RT")) : 2;
+    if ((M + 32 * nrb - 1) / (32 * nrb) > max_rt) return 0;
     return fused_lds_bytes(nrb, pick_fns(nrb, 1 << n_bits), 1 << n_bits) <= 160 * 1024 ? 1 : 0;
 }
 

@@ -6,6 +6,8 @@ over patches: M = N*gh*gw, K = ic*kh*kw, N = oc.  The weight search (conv.py:226
 with fp32 MFMA (the input stays unquantised: qconv_a_bit = 8, conv.py:55-58 and configs/*.py:12), scoring all 128
 weight candidates of every output channel in one launch.  Overlapping / padded convolutions are rejected loudly.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -14,7 +16,7 @@ from .. import backend, search
 from ..ops import F32, Strided, pad_k
 from ..quantizers.uniform import UniformQuantizer
 
-MAX_PACK_BYTES = 6 << 30
+MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
 
 
 class MinMaxQuantConv2d(nn.Conv2d):

@@ -15,6 +15,8 @@ What differs from the reference, by design:
 Out of scope: the symmetric PTQSL search (dead code in the reference, linear.py:171) and
 PostGeluTwinUniformBatchingQuantLinear (ptq4vit ablation).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -28,7 +30,9 @@ GELU_SHIFT = 0.16997124254703522      # -min(gelu(x)), reference linear.py:749
 GELU_SHIFT32 = float(torch.tensor(GELU_SHIFT, dtype=torch.float32))     # the Parameter's fp32 value
 import os as _os
 FUSED_ACT_SEARCH = _os.environ.get("ADALOG_FUSED_ACT", "1") != "0"      # A/B switch: 0 = pack + streaming GEMM (round 1)
-MAX_PACK_BYTES = 6 << 30              # candidates are scored in chunks when a packed operand would exceed this
+# candidates are scored in chunks when a packed operand would exceed this (8 GiB of 288: vit_large's fc2 activation search --
+# 51.6 MB per candidate -- stays whole; a chunk of 124 is not a candidate count the streaming kernel takes)
+MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
 
 
 class MinMaxQuantLinear(nn.Linear):

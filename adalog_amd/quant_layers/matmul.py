@@ -7,6 +7,8 @@ Every (image, head) pair is one GEMM group g = n*H + h; per-head parameters are 
 kernels, so a scoring call for 128 candidates is one batched MFMA launch over [P, N*H] groups.
 B enters the GEMM K-contiguous, i.e. as B^T -- taken as a strided *view*, packed by the operand kernel (no copy).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -15,7 +17,7 @@ from ..ops import BF16, FP8, I8, Strided, pad_k  # noqa: F401
 from ..quantizers.logarithm import AdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
-MAX_PACK_BYTES = 6 << 30
+MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
 
 
 class MinMaxQuantMatMul(nn.Module):
