@@ -76,7 +76,7 @@ static int pick_tm(int M, bool scoring) {
     return 1;
 }
 
-struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff, stream, acc, wgs, slab, slab_U, slab_R; int64_t elems; };
+struct Layout { int big, tm, wide, MT, NT, Npad, c_eff, n_eff, stream, acc, wgs, slab, slab_U, slab_R, slab_nb; int64_t elems; };
 
 // Wide (one workgroup per CU, 192/256-row tile) form of the streaming kernel: from 8 K-steps on, where the L2 -> LDS path
 // bounds the main loop (measured: K = 768 int8 -- vit_base / deit_base -- 0.39 -> 0.44 of peak, a calibration 4.5 % shorter;
@@ -114,11 +114,17 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     // streamed (fixed) operand: every workgroup walks all of it past its resident slab, from L2 or the Infinity Cache (16 MiB:
     // swin stage 0's 100 352 tokens x 128 B -- those launches ran on the streaming kernel at 0.26 of peak, 0.43 here)
     static const int64_t slab_max_bytes = getenv("ADALOG_GEMM_SLAB_MAXB") ? atoll(getenv("ADALOG_GEMM_SLAB_MAXB")) : ((int64_t)16 << 20);
-    if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && (dtype == 0 || dtype == 3) && G == 1 && kb <= 6 * BK3 && kvalid_bytes > BK3 && M % 32 == 0 && M >= slab_min_m &&
-        (int64_t)M * kb <= slab_max_bytes && (int64_t)cdiv(N, BN2) * (M / 32) < ((int64_t)1 << 30)) {
+    // 256-column slabs up to 6 K-steps; 128-column slabs up to 12 (K = 512 / 768: swin stage 2, vit_base) when a slab still holds
+    // whole reference columns (64 or 128 candidates)
+    static const int use_slab128 = getenv("ADALOG_GEMM_SLAB128") ? atoi(getenv("ADALOG_GEMM_SLAB128")) : 1;
+    const int slab_nb = kb <= 6 * BK3 ? 8 : ((use_slab128 && kb <= 12 * BK3 && (ref_div == 64 || ref_div == 128)) ? 4 : 0);
+    if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && (dtype == 0 || dtype == 3) && G == 1 && slab_nb != 0 && kvalid_bytes > BK3 && M % 32 == 0 && M >= slab_min_m &&
+        (int64_t)M * kb <= slab_max_bytes && (int64_t)cdiv(N, 32 * slab_nb) * (M / 32) < ((int64_t)1 << 30)) {
+        const int SBN = 32 * slab_nb;
+        L.slab_nb = slab_nb;
         L.slab = 1;
         L.slab_U = M / 32;
-        L.NT = cdiv(N, BN2);
+        L.NT = cdiv(N, SBN);
         const int64_t units = (int64_t)L.NT * L.slab_U;
         L.slab_R = (int)(cdiv(cdiv(units, (int64_t)device_cus()), (int64_t)8) * 8);
         L.wgs = (int)cdiv(units, (int64_t)L.slab_R);
@@ -251,28 +257,34 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         // slab kernel: one workgroup per CU, each takes a contiguous range of (slab, unit) pairs
         p.MT = L.MT; p.NT = L.NT; p.slab_U = L.slab_U; p.slab_R = L.slab_R;
         const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
-        const size_t shm = (size_t)nk * BN2 * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * BN2 * 4;
+        const int SBN = 32 * L.slab_nb;
+        const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4;
         // a slab that is not cut has unused pieces: they must read as zero
         if (!L.acc) {
             const hipError_t me = hipMemsetAsync(partial, 0, (size_t)L.elems * sizeof(float), st);
             if (me != hipSuccess) { adalog_set_error("adalog_gemm_score (clear partials)", me); return (int)me; }
         }
-        const int nref = BN2 / ref_div;
-#define LAUNCH_SLAB(NREFV, ROWSV, DTV)                                                                            \
+        const int nref = SBN / ref_div;
+#define LAUNCH_SLAB(NREFV, ROWSV, DTV, NBV)                                                                       \
         do {                                                                                                      \
             static bool attr_set = false;                                                                         \
             if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, ROWSV, DTV>),         \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, ROWSV, DTV, NBV>),    \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
-            adalog_note_kernel(DTV == 3 ? "k_gemm_slab<fp8>" : "k_gemm_slab<i8>");                                 \
-            hipLaunchKernelGGL((k_gemm_slab<NREFV, ROWSV, DTV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);   \
+            adalog_note_kernel(DTV == 3 ? (NBV == 8 ? "k_gemm_slab<fp8>" : "k_gemm_slab128<fp8>") : (NBV == 8 ? "k_gemm_slab<i8>" : "k_gemm_slab128<i8>")); \
+            hipLaunchKernelGGL((k_gemm_slab<NREFV, ROWSV, DTV, NBV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
         } while (0)
 #define LAUNCH_SLAB_DT(DTV)                                                                                       \
         do {                                                                                                      \
-            if (row_scale) { if (nref == 1) LAUNCH_SLAB(1, true, DTV); else if (nref == 2) LAUNCH_SLAB(2, true, DTV); else LAUNCH_SLAB(4, true, DTV); } \
-            else { if (nref == 1) LAUNCH_SLAB(1, false, DTV); else if (nref == 2) LAUNCH_SLAB(2, false, DTV); else LAUNCH_SLAB(4, false, DTV); } \
+            if (L.slab_nb == 8) {                                                                                 \
+                if (row_scale) { if (nref == 1) LAUNCH_SLAB(1, true, DTV, 8); else if (nref == 2) LAUNCH_SLAB(2, true, DTV, 8); else LAUNCH_SLAB(4, true, DTV, 8); } \
+                else { if (nref == 1) LAUNCH_SLAB(1, false, DTV, 8); else if (nref == 2) LAUNCH_SLAB(2, false, DTV, 8); else LAUNCH_SLAB(4, false, DTV, 8); } \
+            } else {                                                                                              \
+                if (row_scale) { if (nref == 1) LAUNCH_SLAB(1, true, DTV, 4); else LAUNCH_SLAB(2, true, DTV, 4); } \
+                else { if (nref == 1) LAUNCH_SLAB(1, false, DTV, 4); else LAUNCH_SLAB(2, false, DTV, 4); }        \
+            }                                                                                                     \
         } while (0)
         if (dtype == 3) LAUNCH_SLAB_DT(3); else LAUNCH_SLAB_DT(0);
 #undef LAUNCH_SLAB_DT

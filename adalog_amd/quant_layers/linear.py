@@ -33,6 +33,9 @@ FUSED_ACT_SEARCH = _os.environ.get("ADALOG_FUSED_ACT", "1") != "0"      # A/B sw
 # candidates are scored in chunks when a packed operand would exceed this (8 GiB of 288: vit_large's fc2 activation search --
 # 51.6 MB per candidate -- stays whole; a chunk of 124 is not a candidate count the streaming kernel takes)
 MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
+# weight searches whose launches run on the slab kernel (no row scale in the epilogue) store their operands as fp8: no int -> float
+# conversion per output (K <= 384: 256-column slabs; K <= 768: 128-column slabs)
+FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
 
 
 class MinMaxQuantLinear(nn.Linear):
@@ -200,7 +203,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         aq = self.a_quantizer
         x3 = self._x2().unsqueeze(0)
         # weight searches of short-K layers run on the slab kernel, where fp8 storage saves the epilogue's conversions
-        dt = self._int_dt(self.out_features, prefer_fp8=self.in_features <= 384)
+        dt = self._int_dt(self.out_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K)
         xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, dt)
         return dt, xp, Strided(aq.scale.data.view(-1)), 1.0, None
 

@@ -600,7 +600,9 @@ def test_gemm_slab_kernel(ops, dtype, P):
     G, gmod = 1, 1
     dt_c, dt_o = {"i8": (CB.I8, ops.I8), "fp8": (CB.FP8, ops.FP8)}[dtype]
     tdt = {"i8": torch.int8, "fp8": torch.float8_e4m3fn}[dtype]
-    for M, Ncols, K in ((768, 21 * 128 // P + 1, 384), (1152, 9, 136), (800, 70000 // P + 3, 100)):
+    # (K = 512 / 768 / 700: the 128-column form of the kernel, for 64 or 128 candidates; with 256 they stay on the streaming kernel)
+    for M, Ncols, K in ((768, 21 * 128 // P + 1, 384), (1152, 9, 136), (800, 70000 // P + 3, 100), (768, 11, 512), (1024, 5, 768),
+                        (800, 7, 700)):
         Kp = CB.pad_k(K, dt_c)
         A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
         A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).float().to(tdt)
@@ -620,10 +622,19 @@ def test_gemm_slab_kernel(ops, dtype, P):
                     want = CB.gemm_score(dt_c, A, B, M, Ncols, P, G, gmod, ref, CB.Strided(sa), CB.Strided(sb, c=Ncols, n=1), cb,
                                          False, keep_n, 0.01, ref_div=P, ref_transposed=True,
                                          row_scale=rs if rows else None, row_bias=rb if rows else None)
-                    got = ops.gemm_score(dt_o, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV)),
-                                         ops.Strided(sb.to(DEV), c=Ncols, n=1), ob, False, keep_n, 0.01, ref_div=P, order=2,
-                                         ref_transposed=True, row_scale=rs.to(DEV) if rows else None,
-                                         row_bias=rb.to(DEV) if rows else None)
+                    ops.GEMM_EVENTS = []                                        # (the ctypes route reports the kernel behind a launch)
+                    try:
+                        got = ops.gemm_score(dt_o, Ad, Bd, M, Ncols, P, G, gmod, ref.to(DEV), ops.Strided(sa.to(DEV)),
+                                             ops.Strided(sb.to(DEV), c=Ncols, n=1), ob, False, keep_n, 0.01, ref_div=P, order=2,
+                                             ref_transposed=True, row_scale=rs.to(DEV) if rows else None,
+                                             row_bias=rb.to(DEV) if rows else None)
+                        kernel = ops.GEMM_EVENTS[-1][-1]
+                    finally:
+                        ops.GEMM_EVENTS = None
+                    if K <= 384:
+                        assert kernel.startswith("k_gemm_slab<"), kernel
+                    elif P in (64, 128):
+                        assert kernel.startswith("k_gemm_slab128<"), kernel
                     assert got.shape == want.shape
                     assert rel_err(got.cpu(), want) <= 3e-6, (M, Ncols, K, bias_kind, rows, keep_n, rel_err(got.cpu(), want))
 
