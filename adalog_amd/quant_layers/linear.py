@@ -33,8 +33,9 @@ FUSED_ACT_SEARCH = _os.environ.get("ADALOG_FUSED_ACT", "1") != "0"      # A/B sw
 # candidates are scored in chunks when a packed operand would exceed this (8 GiB of 288: vit_large's fc2 activation search --
 # 51.6 MB per candidate -- stays whole; a chunk of 124 is not a candidate count the streaming kernel takes)
 MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
-# weight searches whose launches run on the slab kernel (no row scale in the epilogue) store their operands as fp8: no int -> float
-# conversion per output (K <= 384: 256-column slabs; K <= 768: 128-column slabs)
+# searches whose launches run on the slab kernel store their <= 4-bit operands as fp8 (exact, search.int_operand_dtype): no
+# int -> float conversion per output (K <= 384: 256-column slabs; K <= 768: 128-column slabs).  Weight searches gain 10-20 %,
+# activation searches (row scale in the epilogue) 2-4 % -- in round 1 the latter lost 4 %, the compiler spilled there
 FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
 
 
@@ -296,7 +297,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_a_self(s, z)
         else:
-            dt = self._int_dt(self.raw_input.numel() // self.in_features)
+            dt = self._int_dt(self.raw_input.numel() // self.in_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K)
             wp = self._pack_w_fixed(dt)
             wp.int_dt = dt
             fn = lambda s, z, t: self._score_a(wp, s, z)

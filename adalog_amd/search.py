@@ -230,8 +230,8 @@ def int_operand_dtype(bits_a: int, bits_b: int, chunk: int, zp_on_grid: bool = T
     Measured on MI355X (deit_small W4A4): identical scores everywhere.  Whether it is faster depends on how much of a
     launch is epilogue: the attention q.k^T searches (one 64-byte K-step, group kernel) and the weight searches of the
     K <= 384 linear layers (slab kernel without a row scale: 2.29 -> 2.49 PFLOP/s) gain, so their callers pass
-    ``prefer_fp8``; the activation searches (row scale in the epilogue, more live registers: -4 %) and the streaming
-    kernel's launches (bound by the operand stream) do not.  ADALOG_INT_FP8=1 / 0 forces fp8 wherever it is exact /
+    ``prefer_fp8``; so do, since the 128-column slabs, the activation searches of K <= 768 (+2 %); the streaming kernel's
+    launches (bound by the operand stream) do not.  ADALOG_INT_FP8=1 / 0 forces fp8 wherever it is exact /
     nowhere."""
     import os
     from .ops import FP8, I8
