@@ -8,6 +8,7 @@
 static char g_err[512];
 extern "C" void adalog_set_error(const char* where, hipError_t e) { snprintf(g_err, sizeof g_err, "%s: %s", where, hipGetErrorString(e)); }
 extern "C" void adalog_set_error_msg(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+extern "C" void adalog_note_kernel(const char*) {}
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 struct Case { const char* name; int M, N, K, P; int rows; int dtype = 0; };
@@ -74,6 +75,30 @@ int main(int argc, char** argv) {
                 CK(hipEventRecord(e0)); for (int i = 0; i < 5; ++i) run(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
                 printf("%-24s %s %s: MT %3d mode %d  %.3f ms  %.1f TFLOP/s\n", cs.name, red ? "acc " : "cols", slab ? "slab  " : "stream", MT, mode, ms, flop / ms * 1e-9);
+                if (slab && red) {                       // cycle stamps of the slab kernel: effective clock, share spent switching slabs
+                    long long* tl; CK(hipMalloc(&tl, 4 * 8192 * sizeof(long long))); CK(hipMemset(tl, 0, 4 * 8192 * sizeof(long long)));
+                    g_timeline = tl;
+                    hipEvent_t e2, e3; CK(hipEventCreate(&e2)); CK(hipEventCreate(&e3));
+                    CK(hipEventRecord(e2)); run(); CK(hipEventRecord(e3)); CK(hipEventSynchronize(e3));
+                    float ms2; CK(hipEventElapsedTime(&ms2, e2, e3));
+                    g_timeline = nullptr;
+                    std::vector<long long> ht(4 * 8192);
+                    CK(hipMemcpy(ht.data(), tl, ht.size() * sizeof(long long), hipMemcpyDeviceToHost));
+                    double tot = 0, sw = 0, nsw = 0; int nw = 0;
+                    for (int g = 0; g < 1024; ++g) if (ht[g * 8 + 1] > ht[g * 8]) { tot += (double)(ht[g * 8 + 1] - ht[g * 8]); sw += (double)ht[g * 8 + 2]; nsw += (double)ht[g * 8 + 3]; ++nw; }
+                    if (nw) printf("   stamps: %d workgroups, %.0f cycles each (%.3f ms -> %.2f GHz if one runs the whole launch), %.1f slab switches, %.0f cycles each = %.1f %% of the kernel\n",
+                                   nw, tot / nw, ms2, tot / nw / (ms2 * 1e6), nsw / nw, nsw ? sw / nsw : 0.0, 100.0 * sw / tot);
+                    // the second switch of a few workgroups, per wave: arrival, after barrier 1, slab + scales landed, after barrier 2
+                    for (int g = 100; g < 101; ++g) {
+                        const long long* q = &ht[8192 + (size_t)g * 32];
+                        if (!q[0]) continue;
+                        long long t0 = q[0]; for (int w2 = 1; w2 < 8; ++w2) if (q[w2 * 4] && q[w2 * 4] < t0) t0 = q[w2 * 4];
+                        printf("      wg %3d, second switch, per wave arrive/after barrier 1/slab landed/after barrier 2 (cycles after the first arrival):", g);
+                        for (int w2 = 0; w2 < 8; ++w2) printf("  w%d %lld/%lld/%lld/%lld", w2, q[w2 * 4] - t0, q[w2 * 4 + 1] - t0, q[w2 * 4 + 2] - t0, q[w2 * 4 + 3] - t0);
+                        printf("\n");
+                    }
+                    CK(hipFree(tl));
+                }
                 std::vector<double>& out = sums[red][slab];
                 if (mode == 2) {
                     std::vector<double> hd((size_t)pe / 2);

@@ -31,7 +31,8 @@ if which == "qk":                   # attention q.k^T search: 192 (image, head) 
     torch.cuda.synchronize()
     print("done")
     sys.exit(0)
-I, O = {"qkv": (384, 1152), "fc2": (1536, 384), "proj": (384, 384)}[which]
+I, O = {"qkv": (384, 1152), "fc1": (384, 1536), "fc2": (1536, 384), "proj": (384, 384)}[which]
+DT = ops.FP8 if os.environ.get("PROF_DT", "i8") == "fp8" else ops.I8      # operand storage (fp8 = what K <= 768 searches use)
 x = torch.randn(1, M, I, device=dev)
 W = torch.randn(1, O, I, device=dev) * 0.05
 ref = torch.randn(1, M, O, device=dev)
@@ -40,19 +41,19 @@ xs, xz = torch.tensor([0.3], device=dev), torch.tensor([8.0], device=dev)
 ws, wz = torch.full((O,), 0.01, device=dev), torch.full((O,), 8.0, device=dev)
 csw = torch.rand(P, O, device=dev) * 0.01 + 0.005; czw = torch.randint(4, 12, (P, O), device=dev).float()
 csa = torch.rand(P, 1, device=dev) * 0.2 + 0.2; cza = torch.randint(4, 12, (P, 1), device=dev).float()
-xp = ops.pack_uniform(x, xs, xz, 1, 0, 1, 0, 0, 4, ops.I8)
-wp = ops.pack_uniform(W, csw, czw, P, O, 1, 0, 1, 4, ops.I8, c_inner=True)
-wfix = ops.pack_uniform(W, ws, wz, 1, 0, 1, 0, 1, 4, ops.I8)
-xP = ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, ops.I8, c_inner=True)
+xp = ops.pack_uniform(x, xs, xz, 1, 0, 1, 0, 0, 4, DT)
+wp = ops.pack_uniform(W, csw, czw, P, O, 1, 0, 1, 4, DT, c_inner=True)
+wfix = ops.pack_uniform(W, ws, wz, 1, 0, 1, 0, 1, 4, DT)
+xP = ops.pack_uniform(x, csa, cza, P, 1, 1, 0, 0, 4, DT, c_inner=True)
 ref_t = ref.transpose(1, 2).contiguous()
 one = torch.ones(1, device=dev)
 mode = sys.argv[2] if len(sys.argv) > 2 else "both"
 for _ in range(3):
     if mode in ("both", "w"):       # weight search: rows = tokens, columns = (out channel, candidate)
-        ops.gemm_score(ops.I8, xp, wp, M, O, P, 1, 1, ref_t, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True, 1.0 / T,
+        ops.gemm_score(DT, xp, wp, M, O, P, 1, 1, ref_t, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True, 1.0 / T,
                        ref_div=P, order=2, ref_transposed=True)
     if mode in ("both", "a"):       # activation search (transposed): rows = out channels, columns = (token, candidate)
-        ops.gemm_score(ops.I8, wfix, xP, O, M, P, 1, 1, ref, S(one), S(csa, c=1), None, False, False, 1.0 / (T * O),
+        ops.gemm_score(DT, wfix, xP, O, M, P, 1, 1, ref, S(one), S(csa, c=1), None, False, False, 1.0 / (T * O),
                        ref_div=P, order=2, ref_transposed=True, row_scale=ws, row_bias=bias)
 torch.cuda.synchronize()
 print("done")
