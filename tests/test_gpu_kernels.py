@@ -601,8 +601,9 @@ def test_gemm_slab_kernel(ops, dtype, P):
     dt_c, dt_o = {"i8": (CB.I8, ops.I8), "fp8": (CB.FP8, ops.FP8)}[dtype]
     tdt = {"i8": torch.int8, "fp8": torch.float8_e4m3fn}[dtype]
     # (K = 512 / 768 / 700: the 128-column form of the kernel, for 64 or 128 candidates; with 256 they stay on the streaming kernel)
+    # (K = 320 / 256: five and four K-steps -- an odd step count ends a unit with the streamed fragment in the other buffer)
     for M, Ncols, K in ((768, 21 * 128 // P + 1, 384), (1152, 9, 136), (800, 70000 // P + 3, 100), (768, 11, 512), (1024, 5, 768),
-                        (800, 7, 700)):
+                        (800, 7, 700), (832, 13, 320), (768, 6, 256)):
         Kp = CB.pad_k(K, dt_c)
         A = torch.zeros(1, G, M, Kp, dtype=tdt); B = torch.zeros(1, G, Ncols * P, Kp, dtype=tdt)
         A[..., :K] = torch.randint(-15, 16, (1, G, M, K), generator=gen).float().to(tdt)
