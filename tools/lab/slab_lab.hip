@@ -90,11 +90,11 @@ int main(int argc, char** argv) {
                                    nw, tot / nw, ms2, tot / nw / (ms2 * 1e6), nsw / nw, nsw ? sw / nsw : 0.0, 100.0 * sw / tot);
                     // the second switch of a few workgroups, per wave: arrival, after barrier 1, slab + scales landed, after barrier 2
                     for (int g = 100; g < 101; ++g) {
-                        const long long* q = &ht[8192 + (size_t)g * 32];
+                        const long long* q = &ht[8192 + (size_t)g * 64];
                         if (!q[0]) continue;
-                        long long t0 = q[0]; for (int w2 = 1; w2 < 8; ++w2) if (q[w2 * 4] && q[w2 * 4] < t0) t0 = q[w2 * 4];
-                        printf("      wg %3d, second switch, per wave arrive/after barrier 1/slab landed/after barrier 2 (cycles after the first arrival):", g);
-                        for (int w2 = 0; w2 < 8; ++w2) printf("  w%d %lld/%lld/%lld/%lld", w2, q[w2 * 4] - t0, q[w2 * 4 + 1] - t0, q[w2 * 4 + 2] - t0, q[w2 * 4 + 3] - t0);
+                        long long t0 = q[0]; for (int w2 = 1; w2 < 8; ++w2) if (q[w2 * 8] && q[w2 * 8] < t0) t0 = q[w2 * 8];
+                        printf("      wg %3d, second switch, per wave arrive/after barrier 1/stores issued/slab stored/scales loaded/all landed/after barrier 2 (cycles after the first arrival):", g);
+                        for (int w2 = 0; w2 < 8; w2 += 2) printf("  w%d %lld/%lld/%lld/%lld/%lld/%lld/%lld", w2, q[w2 * 8] - t0, q[w2 * 8 + 1] - t0, q[w2 * 8 + 6] ? q[w2 * 8 + 6] - t0 : 0, q[w2 * 8 + 4] - t0, q[w2 * 8 + 5] - t0, q[w2 * 8 + 2] - t0, q[w2 * 8 + 3] - t0);
                         printf("\n");
                     }
                     CK(hipFree(tl));
