@@ -56,6 +56,7 @@ SIGNATURES = {
     "adalog_gemm_win_ok": (i32, [i32, i32, i32, i32, i32, i32, i64]),
     "adalog_rec_loss": (i32, [p, p, i64, f32, p, p, p]),
     "adalog_rec_loss_backward": (i32, [p, p, i64, f32, p, p, p]),
+    "adalog_brecq_init": (i32, []),
     "adalog_shift_fold": (i32, [p, p, p, p, i32, i32, p, p]),
     "adalog_minmax_rows": (i32, [p, i32, i32, i32, p, p, p]),
     "adalog_absminmax_cols": (i32, [p, i64, i32, i32, p, p, p]),

@@ -37,7 +37,11 @@ __device__ __forceinline__ float load_agent(const float* p) {
 __device__ __forceinline__ bool last_block_arrives(unsigned int* counter, unsigned total) {
     __shared__ int is_last;
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // the partial stores are acknowledged before the ticket
+        // the partial stores must be acknowledged before the ticket is drawn.  A workgroup-scope fence compiles to
+        // `s_waitcnt lgkmcnt(0)` only -- the stores are VMEM operations to other addresses (possibly other channels) than the
+        // ticket, so without the explicit vmcnt wait the ticket could become visible first (tests/test_abi.py greps the ISA)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (t == total - 1) ? 1 : 0;
         if (is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -318,21 +322,25 @@ __global__ __launch_bounds__(256) void k_rec_loss_bwd(const float* __restrict__ 
 // (the last block puts its word back to zero).  Launches that overlap in time hold different slots as long as fewer
 // than RING of them are in flight.
 constexpr int RING = 1024;
+constexpr int MAX_DEV = 16;
+// One ring per device (a ring allocated on device 0 would be a foreign pointer for a kernel on device 1); the table is
+// guarded by a mutex on every call (a few ns against a kernel launch).  The first call for a device allocates and
+// synchronises, which a stream capture does not survive: adalog_brecq_init() makes that call ahead of any capture.
 unsigned int* ticket_slot() {
-    static unsigned int* ring = nullptr;
-    static std::atomic<unsigned> next{0};
+    static unsigned int* rings[MAX_DEV] = {};
+    static unsigned next[MAX_DEV] = {};
     static std::mutex mu;
-    if (!ring) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!ring) {
-            unsigned int* p = nullptr;
-            if (hipMalloc(&p, RING * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, RING * sizeof(unsigned int)) != hipSuccess
-                || hipDeviceSynchronize() != hipSuccess)
-                return nullptr;
-            ring = p;
-        }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!rings[dev]) {
+        unsigned int* p = nullptr;
+        if (hipMalloc(&p, RING * sizeof(unsigned int)) != hipSuccess || hipMemset(p, 0, RING * sizeof(unsigned int)) != hipSuccess
+            || hipDeviceSynchronize() != hipSuccess)
+            return nullptr;
+        rings[dev] = p;
     }
-    return ring + (next.fetch_add(1) % RING);
+    return rings[dev] + (next[dev]++ % RING);
 }
 
 inline int grid1(int64_t n, int cap = 2048) {
@@ -343,6 +351,13 @@ inline int grid1(int64_t n, int cap = 2048) {
 }
 
 }  // namespace
+
+// Allocates the current device's ticket ring (idempotent).  Call once per device before capturing BRECQ launches into a
+// HIP graph: the allocation synchronises the device, which would invalidate a capture in progress.
+extern "C" int adalog_brecq_init(void) {
+    ADALOG_ARG_CHECK(ticket_slot() != nullptr, "brecq_init: cannot allocate the ticket counters");
+    return 0;
+}
 
 // x blocks per row of the [rows][inner] view: enough blocks in total to fill the chip, at least 2048 elements per block
 extern "C" int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, int64_t inner) {

@@ -476,11 +476,18 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
                             shift=aq.shift.data, clamp_u=True)
         return BF16, xp, Strided(aq.scale.data.view(-1)), self._ts32(), aq.shift.data
 
+    def _shift32(self):
+        """The quantiser's shift as the fp32 host value the fused kernels take (one host read per search: a loaded
+        checkpoint or a future searched shift need not equal GELU_SHIFT32, and the packed path reads aq.shift)."""
+        if getattr(self, "_shift_host", None) is None:
+            self._shift_host = float(self.a_quantizer.shift.data.reshape(-1)[0])
+        return self._shift_host
+
     def _log2_x(self):
         """log2(raw_input + shift), once per captured tensor (input of the fused activation search)."""
         key = (self.raw_input.data_ptr(), self.raw_input._version)
         if getattr(self, "_lx_key", None) != key:
-            self._lx = backend.get().log2_shift(self._x2(), GELU_SHIFT32)
+            self._lx = backend.get().log2_shift(self._x2(), self._shift32())
             self._lx_key = key
         return self._lx
 
@@ -499,7 +506,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
             # quantise-in-the-loader kernel: the [M*P, K] candidate operand is never written (gemm_fused.hip)
             return be.score_act_fused(wp, x3[0], self._log2_x(), self.raw_out.reshape(-1, self.out_features),
                                       self.w_quantizer.scale.data.view(-1), bias_fold, scale.reshape(-1), qv.reshape(-1),
-                                      aq.n_bits, self._mant37(dev), float(GELU_SHIFT32), True, self._ts32(), norm)
+                                      aq.n_bits, self._mant37(dev), self._shift32(), True, self._ts32(), norm)
         out = []
         chunk = self._cand_chunk(M, pad_k(self.in_features, BF16) * 2)
         for s in range(0, P, chunk):
@@ -548,19 +555,23 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         self._initialize_calib_parameters()
-        self.weight_fpcs(steps=self.steps, search_strategy="self")
-        ud_candidates, input_scale_candidates = self.calculate_percentile_activation_candidates()
-        self.a_quantizer.scale.data.copy_(input_scale_candidates[:, -2])
-        self.a_quantizer.inited = True
-        self._q_host = int(self.a_quantizer.q.item())
-        for _ in range(self.search_round):
-            self.activation_fpcs(ud_candidates=ud_candidates, steps=self.steps)
-            self.weight_fpcs(steps=self.steps, search_strategy="output")
+        self._shift_host = None
+        try:
+            self.weight_fpcs(steps=self.steps, search_strategy="self")
+            ud_candidates, input_scale_candidates = self.calculate_percentile_activation_candidates()
+            self.a_quantizer.scale.data.copy_(input_scale_candidates[:, -2])
+            self.a_quantizer.inited = True
+            self._q_host = int(self.a_quantizer.q.item())
+            for _ in range(self.search_round):
+                self.activation_fpcs(ud_candidates=ud_candidates, steps=self.steps)
+                self.weight_fpcs(steps=self.steps, search_strategy="output")
+        finally:
+            # the caches are keyed by storage address: they must not outlive this search, whether it ends or raises
+            search.forget_grids()
+            self._ref_t = self._ref_t_key = None
+            self._lx = self._lx_key = None
         self.calibrated = True
-        search.forget_grids()
         del self.raw_input, self.raw_out
-        self._ref_t = self._ref_t_key = None
-        self._lx = self._lx_key = None
 
     def reparam_bias(self):
         """linear.py:999-1006: bias += (-shift * 1^T) . q_w(W)^T, then the quantiser stops subtracting the shift."""

@@ -116,6 +116,9 @@ class BlockReconstructor(QuantCalibrator):
         want_graph = os.environ.get("ADALOG_BRECQ_GRAPH", "1" if ws == 1 else "0") == "1"
         use_graph = (torch.device(device).type == 'cuda' and want_graph and n_local >= local_bs and iters > 8)
         full_graph = use_graph and ws == 1
+        if use_graph:
+            from .. import _lib                          # the ticket counters are allocated (with a device sync) before any capture
+            _lib.check(_lib.load().adalog_brecq_init(), "adalog_brecq_init")
         okw = dict(capturable=True) if full_graph else {}
         if torch.device(device).type == 'cuda':
             okw['fused'] = True                          # one kernel per optimiser step instead of six foreach passes

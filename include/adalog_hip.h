@@ -267,6 +267,10 @@ int adalog_round_loss_multi(const float* const* alphas, float* const* grads, con
 int adalog_rec_loss(const float* pred, const float* tgt, int64_t n, float scale, float* loss, float* workspace, void* stream);
 int adalog_rec_loss_backward(const float* pred, const float* tgt, int64_t n, float scale, const float* gmul, float* gpred,
                              void* stream);
+/* Allocates the current device's ticket counters of the BRECQ kernels' in-kernel reductions (idempotent, one ring per
+ *   device).  The allocation synchronises the device: call it before capturing BRECQ launches into a HIP graph
+ *   (the training loop of reference utils/block_recon.py:114-127 is replayed from one). */
+int adalog_brecq_init(void);
 
 #ifdef __cplusplus
 }

@@ -86,3 +86,27 @@ def test_generated_asm_is_up_to_date(tmp_path):
         assert have == want, f"fused_loop_nrb{nrb}_s{fns}.inc is stale: run tools/gen_fused_asm_all.sh"
     os.environ.pop("FUSED_NRB", None)
     os.environ.pop("FUSED_FNS", None)
+
+
+def test_brecq_ticket_is_ordered_after_the_partial_stores(tmp_path):
+    """ISA shape of the 'last block finishes' reductions (csrc/brecq.hip last_block_arrives): between a block's partial
+    store (global_store ... sc1) and its ticket (global_atomic_add) there must be an `s_waitcnt vmcnt(0)` -- a workgroup
+    fence alone compiles to lgkmcnt(0), which does not order two VMEM operations to different addresses."""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "brecq.s"
+    csrc = os.path.join(ROOT, "adalog_amd", "csrc")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
+                    os.path.join(csrc, "brecq.hip"), "-o", str(asm)], check=True, capture_output=True)
+    lines = open(asm).read().splitlines()
+    atomics = [i for i, ln in enumerate(lines) if "global_atomic_add" in ln]
+    assert len(atomics) >= 5, "expected one ticket per reducing kernel"
+    for i in atomics:
+        j = i - 1
+        while j >= 0 and "global_store_dword" not in lines[j]:
+            j -= 1
+        assert j >= 0, "no partial store in front of a ticket"
+        between = lines[j + 1:i]
+        assert any("s_waitcnt" in ln and "vmcnt(0)" in ln for ln in between), \
+            f"ticket at line {i} is not ordered after the store at line {j}"
