@@ -553,6 +553,175 @@ def gen_brecq():
     save("brecq_toy", **arrays)
 
 
+# ----------------------------------------------------------------------------- wrapper rules + attention forwards
+def _install_timm_stub():
+    """A container-only `timm` whose Attention / WindowAttention / Block / ... ARE the product's model classes
+    (adalog_amd/utils/models.py: pure-torch module trees with timm-0.9.2 names).  The reference's own wrap_net.py and
+    block_recon.py then run over those trees: what is pinned is the reference's CODE (naming rules, class choice, attention
+    forwards, block discovery), the container classes only supply the module tree."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from adalog_amd.utils import models as PM
+
+    class _Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            m = _Stub(self.__name__ + "." + k)
+            setattr(self, k, m)
+            return m
+    names = ("timm", "timm.models", "timm.models.swin_transformer", "timm.models.vision_transformer", "timm.layers",
+             "timm.layers.patch_embed")
+    for name in names:
+        if name not in sys.modules:
+            sys.modules[name] = _Stub(name)
+    for name in names[1:]:                                  # attribute chain timm.models.vision_transformer... resolves
+        parent, _, leaf = name.rpartition(".")
+        setattr(sys.modules[parent], leaf, sys.modules[name])
+    vt, st, pe = (sys.modules["timm.models.vision_transformer"], sys.modules["timm.models.swin_transformer"],
+                  sys.modules["timm.layers.patch_embed"])
+    vt.Attention, vt.Block = PM.Attention, PM.Block
+    st.WindowAttention, st.SwinTransformerBlock, st.PatchMerging = PM.WindowAttention, PM.SwinTransformerBlock, PM.PatchMerging
+    st.window_partition, st.window_reverse = PM.window_partition, PM.window_reverse
+    pe.PatchEmbed = PM.PatchEmbed
+    return PM
+
+
+def _ref_cfg(bits):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(f"refcfg{bits}", os.path.join(REF, "configs", f"{bits}bit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.Config()
+
+
+def _wrap_table(model):
+    """One row per quantised module, in named_modules() (= calibration) order."""
+    mods = dict(model.named_modules())
+    by_id = {id(m): n for n, m in mods.items()}
+    rows = []
+    for name, m in mods.items():
+        if not hasattr(m, "calibrated"):
+            continue
+        cls = type(m).__name__
+        if hasattr(m, "A_quantizer"):
+            bits = (m.A_quantizer.n_bits, m.B_quantizer.n_bits)
+            n_V, prev, has_bias, heads = 0, "", 0, int(m.num_heads)
+            q_cls = type(m.A_quantizer).__name__
+        else:
+            bits = (m.w_quantizer.n_bits, m.a_quantizer.n_bits)
+            n_V = int(getattr(m, "n_V", 0))
+            pl = getattr(m, "prev_layer", None)
+            prev = by_id[id(pl)] if pl is not None else ""
+            has_bias = int(m.bias is not None)
+            heads = 0
+            q_cls = type(m.a_quantizer).__name__
+        rows.append((name, cls, bits[0], bits[1], n_V, prev, has_bias, heads, q_cls, m.mode))
+    return rows
+
+
+def gen_wrapper():
+    """utils/wrap_net.py:55-210 (wrap_modules_in_net / wrap_reparamed_modules_in_net), :19-52 (vit_attn_forward /
+    swin_attn_forward) and utils/block_recon.py:23-36 (block discovery) run over the product's model trees."""
+    PM = _install_timm_stub()
+    from utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net      # the reference's
+    from utils.block_recon import BlockReconstructor
+    arrays = {}
+    # ---- (1) naming rules: which class / bit widths / n_V / prev_layer every module gets
+    for tag, name in (("deit_tiny", "deit_tiny"), ("swin_tiny", "swin_tiny")):
+        for bits in (3, 4, 6):
+            for reparam in (True, False):
+                if not reparam and bits != 4:
+                    continue
+                torch.manual_seed(7)
+                model = PM.create_model(name).eval()
+                cfg = _ref_cfg(bits)
+                model = wrap_modules_in_net(model, cfg, reparam=reparam)
+                rows = _wrap_table(model)
+                key = f"{tag}_w{bits}_{'reparam' if reparam else 'plain'}"
+                arrays[key + "_name"] = np.array([r[0] for r in rows])
+                arrays[key + "_class"] = np.array([r[1] for r in rows])
+                arrays[key + "_bits"] = np.array([[r[2], r[3]] for r in rows], dtype=np.int64)
+                arrays[key + "_nV"] = np.array([r[4] for r in rows], dtype=np.int64)
+                arrays[key + "_prev"] = np.array([r[5] for r in rows])
+                arrays[key + "_bias"] = np.array([r[6] for r in rows], dtype=np.int64)
+                arrays[key + "_heads"] = np.array([r[7] for r in rows], dtype=np.int64)
+                arrays[key + "_aq"] = np.array([r[8] for r in rows])
+                arrays[key + "_mode"] = np.array([r[9] for r in rows])
+                # every module except the wrapped ones keeps its place: the full named_modules() order after wrapping
+                arrays[key + "_all_modules"] = np.array([n for n, _ in model.named_modules()])
+                if reparam and bits == 4:
+                    full = PM.create_model(name).eval()
+                    rec = BlockReconstructor(model, full, None)
+                    arrays[f"{tag}_blocks"] = np.array(list(rec.blocks.keys()))
+                    arrays[f"{tag}_full_blocks"] = np.array(list(rec.full_blocks.keys()))
+                    # the un-wrap step needs per-tensor activation parameters (what reparam() leaves, linear.py:617-619)
+                    for m in model.modules():
+                        if type(m).__name__ == "AsymmetricallyChannelWiseBatchingQuantLinear":
+                            del m.a_quantizer.scale, m.a_quantizer.zero_point
+                            m.a_quantizer.channel_wise = False
+                            m.a_quantizer.scale = torch.nn.Parameter(torch.ones(1))
+                            m.a_quantizer.zero_point = torch.nn.Parameter(torch.zeros(1))
+                    model = wrap_reparamed_modules_in_net(model)
+                    rows2 = _wrap_table(model)
+                    arrays[key + "_unwrapped_class"] = np.array([r[1] for r in rows2])
+                    arrays[key + "_unwrapped_calibrated"] = np.array(
+                        [int(dict(model.named_modules())[r[0]].calibrated) for r in rows2], dtype=np.int64)
+                    sd = model.state_dict()
+                    arrays[key + "_sd_keys"] = np.array(list(sd.keys()))
+                    arrays[key + "_sd_shapes"] = np.array([",".join(str(d) for d in v.shape) for v in sd.values()])
+
+    # ---- (2) attention forwards in 'raw' mode: the reference's patched forward on seeded weights
+    torch.manual_seed(71)
+    vit = PM.VisionTransformer(img_size=32, patch_size=8, embed_dim=32, depth=2, num_heads=4, num_classes=10).eval()
+    for prm in vit.parameters():
+        prm.data.add_(torch.randn_like(prm) * 0.2)
+    arrays.update({"vit_in_" + k.replace(".", "__"): v.clone() for k, v in vit.state_dict().items()})
+    x = torch.randn(3, 3, 32, 32)
+    tok = torch.randn(3, 17, 32)
+    cfg = _ref_cfg(4)
+    cfg.search_round, cfg.steps, cfg.calib_batch_size = 1, 2, 2
+    vit = wrap_modules_in_net(vit, cfg, reparam=True)
+    with torch.no_grad():
+        arrays["vit_x"], arrays["vit_tok"] = x, tok
+        arrays["vit_out_raw"] = vit(x)
+        arrays["vit_attn_out_raw"] = vit.blocks[1].attn(tok)                  # vit_attn_forward, wrap_net.py:19-32
+
+    torch.manual_seed(72)
+    swin = PM.SwinTransformer(img_size=56, patch_size=4, embed_dim=16, depths=(2, 2), num_heads=(2, 4), window_size=7,
+                              num_classes=10).eval()
+    for prm in swin.parameters():
+        prm.data.add_(torch.randn_like(prm) * 0.2)
+    arrays.update({"swin_in_" + k.replace(".", "__"): v.clone() for k, v in swin.state_dict().items()})
+    xs = torch.randn(2, 3, 56, 56)
+    wtok = torch.randn(8, 49, 16)
+    mask = torch.where(torch.rand(4, 49, 49) < 0.3, torch.tensor(-100.0), torch.tensor(0.0))
+    swin = wrap_modules_in_net(swin, cfg, reparam=True)
+    with torch.no_grad():
+        arrays["swin_x"], arrays["swin_wtok"], arrays["swin_mask"] = xs, wtok, mask
+        arrays["swin_out_raw"] = swin(xs)
+        att = swin.layers[0].blocks[1].attn                                  # swin_attn_forward, wrap_net.py:35-52
+        arrays["swin_attn_out_nomask"] = att(wtok)
+        arrays["swin_attn_out_mask"] = att(wtok, mask)
+
+    # ---- (3) the whole flow on the wrapped tiny ViT: calibrate (with the LayerNorm fold), un-wrap, reparam_bias
+    loader = [(x[:2], None), (x[2:], None)]
+    order = []
+    for name, m in vit.named_modules():
+        if hasattr(m, "hyperparameter_searching"):
+            orig = m.hyperparameter_searching
+            m.hyperparameter_searching = (lambda orig=orig, name=name: (order.append(name), orig())[1])
+    RefCalibrator(vit, loader).batching_quant_calib()
+    vit = wrap_reparamed_modules_in_net(vit)
+    with torch.no_grad():
+        for m in vit.modules():
+            if hasattr(m, "mode") and hasattr(m, "reparam_bias"):             # finish_training, test_quant.py:130-133
+                m.reparam_bias()
+        arrays["vit_out_quant"] = vit(x)
+    arrays["vit_calib_order"] = np.array(order)
+    arrays.update({"vit_out_" + k.replace(".", "__"): v.clone() for k, v in vit.state_dict().items()})
+    save("wrapper_rules", **arrays)
+
+
 if __name__ == "__main__":
     gen_quantizers()
     for bits, seed in ((3, 11), (4, 12), (6, 13)):
@@ -572,4 +741,5 @@ if __name__ == "__main__":
         gen_conv(bits, seed)
     gen_quantile_large()
     gen_calibrator()
+    gen_wrapper()
     gen_brecq()
