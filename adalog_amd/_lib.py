@@ -38,6 +38,9 @@ SIGNATURES = {
     "adalog_score_w_self": (i32, [p, i32, i32, p, p, i32, i32, p, p]),
     "adalog_score_a_self": (i32, [p, i64, i32, p, p, i32, i32, i32, f64, p, i64, p, p]),
     "adalog_score_a_self_partial_elems": (i64, [i64, i32, i32]),
+    "adalog_sorted_prefix_workspace_bytes": (i64, [i64, i64]),
+    "adalog_sorted_prefix_build": (i32, [p, i64, i64, p, p, p, i64, p]),
+    "adalog_score_self_sorted": (i32, [p, p, i64, i64, p, p, i32, i32, f64, p, p]),
     "adalog_quantile_rows": (i32, [p, i64, i64, i32, p, p, i32, p, p, i64, p]),
     "adalog_positive_percentile_rows": (i32, [p, i64, i64, i32, p, p, p, i64, p]),
     "adalog_select_workspace_bytes": (i64, [i64, i32]),

@@ -56,6 +56,11 @@ int adalog_score_w_self(const float* w, int rows, int I, const float* scale, con
 int adalog_score_a_self(const float* x, int64_t rows, int I, const float* scale, const float* zp, int P, int channel_wise,
                         int n_bits, double norm, float* partial, int64_t partial_elems, float* scores, void* stream);
 int64_t adalog_score_a_self_partial_elems(int64_t rows, int I, int P);
+int64_t adalog_sorted_prefix_workspace_bytes(int64_t S, int64_t n);
+int adalog_sorted_prefix_build(const float* x, int64_t S, int64_t n, float* sorted, double* prefix, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+int adalog_score_self_sorted(const float* sorted, const double* prefix, int64_t S, int64_t n, const float* scale,
+                             const float* zp, int P, int n_bits, double norm, float* scores, void* stream);
 }
 
 namespace {
@@ -249,6 +254,34 @@ at::Tensor score_a_self(const at::Tensor& x2, const at::Tensor& scale, const at:
     return scores;
 }
 
+// linear.py:296-318 / 320-353 in sorted-prefix form (csrc/sorted_score.hip): x2 [S, n] -> (sorted [S, n], prefix [S, n + 1, 2] f64)
+std::tuple<at::Tensor, at::Tensor> sorted_prefix(const at::Tensor& x2) {
+    TORCH_CHECK(x2.dim() == 2, "x2: expected [S, n]");
+    const int64_t S = x2.size(0), n = x2.size(1);
+    const int64_t wsb = adalog_sorted_prefix_workspace_bytes(S, n);
+    TORCH_CHECK(wsb >= 0, "adalog::sorted_prefix: unsupported size");
+    at::Tensor ws = at::empty({(wsb + 15) / 16 * 2}, x2.options().dtype(at::kDouble));
+    at::Tensor sorted = at::empty_like(x2);
+    at::Tensor prefix = at::empty({S, n + 1, 2}, x2.options().dtype(at::kDouble));
+    check(adalog_sorted_prefix_build(fptr(x2, "x"), S, n, sorted.data_ptr<float>(), prefix.data_ptr<double>(), ws.data_ptr(),
+                                     ws.numel() * 8, cur_stream()),
+          "adalog::sorted_prefix");
+    return {sorted, prefix};
+}
+
+at::Tensor score_self_sorted(const at::Tensor& sorted, const at::Tensor& prefix, const at::Tensor& scale, const at::Tensor& zp,
+                             int64_t n_bits, double norm) {
+    const int64_t S = sorted.size(0), n = sorted.size(1), P = scale.size(0);
+    TORCH_CHECK(prefix.is_cuda() && prefix.scalar_type() == at::kDouble && prefix.is_contiguous() && prefix.numel() == S * (n + 1) * 2,
+                "prefix: expected a contiguous float64 HIP tensor [S, n + 1, 2]");
+    TORCH_CHECK(scale.numel() == P * S && zp.numel() == P * S, "scale / zp: expected [P, S]");
+    at::Tensor scores = at::empty({P, S}, sorted.options());
+    check(adalog_score_self_sorted(fptr(sorted, "sorted"), prefix.data_ptr<double>(), S, n, fptr(scale, "scale"), fptr(zp, "zp"), (int)P,
+                                   (int)n_bits, norm, scores.data_ptr<float>(), cur_stream()),
+          "adalog::score_self_sorted");
+    return scores;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(adalog, m) {
@@ -269,6 +302,8 @@ TORCH_LIBRARY(adalog, m) {
           "bool has_clamp, float clamp_min) -> (Tensor, Tensor, Tensor)");
     m.def("score_w_self(Tensor w2, Tensor scale, Tensor zp, int n_bits) -> Tensor");
     m.def("score_a_self(Tensor x2, Tensor scale, Tensor zp, bool channel_wise, int n_bits, float norm) -> Tensor");
+    m.def("sorted_prefix(Tensor x2) -> (Tensor, Tensor)");
+    m.def("score_self_sorted(Tensor sorted, Tensor prefix, Tensor scale, Tensor zp, int n_bits, float norm) -> Tensor");
 }
 
 // HIP dispatch key only ("CUDA" is the HIP key on ROCm builds of PyTorch): there is deliberately no CPU implementation
@@ -284,4 +319,6 @@ TORCH_LIBRARY_IMPL(adalog, CUDA, m) {
     m.impl("topk_next", &topk_next);
     m.impl("score_w_self", &score_w_self);
     m.impl("score_a_self", &score_a_self);
+    m.impl("sorted_prefix", &sorted_prefix);
+    m.impl("score_self_sorted", &score_self_sorted);
 }

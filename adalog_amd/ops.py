@@ -436,6 +436,54 @@ def score_a_self(x2, scale, zp, channel_wise: bool, n_bits: int, norm: float):
     return scores
 
 
+class SortedPrefix:
+    """A [S, n] tensor sorted per segment with fp64 prefix sums of x and x^2 along the sorted order (csrc/sorted_score.hip):
+    what the self-MSE searches score their candidates from.  Built once per captured tensor, shared by the FPCS steps."""
+    __slots__ = ("sorted", "prefix", "S", "n")
+
+    def __init__(self, x2):
+        x2 = _f32c(x2, "x")
+        if x2.dim() != 2:
+            raise ValueError("SortedPrefix: expected [S, n]")
+        self.S, self.n = x2.shape
+        if _torch_ops.available():
+            self.sorted, self.prefix = _top("sorted_prefix", x2)
+            return
+        lib = _lib.load()
+        wsb = lib.adalog_sorted_prefix_workspace_bytes(self.S, self.n)
+        if wsb < 0:
+            raise _lib.AdalogHipError("sorted_prefix: unsupported size")
+        ws = torch.empty((wsb + 15) // 16 * 2, dtype=torch.float64, device=x2.device)
+        self.sorted = torch.empty_like(x2)
+        self.prefix = torch.empty((self.S, self.n + 1, 2), dtype=torch.float64, device=x2.device)
+        rc = lib.adalog_sorted_prefix_build(x2.data_ptr(), self.S, self.n, self.sorted.data_ptr(), self.prefix.data_ptr(),
+                                            ws.data_ptr(), ws.numel() * 8, _stream())
+        _lib.check(rc, "adalog_sorted_prefix_build")
+
+
+def sorted_prefix(x2):
+    return SortedPrefix(x2)
+
+
+def sorted_prefix_ok(S: int, n: int, n_bits: int) -> bool:
+    return 1 <= n_bits <= 8 and S <= 65535 and _lib.load().adalog_sorted_prefix_workspace_bytes(int(S), int(n)) >= 0
+
+
+def score_self_sorted(sp: SortedPrefix, scale, zp, n_bits: int, norm: float):
+    """scores [P, S] = -norm * sum over each segment of (x - fq_p(x))^2 for the P candidates scale / zp [P, S]."""
+    scale, zp = _f32c(scale, "scale"), _f32c(zp, "zp")
+    P = scale.shape[0]
+    if scale.numel() != P * sp.S or zp.numel() != P * sp.S:
+        raise ValueError("score_self_sorted: scale / zp must be [P, S]")
+    if _torch_ops.available():
+        return _top("score_self_sorted", sp.sorted, sp.prefix, scale, zp, int(n_bits), float(norm))
+    scores = torch.empty((P, sp.S), dtype=torch.float32, device=scale.device)
+    rc = _lib.load().adalog_score_self_sorted(sp.sorted.data_ptr(), sp.prefix.data_ptr(), sp.S, sp.n, scale.data_ptr(),
+                                             zp.data_ptr(), P, int(n_bits), float(norm), scores.data_ptr(), _stream())
+    _lib.check(rc, "adalog_score_self_sorted")
+    return scores
+
+
 # ------------------------------------------------------------------------------------------------ order statistics
 def quantile_ranks(qs, n: int):
     """Host-side rank arithmetic exactly as ATen's quantile does it: pos = q * (n - 1) in fp32."""

@@ -37,6 +37,8 @@ MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
 # int -> float conversion per output (K <= 384: 256-column slabs; K <= 768: 128-column slabs).  Weight searches gain 10-20 %,
 # activation searches (row scale in the epilogue) 2-4 % -- in round 1 the latter lost 4 %, the compiler spilled there
 FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
+# self-MSE searches scored from the sorted tensor (csrc/sorted_score.hip); 0 = one pass over the tensor per step (round 1/2)
+SORTED_SELF_SEARCH = os.environ.get('ADALOG_SORTED_SELF', '1') != '0'
 
 
 class MinMaxQuantLinear(nn.Linear):
@@ -271,13 +273,29 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _score_w_self(self, scale, zp):
-        return backend.get().score_w_self(self._w2(), scale, zp, self.w_quantizer.n_bits)
+        """linear.py:296-318: scores [P, O] = -mean_i (W - fq_p(W))^2 from the sorted weight rows (csrc/sorted_score.hip)."""
+        be = backend.get()
+        w2 = self._w2()
+        if SORTED_SELF_SEARCH and be.sorted_prefix_ok(w2.shape[0], w2.shape[1], self.w_quantizer.n_bits):
+            sp = search.memo_tensor_fn("spw", w2, (), lambda: be.sorted_prefix(w2))
+            return be.score_self_sorted(sp, scale, zp, self.w_quantizer.n_bits, 1.0 / w2.shape[1])
+        return be.score_w_self(w2, scale, zp, self.w_quantizer.n_bits)
 
     def _score_a_self(self, scale, zp):
+        """linear.py:320-353: scores [P, I | 1] = -sum_images mean_tokens (x - fq_p(x))^2.  The captured activation is sorted
+        once per search (per channel: one segment per channel; per tensor: one segment), every step then costs 2^bits
+        bisections per candidate instead of a pass over the tensor."""
+        be = backend.get()
         cw = self.a_quantizer.channel_wise
         T = self._tokens_per_image()
         norm = 1.0 / T if cw else 1.0 / (T * self.in_features)
-        return backend.get().score_a_self(self._x2(), scale, zp, cw, self.a_quantizer.n_bits, norm)
+        x2 = self._x2()
+        S, n = (x2.shape[1], x2.shape[0]) if cw else (1, x2.numel())
+        if SORTED_SELF_SEARCH and be.sorted_prefix_ok(S, n, self.a_quantizer.n_bits):
+            sp = search.memo_tensor_fn("spa", self.raw_input, (cw,),
+                                       lambda: be.sorted_prefix(x2.t().contiguous() if cw else x2.reshape(1, -1)))
+            return be.score_self_sorted(sp, scale, zp, self.a_quantizer.n_bits, norm)
+        return be.score_a_self(x2, scale, zp, cw, self.a_quantizer.n_bits, norm)
 
     # ------------------------------------------------------------------ FPCS (linear.py:483-523)
     def weight_fpcs(self, fpcs_width=16, steps=6, search_strategy="output"):

@@ -189,6 +189,20 @@ int adalog_score_a_self(const float* x, int64_t rows, int I, const float* scale,
                         int n_bits, double norm, float* partial, int64_t partial_elems, float* scores, void* stream);
 int64_t adalog_score_a_self_partial_elems(int64_t rows, int I, int P);
 
+/* ---- K9 / K10 in sorted-prefix form                                   reference linear.py:296-318, 320-353
+ * A uniform quantiser is a monotone step function, so the elements a candidate maps to one level are one contiguous run of
+ * the SORTED tensor: sort each segment once per captured tensor (per-tensor search: S = 1; per-channel / per-weight-row:
+ * one segment each), keep fp64 exclusive prefix sums of x and x^2 along the sorted order, and score a candidate from
+ * 2^bits bisections (exact predicate rne(x / s) >= k) + prefix differences instead of quantising every element.
+ *   adalog_sorted_prefix_build: x [S][n] -> sorted [S][n], prefix [S][n + 1][2] (double); workspace of
+ *     adalog_sorted_prefix_workspace_bytes(S, n) bytes (-1: unsupported size), 16-byte aligned.
+ *   adalog_score_self_sorted: scale / zp [P][S] -> scores[p][seg] = -norm * sum_seg (x - fq_p(x))^2. */
+int64_t adalog_sorted_prefix_workspace_bytes(int64_t S, int64_t n);
+int adalog_sorted_prefix_build(const float* x, int64_t S, int64_t n, float* sorted, double* prefix, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+int adalog_score_self_sorted(const float* sorted, const double* prefix, int64_t S, int64_t n, const float* scale,
+                             const float* zp, int P, int n_bits, double norm, float* scores, void* stream);
+
 /* ---- K5/K6  exact order statistics by radix select
  * adalog_quantile_rows: torch.quantile(x.view(S, n), q, dim=-1, interpolation='linear') for nq <= 4 quantiles, then the mean
  *   over each group of `mbs` consecutive rows (the reference's chunked quantile, linear.py:465-471, matmul.py:219-230).

@@ -204,6 +204,29 @@ def score_a_self(x2, scale, zp, channel_wise, n_bits, norm):
     return (-norm * tot).float()
 
 
+class SortedPrefix:
+    """spec of ops.SortedPrefix: the consumer below only needs the segments themselves"""
+    def __init__(self, x2):
+        self.x2, (self.S, self.n) = x2, x2.shape
+
+
+def sorted_prefix(x2):
+    return SortedPrefix(x2)
+
+
+def sorted_prefix_ok(S, n, n_bits):
+    return True
+
+
+def score_self_sorted(sp, scale, zp, n_bits, norm):
+    """scores [P, S] = -norm * sum over each segment of (x - fq_p(x))^2 (uniform.py:29-36 per segment)"""
+    x = sp.x2.unsqueeze(0)                                                   # [1, S, n]
+    s, z = scale.reshape(-1, sp.S, 1), zp.reshape(-1, sp.S, 1)
+    q = (torch.round(x / s) + z).clamp(0, 2 ** n_bits - 1)
+    e2 = ((x - (q - z) * s).double()) ** 2
+    return (-norm * e2.sum(-1)).float()
+
+
 def quantile_ranks(qs, n):
     pos = torch.tensor(qs, dtype=torch.float32) * (n - 1)
     lo = pos.floor()

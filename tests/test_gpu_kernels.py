@@ -361,6 +361,53 @@ def test_self_mse_scores(ops, bits):
         assert rel_err(got.cpu(), want) <= 1e-5
 
 
+@pytest.mark.parametrize("bits", [3, 4, 6, 8])
+def test_self_mse_scores_sorted_prefix(ops, bits):
+    """csrc/sorted_score.hip: the self-MSE searches scored from the sorted tensor (segments sorted by a library radix sort,
+    fp64 prefix sums, 2^bits bisections per candidate with the reference's exact rounding predicate) against the oracle's
+    element-by-element evaluation: weights (a segment per row), per-channel and per-tensor activations, ragged segment
+    lengths, duplicated values, +-0, candidates with a NON-integral zero point and with clamping at both ends."""
+    gen = g(650 + bits)
+    W = torch.randn(3, 64, 192, generator=gen) * 0.1
+    sc, zp = O.weight_candidates(W, min(bits, 6))
+    if bits <= 6:
+        want = O.score_w_self(W, sc, zp, bits).reshape(128, -1)
+        sp = ops.sorted_prefix(W.view(-1, 192).to(DEV))
+        assert torch.equal(sp.sorted.cpu(), W.view(-1, 192).sort(dim=-1).values)
+        pf = sp.prefix.cpu()
+        ref_pf = torch.cat([torch.zeros(192, 1, dtype=torch.float64), sp.sorted.cpu().double().cumsum(-1)], -1)
+        torch.testing.assert_close(pf[..., 0], ref_pf, rtol=1e-13, atol=1e-13)
+        got = ops.score_self_sorted(sp, sc.reshape(128, -1).to(DEV), zp.reshape(128, -1).float().to(DEV), bits, 1.0 / 192)
+        assert rel_err(got.cpu(), want) <= 1e-5
+    for rows, C in ((6 * 197, 96), (1027, 5), (4096, 3)):                      # n % 4 != 0, n % 1024 == 0, tiny segment counts
+        x = torch.randn(rows, C, generator=gen) * torch.linspace(0.3, 2, C)
+        x[:7, 0] = x[7:14, 0]
+        x[20, :] = 0.0
+        x[21, :] = -0.0
+        for cw in (True, False):
+            cols = C if cw else 1
+            P = 128
+            s = (x.abs().max() / (2 ** bits - 1)) * (0.5 + 1.5 * torch.rand(P, cols, generator=gen))
+            z = torch.randint(0, 2 ** bits, (P, cols), generator=gen).float()
+            z[::7] += 0.37                                                      # non-integral zero points (never produced by FPCS)
+            z[5] = 0.0
+            z[6] = 2 ** bits - 1.0
+            want = CB.score_a_self(x, s, z, cw, bits, 0.01)
+            x2 = x.t().contiguous() if cw else x.reshape(1, -1)
+            sp = ops.sorted_prefix(x2.to(DEV))
+            got = ops.score_self_sorted(sp, s.to(DEV), z.to(DEV), bits, 0.01)
+            assert rel_err(got.cpu(), want) <= 2e-5, (rows, C, cw)
+    # a large single segment (deit_small: 6304 x 384 = 2.4 M elements), per-tensor candidates from the reference's grid
+    x = torch.randn(32 * 197 * 384, generator=gen) * 1.3 + 0.2
+    if bits <= 6:
+        s2, z2 = O.activation_candidates(x.view(32, 197, 384), bits, False)                  # [1, 128]
+        sub = [0, 31, 64, 127]
+        want = O.score_a_self(x.view(32, 197, 384), s2[:, sub], z2[:, sub], bits, False, 32).reshape(-1)
+        sp = ops.sorted_prefix(x.view(1, -1).to(DEV))
+        got = ops.score_self_sorted(sp, s2.t().contiguous().to(DEV), z2.t().contiguous().float().to(DEV), bits, 1.0 / (197 * 384))
+        assert rel_err(got.cpu().reshape(-1)[sub], want) <= 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ order statistics
 @pytest.mark.parametrize("S,n", [(1, 1000003), (96, 384), (7, 6304), (4, 65536)])
 def test_quantile_rows(ops, S, n):
