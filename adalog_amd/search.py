@@ -123,21 +123,25 @@ _GRID_MEMO = {}
 def _memo(kind, x, extra, make):
     """The percentile grid depends only on the tensor it is computed from, and every search round asks for it again
     (1 + search_round times per operand).  Keyed by storage pointer + in-place version + shape: a re-parameterised
-    weight or a new raw_input gives a new key.  ``delta`` is handed out as a copy (the FPCS driver narrows it in place).
-    Entries die with their tensor's search (forget_grids)."""
+    weight or a new raw_input gives a new key.  The entry holds a reference to the tensor it was computed from, so its
+    storage cannot be freed and handed to another tensor (same address, same version) while the entry lives.
+    ``delta`` is handed out as a copy (the FPCS driver narrows it in place).  Entries die with their tensor's search
+    (forget_grids)."""
     key = (kind, x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride())) + tuple(extra)
     hit = _GRID_MEMO.get(key)
     if hit is None:
-        hit = _GRID_MEMO[key] = make()
+        hit = _GRID_MEMO[key] = (x, make())
+    hit = hit[1]
     return hit[0], hit[1], hit[2].clone()
 
 
 def memo_tensor_fn(kind, x, extra, make):
-    """Same memo for other pure functions of a captured tensor (post-GELU positive percentiles); result returned as is."""
+    """Same memo for other pure functions of a captured tensor (post-GELU positive percentiles, the sorted copy + prefix
+    sums of the self-MSE searches); result returned as is."""
     key = (kind, x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride())) + tuple(extra)
     if key not in _GRID_MEMO:
-        _GRID_MEMO[key] = make()
-    return _GRID_MEMO[key]
+        _GRID_MEMO[key] = (x, make())
+    return _GRID_MEMO[key][1]
 
 
 def forget_grids():

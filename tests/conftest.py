@@ -22,3 +22,15 @@ def golden():
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 
     return load
+
+
+@pytest.fixture(autouse=True)
+def _forget_search_memos():
+    """The searches memoise per-tensor work (percentile grids, sorted copies) until a module's search ends; tests that
+    call scoring functions directly never reach that point, so the memo is dropped after every test."""
+    yield
+    try:
+        from adalog_amd import search
+        search.forget_grids()
+    except Exception:
+        pass
