@@ -94,7 +94,7 @@ static int pick_wide(int M, int64_t kvalid_bytes) {
 // reduce_cols with ref_div > 1 asks for per-workgroup accumulation, which only the streaming kernel provides: when that
 // kernel is not eligible the launch falls back to per-tile partials (candidate innermost), and the layout says so.
 static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, bool scoring = true,
-                        int64_t kvalid_bytes = 0, int64_t kb = 0, bool ref_transposed = false, int dtype = -1) {
+                        int64_t kvalid_bytes = 0, int64_t kb = 0, bool ref_transposed = false, int dtype = -1, bool gen = false) {
     static const int use_stream = getenv("ADALOG_GEMM_STREAM") ? atoi(getenv("ADALOG_GEMM_STREAM")) : 1;
     static const int use_wgacc = getenv("ADALOG_GEMM_WGACC") ? atoi(getenv("ADALOG_GEMM_WGACC")) : 1;
     Layout L{};
@@ -110,7 +110,9 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     // Slab kernel: int8 or fp8 storage, one group, 2..6 K-steps (the 256-column slab is <= 96 KiB), whole 32-row units, at least three
     // units per wave and slab, and a streamed operand small enough for the caches.
     static const int use_slab = getenv("ADALOG_GEMM_SLAB") ? atoi(getenv("ADALOG_GEMM_SLAB")) : 1;
-    static const int slab_min_m = getenv("ADALOG_GEMM_SLAB_MINM") ? atoi(getenv("ADALOG_GEMM_SLAB_MINM")) : 768;
+    // (the GEN form -- no packed operand, no packer launch -- pays from one unit per wave and slab on: attn.proj's 384 rows)
+    static const int slab_min_m_env = getenv("ADALOG_GEMM_SLAB_MINM") ? atoi(getenv("ADALOG_GEMM_SLAB_MINM")) : 768;
+    const int slab_min_m = gen ? 256 : slab_min_m_env;
     // streamed (fixed) operand: every workgroup walks all of it past its resident slab, from L2 or the Infinity Cache (16 MiB:
     // swin stage 0's 100 352 tokens x 128 B -- those launches ran on the streaming kernel at 0.26 of peak, 0.43 here)
     static const int64_t slab_max_bytes = getenv("ADALOG_GEMM_SLAB_MAXB") ? atoll(getenv("ADALOG_GEMM_SLAB_MAXB")) : ((int64_t)16 << 20);
@@ -440,6 +442,98 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     }
     ADALOG_LAUNCH_CHECK("adalog_gemm_score");
     return 0;
+}
+
+// ---- activation-candidate scoring call with the candidate operand GENERATED inside the slab kernel (k_gemm_slab<.., GEN>)
+// reference linear.py:394-430 (_search_best_a_scale): scores[p] = -norm * sum_{t, o} (raw_out[t][o] - bias[o] -
+//   s_w[o] * s_p * sum_k Wq[o][k] * (clamp(rne(x[t][k] / s_p) + z_p, 0, 2^bits - 1) - z_p))^2
+// Wp: packed weight image (q_w - z_w) [M][Kp] int8 (dtype 0) or fp8 e4m3 (dtype 3); x: fp32 [T][ldx] (K valid); ref: raw_out
+// [T][M]; scale / zp: the P (64, 128 or 256) per-tensor candidates; row_scale [M] = s_w, row_bias [M] = bias (or null).
+extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
+                                    int keep_h, int keep_n, int cand_inner, double norm, void* workspace,
+                                    int64_t workspace_bytes, void* stream);
+
+static Layout gen_layout(int dtype, int M, int64_t T, int K, int64_t Kp, int P) {
+    Layout L{};
+    if (!(dtype == 0 || dtype == 3) || !(P == 64 || P == 128 || P == 256) || T < 1 || T * P >= ((int64_t)1 << 31) || K < 16 || K % 16 != 0 ||
+        Kp < K) return L;
+    return layout_of(M, (int)(T * P), 1, 1, 1, P, 1, true, (int64_t)K, Kp, true, dtype, true);
+}
+
+extern "C" int adalog_score_act_gen_ok(int dtype, int M, int64_t T, int K, int64_t Kp, int P) {
+    static const int use_gen = getenv("ADALOG_SLAB_GEN") ? atoi(getenv("ADALOG_SLAB_GEN")) : 1;
+    if (!use_gen || Kp % BK3 != 0) return 0;
+    const Layout L = gen_layout(dtype, M, T, K, Kp, P);
+    return (L.slab && L.acc) ? 1 : 0;
+}
+
+extern "C" int64_t adalog_score_act_gen_workspace_bytes(int dtype, int M, int64_t T, int K, int64_t Kp, int P) {
+    const Layout L = gen_layout(dtype, M, T, K, Kp, P);
+    if (!(L.slab && L.acc)) return -1;
+    return L.elems * (int64_t)sizeof(float) + ((int64_t)M * 4 + 15) / 16 * 16;          // accumulators + a zero row-bias vector
+}
+
+extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp, const float* x, int64_t T, int K, int64_t ldx,
+                                    const float* scale, const float* zp, int P, int n_bits, const float* ref,
+                                    const float* row_scale, const float* row_bias, double norm, void* workspace,
+                                    int64_t workspace_bytes, float* scores, void* stream) {
+    ADALOG_ARG_CHECK(Wp && x && scale && zp && ref && row_scale && workspace && scores, "score_act_gen: null pointer");
+    ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7 && (dtype != 3 || n_bits <= 4), "score_act_gen: bad bit width for the operand type");
+    ADALOG_ARG_CHECK(ldx >= K && (ldx % 4 == 0) && ((uintptr_t)x & 15) == 0, "score_act_gen: activation rows must be 16-byte aligned");
+    const Layout L = gen_layout(dtype, M, T, K, Kp, P);
+    ADALOG_ARG_CHECK(L.slab && L.acc && Kp % BK3 == 0, "score_act_gen: shape not taken by the slab kernel (adalog_score_act_gen_ok)");
+    ADALOG_ARG_CHECK(workspace_bytes >= adalog_score_act_gen_workspace_bytes(dtype, M, T, K, Kp, P) && ((uintptr_t)workspace & 15) == 0,
+                     "score_act_gen: workspace too small or misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* zero_bias = (float*)((uint8_t*)workspace + L.elems * sizeof(float));
+    if (!row_bias) {
+        const hipError_t me = hipMemsetAsync(zero_bias, 0, (size_t)M * 4, st);
+        if (me != hipSuccess) { adalog_set_error("adalog_score_act_gen (zero bias)", me); return (int)me; }
+        row_bias = zero_bias;
+    }
+    GemmArgs p{};
+    p.A = (const uint8_t*)Wp; p.B = nullptr;
+    p.M = M; p.N = (int)(T * P); p.Kb = Kp; p.Kvb = K; p.C = 1; p.G = 1; p.gmod = 1;
+    p.ref = ref; p.ldr = 1; p.sRg = 0; p.ref_cs = M; p.ref_div = P;
+    ADALOG_ARG_CHECK((int64_t)(T - 1) * M + M < ((int64_t)1 << 31), "score_act_gen: reference exceeds 32-bit addressing");
+    p.sa = scale; p.sa_c = 0; p.sa_mul = 1.0f; p.sb = scale; p.sb_c = 1; p.sb_n = 0;
+    p.row_scale = row_scale; p.row_bias = row_bias;
+    p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad; p.order = 2; p.reduce_cols = 0;
+    p.partial = partial; p.wg_acc = (double*)partial; p.timeline = g_timeline;
+    p.slab_U = L.slab_U; p.slab_R = L.slab_R;
+    p.gen_x = x; p.gen_ldx = ldx; p.gen_K = K; p.gen_scale = scale; p.gen_zp = zp;
+    p.gen_qmax = (float)((1 << n_bits) - 1);
+    // tie zone: the reciprocal-multiply quotient is within ~2 ulp of the IEEE one; only |quotient| <= 2^bits matters (beyond it
+    // both clamp alike), so 6e-7 * 2^bits bounds the difference with a factor of 2.5 to spare; never narrower than 1e-5
+    const float zone = 6e-7f * (float)(1 << n_bits);
+    p.gen_tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
+    const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
+    const int SBN = 32 * L.slab_nb;
+    const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4;
+    const int nref = SBN / P;
+#define LAUNCH_GEN(NREFV, DTV, NBV)                                                                               \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, true, DTV, NBV, true>),   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        adalog_note_kernel(DTV == 3 ? (NBV == 8 ? "k_gemm_slab_gen<fp8>" : "k_gemm_slab128_gen<fp8>") : (NBV == 8 ? "k_gemm_slab_gen<i8>" : "k_gemm_slab128_gen<i8>")); \
+        hipLaunchKernelGGL((k_gemm_slab<NREFV, true, DTV, NBV, true>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
+    } while (0)
+#define LAUNCH_GEN_DT(DTV)                                                                                        \
+    do {                                                                                                          \
+        if (L.slab_nb == 8) { if (nref == 1) LAUNCH_GEN(1, DTV, 8); else if (nref == 2) LAUNCH_GEN(2, DTV, 8); else LAUNCH_GEN(4, DTV, 8); } \
+        else { if (nref == 1) LAUNCH_GEN(1, DTV, 4); else LAUNCH_GEN(2, DTV, 4); }                                \
+    } while (0)
+    if (dtype == 3) LAUNCH_GEN_DT(3); else LAUNCH_GEN_DT(0);
+#undef LAUNCH_GEN_DT
+#undef LAUNCH_GEN
+    ADALOG_LAUNCH_CHECK("adalog_score_act_gen");
+    // fixed-order fp64 finish of the per-workgroup accumulators [wgs][1][256]
+    return adalog_finish_scores(partial, scores, L.wgs, BN2, BN2, P, 1, 1, 0, 0, 2, norm, nullptr, 0, stream);
 }
 
 // scores[c][h?][n?] = -norm * sum over (image, [h], m_tile, [n]) of partial[c][g][m_tile][n] with the layout returned by

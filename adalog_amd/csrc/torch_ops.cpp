@@ -56,6 +56,12 @@ int adalog_score_w_self(const float* w, int rows, int I, const float* scale, con
 int adalog_score_a_self(const float* x, int64_t rows, int I, const float* scale, const float* zp, int P, int channel_wise,
                         int n_bits, double norm, float* partial, int64_t partial_elems, float* scores, void* stream);
 int64_t adalog_score_a_self_partial_elems(int64_t rows, int I, int P);
+int adalog_score_act_gen_ok(int dtype, int M, int64_t T, int K, int64_t Kp, int P);
+int64_t adalog_score_act_gen_workspace_bytes(int dtype, int M, int64_t T, int K, int64_t Kp, int P);
+int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp, const float* x, int64_t T, int K, int64_t ldx,
+                         const float* scale, const float* zp, int P, int n_bits, const float* ref, const float* row_scale,
+                         const float* row_bias, double norm, void* workspace, int64_t workspace_bytes, float* scores,
+                         void* stream);
 int64_t adalog_sorted_prefix_workspace_bytes(int64_t S, int64_t n);
 int adalog_sorted_prefix_build(const float* x, int64_t S, int64_t n, float* sorted, double* prefix, void* workspace,
                                int64_t workspace_bytes, void* stream);
@@ -254,6 +260,24 @@ at::Tensor score_a_self(const at::Tensor& x2, const at::Tensor& scale, const at:
     return scores;
 }
 
+// linear.py:394-430: one activation-candidate scoring call, the candidate operand generated inside the slab kernel
+at::Tensor score_act_gen(int64_t dtype, const at::Tensor& wp, const at::Tensor& x2, const at::Tensor& scale, const at::Tensor& zp,
+                         int64_t n_bits, const at::Tensor& ref2, const at::Tensor& row_scale, const c10::optional<at::Tensor>& row_bias,
+                         double norm) {
+    TORCH_CHECK(wp.is_cuda() && wp.is_contiguous() && wp.scalar_type() == pack_dtype(dtype), "wp: contiguous packed weight image of the given dtype");
+    const int64_t M = wp.size(-2), Kp = wp.size(-1), T = x2.size(0), K = x2.size(1), P = scale.numel();
+    TORCH_CHECK(ref2.dim() == 2 && ref2.size(0) == T && ref2.size(1) == M, "ref: expected [T, M]");
+    const int64_t wsb = adalog_score_act_gen_workspace_bytes((int)dtype, (int)M, T, (int)K, Kp, (int)P);
+    TORCH_CHECK(wsb >= 0, "adalog::score_act_gen: shape not supported (adalog_score_act_gen_ok)");
+    at::Tensor ws = at::empty({(wsb + 15) / 16 * 2}, x2.options().dtype(at::kDouble));
+    at::Tensor scores = at::empty({P, 1}, x2.options());
+    check(adalog_score_act_gen((int)dtype, wp.data_ptr(), (int)M, Kp, fptr(x2, "x"), T, (int)K, K, fptr(scale, "scale"), fptr(zp, "zp"),
+                               (int)P, (int)n_bits, fptr(ref2, "ref"), fptr(row_scale, "row_scale"), optf(row_bias, "row_bias"), norm,
+                               ws.data_ptr(), ws.numel() * 8, scores.data_ptr<float>(), cur_stream()),
+          "adalog::score_act_gen");
+    return scores;
+}
+
 // linear.py:296-318 / 320-353 in sorted-prefix form (csrc/sorted_score.hip): x2 [S, n] -> (sorted [S, n], prefix [S, n + 1, 2] f64)
 std::tuple<at::Tensor, at::Tensor> sorted_prefix(const at::Tensor& x2) {
     TORCH_CHECK(x2.dim() == 2, "x2: expected [S, n]");
@@ -302,6 +326,8 @@ TORCH_LIBRARY(adalog, m) {
           "bool has_clamp, float clamp_min) -> (Tensor, Tensor, Tensor)");
     m.def("score_w_self(Tensor w2, Tensor scale, Tensor zp, int n_bits) -> Tensor");
     m.def("score_a_self(Tensor x2, Tensor scale, Tensor zp, bool channel_wise, int n_bits, float norm) -> Tensor");
+    m.def("score_act_gen(int dtype, Tensor wp, Tensor x2, Tensor scale, Tensor zp, int n_bits, Tensor ref2, Tensor row_scale, "
+          "Tensor? row_bias, float norm) -> Tensor");
     m.def("sorted_prefix(Tensor x2) -> (Tensor, Tensor)");
     m.def("score_self_sorted(Tensor sorted, Tensor prefix, Tensor scale, Tensor zp, int n_bits, float norm) -> Tensor");
 }
@@ -319,6 +345,7 @@ TORCH_LIBRARY_IMPL(adalog, CUDA, m) {
     m.impl("topk_next", &topk_next);
     m.impl("score_w_self", &score_w_self);
     m.impl("score_a_self", &score_a_self);
+    m.impl("score_act_gen", &score_act_gen);
     m.impl("sorted_prefix", &sorted_prefix);
     m.impl("score_self_sorted", &score_self_sorted);
 }

@@ -338,6 +338,43 @@ def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: i
     return scores
 
 
+def score_act_gen_ok(dtype: int, M: int, T: int, K: int, Kp: int, P: int) -> bool:
+    return bool(_lib.load().adalog_score_act_gen_ok(int(dtype), int(M), int(T), int(K), int(Kp), int(P)))
+
+
+def score_act_gen(dtype: int, wp, x2, scale, zp, n_bits: int, ref2, row_scale, row_bias, norm: float):
+    """Activation-candidate scores [P, 1] of a uniformly quantised Linear layer with the candidate operand generated inside
+    the slab kernel (gemm_k_slab.inc, GEN form): wp = packed weight image [1, 1, M, Kp] (int8 / fp8), x2 = activation [T, K],
+    ref2 = raw_out [T, M], (scale, zp) = the P per-tensor candidates; row_scale = weight scales [M], row_bias = bias [M]."""
+    lib = _lib.load()
+    M, Kp = wp.shape[-2], wp.shape[-1]
+    x2, ref2 = _f32c(x2, "x"), _f32c(ref2, "ref")
+    T, K = x2.shape
+    scale, zp = _f32c(scale, "scale").reshape(-1), _f32c(zp, "zp").reshape(-1)
+    P = scale.numel()
+    assert wp.dtype == _TORCH_DT[dtype] and wp.is_contiguous() and ref2.shape == (T, M)
+    row_scale = _f32c(row_scale, "row_scale")
+    row_bias = None if row_bias is None else _f32c(row_bias, "row_bias")
+    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
+        return _top("score_act_gen", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias, float(norm))
+    wsb = lib.adalog_score_act_gen_workspace_bytes(dtype, M, T, K, Kp, P)
+    if wsb < 0:
+        raise _lib.AdalogHipError("score_act_gen: shape not supported (score_act_gen_ok)")
+    ws = torch.empty((wsb + 15) // 16 * 2, dtype=torch.float64, device=x2.device)
+    scores = torch.empty((P, 1), dtype=torch.float32, device=x2.device)
+    if GEMM_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.adalog_score_act_gen(dtype, wp.data_ptr(), M, Kp, x2.data_ptr(), T, K, K, scale.data_ptr(), zp.data_ptr(), P,
+                                  int(n_bits), ref2.data_ptr(), row_scale.data_ptr(), _ptr(row_bias), float(norm),
+                                  ws.data_ptr(), ws.numel() * 8, scores.data_ptr(), _stream())
+    if GEMM_EVENTS is not None:
+        ev1.record()
+        GEMM_EVENTS.append((dtype, M, T, K, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
+    _lib.check(rc, "adalog_score_act_gen")
+    return scores
+
+
 # ------------------------------------------------------------------------------------------------ FPCS pieces
 def topk(scores, k: int):
     scores = _f32c(scores, "scores")

@@ -38,6 +38,8 @@ MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
 # activation searches (row scale in the epilogue) 2-4 % -- in round 1 the latter lost 4 %, the compiler spilled there
 FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
 # self-MSE searches scored from the sorted tensor (csrc/sorted_score.hip); 0 = one pass over the tensor per step (round 1/2)
+# uniform activation searches: candidate operand generated in the slab kernel (1) or packed to HBM first (0, rounds 1-2)
+GEN_ACT_SEARCH = os.environ.get('ADALOG_GEN_ACT', '1') != '0'
 SORTED_SELF_SEARCH = os.environ.get('ADALOG_SORTED_SELF', '1') != '0'
 
 
@@ -259,6 +261,12 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         P = scale.shape[0]
         out = []
         dt = getattr(wp, "int_dt", I8)
+        norm = 1.0 / (self._tokens_per_image() * self.out_features)
+        if GEN_ACT_SEARCH and scale.shape[1] == 1 and hasattr(be, "score_act_gen") and \
+                be.score_act_gen_ok(dt, self.out_features, M, self.in_features, wp.shape[-1], P):
+            # the candidate operand is generated inside the slab kernel: nothing is packed (gemm_k_slab.inc, GEN form)
+            return be.score_act_gen(dt, wp, x3[0], scale, zp, aq.n_bits, self.raw_out.reshape(-1, self.out_features),
+                                    self.w_quantizer.scale.data.view(-1), None if self.bias is None else self.bias.data, norm)
         chunk = self._cand_chunk(M, pad_k(self.in_features, I8))
         for s in range(0, P, chunk):
             e = min(P, s + chunk)

@@ -177,6 +177,22 @@ int adalog_fpcs_next(const float* scale, const float* zp, const float* third, in
 int adalog_candidate_grid(const float* quant4, int cols, int num_scale, int num_zp, int zp_min, int n_bits, const float* lin,
                           int has_clamp, float clamp_min, float* scale, float* zp, float* delta, void* stream);
 
+/* ---- K8 with the candidate operand generated in the kernel            reference linear.py:394-430 (_search_best_a_scale)
+ * One activation-candidate scoring call of a uniformly quantised Linear layer WITHOUT a packed candidate operand: the slab
+ * kernel quantises the two (or one / four) activation rows of a slab for all P candidates straight from the fp32 activation.
+ *   scores[p] = -norm * sum_{t, o} (ref[t][o] - row_bias[o] - row_scale[o] * s_p * sum_k Wq[o][k] * xq_p[t][k])^2,
+ *   xq_p = clamp(rne(x / s_p) + z_p, 0, 2^bits - 1) - z_p.
+ * Wp: packed weight image [M][Kp] (adalog_pack_uniform, dtype 0 = int8 or 3 = fp8 e4m3 for <= 4 bit); x: fp32 [T][ldx], K valid
+ * (K % 16 == 0); ref: fp32 [T][M]; scale / zp: [P], P in {64, 128, 256}; row_bias may be null.  adalog_score_act_gen_ok says
+ * whether the shape is taken (else: adalog_pack_uniform + adalog_gemm_score).  workspace: 16-byte aligned,
+ * adalog_score_act_gen_workspace_bytes(...) bytes. */
+int adalog_score_act_gen_ok(int dtype, int M, int64_t T, int K, int64_t Kp, int P);
+int64_t adalog_score_act_gen_workspace_bytes(int dtype, int M, int64_t T, int K, int64_t Kp, int P);
+int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp, const float* x, int64_t T, int K, int64_t ldx,
+                         const float* scale, const float* zp, int P, int n_bits, const float* ref, const float* row_scale,
+                         const float* row_bias, double norm, void* workspace, int64_t workspace_bytes, float* scores,
+                         void* stream);
+
 /* ---- K9   _search_best_w_scale_self                                   reference linear.py:296-309
  * scores[p][row] = -mean_i (w[row][i] - fq_p(w[row][i]))^2,  w: [rows][I], scale/zp: [P][rows]. */
 int adalog_score_w_self(const float* w, int rows, int I, const float* scale, const float* zp, int P, int n_bits,

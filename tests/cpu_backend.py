@@ -204,6 +204,25 @@ def score_a_self(x2, scale, zp, channel_wise, n_bits, norm):
     return (-norm * tot).float()
 
 
+def score_act_gen_ok(dtype, M, T, K, Kp, P):
+    return K % 16 == 0 and M % 32 == 0 and M >= 256 and P in (64, 128, 256)
+
+
+def score_act_gen(dtype, wp, x2, scale, zp, n_bits, ref2, row_scale, row_bias, norm):
+    """spec of ops.score_act_gen: scores[p] = -norm * sum (ref - bias - s_w * s_p * Wq . xq_p)^2 (linear.py:394-423)"""
+    K = x2.shape[1]
+    Wq = wp.reshape(wp.shape[-2], wp.shape[-1])[:, :K].to(torch.float32)             # q_w - z_w [M, K]
+    out = []
+    for s, z in zip(scale.reshape(-1).tolist(), zp.reshape(-1).tolist()):
+        s32 = torch.tensor(s, dtype=torch.float32)
+        xq = (torch.round(x2 / s32) + round(z)).clamp(0, 2 ** n_bits - 1) - round(z)
+        sim = (xq.double() @ Wq.double().t()) * (row_scale.double().view(1, -1) * float(s32))
+        if row_bias is not None:
+            sim = sim + row_bias.double().view(1, -1)
+        out.append(-norm * ((ref2.double() - sim) ** 2).sum())
+    return torch.stack(out).float().view(-1, 1)
+
+
 class SortedPrefix:
     """spec of ops.SortedPrefix: the consumer below only needs the segments themselves"""
     def __init__(self, x2):

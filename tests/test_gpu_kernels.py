@@ -408,6 +408,52 @@ def test_self_mse_scores_sorted_prefix(ops, bits):
         assert rel_err(got.cpu().reshape(-1)[sub], want) <= 1e-5
 
 
+@pytest.mark.parametrize("M,T,K,P,bits,dt", [
+    (1152, 4 * 197, 384, 128, 4, "fp8"), (1536, 3 * 197, 384, 128, 4, "i8"), (384, 5 * 197, 384, 128, 4, "fp8"),
+    (384, 591, 384, 128, 3, "fp8"),                    # odd token count: the last slab holds one token
+    (768, 1001, 192, 128, 6, "i8"), (512, 777, 96, 128, 4, "fp8"),      # K = 96: the second K-step is half padding
+    (1152, 403, 384, 64, 4, "fp8"), (1152, 402, 384, 256, 4, "i8"),     # 4 tokens / 1 token per slab
+    (2304, 600, 768, 128, 4, "fp8"), (256, 640, 768, 128, 6, "i8"),     # K = 768: 128-column slabs
+])
+def test_score_act_gen_matches_packed_path(ops, M, T, K, P, bits, dt):
+    """gemm_k_slab.inc GEN form (candidate operand generated in the kernel) against pack_uniform + gemm_score on the same
+    candidates (the path it replaces, itself pinned to the reference's traces), incl. values planted ON rounding ties, and
+    against the oracle on four candidates."""
+    gen = g(4000 + M + T + K + P)
+    DT = ops.FP8 if dt == "fp8" else ops.I8
+    x = torch.randn(T, K, generator=gen) * 1.3 + 0.2
+    W = torch.randn(M, K, generator=gen) * 0.05
+    b = torch.randn(M, generator=gen) * 0.1
+    ref = torch.nn.functional.linear(x, W, b)
+    L = 2 ** (bits - 1)
+    w_s = (W.amax(1) - W.amin(1)) / (2 * L - 1)
+    w_z = torch.round(-W.amin(1) / w_s).clamp(0, 2 * L - 1)
+    s = (x.abs().max() * 2 / (2 * L - 1)) * (0.4 + 1.2 * torch.rand(P, 1, generator=gen))
+    z = torch.randint(0, 2 * L, (P, 1), generator=gen).float()
+    # plant exact ties: x = (k + 0.5) * s_p for some candidates (the IEEE quotient decides those bins)
+    for j in range(0, P, 9):
+        kk = torch.randint(-L, L, (K,), generator=gen).float() + 0.5
+        x[(7 * j) % T] = kk * s[j, 0]
+    xd, Wd = x.to(DEV), W.to(DEV)
+    wp = ops.pack_uniform(Wd.unsqueeze(0), w_s.to(DEV), w_z.to(DEV), 1, 0, 1, 0, 1, bits, DT)
+    norm = 1.0 / (197 * M)
+    assert ops.score_act_gen_ok(DT, M, T, K, wp.shape[-1], P)
+    for bias in (b.to(DEV), None):
+        got = ops.score_act_gen(DT, wp, xd, s.to(DEV), z.to(DEV), bits, (ref if bias is not None else ref - b).to(DEV), w_s.to(DEV), bias, norm)
+        xp = ops.pack_uniform(xd.unsqueeze(0), s.to(DEV), z.to(DEV), P, 1, 1, 0, 0, bits, DT, c_inner=True)
+        one = torch.ones(1, device=DEV)
+        want = ops.gemm_score(DT, wp, xp, M, T, P, 1, 1, (ref if bias is not None else ref - b).to(DEV).reshape(1, T, M),
+                              ops.Strided(one), ops.Strided(s.to(DEV).contiguous(), c=1), None, False, False, norm, ref_div=P,
+                              order=2, ref_transposed=True, row_scale=w_s.to(DEV),
+                              row_bias=bias if bias is not None else torch.zeros(M, device=DEV))
+        assert rel_err(got.cpu(), want.cpu()) <= 2e-6, (bias is None)
+    sub = [0, P // 3, P // 2, P - 1]
+    wq = O.uniform_fake_quant(W, w_s.view(-1, 1), w_z.view(-1, 1), bits)[0]
+    refo = O.score_a(x.view(1, T, K), wq, b, ref.view(1, T, M), s[sub].t().contiguous(), z[sub].t().contiguous(), bits, 1)
+    got = ops.score_act_gen(DT, wp, xd, s.to(DEV), z.to(DEV), bits, ref.to(DEV), w_s.to(DEV), b.to(DEV), 1.0 / (T * M))
+    assert rel_err(got.cpu().reshape(-1)[sub], refo.reshape(-1)) <= 1e-4
+
+
 # ------------------------------------------------------------------------------------------------ order statistics
 @pytest.mark.parametrize("S,n", [(1, 1000003), (96, 384), (7, 6304), (4, 65536)])
 def test_quantile_rows(ops, S, n):
