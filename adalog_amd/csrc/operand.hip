@@ -425,6 +425,98 @@ __global__ __launch_bounds__(256) void k_pack_uniform_i8_fast(PackArgs a) {
     }
 }
 
+// Uniform packing with per-ROW candidate parameters (pr != 0: the weight candidates of every weight search -- a (scale, zero
+// point) per candidate and output channel).  k_pack_kfast fetches the two parameters of every (candidate, row) from global
+// memory inside the candidate loop; even fetched one candidate ahead that is an L2 round trip per iteration, and the fc2
+// weight candidates (128 x 384 x 1536 bf16 = 151 MB) were written at 1.05 TB/s.  Here a block owns 256 consecutive k-quads
+// (at most RT rows), stages {1/s, s, -z, qmax - z} of those rows for ALL candidates in LDS once, and its loop over the
+// candidates touches global memory only to store.  The tie zone is tested once per quad, and bf16 comes from the top half of
+// the fp32 (the values are small integers: exact).
+constexpr int TAB_ROWS = 6;
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_uniform_tab(PackArgs a) {
+    constexpr bool FP8OUT = std::is_same<T, fp8_t>::value;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float4* s_tab = reinterpret_cast<float4*>(s_raw);                       // [rows of this block][C]
+    const int64_t nq = a.Kp >> 2;
+    const int64_t total = a.G * a.R * nq;
+    const int64_t q0 = (int64_t)blockIdx.x * 256;
+    const int64_t row0 = q0 / nq;                                            // flattened (g, r) row
+    const int64_t rowN = min((q0 + 255) / nq, a.G * a.R - 1);
+    const int nrows = (int)(rowN - row0 + 1);
+    const int C = (int)a.C;
+    for (int e = threadIdx.x; e < nrows * C; e += 256) {
+        const int rl = e / C, c = e - rl * C;
+        const int64_t gr = row0 + rl, g = gr / a.R, r = gr - g * a.R;
+        const int64_t pidx = c * a.pc + (g % a.gmod) * a.pg + r * a.pr;
+        const float sc = a.scale[pidx], z = rintf(a.zp[pidx]);
+        s_tab[e] = make_float4(__builtin_amdgcn_rcpf(sc), sc, -z, a.qmax - z);
+    }
+    __syncthreads();
+    const int64_t idx = q0 + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t gr = idx / nq, kq = idx - gr * nq;
+    const int64_t g = gr / a.R, r = gr - g * a.R;
+    const int64_t k0 = kq << 2;
+    const float* xp = a.x + g * a.sxg + r * a.sxr + k0;
+    float xv[4];
+    const bool full = k0 + 3 < a.K;
+    if (full && ((uintptr_t)xp & 15) == 0) {
+        const float4 v = *reinterpret_cast<const float4*>(xp);
+        xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[e] = (k0 + e < a.K) ? xp[e] : 0.0f;
+    }
+    const float4* tab = s_tab + (int)(gr - row0) * C;
+    for (int64_t c = blockIdx.y; c < a.C; c += gridDim.y) {
+        const float4 pr = tab[c];
+        float t[4], k[4], dm = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t[e] = xv[e] * pr.x; k[e] = rintf(t[e]); dm = fmaxf(dm, fabsf(t[e] - k[e])); }
+        if (__builtin_expect(dm > 0.4999f, 0)) {                             // tie zone (see k_pack_kfast): the IEEE quotient decides
+#pragma unroll
+            for (int e = 0; e < 4; ++e) k[e] = rintf(xv[e] / pr.y);
+        }
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = __builtin_amdgcn_fmed3f(k[e], pr.z, pr.w);                // clamp(k + z, 0, qmax) - z
+            if (!full && !(k0 + e < a.K)) v[e] = 0.0f;
+        }
+        const int64_t orow = a.c_inner ? (g * a.R + r) * a.C + c : (c * a.G + g) * a.R + r;
+        T* op = reinterpret_cast<T*>(a.out) + orow * a.Kp + k0;
+        if (FP8OUT) {
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+            *reinterpret_cast<int*>(op) = pk;
+        } else if (sizeof(T) == 1) {
+            unsigned pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(v[e] + 128.0f, e, pk);
+            *reinterpret_cast<unsigned*>(op) = pk ^ 0x80808080u;
+        } else if (sizeof(T) == 2) {
+            const unsigned b0 = __float_as_uint(v[0]), b1 = __float_as_uint(v[1]), b2 = __float_as_uint(v[2]), b3 = __float_as_uint(v[3]);
+            *reinterpret_cast<uint2*>(op) = make_uint2((b0 >> 16) | (b1 & 0xffff0000u), (b2 >> 16) | (b3 & 0xffff0000u));
+        } else {
+            *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (a.rowsum) {
+            // one atomic per wavefront when all 64 lanes work on the same row (the common case: Kp/4 >= 64)
+            int isum = (int)((v[0] + v[1]) + (v[2] + v[3]));                 // small integers: exact in fp32
+            const int64_t ridx = (c * a.G + g) * a.R + r;
+            const int64_t first = __builtin_amdgcn_readfirstlane((int)ridx);
+            if (__all((int)ridx == (int)first) && __popcll(__ballot(1)) == 64) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) isum += __shfl_xor(isum, o);
+                if ((threadIdx.x & 63) == 0 && isum != 0) atomicAdd(a.rowsum + ridx, isum);
+            } else if (isum != 0) {
+                atomicAdd(a.rowsum + ridx, isum);
+            }
+        }
+    }
+}
+
 template <typename T, int KIND>
 int launch_pack(const PackArgs& a, hipStream_t st) {
     constexpr int EPT = Out<T>::EPT;
@@ -436,6 +528,19 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         // enough candidate groups to fill the chip when the source is small (weights), all candidates per thread otherwise
         int64_t gy = 1;
         while (gx * gy < 2048 && gy < a.C) gy *= 2;
+        static const int use_tab = getenv("ADALOG_PACK_TAB") ? atoi(getenv("ADALOG_PACK_TAB")) : 1;
+        if (KIND == KIND_UNIFORM && a.pr != 0 && use_tab && (a.Kp >> 2) >= 64 && a.C * TAB_ROWS * sizeof(float4) <= 64 * 1024 &&
+            !getenv("ADALOG_PACK_GENERIC")) {
+            // per-row parameters (weight candidates): parameters staged in LDS per block, exact grid (no grid-stride loop)
+            const int64_t bx = (total + 255) / 256;
+            int64_t by = 1;
+            while (bx * by < 1024 && by < a.C) by *= 2;
+            if (bx < ((int64_t)1 << 31)) {
+                hipLaunchKernelGGL((k_pack_uniform_tab<T>), dim3((unsigned)bx, (unsigned)by), dim3(256),
+                                   (size_t)a.C * TAB_ROWS * sizeof(float4), st, a);
+                return 0;
+            }
+        }
         if (KIND == KIND_UNIFORM && sizeof(T) == 1 && a.pr == 0 && (a.pg == 0 || a.G <= 65535) && !a.rowsum && a.C <= 2048 &&
             !getenv("ADALOG_PACK_GENERIC")) {
             // per-tensor parameters: one grid over all groups; per-group (per-head) parameters: grid.z = groups

@@ -211,6 +211,19 @@ def test_pack_adalog_fast_vs_generic(ops, monkeypatch):
         slow = ops.pack_uniform(xa, su, zu, P, 1, 1, 0, 0, 4, ops.I8, c_inner=c_inner)
         monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
         assert torch.equal(fast, slow), c_inner
+    # uniform, per-ROW candidates (weight searches): LDS-table kernel (k_pack_uniform_tab) vs the generic one, every output type,
+    # ragged K (rows of 1530 and 257 elements), with and without the integer row sums
+    for K, rows in ((1530, 96), (257, 130)):
+        wa = (torch.randn(1, rows, K, generator=gen) * 0.1).to(DEV)
+        sw = (torch.rand(P, rows, generator=gen) * 0.02 + 0.004).to(DEV)
+        zw = torch.randint(0, 16, (P, rows), generator=gen).float().to(DEV)
+        for dt in (ops.I8, ops.FP8, ops.BF16, ops.F32):
+            for c_inner in (True, False):
+                fast, rs_f = ops.pack_uniform(wa, sw, zw, P, rows, 1, 0, 1, 4, dt, want_rowsum=True, c_inner=c_inner)
+                monkeypatch.setenv("ADALOG_PACK_GENERIC", "1")
+                slow, rs_s = ops.pack_uniform(wa, sw, zw, P, rows, 1, 0, 1, 4, dt, want_rowsum=True, c_inner=c_inner)
+                monkeypatch.delenv("ADALOG_PACK_GENERIC", raising=False)
+                assert torch.equal(fast.view(torch.uint8), slow.view(torch.uint8)) and torch.equal(rs_f, rs_s), (K, dt, c_inner)
     # per-head candidates (attention q / k operands): grid.z walks the groups; int8 and fp8, 64-byte rows, ragged K
     xh = torch.randn(24, 197, 61, generator=gen).to(DEV) * 2
     sh_ = (torch.rand(P, 6, generator=gen) * 0.3 + 0.05).to(DEV)
