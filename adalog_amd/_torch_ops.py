@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libadalog_torch.so")
 OPS = ("uniform_fake_quant", "log_fake_quant", "log2_shift", "score_act_fused", "topk", "pack_uniform", "pack_adalog", "gemm_score",
-       "topk_next", "score_w_self", "score_a_self", "sorted_prefix", "score_self_sorted", "score_act_gen")
+       "topk_next", "score_w_self", "score_a_self", "sorted_prefix", "score_self_sorted", "score_act_gen", "gemm_score_partial", "finish_topk_next", "score_act_gen_partial")
 _state = None
 
 

@@ -352,6 +352,10 @@ inline int grid1(int64_t n, int cap = 2048) {
 
 }  // namespace
 
+// One zeroed device word of the current device's ring (the launch's last block puts it back to zero): shared with the fused
+// finish + top-k kernel of gemm_score.hip.  nullptr when the ring cannot be allocated.
+extern "C" unsigned int* adalog_ticket_slot(void) { return ticket_slot(); }
+
 // Allocates the current device's ticket ring (idempotent).  Call once per device before capturing BRECQ launches into a
 // HIP graph: the allocation synchronises the device, which would invalidate a capture in progress.
 extern "C" int adalog_brecq_init(void) {

@@ -467,6 +467,11 @@ extern "C" int adalog_score_act_gen_ok(int dtype, int M, int64_t T, int K, int64
     return (L.slab && L.acc) ? 1 : 0;
 }
 
+extern "C" int adalog_score_act_gen_wgs(int dtype, int M, int64_t T, int K, int64_t Kp, int P) {
+    const Layout L = gen_layout(dtype, M, T, K, Kp, P);
+    return (L.slab && L.acc) ? L.wgs : -1;
+}
+
 extern "C" int64_t adalog_score_act_gen_workspace_bytes(int dtype, int M, int64_t T, int K, int64_t Kp, int P) {
     const Layout L = gen_layout(dtype, M, T, K, Kp, P);
     if (!(L.slab && L.acc)) return -1;
@@ -477,7 +482,7 @@ extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp
                                     const float* scale, const float* zp, int P, int n_bits, const float* ref,
                                     const float* row_scale, const float* row_bias, double norm, void* workspace,
                                     int64_t workspace_bytes, float* scores, void* stream) {
-    ADALOG_ARG_CHECK(Wp && x && scale && zp && ref && row_scale && workspace && scores, "score_act_gen: null pointer");
+    ADALOG_ARG_CHECK(Wp && x && scale && zp && ref && row_scale && workspace, "score_act_gen: null pointer");
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7 && (dtype != 3 || n_bits <= 4), "score_act_gen: bad bit width for the operand type");
     ADALOG_ARG_CHECK(ldx >= K && (ldx % 4 == 0) && ((uintptr_t)x & 15) == 0, "score_act_gen: activation rows must be 16-byte aligned");
     const Layout L = gen_layout(dtype, M, T, K, Kp, P);
@@ -532,7 +537,9 @@ extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp
 #undef LAUNCH_GEN_DT
 #undef LAUNCH_GEN
     ADALOG_LAUNCH_CHECK("adalog_score_act_gen");
-    // fixed-order fp64 finish of the per-workgroup accumulators [wgs][1][256]
+    // fixed-order fp64 finish of the per-workgroup accumulators [wgs][1][256] (scores == null: left to the caller, who hands the
+    // accumulators -- the start of the workspace -- to adalog_finish_scores / adalog_finish_topk_next with MT = adalog_score_act_gen_wgs)
+    if (!scores) return 0;
     return adalog_finish_scores(partial, scores, L.wgs, BN2, BN2, P, 1, 1, 0, 0, 2, norm, nullptr, 0, stream);
 }
 
@@ -576,4 +583,55 @@ extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT,
         hipLaunchKernelGGL(k_finish<true>, dim3((unsigned)((nout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
     ADALOG_LAUNCH_CHECK("adalog_finish_scores");
     return 0;
+}
+
+// finish + top-k + next grid in one launch where the layout allows it (see gemm_finish.inc); otherwise adalog_finish_scores
+// followed by adalog_topk_next.  Arguments: those of adalog_finish_scores, then those of adalog_topk_next (scores [C][cols],
+// cols = (keep_h ? gmod : 1) * (keep_n ? N : 1)).  Single-GPU only: with several ranks the scores are all-reduced between the two.
+extern "C" int adalog_topk_next(const float* scores, int P, int cols, int k, const float* scale, const float* zp, const float* third,
+                                int new_cnt, const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale,
+                                float* out_zp, float* out_third, int* idx_out, void* stream);
+
+extern "C" int adalog_finish_topk_next(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
+                                       int keep_h, int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes,
+                                       int k, const float* scale, const float* zp, const float* third, int new_cnt,
+                                       const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale,
+                                       float* out_zp, float* out_third, void* stream) {
+    ADALOG_ARG_CHECK(partial && scores && scale && out_scale && MT >= 1 && N >= 1 && Npad >= N && C >= 1 && C <= 256 && G >= 1 &&
+                     gmod >= 1 && G % gmod == 0 && k >= 1 && k <= C, "finish_topk_next: bad arguments");
+    ADALOG_ARG_CHECK(new_cnt == 0 || (lin && delta), "finish_topk_next: expansion needs lin and delta");
+    ADALOG_ARG_CHECK(new_cnt > 0 || k == 1, "finish_topk_next: the commit form takes k = 1");
+    ADALOG_ARG_CHECK((zp == nullptr) == (out_zp == nullptr) && (third == nullptr) == (out_third == nullptr),
+                     "finish_topk_next: in/out parameter planes must match");
+    static const int use_fused = getenv("ADALOG_FINISH_TOPK") ? atoi(getenv("ADALOG_FINISH_TOPK")) : 1;
+    const int nh = keep_h ? gmod : 1, nn = keep_n ? N : 1, cols = nh * nn;
+    FinishArgs p{};
+    p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = MT; p.N = N; p.Npad = Npad;
+    p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm; p.cin = cand_inner ? C : 0;
+    TopkArgs t{};
+    t.k = k; t.new_cnt = new_cnt; t.has_clamp = has_clamp; t.clamp_min = clamp_min; t.scale = scale; t.zp = zp; t.third = third;
+    t.lin = lin; t.delta = delta; t.o_scale = out_scale; t.o_zp = out_zp; t.o_third = out_third;
+    hipStream_t st = (hipStream_t)stream;
+    const bool c_ok = (C == 64 || C == 128 || C == 256);
+    if (use_fused && cand_inner == 2 && !keep_n && c_ok && Npad == 256 && nh <= 64) {
+        unsigned int* ticket = adalog_ticket_slot();
+        if (ticket) {
+            hipLaunchKernelGGL(k_finish_wgacc_topk, dim3((unsigned)(C * nh)), dim3(256), 0, st, p, (const double*)partial, MT, t, ticket);
+            ADALOG_LAUNCH_CHECK("adalog_finish_topk_next");
+            return 0;
+        }
+    }
+    const int64_t nout = (int64_t)C * cols;
+    const int64_t per_out = (int64_t)(G / gmod) * (keep_h ? 1 : gmod) * MT * (keep_n ? 1 : N);
+    if (use_fused && cand_inner == 1 && c_ok && per_out <= 512 && nout >= 4096) {
+        const int gpb = 256 / C;
+        hipLaunchKernelGGL(k_finish_tpo_topk, dim3((unsigned)((cols + gpb - 1) / gpb)), dim3(256), 0, st, p, t);
+        ADALOG_LAUNCH_CHECK("adalog_finish_topk_next");
+        return 0;
+    }
+    const int rc = adalog_finish_scores(partial, scores, MT, N, Npad, C, G, gmod, keep_h, keep_n, cand_inner, norm, workspace,
+                                        workspace_bytes, stream);
+    if (rc) return rc;
+    return adalog_topk_next(scores, C, cols, k, scale, zp, third, new_cnt, lin, delta, has_clamp, clamp_min, out_scale, out_zp,
+                            out_third, nullptr, stream);
 }

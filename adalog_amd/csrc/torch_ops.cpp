@@ -48,6 +48,10 @@ int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int6
 int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
                          int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, int cand_inner);
+int adalog_finish_topk_next(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
+                            int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes, int k,
+                            const float* scale, const float* zp, const float* third, int new_cnt, const float* lin, float* delta,
+                            int has_clamp, float clamp_min, float* out_scale, float* out_zp, float* out_third, void* stream);
 int adalog_topk_next(const float* scores, int P, int cols, int k, const float* scale, const float* zp, const float* third,
                      int new_cnt, const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale,
                      float* out_zp, float* out_third, int* idx_out, void* stream);
@@ -179,14 +183,14 @@ at::Tensor pack_adalog(const at::Tensor& x3, const at::Tensor& scale, const at::
     return out;
 }
 
-// One scoring call: the MFMA GEMM with the squared-error epilogue and its fixed-order finish (reference linear.py:378-385,
-// 415-424; matmul.py:154-164, 345-352).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N*ref_div, Kp], ref: [G, M, N] (or [G, N, M]).
-at::Tensor gemm_score(int64_t dtype, const at::Tensor& A, const at::Tensor& B, int64_t M, int64_t N, int64_t C, int64_t G,
-                      int64_t gmod, int64_t k_valid, const at::Tensor& ref, const at::Tensor& sa, int64_t sa_c, int64_t sa_g,
-                      double sa_mul, const at::Tensor& sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
-                      const c10::optional<at::Tensor>& bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, bool keep_h, bool keep_n,
-                      double norm, int64_t ref_div, int64_t order, bool ref_transposed, const c10::optional<at::Tensor>& row_scale,
-                      const c10::optional<at::Tensor>& row_bias) {
+struct GemmLaunch { at::Tensor partial; int MT, Npad, mode, n_last; };
+
+GemmLaunch gemm_score_launch(int64_t dtype, const at::Tensor& A, const at::Tensor& B, int64_t M, int64_t N, int64_t C, int64_t G,
+                             int64_t gmod, int64_t k_valid, const at::Tensor& ref, const at::Tensor& sa, int64_t sa_c, int64_t sa_g,
+                             double sa_mul, const at::Tensor& sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
+                             const c10::optional<at::Tensor>& bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, bool keep_n,
+                             int64_t ref_div, int64_t order, bool ref_transposed, const c10::optional<at::Tensor>& row_scale,
+                             const c10::optional<at::Tensor>& row_bias) {
     TORCH_CHECK(A.is_cuda() && B.is_cuda() && A.is_contiguous() && B.is_contiguous() && A.dim() == 4 && B.dim() == 4, "A / B: contiguous 4-D HIP tensors");
     TORCH_CHECK(A.scalar_type() == pack_dtype(dtype) && B.scalar_type() == pack_dtype(dtype), "A / B: dtype does not match");
     const int64_t Kp = A.size(3), n_cols = N * ref_div, c_grid = ref_div > 1 ? 1 : C;
@@ -199,25 +203,74 @@ at::Tensor gemm_score(int64_t dtype, const at::Tensor& A, const at::Tensor& B, i
     else { ldr = ref.size(-1); ref_cs = 1; }
     const int64_t sRg = G == 1 ? 0 : ref.size(-1) * ref.size(-2);
     const int reduce_cols = keep_n ? 0 : 1;
-    int MT = 0, Npad = 0, mode = 0;
+    GemmLaunch L;
     const int64_t n_part = adalog_gemm_score_layout((int)M, (int)n_cols, (int)c_grid, (int)G, (int)gmod, (int)ref_div, reduce_cols,
-                                                    (int)dtype, Kp, k_valid, ref_transposed ? 1 : 0, &MT, &Npad, &mode);
-    at::Tensor partial = at::empty({(n_part + 1) / 2}, A.options().dtype(at::kDouble));              // 8-byte aligned
+                                                    (int)dtype, Kp, k_valid, ref_transposed ? 1 : 0, &L.MT, &L.Npad, &L.mode);
+    L.partial = at::empty({(n_part + 1) / 2}, A.options().dtype(at::kDouble));              // 8-byte aligned
     check(adalog_gemm_score((int)dtype, A.data_ptr(), B.data_ptr(), sAc, sAg, sBc, sBg, (int)M, (int)n_cols, Kp, k_valid, (int)c_grid,
                             (int)G, (int)gmod, ref.data_ptr<float>(), ldr, sRg, ref_cs, (int)ref_div, fptr(sa, "sa"), sa_c, sa_g,
                             (float)sa_mul, fptr(sb, "sb"), sb_c, sb_g, sb_n, optf(bias, "bias"), bi_c, bi_g, bi_n,
-                            optf(row_scale, "row_scale"), optf(row_bias, "row_bias"), (float*)partial.data_ptr(), n_part, nullptr, 0,
+                            optf(row_scale, "row_scale"), optf(row_bias, "row_bias"), (float*)L.partial.data_ptr(), n_part, nullptr, 0,
                             0, 0, (int)order, reduce_cols, cur_stream()),
           "adalog::gemm_score");
+    L.n_last = (reduce_cols && L.mode != 1) ? L.Npad : (int)N;
+    return L;
+}
+
+// One scoring call: the MFMA GEMM with the squared-error epilogue and its fixed-order finish (reference linear.py:378-385,
+// 415-424; matmul.py:154-164, 345-352).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N*ref_div, Kp], ref: [G, M, N] (or [G, N, M]).
+at::Tensor gemm_score(int64_t dtype, const at::Tensor& A, const at::Tensor& B, int64_t M, int64_t N, int64_t C, int64_t G,
+                      int64_t gmod, int64_t k_valid, const at::Tensor& ref, const at::Tensor& sa, int64_t sa_c, int64_t sa_g,
+                      double sa_mul, const at::Tensor& sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
+                      const c10::optional<at::Tensor>& bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, bool keep_h, bool keep_n,
+                      double norm, int64_t ref_div, int64_t order, bool ref_transposed, const c10::optional<at::Tensor>& row_scale,
+                      const c10::optional<at::Tensor>& row_bias) {
+    const GemmLaunch L = gemm_score_launch(dtype, A, B, M, N, C, G, gmod, k_valid, ref, sa, sa_c, sa_g, sa_mul, sb, sb_c, sb_g, sb_n,
+                                           bias, bi_c, bi_g, bi_n, keep_n, ref_div, order, ref_transposed, row_scale, row_bias);
     const int64_t cols = (keep_h ? gmod : 1) * (keep_n ? N : 1);
     at::Tensor scores = at::empty({C, cols}, A.options().dtype(at::kFloat));
-    const int n_last = (reduce_cols && mode != 1) ? Npad : (int)N;
-    const int64_t wsb = adalog_finish_workspace_bytes(MT, n_last, (int)C, (int)G, keep_n ? 1 : 0, mode);
+    const int64_t wsb = adalog_finish_workspace_bytes(L.MT, L.n_last, (int)C, (int)G, keep_n ? 1 : 0, L.mode);
     at::Tensor ws = at::empty({wsb / 8}, A.options().dtype(at::kDouble));
-    check(adalog_finish_scores((const float*)partial.data_ptr(), scores.data_ptr<float>(), MT, n_last, Npad, (int)C, (int)G, (int)gmod,
-                               keep_h ? 1 : 0, keep_n ? 1 : 0, mode, norm, wsb ? ws.data_ptr() : nullptr, wsb, cur_stream()),
+    check(adalog_finish_scores((const float*)L.partial.data_ptr(), scores.data_ptr<float>(), L.MT, L.n_last, L.Npad, (int)C, (int)G,
+                               (int)gmod, keep_h ? 1 : 0, keep_n ? 1 : 0, L.mode, norm, wsb ? ws.data_ptr() : nullptr, wsb, cur_stream()),
           "adalog::gemm_score (finish)");
     return scores;
+}
+
+// the same launch WITHOUT the finish: returns the partial sums (layout: adalog_gemm_score_layout) for adalog::finish_topk_next
+at::Tensor gemm_score_partial(int64_t dtype, const at::Tensor& A, const at::Tensor& B, int64_t M, int64_t N, int64_t C, int64_t G,
+                              int64_t gmod, int64_t k_valid, const at::Tensor& ref, const at::Tensor& sa, int64_t sa_c, int64_t sa_g,
+                              double sa_mul, const at::Tensor& sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
+                              const c10::optional<at::Tensor>& bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, bool keep_h, bool keep_n,
+                              double norm, int64_t ref_div, int64_t order, bool ref_transposed,
+                              const c10::optional<at::Tensor>& row_scale, const c10::optional<at::Tensor>& row_bias) {
+    (void)keep_h; (void)norm;
+    return gemm_score_launch(dtype, A, B, M, N, C, G, gmod, k_valid, ref, sa, sa_c, sa_g, sa_mul, sb, sb_c, sb_g, sb_n, bias, bi_c, bi_g,
+                             bi_n, keep_n, ref_div, order, ref_transposed, row_scale, row_bias).partial;
+}
+
+// finish + top-k + next grid (linear.py:483-523 after a scoring call) in one launch where the layout allows it
+std::tuple<at::Tensor, at::Tensor, at::Tensor, at::Tensor> finish_topk_next(
+        const at::Tensor& partial, int64_t MT, int64_t n_last, int64_t Npad, int64_t C, int64_t G, int64_t gmod, bool keep_h, bool keep_n,
+        int64_t mode, double norm, int64_t k, const at::Tensor& scale, const c10::optional<at::Tensor>& zp,
+        const c10::optional<at::Tensor>& third, int64_t new_cnt, const c10::optional<at::Tensor>& lin,
+        const c10::optional<at::Tensor>& delta, bool has_clamp, double clamp_min) {
+    TORCH_CHECK(partial.is_cuda() && partial.is_contiguous(), "partial: contiguous HIP tensor");
+    const int64_t cols = scale.size(1), rows = new_cnt > 0 ? k * new_cnt : 1;
+    at::Tensor scores = at::empty({C, cols}, scale.options());
+    at::Tensor o_s = at::empty({rows, cols}, scale.options());
+    at::Tensor o_z = zp.has_value() ? at::empty({rows, cols}, scale.options()) : at::empty({0}, scale.options());
+    at::Tensor o_t = third.has_value() ? at::empty({rows, cols}, scale.options()) : at::empty({0}, scale.options());
+    const int64_t wsb = adalog_finish_workspace_bytes((int)MT, (int)n_last, (int)C, (int)G, keep_n ? 1 : 0, (int)mode);
+    at::Tensor ws = at::empty({wsb / 8}, scale.options().dtype(at::kDouble));
+    check(adalog_finish_topk_next((const float*)partial.data_ptr(), scores.data_ptr<float>(), (int)MT, (int)n_last, (int)Npad, (int)C,
+                                  (int)G, (int)gmod, keep_h ? 1 : 0, keep_n ? 1 : 0, (int)mode, norm, wsb ? ws.data_ptr() : nullptr, wsb,
+                                  (int)k, fptr(scale, "scale"), optf(zp, "zp"), optf(third, "third"), (int)new_cnt, optf(lin, "lin"),
+                                  delta.has_value() ? const_cast<float*>(fptr(*delta, "delta")) : nullptr, has_clamp ? 1 : 0,
+                                  (float)clamp_min, o_s.data_ptr<float>(), zp.has_value() ? o_z.data_ptr<float>() : nullptr,
+                                  third.has_value() ? o_t.data_ptr<float>() : nullptr, cur_stream()),
+          "adalog::finish_topk_next");
+    return {scores, o_s, o_z, o_t};
 }
 
 // linear.py:483-523: top-k of the scores and the next candidate grid around the winners (or the committed winner)
@@ -278,6 +331,23 @@ at::Tensor score_act_gen(int64_t dtype, const at::Tensor& wp, const at::Tensor& 
     return scores;
 }
 
+// ... WITHOUT the finish: returns the workspace whose head holds the fp64 accumulators [wgs][1][256] (for adalog::finish_topk_next)
+at::Tensor score_act_gen_partial(int64_t dtype, const at::Tensor& wp, const at::Tensor& x2, const at::Tensor& scale, const at::Tensor& zp,
+                                 int64_t n_bits, const at::Tensor& ref2, const at::Tensor& row_scale,
+                                 const c10::optional<at::Tensor>& row_bias) {
+    TORCH_CHECK(wp.is_cuda() && wp.is_contiguous() && wp.scalar_type() == pack_dtype(dtype), "wp: contiguous packed weight image of the given dtype");
+    const int64_t M = wp.size(-2), Kp = wp.size(-1), T = x2.size(0), K = x2.size(1), P = scale.numel();
+    TORCH_CHECK(ref2.dim() == 2 && ref2.size(0) == T && ref2.size(1) == M, "ref: expected [T, M]");
+    const int64_t wsb = adalog_score_act_gen_workspace_bytes((int)dtype, (int)M, T, (int)K, Kp, (int)P);
+    TORCH_CHECK(wsb >= 0, "adalog::score_act_gen_partial: shape not supported (adalog_score_act_gen_ok)");
+    at::Tensor ws = at::empty({(wsb + 15) / 16 * 2}, x2.options().dtype(at::kDouble));
+    check(adalog_score_act_gen((int)dtype, wp.data_ptr(), (int)M, Kp, fptr(x2, "x"), T, (int)K, K, fptr(scale, "scale"), fptr(zp, "zp"),
+                               (int)P, (int)n_bits, fptr(ref2, "ref"), fptr(row_scale, "row_scale"), optf(row_bias, "row_bias"), 1.0,
+                               ws.data_ptr(), ws.numel() * 8, nullptr, cur_stream()),
+          "adalog::score_act_gen_partial");
+    return ws;
+}
+
 // linear.py:296-318 / 320-353 in sorted-prefix form (csrc/sorted_score.hip): x2 [S, n] -> (sorted [S, n], prefix [S, n + 1, 2] f64)
 std::tuple<at::Tensor, at::Tensor> sorted_prefix(const at::Tensor& x2) {
     TORCH_CHECK(x2.dim() == 2, "x2: expected [S, n]");
@@ -322,12 +392,20 @@ TORCH_LIBRARY(adalog, m) {
     m.def("gemm_score(int dtype, Tensor A, Tensor B, int M, int N, int C, int G, int gmod, int k_valid, Tensor ref, Tensor sa, int sa_c, "
           "int sa_g, float sa_mul, Tensor sb, int sb_c, int sb_g, int sb_n, Tensor? bias, int bi_c, int bi_g, int bi_n, bool keep_h, "
           "bool keep_n, float norm, int ref_div, int order, bool ref_transposed, Tensor? row_scale, Tensor? row_bias) -> Tensor");
+    m.def("gemm_score_partial(int dtype, Tensor A, Tensor B, int M, int N, int C, int G, int gmod, int k_valid, Tensor ref, Tensor sa, "
+          "int sa_c, int sa_g, float sa_mul, Tensor sb, int sb_c, int sb_g, int sb_n, Tensor? bias, int bi_c, int bi_g, int bi_n, "
+          "bool keep_h, bool keep_n, float norm, int ref_div, int order, bool ref_transposed, Tensor? row_scale, Tensor? row_bias) -> Tensor");
+    m.def("finish_topk_next(Tensor partial, int MT, int n_last, int Npad, int C, int G, int gmod, bool keep_h, bool keep_n, int mode, "
+          "float norm, int k, Tensor scale, Tensor? zp, Tensor? third, int new_cnt, Tensor? lin, Tensor(a!)? delta, bool has_clamp, "
+          "float clamp_min) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("topk_next(Tensor scores, Tensor scale, Tensor? zp, Tensor? third, int k, int new_cnt, Tensor? lin, Tensor(a!)? delta, "
           "bool has_clamp, float clamp_min) -> (Tensor, Tensor, Tensor)");
     m.def("score_w_self(Tensor w2, Tensor scale, Tensor zp, int n_bits) -> Tensor");
     m.def("score_a_self(Tensor x2, Tensor scale, Tensor zp, bool channel_wise, int n_bits, float norm) -> Tensor");
     m.def("score_act_gen(int dtype, Tensor wp, Tensor x2, Tensor scale, Tensor zp, int n_bits, Tensor ref2, Tensor row_scale, "
           "Tensor? row_bias, float norm) -> Tensor");
+    m.def("score_act_gen_partial(int dtype, Tensor wp, Tensor x2, Tensor scale, Tensor zp, int n_bits, Tensor ref2, Tensor row_scale, "
+          "Tensor? row_bias) -> Tensor");
     m.def("sorted_prefix(Tensor x2) -> (Tensor, Tensor)");
     m.def("score_self_sorted(Tensor sorted, Tensor prefix, Tensor scale, Tensor zp, int n_bits, float norm) -> Tensor");
 }
@@ -342,10 +420,13 @@ TORCH_LIBRARY_IMPL(adalog, CUDA, m) {
     m.impl("pack_uniform", &pack_uniform);
     m.impl("pack_adalog", &pack_adalog);
     m.impl("gemm_score", &gemm_score);
+    m.impl("gemm_score_partial", &gemm_score_partial);
+    m.impl("finish_topk_next", &finish_topk_next);
     m.impl("topk_next", &topk_next);
     m.impl("score_w_self", &score_w_self);
     m.impl("score_a_self", &score_a_self);
     m.impl("score_act_gen", &score_act_gen);
+    m.impl("score_act_gen_partial", &score_act_gen_partial);
     m.impl("sorted_prefix", &sorted_prefix);
     m.impl("score_self_sorted", &score_self_sorted);
 }

@@ -195,9 +195,66 @@ def _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid
     return elems, mt.value, npad.value, mode.value
 
 
+class PendingScores:
+    """The partial sums a scoring kernel left behind, not yet reduced to scores: what ``gemm_score(..., defer=True)`` and
+    ``score_act_gen(..., defer=True)`` return.  ``finish()`` gives the [C, cols] scores; on one GPU the FPCS driver hands the
+    object to ``finish_topk_next`` instead, which reduces, ranks and writes the next candidate grid in ONE launch."""
+    __slots__ = ("partial", "MT", "n_last", "Npad", "C", "G", "gmod", "keep_h", "keep_n", "mode", "norm", "cols", "N")
+
+    def __init__(self, partial, MT, n_last, Npad, C, G, gmod, keep_h, keep_n, mode, norm, N):
+        self.partial, self.MT, self.n_last, self.Npad, self.C, self.G, self.gmod = partial, MT, n_last, Npad, C, G, gmod
+        self.keep_h, self.keep_n, self.mode, self.norm, self.N = bool(keep_h), bool(keep_n), mode, float(norm), N
+        self.cols = (gmod if keep_h else 1) * (N if keep_n else 1)
+
+    def _ws(self):
+        lib = _lib.load()
+        nb = lib.adalog_finish_workspace_bytes(self.MT, self.n_last, self.C, self.G, int(self.keep_n), self.mode)
+        return (torch.empty(nb // 8, dtype=torch.float64, device=self.partial.device) if nb else None), nb
+
+    def finish(self):
+        lib = _lib.load()
+        scores = torch.empty((self.C, self.cols), dtype=torch.float32, device=self.partial.device)
+        ws, nb = self._ws()
+        rc = lib.adalog_finish_scores(self.partial.data_ptr(), scores.data_ptr(), self.MT, self.n_last, self.Npad, self.C, self.G,
+                                      self.gmod, int(self.keep_h), int(self.keep_n), self.mode, self.norm, _ptr(ws), nb, _stream())
+        _lib.check(rc, "adalog_finish_scores")
+        return scores
+
+
+def finish_topk_next(pend: PendingScores, scale, zp, third, k: int, new_cnt: int, lin, delta, clamp_min: Optional[float]):
+    """finish(pend) followed by topk_next(...) -- one launch where the partial layout allows it (csrc/gemm_finish.inc).  Same return
+    value as topk_next.  Single-GPU form: with several ranks the scores are all-reduced between the two steps."""
+    scale = _f32c(scale, "scale")
+    rows = k * new_cnt if new_cnt > 0 else 1
+    cols = pend.cols
+    assert scale.shape[0] == pend.C and scale.shape[1] == cols
+    dev = scale.device
+    if _torch_ops.available():
+        scores, o_s, o_z, o_t = _top("finish_topk_next", pend.partial, pend.MT, pend.n_last, pend.Npad, pend.C, pend.G, pend.gmod,
+                                     pend.keep_h, pend.keep_n, pend.mode, pend.norm, int(k), scale, zp, third, int(new_cnt), lin, delta,
+                                     clamp_min is not None, float(clamp_min if clamp_min is not None else 0.0))
+        o_z, o_t = (None if zp is None else o_z), (None if third is None else o_t)
+    else:
+        mk = lambda src: None if src is None else torch.empty((rows, cols), dtype=torch.float32, device=dev)
+        o_s, o_z, o_t = mk(scale), mk(zp), mk(third)
+        scores = torch.empty((pend.C, cols), dtype=torch.float32, device=dev)
+        ws, nb = pend._ws()
+        rc = _lib.load().adalog_finish_topk_next(pend.partial.data_ptr(), scores.data_ptr(), pend.MT, pend.n_last, pend.Npad, pend.C,
+                                                pend.G, pend.gmod, int(pend.keep_h), int(pend.keep_n), pend.mode, pend.norm, _ptr(ws),
+                                                nb, int(k), scale.data_ptr(), _ptr(zp), _ptr(third), int(new_cnt), _ptr(lin),
+                                                _ptr(delta), int(clamp_min is not None),
+                                                float(clamp_min if clamp_min is not None else 0.0), o_s.data_ptr(), _ptr(o_z),
+                                                _ptr(o_t), _stream())
+        _lib.check(rc, "adalog_finish_topk_next")
+    if new_cnt == 0:
+        return o_s[0], (None if o_z is None else o_z[0]), (None if o_t is None else o_t[0])
+    return o_s, o_z, o_t
+
+
 def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
                bias: Optional[Strided], keep_h: bool, keep_n: bool, norm: float, sa_mul: float = 1.0,
-               ref_div: int = 1, order: int = 1, ref_transposed: bool = False, row_scale=None, row_bias=None):
+               ref_div: int = 1, order: int = 1, ref_transposed: bool = False, row_scale=None, row_bias=None,
+               defer: bool = False):
     """scores = finish(gemm_score(...)).  A: [C|1, G|1, M, Kp], B: [C|1, G|1, N, Kp]; ref: [G, M, N] fp32.
 
     With ``ref_div`` = P > 1 B is packed candidates-innermost ([1, G, N*P, Kp]), the GEMM runs over N*P columns and the
@@ -226,14 +283,22 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     sRg = 0 if G == 1 else ref.shape[-1] * ref.shape[-2]
     reduce_cols = 0 if keep_n else 1                    # column axis not kept: the kernel may sum it (per tile / per workgroup)
     k_valid = min(getattr(A, "k_valid", Kp), getattr(B, "k_valid", Kp))
+    def layout():
+        n_part, MT, Npad, mode = _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid, ref_transposed)
+        # reduced column axis: one partial per n-tile (Npad = NT) / per workgroup
+        return n_part, MT, Npad, mode, (Npad if (reduce_cols and mode != 1) else N)
     if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
-        return _top("gemm_score", int(dtype), A, B, int(M), int(N), int(C), int(G), int(gmod), int(k_valid), ref, sa.t, sa.c, sa.g,
-                    float(sa_mul), sb.t, sb.c, sb.g, sb.n, None if bias is None else bias.t, 0 if bias is None else bias.c,
-                    0 if bias is None else bias.g, 0 if bias is None else bias.n, bool(keep_h), bool(keep_n), float(norm),
-                    int(ref_div), int(order), bool(ref_transposed),
-                    None if row_scale is None else _f32c(row_scale, "row_scale"),
-                    None if row_bias is None else _f32c(row_bias, "row_bias"))
-    n_part, MT, Npad, mode = _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid, ref_transposed)
+        args = (int(dtype), A, B, int(M), int(N), int(C), int(G), int(gmod), int(k_valid), ref, sa.t, sa.c, sa.g,
+                float(sa_mul), sb.t, sb.c, sb.g, sb.n, None if bias is None else bias.t, 0 if bias is None else bias.c,
+                0 if bias is None else bias.g, 0 if bias is None else bias.n, bool(keep_h), bool(keep_n), float(norm),
+                int(ref_div), int(order), bool(ref_transposed),
+                None if row_scale is None else _f32c(row_scale, "row_scale"),
+                None if row_bias is None else _f32c(row_bias, "row_bias"))
+        if not defer:
+            return _top("gemm_score", *args)
+        n_part, MT, Npad, mode, n_last = layout()
+        return PendingScores(_top("gemm_score_partial", *args), MT, n_last, Npad, C, G, gmod, keep_h, keep_n, mode, norm, N)
+    n_part, MT, Npad, mode, n_last = layout()
     partial = torch.empty((n_part + 1) // 2, dtype=torch.float64, device=A.device).view(torch.float32)   # 8-byte aligned
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -251,15 +316,8 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
         ev1.record()
         GEMM_EVENTS.append((dtype, M, N, k_valid, C, G, ev0, ev1, lib.adalog_last_kernel().decode()))   # k_valid: un-padded K
     _lib.check(rc, "adalog_gemm_score")
-    cols = (gmod if keep_h else 1) * (N if keep_n else 1)
-    scores = torch.empty((C, cols), dtype=torch.float32, device=A.device)
-    n_last = Npad if (reduce_cols and mode != 1) else N   # reduced: one partial per n-tile (Npad = NT) / per workgroup
-    ws_bytes = lib.adalog_finish_workspace_bytes(MT, n_last, C, G, int(keep_n), mode)
-    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=A.device) if ws_bytes else None
-    rc = lib.adalog_finish_scores(partial.data_ptr(), scores.data_ptr(), MT, n_last, Npad, C, G, gmod, int(keep_h),
-                                  int(keep_n), mode, float(norm), _ptr(ws), ws_bytes, _stream())
-    _lib.check(rc, "adalog_finish_scores")
-    return scores
+    pend = PendingScores(partial, MT, n_last, Npad, C, G, gmod, keep_h, keep_n, mode, norm, N)
+    return pend if defer else pend.finish()
 
 
 def gemm_win_ok(dtype: int, M: int, N: int, G: int, gmod: int, ref_div: int, k_valid: int) -> bool:
@@ -342,7 +400,7 @@ def score_act_gen_ok(dtype: int, M: int, T: int, K: int, Kp: int, P: int) -> boo
     return bool(_lib.load().adalog_score_act_gen_ok(int(dtype), int(M), int(T), int(K), int(Kp), int(P)))
 
 
-def score_act_gen(dtype: int, wp, x2, scale, zp, n_bits: int, ref2, row_scale, row_bias, norm: float):
+def score_act_gen(dtype: int, wp, x2, scale, zp, n_bits: int, ref2, row_scale, row_bias, norm: float, defer: bool = False):
     """Activation-candidate scores [P, 1] of a uniformly quantised Linear layer with the candidate operand generated inside
     the slab kernel (gemm_k_slab.inc, GEN form): wp = packed weight image [1, 1, M, Kp] (int8 / fp8), x2 = activation [T, K],
     ref2 = raw_out [T, M], (scale, zp) = the P per-tensor candidates; row_scale = weight scales [M], row_bias = bias [M]."""
@@ -355,24 +413,29 @@ def score_act_gen(dtype: int, wp, x2, scale, zp, n_bits: int, ref2, row_scale, r
     assert wp.dtype == _TORCH_DT[dtype] and wp.is_contiguous() and ref2.shape == (T, M)
     row_scale = _f32c(row_scale, "row_scale")
     row_bias = None if row_bias is None else _f32c(row_bias, "row_bias")
-    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
-        return _top("score_act_gen", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias, float(norm))
-    wsb = lib.adalog_score_act_gen_workspace_bytes(dtype, M, T, K, Kp, P)
-    if wsb < 0:
+    wgs = lib.adalog_score_act_gen_wgs(dtype, M, T, K, Kp, P)
+    if wgs < 0:
         raise _lib.AdalogHipError("score_act_gen: shape not supported (score_act_gen_ok)")
+    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
+        if not defer:
+            return _top("score_act_gen", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias, float(norm))
+        ws = _top("score_act_gen_partial", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias)
+        return PendingScores(ws, wgs, 256, 256, P, 1, 1, False, False, 2, norm, T)
+    wsb = lib.adalog_score_act_gen_workspace_bytes(dtype, M, T, K, Kp, P)
     ws = torch.empty((wsb + 15) // 16 * 2, dtype=torch.float64, device=x2.device)
-    scores = torch.empty((P, 1), dtype=torch.float32, device=x2.device)
+    scores = None if defer else torch.empty((P, 1), dtype=torch.float32, device=x2.device)
     if GEMM_EVENTS is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     rc = lib.adalog_score_act_gen(dtype, wp.data_ptr(), M, Kp, x2.data_ptr(), T, K, K, scale.data_ptr(), zp.data_ptr(), P,
                                   int(n_bits), ref2.data_ptr(), row_scale.data_ptr(), _ptr(row_bias), float(norm),
-                                  ws.data_ptr(), ws.numel() * 8, scores.data_ptr(), _stream())
+                                  ws.data_ptr(), ws.numel() * 8, _ptr(scores), _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
         GEMM_EVENTS.append((dtype, M, T, K, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
     _lib.check(rc, "adalog_score_act_gen")
-    return scores
+    # (the accumulators [wgs][1][256] fp64 sit at the start of the workspace: the per-workgroup layout of gemm_score)
+    return PendingScores(ws, wgs, 256, 256, P, 1, 1, False, False, 2, norm, T) if defer else scores
 
 
 # ------------------------------------------------------------------------------------------------ FPCS pieces

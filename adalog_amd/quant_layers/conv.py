@@ -141,7 +141,7 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
     def _w2(self):
         return self.weight.data.view(self.out_channels, -1)
 
-    def _score_w(self, xp, ref, M, fmap, scale, zp):
+    def _score_w(self, xp, ref, M, fmap, scale, zp, defer=False):
         """conv.py:226-255 -> scores [P, oc] = -sum_images mean_{fw,fh} (raw_out - conv(x, fq_p(W)) - b)^2."""
         be = backend.get()
         oc = self.out_channels
@@ -157,7 +157,8 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
             wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, oc, 1, 0, 1, self.w_quantizer.n_bits, F32,
                                  c_inner=True)
             out.append(be.gemm_score(F32, xp, wp, M, oc, e - s, 1, 1, ref, Strided(ones), Strided(sc, c=oc, n=1), bias,
-                                     False, True, 1.0 / fmap, ref_div=e - s, order=2, ref_transposed=True))
+                                     False, True, 1.0 / fmap, ref_div=e - s, order=2, ref_transposed=True,
+                                     defer=defer and chunk >= P))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def weight_fpcs(self, fpcs_width=16, steps=4):
@@ -169,7 +170,7 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
         xp = be.pack_raw(patches.unsqueeze(0))
         ref = self.raw_out.permute(1, 0, 2, 3).reshape(1, self.out_channels, M).contiguous()      # [1, oc, tokens]
         scale, zp, delta = search.weight_grid(self._w2(), self.w_quantizer.n_bits, self.eq_n, conv=True)
-        fn = lambda s, z, t: self._score_w(xp, ref, M, gh * gw, s, z)
+        fn = lambda s, z, t: self._score_w(xp, ref, M, gh * gw, s, z, defer=True)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
         if res is not None:
             self.w_quantizer.scale.data.copy_(res[0].view(-1, 1))

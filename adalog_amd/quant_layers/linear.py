@@ -212,7 +212,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, dt)
         return dt, xp, Strided(aq.scale.data.view(-1)), 1.0, None
 
-    def _score_w(self, fixed, scale, zp):
+    def _score_w(self, fixed, scale, zp, defer=False):
         """linear.py:355-384 -> scores [P, O] = -sum_images mean_tokens (raw_out - q_a(x) . fq_p(W)^T - b)^2."""
         be = backend.get()
         dt, xp, sa, sa_mul, shift = fixed
@@ -239,7 +239,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             out.append(be.gemm_score(dt, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2_t(), sa,
                                      Strided(sc, c=self.out_features, n=1), bias, False, True,
                                      1.0 / self._tokens_per_image(), sa_mul=sa_mul, ref_div=e - s, order=2,
-                                     ref_transposed=True))
+                                     ref_transposed=True, defer=defer and chunk >= P))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _pack_w_fixed(self, dt=I8, want_rowsum=False):
@@ -248,7 +248,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         return be.pack_uniform(self._w2().unsqueeze(0), wq.scale.data.view(-1), wq.zero_point.data.view(-1), 1, 0, 1, 0, 1,
                                wq.n_bits, dt, want_rowsum=want_rowsum)
 
-    def _score_a(self, wp, scale, zp):
+    def _score_a(self, wp, scale, zp, defer=False):
         """linear.py:394-423 -> scores [P, 1] = -sum_images mean_{tokens,out} (raw_out - fq_p(x) . q_w(W)^T - b)^2.
 
         Evaluated transposed, out^T = q_w(W) . fq_p(x)^T: GEMM rows = output channels, GEMM columns = (token, candidate)
@@ -266,7 +266,8 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
                 be.score_act_gen_ok(dt, self.out_features, M, self.in_features, wp.shape[-1], P):
             # the candidate operand is generated inside the slab kernel: nothing is packed (gemm_k_slab.inc, GEN form)
             return be.score_act_gen(dt, wp, x3[0], scale, zp, aq.n_bits, self.raw_out.reshape(-1, self.out_features),
-                                    self.w_quantizer.scale.data.view(-1), None if self.bias is None else self.bias.data, norm)
+                                    self.w_quantizer.scale.data.view(-1), None if self.bias is None else self.bias.data, norm,
+                                    defer=defer)
         chunk = self._cand_chunk(M, pad_k(self.in_features, I8))
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
@@ -277,7 +278,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
                                      False, False, 1.0 / (self._tokens_per_image() * self.out_features),
                                      ref_div=e - s, order=2, ref_transposed=True,
                                      row_scale=self.w_quantizer.scale.data.view(-1),
-                                     row_bias=None if self.bias is None else self.bias.data))
+                                     row_bias=None if self.bias is None else self.bias.data, defer=defer and chunk >= P))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _score_w_self(self, scale, zp):
@@ -312,7 +313,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             fn = lambda s, z, t: self._score_w_self(s, z)
         else:
             fixed = self._pack_x_fixed()
-            fn = lambda s, z, t: self._score_w(fixed, s, z)
+            fn = lambda s, z, t: self._score_w(fixed, s, z, defer=True)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
         if res is not None:
             self._commit_w(res[0], res[1])
@@ -326,7 +327,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             dt = self._int_dt(self.raw_input.numel() // self.in_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K)
             wp = self._pack_w_fixed(dt)
             wp.int_dt = dt
-            fn = lambda s, z, t: self._score_a(wp, s, z)
+            fn = lambda s, z, t: self._score_a(wp, s, z, defer=True)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, 1e-4)
         if res is not None:
             self._commit_a(res[0], res[1])
@@ -517,7 +518,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
             self._lx_key = key
         return self._lx
 
-    def _score_scale_logbase(self, wp, bias_fold, scale, qv):
+    def _score_scale_logbase(self, wp, bias_fold, scale, qv, defer=False):
         """linear.py:816-848 / 856-890 / 898-931 -> scores [P, 1] for per-candidate (scale_p, q_p); transposed like
         _score_a (rows = output channels, columns = (token, candidate))."""
         be = backend.get()
@@ -544,7 +545,8 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
                                      Strided(search.const_tensor([1.0], dev)), Strided(sc, c=1), None, False, False,
                                      1.0 / (self._tokens_per_image() * self.out_features), sa_mul=self._ts32(),
                                      ref_div=e - s, order=2, ref_transposed=True,
-                                     row_scale=self.w_quantizer.scale.data.view(-1), row_bias=bias_fold))
+                                     row_scale=self.w_quantizer.scale.data.view(-1), row_bias=bias_fold,
+                                     defer=defer and chunk >= P))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def activation_fpcs(self, ud_candidates, base_num=8, scale_num=16, fpcs_width=32, steps=6):
@@ -567,7 +569,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         delta = (scales16[1:2] - scales16[0:1]).view(1).contiguous()
         scale = scales16.repeat(base_num, 1).contiguous()                           # a.repeat(1, base_num) layout
         qv = top_q.repeat_interleave(scale_num, dim=0).contiguous()
-        fn = lambda s, z, t: self._score_scale_logbase(wp, bias_fold, s, t)
+        fn = lambda s, z, t: self._score_scale_logbase(wp, bias_fold, s, t, defer=True)
         res = search.fpcs(scale, None, qv, delta, fn, steps, fpcs_width, self.eq_n, None)
         if res is not None:
             aq.scale.data.copy_(res[0].view(aq.scale.shape))

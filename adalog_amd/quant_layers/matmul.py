@@ -177,7 +177,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         return be.pack_uniform(self._bt3_packable(B), s, z, 1, 0, H, 1 if H > 1 else 0, 0, self.B_quantizer.n_bits, dt,
                                k_align=al)
 
-    def _score(self, which, fixed, scale, zp, dt=I8, fixed_sa=None, sa_mul=1.0):
+    def _score(self, which, fixed, scale, zp, dt=I8, fixed_sa=None, sa_mul=1.0, defer=False):
         """matmul.py:135-163 (which='A') / :173-201 (which='B') -> scores [P, H].
 
         The candidates go into the GEMM's COLUMN axis (packed candidates-innermost): the 128 candidates of one output
@@ -206,12 +206,12 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
                 sa = Strided(self.B_quantizer.scale.data.view(-1), g=pg)
                 out.append(be.gemm_score(dt, fixed, cand, Sp, S, e - s0, G, H, self._ref3(), sa, sb, None,
                                          self.head_channel_wise, False, self._norm(A, S, Sp), sa_mul=sa_mul,
-                                         ref_div=e - s0, order=2, ref_transposed=True))
+                                         ref_div=e - s0, order=2, ref_transposed=True, defer=defer and chunk >= P))
             else:
                 sa = fixed_sa if fixed_sa is not None else Strided(self.A_quantizer.scale.data.view(-1), g=pg)
                 out.append(be.gemm_score(dt, fixed, cand, S, Sp, e - s0, G, H, self._ref3_t(), sa, sb, None,
                                          self.head_channel_wise, False, self._norm(A, S, Sp), sa_mul=sa_mul,
-                                         ref_div=e - s0, order=2, ref_transposed=True))
+                                         ref_div=e - s0, order=2, ref_transposed=True, defer=defer and chunk >= P))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _commit(self, quantizer, scale, zp):
@@ -224,7 +224,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         scale, zp, delta = search.matmul_grid(x, self.B_quantizer.n_bits, self.eq_n, self.head_channel_wise)
         if fixed is None:
             fixed = self._pack_fixed("B" if which == "A" else "A", dt)
-        fn = lambda s, z, t: self._score(which, fixed, s, z, dt, fixed_sa, sa_mul)
+        fn = lambda s, z, t: self._score(which, fixed, s, z, dt, fixed_sa, sa_mul, defer=True)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
         if res is not None:
             self._commit(self.A_quantizer if which == "A" else self.B_quantizer, res[0], res[1])

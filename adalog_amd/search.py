@@ -39,6 +39,7 @@ def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 1
          clamp_min: Optional[float] = None):
     """Run the progressive search.  ``score_fn(scale, zp, third) -> scores [P, cols]`` (rank-local partial sums).
 
+    ``score_fn`` may return an ``ops.PendingScores`` (partial sums not yet reduced) instead of the scores.
     Returns the committed (scale [cols], zp [cols] | None, third [cols] | None); with steps == 1 nothing is committed
     (the reference's loop never reaches its top-1 branch then) and None is returned.
     """
@@ -47,10 +48,21 @@ def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 1
     lin = linspace01(new_cnt, scale.device)
     remain = steps
     first = True
+    pending_t = getattr(be, "PendingScores", ())
     while remain > 0:
-        scores = parallel.all_reduce_sum(score_fn(scale, zp, third))
+        res = score_fn(scale, zp, third)
         last = (remain == 1) and not first
         k = 1 if last else width
+        if isinstance(res, pending_t) and not parallel.is_dist() and (last or remain > 1):
+            # one GPU: the scoring kernel's partial sums are reduced, ranked and expanded into the next grid by ONE launch
+            # (ops.finish_topk_next); with several ranks the scores are all-reduced between the reduction and the ranking
+            if last:
+                return be.finish_topk_next(res, scale, zp, third, 1, 0, None, None, None)
+            scale, zp, third = be.finish_topk_next(res, scale, zp, third, k, new_cnt, lin, delta, clamp_min)
+            remain -= 1
+            first = False
+            continue
+        scores = parallel.all_reduce_sum(res.finish() if isinstance(res, pending_t) else res)
         if last:
             return be.topk_next(scores, scale, zp, third, 1, 0, None, None, None)
         if remain == 1:          # steps == 1: survivors are selected but never committed (linear.py:490-491)

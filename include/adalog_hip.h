@@ -130,6 +130,14 @@ int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int
 /* Scratch for the two-stage form used when cand_inner = 1 and keep_n = 0 (sums of 10^4..10^5 terms per candidate): bytes
  * to pass as `workspace` (0: not needed; a NULL / short workspace falls back to the one-pass kernels). */
 int64_t adalog_finish_workspace_bytes(int MT, int N, int C, int G, int keep_n, int cand_inner);
+/* adalog_finish_scores followed by adalog_topk_next (reference linear.py:483-523 after a scoring call) -- in ONE launch where the
+ * partial layout allows it (per-workgroup accumulators: the last block to finish ranks; candidate-innermost per-column partials: a
+ * block holds all candidates of its columns), otherwise as the two launches.  Single-GPU form (with several ranks the scores are
+ * all-reduced between the two steps).  `scores` [C][cols] is still written. */
+int adalog_finish_topk_next(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
+                            int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes, int k,
+                            const float* scale, const float* zp, const float* third, int new_cnt, const float* lin, float* delta,
+                            int has_clamp, float clamp_min, float* out_scale, float* out_zp, float* out_third, void* stream);
 
 /* ---- K11 fused  post-GELU activation-candidate search with the AdaLog quantisation inside the GEMM's loader
  *                                               reference linear.py:816-848, :856-890, :898-931 (one scoring call)
@@ -185,9 +193,11 @@ int adalog_candidate_grid(const float* quant4, int cols, int num_scale, int num_
  * Wp: packed weight image [M][Kp] (adalog_pack_uniform, dtype 0 = int8 or 3 = fp8 e4m3 for <= 4 bit); x: fp32 [T][ldx], K valid
  * (K % 16 == 0); ref: fp32 [T][M]; scale / zp: [P], P in {64, 128, 256}; row_bias may be null.  adalog_score_act_gen_ok says
  * whether the shape is taken (else: adalog_pack_uniform + adalog_gemm_score).  workspace: 16-byte aligned,
- * adalog_score_act_gen_workspace_bytes(...) bytes. */
+ * adalog_score_act_gen_workspace_bytes(...) bytes.  scores == NULL: the fp64 accumulators [wgs][1][256] are left at the start of
+ * the workspace for adalog_finish_scores / adalog_finish_topk_next (cand_inner = 2, MT = adalog_score_act_gen_wgs, N = Npad = 256). */
 int adalog_score_act_gen_ok(int dtype, int M, int64_t T, int K, int64_t Kp, int P);
 int64_t adalog_score_act_gen_workspace_bytes(int dtype, int M, int64_t T, int K, int64_t Kp, int P);
+int adalog_score_act_gen_wgs(int dtype, int M, int64_t T, int K, int64_t Kp, int P);   /* workgroups = MT of the accumulators; -1: not taken */
 int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp, const float* x, int64_t T, int K, int64_t ldx,
                          const float* scale, const float* zp, int P, int n_bits, const float* ref, const float* row_scale,
                          const float* row_bias, double norm, void* workspace, int64_t workspace_bytes, float* scores,

@@ -119,8 +119,29 @@ def _gemm(dtype, A, B, C, G):
     return torch.einsum("cgmk,cgnk->cgmn", Ad, Bd)
 
 
+class PendingScores:
+    """spec of ops.PendingScores: the finished scores, wrapped (the stand-in has no partial sums to defer)"""
+    def __init__(self, scores):
+        self._scores = scores
+        self.C, self.cols = scores.shape
+
+    def finish(self):
+        return self._scores
+
+
+def finish_topk_next(pend, scale, zp, third, k, new_cnt, lin, delta, clamp_min):
+    return topk_next(pend.finish(), scale, zp, third, k, new_cnt, lin, delta, clamp_min)
+
+
 def gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1, order=1,
-               ref_transposed=False, row_scale=None, row_bias=None):
+               ref_transposed=False, row_scale=None, row_bias=None, defer=False):
+    s = _gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul, ref_div, order,
+                    ref_transposed, row_scale, row_bias)
+    return PendingScores(s) if defer else s
+
+
+def _gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n, norm, sa_mul=1.0, ref_div=1, order=1,
+                ref_transposed=False, row_scale=None, row_bias=None):
     if ref_div > 1:                               # columns = (n, candidate): un-interleave back to [C, G, N, Kp]
         B = B.view(G, N, ref_div, -1).permute(2, 0, 1, 3)
     D = _gemm(dtype, A, B, C, G)                                            # [C, G, M, N]
@@ -208,7 +229,12 @@ def score_act_gen_ok(dtype, M, T, K, Kp, P):
     return K % 16 == 0 and M % 32 == 0 and M >= 256 and P in (64, 128, 256)
 
 
-def score_act_gen(dtype, wp, x2, scale, zp, n_bits, ref2, row_scale, row_bias, norm):
+def score_act_gen(dtype, wp, x2, scale, zp, n_bits, ref2, row_scale, row_bias, norm, defer=False):
+    s = _score_act_gen(dtype, wp, x2, scale, zp, n_bits, ref2, row_scale, row_bias, norm)
+    return PendingScores(s) if defer else s
+
+
+def _score_act_gen(dtype, wp, x2, scale, zp, n_bits, ref2, row_scale, row_bias, norm):
     """spec of ops.score_act_gen: scores[p] = -norm * sum (ref - bias - s_w * s_p * Wq . xq_p)^2 (linear.py:394-423)"""
     K = x2.shape[1]
     Wq = wp.reshape(wp.shape[-2], wp.shape[-1])[:, :K].to(torch.float32)             # q_w - z_w [M, K]

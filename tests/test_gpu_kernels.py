@@ -467,6 +467,81 @@ def test_score_act_gen_matches_packed_path(ops, M, T, K, P, bits, dt):
     assert rel_err(got.cpu().reshape(-1)[sub], refo.reshape(-1)) <= 1e-4
 
 
+def test_finish_topk_next_fused_equals_two_launches(ops):
+    """csrc/gemm_finish.inc: finish + top-k + next grid in ONE launch (per-column partials: a block ranks its own columns;
+    per-workgroup accumulators: the last block to arrive ranks) against adalog_finish_scores + adalog_topk_next, bit for bit:
+    weight search (a winner per output channel), per-tensor activation search through the packed path and through the
+    in-kernel-generated operand, per-head attention search; expansion (16 x 8), width-32 form with a third plane, and the commit."""
+    from adalog_amd import quant_layers as Q, search
+    gen = g(77)
+    I, Oc, T, N, bits = 384, 768, 197, 8, 4
+    x = torch.randn(N, T, I, generator=gen) * 1.3
+    W = torch.randn(Oc, I, generator=gen) * 0.05
+    b = torch.randn(Oc, generator=gen) * 0.1
+    lay = Q.AsymmetricallyBatchingQuantLinear(I, Oc, True, "raw", bits, bits, calib_batch_size=8, search_round=1, eq_n=128, n_V=1,
+                                              fpcs=True, steps=6).to(DEV)
+    lay.weight.data.copy_(W); lay.bias.data.copy_(b)
+    lay.raw_input = x.to(DEV); lay.raw_out = torch.nn.functional.linear(lay.raw_input, lay.weight.data, lay.bias.data)
+    scw, zpw = O.weight_candidates(W.view(1, Oc, I), bits)
+    sca, zpa = O.activation_candidates(x, bits, False)
+    for q, sc, zp in ((lay.a_quantizer, sca[:, 60], zpa[:, 60].float()), (lay.w_quantizer, scw[60], zpw[60].float())):
+        q.scale.data.copy_(sc.reshape(q.scale.shape)); q.zero_point.data.copy_(zp.reshape(q.zero_point.shape))
+        q.inited = True; q._zp_on_grid = True
+    lin8, lin4 = search.linspace01(8, torch.device(DEV)), search.linspace01(4, torch.device(DEV))
+
+    def both(make_pending, scale, zp, third, cases):
+        for k, new_cnt, lin, clamp in cases:
+            cols = scale.shape[1]
+            d1 = (torch.rand(cols, generator=gen) * 0.01 + 0.001).to(DEV)
+            d2 = d1.clone()
+            pend = make_pending()
+            assert isinstance(pend, ops.PendingScores)
+            want_scores = pend.finish()
+            want = ops.topk_next(want_scores, scale, zp, third, k, new_cnt, lin, d1 if new_cnt else None, clamp)
+            got = ops.finish_topk_next(make_pending(), scale, zp, third, k, new_cnt, lin, d2 if new_cnt else None, clamp)
+            for a, bb in zip(got, want):
+                assert (a is None) == (bb is None)
+                if a is not None:
+                    assert torch.equal(a, bb), (k, new_cnt)
+            assert torch.equal(d1, d2)
+
+    cases = [(16, 8, lin8, None), (16, 8, lin8, 1e-4), (1, 0, None, None)]
+    with torch.no_grad():
+        cw_s, cw_z = scw.reshape(128, -1).to(DEV), zpw.reshape(128, -1).float().to(DEV)
+        fixed = lay._pack_x_fixed()
+        both(lambda: lay._score_w(fixed, cw_s, cw_z, defer=True), cw_s, cw_z, None, cases)                       # [128, 768]
+        ca_s, ca_z = sca.t().contiguous().to(DEV), zpa.t().contiguous().float().to(DEV)
+        dt = lay._int_dt(N * T, prefer_fp8=True)
+        wp = lay._pack_w_fixed(dt); wp.int_dt = dt
+        third = (torch.arange(128, dtype=torch.float32).view(128, 1) + 10).to(DEV)
+        both(lambda: lay._score_a(wp, ca_s, ca_z, defer=True), ca_s, ca_z, third, cases + [(32, 4, lin4, None)])   # generated operand
+        from adalog_amd.quant_layers import linear as LM
+        LM.GEN_ACT_SEARCH = False
+        try:
+            both(lambda: lay._score_a(wp, ca_s, ca_z, defer=True), ca_s, ca_z, None, cases)                      # packed operand
+        finally:
+            LM.GEN_ACT_SEARCH = True
+    H, S, hd = 6, 197, 64
+    A = torch.randn(N, H, S, hd, generator=gen) * (0.5 + torch.rand(1, H, 1, 1, generator=gen))
+    Bt = torch.randn(N, H, S, hd, generator=gen)
+    mm = Q.AsymmetricallyBatchingQuantMatMul(A_bit=bits, B_bit=bits, mode="raw", calib_batch_size=8, search_round=1, eq_n=128,
+                                             head_channel_wise=True, num_heads=H, fpcs=True, steps=6).to(DEV)
+    Bd = Bt.to(DEV).transpose(-2, -1)
+    mm.raw_input, mm.raw_out = [A.to(DEV), Bd], A.to(DEV) @ Bd
+    mm._initialize_calib_parameters()
+    sA, zA = O.matmul_candidates(A, bits)
+    sB, zB = O.matmul_candidates(Bt.transpose(-2, -1), bits)
+    for q, sc, zp in ((mm.A_quantizer, sA[60], zA[60].float()), (mm.B_quantizer, sB[60], zB[60].float())):
+        q.scale.data.copy_(sc.reshape(q.scale.shape).to(DEV)); q.zero_point.data.copy_(zp.reshape(q.zero_point.shape).to(DEV))
+        q.inited = True; q._zp_on_grid = True
+    with torch.no_grad():
+        from tests.trace_replay import _mm_dt
+        dtm = _mm_dt(mm)
+        fixedB = mm._pack_fixed("B", dtm)
+        cs, cz = sA.reshape(128, H).to(DEV), zA.reshape(128, H).float().to(DEV)
+        both(lambda: mm._score("A", fixedB, cs, cz, dtm, defer=True), cs, cz, None, cases)                        # [128, 6 heads]
+
+
 # ------------------------------------------------------------------------------------------------ order statistics
 @pytest.mark.parametrize("S,n", [(1, 1000003), (96, 384), (7, 6304), (4, 65536)])
 def test_quantile_rows(ops, S, n):
