@@ -83,51 +83,68 @@ class GemmProfiler:
 
 def pmc_traffic(kernel, workload_is_default):
     """HBM bytes per launch of `kernel`, REPLAYED from the committed PMC passes of this same command
-    (tools/pmc_bench.sh -> profiles/r02_pmc_bench_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged
+    (tools/pmc_bench.sh -> profiles/r03_pmc_bench_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged
     over every dispatch of one calibration step).  None for any other workload or when the summary is absent."""
     if not workload_is_default:
         return None
-    path = os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_bench_traffic.json")
     try:
         with open(path) as f:
             rows = json.load(f)
     except OSError:
         return None
-    base = kernel.split("<")[0]
+    def matches(pmc_name):
+        """the library's kernel label (adalog_note_kernel) against the demangled instantiation name rocprofv3 reports"""
+        base, _, targs = pmc_name.partition("<")
+        targs = [a.strip() for a in targs.rstrip(">").split(",")] if targs else []
+        label, _, ldt = kernel.partition("<")
+        ldt = ldt.rstrip(">")
+        if label.startswith("k_gemm_slab"):                        # k_gemm_slab<NREF, ROWS, DT, NB, GEN>
+            if base != "k_gemm_slab" or len(targs) < 5:
+                return False
+            gen, nb128 = label.endswith("_gen"), "128" in label
+            return (targs[4] == "true") == gen and (targs[3] == "4") == nb128 and targs[2] == {"fp8": "3", "i8": "0"}.get(ldt, targs[2])
+        return pmc_name.startswith(label)
     tot, n = 0.0, 0
     for name, v in rows.items():
-        if name.startswith(base) and v.get("hbm_read_bytes_per_launch") is not None:
+        if matches(name) and v.get("hbm_read_bytes_per_launch") is not None:
             tot += (v["hbm_read_bytes_per_launch"] + (v.get("hbm_write_bytes_per_launch") or 0.0)) * v["launches"]
             n += v["launches"]
     return tot / n if n else None
 
 
 def hbm_kernels(ops, dev):
-    """Class-E (HBM-bound) kernels of the path at the deit_small / 32-image layer shapes: algorithmic bytes
-    over the median event time, against 8 TB/s."""
-    def timeit(fn, reps=5, inner=10):
-        """median over `reps` of the time of `inner` back-to-back launches / inner (steady-state rate: one launch between two
-        events is mostly launch latency at these sizes: 77 MB is 10 us at 8 TB/s)"""
-        fn(); torch.cuda.synchronize()
+    """Class-E (HBM-bound) kernels of the path at the deit_small / 32-image layer shapes: algorithmic bytes over the
+    event time per launch, against 8 TB/s.  Every launch of a timed batch reads a DIFFERENT copy of its input: the copies
+    together (>= 620 MB) exceed the 256 MiB Infinity Cache, so a launch streams from HBM (round 2 looped over one 77 MB working
+    set -- cache-resident; MI355X_MICROARCH.md: scale past L3)."""
+    NCOPY = 16
+
+    def timeit(fn, reps=3):
+        """median over `reps` of the time of NCOPY back-to-back launches (one per input copy) / NCOPY"""
+        for j in range(NCOPY):
+            fn(j)
+        torch.cuda.synchronize()
         ts = []
         for _ in range(reps):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            for _ in range(inner):
-                fn()
+            for j in range(NCOPY):
+                fn(j)
             b.record(); torch.cuda.synchronize()
-            ts.append(a.elapsed_time(b) / inner)
+            ts.append(a.elapsed_time(b) / NCOPY)
         return sorted(ts)[len(ts) // 2]
     g = torch.Generator().manual_seed(3)
     M = 32 * 197
     out = []
-    x = torch.randn(M, 1536, generator=g).to(dev)                          # fc2 input sized tensor (38.7 MB)
-    xg = torch.nn.functional.gelu(x)
+    x0 = torch.randn(M, 1536, generator=g).to(dev)                         # fc2 input sized tensor (38.7 MB)
+    xs = [x0 + 0.001 * j for j in range(NCOPY)]                            # 16 x 38.7 MB = 620 MB
+    xgs = [torch.nn.functional.gelu(v) for v in xs]
     sc1, zp1 = torch.tensor([0.21], device=dev), torch.tensor([7.0], device=dev)
     P = 128
     cs = (torch.rand(P, 1, generator=g) * 0.2 + 0.1).to(dev)
     cz = torch.randint(4, 12, (P, 1), generator=g).float().to(dev)
-    W = (torch.randn(1536, 384, generator=g) * 0.05).to(dev)
+    Ws = [(torch.randn(1536, 384, generator=g) * 0.05).to(dev) for _ in range(NCOPY)]
     csw = (torch.rand(P, 1536, generator=g) * 0.01 + 0.005).to(dev)
     czw = torch.randint(4, 12, (P, 1536), generator=g).float().to(dev)
     q = torch.tensor([37], dtype=torch.int64, device=dev)
@@ -135,18 +152,20 @@ def hbm_kernels(ops, dev):
     t1, t2 = AdaLogQuantizer.make_tables(37, 8)                             # 4 bit: n_levels = 8, 16-entry tables
     t1, t2 = t1.to(dev), t2.to(dev)
     shift = torch.tensor([0.17], device=dev)
-    x384 = x[:, :384].contiguous().unsqueeze(0)
-    nb = x.numel() * 4
+    nb = x0.numel() * 4
+    sps = [ops.sorted_prefix(v.view(1, -1)) for v in xs[:4]]
     rows = [
-        ("k_uniform_rows (K1 uniform fake-quant, fp32 in/out)", 2 * nb, lambda: ops.uniform_fake_quant(x, sc1, zp1, 4)),
+        ("k_uniform_rows (K1 uniform fake-quant, fp32 in/out)", 2 * nb, lambda j: ops.uniform_fake_quant(xs[j], sc1, zp1, 4)),
         ("k_adalog (K2/K3 shifted AdaLog fake-quant)", 2 * nb,
-         lambda: ops.log_fake_quant(xg, sc1, q, t1, t2, 4, shift=shift, sub_shift=True)),
-        ("k_score_a_self (K10, 128 candidates, x read once)", nb, lambda: ops.score_a_self(x, cs, cz, False, 4, 1.0)),
-        ("k_score_w_self (K9, 128 candidates)", W.numel() * 4, lambda: ops.score_w_self(W, csw, czw, 4)),
-        ("k_sel_hist/pick (K5 quantile, 4 radix passes)", 4 * nb, lambda: ops.quantile_rows(x.view(1, -1), [0.9, 1.0, 0.1, 0.0], 1)),
-        ("k_log2_shift (input of the fused search, once per layer)", 2 * nb, lambda: ops.log2_shift(xg, 0.17)),
-        ("k_pack_uniform_i8_fast (128 candidates -> int8 operand)", x384.numel() * 4 + x384.numel() * P,
-         lambda: ops.pack_uniform(x384, cs, cz, P, 1, 1, 0, 0, 4, ops.I8, c_inner=True)),
+         lambda j: ops.log_fake_quant(xgs[j], sc1, q, t1, t2, 4, shift=shift, sub_shift=True)),
+        ("sorted_prefix build (K10 once per tensor: library radix sort + fp64 prefix sums; read 4 B, write 20 B per element)", 6 * nb,
+         lambda j: ops.sorted_prefix(xs[j].view(1, -1))),
+        ("k_sel_hist/pick (K5 quantile, 4 radix passes)", 4 * nb, lambda j: ops.quantile_rows(xs[j].view(1, -1), [0.9, 1.0, 0.1, 0.0], 1)),
+        ("k_log2_shift (input of the fused search, once per layer)", 2 * nb, lambda j: ops.log2_shift(xgs[j], 0.17)),
+        ("k_pack_uniform_tab (fc2 weight candidates: 128 x 384 x 1536 -> bf16 operand, write side)",
+         Ws[0].numel() * 4 + Ws[0].numel() * P * 2,
+         lambda j: ops.pack_uniform(Ws[j].t().contiguous().unsqueeze(0), csw[:, :384].contiguous(), czw[:, :384].contiguous(), P, 384, 1, 0, 1,
+                                    4, ops.BF16, c_inner=True)),
     ]
     for name, nbytes, fn in rows:
         try:
@@ -155,6 +174,14 @@ def hbm_kernels(ops, dev):
                         "frac_of_8TBps": round(nbytes / ms / 1e6 / 8000.0, 3)})
         except Exception as ex:                                   # a micro-benchmark must never take the headline down
             out.append({"kernel": name, "error": repr(ex)[:200]})
+    # latency-class: a step of the self-MSE search is 2^bits x 128 bisections over the sorted tensor, not a pass over it
+    try:
+        ms = timeit(lambda j: ops.score_self_sorted(sps[j % 4], cs, cz, 4, 1.0))
+        out.append({"kernel": "k_score_sorted (K10 per FPCS step: 128 candidates x 16 bisections over 9.7 M sorted values)", "ms": round(ms, 4),
+                    "bound": "latency", "elements_per_s_equivalent": round(x0.numel() * P / ms / 1e6, 1),
+                    "note": "the pass it replaces (k_score_a_self, 128 candidates per element) took 0.89 ms at this size"})
+    except Exception as ex:
+        out.append({"kernel": "k_score_sorted", "error": repr(ex)[:200]})
     return out
 
 
@@ -198,7 +225,8 @@ def brecq_rate(model_name, bits, dev, iters=2000):
 
 def _cpu_sample(threads, n_cand, min_seconds=0.0):
     """Seconds the oracle needs for one weight-scoring + one activation-scoring call of ``n_cand`` candidates each at
-    deit_small attn.proj size (32 images x 197 tokens, 384 -> 384, W4A4) on ``threads`` host threads."""
+    deit_small attn.proj size (32 images x 197 tokens, 384 -> 384, W4A4) on ``threads`` host threads (thread-count probe, and
+    the tensors of the HIP cross-check)."""
     from oracle import adalog_oracle as O
     torch.set_num_threads(threads)
     O.PCHUNK = 16
@@ -225,28 +253,157 @@ def _cpu_sample(threads, n_cand, min_seconds=0.0):
     return dt, reps, (x, W, b, ro, scw, zpw, sca, zpa, ref_w, ref_a)
 
 
+def _cpu_class_samples(threads, seconds_per_class=2.5, n_cand=16):
+    """one layer of EACH of the six layer classes at config 1's shapes (deit_tiny W6A6, 32 images,
+    T = 197, D = 192, 3 heads), the class's output-search scoring calls on ``n_cand`` candidates (candidates are scored
+    independently, linear.py:363-380), looped for ~seconds_per_class.  -> {class: (GFLOP/s of candidate-GEMM work, seconds)}."""
+    from oracle import adalog_oracle as O
+    torch.set_num_threads(threads)
+    O.PCHUNK = n_cand
+    g = torch.Generator().manual_seed(5)
+    N, T, D, H, MLP, bits = 32, 197, 192, 3, 768, 6
+    hd = D // H
+    sub = slice(0, n_cand)
+    out = {}
+
+    def run(name, flops_per_cand, parts):
+        """parts: [(candidates of this kind in one layer's search, fn scoring n_cand of them)].  Each kind is timed on its own for
+        its share of seconds_per_class; the class rate is the layer's candidate-GEMM flops over the layer's projected time."""
+        total_c = sum(c for c, _ in parts)
+        t_layer, spent = 0.0, 0.0
+        for cnt, fn in parts:
+            fn()                                                     # warm the allocator / thread pool
+            t0 = time.perf_counter()
+            reps = 0
+            while True:
+                fn()
+                reps += 1
+                dt = time.perf_counter() - t0
+                if dt >= seconds_per_class * cnt / total_c:
+                    break
+            t_layer += cnt * dt / (reps * n_cand)
+            spent += dt
+        gemm_c = sum(c for c, fn in parts if not getattr(fn, "no_gemm", False))
+        out[name] = (gemm_c * flops_per_cand / t_layer / 1e9, spent)
+
+    def linear_ops(I, Oc, n_V):
+        x = torch.randn(N, T, I, generator=g)
+        W = torch.randn(Oc, I, generator=g) * 0.05
+        b = torch.randn(Oc, generator=g) * 0.1
+        ro = torch.nn.functional.linear(x, W, b)
+        w3 = W.view(n_V, Oc // n_V, I)
+        scw, zpw = O.weight_candidates(w3, bits)
+        sca, zpa = O.activation_candidates(x, bits, False)
+        xq = O.uniform_fake_quant(x, sca[:, 60], zpa[:, 60].float(), bits)[0]
+        wq = O.uniform_fake_quant(w3, scw[60], zpw[60].float(), bits)[0].view(Oc, I)
+        return x, W, b, ro, w3, scw, zpw, sca, zpa, xq, wq
+
+    # 1. AsymmetricallyBatchingQuantLinear: attn.proj 192 -> 192 (linear.py:355-430)
+    x, W, b, ro, w3, scw, zpw, sca, zpa, xq, wq = linear_ops(D, D, 1)
+    # (per layer: 3 rounds x 6 steps x 128 candidates of each operand, linear.py:536-539)
+    run("linear(proj)", 2.0 * N * T * D * D,
+        [(2304, lambda: O.score_w(xq, w3, b, ro, scw[sub], zpw[sub], bits, 32)),
+         (2304, lambda: O.score_a(x, wq, b, ro, sca[:, sub], zpa[:, sub], bits, 32))])
+    # 2. AsymmetricallyChannelWiseBatchingQuantLinear: attn.qkv 192 -> 576: per-channel self-MSE search, then the plain search
+    x, W, b, ro, w3, scw, zpw, sca, zpa, xq, wq = linear_ops(D, 3 * D, 3)
+    sca_c, zpa_c = O.activation_candidates(x, bits, True)
+    cw_self = lambda: O.score_a_self(x, sca_c[:, sub], zpa_c[:, sub], bits, True, 32)      # 768 per-channel self-MSE candidates, no GEMM
+    cw_self.no_gemm = True
+    run("linear_channelwise(qkv)", 2.0 * N * T * D * 3 * D,
+        [(768, cw_self), (2304, lambda: O.score_w(xq, w3, b, ro, scw[sub], zpw[sub], bits, 32)),
+         (2304, lambda: O.score_a(x, wq, b, ro, sca[:, sub], zpa[:, sub], bits, 32))])
+    # 3. PostGeluLogBasedBatchingQuantLinear: mlp.fc2 768 -> 192 (linear.py:816-931)
+    xg = torch.nn.functional.gelu(2.0 * torch.randn(N, T, MLP, generator=g))
+    Wg = torch.randn(D, MLP, generator=g) * 0.03
+    bg = torch.randn(D, generator=g) * 0.1
+    rog = torch.nn.functional.linear(xg, Wg, bg)
+    w3g = Wg.view(1, D, MLP)
+    scwg, zpwg = O.weight_candidates(w3g, bits)
+    wqg = O.uniform_fake_quant(w3g, scwg[60], zpwg[60].float(), bits)[0].view(D, MLP)
+    shift = torch.tensor(O.GELU_SHIFT)
+    table = O.search_table(bits)
+    ud, sc_all = O.postgelu_candidates(xg, shift.item())
+    scs = (ud[:, 0:1] + (ud[:, 1:] - ud[:, 0:1]) * torch.tensor([i / 15 for i in range(16)]).view(1, -1))[:, :n_cand]
+    qs = torch.tensor([17, 23, 31, 37, 45, 60, 90, 137] * 2).view(1, -1)[:, :n_cand]
+    xqg = O.shift_adalog_fake_quant(xg, sc_all[:, -2].clone(), 41, bits, shift, False)[0]
+    # (3 rounds x (128 bases + 6 x 128 joint candidates) activation, 3 x 6 x 128 weight: linear.py:941-997)
+    run("linear_postgelu(fc2)", 2.0 * N * T * MLP * D,
+        [(2688, lambda: O.score_postgelu(xg, wqg, bg, rog, scs, qs, shift, bits, table, 32)),
+         (2304, lambda: O.score_w(xqg, w3g, bg, rog, scwg[sub], zpwg[sub], bits, 32))])
+    # 4. AsymmetricallyBatchingQuantMatMul: q.k^T [32,3,197,64].[32,3,64,197] (matmul.py:135-209)
+    A = torch.randn(N, H, T, hd, generator=g)
+    B = torch.randn(N, H, T, hd, generator=g).transpose(-2, -1)
+    rom = A @ B
+    sA, zA = O.matmul_candidates(A, bits)
+    sB, zB = O.matmul_candidates(B, bits)
+    Bq = O.uniform_fake_quant(B, sB[60], zB[60].float(), bits)[0]
+    Aq = O.uniform_fake_quant(A, sA[60], zA[60].float(), bits)[0]
+    run("matmul(qk)", 2.0 * N * H * T * T * hd,
+        [(2304, lambda: O.score_matmul(A, B, rom, sA[sub], zA[sub], bits, "A", Bq, True, 32)),
+         (2304, lambda: O.score_matmul(A, B, rom, sB[sub], zB[sub], bits, "B", Aq, True, 32))])
+    # 5. PostSoftmaxAsymmetricallyBatchingQuantMatMul: softmax.v (matmul.py:321-358)
+    As = torch.softmax(4.0 * torch.randn(N, H, T, T, generator=g), dim=-1)
+    Bv = torch.randn(N, H, T, hd, generator=g)
+    ros = As @ Bv
+    sBv, zBv = O.matmul_candidates(Bv, bits)
+    Bvq = O.uniform_fake_quant(Bv, sBv[60], zBv[60].float(), bits)[0]
+    Asq = O.adalog_fake_quant(As, torch.ones(1, 1, 1, 1), 29, bits)[0]
+    qsub = torch.tensor([10 + 8 * i for i in range(n_cand)]).view(-1, 1, 1, 1, 1)
+    # (3 rounds x (128 log bases + 6 x 128 B candidates): matmul.py:360-378)
+    run("matmul_postsoftmax(av)", 2.0 * N * H * T * T * hd,
+        [(384, lambda: O.score_log_base_A(As, Bvq, ros, qsub, bits, table, 32)),
+         (2304, lambda: O.score_matmul(As, Bv, ros, sBv[sub], zBv[sub], bits, "B", Asq, True, 32))])
+    # 6. AsymmetricallyBatchingQuantConv2d: patch embedding 3 -> 192, 16 x 16 / 16 (conv.py:226-263)
+    xi = torch.randn(N, 3, 224, 224, generator=g)
+    Wc = torch.randn(D, 3, 16, 16, generator=g) * 0.05
+    bc = torch.randn(D, generator=g) * 0.1
+    roc = torch.nn.functional.conv2d(xi, Wc, bc, (16, 16))
+    w2 = Wc.view(D, -1)
+    scc, zpc = O.weight_candidates(w2, bits, conv=True)
+    run("conv(patch_embed)", 2.0 * N * 196 * 768 * D,
+        [(768, lambda: O.score_conv_w(xi, w2, bc, roc, scc[sub], zpc[sub], bits, (16, 16), (16, 16), 32))])
+    return out
+
+
 def cpu_baseline(nproc, with_hip=True):
-    """The CPU oracle (a port of the reference's algorithm, validated against the reference's golden traces) on a bounded
-    sample, timed at 8 / 32 / nproc host threads -- the best thread count is the baseline and is stated (the reference's
-    elementwise chains over [N,T,I,P] temporaries are memory-bound: more threads than memory channels only adds
-    contention).  Scaled to images/s with the candidate-GEMM work of the whole model (1354 TFLOP
-    for deit_small at 32 images).  BASELINE.md section 3.1 measured the reference's own code at 24-46 GFLOP/s on 8 vCPUs."""
+    """The CPU oracle (a port of the reference's algorithm, validated against the reference's golden traces) on a BOUNDED sample,
+    as BASELINE.md section 3.2 plans it: one layer of each of the six layer classes at config 1's shapes (deit_tiny W6A6, 32
+    images), each class's rate weighted by its share of the benchmarked model's candidate-GEMM work.
+    Thread count: the best of 8 / 32 / nproc on a quick probe (the reference's elementwise chains over [N,T,I,P] temporaries are
+    memory-bound: more threads than memory channels only adds contention); `cores` is the host's core count, `threads` what ran.
+    BASELINE.md section 3.1 measured the reference's own code at 24-46 GFLOP/s on 8 vCPUs."""
     N, T, I, Oc, bits = 32, 197, 384, 384, 4
     tried = {}
     for th in sorted({min(8, nproc), min(32, nproc), nproc}):
         dt, reps, _ = _cpu_sample(th, 16)                       # probe: 16 candidates per call
         tried[th] = reps * 2 * 2.0 * N * T * I * Oc * 16 / dt / 1e9
     best = max(tried, key=tried.get)
-    dt, reps, (x, W, b, ro, scw, zpw, sca, zpa, ref_w, ref_a) = _cpu_sample(best, 128, 12.0)
-    flops = reps * 2 * 2.0 * N * T * I * Oc * 128
-    rate = flops / dt                                   # candidate-GEMM flop/s of the CPU path
-    total = 1354e12                                     # deit_small, 32 images (BASELINE.md section 2)
-    out = {"value": 32.0 / (total / rate), "unit": "images/s", "cores": best, "kind": "port",
-           "sample": f"{reps} x (oracle score_w + score_a, 128 candidates each), deit_small attn.proj 32x197x384->384 W4A4 on {best} "
-                     f"threads (best of {sorted(tried)}; host has {nproc}): {dt:.1f} s = {rate / 1e9:.1f} GFLOP/s "
-                     f"candidate-GEMM rate; scaled by 1354 TFLOP per 32-image calibration",
-           "sample_seconds": dt, "gflops_by_threads": {str(k): round(v, 1) for k, v in tried.items()},
-           "reference_code_gflops_8vcpu": [24.1, 45.9]}
+    classes = _cpu_class_samples(best)
+    # candidate-GEMM work of the benchmarked model (deit_small, 32 images; BASELINE.md section 2) by layer class, TFLOP:
+    # 4608 scored candidates per plain / channel-wise Linear and q.k^T, 4992 per post-GELU Linear, 2688 per softmax.v, 768 per conv
+    D, Hh, Tt, MLP, NI = 384, 6, 197, 1536, 32
+    MT = NI * Tt
+    work = {"linear(proj)": 12 * 4608 * 2.0 * MT * D * D + 4608 * 2.0 * NI * D * 1000,
+            "linear_channelwise(qkv)": 12 * 4608 * 2.0 * MT * D * (3 * D + MLP),
+            "linear_postgelu(fc2)": 12 * 4992 * 2.0 * MT * MLP * D,
+            "matmul(qk)": 12 * 4608 * 2.0 * NI * Hh * Tt * Tt * (D // Hh),
+            "matmul_postsoftmax(av)": 12 * 2688 * 2.0 * NI * Hh * Tt * Tt * (D // Hh),
+            "conv(patch_embed)": 768 * 2.0 * NI * 196 * 768 * D}
+    total = sum(work.values())                                  # = 1354 TFLOP
+    seconds = sum(work[k] / (classes[k][0] * 1e9) for k in work)
+    sample_s = sum(v[1] for v in classes.values())
+    dt, reps, (x, W, b, ro, scw, zpw, sca, zpa, ref_w, ref_a) = _cpu_sample(best, 128, 0.0)     # tensors of the HIP cross-check
+    out = {"value": 32.0 / seconds, "unit": "images/s", "cores": nproc, "threads": best, "kind": "port",
+           "sample": f"oracle scoring calls (16 candidates each, ~2.5 s per class) of one layer of each of the six layer classes at "
+                     f"config 1's shapes (deit_tiny W6A6, 32 images) on {best} threads (best of {sorted(tried)} in a probe; host has "
+                     f"{nproc} cores): {sample_s:.1f} s of CPU work; per-class candidate-GEMM rates weighted by deit_small's "
+                     f"{total / 1e12:.0f} TFLOP of candidate GEMMs per 32-image calibration -> {seconds:.0f} s per calibration",
+           "sample_seconds": sample_s,
+           "gflops_by_class": {k: round(v[0], 1) for k, v in classes.items()},
+           "work_tflop_by_class": {k: round(v / 1e12, 1) for k, v in work.items()},
+           "gflops_by_threads_probe": {str(k): round(v, 1) for k, v in tried.items()},
+           "reference_code_gflops_8vcpu": {"linear(proj)": 45.9, "matmul(qk)": 24.1, "matmul_postsoftmax(av)": 26.3,
+                                           "linear_postgelu(fc2)": 37.3}}
     if not with_hip:
         return out
     # the oracle as the CHECKER at full layer size: the same two scoring calls through the product path (HIP kernels)
@@ -381,6 +538,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong" if args.images_total is not None else "weak",
             "vs_baseline": None, "dtype": DT_NAME[dom], "data": "synthetic",
+            "dtype_note": "operand STORAGE type of the dominant scoring kernel: fp8 (e4m3) / int8 hold the exact integers q - z of the "
+                          "<= 4-bit / <= 6-bit operands, bf16 holds the AdaLog values m * 2^-t exactly; products accumulate in fp32 "
+                          "(sums < 2^24: exact) or int32 -- not a narrower precision than the reference's fp32 GEMM",
             "config": {"workload": f"{args.model} W{cfg.w_bit}A{cfg.a_bit} --calibrate, {args.images_per_gpu} calib images "
                                    f"per GPU ({cfg.calib_size} total), eq_n=128, 3 rounds, FPCS 6 steps",
                        "calib_wall_s_per_step": wall / args.steps,
@@ -398,8 +558,9 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],
                          "traffic": pmc_traffic(dom_name, default_workload),
-                         "traffic_note": "replayed from profiles/r02_pmc_bench_traffic.json (rocprofv3 --pmc passes of this same "
-                                         "command); null for any other workload",
+                         "traffic_source": "REPLAYED, not measured by this run: profiles/r03_pmc_bench_traffic.json holds the rocprofv3 --pmc "
+                                           "passes of this same command (tools/pmc_bench.sh; FETCH_SIZE x2 per the gfx950 note + "
+                                           "WRITE_SIZE, per launch); null for any other workload",
                          "launches": n, "avg_launch_ms": ms / max(n, 1)},
         }
         if not args.no_cpu_baseline and world == 1:
