@@ -45,12 +45,6 @@ namespace {
 
 }  // namespace
 
-// slab kernel: waves draw their units from an LDS counter (ADALOG_SLAB_DYN=0: the fixed round-robin split of rounds 1-2)
-static int slab_dyn_default() {
-    static const int v = getenv("ADALOG_SLAB_DYN") ? atoi(getenv("ADALOG_SLAB_DYN")) : 0;
-    return v;
-}
-
 static int device_cus() {
     static int n_cu = 0;
     if (!n_cu) {
@@ -266,8 +260,7 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         p.MT = L.MT; p.NT = L.NT; p.slab_U = L.slab_U; p.slab_R = L.slab_R;
         const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
         const int SBN = 32 * L.slab_nb;
-        const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4 + 16;    // (+ the unit counter)
-        p.slab_dyn = slab_dyn_default();
+        const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4;
         // a slab that is not cut has unused pieces: they must read as zero
         if (!L.acc) {
             const hipError_t me = hipMemsetAsync(partial, 0, (size_t)L.elems * sizeof(float), st);
@@ -522,8 +515,7 @@ extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp
     p.gen_tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
     const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
     const int SBN = 32 * L.slab_nb;
-    const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4 + 16;        // (+ the unit counter)
-    p.slab_dyn = slab_dyn_default();
+    const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4;
     const int nref = SBN / P;
 #define LAUNCH_GEN(NREFV, DTV, NBV)                                                                               \
     do {                                                                                                          \
