@@ -326,12 +326,12 @@ constexpr int MAX_DEV = 16;
 // One ring per device (a ring allocated on device 0 would be a foreign pointer for a kernel on device 1); the table is
 // guarded by a mutex on every call (a few ns against a kernel launch).  The first call for a device allocates and
 // synchronises, which a stream capture does not survive: adalog_brecq_init() makes that call ahead of any capture.
-unsigned int* ticket_slot() {
+unsigned int* ticket_slots(int n) {
     static unsigned int* rings[MAX_DEV] = {};
     static unsigned next[MAX_DEV] = {};
     static std::mutex mu;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    if (n < 1 || n > 64 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
     if (!rings[dev]) {
         unsigned int* p = nullptr;
@@ -340,8 +340,12 @@ unsigned int* ticket_slot() {
             return nullptr;
         rings[dev] = p;
     }
-    return rings[dev] + (next[dev]++ % RING);
+    if (next[dev] % RING + n > RING) next[dev] += RING - next[dev] % RING;      // n consecutive words: do not wrap inside a request
+    unsigned int* r = rings[dev] + next[dev] % RING;
+    next[dev] += n;
+    return r;
 }
+unsigned int* ticket_slot() { return ticket_slots(1); }
 
 inline int grid1(int64_t n, int cap = 2048) {
     int64_t b = (n + 255) / 256;
@@ -355,6 +359,7 @@ inline int grid1(int64_t n, int cap = 2048) {
 // One zeroed device word of the current device's ring (the launch's last block puts it back to zero): shared with the fused
 // finish + top-k kernel of gemm_score.hip.  nullptr when the ring cannot be allocated.
 extern "C" unsigned int* adalog_ticket_slot(void) { return ticket_slot(); }
+extern "C" unsigned int* adalog_ticket_slots(int n) { return ticket_slots(n); }
 
 // Allocates the current device's ticket ring (idempotent).  Call once per device before capturing BRECQ launches into a
 // HIP graph: the allocation synchronises the device, which would invalidate a capture in progress.

@@ -12,6 +12,7 @@ extern "C" void adalog_set_error(const char* where, hipError_t e);
 extern "C" void adalog_set_error_msg(const char* msg);
 extern "C" void adalog_note_kernel(const char* name);
 extern "C" unsigned int* adalog_ticket_slot(void);      // brecq.hip: a zeroed device word for "last block finishes" kernels
+extern "C" unsigned int* adalog_ticket_slots(int n);    // ... n <= 64 consecutive zeroed words
 
 #define ADALOG_LAUNCH_CHECK(name)                                   \
     do {                                                            \

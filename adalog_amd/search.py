@@ -129,7 +129,21 @@ def _flat_layout(local_numel: int, rows: int = 1):
     return None
 
 
-_GRID_MEMO = {}
+class _Memo(dict):
+    pass
+
+
+_memo_tls = __import__("threading").local()
+
+
+def _memo_dict():
+    """one memo per host thread: the calibrator runs two modules' searches side by side (adalog_amd.parallel lanes), and a
+    module that finishes must only forget its own entries"""
+    d = getattr(_memo_tls, "d", None)
+    if d is None:
+        d = _memo_tls.d = _Memo()
+    return d
+
 
 
 def _memo(kind, x, extra, make):
@@ -140,9 +154,10 @@ def _memo(kind, x, extra, make):
     ``delta`` is handed out as a copy (the FPCS driver narrows it in place).  Entries die with their tensor's search
     (forget_grids)."""
     key = (kind, x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride())) + tuple(extra)
-    hit = _GRID_MEMO.get(key)
+    memo = _memo_dict()
+    hit = memo.get(key)
     if hit is None:
-        hit = _GRID_MEMO[key] = (x, make())
+        hit = memo[key] = (x, make())
     hit = hit[1]
     return hit[0], hit[1], hit[2].clone()
 
@@ -151,14 +166,15 @@ def memo_tensor_fn(kind, x, extra, make):
     """Same memo for other pure functions of a captured tensor (post-GELU positive percentiles, the sorted copy + prefix
     sums of the self-MSE searches); result returned as is."""
     key = (kind, x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride())) + tuple(extra)
-    if key not in _GRID_MEMO:
-        _GRID_MEMO[key] = (x, make())
-    return _GRID_MEMO[key][1]
+    memo = _memo_dict()
+    if key not in memo:
+        memo[key] = (x, make())
+    return memo[key][1]
 
 
 def forget_grids():
     """Drop the memoised grids (called when a module's search ends and its captures are released)."""
-    _GRID_MEMO.clear()
+    _memo_dict().clear()
 
 
 def weight_grid(w2, n_bits: int, eq_n: int, conv: bool = False):

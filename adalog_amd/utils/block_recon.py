@@ -162,10 +162,7 @@ class BlockReconstructor(QuantCalibrator):
             err = loss_func(out_quant, cur_out)
             err.backward()
             if ws > 1:                                   # data-parallel: mean of the per-rank batch-mean gradients
-                for prm in params:
-                    if prm.grad is not None:
-                        parallel.all_reduce_sum(prm.grad)
-                        prm.grad.div_(ws)
+                parallel.all_reduce_mean_bucket([prm.grad for prm in params if prm.grad is not None])
             optim_steps()
             if a_scheduler is not None:
                 a_scheduler.step()
@@ -203,10 +200,7 @@ class BlockReconstructor(QuantCalibrator):
                             optim_steps()
                 graph.replay()                               # grads are overwritten, not accumulated (none existed at capture)
                 if not full_graph:
-                    for prm in params:
-                        if prm.grad is not None:
-                            parallel.all_reduce_sum(prm.grad)
-                            prm.grad.div_(ws)
+                    parallel.all_reduce_mean_bucket([prm.grad for prm in params if prm.grad is not None])
                     optim_steps()
                 if a_scheduler is not None:
                     a_scheduler.step()

@@ -17,6 +17,7 @@ What is different, by design:
   * with torch.distributed initialised the loader is expected to yield this rank's image shard; searches all-reduce
     their scores (adalog_amd.parallel).
 """
+import os
 import re
 import time
 
@@ -126,6 +127,85 @@ class QuantCalibrator:
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in self._capture_events) * 1e-3
 
+    def _search_one(self, name, module, device):
+        t0 = time.perf_counter()
+        ev = self._event_pair(device)
+        with torch.no_grad():
+            module.hyperparameter_searching()
+            if hasattr(module, 'prev_layer') and module.prev_layer is not None:
+                module.reparam()
+        if ev is not None:
+            ev[1].record()
+            self._events[name] = ev
+        self.timings[name] = time.perf_counter() - t0      # host-side enqueue time; the stream runs behind
+        if self.verbose:
+            print(f"calibrated {name}")
+
+    def _lanes(self, device):
+        """Two (communicator, stream) lanes when the images are sharded over several ranks (adalog_amd.parallel): one module's
+        score all-reduce then hides under the other module's scoring GEMMs.  ADALOG_INTERLEAVE=0: the sequential schedule."""
+        from .. import parallel
+        if not parallel.is_dist() or os.environ.get("ADALOG_INTERLEAVE", "1") == "0":
+            return None
+        groups = parallel.lane_groups(2)
+        on_gpu = torch.device(device).type == "cuda"
+        return [(g, torch.cuda.Stream(device=device) if on_gpu else None) for g in groups]
+
+    def _search_interleaved(self, group, device, lanes):
+        """The group's modules dealt round-robin to the lanes (same deal on every rank: each lane's collectives then follow the
+        same sequence everywhere), one host thread per lane.  Modules are independent (their captures are taken, all of the FP
+        model: reference utils/calibrator.py:34-67; reparam() touches only the module's own weight and its LayerNorm)."""
+        import threading
+        from .. import parallel
+        on_gpu = torch.device(device).type == "cuda"
+        ready = torch.cuda.Event() if on_gpu else None
+        if on_gpu:
+            ready.record()                                     # the captures were written on the calling stream
+        errors, done = [], []
+
+        def work(li):
+            grp, stream = lanes[li]
+            parallel.set_lane(grp)
+            try:
+                if on_gpu:
+                    torch.cuda.set_device(device)
+                    with torch.cuda.stream(stream):
+                        stream.wait_event(ready)
+                        for name, module in group[li::len(lanes)]:
+                            for t in self._captured_tensors(module):
+                                t.record_stream(stream)        # allocated on the capture stream, read (and freed) on this one
+                            self._search_one(name, module, device)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        done.append(ev)
+                else:
+                    for name, module in group[li::len(lanes)]:
+                        self._search_one(name, module, device)
+            except BaseException as ex:                        # re-raised on the calling thread
+                errors.append(ex)
+            finally:
+                parallel.set_lane(None)
+
+        threads = [threading.Thread(target=work, args=(li,), name=f"adalog-lane{li}") for li in range(len(lanes))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        for ev in done:
+            torch.cuda.current_stream().wait_event(ev)
+
+    @staticmethod
+    def _captured_tensors(module):
+        out = []
+        for v in (getattr(module, "raw_input", None), getattr(module, "raw_out", None)):
+            if isinstance(v, (list, tuple)):
+                out += [t for t in v if torch.is_tensor(t) and t.is_cuda]
+            elif torch.is_tensor(v) and v.is_cuda:
+                out.append(v)
+        return out
+
     def batching_quant_calib(self):
         pending = self._pending()
         groups = []
@@ -135,21 +215,15 @@ class QuantCalibrator:
                 groups[-1][1].append((name, module))
             else:
                 groups.append((key, [(name, module)]))
+        device = next(self.model.parameters()).device
+        lanes = self._lanes(device)
         for key, group in groups:
             self._capture(group)
-            for name, module in group:
-                t0 = time.perf_counter()
-                ev = self._event_pair(next(self.model.parameters()).device)
-                with torch.no_grad():
-                    module.hyperparameter_searching()
-                    if hasattr(module, 'prev_layer') and module.prev_layer is not None:
-                        module.reparam()
-                if ev is not None:
-                    ev[1].record()
-                    self._events[name] = ev
-                self.timings[name] = time.perf_counter() - t0      # host-side enqueue time; the stream runs behind
-                if self.verbose:
-                    print(f"calibrated {name}")
+            if lanes is None or len(group) < 2:
+                for name, module in group:
+                    self._search_one(name, module, device)
+            else:
+                self._search_interleaved(group, device, lanes)
         for _, module in self.model.named_modules():
             if hasattr(module, 'mode'):
                 module.mode = "quant_forward"

@@ -507,6 +507,7 @@ def main():
     parallel.barrier()
     torch.cuda.synchronize()
     prof.start()
+    parallel.reset_stats()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(models[args.warmup + i])
@@ -515,6 +516,7 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     by = prof.stop()
+    coll = parallel.collective_stats()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([wall], device=dev, dtype=torch.float64)
@@ -554,6 +556,13 @@ def main():
                        "capture_seconds_per_step": sum(capt) / max(len(capt), 1),
                        "fpcs_note": "device events on the search stream around every module's hyperparameter_searching (+ reparam), "
                                     "summed over the modules (rank 0); capture = the FP forward passes that record the activations",
+                       "collectives": {"per_step": coll["collectives"] / args.steps, "bytes_per_step": coll["bytes"] / args.steps,
+                                       "stream_ms_per_step": None if coll["device_ms"] is None else coll["device_ms"] / args.steps,
+                                       "schedule": "two lanes (two modules' searches side by side, each on its own stream and "
+                                                   "communicator)" if world > 1 and os.environ.get("ADALOG_INTERLEAVE", "1") != "0"
+                                                   else "sequential",
+                                       "note": "score / min-max / histogram all-reduces of rank 0 during the timed steps; stream_ms = "
+                                               "summed event time around them on their lane's stream (includes waiting for the peers)"},
                        "depth_override": args.depth},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],

@@ -170,3 +170,62 @@ def test_brecq_gradient_all_reduce_keeps_ranks_in_lock_step():
     assert not torch.equal(r0["alpha1"], single["alpha1"])
     init = torch.from_numpy(np.load(os.path.join(ROOT, "tests", "golden", "brecq_toy.npz"))["alpha_fc1"])
     assert (r0["alpha1"] - init).abs().max().item() > 1e-4
+
+
+def _calib_worker(rank, world, port, interleave, outdir):
+    """The whole calibrator over sharded images: a tiny wrapped ViT, `world` gloo ranks, the two-lane interleaved schedule
+    (adalog_amd.parallel lanes: two modules' searches side by side, each lane on its own communicator) or the sequential one."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      ADALOG_INTERLEAVE="1" if interleave else "0")
+    import torch.distributed as dist
+    from adalog_amd import backend, parallel
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    from tests import cpu_backend, wrapper_cases as WC
+    torch.set_num_threads(1)
+    backend.set_backend(cpu_backend)
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "wrapper_rules.npz"))
+    cfg = WC.cfg_of(4)
+    cfg.search_round, cfg.steps, cfg.calib_batch_size = 1, 2, 2
+    vit = wrap_modules_in_net(WC._load(WC.tiny_vit(), g, "vit_in_", torch.device("cpu")), cfg, reparam=True)
+    x = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(3))
+    per = 8 // world
+    xs = x[rank * per:(rank + 1) * per]
+    parallel.reset_stats()
+    QuantCalibrator(vit, [(xs, None)], capture="block").batching_quant_calib()
+    stats = parallel.collective_stats()
+    vit = wrap_reparamed_modules_in_net(vit)
+    sd = {k: v.detach().clone() for k, v in vit.state_dict().items()}
+    sd["__collectives"] = torch.tensor(stats["collectives"])
+    torch.save(sd, os.path.join(outdir, f"calib_w{world}_i{int(interleave)}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_interleaved_calibration_is_the_sequential_one(world):
+    """Two lanes (module-parallel searches whose score all-reduces overlap the other lane's GEMMs) must change nothing: every
+    rank holds bit-identical parameters, identical to the sequential schedule's on the same ranks, and the same number of
+    collectives is issued; the sharded result agrees with the single-process one up to exact-tie resolution."""
+    with tempfile.TemporaryDirectory() as d:
+        for inter in (True, False):
+            mp.spawn(_calib_worker, args=(world, _free_port(), inter, d), nprocs=world, join=True)
+        mp.spawn(_calib_worker, args=(1, _free_port(), False, d), nprocs=1, join=True)
+        runs = {(i, r): torch.load(os.path.join(d, f"calib_w{world}_i{i}_r{r}.pt")) for i in (0, 1) for r in range(world)}
+        single = torch.load(os.path.join(d, "calib_w1_i0_r0.pt"))
+    assert int(runs[(1, 0)]["__collectives"]) > 100
+    for k in runs[(1, 0)]:
+        for r in range(1, world):
+            assert torch.equal(runs[(1, 0)][k], runs[(1, r)][k]), f"interleaved: ranks disagree on {k}"
+        assert torch.equal(runs[(1, 0)][k], runs[(0, 0)][k]), f"interleaved and sequential schedules disagree on {k}"
+    n_scale = n_off = 0
+    for k, v in single.items():
+        if k.endswith(".scale"):
+            n_scale += v.numel()
+            n_off += int(((v - runs[(1, 0)][k]).abs() > 2e-3 * v.abs()).sum())
+    assert n_off <= 0.05 * n_scale, (n_off, n_scale)
