@@ -191,13 +191,20 @@ def test_cli_swin_base_w3a3_sharded_over_two_ranks(tmp_path):
     assert "on 2 GPU(s)" in r.stdout + r.stderr
 
 
-def test_cli_deit_base_w3a3_calibrate(tmp_path):
-    """BASELINE config 5's model and bit width on one GPU (its eight-GPU / BRECQ parts are covered by the sharded and the
-    --optimize tests above): deit_base W3A3 --calibrate."""
+def test_cli_deit_base_w3a3_calibrate_and_optimize(tmp_path):
+    """BASELINE config 5 on one GPU (its eight-GPU part is covered by the sharded test above and the gloo tests): deit_base W3A3
+    `--calibrate --optimize` through the CLI -- calibration at 3 bit (fp8 storage of the q.k^T / linear operands), then BRECQ over
+    every block for a few iterations on the config's 1024 optimisation images, checkpoints in the reference's naming."""
     out = str(tmp_path / "run6")
     cmd = [sys.executable, os.path.join(ROOT, "test_quant.py"), "--model", "deit_base", "--config",
-           os.path.join(ROOT, "configs", "3bit.py"), "--calibrate", "--calib-size", "32", "--calib-batch-size", "32",
-           "--val-size", "32", "--val-batch-size", "32", "--output-dir", out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+           os.path.join(ROOT, "configs", "3bit.py"), "--calibrate", "--optimize", "--optim-iters", "24", "--calib-size", "32",
+           "--calib-batch-size", "32", "--val-size", "32", "--val-batch-size", "32", "--output-dir", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    files = os.listdir(out)
     assert os.path.exists(os.path.join(out, "deit_base_w3_a3_s3_calibsize_32.pth"))
+    opt = [f for f in files if f.startswith("deit_base_w3_a3_s3_optimsize_")]
+    assert opt, files
+    sd = torch.load(os.path.join(out, opt[0]), map_location="cpu")
+    assert sd["blocks.11.attn.qkv.w_quantizer.scale"].shape == (3, 768, 1)
+    assert not any(k.endswith("alpha") for k in sd)                           # hard rounding committed (block_recon.py:151-157)

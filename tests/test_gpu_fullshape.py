@@ -66,6 +66,8 @@ LINEAR = [  # tag, I, O, n_V, tokens per image, images, bits
     ("vit_base.fc1", 768, 3072, 1, 197, 32, 4),
     ("swin_base.reduction", 512, 256, 1, 784, 32, 3),
     ("swin_base.l0.fc1", 128, 512, 1, 3136, 32, 3),
+    # BASELINE config 4's per-rank share: 1024 calibration images over 8 GPUs = 128 images per rank (401 408 tokens in stage 0)
+    ("swin_base.l0.fc1@128img", 128, 512, 1, 3136, 128, 3),
 ]
 
 

@@ -32,7 +32,7 @@ for rep in range(2):
     for ev in prof.events():
         if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::fill_", "aten::zero_", "aten::zeros", "aten::to",
                        "aten::_to_copy"):
-            stack = [s for s in (ev.stack or []) if "adalog_amd" in s or "bench" in s]
-            cnt[(ev.name, stack[0] if stack else "?")] += 1
+            stack = [s for s in (ev.stack or []) if ".py" in s and "torch/" not in s]
+            cnt[(ev.name, " <- ".join(st.split("/")[-1] for st in stack[:3]) if stack else "?")] += 1
     for (name, where), n in cnt.most_common(40):
         print(f"{n:6d}  {name:18s} {where}")

@@ -12,8 +12,9 @@ groups=("FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCL
         "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
         "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC")
 for shape in $shapes; do
-  for mode in w a; do
-    if [ "$shape" = qk ] && [ "$mode" = w ]; then continue; fi
+  for mode in w a g; do
+    if [ "$shape" = qk ] && [ "$mode" != a ]; then continue; fi
+    if [ "$shape" = fc2 ] && [ "$mode" = g ]; then continue; fi
     i=0
     for g in "${groups[@]}"; do
       d="$out/${shape}_${mode}_$i"

@@ -52,6 +52,8 @@ for _ in range(3):
     if mode in ("both", "w"):       # weight search: rows = tokens, columns = (out channel, candidate)
         ops.gemm_score(DT, xp, wp, M, O, P, 1, 1, ref_t, S(xs), S(csw, c=O, n=1), S(bias, n=1), False, True, 1.0 / T,
                        ref_div=P, order=2, ref_transposed=True)
+    if mode == "g":                 # activation search, candidate operand generated inside the slab kernel (round 3 default)
+        ops.score_act_gen(DT, wfix, x[0], csa, cza, 4, ref[0], ws, bias, 1.0 / (T * O))
     if mode in ("both", "a"):       # activation search (transposed): rows = out channels, columns = (token, candidate)
         ops.gemm_score(DT, wfix, xP, O, M, P, 1, 1, ref, S(one), S(csa, c=1), None, False, False, 1.0 / (T * O),
                        ref_div=P, order=2, ref_transposed=True, row_scale=ws, row_bias=bias)
