@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libadalog_hip.so")
+# (ADALOG_LIB: another build of the same library -- same-box A/B runs of a kernel change; the torch ops link the default one)
+LIB_PATH = os.environ.get("ADALOG_LIB") or os.path.join(_HERE, "csrc", "libadalog_hip.so")
 
 p, i32, i64, f32, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 

@@ -5,8 +5,10 @@ this environment does not have: folders are walked with ``os``, images decoded w
 What the reference takes from timm (``resolve_data_config(model.default_cfg)`` + ``create_transform``) is restated here as a
 per-family table of the timm 0.9.2 defaults (interpolation, crop fraction, mean / std).  Follow-the-source restatement:
 timm is not importable here, so these numbers are **unpinned** against it; the evaluation transform is
-the standard resize(size / crop_pct) -> centre crop -> normalise, the training-side transform used for the calibration
-subset is random-resized-crop + horizontal flip (timm's colour jitter is left out).
+the standard resize(size / crop_pct) -> centre crop -> normalise (resize arithmetic as torchvision's: long side truncated), the
+training-side transform used for the calibration subset is random-resized-crop + horizontal flip.  KNOWN DEVIATION: timm's
+training transform also applies colour jitter (0.4), which is left out here -- calibration images, and with them Prec@1, do not
+reproduce the reference bit for bit (test_quant.py logs this once).
 """
 import math
 import os
@@ -44,6 +46,17 @@ def _to_tensor(img, mean, std):
     return (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)
 
 
+def _resize_short(img, size, resample):
+    """torchvision.transforms.Resize(int): the short side becomes `size`, the long side int(size * long / short) -- TRUNCATED,
+    as torchvision computes it (functional._compute_resized_output_size)."""
+    w, h = img.size
+    if (w <= h and w == size) or (h <= w and h == size):
+        return img
+    if w < h:
+        return img.resize((size, int(size * h / w)), resample)
+    return img.resize((int(size * w / h), size), resample)
+
+
 class EvalTransform:
     """resize the short side to round(input_size / crop_pct), centre crop, to tensor, normalise"""
 
@@ -52,9 +65,7 @@ class EvalTransform:
         self.scale_size = int(math.floor(input_size / crop_pct))
 
     def __call__(self, img):
-        w, h = img.size
-        s = self.scale_size / min(w, h)
-        img = img.resize((max(self.size, round(w * s)), max(self.size, round(h * s))), self.resample)
+        img = _resize_short(img, self.scale_size, self.resample)
         w, h = img.size
         left, top = (w - self.size) // 2, (h - self.size) // 2
         return _to_tensor(img.crop((left, top, left + self.size, top + self.size)), self.mean, self.std)
@@ -63,11 +74,15 @@ class EvalTransform:
 class TrainTransform:
     """random-resized crop (scale 0.08..1, ratio 3/4..4/3) + horizontal flip, to tensor, normalise; draws from torch's RNG"""
 
-    def __init__(self, input_size=224, interpolation="bicubic", crop_pct=0.875, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD):
+    def __init__(self, input_size=224, interpolation="bicubic", crop_pct=0.875, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD,
+                 pre_resize=None):
         self.size, self.resample, self.mean, self.std = input_size, _resample(interpolation), mean, std
+        self.pre_resize = pre_resize                      # Resize(256) in front of the crop (datasets.py:71-72, torchvision recipe)
 
     def __call__(self, img):
         from PIL import Image
+        if self.pre_resize:
+            img = _resize_short(img, self.pre_resize, self.resample)
         w, h = img.size
         area = w * h
         box = None
@@ -178,7 +193,7 @@ class ImageNetLoaderGenerator(LoaderGenerator):
 
     def load(self):
         cfg = dict(input_size=224, interpolation="bilinear", crop_pct=0.875, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD)
-        self.train_transform, self.val_transform = TrainTransform(**cfg), EvalTransform(**cfg)
+        self.train_transform, self.val_transform = TrainTransform(**cfg, pre_resize=256), EvalTransform(**cfg)
 
 
 class ViTImageNetLoaderGenerator(ImageNetLoaderGenerator):

@@ -233,6 +233,9 @@ def main(args):
         # reference test_quant.py:167-171: ViTImageNetLoaderGenerator(root, val_batch_size, num_workers, kwargs={"model": model})
         from adalog_amd.utils.datasets import ViTImageNetLoaderGenerator
         loader_gen = ViTImageNetLoaderGenerator(args.dataset, args.val_batch_size, args.num_workers, kwargs={"model": args.model})
+        logging.info("known deviation from the reference's preprocessing: timm is not available, so the model's data config comes "
+                     "from a table of the timm 0.9.2 defaults and the calibration-side transform omits timm's colour jitter; "
+                     "Prec@1 is not bit-comparable with the reference's (adalog_amd/utils/datasets.py)")
         val_loader = loader_gen.val_loader()
         validate_any = lambda m: validate_dataset(val_loader, m, full_model, device)
     else:

@@ -1070,6 +1070,42 @@ def test_torch_ops_route_matches_c_abi():
     assert torch.equal(torch.ops.adalog.topk(sc, 16), OPS.topk(sc, 16))
     xg = torch.nn.functional.gelu(x)
     assert torch.equal(torch.ops.adalog.log2_shift(xg, 0.17), OPS.log2_shift(xg, 0.17))
+    # one scoring call of each kind through BOTH routes (bench.py times the ctypes route, the product runs the torch.ops one):
+    # gemm_score (+ deferred finish and the fused finish / top-k), the in-kernel-generated activation search, the sorted self-MSE search
+    M, T, K, P = 768, 4 * 197, 384, 128
+    xa = (torch.randn(T, K, generator=g) * 1.3).to(DEV)
+    W = (torch.randn(M, K, generator=g) * 0.05).to(DEV)
+    ref = torch.nn.functional.linear(xa, W)
+    ws, wz = torch.full((M,), 0.01, device=DEV), torch.full((M,), 8.0, device=DEV)
+    cs = (torch.rand(P, 1, generator=g) * 0.2 + 0.2).to(DEV)
+    cz = torch.randint(4, 12, (P, 1), generator=g).float().to(DEV)
+    lin8 = torch.linspace(0, 1, 8).to(DEV)
+
+    def run_all():
+        wp = OPS.pack_uniform(W.unsqueeze(0), ws, wz, 1, 0, 1, 0, 1, 4, OPS.FP8)
+        xp = OPS.pack_uniform(xa.unsqueeze(0), cs, cz, P, 1, 1, 0, 0, 4, OPS.FP8, c_inner=True)
+        one = torch.ones(1, device=DEV)
+        kw = dict(ref_div=P, order=2, ref_transposed=True, row_scale=ws, row_bias=torch.zeros(M, device=DEV))
+        a = OPS.gemm_score(OPS.FP8, wp, xp, M, T, P, 1, 1, ref.reshape(1, T, M), OPS.Strided(one), OPS.Strided(cs, c=1), None, False, False,
+                           1e-3, **kw)
+        pend = OPS.gemm_score(OPS.FP8, wp, xp, M, T, P, 1, 1, ref.reshape(1, T, M), OPS.Strided(one), OPS.Strided(cs, c=1), None, False,
+                              False, 1e-3, defer=True, **kw)
+        b = pend.finish()
+        d = torch.full((1,), 0.01, device=DEV)
+        nxt = OPS.finish_topk_next(pend, cs, cz, None, 16, 8, lin8, d, 1e-4)
+        gsc = OPS.score_act_gen(OPS.FP8, wp, xa, cs, cz, 4, ref, ws, None, 1e-3)
+        sp = OPS.sorted_prefix(xa.reshape(1, -1))
+        ss = OPS.score_self_sorted(sp, cs, cz, 4, 1e-3)
+        return [a, b, nxt[0], nxt[1], d, gsc, sp.sorted, sp.prefix, ss]
+
+    via_torch = run_all()
+    _torch_ops._state = False                                     # force the ctypes route of adalog_amd.ops
+    try:
+        via_ctypes = run_all()
+    finally:
+        _torch_ops._state = True
+    for i, (u, v) in enumerate(zip(via_torch, via_ctypes)):
+        assert torch.equal(u, v), f"torch.ops and ctypes routes disagree on result {i}"
 
 
 @pytest.mark.parametrize("shape", [(4, 7, 33), (32, 197, 384), (3, 5)])
