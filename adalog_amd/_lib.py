@@ -23,6 +23,7 @@ SIGNATURES = {
     "adalog_pack_uniform": (i32, [p, i64, i64, i64, i64, i64, i64, p, p, i64, i64, i64, i64, i64, i32, i32, p, i64, p, i32, p]),
     "adalog_pack_adalog_bf16": (i32, [p, i64, i64, i64, i64, i64, i64, p, p, i64, i64, i64, i64, i32, p, p, i32, p, i64, i32, p]),
     "adalog_pack_raw_f32": (i32, [p, i64, i64, i64, i64, i64, i64, p, i64, p]),
+    "adalog_pack_split3_bf16": (i32, [p, i64, i64, i64, i64, i64, i64, p, i64, p]),
     "adalog_gemm_score": (i32, [i32, p, p, i64, i64, i64, i64, i32, i32, i64, i64, i32, i32, i32, p, i64, i64, i64, i32,
                                 p, i64, i64, f32, p, i64, i64, i64, p, i64, i64, i64, p, p, p, i64, p, i64, i64, i64, i32, i32, p]),
     "adalog_gemm_score_layout": (i64, [i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, p, p, p]),

@@ -652,3 +652,46 @@ extern "C" int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t
     ADALOG_LAUNCH_CHECK("adalog_pack_raw_f32");
     return 0;
 }
+
+// ---- three-term bf16 image of an UNQUANTISED fp32 operand (patch-embedding weight search: the input keeps 8 bits or more and is
+// scored as it is, conv.py:226-255).  x = hi + mid + lo exactly (8 + 8 + 8 mantissa bits, each residual is exact in fp32), stored
+// as [row][hi(0..Kt) | mid(0..Kt) | lo(0..Kt)]; against a candidate operand of exact small integers repeated three times along K
+// the bf16 MFMA then accumulates the same fp32 products as the fp32 MFMA does, at 5x its rate.
+namespace {
+__device__ __forceinline__ unsigned bf16_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__global__ __launch_bounds__(256) void k_pack_split3(const float* __restrict__ x, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
+                                                    uint16_t* __restrict__ out, int64_t Kt) {
+    const int64_t g = blockIdx.z;
+    for (int64_t row = blockIdx.y; row < R; row += gridDim.y) {
+    uint16_t* o = out + (g * R + row) * 3 * Kt;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < Kt; k += (int64_t)gridDim.x * 256) {
+        unsigned h = 0, m = 0, l = 0;
+        if (k < K) {
+            const float v = x[g * sxg + row * sxr + k * sxk];
+            h = bf16_rne(v);
+            const float r1 = v - __uint_as_float(h << 16);
+            m = bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float(m << 16);
+            l = bf16_rne(r2);
+        }
+        o[k] = (uint16_t)h; o[Kt + k] = (uint16_t)m; o[2 * Kt + k] = (uint16_t)l;
+    }
+    }
+}
+}  // namespace
+
+extern "C" int adalog_pack_split3_bf16(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
+                                       void* out, int64_t Kt, void* stream) {
+    ADALOG_ARG_CHECK(x && out && G >= 1 && R >= 1 && K >= 1, "pack_split3: bad arguments");
+    ADALOG_ARG_CHECK(Kt >= K && Kt % 32 == 0, "pack_split3: Kt must cover K and be a multiple of 32 elements");
+    ADALOG_ARG_CHECK(G < 65536, "pack_split3: too many groups for one launch");
+    const unsigned bx = (unsigned)((Kt + 255) / 256);
+    hipLaunchKernelGGL(k_pack_split3, dim3(bx, (unsigned)(R < 65535 ? R : 65535), (unsigned)G), dim3(256), 0, (hipStream_t)stream, x, R, K, sxg, sxr, sxk,
+                       (uint16_t*)out, Kt);
+    ADALOG_LAUNCH_CHECK("adalog_pack_split3_bf16");
+    return 0;
+}

@@ -171,6 +171,18 @@ def pack_raw(x3):
     return out
 
 
+def pack_split3(x3, k_align: int = 128):
+    """fp32 [G, R, K] -> bf16 [1, G, R, 3*Kt]: the three-term bf16 image hi | mid | lo of an unquantised operand (exact:
+    hi + mid + lo == x), Kt = pad_k(K, BF16).  Pairs with a bf16 candidate operand repeated three times along K."""
+    G, R, K, sg, sr, sk = _view3(x3)
+    Kt = pad_k(K, BF16, k_align)
+    out = torch.empty((1, G, R, 3 * Kt), dtype=torch.bfloat16, device=x3.device)
+    rc = _lib.load().adalog_pack_split3_bf16(x3.data_ptr(), G, R, K, sg, sr, sk, out.data_ptr(), Kt, _stream())
+    _lib.check(rc, "adalog_pack_split3_bf16")
+    out.k_valid = 2 * Kt + K
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ scoring GEMM
 class Strided:
     """A device fp32 parameter with (candidate, head, column) element strides for the GEMM epilogue."""

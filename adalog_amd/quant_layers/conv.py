@@ -13,10 +13,11 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import backend, search
-from ..ops import F32, Strided, pad_k
+from ..ops import BF16, F32, Strided, pad_k
 from ..quantizers.uniform import UniformQuantizer
 
 MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
+SPLIT3_INPUT = os.environ.get('ADALOG_CONV_SPLIT3', '1') != '0'   # unquantised input as three exact bf16 terms (else fp32 MFMA)
 
 
 class MinMaxQuantConv2d(nn.Conv2d):
@@ -141,22 +142,35 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
     def _w2(self):
         return self.weight.data.view(self.out_channels, -1)
 
+    def _pack_x(self, patches):
+        """The unquantised input of the weight search (conv.py:55-58 with qconv_a_bit = 8) as a GEMM operand: three exact
+        bf16 terms per value (the candidate weights, exact small integers, are then repeated three times along K and the
+        products run on the bf16 MFMA at 5x the fp32 rate), or a zero-padded fp32 copy (ADALOG_CONV_SPLIT3=0)."""
+        be = backend.get()
+        if SPLIT3_INPUT:
+            return be.pack_split3(patches.unsqueeze(0))
+        return be.pack_raw(patches.unsqueeze(0))
+
     def _score_w(self, xp, ref, M, fmap, scale, zp, defer=False):
         """conv.py:226-255 -> scores [P, oc] = -sum_images mean_{fw,fh} (raw_out - conv(x, fq_p(W)) - b)^2."""
         be = backend.get()
         oc = self.out_channels
         K = self._w2().shape[1]
         P = scale.shape[0]
-        chunk = max(1, min(P, MAX_PACK_BYTES // max(1, oc * pad_k(K, F32) * 4)))
+        split3 = xp.dtype == torch.bfloat16
+        dt = BF16 if split3 else F32
+        chunk = max(1, min(P, MAX_PACK_BYTES // max(1, oc * pad_k(K, F32) * (6 if split3 else 4))))
         ones = search.const_tensor([1.0], xp.device)
         bias = None if self.bias is None else Strided(self.bias.data, n=1)
         out = []
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
-            wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, oc, 1, 0, 1, self.w_quantizer.n_bits, F32,
+            wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, oc, 1, 0, 1, self.w_quantizer.n_bits, dt,
                                  c_inner=True)
-            out.append(be.gemm_score(F32, xp, wp, M, oc, e - s, 1, 1, ref, Strided(ones), Strided(sc, c=oc, n=1), bias,
+            if split3:
+                wp = wp.repeat(1, 1, 1, 3)              # [hi | mid | lo] of x each meet the same integers
+            out.append(be.gemm_score(dt, xp, wp, M, oc, e - s, 1, 1, ref, Strided(ones), Strided(sc, c=oc, n=1), bias,
                                      False, True, 1.0 / fmap, ref_div=e - s, order=2, ref_transposed=True,
                                      defer=defer and chunk >= P))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
@@ -167,7 +181,7 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
         self._check_patch_conv()
         patches, gh, gw = self._patches(self.raw_input)
         M = patches.shape[0]
-        xp = be.pack_raw(patches.unsqueeze(0))
+        xp = self._pack_x(patches)
         ref = self.raw_out.permute(1, 0, 2, 3).reshape(1, self.out_channels, M).contiguous()      # [1, oc, tokens]
         scale, zp, delta = search.weight_grid(self._w2(), self.w_quantizer.n_bits, self.eq_n, conv=True)
         fn = lambda s, z, t: self._score_w(xp, ref, M, gh * gw, s, z, defer=True)

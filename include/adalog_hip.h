@@ -60,7 +60,10 @@ int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n
  *   u = (x + shift)/s_c [clamped to [1e-15,1] when clamp_u];  masked bins (k >= 2L) -> 0
  *   replaces linear.py:830-836,872-878,913-919 and matmul.py:337-342.  mant37: fp32 [37] integer numerators
  *   round(2^(-j/37) * (4L-2))  (linear.py:750-752).
- * adalog_pack_raw_f32: zero-padded fp32 copy (conv input with qconv_a_bit = 8, conv.py:55-58). */
+ * adalog_pack_raw_f32: zero-padded fp32 copy (conv input with qconv_a_bit = 8, conv.py:55-58).
+ * adalog_pack_split3_bf16: the same unquantised operand as three bf16 terms, out[row] = [hi(Kt) | mid(Kt) | lo(Kt)] with
+ *   hi + mid + lo == x exactly (8 + 8 + 8 mantissa bits; zero past K).  Scored against an exact-integer bf16 candidate operand
+ *   repeated three times along K, the bf16 MFMA accumulates the products the fp32 MFMA would, at 5x its rate. */
 int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
                         const float* scale, const float* zero_point, int64_t C, int64_t pc, int64_t gmod, int64_t pg,
                         int64_t pr, int n_bits, int out_dtype, void* out, int64_t Kp, int32_t* rowsum, int c_inner,
@@ -71,6 +74,8 @@ int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int64_t K, int
                             int c_inner, void* stream);
 int adalog_pack_raw_f32(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk, void* out,
                         int64_t Kp, void* stream);
+int adalog_pack_split3_bf16(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk, void* out,
+                            int64_t Kt, void* stream);
 
 /* ---- K7/K8/K11-K15  scoring GEMM with fused squared-error epilogue (MFMA)
  * For candidate c < C and group g < G (gh = g % gmod):

@@ -106,6 +106,19 @@ def pack_raw(x3):
     return out
 
 
+def pack_split3(x3, k_align=128):
+    G, R, K = x3.shape
+    Kt = pad_k(K, BF16, k_align)
+    out = torch.zeros((1, G, R, 3 * Kt), dtype=torch.bfloat16)
+    hi = x3.to(torch.bfloat16)
+    r1 = x3 - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    assert torch.equal(hi.float() + mid.float() + lo.float(), x3), "three bf16 terms must reproduce fp32 exactly"
+    out[0, :, :, :K], out[0, :, :, Kt:Kt + K], out[0, :, :, 2 * Kt:2 * Kt + K] = hi, mid, lo
+    return out
+
+
 def _epi(t: Strided, C, G, gmod, N):
     c = torch.arange(C).view(C, 1, 1)
     gh = (torch.arange(G) % gmod).view(1, G, 1)

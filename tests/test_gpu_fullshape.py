@@ -288,7 +288,7 @@ def test_conv_scores_full_shape(tag, ic, oc, k, hw, N, bits):
     with torch.no_grad():
         patches, gh, gw = lay._patches(lay.raw_input)
         M = patches.shape[0]
-        xp = be.pack_raw(patches.unsqueeze(0))
+        xp = lay._pack_x(patches)
         rf = lay.raw_out.permute(1, 0, 2, 3).reshape(1, oc, M).contiguous()
         got = lay._score_w(xp, rf, M, gh * gw, sc.reshape(128, -1).to(DEV), zp.reshape(128, -1).float().to(DEV))[SUB]
     err = _rel(got, ref)

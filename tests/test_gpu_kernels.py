@@ -248,6 +248,37 @@ def test_pack_raw(ops):
     assert torch.equal(ops.pack_raw(x3.to(DEV)).cpu(), CB.pack_raw(x3))
 
 
+def test_pack_split3_is_exact_and_scores_like_fp32(ops):
+    """conv.py:226-255 with the unquantised input as three bf16 terms: hi + mid + lo == x bit for bit, and the scores of the
+    bf16 GEMM over [hi | mid | lo] x [W | W | W] equal the fp32-operand GEMM's (same fp32 products, other summation order)."""
+    gen = g(15)
+    M, K, O_, P, bits = 300, 48 * 3, 40, 128, 4
+    x3 = torch.randn(1, M, K, generator=gen) * torch.logspace(-3, 2, K).view(1, 1, K)
+    x3[0, 0, :4] = torch.tensor([0.0, 1e-30, -3.0e38, 1.0 + 2.0 ** -23])
+    got = ops.pack_split3(x3.to(DEV)).cpu()
+    assert torch.equal(got.view(torch.int16), CB.pack_split3(x3).view(torch.int16))
+    Kt = got.shape[-1] // 3
+    s3 = got[..., :Kt].float() + got[..., Kt:2 * Kt].float() + got[..., 2 * Kt:].float()
+    assert torch.equal(s3[..., :K], x3[None]) and (s3[..., K:] == 0).all()
+    x3[0, 0, :4] = torch.tensor([0.0, 1e-30, -3.0, 1.0 + 2.0 ** -23])        # (3e38 squared overflows any score)
+    W = torch.randn(1, O_, K, generator=gen) * 0.1
+    sc = torch.rand(P, O_, generator=gen) * 0.02 + 0.005
+    zp = torch.randint(4, 12, (P, O_), generator=gen).float()
+    ref = torch.randn(1, O_, M, generator=gen)
+    bias = torch.randn(O_, generator=gen)
+    one = torch.ones(1)
+    res = {}
+    for name, dt in (("f32", ops.F32), ("split3", ops.BF16)):
+        xa = ops.pack_raw(x3.to(DEV)) if name == "f32" else ops.pack_split3(x3.to(DEV))
+        wb = ops.pack_uniform(W.to(DEV), sc.to(DEV), zp.to(DEV), P, O_, 1, 0, 1, bits, dt, c_inner=True)
+        if name == "split3":
+            wb = wb.repeat(1, 1, 1, 3)
+        res[name] = ops.gemm_score(dt, xa, wb, M, O_, P, 1, 1, ref.to(DEV), ops.Strided(one.to(DEV)),
+                                   ops.Strided(sc.to(DEV), c=O_, n=1), ops.Strided(bias.to(DEV), n=1), False, True, 1.0 / 7,
+                                   ref_div=P, order=2, ref_transposed=True).cpu()
+    assert res["split3"].shape == (P, O_) and rel_err(res["split3"], res["f32"]) <= 2e-6
+
+
 # ------------------------------------------------------------------------------------------------ scoring GEMM
 def _strided(mod, t, **kw):
     return mod.Strided(t, **kw)

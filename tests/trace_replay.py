@@ -325,7 +325,7 @@ def replay_conv(golden, bits, device="cpu"):
     lay.raw_input, lay.raw_out = x.to(dev), ro.to(dev)
     patches, gh, gw = lay._patches(lay.raw_input)
     M = patches.shape[0]
-    xp = be.pack_raw(patches.unsqueeze(0))
+    xp = lay._pack_x(patches)
     ref = lay.raw_out.permute(1, 0, 2, 3).reshape(1, oc, M).contiguous()
     rp = Replay(g)
 
