@@ -308,6 +308,8 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
 
     # ------------------------------------------------------------------ FPCS (linear.py:483-523)
     def weight_fpcs(self, fpcs_width=16, steps=6, search_strategy="output"):
+        if search_strategy != "self" and search.round_is_redundant(self, "w", self.a_quantizer):
+            return                                 # the activation quantiser is what this search saw last round: same winner
         scale, zp, delta = search.weight_grid(self._w2(), self.w_quantizer.n_bits, self.eq_n)
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_w_self(s, z)
@@ -320,6 +322,8 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
 
     def activation_fpcs(self, fpcs_width=16, steps=6, search_strategy="output"):
         aq = self.a_quantizer
+        if search_strategy != "self" and search.round_is_redundant(self, "a", self.w_quantizer):
+            return
         scale, zp, delta = search.activation_grid(self.raw_input, aq.n_bits, self.eq_n, aq.channel_wise)
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_a_self(s, z)
@@ -338,12 +342,14 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if not self.fpcs:
             raise NotImplementedError("non-FPCS single-pass search is not part of the accelerated path (configs use fpcs=True)")
         self._initialize_calib_parameters()
+        search.begin_rounds(self)
         self.weight_fpcs(steps=self.steps, search_strategy="self")
         self.activation_fpcs(steps=self.steps, search_strategy="self")
         for _ in range(self.search_round):
             self.weight_fpcs(steps=self.steps, search_strategy="output")
             self.activation_fpcs(steps=self.steps, search_strategy="output")
         self.calibrated = True
+        search.begin_rounds(self)
         search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
@@ -553,6 +559,8 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         """linear.py:941-967: 128 log bases -> top-8 bases x 16 scales -> width-32 FPCS with 4 neighbours."""
         be = backend.get()
         aq = self.a_quantizer
+        if search.round_is_redundant(self, "a", self.w_quantizer, aq):     # (starts from its own current scale: part of the input)
+            return
         dev = self.weight.device
         wp, rowsum = self._pack_w_fixed(BF16, want_rowsum=True)
         bias_fold = be.shift_fold(rowsum.view(1, -1), self.w_quantizer.scale.data.view(1, -1), aq.shift.data,
@@ -584,6 +592,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         self._initialize_calib_parameters()
         self._shift_host = None
+        search.begin_rounds(self)
         try:
             self.weight_fpcs(steps=self.steps, search_strategy="self")
             ud_candidates, input_scale_candidates = self.calculate_percentile_activation_candidates()
@@ -596,6 +605,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         finally:
             # the caches are keyed by storage address: they must not outlive this search, whether it ends or raises
             search.forget_grids()
+            search.begin_rounds(self)
             self._ref_t = self._ref_t_key = None
             self._lx = self._lx_key = None
         self.calibrated = True

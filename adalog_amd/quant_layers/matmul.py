@@ -218,8 +218,10 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         quantizer.scale.data.copy_(scale.view(quantizer.scale.shape))
         quantizer.zero_point.data.copy_(zp.view(quantizer.zero_point.shape))
 
-    def _fpcs(self, which, fpcs_width=16, steps=6, fixed=None, dt=I8, fixed_sa=None, sa_mul=1.0):
+    def _fpcs(self, which, fpcs_width=16, steps=6, fixed=None, dt=I8, fixed_sa=None, sa_mul=1.0, checked=False):
         """matmul.py:243-262."""
+        if not checked and search.round_is_redundant(self, which, self.B_quantizer if which == "A" else self.A_quantizer):
+            return                                 # the other operand's quantiser is what this search saw last round
         x = self.raw_input[0] if which == "A" else self.raw_input[1]
         scale, zp, delta = search.matmul_grid(x, self.B_quantizer.n_bits, self.eq_n, self.head_channel_wise)
         if fixed is None:
@@ -243,6 +245,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         self._initialize_calib_parameters()
+        search.begin_rounds(self)
         self._init_from_grid("A")
         self._init_from_grid("B")
         G, S, K, Sp = self._dims()
@@ -253,6 +256,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
             self._fpcs("A", steps=self.steps, dt=dt)
             self._fpcs("B", steps=self.steps, dt=dt)
         self.calibrated = True
+        search.begin_rounds(self)
         search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None
@@ -340,6 +344,8 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         """matmul.py:321-358: score the 128 bases, commit the best."""
         be = backend.get()
         aq = self.A_quantizer
+        if search.round_is_redundant(self, "Aq", self.B_quantizer):
+            return
         q_all, scores = self._score_A_log_base()
         idx = search.argbest(scores, 1)
         best_q = be.fpcs_next(q_all.view(-1, 1), None, None, idx, 1, 0, None, None, None)[0]
@@ -353,17 +359,21 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         if not self.fpcs:
             raise NotImplementedError("non-FPCS search is not part of the accelerated path")
         self._initialize_calib_parameters()
+        search.begin_rounds(self)
         self._init_from_grid("B")
         A = self.raw_input[0]
         dev = A.device
         for _ in range(self.search_round):
             self._search_best_A_log_base()
+            if search.round_is_redundant(self, "B", self.A_quantizer):
+                continue                           # same log base as last round: the B search would repeat itself
             # B search against q_A(A): eval-form AdaLog of A (clamped, scale 1) is the fixed bf16 operand
             qv = search.const_tensor([float(self._q_host)], dev)
             ap = self._pack_A_adalog(self._a3(A), qv, self.A_quantizer.scale.data.view(-1), 1, True, k_align=self._kalign())
             self._fpcs("B", steps=self.steps, fixed=ap, dt=BF16, fixed_sa=Strided(self.A_quantizer.scale.data.view(-1)),
-                       sa_mul=self._ts32())
+                       sa_mul=self._ts32(), checked=True)
         self.calibrated = True
+        search.begin_rounds(self)
         search.forget_grids()
         del self.raw_input, self.raw_out
         self._ref_t = self._ref_t_key = None

@@ -35,6 +35,44 @@ def const_tensor(values, device, dtype=torch.float32) -> torch.Tensor:
     return _LIN_CACHE[key]
 
 
+# ------------------------------------------------------------------------------------------------ converged rounds
+# The alternating rounds of a module's search (weights | activations, A | B: linear.py:538-541, matmul.py:275-277) re-run each
+# output-MSE search with the OTHER operand's quantiser as it stands.  A search is a pure function of that quantiser (the
+# captures, the weights and the percentile grid do not change inside a module's search), so when the other quantiser comes
+# back bit-identical to what this search saw last time -- the rounds have converged, ~20 % of the Linear searches of a
+# deit_small calibration -- its result is the one already committed and the search is not repeated.  One host read
+# (torch.equal) per check.  ADALOG_SKIP_CONVERGED=0 re-runs everything, as the reference does.
+SKIP_CONVERGED = __import__("os").environ.get("ADALOG_SKIP_CONVERGED", "1") != "0"
+ROUND_STATS = {"checked": 0, "unchanged": 0}
+
+
+def quantizer_state(q):
+    """the tensors that define a calibrated quantiser (uniform: scale, zero point; AdaLog: scale, base q)"""
+    return tuple(t.detach().clone() for t in (getattr(q, "scale", None), getattr(q, "zero_point", None), getattr(q, "q", None))
+                 if torch.is_tensor(t))
+
+
+def begin_rounds(module):
+    """call at the start (and end) of a module's hyperparameter search: forgets what its searches have seen"""
+    module.__dict__["_round_inputs"] = {}
+
+
+def round_is_redundant(module, tag: str, *quantizers) -> bool:
+    """True when the search `tag` of this module last ran against exactly this state of the quantisers it reads (the other
+    operand's; its own too when the search starts from its current parameters) -- then its committed result stands.
+    Records the state either way."""
+    seen = module.__dict__.setdefault("_round_inputs", {})
+    state = tuple(t for q in quantizers for t in quantizer_state(q))
+    prev = seen.get(tag)
+    seen[tag] = state
+    if prev is None:
+        return False
+    ROUND_STATS["checked"] += 1
+    same = len(prev) == len(state) and all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(prev, state))
+    ROUND_STATS["unchanged"] += int(same)
+    return same and SKIP_CONVERGED
+
+
 def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 16, eq_n: int = 128,
          clamp_min: Optional[float] = None):
     """Run the progressive search.  ``score_fn(scale, zp, third) -> scores [P, cols]`` (rank-local partial sums).

@@ -145,10 +145,14 @@ class QuantCalibrator:
         """Two (communicator, stream) lanes when the images are sharded over several ranks (adalog_amd.parallel): one module's
         score all-reduce then hides under the other module's scoring GEMMs.  ADALOG_INTERLEAVE=0: the sequential schedule."""
         from .. import parallel
-        if not parallel.is_dist() or os.environ.get("ADALOG_INTERLEAVE", "1") == "0":
+        on_gpu = torch.device(device).type == "cuda"
+        if not parallel.is_dist():
+            # one process: ADALOG_LANES=n (>= 2) runs n modules' searches side by side on n streams (no communicators)
+            n = int(os.environ.get("ADALOG_LANES", "1"))
+            return [(None, torch.cuda.Stream(device=device)) for _ in range(n)] if n >= 2 and on_gpu else None
+        if os.environ.get("ADALOG_INTERLEAVE", "1") == "0":
             return None
         groups = parallel.lane_groups(2)
-        on_gpu = torch.device(device).type == "cuda"
         return [(g, torch.cuda.Stream(device=device) if on_gpu else None) for g in groups]
 
     def _search_interleaved(self, group, device, lanes):

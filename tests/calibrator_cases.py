@@ -146,3 +146,47 @@ def case_capture_equivalence(device="cpu", bits=4):
     e_b = ((outs["block"] - y_fp) ** 2).mean().item()
     return {"scales": n_scale, "scales_off": n_bad, "mse_module": e_m, "mse_block": e_b,
             "max_out_diff": (outs["module"] - outs["block"]).abs().max().item(), "out_max": outs["module"].abs().max().item()}
+
+
+def case_converged_rounds_are_skipped_exactly(device="cpu", bits=4, rounds=4):
+    """adalog_amd.search.round_is_redundant: an output-MSE search whose inputs (the other operand's quantiser) are bit-identical
+    to the ones it ran on in the previous round is not repeated.  The calibrated model must equal, tensor for tensor, the one
+    obtained by re-running every search as the reference does (linear.py:538-541, matmul.py:275-277), and the case must
+    actually exercise the shortcut."""
+    import copy
+    import importlib.util
+    import os
+    from adalog_amd import search
+    from adalog_amd.utils.models import VisionTransformer
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    dev = torch.device(device)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(f"cfg{bits}cr", os.path.join(root, "configs", f"{bits}bit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = mod.Config()
+    cfg.search_round, cfg.steps = rounds, 3
+    torch.manual_seed(11)
+    base = VisionTransformer(img_size=32, patch_size=8, embed_dim=32, depth=2, num_heads=2, num_classes=10).eval()
+    for p in base.parameters():
+        p.data.mul_(8.0)
+    x = torch.randn(8, 3, 32, 32).to(dev)
+    sds, stats = {}, {}
+    keep = search.SKIP_CONVERGED
+    try:
+        for skip in (False, True):
+            search.SKIP_CONVERGED = skip
+            search.ROUND_STATS.update(checked=0, unchanged=0)
+            model = wrap_modules_in_net(copy.deepcopy(base), cfg, reparam=True).to(dev)
+            QuantCalibrator(model, [(x, None)], capture="block").batching_quant_calib()
+            model = wrap_reparamed_modules_in_net(model)
+            sds[skip] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            stats[skip] = dict(search.ROUND_STATS)
+    finally:
+        search.SKIP_CONVERGED = keep
+    assert set(sds[False]) == set(sds[True])
+    for k, a in sds[False].items():
+        assert torch.equal(a, sds[True][k]), k
+    assert stats[True]["unchanged"] > 0, stats                       # the shortcut was taken ...
+    assert stats[False]["unchanged"] >= stats[True]["unchanged"], stats   # ... and a full run meets at least as many fixed points
+    return stats

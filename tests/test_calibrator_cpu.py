@@ -73,3 +73,8 @@ def test_calibrator_on_vit_block_with_reparam():
 def test_block_capture_equals_module_capture():
     r = CC.case_capture_equivalence()
     assert r["scales_off"] == 0 and r["max_out_diff"] <= 1e-3 * r["out_max"], r
+
+
+def test_converged_rounds_are_skipped_exactly():
+    stats = CC.case_converged_rounds_are_skipped_exactly()
+    assert stats[True]["checked"] > 0

@@ -124,6 +124,42 @@ def test_block_capture_equals_module_capture_on_hip(bits):
     assert abs(r["mse_block"] / r["mse_module"] - 1.0) <= 0.02, r
 
 
+def test_converged_rounds_are_skipped_exactly_on_hip():
+    from adalog_amd import backend
+    from tests import calibrator_cases as CC
+    backend.set_backend(None)
+    stats = CC.case_converged_rounds_are_skipped_exactly(DEV)
+    assert stats[True]["checked"] > 0
+
+
+def test_two_lanes_on_one_gpu_give_the_sequential_parameters(monkeypatch):
+    """ADALOG_LANES=2 (one process: two modules' searches side by side on two streams, calibrator._search_interleaved) must
+    calibrate every parameter exactly as the sequential schedule does -- the modules' searches are independent
+    (reference utils/calibrator.py:34-67)."""
+    import copy
+    import numpy as np
+    from adalog_amd import backend
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net
+    from tests import wrapper_cases as WC
+    backend.set_backend(None)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "wrapper_rules.npz"))
+    cfg = WC.cfg_of(4)
+    cfg.search_round, cfg.steps, cfg.calib_batch_size = 2, 3, 8
+    base = WC._load(WC.tiny_vit(), g, "vit_in_", torch.device("cpu"))
+    x = torch.randn(8, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
+    states = {}
+    for lanes in ("1", "2"):
+        monkeypatch.setenv("ADALOG_LANES", lanes)
+        vit = wrap_modules_in_net(copy.deepcopy(base), cfg, reparam=True).to(DEV)
+        QuantCalibrator(vit, [(x, None)], capture="block").batching_quant_calib()
+        torch.cuda.synchronize()
+        states[lanes] = {k: v.detach().cpu().clone() for k, v in vit.state_dict().items()}
+    assert states["1"].keys() == states["2"].keys()
+    for k, v in states["1"].items():
+        assert torch.equal(v, states["2"][k]), k
+
+
 def test_cli_vit_base_calibrate_and_optimize(tmp_path):
     """BASELINE config 3 in reduced form: vit_base W4A4 `--calibrate --optimize` through the CLI -- calibration of the
     768-wide model (two-row-tile fused search, K = 768 int8 searches), then BRECQ over every block (HIP-graph replay,

@@ -24,15 +24,24 @@ for rep in range(2):
         QuantCalibrator(model, [(imgs, None)], capture="block").batching_quant_calib()
         torch.cuda.synchronize()
         continue
-    with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CPU, torch.profiler.ProfilerActivity.CUDA],
-                                with_stack=True) as prof:
+    import traceback
+    from torch.overrides import TorchFunctionMode
+
+    WATCH = {"copy_", "to", "clone", "contiguous", "float", "cat", "stack", "zeros", "zeros_like", "full", "tensor", "repeat",
+             "index_select", "fill_", "zero_", "expand_as", "reshape", "double", "int", "long", "item", "tolist", "cpu"}
+    cnt = collections.Counter()
+
+    class Spy(TorchFunctionMode):
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            name = getattr(func, "__name__", str(func))
+            if name in WATCH:
+                fr = [f for f in traceback.extract_stack()[:-1] if "adalog_amd" in f.filename]
+                where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-2:][::-1]) if fr else "?"
+                cnt[(name, where)] += 1
+            return func(*args, **(kwargs or {}))
+
+    with Spy():
         QuantCalibrator(model, [(imgs, None)], capture="block").batching_quant_calib()
         torch.cuda.synchronize()
-    cnt = collections.Counter()
-    for ev in prof.events():
-        if ev.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::fill_", "aten::zero_", "aten::zeros", "aten::to",
-                       "aten::_to_copy"):
-            stack = [s for s in (ev.stack or []) if ".py" in s and "torch/" not in s]
-            cnt[(ev.name, " <- ".join(st.split("/")[-1] for st in stack[:3]) if stack else "?")] += 1
-    for (name, where), n in cnt.most_common(40):
-        print(f"{n:6d}  {name:18s} {where}")
+    for (name, where), n in cnt.most_common(70):
+        print(f"{n:6d}  {name:14s} {where}")
