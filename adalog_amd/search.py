@@ -46,10 +46,16 @@ SKIP_CONVERGED = __import__("os").environ.get("ADALOG_SKIP_CONVERGED", "1") != "
 ROUND_STATS = {"checked": 0, "unchanged": 0}
 
 
-def quantizer_state(q):
-    """the tensors that define a calibrated quantiser (uniform: scale, zero point; AdaLog: scale, base q)"""
-    return tuple(t.detach().clone() for t in (getattr(q, "scale", None), getattr(q, "zero_point", None), getattr(q, "q", None))
-                 if torch.is_tensor(t))
+def quantizer_state(*quantizers):
+    """the bits of the tensors that define calibrated quantisers (uniform: scale, zero point; AdaLog: scale, base q), as ONE
+    flat int32 tensor: a state comparison is then one kernel and one host read"""
+    parts = []
+    for q in quantizers:
+        for t in (getattr(q, "scale", None), getattr(q, "zero_point", None), getattr(q, "q", None)):
+            if torch.is_tensor(t):
+                t = t.detach().reshape(-1)
+                parts.append(t.view(torch.int32) if t.dtype == torch.float32 else t.to(torch.int32))
+    return torch.cat(parts) if len(parts) != 1 else parts[0].clone()
 
 
 def begin_rounds(module):
@@ -62,13 +68,13 @@ def round_is_redundant(module, tag: str, *quantizers) -> bool:
     operand's; its own too when the search starts from its current parameters) -- then its committed result stands.
     Records the state either way."""
     seen = module.__dict__.setdefault("_round_inputs", {})
-    state = tuple(t for q in quantizers for t in quantizer_state(q))
+    state = quantizer_state(*quantizers)
     prev = seen.get(tag)
     seen[tag] = state
     if prev is None:
         return False
     ROUND_STATS["checked"] += 1
-    same = len(prev) == len(state) and all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(prev, state))
+    same = prev.shape == state.shape and torch.equal(prev, state)
     ROUND_STATS["unchanged"] += int(same)
     return same and SKIP_CONVERGED
 

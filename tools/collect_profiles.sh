@@ -7,6 +7,7 @@ for m in deit_tiny vit_base swin_small swin_base w3 w6 swin_base_w3_128img; do [
 grep -h '^{' $f/bench_gloo2.json | tail -1 > profiles/${r}_bench_gloo_2ranks_1gpu.json
 cp $f/prof/p_kernel_stats.csv profiles/${r}_kernel_stats_deit_small_w4a4.csv
 cp $f/prof/p_domain_stats.csv profiles/${r}_domain_stats.csv
+[ -f $f/prof_all/p_kernel_stats.csv ] && cp $f/prof_all/p_kernel_stats.csv profiles/${r}_kernel_stats_deit_small_w4a4_allrounds.csv
 for m in vit_base swin_base; do [ -f $f/prof_$m/p_kernel_stats.csv ] && cp $f/prof_$m/p_kernel_stats.csv profiles/${r}_kernel_stats_${m}_w4a4.csv; done
 [ -f $f/pmc/traffic.json ] && cp $f/pmc/traffic.json profiles/${r}_pmc_bench_traffic.json
 [ -f $f/pmc_fused/summary.json ] && cp $f/pmc_fused/summary.json profiles/${r}_pmc_fused_summary.json

@@ -8,7 +8,7 @@ out=${1:-gpurun_out/pmc_bench}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d "$out/$c" -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > "$out/$c.log" 2>&1 < /dev/null
+  rocprofv3 --pmc $c --output-format csv -d "$out/$c" -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-rerun-all > "$out/$c.log" 2>&1 < /dev/null
 done
 python3 - "$out" <<'PY'
 import csv, glob, json, os, sys
