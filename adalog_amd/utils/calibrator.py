@@ -41,6 +41,16 @@ class QuantCalibrator:
         self.capture_seconds = 0.0
         self._events = {}                    # module name -> (start, end) device events around its search (+ reparam)
         self._capture_events = []
+        # Finished blocks answer from a cache.  The reference re-runs the whole network for every module it calibrates
+        # (calibrator.py:44-47); with one pass per block that is still (depth + 1) / 2 full forwards per calibration.  A block
+        # whose modules are all calibrated (and re-parameterised) no longer changes, nor does anything upstream of it, so its
+        # output for calibration batch i is a constant: it is recorded the first time the block runs after being finished (during
+        # the NEXT block's capture pass) and returned from then on instead of being recomputed -- the tensors downstream are
+        # bit for bit the ones a full forward produces.  ADALOG_CAPTURE_CACHE=0: recompute.
+        self._cache_blocks = capture == "block" and os.environ.get("ADALOG_CAPTURE_CACHE", "1") != "0"
+        self._finished = []                  # finished blocks not cached yet
+        self._patched = []                   # blocks whose forward returns the cached outputs
+        self._bi = 0                         # index of the calibration batch in flight
 
     # hooks keep the reference's names (calibrator.py:14-28); tensors stay on the device
     def single_input_forward_hook(self, module, inp, outp):
@@ -84,14 +94,27 @@ class QuantCalibrator:
         def stop(module, inp, outp):
             raise _StopForward()
         hooks.append(last.register_forward_hook(stop))
+        recording = []
+        for block in self._finished:
+            outs = []
+            recording.append((block, outs))
+            hooks.append(block.register_forward_hook(lambda m, i, o, _outs=outs: _outs.append(o.detach() if torch.is_tensor(o) else o)))
+        n_batches = 0
         with torch.no_grad():
-            for inp, _ in self.calib_loader:
+            for bi, (inp, _) in enumerate(self.calib_loader):
+                self._bi = bi
+                n_batches += 1
                 try:
                     self.model(inp.to(device, non_blocking=True))
                 except _StopForward:
                     pass
         for h in hooks:
             h.remove()
+        for block, outs in recording:
+            if len(outs) == n_batches:                       # (the pass ran through it for every batch)
+                block.forward = lambda *a, _outs=outs, **k: _outs[self._bi]
+                self._patched.append(block)
+                self._finished.remove(block)
         for _, module in group:
             module.raw_out = torch.cat(module.tmp_out, dim=0)
             if isinstance(module, (MinMaxQuantLinear, MinMaxQuantConv2d)):
@@ -221,13 +244,20 @@ class QuantCalibrator:
                 groups.append((key, [(name, module)]))
         device = next(self.model.parameters()).device
         lanes = self._lanes(device)
-        for key, group in groups:
-            self._capture(group)
-            if lanes is None or len(group) < 2:
-                for name, module in group:
-                    self._search_one(name, module, device)
-            else:
-                self._search_interleaved(group, device, lanes)
+        try:
+            for key, group in groups:
+                self._capture(group)
+                if lanes is None or len(group) < 2:
+                    for name, module in group:
+                        self._search_one(name, module, device)
+                else:
+                    self._search_interleaved(group, device, lanes)
+                if self._cache_blocks and re.search(r"blocks\.\d+$", key):
+                    self._finished.append(self.model.get_submodule(key))
+        finally:
+            for block in self._patched:                      # back to computing (the instance attribute shadowed the method)
+                del block.forward
+            self._patched, self._finished = [], []
         for _, module in self.model.named_modules():
             if hasattr(module, 'mode'):
                 module.mode = "quant_forward"

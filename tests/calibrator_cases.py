@@ -190,3 +190,47 @@ def case_converged_rounds_are_skipped_exactly(device="cpu", bits=4, rounds=4):
     assert stats[True]["unchanged"] > 0, stats                       # the shortcut was taken ...
     assert stats[False]["unchanged"] >= stats[True]["unchanged"], stats   # ... and a full run meets at least as many fixed points
     return stats
+
+
+def case_capture_cache_equals_recompute(device="cpu", which="vit"):
+    """QuantCalibrator's cache of finished blocks (the blocks upstream of the one being captured return their recorded outputs
+    instead of recomputing them; reference utils/calibrator.py:44-47 re-runs the whole network) must not change one captured
+    value: the calibrated model is equal tensor for tensor with the cache on and off."""
+    import copy
+    import os
+    import numpy as np
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    from tests import wrapper_cases as WC
+    dev = torch.device(device)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, "tests", "golden", "wrapper_rules.npz"))
+    cfg = WC.cfg_of(4)
+    cfg.search_round, cfg.steps, cfg.calib_batch_size = 1, 2, 4
+    base = WC._load(WC.tiny_vit() if which == "vit" else WC.tiny_swin(), g, f"{which}_in_", torch.device("cpu"))
+    side = 32 if which == "vit" else 56
+    x = torch.randn(8, 3, side, side, generator=torch.Generator().manual_seed(3)).to(dev)
+    loader = [(x[:4], None), (x[4:], None)]                              # two calibration batches
+    sds, passes = {}, {}
+    keep = os.environ.get("ADALOG_CAPTURE_CACHE")
+    try:
+        for cache in ("0", "1"):
+            os.environ["ADALOG_CAPTURE_CACHE"] = cache
+            model = wrap_modules_in_net(copy.deepcopy(base), cfg, reparam=True).to(dev)
+            calls = [0]
+            inner = [m for n, m in model.named_modules() if n.endswith(".norm1")]          # one per block, inside it
+            hooks = [b.register_forward_pre_hook(lambda m, i, _c=calls: _c.__setitem__(0, _c[0] + 1)) for b in inner]
+            QuantCalibrator(model, loader, capture="block").batching_quant_calib()
+            for h in hooks:
+                h.remove()
+            model = wrap_reparamed_modules_in_net(model)
+            sds[cache] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+            passes[cache] = calls[0]
+    finally:
+        if keep is None:
+            os.environ.pop("ADALOG_CAPTURE_CACHE", None)
+        else:
+            os.environ["ADALOG_CAPTURE_CACHE"] = keep
+    assert set(sds["0"]) == set(sds["1"])
+    for k, a in sds["0"].items():
+        assert torch.equal(a, sds["1"][k]), k
+    return passes

@@ -78,3 +78,9 @@ def test_block_capture_equals_module_capture():
 def test_converged_rounds_are_skipped_exactly():
     stats = CC.case_converged_rounds_are_skipped_exactly()
     assert stats[True]["checked"] > 0
+
+
+@pytest.mark.parametrize("which", ["vit", "swin"])
+def test_capture_cache_equals_recompute(which):
+    passes = CC.case_capture_cache_equals_recompute("cpu", which)
+    assert 0 < passes["1"] < passes["0"]       # block bodies run less often with the cache (2 per block instead of depth - i + 1)

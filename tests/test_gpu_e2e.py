@@ -132,6 +132,15 @@ def test_converged_rounds_are_skipped_exactly_on_hip():
     assert stats[True]["checked"] > 0
 
 
+@pytest.mark.parametrize("which", ["vit", "swin"])
+def test_capture_cache_equals_recompute_on_hip(which):
+    from adalog_amd import backend
+    from tests import calibrator_cases as CC
+    backend.set_backend(None)
+    passes = CC.case_capture_cache_equals_recompute(DEV, which)
+    assert 0 < passes["1"] < passes["0"]
+
+
 def test_two_lanes_on_one_gpu_give_the_sequential_parameters(monkeypatch):
     """ADALOG_LANES=2 (one process: two modules' searches side by side on two streams, calibrator._search_interleaved) must
     calibrate every parameter exactly as the sequential schedule does -- the modules' searches are independent
