@@ -41,6 +41,7 @@ FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
 # uniform activation searches: candidate operand generated in the slab kernel (1) or packed to HBM first (0, rounds 1-2)
 GEN_ACT_SEARCH = os.environ.get('ADALOG_GEN_ACT', '1') != '0'
 SORTED_SELF_SEARCH = os.environ.get('ADALOG_SORTED_SELF', '1') != '0'
+RUN_DEAD_W_SELF = os.environ.get('ADALOG_DEAD_W_SELF', '0') == '1'
 
 
 class MinMaxQuantLinear(nn.Linear):
@@ -343,7 +344,11 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             raise NotImplementedError("non-FPCS single-pass search is not part of the accelerated path (configs use fpcs=True)")
         self._initialize_calib_parameters()
         search.begin_rounds(self)
-        self.weight_fpcs(steps=self.steps, search_strategy="self")
+        # linear.py:536: the weights' self-MSE search.  Its result is overwritten by the first round's output-MSE weight search
+        # (which reads the activation quantiser and the percentile grid, never the current weight parameters) before anything
+        # reads it, so with search_round >= 1 it is dead work and is not run (ADALOG_DEAD_W_SELF=1 runs it, as the reference does).
+        if self.search_round < 1 or RUN_DEAD_W_SELF:
+            self.weight_fpcs(steps=self.steps, search_strategy="self")
         self.activation_fpcs(steps=self.steps, search_strategy="self")
         for _ in range(self.search_round):
             self.weight_fpcs(steps=self.steps, search_strategy="output")
