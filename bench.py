@@ -440,8 +440,13 @@ def main():
                          "default: --images-per-gpu x N (weak scaling)")
     ap.add_argument("--depth", type=int, default=None, help="truncate the block count (debug only; invalidates the metric)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-rerun-all", action="store_true",
-                    help="skip the second timed region (the same K steps with every round's search re-run, ADALOG_SKIP_CONVERGED=0)")
+    ap.add_argument("--schedule", choices=("reference", "product"), default="reference",
+                    help="what the main timed region (`value`) runs.  reference: every search of every round, as reference "
+                         "quant_layers/linear.py:536-541 / matmul.py:275-277 do -- no candidate work is skipped.  product: the "
+                         "package's default, which does not re-run a search whose inputs are bit-identical to the previous round's "
+                         "nor the dead weight self-search (same calibrated model).  The other schedule is timed in a second region "
+                         "of the same run and reported under config.other_schedule")
+    ap.add_argument("--no-rerun-all", action="store_true", help="skip the second timed region")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -495,6 +500,17 @@ def main():
 
     prof = GemmProfiler(ops)
 
+    from adalog_amd import search as _search
+    from adalog_amd.quant_layers import linear as _linear
+    product_defaults = (_search.SKIP_CONVERGED, _linear.RUN_DEAD_W_SELF)
+
+    def set_schedule(name):
+        if name == "reference":
+            _search.SKIP_CONVERGED, _linear.RUN_DEAD_W_SELF = False, True
+        else:
+            _search.SKIP_CONVERGED, _linear.RUN_DEAD_W_SELF = product_defaults
+
+    set_schedule(args.schedule)
     cals = []
 
     def one_step(model):
@@ -510,7 +526,6 @@ def main():
     torch.cuda.synchronize()
     prof.start()
     parallel.reset_stats()
-    from adalog_amd import search as _search
     _search.ROUND_STATS.update(checked=0, unchanged=0)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -522,11 +537,11 @@ def main():
     by = prof.stop()
     coll = parallel.collective_stats()
     round_stats = dict(_search.ROUND_STATS)
-    # second timed region, same K steps, with the converged rounds' searches RE-RUN as the reference does (their results are the
-    # ones already committed: tests/calibrator_cases.py) -- so the line carries both numbers
+    # second timed region: the same K steps on the OTHER schedule (both produce the same calibrated model, tests/calibrator_cases.py)
     wall_all = None
-    if _search.SKIP_CONVERGED and not args.no_rerun_all:
-        _search.SKIP_CONVERGED = False
+    other = "product" if args.schedule == "reference" else "reference"
+    if not args.no_rerun_all:
+        set_schedule(other)
         more = [copy.deepcopy(base) for _ in range(args.steps)]
         torch.cuda.synchronize()
         parallel.barrier()
@@ -538,7 +553,7 @@ def main():
         parallel.barrier()
         torch.cuda.synchronize()
         wall_all = time.perf_counter() - t1
-        _search.SKIP_CONVERGED = True
+        set_schedule(args.schedule)
         del more
     if world > 1:
         import torch.distributed as dist
@@ -587,17 +602,21 @@ def main():
                                                    else "sequential",
                                        "note": "score / min-max / histogram all-reduces of rank 0 during the timed steps; stream_ms = "
                                                "summed event time around them on their lane's stream (includes waiting for the peers)"},
-                       "converged_rounds": {
-                           "checked_per_step": round_stats["checked"] / args.steps,
-                           "unchanged_per_step": round_stats["unchanged"] / args.steps,
-                           "skipped": bool(_search.SKIP_CONVERGED),
-                           "all_rounds_rerun": None if wall_all is None else {
-                               "ms_per_step": wall_all * 1e3 / args.steps, "images_per_s": cfg.calib_size * args.steps / wall_all,
-                               "steps": args.steps, "how": "second timed region of this run, ADALOG_SKIP_CONVERGED=0"},
-                           "note": "output-MSE searches of rounds 2..3 whose inputs (the other operand's quantiser) were bit-identical "
-                                   "to the previous round's: a pure function of unchanged inputs, so the committed result stands and "
-                                   "the search is not re-run (same calibrated model, tests/calibrator_cases.py); "
-                                   "ADALOG_SKIP_CONVERGED=0 re-runs them as the reference does"},
+                       "schedule": {
+                           "timed": args.schedule,
+                           "reference": "every search of every round is run, as reference quant_layers/linear.py:536-541 and "
+                                        "matmul.py:275-277 do: no candidate work is skipped",
+                           "product": "the package default: an output-MSE search of round 2..3 whose inputs (the other operand's "
+                                      "quantiser) are bit-identical to the previous round's is not re-run (a pure function of unchanged "
+                                      "inputs: it would commit what is committed), nor is the weights' self-MSE search whose result "
+                                      "the first round overwrites unread; same calibrated model tensor for tensor "
+                                      "(tests/calibrator_cases.py); ADALOG_SKIP_CONVERGED=0 ADALOG_DEAD_W_SELF=1 = reference schedule",
+                           "round_checks_per_step": round_stats["checked"] / args.steps,
+                           "round_inputs_unchanged_per_step": round_stats["unchanged"] / args.steps},
+                       "other_schedule": None if wall_all is None else {
+                           "schedule": other, "ms_per_step": wall_all * 1e3 / args.steps,
+                           "images_per_s": cfg.calib_size * args.steps / wall_all, "steps": args.steps,
+                           "how": "second timed region of this run (same barriers and synchronisation, no warm-up of its own)"},
                        "depth_override": args.depth},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],

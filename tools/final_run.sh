@@ -8,10 +8,10 @@ mkdir -p gpurun_out/final
 rm -f gpurun_out/trace_parity.jsonl gpurun_out/fullshape_parity.jsonl gpurun_out/golden_forward_parity.jsonl gpurun_out/wrapper_flow_parity.jsonl
 (time timeout 1800 python -m pytest tests -m gpu -q) > gpurun_out/final/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/final/pytest_gpu.log
 timeout 900 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; head -c 300 gpurun_out/final/bench.json; echo
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rerun-all > gpurun_out/final/prof.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --schedule product --no-rerun-all > gpurun_out/final/prof.log 2>&1
 rm -f gpurun_out/final/prof/p_kernel_trace.csv gpurun_out/final/prof/*/p_kernel_trace.csv
-# the same three calibrations with every round's search re-run (what the reference executes)
-ADALOG_SKIP_CONVERGED=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_all -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-rerun-all > gpurun_out/final/prof_all.log 2>&1
+# the same three calibrations on the reference's schedule (every search of every round: what `value` is measured on)
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_all -o p -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --schedule reference --no-rerun-all > gpurun_out/final/prof_all.log 2>&1
 rm -f gpurun_out/final/prof_all/p_kernel_trace.csv gpurun_out/final/prof_all/*/p_kernel_trace.csv
 timeout 600 bash tools/pmc_bench.sh gpurun_out/final/pmc > gpurun_out/final/pmc.log 2>&1; tail -5 gpurun_out/final/pmc.log
 timeout 300 bash tools/pmc_fused.sh gpurun_out/final/pmc_fused > gpurun_out/final/pmc_fused.log 2>&1
@@ -22,6 +22,6 @@ for b in 3 6; do timeout 300 python bench.py --bits $b --steps 1 --warmup 1 --no
 timeout 900 python bench.py --model swin_base --bits 3 --images-per-gpu 128 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/bench_swin_base_w3_128img.json 2> gpurun_out/final/bench_swin128.err; head -c 200 gpurun_out/final/bench_swin_base_w3_128img.json; echo
 # per-model kernel statistics of the two larger BASELINE models (one warm calibration each)
 for m in vit_base swin_base; do
-  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_$m -o p -- python3 bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline --no-rerun-all > gpurun_out/final/prof_$m.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_$m -o p -- python3 bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline --schedule product --no-rerun-all > gpurun_out/final/prof_$m.log 2>&1
   rm -f gpurun_out/final/prof_$m/p_kernel_trace.csv gpurun_out/final/prof_$m/*/p_kernel_trace.csv
 done
