@@ -34,6 +34,19 @@ def _top(name, *args):
         raise
 
 
+def _timed(meta, call):
+    """bench.py's per-launch timing (GEMM_EVENTS is a list while it runs): events on the current stream around the launch,
+    on whichever route the launch takes"""
+    if GEMM_EVENTS is None:
+        return call()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    r = call()
+    ev1.record()
+    GEMM_EVENTS.append(meta + (ev0, ev1, _lib.load().adalog_last_kernel().decode()))
+    return r
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -299,7 +312,8 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
         n_part, MT, Npad, mode = _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid, ref_transposed)
         # reduced column axis: one partial per n-tile (Npad = NT) / per workgroup
         return n_part, MT, Npad, mode, (Npad if (reduce_cols and mode != 1) else N)
-    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
+    meta = (dtype, M, N, k_valid, C, G)                               # k_valid: un-padded K
+    if _torch_ops.available():
         args = (int(dtype), A, B, int(M), int(N), int(C), int(G), int(gmod), int(k_valid), ref, sa.t, sa.c, sa.g,
                 float(sa_mul), sb.t, sb.c, sb.g, sb.n, None if bias is None else bias.t, 0 if bias is None else bias.c,
                 0 if bias is None else bias.g, 0 if bias is None else bias.n, bool(keep_h), bool(keep_n), float(norm),
@@ -307,9 +321,10 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
                 None if row_scale is None else _f32c(row_scale, "row_scale"),
                 None if row_bias is None else _f32c(row_bias, "row_bias"))
         if not defer:
-            return _top("gemm_score", *args)
+            return _timed(meta, lambda: _top("gemm_score", *args))
         n_part, MT, Npad, mode, n_last = layout()
-        return PendingScores(_top("gemm_score_partial", *args), MT, n_last, Npad, C, G, gmod, keep_h, keep_n, mode, norm, N)
+        return PendingScores(_timed(meta, lambda: _top("gemm_score_partial", *args)), MT, n_last, Npad, C, G, gmod, keep_h, keep_n,
+                             mode, norm, N)
     n_part, MT, Npad, mode, n_last = layout()
     partial = torch.empty((n_part + 1) // 2, dtype=torch.float64, device=A.device).view(torch.float32)   # 8-byte aligned
     if GEMM_EVENTS is not None:
@@ -385,10 +400,11 @@ def score_act_fused(wp, x2, lx2, ref2, row_scale, row_bias, scale, qv, n_bits: i
     P = scale.numel()
     assert wp.dtype == torch.bfloat16 and wp.is_contiguous() and ref2.shape == (T, M)
     x2, lx2, ref2 = _f32c(x2, "x"), _f32c(lx2, "log2 x"), _f32c(ref2, "ref")
-    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
-        return _top("score_act_fused", wp, x2, lx2, ref2, _f32c(row_scale, "row_scale"),
-                    None if row_bias is None else _f32c(row_bias, "row_bias"), _f32c(scale, "scale"), _f32c(qv, "qv"),
-                    int(n_bits), _f32c(mant37, "mant37"), float(shift), bool(clamp_u), float(sa_mul), float(norm))
+    if _torch_ops.available():
+        return _timed((BF16, M, T, K, P, 1), lambda: _top(
+            "score_act_fused", wp, x2, lx2, ref2, _f32c(row_scale, "row_scale"),
+            None if row_bias is None else _f32c(row_bias, "row_bias"), _f32c(scale, "scale"), _f32c(qv, "qv"),
+            int(n_bits), _f32c(mant37, "mant37"), float(shift), bool(clamp_u), float(sa_mul), float(norm)))
     ws_bytes = lib.adalog_score_act_fused_workspace_bytes(T, Kp)
     ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x2.device)
     scores = torch.empty((P, 1), dtype=torch.float32, device=x2.device)
@@ -428,10 +444,12 @@ def score_act_gen(dtype: int, wp, x2, scale, zp, n_bits: int, ref2, row_scale, r
     wgs = lib.adalog_score_act_gen_wgs(dtype, M, T, K, Kp, P)
     if wgs < 0:
         raise _lib.AdalogHipError("score_act_gen: shape not supported (score_act_gen_ok)")
-    if GEMM_EVENTS is None and _torch_ops.available():                # (the timing hooks of bench.py live on the ctypes route)
+    if _torch_ops.available():
+        meta = (dtype, M, T, K, P, 1)
         if not defer:
-            return _top("score_act_gen", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias, float(norm))
-        ws = _top("score_act_gen_partial", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias)
+            return _timed(meta, lambda: _top("score_act_gen", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias,
+                                             float(norm)))
+        ws = _timed(meta, lambda: _top("score_act_gen_partial", int(dtype), wp, x2, scale, zp, int(n_bits), ref2, row_scale, row_bias))
         return PendingScores(ws, wgs, 256, 256, P, 1, 1, False, False, 2, norm, T)
     wsb = lib.adalog_score_act_gen_workspace_bytes(dtype, M, T, K, Kp, P)
     ws = torch.empty((wsb + 15) // 16 * 2, dtype=torch.float64, device=x2.device)
