@@ -44,6 +44,20 @@ def const_tensor(values, device, dtype=torch.float32) -> torch.Tensor:
 # (torch.equal) per check.  ADALOG_SKIP_CONVERGED=0 re-runs everything, as the reference does.
 SKIP_CONVERGED = __import__("os").environ.get("ADALOG_SKIP_CONVERGED", "1") != "0"
 ROUND_STATS = {"checked": 0, "unchanged": 0}
+_ROUND_PENDING = []                # device flags of checks made while nothing is skipped (read by round_stats(), not by the search)
+
+
+def round_stats():
+    """{"checked", "unchanged"} so far; resolves the comparisons that were left on the device (one host read)"""
+    if _ROUND_PENDING:
+        ROUND_STATS["unchanged"] += int(torch.stack(_ROUND_PENDING).sum().item())
+        _ROUND_PENDING.clear()
+    return dict(ROUND_STATS)
+
+
+def reset_round_stats():
+    _ROUND_PENDING.clear()
+    ROUND_STATS.update(checked=0, unchanged=0)
 
 
 def quantizer_state(*quantizers):
@@ -74,9 +88,14 @@ def round_is_redundant(module, tag: str, *quantizers) -> bool:
     if prev is None:
         return False
     ROUND_STATS["checked"] += 1
-    same = prev.shape == state.shape and torch.equal(prev, state)
+    if prev.shape != state.shape:
+        return False
+    if not SKIP_CONVERGED:                 # every search runs anyway: the comparison stays on the device, the host does not wait
+        _ROUND_PENDING.append((prev == state).all())
+        return False
+    same = torch.equal(prev, state)
     ROUND_STATS["unchanged"] += int(same)
-    return same and SKIP_CONVERGED
+    return same
 
 
 def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 16, eq_n: int = 128,

@@ -526,7 +526,7 @@ def main():
     torch.cuda.synchronize()
     prof.start()
     parallel.reset_stats()
-    _search.ROUND_STATS.update(checked=0, unchanged=0)
+    _search.reset_round_stats()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(models[args.warmup + i])
@@ -536,7 +536,7 @@ def main():
     wall = time.perf_counter() - t0
     by = prof.stop()
     coll = parallel.collective_stats()
-    round_stats = dict(_search.ROUND_STATS)
+    round_stats = _search.round_stats()
     # second timed region: the same K steps on the OTHER schedule (both produce the same calibrated model, tests/calibrator_cases.py)
     wall_all = None
     other = "product" if args.schedule == "reference" else "reference"

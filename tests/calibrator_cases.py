@@ -178,12 +178,12 @@ def case_converged_rounds_are_skipped_exactly(device="cpu", bits=4, rounds=4):
         for skip in (False, True):                                       # False: the reference's schedule, True: the product's
             search.SKIP_CONVERGED = skip
             qlinear.RUN_DEAD_W_SELF = not skip                            # (the weights' self-MSE search the first round overwrites)
-            search.ROUND_STATS.update(checked=0, unchanged=0)
+            search.reset_round_stats()
             model = wrap_modules_in_net(copy.deepcopy(base), cfg, reparam=True).to(dev)
             QuantCalibrator(model, [(x, None)], capture="block").batching_quant_calib()
             model = wrap_reparamed_modules_in_net(model)
             sds[skip] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-            stats[skip] = dict(search.ROUND_STATS)
+            stats[skip] = search.round_stats()
     finally:
         search.SKIP_CONVERGED, qlinear.RUN_DEAD_W_SELF = keep
     assert set(sds[False]) == set(sds[True])
