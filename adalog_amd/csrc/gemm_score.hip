@@ -177,6 +177,15 @@ static bool grpk_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64
            (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
 }
 
+// ... and of its mixed form (dtype 4: bf16 rows x fp8 columns): exactly 4 K-steps of 64 elements (K = 193..256).
+static bool grpk8_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid, const float* bias, const float* row_scale,
+                     int64_t sb_n, int64_t ref_cs) {
+    static const int use_grp = getenv("ADALOG_GEMM_GRP") ? atoi(getenv("ADALOG_GEMM_GRP")) : 1;
+    return use_grp && k_valid > 192 && k_valid <= 256 && M > 128 && M <= 224 && G >= 8 && gmod <= 16 && !bias && !row_scale &&
+           sb_n == 0 && (ref_div == 64 || ref_div == 128 || ref_div == 256) && N % ref_div == 0 &&
+           (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
+}
+
 // ... and of the window kernel: int8 or fp8, one K-step, at most 64 rows, hundreds of groups or more, at least as many waves as
 // heads per image (every participating wave owns one head).
 static bool win_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
@@ -192,6 +201,7 @@ static bool win_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_
 // [c_eff][G][MT][Npad] the kernel will write, for allocation and for adalog_finish_scores.
 extern "C" int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_div, int reduce_cols, int dtype,
                                             int64_t Kp, int64_t k_valid, int ref_transposed, int* MT, int* Npad, int* mode) {
+    if (dtype == 4) dtype = 1;                          // mixed operands (bf16 rows x fp8 columns): laid out like the bf16 launch
     const int esz = (dtype == 0 || dtype == 3) ? 1 : dtype == 1 ? 2 : 4;
     const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, true, (k_valid > 0 ? k_valid : Kp) * esz, Kp * esz,
                                ref_transposed != 0, dtype);
@@ -210,6 +220,15 @@ extern "C" int adalog_gemm_win_ok(int dtype, int M, int N, int G, int gmod, int 
     return (L.stream && L.acc && win_ok(dtype, M, N, G, gmod, ref_div, k_valid * esz, nullptr, nullptr, 0, M, L.wgs)) ? 1 : 0;
 }
 
+// 1 when adalog_gemm_score takes dtype 4 (A: bf16 rows, B: fp8 e4m3 candidate columns, both [..][Kp] with Kp = 256 elements) for
+// this shape: the softmax.v weight search of a 197-token ViT (M = 197 attention rows, K = 197 keys) with <= 4-bit candidates.
+// C = 1, reduce_cols = 1, transposed reference.
+extern "C" int adalog_gemm_mixed_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid) {
+    if (ref_div < 1 || N % ref_div != 0) return 0;
+    const Layout L = layout_of(M, N, 1, G, gmod, ref_div, 1, true, k_valid * 2, 256 * 2, true, 1);
+    return (L.stream && L.acc && grpk8_ok(M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M)) ? 1 : 0;
+}
+
 extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
                                  int64_t sBg, int M, int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref,
                                  int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c,
@@ -218,8 +237,46 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                  const float* row_bias, float* partial, int64_t partial_elems, float* out, int64_t ldo,
                                  int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream) {
     ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
-    ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 3, "gemm_score: dtype must be 0 (i8), 1 (bf16), 2 (f32) or 3 (fp8 e4m3)");
+    ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 4, "gemm_score: dtype must be 0 (i8), 1 (bf16), 2 (f32), 3 (fp8 e4m3) or 4 (bf16 rows x fp8 columns)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
+    if (dtype == 4) {
+        // mixed operands: one kernel, one shape family (adalog_gemm_mixed_ok)
+        ADALOG_ARG_CHECK(Kp == 256 && k_valid > 0 && C == 1 && partial && ref && !out && ldr == 1 && reduce_cols == 1 &&
+                         adalog_gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid) && grpk8_ok(M, N, G, gmod, ref_div, k_valid, bias, row_scale, sb_n, ref_cs),
+                         "gemm_score: bf16 x fp8 operands are taken for the shapes adalog_gemm_mixed_ok accepts only (Kp = 256, C = 1, transposed reference)");
+        const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, true, k_valid * 2, Kp * 2, true, 1);
+        GemmArgs p{};
+        p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
+        p.sAc = sAc * 2; p.sAg = sAg * 2; p.sBc = sBc; p.sBg = sBg;
+        p.M = M; p.N = N; p.Kb = Kp; p.KbA = Kp * 2; p.Kvb = k_valid; p.C = C; p.G = G; p.gmod = gmod;
+        p.ref = ref; p.ldr = ldr; p.sRg = sRg; p.ref_cs = ref_cs; p.ref_div = ref_div;
+        p.sa = sa; p.sa_c = sa_c; p.sa_g = sa_g; p.sa_mul = sa_mul;
+        p.sb = sb; p.sb_c = sb_c; p.sb_g = sb_g; p.sb_n = sb_n;
+        p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad; p.order = order; p.reduce_cols = 0; p.partial = partial;
+        ADALOG_ARG_CHECK(partial_elems >= L.elems && ((uintptr_t)partial & 7) == 0, "gemm_score: accumulator buffer too small or misaligned");
+        p.wg_acc = (double*)partial;
+        const int NB = N / 32;
+        const int nch0 = cdiv((int64_t)3 * L.wgs, G);
+        const int CB = cdiv(cdiv(NB, nch0 < 1 ? 1 : nch0), 8) * 8;
+        p.slab_R = CB; p.slab_U = cdiv(NB, CB);
+        const size_t shm = (size_t)3 * 4 * 4 * 32 * BK3 + (size_t)7 * ref_div * 4 + (size_t)gmod * 256 * 8;   // 3 stages of 4 K-steps x 4 blocks
+        hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_GRPK8(NJV)                                                                                         \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_grpk8<NJV, 4>),                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            adalog_note_kernel("k_gemm_grpk8<bf16xfp8>");                                                         \
+            hipLaunchKernelGGL((k_gemm_grpk8<NJV, 4>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);             \
+        } while (0)
+        if (ref_div == 64) LAUNCH_GRPK8(2); else if (ref_div == 128) LAUNCH_GRPK8(4); else LAUNCH_GRPK8(8);
+#undef LAUNCH_GRPK8
+        ADALOG_LAUNCH_CHECK("adalog_gemm_score (bf16 x fp8)");
+        return 0;
+    }
     const int esz = (dtype == 0 || dtype == 3) ? 1 : dtype == 1 ? 2 : 4;
     ADALOG_ARG_CHECK(Kp > 0 && ((Kp * esz) % BK3 == 0 || (Kp * esz == 32 && (dtype == 0 || dtype == 3))),
                      "gemm_score: padded K must be a multiple of 64 bytes (32-byte rows: int8 / fp8, window kernel only)");

@@ -192,7 +192,9 @@ GemmLaunch gemm_score_launch(int64_t dtype, const at::Tensor& A, const at::Tenso
                              int64_t ref_div, int64_t order, bool ref_transposed, const c10::optional<at::Tensor>& row_scale,
                              const c10::optional<at::Tensor>& row_bias) {
     TORCH_CHECK(A.is_cuda() && B.is_cuda() && A.is_contiguous() && B.is_contiguous() && A.dim() == 4 && B.dim() == 4, "A / B: contiguous 4-D HIP tensors");
-    TORCH_CHECK(A.scalar_type() == pack_dtype(dtype) && B.scalar_type() == pack_dtype(dtype), "A / B: dtype does not match");
+    // dtype 4: bf16 rows x fp8 candidate columns (adalog_gemm_mixed_ok)
+    TORCH_CHECK(A.scalar_type() == pack_dtype(dtype == 4 ? 1 : dtype) && B.scalar_type() == pack_dtype(dtype == 4 ? 3 : dtype),
+                "A / B: dtype does not match");
     const int64_t Kp = A.size(3), n_cols = N * ref_div, c_grid = ref_div > 1 ? 1 : C;
     TORCH_CHECK(B.size(3) == Kp && A.size(2) == M && B.size(2) == n_cols, "A / B: shapes do not match M, N, Kp");
     const int64_t sAc = A.size(0) == 1 ? 0 : A.stride(0), sAg = (A.size(1) == 1 && G > 1) ? 0 : A.stride(1);

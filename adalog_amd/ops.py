@@ -13,6 +13,7 @@ import torch
 from . import _lib, _torch_ops
 
 I8, BF16, F32, FP8 = 0, 1, 2, 3        # FP8: e4m3 bytes holding q - z of <= 4-bit layers exactly (same MFMA rate as int8)
+BF16_FP8 = 4                           # gemm_score only: bf16 rows x fp8 candidate columns, converted in registers (gemm_mixed_ok)
 # bench.py sets this to a list to time the scoring GEMM launches: (dtype, M, N, Kp, C, G, A.data_ptr(), start, end) with
 # the two events recorded on the launch stream immediately around the adalog_gemm_score kernel (not the finish kernel)
 GEMM_EVENTS = None
@@ -294,7 +295,8 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     n_cols = N * ref_div
     c_grid = 1 if ref_div > 1 else C
     assert B.shape[-1] == Kp and A.shape[-2] == M and B.shape[-2] == n_cols
-    assert A.dtype == _TORCH_DT[dtype] and B.dtype == _TORCH_DT[dtype] and A.is_contiguous() and B.is_contiguous()
+    assert A.dtype == _TORCH_DT[BF16 if dtype == BF16_FP8 else dtype] and B.dtype == _TORCH_DT[FP8 if dtype == BF16_FP8 else dtype]
+    assert A.is_contiguous() and B.is_contiguous()
     sAc = 0 if A.shape[0] == 1 else A.stride(0)
     sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
     sBc = 0 if B.shape[0] == 1 else B.stride(0)
@@ -345,6 +347,12 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
     _lib.check(rc, "adalog_gemm_score")
     pend = PendingScores(partial, MT, n_last, Npad, C, G, gmod, keep_h, keep_n, mode, norm, N)
     return pend if defer else pend.finish()
+
+
+def gemm_mixed_ok(M: int, N: int, G: int, gmod: int, ref_div: int, k_valid: int) -> bool:
+    """True when gemm_score(BF16_FP8, ...) takes this shape (C = 1, candidates innermost, transposed reference, column axis
+    summed): A bf16 [.., M, 256], B fp8 [.., N * ref_div, 256]."""
+    return bool(_lib.load().adalog_gemm_mixed_ok(int(M), int(N) * int(ref_div), int(G), int(gmod), int(ref_div), int(k_valid)))
 
 
 def gemm_win_ok(dtype: int, M: int, N: int, G: int, gmod: int, ref_div: int, k_valid: int) -> bool:

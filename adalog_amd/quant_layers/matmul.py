@@ -13,11 +13,12 @@ import torch
 import torch.nn as nn
 
 from .. import backend, search
-from ..ops import BF16, FP8, I8, Strided, pad_k  # noqa: F401
+from ..ops import BF16, BF16_FP8, FP8, I8, Strided, pad_k  # noqa: F401
 from ..quantizers.logarithm import AdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
 MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
+MIXED_B_SEARCH = os.environ.get('ADALOG_MIXED_B', '1') != '0'     # softmax.v weight search: fp8 candidates against the bf16 probabilities
 
 
 class MinMaxQuantMatMul(nn.Module):
@@ -192,15 +193,19 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         src = self._a3(A) if which == "A" else self._bt3_packable(B)
         bits = self.A_quantizer.n_bits if which == "A" else self.B_quantizer.n_bits
         rows = S if which == "A" else Sp
+        mixed = dt == BF16_FP8                     # fixed operand bf16 [.., 256], candidates fp8 [.., 256] (ops.gemm_mixed_ok)
+        cdt = FP8 if mixed else dt                 # what the candidates are packed as
         esz = 2 if dt == BF16 else 1
-        al = self._kalign(dt)
-        chunk = self._cand_chunk(G * rows * pad_k(K, dt, al) * esz)
+        al = 256 if mixed else self._kalign(dt)
+        chunk = self._cand_chunk(G * rows * pad_k(K, cdt, al) * esz)
+        if mixed and chunk < P:
+            raise RuntimeError("the mixed softmax.v search scores all candidates in one launch")
         pg = 1 if H > 1 else 0
         out = []
         for s0 in range(0, P, chunk):
             e = min(P, s0 + chunk)
             sc, zc = scale[s0:e].contiguous(), zp[s0:e].contiguous()
-            cand = be.pack_uniform(src, sc, zc, e - s0, H, H, pg, 0, bits, dt, c_inner=True, k_align=al)
+            cand = be.pack_uniform(src, sc, zc, e - s0, H, H, pg, 0, bits, cdt, c_inner=True, k_align=al)
             sb = Strided(sc, c=H, g=pg)
             if which == "A":
                 sa = Strided(self.B_quantizer.scale.data.view(-1), g=pg)
@@ -340,6 +345,17 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
                                      ref_div=e - s0, order=2, ref_transposed=True))
         return q_all, (out[0] if len(out) == 1 else torch.cat(out, 0))
 
+    def _mixed_B_search(self):
+        """bf16 rows x fp8 candidate columns for the B (v) search: needs exact fp8 candidates (<= 4 bit), the kernel's shape family
+        (ops.gemm_mixed_ok) and all candidates in one launch."""
+        if not MIXED_B_SEARCH or self.B_quantizer.n_bits > 4 or self.eq_n not in (64, 128, 256):
+            return False
+        be = backend.get()
+        G, S, K, Sp = self._dims()
+        if not hasattr(be, "gemm_mixed_ok") or self._cand_chunk(G * Sp * 256) < self.eq_n:
+            return False
+        return bool(be.gemm_mixed_ok(S, Sp, G, self._heads(), self.eq_n, K))
+
     def _search_best_A_log_base(self):
         """matmul.py:321-358: score the 128 bases, commit the best."""
         be = backend.get()
@@ -367,11 +383,15 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
             self._search_best_A_log_base()
             if search.round_is_redundant(self, "B", self.A_quantizer):
                 continue                           # same log base as last round: the B search would repeat itself
-            # B search against q_A(A): eval-form AdaLog of A (clamped, scale 1) is the fixed bf16 operand
+            # B search against q_A(A): eval-form AdaLog of A (clamped, scale 1) is the fixed bf16 operand.  When the shape allows
+            # (197 keys, <= 4-bit v) the 128 x candidates are packed as fp8 and converted to bf16 inside the kernel: the operand
+            # a launch streams is 256 instead of 448 bytes per column
+            mixed = self._mixed_B_search()
             qv = search.const_tensor([float(self._q_host)], dev)
-            ap = self._pack_A_adalog(self._a3(A), qv, self.A_quantizer.scale.data.view(-1), 1, True, k_align=self._kalign())
-            self._fpcs("B", steps=self.steps, fixed=ap, dt=BF16, fixed_sa=Strided(self.A_quantizer.scale.data.view(-1)),
-                       sa_mul=self._ts32(), checked=True)
+            ap = self._pack_A_adalog(self._a3(A), qv, self.A_quantizer.scale.data.view(-1), 1, True,
+                                     k_align=512 if mixed else self._kalign())
+            self._fpcs("B", steps=self.steps, fixed=ap, dt=BF16_FP8 if mixed else BF16,
+                       fixed_sa=Strided(self.A_quantizer.scale.data.view(-1)), sa_mul=self._ts32(), checked=True)
         self.calibrated = True
         search.begin_rounds(self)
         search.forget_grids()

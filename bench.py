@@ -31,8 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TOPS = {0: 5000.0, 1: 2500.0, 2: 157.3, 3: 5000.0}      # dense MFMA peaks, TFLOP/s (MI355X_MICROARCH.md): i8 = fp8 = 2x bf16
-DT_NAME = {0: "i8", 1: "bf16", 2: "f32", 3: "fp8"}
+PEAK_TOPS = {0: 5000.0, 1: 2500.0, 2: 157.3, 3: 5000.0, 4: 2500.0}      # dense MFMA peaks, TFLOP/s (MI355X_MICROARCH.md): i8 = fp8 = 2x bf16; 4 = bf16 MFMA fed from fp8 storage
+DT_NAME = {0: "i8", 1: "bf16", 2: "f32", 3: "fp8", 4: "bf16xfp8"}
 
 
 def load_cfg(bits):

@@ -97,6 +97,11 @@ int adalog_pack_split3_bf16(const float* x, int64_t G, int64_t R, int64_t K, int
  *   can be non-zero (the pack kernels zero-fill [K, Kp)); 0 means Kp.  The streaming kernel skips whole 64-byte
  *   K-steps of padding (q.k^T with head_dim 64: half of the padded row).
  * partial must hold adalog_gemm_score_layout(M, N, C, G, ...) floats. */
+/* adalog_gemm_mixed_ok: 1 when adalog_gemm_score takes dtype 4 -- A: bf16 rows [..][256], B: fp8 e4m3 candidate columns
+ *   [..][256] (q - z of a <= 4-bit quantiser: exact) -- for this shape: the softmax.v weight search of a 197-token ViT
+ *   (reference matmul.py:173-201 with the AdaLog-quantised attention probabilities as the fixed operand).  The kernel converts
+ *   the fp8 fragments to bf16 in registers (exact), so the streamed candidate operand is 256 instead of 448 bytes per column. */
+int adalog_gemm_mixed_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid);
 int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc, int64_t sBg, int M,
                       int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int64_t ref_cs,
                       int ref_div, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,

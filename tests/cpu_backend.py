@@ -13,6 +13,7 @@ import torch
 from oracle import adalog_oracle as O
 
 I8, BF16, F32, FP8 = 0, 1, 2, 3
+BF16_FP8 = 4                                   # gemm_score only: bf16 rows x fp8 candidate columns
 _ESZ = {I8: 1, BF16: 2, F32: 4, FP8: 1}
 _TORCH_DT = {I8: torch.int8, BF16: torch.bfloat16, F32: torch.float32, FP8: torch.float8_e4m3fn}
 
@@ -476,6 +477,11 @@ def round_loss_multi(alphas, b, weight):
         total = total + round_loss(al, bb, galpha=g_, gscale=weight)
         grads.append(g_)
     return (total * weight).view(1), grads
+
+
+def gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid):
+    """spec of ops.gemm_mixed_ok (csrc/gemm_score.hip grpk8_ok): the 197-token softmax.v weight search"""
+    return 192 < k_valid <= 256 and 128 < M <= 224 and G >= 8 and gmod <= 16 and ref_div in (64, 128, 256)
 
 
 def gemm_win_ok(dtype, M, N, G, gmod, ref_div, k_valid):

@@ -248,6 +248,41 @@ def test_pack_raw(ops):
     assert torch.equal(ops.pack_raw(x3.to(DEV)).cpu(), CB.pack_raw(x3))
 
 
+@pytest.mark.parametrize("heads,bits", [(6, 4), (3, 3)])
+def test_gemm_mixed_bf16_rows_fp8_columns(ops, heads, bits):
+    """matmul.py:173-201 with the AdaLog-quantised probabilities as the fixed operand: candidates packed as fp8 and converted to
+    bf16 in the kernel (k_gemm_grpk8) must score like the all-bf16 launch (same exact operand values, other summation order)
+    and like the CPU spec."""
+    gen = g(21)
+    S, K, Sp, P, imgs = 197, 197, 64, 128, 4
+    G = imgs * heads
+    assert ops.gemm_mixed_ok(S, Sp, G, heads, P, K)
+    a = torch.softmax(torch.randn(G, S, K, generator=gen) * 2, -1)
+    a = (a * 64).round().clamp(0, 255) / 64                                     # bf16-exact stand-in for the AdaLog values
+    a[0, 5] = 0
+    v = torch.randn(G, Sp, K, generator=gen)                                   # B^T: [G, dims, keys]
+    sc = torch.rand(P, heads, generator=gen) * 0.2 + 0.05
+    zp = torch.randint(2 ** (bits - 1) - 2, 2 ** (bits - 1) + 2, (P, heads), generator=gen).float()
+    ref = torch.randn(G, Sp, S, generator=gen)                                 # transposed reference [G, S', S]
+    one = torch.ones(1)
+    res = {}
+    for name in ("mixed", "bf16", "cpu"):
+        mod = CB if name == "cpu" else ops
+        dev = "cpu" if name == "cpu" else DEV
+        dt = mod.BF16_FP8 if name == "mixed" else mod.BF16
+        Kp = 256 if name == "mixed" else mod.pad_k(K, mod.BF16, 64)
+        ap = torch.zeros(1, G, S, Kp, dtype=torch.bfloat16, device=dev)
+        ap[0, :, :, :K] = a.to(torch.bfloat16).to(dev)
+        ap.k_valid = K
+        cand = mod.pack_uniform(v.to(dev), sc.to(dev), zp.to(dev), P, heads, heads, 1, 0, bits, mod.FP8 if name == "mixed" else mod.BF16,
+                                c_inner=True, k_align=256 if name == "mixed" else 64)
+        res[name] = mod.gemm_score(dt, ap, cand, S, Sp, P, G, heads, ref.to(dev), mod.Strided(one.to(dev)),
+                                   mod.Strided(sc.to(dev), c=heads, g=1), None, True, False, 1.0 / (S * Sp), ref_div=P, order=2,
+                                   ref_transposed=True).cpu()
+    assert res["mixed"].shape == (P, heads)
+    assert rel_err(res["mixed"], res["bf16"]) <= 2e-6 and rel_err(res["mixed"], res["cpu"]) <= 2e-6
+
+
 def test_pack_split3_is_exact_and_scores_like_fp32(ops):
     """conv.py:226-255 with the unquantised input as three bf16 terms: hi + mid + lo == x bit for bit, and the scores of the
     bf16 GEMM over [hi | mid | lo] x [W | W | W] equal the fp32-operand GEMM's (same fp32 products, other summation order)."""
