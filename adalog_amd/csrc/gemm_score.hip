@@ -186,6 +186,15 @@ static bool grpk8_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid
            (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
 }
 
+// ... mixed operands, window family: K <= 64 elements (one 64-byte fp8 K-step against 128-byte bf16 rows), at most 64 rows.
+static bool winb_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid, const float* bias, const float* row_scale, int64_t sb_n,
+                    int64_t ref_cs, int wgs) {
+    static const int use_win = getenv("ADALOG_GEMM_WIN") ? atoi(getenv("ADALOG_GEMM_WIN")) : 1;
+    const int n_eff = ref_div > 0 ? N / ref_div : 0;
+    return use_win && k_valid >= 1 && k_valid <= 64 && M >= 4 && M <= 64 && G >= 256 && gmod <= 32 && !bias && !row_scale && sb_n == 0 &&
+           (ref_div == 64 || ref_div == 128 || ref_div == 256) && N % ref_div == 0 && n_eff <= 64 && wgs * 4 >= gmod && ref_cs >= M;
+}
+
 // ... and of the window kernel: int8 or fp8, one K-step, at most 64 rows, hundreds of groups or more, at least as many waves as
 // heads per image (every participating wave owns one head).
 static bool win_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
@@ -224,9 +233,12 @@ extern "C" int adalog_gemm_win_ok(int dtype, int M, int N, int G, int gmod, int 
 // this shape: the softmax.v weight search of a 197-token ViT (M = 197 attention rows, K = 197 keys) with <= 4-bit candidates.
 // C = 1, reduce_cols = 1, transposed reference.
 extern "C" int adalog_gemm_mixed_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid) {
-    if (ref_div < 1 || N % ref_div != 0) return 0;
-    const Layout L = layout_of(M, N, 1, G, gmod, ref_div, 1, true, k_valid * 2, 256 * 2, true, 1);
-    return (L.stream && L.acc && grpk8_ok(M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M)) ? 1 : 0;
+    if (ref_div < 1 || N % ref_div != 0 || k_valid < 1) return 0;
+    const int64_t Kp = k_valid <= 64 ? 64 : 256;                        // the two shape families: windows / 197-token groups
+    const Layout L = layout_of(M, N, 1, G, gmod, ref_div, 1, true, k_valid * 2, Kp * 2, true, 1);
+    if (!(L.stream && L.acc)) return 0;
+    if (k_valid <= 64) return winb_ok(M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M, L.wgs) ? 1 : 0;
+    return grpk8_ok(M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M) ? 1 : 0;
 }
 
 extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
@@ -241,10 +253,14 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
     if (dtype == 4) {
         // mixed operands: one kernel, one shape family (adalog_gemm_mixed_ok)
-        ADALOG_ARG_CHECK(Kp == 256 && k_valid > 0 && C == 1 && partial && ref && !out && ldr == 1 && reduce_cols == 1 &&
-                         adalog_gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid) && grpk8_ok(M, N, G, gmod, ref_div, k_valid, bias, row_scale, sb_n, ref_cs),
-                         "gemm_score: bf16 x fp8 operands are taken for the shapes adalog_gemm_mixed_ok accepts only (Kp = 256, C = 1, transposed reference)");
+        const bool window = k_valid > 0 && k_valid <= 64;
+        ADALOG_ARG_CHECK(Kp == (window ? 64 : 256) && k_valid > 0 && C == 1 && partial && ref && !out && ldr == 1 && reduce_cols == 1 &&
+                         adalog_gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid),
+                         "gemm_score: bf16 x fp8 operands are taken for the shapes adalog_gemm_mixed_ok accepts only (Kp = 64 or 256, C = 1, transposed reference)");
         const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, true, k_valid * 2, Kp * 2, true, 1);
+        ADALOG_ARG_CHECK(window ? winb_ok(M, N, G, gmod, ref_div, k_valid, bias, row_scale, sb_n, ref_cs, L.wgs)
+                                : grpk8_ok(M, N, G, gmod, ref_div, k_valid, bias, row_scale, sb_n, ref_cs),
+                         "gemm_score: bf16 x fp8 operands: epilogue options not supported for this shape");
         GemmArgs p{};
         p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
         p.sAc = sAc * 2; p.sAg = sAg * 2; p.sBc = sBc; p.sBg = sBg;
@@ -255,12 +271,32 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad; p.order = order; p.reduce_cols = 0; p.partial = partial;
         ADALOG_ARG_CHECK(partial_elems >= L.elems && ((uintptr_t)partial & 7) == 0, "gemm_score: accumulator buffer too small or misaligned");
         p.wg_acc = (double*)partial;
+        hipStream_t st = (hipStream_t)stream;
+        if (window) {
+            const int n_eff = N / ref_div;
+            const size_t ref_lds = (size_t)4 * n_eff * 64 * 4, acc_lds = (size_t)gmod * 256 * 8;
+            const size_t shm_w = ref_lds > acc_lds ? ref_lds : acc_lds;
+#define LAUNCH_WINB(NJV)                                                                                          \
+            do {                                                                                                  \
+                static bool attr_set = false;                                                                     \
+                if (!attr_set) {                                                                                  \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_winb<NJV>),                   \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);             \
+                    attr_set = true;                                                                              \
+                }                                                                                                 \
+                adalog_note_kernel("k_gemm_winb<bf16xfp8>");                                                      \
+                hipLaunchKernelGGL((k_gemm_winb<NJV>), dim3((unsigned)L.wgs), dim3(256), shm_w, st, p);           \
+            } while (0)
+            if (ref_div == 64) LAUNCH_WINB(2); else if (ref_div == 128) LAUNCH_WINB(4); else LAUNCH_WINB(8);
+#undef LAUNCH_WINB
+            ADALOG_LAUNCH_CHECK("adalog_gemm_score (bf16 x fp8, windows)");
+            return 0;
+        }
         const int NB = N / 32;
         const int nch0 = cdiv((int64_t)3 * L.wgs, G);
         const int CB = cdiv(cdiv(NB, nch0 < 1 ? 1 : nch0), 8) * 8;
         p.slab_R = CB; p.slab_U = cdiv(NB, CB);
         const size_t shm = (size_t)3 * 4 * 4 * 32 * BK3 + (size_t)7 * ref_div * 4 + (size_t)gmod * 256 * 8;   // 3 stages of 4 K-steps x 4 blocks
-        hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_GRPK8(NJV)                                                                                         \
         do {                                                                                                      \
             static bool attr_set = false;                                                                         \

@@ -351,7 +351,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
 
 def gemm_mixed_ok(M: int, N: int, G: int, gmod: int, ref_div: int, k_valid: int) -> bool:
     """True when gemm_score(BF16_FP8, ...) takes this shape (C = 1, candidates innermost, transposed reference, column axis
-    summed): A bf16 [.., M, 256], B fp8 [.., N * ref_div, 256]."""
+    summed): A bf16 [.., M, Kp], B fp8 [.., N * ref_div, Kp] with Kp = 64 (K <= 64: windows) or 256 (K = 193..256)."""
     return bool(_lib.load().adalog_gemm_mixed_ok(int(M), int(N) * int(ref_div), int(G), int(gmod), int(ref_div), int(k_valid)))
 
 

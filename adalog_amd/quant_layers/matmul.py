@@ -196,7 +196,7 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         mixed = dt == BF16_FP8                     # fixed operand bf16 [.., 256], candidates fp8 [.., 256] (ops.gemm_mixed_ok)
         cdt = FP8 if mixed else dt                 # what the candidates are packed as
         esz = 2 if dt == BF16 else 1
-        al = 256 if mixed else self._kalign(dt)
+        al = (64 if K <= 64 else 256) if mixed else self._kalign(dt)      # fp8 rows of the two mixed shape families
         chunk = self._cand_chunk(G * rows * pad_k(K, cdt, al) * esz)
         if mixed and chunk < P:
             raise RuntimeError("the mixed softmax.v search scores all candidates in one launch")
@@ -346,13 +346,14 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         return q_all, (out[0] if len(out) == 1 else torch.cat(out, 0))
 
     def _mixed_B_search(self):
-        """bf16 rows x fp8 candidate columns for the B (v) search: needs exact fp8 candidates (<= 4 bit), the kernel's shape family
-        (ops.gemm_mixed_ok) and all candidates in one launch."""
+        """bf16 rows x fp8 candidate columns for the B (v) search: needs exact fp8 candidates (<= 4 bit), one of the kernels' shape
+        families (ops.gemm_mixed_ok: 197-token groups, rows of 256 elements; windows of <= 64 keys, rows of 64) and all candidates in
+        one launch."""
         if not MIXED_B_SEARCH or self.B_quantizer.n_bits > 4 or self.eq_n not in (64, 128, 256):
             return False
         be = backend.get()
         G, S, K, Sp = self._dims()
-        if not hasattr(be, "gemm_mixed_ok") or self._cand_chunk(G * Sp * 256) < self.eq_n:
+        if not hasattr(be, "gemm_mixed_ok") or self._cand_chunk(G * Sp * (64 if K <= 64 else 256)) < self.eq_n:
             return False
         return bool(be.gemm_mixed_ok(S, Sp, G, self._heads(), self.eq_n, K))
 
@@ -388,8 +389,9 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
             # a launch streams is 256 instead of 448 bytes per column
             mixed = self._mixed_B_search()
             qv = search.const_tensor([float(self._q_host)], dev)
+            K = A.shape[-1]
             ap = self._pack_A_adalog(self._a3(A), qv, self.A_quantizer.scale.data.view(-1), 1, True,
-                                     k_align=512 if mixed else self._kalign())
+                                     k_align=(128 if K <= 64 else 512) if mixed else self._kalign())
             self._fpcs("B", steps=self.steps, fixed=ap, dt=BF16_FP8 if mixed else BF16,
                        fixed_sa=Strided(self.A_quantizer.scale.data.view(-1)), sa_mul=self._ts32(), checked=True)
         self.calibrated = True

@@ -480,8 +480,13 @@ def round_loss_multi(alphas, b, weight):
 
 
 def gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid):
-    """spec of ops.gemm_mixed_ok (csrc/gemm_score.hip grpk8_ok): the 197-token softmax.v weight search"""
-    return 192 < k_valid <= 256 and 128 < M <= 224 and G >= 8 and gmod <= 16 and ref_div in (64, 128, 256)
+    """spec of ops.gemm_mixed_ok (csrc/gemm_score.hip grpk8_ok / winb_ok): the softmax.v weight search of a 197-token ViT, or of
+    windows of <= 64 keys"""
+    if ref_div not in (64, 128, 256):
+        return False
+    if k_valid <= 64:
+        return 4 <= M <= 64 and G >= 256 and gmod <= 32 and N <= 64
+    return 192 < k_valid <= 256 and 128 < M <= 224 and G >= 8 and gmod <= 16
 
 
 def gemm_win_ok(dtype, M, N, G, gmod, ref_div, k_valid):

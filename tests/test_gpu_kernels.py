@@ -248,14 +248,16 @@ def test_pack_raw(ops):
     assert torch.equal(ops.pack_raw(x3.to(DEV)).cpu(), CB.pack_raw(x3))
 
 
-@pytest.mark.parametrize("heads,bits", [(6, 4), (3, 3)])
-def test_gemm_mixed_bf16_rows_fp8_columns(ops, heads, bits):
+@pytest.mark.parametrize("heads,bits,S,K,Sp,imgs", [(6, 4, 197, 197, 64, 4), (3, 3, 197, 197, 64, 4), (4, 4, 49, 49, 32, 128),
+                                                      (32, 3, 49, 49, 32, 16), (8, 4, 49, 49, 32, 40)])
+def test_gemm_mixed_bf16_rows_fp8_columns(ops, heads, bits, S, K, Sp, imgs):
     """matmul.py:173-201 with the AdaLog-quantised probabilities as the fixed operand: candidates packed as fp8 and converted to
     bf16 in the kernel (k_gemm_grpk8) must score like the all-bf16 launch (same exact operand values, other summation order)
     and like the CPU spec."""
     gen = g(21)
-    S, K, Sp, P, imgs = 197, 197, 64, 128, 4
+    P = 128
     G = imgs * heads
+    KP = 64 if K <= 64 else 256
     assert ops.gemm_mixed_ok(S, Sp, G, heads, P, K)
     a = torch.softmax(torch.randn(G, S, K, generator=gen) * 2, -1)
     a = (a * 64).round().clamp(0, 255) / 64                                     # bf16-exact stand-in for the AdaLog values
@@ -270,12 +272,12 @@ def test_gemm_mixed_bf16_rows_fp8_columns(ops, heads, bits):
         mod = CB if name == "cpu" else ops
         dev = "cpu" if name == "cpu" else DEV
         dt = mod.BF16_FP8 if name == "mixed" else mod.BF16
-        Kp = 256 if name == "mixed" else mod.pad_k(K, mod.BF16, 64)
+        Kp = KP if name == "mixed" else mod.pad_k(K, mod.BF16, 64)
         ap = torch.zeros(1, G, S, Kp, dtype=torch.bfloat16, device=dev)
         ap[0, :, :, :K] = a.to(torch.bfloat16).to(dev)
         ap.k_valid = K
         cand = mod.pack_uniform(v.to(dev), sc.to(dev), zp.to(dev), P, heads, heads, 1, 0, bits, mod.FP8 if name == "mixed" else mod.BF16,
-                                c_inner=True, k_align=256 if name == "mixed" else 64)
+                                c_inner=True, k_align=KP if name == "mixed" else 64)
         res[name] = mod.gemm_score(dt, ap, cand, S, Sp, P, G, heads, ref.to(dev), mod.Strided(one.to(dev)),
                                    mod.Strided(sc.to(dev), c=heads, g=1), None, True, False, 1.0 / (S * Sp), ref_div=P, order=2,
                                    ref_transposed=True).cpu()
