@@ -234,7 +234,15 @@ extern "C" int adalog_gemm_win_ok(int dtype, int M, int N, int G, int gmod, int 
 // C = 1, reduce_cols = 1, transposed reference.
 extern "C" int adalog_gemm_mixed_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid) {
     if (ref_div < 1 || N % ref_div != 0 || k_valid < 1) return 0;
-    const int64_t Kp = k_valid <= 64 ? 64 : 256;                        // the two shape families: windows / 197-token groups
+    if (k_valid > 256) {
+        // third family: the wide streaming kernel (one group or many), rows of any multiple of 64 elements: taken when the all-bf16
+        // launch of this shape would run on the wide form (K >= 256 elements, M >= 192)
+        static const int use_mx = getenv("ADALOG_GEMM_STREAM_MX") ? atoi(getenv("ADALOG_GEMM_STREAM_MX")) : 1;
+        const int64_t Kp = (k_valid + 63) / 64 * 64;
+        const Layout L = layout_of(M, N, 1, G, gmod, ref_div, 0, true, k_valid * 2, Kp * 2, true, 1);
+        return (use_mx && L.stream && L.wide && !L.slab) ? 1 : 0;
+    }
+    const int64_t Kp = k_valid <= 64 ? 64 : 256;                        // windows / 197-token groups
     const Layout L = layout_of(M, N, 1, G, gmod, ref_div, 1, true, k_valid * 2, Kp * 2, true, 1);
     if (!(L.stream && L.acc)) return 0;
     if (k_valid <= 64) return winb_ok(M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M, L.wgs) ? 1 : 0;
@@ -251,6 +259,53 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 4, "gemm_score: dtype must be 0 (i8), 1 (bf16), 2 (f32), 3 (fp8 e4m3) or 4 (bf16 rows x fp8 columns)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
+    if (dtype == 4 && k_valid > 256) {
+        // mixed operands, streaming family: the wide persistent kernel with two 64-byte planes of bf16 rows per fp8 K-step
+        ADALOG_ARG_CHECK(Kp % 64 == 0 && k_valid <= Kp && C == 1 && partial && ref && !out && ldr == 1 && !row_scale &&
+                         adalog_gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid),
+                         "gemm_score: bf16 x fp8 operands, streaming family: Kp a multiple of 64, C = 1, transposed reference, a shape adalog_gemm_mixed_ok accepts");
+        ADALOG_ARG_CHECK(order >= 0 && order <= 2, "gemm_score: order must be 0, 1 or 2");
+        const Layout L = layout_of(M, N, C, G, gmod, ref_div, reduce_cols, true, k_valid * 2, Kp * 2, true, 1);
+        ADALOG_ARG_CHECK(L.stream && L.wide && !L.slab, "gemm_score: bf16 x fp8 operands: not a wide streaming shape");
+        GemmArgs p{};
+        p.A = (const uint8_t*)A; p.B = (const uint8_t*)B;
+        p.sAc = sAc * 2; p.sAg = sAg * 2; p.sBc = sBc; p.sBg = sBg;
+        p.M = M; p.N = N; p.Kb = Kp; p.KbA = Kp * 2; p.Kvb = k_valid; p.C = C; p.G = G; p.gmod = gmod;
+        p.ref = ref; p.ldr = ldr; p.sRg = sRg; p.ref_cs = ref_cs; p.ref_div = ref_div;
+        ADALOG_ARG_CHECK(((int64_t)(M - 1) * ldr + (int64_t)(L.n_eff - 1) * (ref_cs > 0 ? ref_cs : 1) < ((int64_t)1 << 31)),
+                         "gemm_score: reference group exceeds 32-bit addressing");
+        p.sa = sa; p.sa_c = sa_c; p.sa_g = sa_g; p.sa_mul = sa_mul;
+        p.sb = sb; p.sb_c = sb_c; p.sb_g = sb_g; p.sb_n = sb_n;
+        p.bias = bias; p.bi_c = bi_c; p.bi_g = bi_g; p.bi_n = bi_n;
+        p.row_bias = row_bias;
+        p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad;
+        p.order = order; p.reduce_cols = 0; p.partial = partial;
+        ADALOG_ARG_CHECK(partial_elems >= L.elems, "gemm_score: partial buffer too small");
+        if (L.acc) { ADALOG_ARG_CHECK(((uintptr_t)partial & 7) == 0, "gemm_score: accumulator buffer must be 8-byte aligned"); p.wg_acc = (double*)partial; }
+        {
+            static const int64_t grp_bytes = getenv("ADALOG_GEMM_GM_BYTES") ? atoll(getenv("ADALOG_GEMM_GM_BYTES")) : ((int64_t)8 << 20);
+            int64_t gm = grp_bytes / ((int64_t)64 * L.tm * p.KbA);
+            if (const char* e = getenv("ADALOG_GEMM_GM")) gm = atoi(e);
+            p.gm = (int)(gm < 1 ? 1 : gm > L.MT ? L.MT : gm);
+        }
+        hipStream_t st = (hipStream_t)stream;
+        const size_t shm = (size_t)3 * (2 * 64 * L.tm + BN2) * BK3;
+#define LAUNCH_STREAM_MX(RIV)                                                                                     \
+        do {                                                                                                      \
+            static bool attr_set = false;                                                                         \
+            if (!attr_set) {                                                                                      \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<1, RIV, 8, 3, true>),      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                \
+                attr_set = true;                                                                                  \
+            }                                                                                                     \
+            adalog_note_kernel("k_gemm_stream<bf16xfp8>");                                                        \
+            hipLaunchKernelGGL((k_gemm_stream<1, RIV, 8, 3, true>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
+        } while (0)
+        if (L.wide == 4) LAUNCH_STREAM_MX(4); else LAUNCH_STREAM_MX(3);
+#undef LAUNCH_STREAM_MX
+        ADALOG_LAUNCH_CHECK("adalog_gemm_score (bf16 x fp8, streaming)");
+        return 0;
+    }
     if (dtype == 4) {
         // mixed operands: one kernel, one shape family (adalog_gemm_mixed_ok)
         const bool window = k_valid > 0 && k_valid <= 64;

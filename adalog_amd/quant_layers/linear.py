@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import backend, search
-from ..ops import BF16, FP8, I8, Strided, pad_k  # noqa: F401  (dtype codes / epilogue parameter helper; pure metadata)
+from ..ops import BF16, BF16_FP8, FP8, I8, Strided, pad_k  # noqa: F401  (dtype codes / epilogue parameter helper; pure metadata)
 from ..quantizers.logarithm import ShiftAdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
@@ -42,6 +42,7 @@ FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
 GEN_ACT_SEARCH = os.environ.get('ADALOG_GEN_ACT', '1') != '0'
 SORTED_SELF_SEARCH = os.environ.get('ADALOG_SORTED_SELF', '1') != '0'
 RUN_DEAD_W_SELF = os.environ.get('ADALOG_DEAD_W_SELF', '0') == '1'
+MIXED_W_SEARCH = os.environ.get('ADALOG_MIXED_W', '1') != '0'     # bf16 activations x fp8 weight candidates (wide streaming kernel)
 
 
 class MinMaxQuantLinear(nn.Linear):
@@ -222,22 +223,27 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         wq = self.w_quantizer
         out = []
         chunk = self._cand_chunk(self.out_features, pad_k(self.in_features, dt) * (2 if dt == BF16 else 1))
+        # bf16 activations (AdaLog values) against <= 4-bit weight candidates: the candidates go out as fp8 (exact) and the wide
+        # streaming kernel converts them in registers -- 3/4 of the bytes through the L2 -> LDS path that bounds it
+        mixed = (dt == BF16 and MIXED_W_SEARCH and wq.n_bits <= 4 and chunk >= P and xp.shape[-1] % 64 == 0
+                 and hasattr(be, "gemm_mixed_ok") and be.gemm_mixed_ok(M, self.out_features, 1, 1, P, self.in_features))
+        cdt, gdt, kal = (FP8, BF16_FP8, 64) if mixed else (dt, dt, 128)
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()
             bias = None if self.bias is None else Strided(self.bias.data, n=1)
             # columns = (out channel, candidate): the e-s candidates of a channel share one reference column
             if shift is None:
-                wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1, wq.n_bits, dt,
-                                     c_inner=True)
+                wp = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1, wq.n_bits, cdt,
+                                     c_inner=True, k_align=kal)
             else:
                 # post-GELU operand is y*s - shift: the -shift term is a per-(candidate, row) constant
                 #   -shift * s_w[p,o] * sum_i (q_w - z_w)  folded into the bias (cf. reparam_bias, linear.py:999-1006)
                 wp, rowsum = be.pack_uniform(self._w2().unsqueeze(0), sc, zc, e - s, self.out_features, 1, 0, 1,
-                                             wq.n_bits, dt, want_rowsum=True, c_inner=True)
+                                             wq.n_bits, cdt, want_rowsum=True, c_inner=True, k_align=kal)
                 fold = be.shift_fold(rowsum.view(e - s, -1), sc, shift, None if self.bias is None else self.bias.data)
                 bias = Strided(fold, c=self.out_features, n=1)
-            out.append(be.gemm_score(dt, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2_t(), sa,
+            out.append(be.gemm_score(gdt, xp, wp, M, self.out_features, e - s, 1, 1, self._ref2_t(), sa,
                                      Strided(sc, c=self.out_features, n=1), bias, False, True,
                                      1.0 / self._tokens_per_image(), sa_mul=sa_mul, ref_div=e - s, order=2,
                                      ref_transposed=True, defer=defer and chunk >= P))

@@ -484,6 +484,8 @@ def gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid):
     windows of <= 64 keys"""
     if ref_div not in (64, 128, 256):
         return False
+    if k_valid > 256:                                  # the wide streaming family (csrc pick_wide: K >= 256 elements, M >= 192)
+        return M >= 192
     if k_valid <= 64:
         return 4 <= M <= 64 and G >= 256 and gmod <= 32 and N <= 64
     return 192 < k_valid <= 256 and 128 < M <= 224 and G >= 8 and gmod <= 16

@@ -285,6 +285,40 @@ def test_gemm_mixed_bf16_rows_fp8_columns(ops, heads, bits, S, K, Sp, imgs):
     assert rel_err(res["mixed"], res["bf16"]) <= 2e-6 and rel_err(res["mixed"], res["cpu"]) <= 2e-6
 
 
+@pytest.mark.parametrize("M,K,O_,bits,with_bias", [(6304, 1536, 384, 4, True), (1000, 512, 96, 3, False), (777, 320, 40, 4, True)])
+def test_gemm_mixed_streaming_weight_search(ops, M, K, O_, bits, with_bias):
+    """linear.py:355-392 for the post-GELU layer: bf16 activation operand (AdaLog values) against fp8 weight candidates on the
+    wide streaming kernel (k_gemm_stream<..., MX>) must score like the all-bf16 launch and like the CPU spec; ragged M, K not
+    a multiple of 128, column bias per (candidate, channel)."""
+    gen = g(23)
+    P = 128
+    assert ops.gemm_mixed_ok(M, O_, 1, 1, P, K)
+    x = (torch.rand(1, M, K, generator=gen) * 32).round() / 32 * torch.pow(2.0, -torch.randint(0, 6, (1, M, K), generator=gen).float())
+    W = torch.randn(1, O_, K, generator=gen) * 0.1
+    sc = torch.rand(P, O_, generator=gen) * 0.02 + 0.005
+    zp = torch.randint(2 ** (bits - 1) - 2, 2 ** (bits - 1) + 2, (P, O_), generator=gen).float()
+    ref = torch.randn(1, O_, M, generator=gen)
+    bias = torch.randn(P, O_, generator=gen) if with_bias else None
+    one = torch.ones(1)
+    res = {}
+    for name in ("mixed", "bf16", "cpu"):
+        mod = CB if name == "cpu" else ops
+        dev = "cpu" if name == "cpu" else DEV
+        Kp = mod.pad_k(K, mod.BF16, 128)
+        xp = torch.zeros(1, 1, M, Kp, dtype=torch.bfloat16, device=dev)
+        xp[0, 0, :, :K] = x[0].to(torch.bfloat16).to(dev)
+        assert torch.equal(xp[0, 0, :, :K].float().cpu(), x[0])
+        xp.k_valid = K
+        wp = mod.pack_uniform(W.to(dev), sc.to(dev), zp.to(dev), P, O_, 1, 0, 1, bits, mod.FP8 if name == "mixed" else mod.BF16,
+                              c_inner=True, k_align=64 if name == "mixed" else 128)
+        b = None if bias is None else mod.Strided(bias.to(dev), c=O_, n=1)
+        res[name] = mod.gemm_score(mod.BF16_FP8 if name == "mixed" else mod.BF16, xp, wp, M, O_, P, 1, 1, ref.to(dev),
+                                   mod.Strided(one.to(dev)), mod.Strided(sc.to(dev), c=O_, n=1), b, False, True, 1.0 / 197,
+                                   sa_mul=0.5, ref_div=P, order=2, ref_transposed=True).cpu()
+    assert res["mixed"].shape == (P, O_)
+    assert rel_err(res["mixed"], res["bf16"]) <= 2e-6 and rel_err(res["mixed"], res["cpu"]) <= 2e-6
+
+
 def test_pack_split3_is_exact_and_scores_like_fp32(ops):
     """conv.py:226-255 with the unquantised input as three bf16 terms: hi + mid + lo == x bit for bit, and the scores of the
     bf16 GEMM over [hi | mid | lo] x [W | W | W] equal the fp32-operand GEMM's (same fp32 products, other summation order)."""
