@@ -168,6 +168,11 @@ static bool grp_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_
            (int64_t)(N / ref_div) * ref_cs * 4 < ((int64_t)1 << 31);
 }
 
+static bool grpw_on() {
+    static const int v = getenv("ADALOG_GEMM_GRPW") ? atoi(getenv("ADALOG_GEMM_GRPW")) : 1;     // wave-private form of the q.k^T kernel
+    return v != 0;
+}
+
 // ... and of its several-K-steps form: bf16, exactly 7 K-steps (K = 193..224 elements: the 197 tokens of a 224 x 224 ViT).
 static bool grpk_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t kvalid_bytes, const float* bias,
                     const float* row_scale, int64_t sb_n, int64_t ref_cs) {
@@ -461,6 +466,25 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         if (dtype == 3) { if (ref_div == 64) LAUNCH_WIN(2, 3); else if (ref_div == 128) LAUNCH_WIN(4, 3); else LAUNCH_WIN(8, 3); }
         else { if (ref_div == 64) LAUNCH_WIN(2, 0); else if (ref_div == 128) LAUNCH_WIN(4, 0); else LAUNCH_WIN(8, 0); }
 #undef LAUNCH_WIN
+    } else if (L.stream && !out && L.acc && grp_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs) &&
+               grpw_on() && L.wgs * 4 >= gmod && ref_cs >= M) {
+        // wave-private group kernel (q.k^T searches): a wave per (group, chunk of reference columns), no barrier in the loop
+        const int n_eff = N / ref_div;
+        const int64_t waves = (int64_t)L.wgs * 4;
+        int nch = (int)cdiv(3 * waves, G);
+        nch = nch < 1 ? 1 : nch > n_eff ? n_eff : nch;
+        const int cbc = cdiv(n_eff, nch);
+        p.slab_R = cbc; p.slab_U = cdiv(n_eff, cbc);
+        const size_t ref_lds = (size_t)4 * 2 * 224 * 4, acc_lds = (size_t)gmod * 256 * 8;
+        const size_t shm = ref_lds > acc_lds ? ref_lds : acc_lds;
+#define LAUNCH_GRPW(NJV, DTV)                                                                                     \
+        do {                                                                                                      \
+            adalog_note_kernel(DTV == 3 ? "k_gemm_grpw<fp8>" : "k_gemm_grpw<i8>");                                 \
+            hipLaunchKernelGGL((k_gemm_grpw<NJV, DTV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);            \
+        } while (0)
+        if (dtype == 3) { if (ref_div == 64) LAUNCH_GRPW(2, 3); else if (ref_div == 128) LAUNCH_GRPW(4, 3); else LAUNCH_GRPW(8, 3); }
+        else { if (ref_div == 64) LAUNCH_GRPW(2, 0); else if (ref_div == 128) LAUNCH_GRPW(4, 0); else LAUNCH_GRPW(8, 0); }
+#undef LAUNCH_GRPW
     } else if (L.stream && !out && L.acc && grp_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs)) {
         // group kernel (q.k^T searches): same accumulator layout and workgroup count as the streaming kernel
         const int NB = N / 32;
