@@ -285,7 +285,8 @@ def test_gemm_mixed_bf16_rows_fp8_columns(ops, heads, bits, S, K, Sp, imgs):
     assert rel_err(res["mixed"], res["bf16"]) <= 2e-6 and rel_err(res["mixed"], res["cpu"]) <= 2e-6
 
 
-@pytest.mark.parametrize("M,K,O_,bits,with_bias", [(6304, 1536, 384, 4, True), (1000, 512, 96, 3, False), (777, 320, 40, 4, True)])
+@pytest.mark.parametrize("M,K,O_,bits,with_bias", [(6304, 1536, 384, 4, True), (1000, 512, 96, 3, False), (777, 320, 40, 4, True),
+                                                   (500, 1000, 37, 4, True), (193, 260, 3, 2, False)])
 def test_gemm_mixed_streaming_weight_search(ops, M, K, O_, bits, with_bias):
     """linear.py:355-392 for the post-GELU layer: bf16 activation operand (AdaLog values) against fp8 weight candidates on the
     wide streaming kernel (k_gemm_stream<..., MX>) must score like the all-bf16 launch and like the CPU spec; ragged M, K not
