@@ -92,15 +92,20 @@ int adalog_pack_split3_bf16(const float* x, int64_t G, int64_t R, int64_t K, int
  * reduce_cols = 1: the tile's column sums are added up in-kernel (fixed order) and partial holds one value per tile,
  *   [C][G][m_tile][n_tile] -- for searches whose score does not keep the column axis.
  * order: workgroup -> tile order, fastest index first (L2 reuse): 0 = n,m,g,c   1 = n,c,m,g   2 = m,n,c,g.
- * dtype: 0 = int8 (exact integer dot products), 1 = bf16, 2 = fp32.  bias may be NULL.  partial and ref go together.
+ * dtype: 0 = int8 (exact integer dot products), 1 = bf16, 2 = fp32, 3 = fp8 e4m3 holding exact integers of <= 4-bit operands,
+ *   4 = A bf16 rows x B fp8 columns, converted to bf16 in registers (the shapes adalog_gemm_mixed_ok accepts; sAc / sBc ... in
+ *   elements of the respective operand).  bias may be NULL.  partial and ref go together.
  * Kp: row stride of both packed operands in elements (a multiple of 128 bytes); k_valid: leading elements of a row that
  *   can be non-zero (the pack kernels zero-fill [K, Kp)); 0 means Kp.  The streaming kernel skips whole 64-byte
  *   K-steps of padding (q.k^T with head_dim 64: half of the padded row).
  * partial must hold adalog_gemm_score_layout(M, N, C, G, ...) floats. */
-/* adalog_gemm_mixed_ok: 1 when adalog_gemm_score takes dtype 4 -- A: bf16 rows [..][256], B: fp8 e4m3 candidate columns
- *   [..][256] (q - z of a <= 4-bit quantiser: exact) -- for this shape: the softmax.v weight search of a 197-token ViT
- *   (reference matmul.py:173-201 with the AdaLog-quantised attention probabilities as the fixed operand).  The kernel converts
- *   the fp8 fragments to bf16 in registers (exact), so the streamed candidate operand is 256 instead of 448 bytes per column. */
+/* adalog_gemm_mixed_ok: 1 when adalog_gemm_score takes dtype 4 -- A: bf16 rows [..][Kp], B: fp8 e4m3 candidate columns
+ *   [..][Kp] (q - z of a <= 4-bit quantiser: exact) -- for this shape (N includes the candidate factor ref_div; C = 1,
+ *   transposed reference).  Three families, all searches whose FIXED operand holds AdaLog values (bf16) and whose candidates are
+ *   uniform:  k_valid 193..256, 129..224 rows, >= 8 groups (softmax.v weight search of a 197-token ViT, reference matmul.py:173-201;
+ *   Kp = 256);  k_valid <= 64, <= 64 rows, >= 256 groups (the same search over swin windows; Kp = 64);  k_valid > 256 on the wide
+ *   streaming form (weight search of the post-GELU layer, reference linear.py:355-392; Kp = any multiple of 64).  The kernels convert
+ *   the fp8 fragments with v_cvt_scalef32_pk_bf16_fp8, so the streamed candidate operand has half the bytes of a bf16 one. */
 int adalog_gemm_mixed_ok(int M, int N, int G, int gmod, int ref_div, int64_t k_valid);
 int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc, int64_t sBg, int M,
                       int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref, int64_t ldr, int64_t sRg, int64_t ref_cs,
