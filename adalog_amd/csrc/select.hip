@@ -53,15 +53,19 @@ __global__ __launch_bounds__(256) void k_sel_hist(const float* __restrict__ x, i
         const float v = xs[i];
         if (positive_only && !(v > 0.0f)) continue;
         const uint32_t key = f2key(v);
-        const uint32_t hi = pass == 0 ? 0u : (key >> (shift + 8));
         const unsigned bin = (key >> shift) & 255u;
-        for (int r = 0; r < R; ++r)
-            if (pass == 0 || hi == pre[r]) atomicAdd(&h[r][bin], 1u);
+        if (pass == 0) {                                   // the histogram of the top byte is the same for every rank: count once
+            atomicAdd(&h[0][bin], 1u);
+        } else {
+            const uint32_t hi = key >> (shift + 8);
+            for (int r = 0; r < R; ++r)
+                if (hi == pre[r]) atomicAdd(&h[r][bin], 1u);
+        }
     }
     __syncthreads();
     unsigned* gh = hist + ((int64_t)slot * R) * 256;
     for (int i = threadIdx.x; i < R * 256; i += blockDim.x) {
-        const unsigned c = (&h[0][0])[i];
+        const unsigned c = pass == 0 ? h[0][i & 255] : (&h[0][0])[i];
         if (c) atomicAdd(gh + i, c);
     }
 }
