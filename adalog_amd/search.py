@@ -43,6 +43,7 @@ def const_tensor(values, device, dtype=torch.float32) -> torch.Tensor:
 # deit_small calibration -- its result is the one already committed and the search is not repeated.  One host read
 # (torch.equal) per check.  ADALOG_SKIP_CONVERGED=0 re-runs everything, as the reference does.
 SKIP_CONVERGED = __import__("os").environ.get("ADALOG_SKIP_CONVERGED", "1") != "0"
+COLLECT_ROUND_STATS = False        # True: count unchanged inputs also when nothing is skipped (lab / tests)
 ROUND_STATS = {"checked": 0, "unchanged": 0}
 _ROUND_PENDING = []                # device flags of checks made while nothing is skipped (read by round_stats(), not by the search)
 
@@ -81,6 +82,8 @@ def round_is_redundant(module, tag: str, *quantizers) -> bool:
     """True when the search `tag` of this module last ran against exactly this state of the quantisers it reads (the other
     operand's; its own too when the search starts from its current parameters) -- then its committed result stands.
     Records the state either way."""
+    if not SKIP_CONVERGED and not COLLECT_ROUND_STATS:
+        return False                       # every search runs and nobody asked for the statistics: no snapshots, no compares
     seen = module.__dict__.setdefault("_round_inputs", {})
     state = quantizer_state(*quantizers)
     prev = seen.get(tag)

@@ -536,12 +536,13 @@ def main():
     wall = time.perf_counter() - t0
     by = prof.stop()
     coll = parallel.collective_stats()
-    round_stats = _search.round_stats()
+    round_stats = _search.round_stats() if args.schedule == "product" else None
     # second timed region: the same K steps on the OTHER schedule (both produce the same calibrated model, tests/calibrator_cases.py)
     wall_all = None
     other = "product" if args.schedule == "reference" else "reference"
     if not args.no_rerun_all:
         set_schedule(other)
+        _search.reset_round_stats()
         more = [copy.deepcopy(base) for _ in range(args.steps)]
         torch.cuda.synchronize()
         parallel.barrier()
@@ -553,6 +554,8 @@ def main():
         parallel.barrier()
         torch.cuda.synchronize()
         wall_all = time.perf_counter() - t1
+        if other == "product":
+            round_stats = _search.round_stats()              # (the product schedule is the one that compares quantiser states)
         set_schedule(args.schedule)
         del more
     if world > 1:
@@ -611,8 +614,9 @@ def main():
                                       "inputs: it would commit what is committed), nor is the weights' self-MSE search whose result "
                                       "the first round overwrites unread; same calibrated model tensor for tensor "
                                       "(tests/calibrator_cases.py); ADALOG_SKIP_CONVERGED=0 ADALOG_DEAD_W_SELF=1 = reference schedule",
-                           "round_checks_per_step": round_stats["checked"] / args.steps,
-                           "round_inputs_unchanged_per_step": round_stats["unchanged"] / args.steps},
+                           "round_checks_per_step": None if round_stats is None else round_stats["checked"] / args.steps,
+                           "round_inputs_unchanged_per_step": None if round_stats is None else round_stats["unchanged"] / args.steps,
+                           "round_stats_from": "the product-schedule region (the reference schedule takes no snapshots)"},
                        "other_schedule": None if wall_all is None else {
                            "schedule": other, "ms_per_step": wall_all * 1e3 / args.steps,
                            "images_per_s": cfg.calib_size * args.steps / wall_all, "steps": args.steps,

@@ -174,6 +174,7 @@ def case_converged_rounds_are_skipped_exactly(device="cpu", bits=4, rounds=4):
     x = torch.randn(8, 3, 32, 32).to(dev)
     sds, stats = {}, {}
     keep = (search.SKIP_CONVERGED, qlinear.RUN_DEAD_W_SELF)
+    keep_collect, search.COLLECT_ROUND_STATS = search.COLLECT_ROUND_STATS, True
     try:
         for skip in (False, True):                                       # False: the reference's schedule, True: the product's
             search.SKIP_CONVERGED = skip
@@ -186,6 +187,7 @@ def case_converged_rounds_are_skipped_exactly(device="cpu", bits=4, rounds=4):
             stats[skip] = search.round_stats()
     finally:
         search.SKIP_CONVERGED, qlinear.RUN_DEAD_W_SELF = keep
+        search.COLLECT_ROUND_STATS = keep_collect
     assert set(sds[False]) == set(sds[True])
     for k, a in sds[False].items():
         assert torch.equal(a, sds[True][k]), k

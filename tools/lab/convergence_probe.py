@@ -18,6 +18,7 @@ model = wrap_modules_in_net(copy.deepcopy(base), cfg, reparam=True).to(dev)
 stats = collections.Counter()
 orig = search.round_is_redundant
 search.SKIP_CONVERGED = False
+search.COLLECT_ROUND_STATS = True
 
 
 def spy(module, tag, *qs):
