@@ -119,10 +119,8 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     // 256-column slabs up to 6 K-steps; 128-column slabs up to 12 (K = 512 / 768: swin stage 2, vit_base) when a slab still holds
     // whole reference columns (64 or 128 candidates)
     static const int use_slab128 = getenv("ADALOG_GEMM_SLAB128") ? atoi(getenv("ADALOG_GEMM_SLAB128")) : 1;
-    // (ADALOG_GEMM_SLAB_FORCE128=1: 128-column slabs also where 256-column slabs fit -- an A/B switch for the lab)
-    static const int force128 = getenv("ADALOG_GEMM_SLAB_FORCE128") ? atoi(getenv("ADALOG_GEMM_SLAB_FORCE128")) : 0;
     const bool ok128 = use_slab128 && kb <= 12 * BK3 && (ref_div == 64 || ref_div == 128);
-    const int slab_nb = (kb <= 6 * BK3 && !(force128 && ok128)) ? 8 : (ok128 ? 4 : 0);
+    const int slab_nb = kb <= 6 * BK3 ? 8 : (ok128 ? 4 : 0);       // (128-column slabs at K = 384 were measured: +57 ms per calibration)
     if (L.stream && (g_slab_override >= 0 ? g_slab_override : use_slab) && (dtype == 0 || dtype == 3) && G == 1 && slab_nb != 0 && kvalid_bytes > BK3 && M % 32 == 0 && M >= slab_min_m &&
         (int64_t)M * kb <= slab_max_bytes && (int64_t)cdiv(N, 32 * slab_nb) * (M / 32) < ((int64_t)1 << 30)) {
         const int SBN = 32 * slab_nb;
