@@ -131,6 +131,10 @@ class BlockReconstructor(QuantCalibrator):
                                  rec_loss='mse' if 'head' not in name else 'kl_div', b_range=b_range, decay_start=0,
                                  warmup=warmup, p=p)
         gen = torch.Generator().manual_seed(1234 + parallel.rank())
+        # test hooks (tests/golden/brecq_traj.npz replays the reference's own mini-batch sequence and compares the trained
+        # values after given iterations): index_source(it, n, bs) -> LongTensor of bs indices; iter_hook(it) after iteration it
+        index_source = getattr(self, 'index_source', None)
+        iter_hook = getattr(self, 'iter_hook', None)
         # Only alpha and the activation scales are optimised (block_recon.py:97-108).  The reference leaves every other
         # parameter of the block with requires_grad=True and autograd fills their .grad each iteration (bias sums,
         # LayerNorm gamma/beta, ~40 accumulations) although nothing reads them; freezing them for the duration of the
@@ -169,9 +173,14 @@ class BlockReconstructor(QuantCalibrator):
 
         try:
             for it in range(iters):
-                idx = torch.randperm(n_local, generator=gen)[:local_bs].to(block.raw_input.device)
+                if index_source is not None:
+                    idx = index_source(it, n_local, local_bs).to(block.raw_input.device)
+                else:
+                    idx = torch.randperm(n_local, generator=gen)[:local_bs].to(block.raw_input.device)
                 if not use_graph or it < 3:                  # eager (and the warm-up iterations before the capture)
                     eager_step(block.raw_input[idx].to(device), block.raw_out[idx].to(device))
+                    if iter_hook is not None:
+                        iter_hook(it + 1, loss_func)
                     continue
                 if graph is None:
                     static_inp, static_out = block.raw_input[idx].to(device).clone(), block.raw_out[idx].to(device).clone()
@@ -204,7 +213,10 @@ class BlockReconstructor(QuantCalibrator):
                     optim_steps()
                 if a_scheduler is not None:
                     a_scheduler.step()
+                loss_func.cur = (static_rec, static_rnd)
                 loss_func.log(static_rec, static_rnd)
+                if iter_hook is not None:
+                    iter_hook(it + 1, loss_func)
         finally:                                         # (also when an iteration raises: leave the block as it was found)
             graph = None
             torch.backends.cuda.matmul.allow_tf32 = prev_tf32
@@ -286,6 +298,7 @@ class LossFunction:
         self.count = 0
         self.b = 0
         self.last = (0.0, 0.0, 0.0)
+        self.cur = (0.0, 0.0)
 
     @staticmethod
     def lp_loss(pred, tgt, p=2.0, reduction='none', scale=1.0):
@@ -343,6 +356,7 @@ class LossFunction:
     def __call__(self, pred, tgt):
         rec_loss = self.rec_term(pred, tgt)
         round_loss = self.round_term()
+        self.cur = (rec_loss, round_loss)                # this iteration's two terms (device scalars; read only by tests / logs)
         self.log(rec_loss, round_loss)
         return rec_loss + round_loss
 

@@ -304,6 +304,96 @@ def case_brecq_toy(golden, device="cpu"):
     close(blk.fc1.w_quantizer.get_hard_value(blk.fc1.weight.data), t(g["hard_fc1"]), 1e-6, 1e-7)
 
 
+def case_brecq_traj(golden, device="cpu", graph=None, tol=1e-3):
+    """The LOOP of utils/block_recon.py:84-137 against the reference's own 20-iteration run (golden brecq_traj, made by
+    tools/make_golden.py: gen_brecq_traj): the reference's mini-batch index sequence is injected, and alpha, every trained
+    activation scale, the per-iteration loss and b are compared after iterations 1, 5 and 20.  ``graph``: None = the
+    loop's own choice, True / False = force the HIP-graph replay on / off (ADALOG_BRECQ_GRAPH)."""
+    import os
+    DEV[0] = torch.device(device)
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    g = golden("brecq_traj")
+    iters, bs = [int(v) for v in g["cfg"]]
+    I, Hd, H = 16, 32, 2
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            kw = dict(mode="raw", w_bit=4, a_bit=4, calib_batch_size=4, search_round=1, eq_n=128, fpcs=True, steps=2)
+            self.fc1 = Q.AsymmetricallyBatchingQuantLinear(I, Hd, True, n_V=1, **kw)
+            self.fc2 = Q.PostGeluLogBasedBatchingQuantLinear(Hd, I, True, n_V=1, quantizer="adalog", **kw)
+            mk = dict(B_bit=4, mode="raw", calib_batch_size=4, search_round=1, eq_n=128, head_channel_wise=True,
+                      num_heads=H, fpcs=True, steps=2)
+            self.matmul1 = Q.AsymmetricallyBatchingQuantMatMul(A_bit=4, **mk)
+            self.matmul2 = Q.PostSoftmaxAsymmetricallyBatchingQuantMatMul(A_bit=4, quantizer="adalog", **mk)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            h = x.reshape(B, N, H, C // H).permute(0, 2, 1, 3)
+            a = self.matmul2(self.matmul1(h, h.transpose(-2, -1)).softmax(-1), h)
+            x = x + a.permute(0, 2, 1, 3).reshape(B, N, C)
+            return x + self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+    blk = Blk().eval().to(DEV[0])
+    sd = {k[4:].replace("__", "."): t(v) for k, v in g.items() if k.startswith("cal_")}
+    res = blk.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and not res.missing_keys, res
+    for m in blk.modules():
+        if hasattr(m, "mode"):
+            m.calibrated = True
+            for a in ("a_quantizer", "w_quantizer", "A_quantizer", "B_quantizer"):
+                if hasattr(m, a):
+                    getattr(m, a).inited = True
+    blk.raw_input, blk.raw_out = t(g["x"]).clone(), t(g["tgt"]).clone()
+    perms = torch.from_numpy(g["perms"])
+    rec = object.__new__(BlockReconstructor)
+    rec.index_source = lambda it, n, b: perms[it][:b]
+    seen = {}
+
+    def names():
+        return [("alpha_fc1", blk.fc1.w_quantizer.alpha), ("alpha_fc2", blk.fc2.w_quantizer.alpha),
+                ("a_scale_fc1", blk.fc1.a_quantizer.scale), ("a_scale_fc2", blk.fc2.a_quantizer.scale),
+                ("A_scale_mm1", blk.matmul1.A_quantizer.scale), ("B_scale_mm1", blk.matmul1.B_quantizer.scale),
+                ("A_scale_mm2", blk.matmul2.A_quantizer.scale), ("B_scale_mm2", blk.matmul2.B_quantizer.scale)]
+    losses, bvals = [], []
+
+    def hook(it, lf):
+        rec_t, rnd_t = lf.cur
+        losses.append(float(torch.as_tensor(rec_t).detach()) + float(torch.as_tensor(rnd_t).detach()))
+        bvals.append(float(lf.b))
+        if it in (1, 5, 20):
+            for n_, p_ in names():
+                seen[f"it{it:02d}_{n_}"] = p_.detach().clone()
+    rec.iter_hook = hook
+    prev = os.environ.get("ADALOG_BRECQ_GRAPH")
+    if graph is not None:
+        os.environ["ADALOG_BRECQ_GRAPH"] = "1" if graph else "0"
+    try:
+        rec.reconstruct_single_block("blk", blk, DEV[0], batch_size=bs, iters=iters, quant_act=True)
+    finally:
+        if graph is not None:
+            if prev is None:
+                os.environ.pop("ADALOG_BRECQ_GRAPH", None)
+            else:
+                os.environ["ADALOG_BRECQ_GRAPH"] = prev
+    assert len(losses) == iters
+    worst = {}
+    for k, v in seen.items():
+        ref = t(g[k])
+        err = ((v.reshape(ref.shape) - ref).abs().max() / ref.abs().max().clamp_min(1e-12)).item()
+        worst[k] = err
+        assert err <= tol, (k, err)
+    lref = torch.from_numpy(g["losses"])
+    lerr = ((torch.tensor(losses, dtype=torch.float64) - lref).abs() / lref.abs()).max().item()
+    assert lerr <= tol, ("loss", lerr, losses, lref)
+    assert max(abs(a - b) for a, b in zip(bvals, g["b"].tolist())) < 1e-9
+    # hard rounding committed from the trained alpha equals the reference's
+    close(blk.fc1.w_quantizer.get_hard_value(blk.fc1.weight.data), t(g["hard_fc1"]), 1e-6, 1e-7)
+    close(blk.fc2.w_quantizer.get_hard_value(blk.fc2.weight.data), t(g["hard_fc2"]), 1e-6, 1e-7)
+    worst["loss"] = lerr
+    return worst
+
+
 def case_brecq_reconstruct(device="cpu", iters=60):
     """reconstruct_model end to end on a tiny ViT: the training loop runs, the reconstruction loss goes down, hard
     rounding is committed (weights land on the quantisation grid) and the model stays in quant_forward."""

@@ -17,5 +17,9 @@ def test_brecq_toy_forward_backward(golden):
     LC.case_brecq_toy(golden)
 
 
+def test_brecq_trajectory_matches_reference_loop(golden):
+    LC.case_brecq_traj(golden)
+
+
 def test_brecq_reconstruct_model():
     LC.case_brecq_reconstruct(iters=30)

@@ -114,6 +114,17 @@ def test_brecq_toy_forward_backward(golden):
     LC.case_brecq_toy(golden, DEV)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_brecq_trajectory_matches_reference_loop(golden, graph):
+    """20 iterations of the reference's own loop (golden brecq_traj), eager and HIP-graph replayed."""
+    import json, os
+    worst = LC.case_brecq_traj(golden, DEV, graph=graph)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "brecq_traj_parity.jsonl"), "a") as f:
+        f.write(json.dumps({"graph": graph, "worst_rel_err": worst}) + "\n")
+
+
 def test_brecq_reconstruct_model():
     LC.case_brecq_reconstruct(DEV, iters=200)
 

@@ -468,10 +468,8 @@ def gen_calibrator():
     save("calibrator_toy", **arrays)
 
 
-def gen_brecq():
-    """BRECQ pieces (utils/block_recon.py needs timm at import: a container-only attribute stub satisfies it).
-    One forward/backward of a toy block of the reference's own layers in training mode pins the STE gradients of the
-    uniform / AdaLog quantisers, the AdaRound gradient, the reconstruction loss and the rounding regulariser."""
+def _brecq_timm_stub():
+    """utils/block_recon.py imports timm at module level: a container-only attribute stub satisfies the import."""
     class _Stub(types.ModuleType):
         def __getattr__(self, k):
             if k.startswith("__"):
@@ -482,8 +480,16 @@ def gen_brecq():
     for name in ("timm", "timm.models", "timm.models.swin_transformer", "timm.models.vision_transformer", "timm.layers",
                  "timm.layers.patch_embed"):
         sys.modules.setdefault(name, _Stub(name))
-    sys.modules["timm.models.swin_transformer"].window_partition = None
-    sys.modules["timm.models.swin_transformer"].window_reverse = None
+    if not hasattr(sys.modules["timm.models.swin_transformer"], "window_partition"):
+        sys.modules["timm.models.swin_transformer"].window_partition = None
+        sys.modules["timm.models.swin_transformer"].window_reverse = None
+
+
+def gen_brecq():
+    """BRECQ pieces (utils/block_recon.py needs timm at import: a container-only attribute stub satisfies it).
+    One forward/backward of a toy block of the reference's own layers in training mode pins the STE gradients of the
+    uniform / AdaLog quantisers, the AdaRound gradient, the reconstruction loss and the rounding regulariser."""
+    _brecq_timm_stub()
     from utils.block_recon import LossFunction, LinearTempDecay, BlockReconstructor
     arrays = {}
     arrays["lp_ones"] = LossFunction.lp_loss(torch.ones(2, 3, 4), torch.zeros(2, 3, 4))
@@ -551,6 +557,106 @@ def gen_brecq():
     arrays["g_B_scale_mm"] = blk.matmul1.B_quantizer.scale.grad
     arrays["hard_fc1"] = blk.fc1.w_quantizer.get_hard_value(blk.fc1.weight.data)
     save("brecq_toy", **arrays)
+
+
+def gen_brecq_traj():
+    """A 20-iteration BRECQ TRAJECTORY of the reference's own loop (utils/block_recon.py:84-137: two Adam optimisers, cosine
+    schedule on the activation scales, 20 % warm-up of the rounding regulariser, b: 20 -> 2) on a toy block of the reference's
+    layers with quant_act=True.  torch.randperm is wrapped to record the mini-batch indices; the scheduler's step() (called
+    once at the end of every iteration) snapshots alpha / activation scales after iterations 1, 5 and 20; LossFunction.__call__
+    is wrapped to record every iteration's total loss and b."""
+    _brecq_timm_stub()
+    from utils import block_recon as BR
+    torch.manual_seed(97)
+    I, Hd, H = 16, 32, 2
+
+    class Blk(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            kw = dict(mode="raw", w_bit=4, a_bit=4, calib_batch_size=4, search_round=1, eq_n=128, fpcs=True, steps=2)
+            self.fc1 = RL.AsymmetricallyBatchingQuantLinear(I, Hd, True, n_V=1, **kw)
+            self.fc2 = RL.PostGeluLogBasedBatchingQuantLinear(Hd, I, True, n_V=1, quantizer="adalog", **kw)
+            mk = dict(B_bit=4, mode="raw", calib_batch_size=4, search_round=1, eq_n=128, head_channel_wise=True,
+                      num_heads=H, fpcs=True, steps=2)
+            self.matmul1 = RL.AsymmetricallyBatchingQuantMatMul(A_bit=4, **mk)
+            self.matmul2 = RL.PostSoftmaxAsymmetricallyBatchingQuantMatMul(A_bit=4, quantizer="adalog", **mk)
+
+        def forward(self, x):
+            B, N, C = x.shape
+            h = x.reshape(B, N, H, C // H).permute(0, 2, 1, 3)
+            a = self.matmul2(self.matmul1(h, h.transpose(-2, -1)).softmax(-1), h)
+            x = x + a.permute(0, 2, 1, 3).reshape(B, N, C)
+            return x + self.fc2(torch.nn.functional.gelu(self.fc1(x)))
+
+    blk = Blk().eval()
+    for m in (blk.fc1, blk.fc2):
+        m.weight.data.normal_(0, 0.2)
+        m.bias.data.normal_(0, 0.1)
+    xs = torch.randn(12, 5, I)
+    arrays = {"in_" + k.replace(".", "__"): v.clone() for k, v in blk.state_dict().items()}
+    RefCalibrator(blk, [(xs[:4], None), (xs[4:8], None), (xs[8:], None)]).batching_quant_calib()
+    arrays.update({"cal_" + k.replace(".", "__"): v.clone() for k, v in blk.state_dict().items()})
+    arrays["x"] = xs
+    tgt = blk(xs).detach() + 0.05 * torch.randn(12, 5, I)      # FP block output + noise (any fixed target pins the loop)
+    arrays["tgt"] = tgt
+    rec = object.__new__(BR.BlockReconstructor)
+    blk.raw_input, blk.raw_out = xs.clone(), tgt.clone()
+    iters, bs = 20, 4
+    arrays["cfg"] = np.array([iters, bs], dtype=np.int64)
+
+    perms, losses, bvals, snaps = [], [], [], {}
+    orig_randperm, orig_call, orig_sched = torch.randperm, BR.LossFunction.__call__, torch.optim.lr_scheduler.CosineAnnealingLR.step
+    it_box = [0]
+
+    def randperm(n, *a, **k):
+        r = orig_randperm(n, *a, **k)
+        perms.append(r.clone())
+        return r
+
+    def lf_call(self, pred, tgt_):
+        out = orig_call(self, pred, tgt_)
+        losses.append(float(out.detach()))
+        b = self.temp_decay(self.count)
+        bvals.append(0.0 if self.count < self.loss_start else float(b))
+        return out
+
+    def names():
+        return [("alpha_fc1", blk.fc1.w_quantizer.alpha), ("alpha_fc2", blk.fc2.w_quantizer.alpha),
+                ("a_scale_fc1", blk.fc1.a_quantizer.scale), ("a_scale_fc2", blk.fc2.a_quantizer.scale),
+                ("A_scale_mm1", blk.matmul1.A_quantizer.scale), ("B_scale_mm1", blk.matmul1.B_quantizer.scale),
+                ("A_scale_mm2", blk.matmul2.A_quantizer.scale), ("B_scale_mm2", blk.matmul2.B_quantizer.scale)]
+
+    def sched_step(self, *a, **k):
+        r = orig_sched(self, *a, **k)
+        if getattr(self, "_traj_ready", False):          # the constructor calls step() once: skip that call
+            it_box[0] += 1
+            if it_box[0] in (1, 5, 20):
+                for n_, p_ in names():
+                    snaps[f"it{it_box[0]:02d}_{n_}"] = p_.detach().clone()
+                snaps[f"it{it_box[0]:02d}_lr"] = np.float64(self.get_last_lr()[0])
+        else:
+            self._traj_ready = True
+        return r
+
+    torch.randperm, BR.LossFunction.__call__ = randperm, lf_call
+    torch.optim.lr_scheduler.CosineAnnealingLR.step = sched_step
+    shim_avail = torch.cuda.is_available
+    torch.cuda.is_available = lambda: False              # Adam's capture health check must not look for a device
+    try:
+        torch.manual_seed(1234)
+        rec.reconstruct_single_block("blk", blk, torch.device("cpu"), batch_size=bs, iters=iters, quant_act=True)
+    finally:
+        torch.randperm, BR.LossFunction.__call__ = orig_randperm, orig_call
+        torch.optim.lr_scheduler.CosineAnnealingLR.step = orig_sched
+        torch.cuda.is_available = shim_avail
+    assert len(perms) == iters and len(losses) == iters and it_box[0] == iters, (len(perms), len(losses), it_box)
+    arrays["perms"] = torch.stack(perms)                 # [iters, n]: the loop uses perm[:batch_size]
+    arrays["losses"] = np.array(losses, dtype=np.float64)
+    arrays["b"] = np.array(bvals, dtype=np.float64)
+    arrays.update(snaps)
+    arrays["hard_fc1"] = blk.fc1.w_quantizer.get_hard_value(blk.fc1.weight.data)
+    arrays["hard_fc2"] = blk.fc2.w_quantizer.get_hard_value(blk.fc2.weight.data)
+    save("brecq_traj", **arrays)
 
 
 # ----------------------------------------------------------------------------- wrapper rules + attention forwards
@@ -743,3 +849,4 @@ if __name__ == "__main__":
     gen_calibrator()
     gen_wrapper()
     gen_brecq()
+    gen_brecq_traj()
