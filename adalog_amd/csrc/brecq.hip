@@ -318,6 +318,27 @@ __global__ __launch_bounds__(256) void k_rec_loss_bwd(const float* __restrict__ 
         gpred[i] = (pred[i] - tgt[i]) * f;
 }
 
+// q - z of the per-tensor asymmetric quantiser, as fp32: the exact integer operand of the training-mode GEMM
+// (brecq_gemm.hip), whose epilogue multiplies by the trained scale -- (q - z) * s is the fake-quantised activation.
+__global__ __launch_bounds__(256) void k_uniform_int(const float* __restrict__ x, float* __restrict__ y, int64_t n,
+                                                     const float* __restrict__ scale, const float* __restrict__ zp, float qmax) {
+    const float s = scale[0], z = rintf(zp[0]);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        float4 o;
+        o.x = fminf(fmaxf(rintf(v.x / s) + z, 0.0f), qmax) - z;
+        o.y = fminf(fmaxf(rintf(v.y / s) + z, 0.0f), qmax) - z;
+        o.z = fminf(fmaxf(rintf(v.z / s) + z, 0.0f), qmax) - z;
+        o.w = fminf(fmaxf(rintf(v.w / s) + z, 0.0f), qmax) - z;
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        y[i] = fminf(fmaxf(rintf(x[i] / s) + z, 0.0f), qmax) - z;
+    }
+}
+
 // Ticket counters for the "last block finishes" reductions: a ring of zeroed device words, one handed to each launch
 // (the last block puts its word back to zero).  Launches that overlap in time hold different slots as long as fewer
 // than RING of them are in flight.
@@ -377,6 +398,18 @@ extern "C" int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, 
     if (nb > want) nb = want;
     if (nb < 1) nb = 1;
     return (int)nb;
+}
+
+// y[i] = clamp(rne(x[i] / s) + rne(zp), 0, 2^bits - 1) - rne(zp)   (per-tensor s, zp: device scalars; x, y 16-byte aligned)
+extern "C" int adalog_uniform_int_f32(const float* x, float* y, int64_t n, const float* scale, const float* zero_point,
+                                      int n_bits, void* stream) {
+    if (n == 0) return 0;
+    ADALOG_ARG_CHECK(x && y && scale && zero_point && n_bits >= 2 && n_bits <= 8, "uniform_int: bad arguments");
+    ADALOG_ARG_CHECK((((uintptr_t)x | (uintptr_t)y) & 15) == 0, "uniform_int: x / y must be 16-byte aligned");
+    hipLaunchKernelGGL(k_uniform_int, dim3(grid1(n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, n, scale, zero_point,
+                       (float)((1 << n_bits) - 1));
+    ADALOG_LAUNCH_CHECK("adalog_uniform_int_f32");
+    return 0;
 }
 
 // gscale / gzp: [n_channels] (each optional).  workspace: 2 * rows * adalog_uniform_fq_backward_blocks floats.

@@ -850,3 +850,101 @@ def round_loss_multi(alphas, b, weight: float):
                                      loss.data_ptr(), ws.data_ptr(), _stream())
     _lib.check(rc, "adalog_round_loss_multi")
     return loss, grads
+
+
+# ---------------------------------------------------------------------------------------------- BRECQ training-mode GEMMs
+def _mat_layout(t: torch.Tensor):
+    """How the kernel reads a logical [..., R, K] operand: (trans, ld, groups, group_stride) or None.
+    trans = 0: K contiguous (rows of ld elements); trans = 1: R contiguous (K-major).  Leading dims must collapse to one
+    group index with a uniform stride."""
+    if t.dtype != torch.float32 or not t.is_cuda or t.dim() < 2:
+        return None
+    R, K = t.shape[-2:]
+    sr, sk = t.stride(-2), t.stride(-1)
+    if (sk == 1 or K == 1) and (sr >= K or R == 1):
+        trans, ld = 0, (sr if R > 1 else max(K, 4))
+    elif (sr == 1 or R == 1) and (sk >= R or K == 1):
+        trans, ld = 1, (sk if K > 1 else max(R, 4))
+    else:
+        return None
+    G, gs = 1, 0
+    lead = [(t.shape[i], t.stride(i)) for i in range(t.dim() - 2) if t.shape[i] != 1]
+    if lead:
+        G = 1
+        for n_, _ in lead:
+            G *= n_
+        gs = lead[-1][1]
+        for (n0, s0), (n1, s1) in zip(lead[:-1], lead[1:]):
+            if s0 != s1 * n1:
+                return None
+    if ld % 4 or gs % 4 or t.data_ptr() % 16:
+        return None
+    return trans, ld, G, gs
+
+
+def gemm_f32x3_ok(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None) -> bool:
+    """Whether a @ b^T (a: [..., M, K], b: [..., N, K], same leading shape) runs on adalog_gemm_f32x3."""
+    la, lb = _mat_layout(a), _mat_layout(b)
+    if la is None or lb is None or a.shape[-1] != b.shape[-1] or la[2] != lb[2]:
+        return False
+    M, N = a.shape[-2], b.shape[-2]
+    if N % 4 or a.numel() == 0 or b.numel() == 0:
+        return False
+    if bias is not None and (N % 16 or bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16
+                             or bias.numel() != N):
+        return False
+    per = 4 * max(M * la[1] if not la[0] else a.shape[-1] * la[1], N * lb[1] if not lb[0] else a.shape[-1] * lb[1])
+    return per < (1 << 31)
+
+
+def gemm_f32x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
+               allow_split: bool = True, alpha_dev: Optional[torch.Tensor] = None, exact_a: bool = False,
+               exact_b: bool = False) -> torch.Tensor:
+    """alpha * alpha_dev[0] * a @ b^T (+ bias) for fp32 operands of either memory orientation, at fp32 accuracy on the bf16
+    matrix cores (csrc/brecq_gemm.hip).  a: [..., M, K], b: [..., N, K] -> [..., M, N] (contiguous).
+    exact_a / exact_b: that operand holds integers exactly representable in bf16 (3 products instead of 6 where supported)."""
+    la, lb = _mat_layout(a), _mat_layout(b)
+    if not gemm_f32x3_ok(a, b, bias):
+        raise _lib.AdalogHipError(f"gemm_f32x3: unsupported operand layout {tuple(a.shape)}/{a.stride()} x {tuple(b.shape)}/{b.stride()}")
+    M, K, N, G = a.shape[-2], a.shape[-1], b.shape[-2], la[2]
+    out = torch.empty(a.shape[:-2] + (M, N), dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    sp, ea, eb = (1 if allow_split else 0), (1 if exact_a else 0), (1 if exact_b else 0)
+    wsb = int(lib.adalog_gemm_f32x3_workspace_bytes(M, N, K, G, sp, ea, eb, la[0], lb[0]))
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device) if wsb else None
+    rc = lib.adalog_gemm_f32x3(a.data_ptr(), la[1], la[0], b.data_ptr(), lb[1], lb[0], out.data_ptr(), N, M, N, K, G,
+                               la[3], lb[3], M * N, _ptr(bias), float(alpha), _ptr(alpha_dev), sp, ea, eb, _ptr(ws), _stream())
+    _lib.check(rc, "adalog_gemm_f32x3")
+    return out
+
+
+def gemm_f32x3_planes(a: torch.Tensor, bp: torch.Tensor, K: int, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
+                      allow_split: bool = True, alpha_dev: Optional[torch.Tensor] = None, exact_a: bool = False) -> torch.Tensor:
+    """a @ B^T (+ bias) with B handed over pre-split by pack_split3(): bp is its [1, G, N, 3*Kt] bf16 image (hi | mid | lo per
+    row).  a: [..., M, K] fp32, K-contiguous -> [..., M, N]."""
+    la = _mat_layout(a)
+    if la is None or la[0] != 0 or a.shape[-1] != K or bp.dtype != torch.bfloat16 or not bp.is_contiguous():
+        raise _lib.AdalogHipError(f"gemm_f32x3_planes: unsupported operand layout {tuple(a.shape)}/{a.stride()}")
+    G, N, Kt = bp.shape[-3], bp.shape[-2], bp.shape[-1] // 3
+    M = a.shape[-2]
+    if la[2] != G or N % 4 or (bias is not None and N % 16):
+        raise _lib.AdalogHipError("gemm_f32x3_planes: group count / N not supported")
+    out = torch.empty(a.shape[:-2] + (M, N), dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    sp, ea = (1 if allow_split else 0), (1 if exact_a else 0)
+    wsb = int(lib.adalog_gemm_f32x3_planes_workspace_bytes(M, N, K, G, sp, ea))
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device) if wsb else None
+    rc = lib.adalog_gemm_f32x3_planes(a.data_ptr(), la[1], bp.data_ptr(), Kt, out.data_ptr(), N, M, N, K, G, la[3], M * N,
+                                      _ptr(bias), float(alpha), _ptr(alpha_dev), sp, ea, _ptr(ws), _stream())
+    _lib.check(rc, "adalog_gemm_f32x3_planes")
+    return out
+
+
+def uniform_int(x: torch.Tensor, scale: torch.Tensor, zero_point: torch.Tensor, n_bits: int) -> torch.Tensor:
+    """q - z of the per-tensor asymmetric quantiser as fp32 (exact small integers); (q - z) * scale is uniform_fake_quant(x)."""
+    x = _f32c(x, "x")
+    y = torch.empty_like(x)
+    rc = _lib.load().adalog_uniform_int_f32(x.data_ptr(), y.data_ptr(), x.numel(), _f32c(scale, "scale").data_ptr(),
+                                            _f32c(zero_point, "zero_point").data_ptr(), int(n_bits), _stream())
+    _lib.check(rc, "adalog_uniform_int_f32")
+    return y

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import backend, search
+from .. import backend, search, train_mm
 from ..ops import BF16, F32, Strided, pad_k
 from ..quantizers.uniform import UniformQuantizer
 
@@ -42,7 +42,8 @@ class MinMaxQuantConv2d(nn.Conv2d):
             n, ic, H, W = x.shape
             gh, gw = H // kh, W // kw
             patches = x.reshape(n, ic, gh, kh, gw, kw).permute(0, 2, 4, 1, 3, 5).reshape(n * gh * gw, ic * kh * kw)
-            out = F.linear(patches, w.reshape(w.shape[0], -1), b)
+            w2 = w.reshape(w.shape[0], -1)
+            out = train_mm.linear(patches, w2, b) if w2.requires_grad else F.linear(patches, w2, b)
             return out.reshape(n, gh, gw, -1).permute(0, 3, 1, 2)
         return F.conv2d(x, w, b, self.stride, self.padding, self.dilation, self.groups)
 

@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import backend, search
+from .. import backend, search, train_mm
 from ..ops import BF16, BF16_FP8, FP8, I8, Strided, pad_k  # noqa: F401  (dtype codes / epilogue parameter helper; pure metadata)
 from ..quantizers.logarithm import ShiftAdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
@@ -77,10 +77,14 @@ class MinMaxQuantLinear(nn.Linear):
     def quant_forward(self, x):
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
         w_sim, bias_sim = self.quant_weight_bias()
+        if w_sim.requires_grad:                          # a BRECQ iteration: the contractions run on csrc/brecq_gemm.hip
+            return train_mm.quant_linear(x, self.a_quantizer, w_sim, bias_sim)
         return F.linear(self.quant_input(x), w_sim, bias_sim)
 
     def debug_only_quant_weight(self, x):
         w_sim, bias_sim = self.quant_weight_bias()
+        if w_sim.requires_grad:
+            return train_mm.linear(x, w_sim, bias_sim)
         return F.linear(x, w_sim, bias_sim)
 
     def debug_only_quant_act(self, x):

@@ -1,0 +1,123 @@
+"""Training-mode (BRECQ) contractions of the quantised layers on the hand-written fp32-accurate MFMA kernel.
+
+One BRECQ iteration (reference utils/block_recon.py:116-121) runs, per Linear layer, F.linear(x_sim, w_sim, bias) forward and the
+two backward products dL/dx_sim = dL/dy . w_sim and dL/dw_sim = dL/dy^T . x_sim (reference quant_layers/linear.py:46-50 under
+autograd).  Here these are csrc/brecq_gemm.hip launches (adalog_gemm_f32x3 / _planes: fp32 operands split in registers into three
+bf16 terms, six bf16 MFMA products, fp32 accumulation -- fp32-class accuracy), with the structure of the operands used:
+
+  * a uniformly fake-quantised activation is  x_sim = s_a * x_int  with x_int = q - z a small integer: the kernels take x_int
+    (exact in ONE bf16 term: 3 products instead of 6, no split) and apply the trained scale s_a in the epilogue; the
+    straight-through gradients of (x, s_a) come from the same fused kernel as before, fed with dL/dx_sim;
+  * the soft-rounded weights w_sim (small, re-read by every row tile) are split once per iteration by the packer, in both
+    orientations, instead of once per tile in the GEMM;
+  * dL/dw_sim reads dL/dy and x_int K-major straight from their row-major tensors (no transposed copies).
+
+ADALOG_BRECQ_MM=0 falls back to the fp32 library GEMMs (torch / rocBLAS) for A/B measurements.
+"""
+import os
+
+import torch
+import torch.nn.functional as F
+
+from . import backend
+
+ENABLED = os.environ.get("ADALOG_BRECQ_MM", "1") != "0"
+WEIGHT_PLANES = os.environ.get("ADALOG_BRECQ_WPLANES", "1") != "0"      # pre-split w_sim (0: split in the GEMM's registers)
+INT_ACT = os.environ.get("ADALOG_BRECQ_INT_ACT", "1") != "0"            # integer activation operand (0: s_a * x_int as fp32)
+
+
+def _usable(x2, w2, bias):
+    if not (ENABLED and x2.is_cuda and x2.dtype == torch.float32 and w2.dtype == torch.float32):
+        return False
+    be = backend.get()
+    if not hasattr(be, "gemm_f32x3"):
+        return False
+    M, K = x2.shape
+    N = w2.shape[0]
+    # every form used below: K-contiguous and K-major reads of x2 / gy / w2 need 16-byte aligned rows in both orientations
+    return K % 4 == 0 and N % 4 == 0 and M >= 1 and x2.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0 \
+        and (bias is None or (N % 16 == 0 and bias.is_contiguous() and bias.data_ptr() % 16 == 0))
+
+
+def _planes(be, w2):
+    """w2 [N, K] -> its pre-split image for adalog_gemm_f32x3_planes (rows of hi | mid | lo)."""
+    return be.pack_split3(w2.unsqueeze(0), 64)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x2 @ w2^T + bias with general fp32 operands (x2 [M, K], w2 [N, K])."""
+
+    @staticmethod
+    def forward(ctx, x2, w2, bias):
+        be = backend.get()
+        ctx.save_for_backward(x2, w2)
+        if WEIGHT_PLANES:
+            return be.gemm_f32x3_planes(x2, _planes(be, w2), x2.shape[1], bias)
+        return be.gemm_f32x3(x2, w2, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w2 = ctx.saved_tensors
+        be = backend.get()
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = be.gemm_f32x3_planes(gy, _planes(be, w2.t()), w2.shape[0]) if WEIGHT_PLANES else be.gemm_f32x3(gy, w2.t())
+        if ctx.needs_input_grad[1]:
+            gw = be.gemm_f32x3(gy.t(), x2.t())
+        gb = gy.sum(0) if ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+class _QuantLinearFn(torch.autograd.Function):
+    """y = (s_a * x_int) @ w2^T + bias,  x_int = clamp(rne(x / s_a) + z, 0, 2^bits - 1) - z   (per-tensor uniform quantiser
+    with the straight-through estimator, reference quantizers/uniform.py:29-35 + _ste.py:5-6, fused with the layer's GEMMs)."""
+
+    @staticmethod
+    def forward(ctx, x2, a_scale, a_zp, w2, bias, n_bits):
+        be = backend.get()
+        xi = be.uniform_int(x2, a_scale, a_zp, n_bits)
+        ctx.save_for_backward(x2, xi, a_scale, a_zp, w2)
+        ctx.n_bits = n_bits
+        if WEIGHT_PLANES:
+            return be.gemm_f32x3_planes(xi, _planes(be, w2), x2.shape[1], bias, alpha_dev=a_scale, exact_a=True)
+        return be.gemm_f32x3(xi, w2, bias, alpha_dev=a_scale, exact_a=True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, xi, a_scale, a_zp, w2 = ctx.saved_tensors
+        be = backend.get()
+        gy = gy.contiguous()
+        gx = gs = gw = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            gxs = be.gemm_f32x3_planes(gy, _planes(be, w2.t()), w2.shape[0]) if WEIGHT_PLANES else be.gemm_f32x3(gy, w2.t())
+            gx, gs, _ = be.uniform_fake_quant_backward(gxs, x2, a_scale, a_zp, ctx.n_bits, False, ctx.needs_input_grad[1], False)
+            if not ctx.needs_input_grad[0]:
+                gx = None
+        if ctx.needs_input_grad[3]:
+            gw = be.gemm_f32x3(gy.t(), xi.t(), alpha_dev=a_scale, exact_b=True)      # s_a * dL/dy^T . x_int
+        gb = gy.sum(0) if ctx.needs_input_grad[4] else None
+        return gx, gs, None, gw, gb, None
+
+
+def linear(x_sim, w_sim, bias):
+    """F.linear(x_sim, w_sim, bias) for a BRECQ iteration."""
+    lead = x_sim.shape[:-1]
+    x2 = x_sim.reshape(-1, x_sim.shape[-1])
+    if not (torch.is_grad_enabled() and _usable(x2, w_sim, bias)):
+        return F.linear(x_sim, w_sim, bias)
+    return _LinearFn.apply(x2.contiguous(), w_sim.contiguous(), bias).view(*lead, w_sim.shape[0])
+
+
+def quant_linear(x, a_quantizer, w_sim, bias):
+    """F.linear(a_quantizer(x), w_sim, bias) for a BRECQ iteration; fuses a per-tensor asymmetric uniform activation quantiser."""
+    from .quantizers.uniform import UniformQuantizer
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    aq = a_quantizer
+    fused = (INT_ACT and type(aq) is UniformQuantizer and aq.training_mode and not aq.sym and aq.n_bits < 8
+             and aq.scale.numel() == 1 and torch.is_grad_enabled() and _usable(x2, w_sim, bias))
+    if not fused:
+        return linear(aq(x), w_sim, bias)
+    out = _QuantLinearFn.apply(x2.contiguous(), aq.scale.view(1), aq.zero_point.view(1), w_sim.contiguous(), bias, aq.n_bits)
+    return out.view(*lead, w_sim.shape[0])

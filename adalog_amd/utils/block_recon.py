@@ -213,7 +213,7 @@ class BlockReconstructor(QuantCalibrator):
                     optim_steps()
                 if a_scheduler is not None:
                     a_scheduler.step()
-                loss_func.cur = (static_rec, static_rnd)
+                loss_func.cur = (static_rec.detach(), static_rnd.detach())
                 loss_func.log(static_rec, static_rnd)
                 if iter_hook is not None:
                     iter_hook(it + 1, loss_func)
@@ -356,7 +356,9 @@ class LossFunction:
     def __call__(self, pred, tgt):
         rec_loss = self.rec_term(pred, tgt)
         round_loss = self.round_term()
-        self.cur = (rec_loss, round_loss)                # this iteration's two terms (device scalars; read only by tests / logs)
+        # this iteration's two terms (detached device scalars, read only by tests / logs: a reference to the live loss would
+        # keep the iteration's autograd graph alive and break the HIP-graph capture of the next one)
+        self.cur = (rec_loss.detach(), round_loss.detach() if torch.is_tensor(round_loss) else round_loss)
         self.log(rec_loss, round_loss)
         return rec_loss + round_loss
 

@@ -298,6 +298,10 @@ int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, 
  *   read on the device, so a captured HIP graph of a BRECQ iteration follows the decaying b.  workspace: 1024 floats.
  * The per-tensor parameter gradients and the loss value are reduced inside the producing kernel: every block leaves an
  *   fp32 partial, and the last block to arrive (device ticket counter) sums them in fp64 in a fixed order. */
+/* y = clamp(rne(x/s) + rne(zp), 0, 2L-1) - rne(zp) as fp32 (per-tensor s, zp): the exact integer part of reference
+ *   quantizers/uniform.py:29-35, i.e. the fake-quantised activation before its scale -- the integer operand of adalog_gemm_f32x3. */
+int adalog_uniform_int_f32(const float* x, float* y, int64_t n, const float* scale, const float* zero_point, int n_bits,
+                           void* stream);
 int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, int64_t inner);
 int adalog_uniform_fq_backward(const float* gy, const float* x, float* gx, int64_t n, const float* scale,
                                const float* zero_point, int64_t n_channels, int64_t inner, int n_bits, int symmetric,
@@ -326,6 +330,35 @@ int adalog_rec_loss_backward(const float* pred, const float* tgt, int64_t n, flo
  *   device).  The allocation synchronises the device: call it before capturing BRECQ launches into a HIP graph
  *   (the training loop of reference utils/block_recon.py:114-127 is replayed from one). */
 int adalog_brecq_init(void);
+
+
+/* ---- K17b  BRECQ's training-mode contractions (csrc/brecq_gemm.hip).  Replaces the fp32 library GEMMs of one iteration of
+ *   reference utils/block_recon.py:116-121 -- F.linear(x_sim, w_sim, bias) (quant_layers/linear.py:46-50) and A_sim @ B_sim
+ *   (quant_layers/matmul.py:41-44), forward and both backward products each:
+ *     C[g][m][n] = alpha * (alpha_dev ? alpha_dev[0] : 1) * sum_k opA(A[g])[m][k] * opB(B[g])[n][k]  + bias[n]
+ *     opA(A)[m][k] = transA ? A[k*lda + m] : A[m*lda + k],   opB(B)[n][k] = transB ? B[k*ldb + n] : B[n*ldb + k]
+ *   fp32 operands, fp32 result, fp32-class accuracy: each operand element is split in registers into three bf16 terms
+ *   (exact: 24 significand bits) and the six bf16 MFMA products of weight >= 2^-24 are accumulated in fp32.
+ *   Requirements: pointers 16-byte aligned; lda, ldb, ldc, sAg, sBg, sCg (element strides between the G groups) multiples of
+ *   4; N % 4 == 0, with a bias N % 16 == 0; an operand matrix below 2 GiB.  allow_split: the library may split K into
+ *   fixed ranges (few-tile, long-K products such as dL/dw) and add the partial tiles in a fixed order; workspace then holds
+ *   adalog_gemm_f32x3_workspace_bytes(...) bytes (0 = none needed).  exactA / exactB: the caller guarantees that the operand's
+ *   values are exact in bf16 (integers |v| <= 256: the integer part q - z of a uniformly fake-quantised activation, whose
+ *   trained scale is then handed over as alpha_dev): the forward (exactA, both operands K-contiguous) and dL/dw (exactB, both
+ *   K-major) forms then take 3 products instead of 6; the result is the same either way. */
+int64_t adalog_gemm_f32x3_workspace_bytes(int M, int N, int K, int G, int allow_split, int exactA, int exactB, int transA,
+                                          int transB);
+int adalog_gemm_f32x3(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C, int64_t ldc,
+                      int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, const float* bias, float alpha,
+                      const float* alpha_dev, int allow_split, int exactA, int exactB, float* workspace, void* stream);
+/* The same product with B ALREADY SPLIT into three bf16 planes by adalog_pack_split3_bf16 (row n of group g at
+ *   Bp + (g*N + n)*3*Kt: hi | mid | lo of Kt >= K elements each, zero beyond K, Kt % 32 == 0) -- for an operand that every row
+ *   tile re-reads (the soft-rounded weights w_sim / w_sim^T of reference quant_layers/linear.py:46-50): the split then runs
+ *   once per iteration in the packer instead of once per row tile in the GEMM's registers.  A is K-contiguous. */
+int64_t adalog_gemm_f32x3_planes_workspace_bytes(int M, int N, int K, int G, int allow_split, int exactA);
+int adalog_gemm_f32x3_planes(const float* A, int64_t lda, const void* Bp, int64_t Kt, float* C, int64_t ldc, int M, int N, int K,
+                             int G, int64_t sAg, int64_t sCg, const float* bias, float alpha, const float* alpha_dev,
+                             int allow_split, int exactA, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

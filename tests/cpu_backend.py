@@ -493,3 +493,32 @@ def gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid):
 
 def gemm_win_ok(dtype, M, N, G, gmod, ref_div, k_valid):
     return False                                       # the CPU stand-in has one GEMM path: 64-byte rows everywhere
+
+
+def gemm_f32x3_ok(a, b, bias=None):
+    return a.shape[-1] == b.shape[-1]
+
+
+def gemm_f32x3(a, b, bias=None, alpha=1.0, allow_split=True, alpha_dev=None, exact_a=False, exact_b=False):
+    """Specification of adalog_gemm_f32x3: a @ b^T (+ bias) in fp64, rounded once (the kernel's result is within fp32
+    accumulation noise of it)."""
+    out = alpha * (a.double() @ b.double().transpose(-2, -1))
+    if alpha_dev is not None:
+        out = out * alpha_dev.double().reshape(())
+    if bias is not None:
+        out = out + bias.double()
+    return out.float()
+
+
+def gemm_f32x3_planes(a, bp, K, bias=None, alpha=1.0, allow_split=True, alpha_dev=None, exact_a=False):
+    """Specification of adalog_gemm_f32x3_planes: bp = pack_split3(B) ([1, G, N, 3*Kt] bf16, hi | mid | lo per row)."""
+    Kt = bp.shape[-1] // 3
+    b = (bp[0, ..., :Kt].double() + bp[0, ..., Kt:2 * Kt].double() + bp[0, ..., 2 * Kt:].double())[..., :K]
+    if a.dim() == 2:
+        b = b[0]
+    return gemm_f32x3(a, b.float(), bias, alpha, allow_split, alpha_dev)
+
+
+def uniform_int(x, scale, zero_point, n_bits):
+    z = torch.round(zero_point.reshape(()))
+    return (torch.round(x / scale.reshape(())) + z).clamp(0, 2 ** n_bits - 1) - z
