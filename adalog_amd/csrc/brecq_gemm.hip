@@ -553,48 +553,44 @@ static const BqShape BQ_SHAPES[4] = {
     {1, 2, 2, 64, 128, 3, 0.60, "bq_gemm<64x128,4w>"},
 };
 
-// Tile shape and K split, from a small time model (microseconds; constants from the MI355X measurements in profiles/r04_notes.md):
-// a K-step of 128 x 256 outputs costs ~0.75 us of a CU's matrix pipe when two waves per SIMD overlap their split arithmetic with
-// each other's MFMAs and ~1.45 us when a wave has a SIMD to itself; ~3 us fixed per work item; a split product pays its partial
-// tiles' round trip through the cache hierarchy at ~3 TB/s.
+// workgroups of a shape that fit the chip at once
+int bq_slots(int shape, bool bp) {
+    const BqShape& sh = BQ_SHAPES[shape];
+    int per_cu = (160 * 1024) / (BQ_NS * (sh.bm * 64 + sh.bn * (bp ? 96 : 64)));
+    if (per_cu > sh.per_cu) per_cu = sh.per_cu;
+    if (per_cu < 1) per_cu = 1;
+    return bq_cus() * per_cu;
+}
+
+// Tile shape and K split.  Rules from the MI355X measurements of tools/lab/bq_lab (profiles/r04_notes.md): the products of a
+// BRECQ iteration are small (5-45 GFLOP of bf16 work), so what decides is how evenly the work items cover the chip: 128 x 128
+// tiles, two workgroups per CU, whenever that gives >= ~400 items; otherwise the K range is cut so that it does (the partial tiles
+// are added in a fixed order), provided every range keeps >= 24 K-steps; few-tile products (dL/dw) take 64 x 128 tiles.
 BqPlan bq_plan(int M, int N, int K, int G, int allow_split, int products, int bp = 0) {
-    const int cus = bq_cus();
+    (void)products;
     const int nk = cdiv(K, BQ_KS);
-    BqPlan best = {2, 1, cdiv(M, 128), cdiv(N, 128), nk, 1};
-    double best_t = 1e300;
-    int force = -1, force_s = 0;
-    if (const char* e = getenv("ADALOG_BQ_SHAPE")) force = atoi(e);
-    if (const char* e = getenv("ADALOG_BQ_SPLIT")) force_s = atoi(e);
-    const double out_mb = (double)G * M * N * 4.0 / 1.0e6;
-    const double pw = products / 6.0;
-    for (int c = 0; c < 4; ++c) {
-        if (force >= 0 && c != force) continue;
-        const BqShape& sh = BQ_SHAPES[c];
-        const int MT = cdiv(M, sh.bm), NT = cdiv(N, sh.bn);
-        const int64_t tiles = (int64_t)MT * NT * G;
-        int per_cu = (160 * 1024) / (BQ_NS * (sh.bm * 64 + sh.bn * (bp ? 96 : 64)));   // (pre-split B: 96 bytes per row and stage)
-        if (per_cu > sh.per_cu) per_cu = sh.per_cu;
-        if (per_cu < 1) per_cu = 1;
-        const int slots = cus * per_cu;
-        int smax = allow_split ? nk / 6 : 1;                            // at least 6 K-steps per split
-        if (smax > 64) smax = 64;
-        if (smax < 1) smax = 1;
-        for (int S = 1; S <= smax; ++S) {
-            if (force_s > 0 && allow_split && S != (force_s > smax ? smax : force_s)) continue;
-            const int64_t items = tiles * S;
-            // items run `per_cu` at a time on a CU; a CU's rate is the overlapped one when >= 2 waves share each SIMD
-            const int64_t per = (items + cus - 1) / cus;                 // items on the busiest CU
-            const bool overlapped = sh.wn == 4 || (per >= 2 && per_cu >= 2) || bp;
-            const double step = (overlapped ? 0.75 : 1.45) * (0.3 + 0.7 * pw) * (sh.bm * sh.bn / (128.0 * 256.0)) / sh.speed;
-            double t = (double)per * ((double)cdiv(nk, S) * step) + 3.0 * (double)((per + per_cu - 1) / per_cu);
-            if (S > 1) t += 2.0 + (2.0 * S + 1.0) * out_mb / 3.0;       // partial tiles written and read back, result written
-            if (t < best_t) {
-                best_t = t;
-                best = {c, S, MT, NT, nk, (int)(items < slots ? items : slots)};
-            }
-        }
+    int shape = 2;
+    if (const char* e = getenv("ADALOG_BQ_SHAPE")) { const int v = atoi(e); if (v >= 0 && v < 4) shape = v; else shape = -1; }
+    else {
+        const int64_t t2 = (int64_t)cdiv(M, 128) * cdiv(N, 128) * G;
+        shape = t2 >= 64 ? 2 : 3;
     }
-    return best;
+    if (shape < 0) shape = 2;
+    const BqShape& sh = BQ_SHAPES[shape];
+    const int MT = cdiv(M, sh.bm), NT = cdiv(N, sh.bn);
+    const int64_t tiles = (int64_t)MT * NT * G;
+    const int slots = bq_slots(shape, bp != 0);
+    int S = 1;
+    if (allow_split && tiles < 400) {
+        S = (int)((480 + tiles / 2) / tiles);
+        int smax = nk / 24;
+        if (smax > 16) smax = 16;
+        if (S > smax) S = smax;
+        if (S < 1) S = 1;
+    }
+    if (const char* e = getenv("ADALOG_BQ_SPLIT")) { const int v = atoi(e); if (v >= 1 && allow_split) S = v > nk ? nk : v; }
+    const int64_t items = tiles * S;
+    return {shape, S, MT, NT, nk, (int)(items < slots ? items : slots)};
 }
 
 template <int RI, int CJ, int WN, bool TA, bool TB, int PA, int PB, bool KT>
