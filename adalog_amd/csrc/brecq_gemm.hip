@@ -456,6 +456,7 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
         float* Cb = p.C + (p.S > 1 ? ((int64_t)tl.s * p.G + tl.g) * (int64_t)p.M * p.N : (int64_t)tl.g * p.sCg);
         const int64_t ldc = p.S > 1 ? p.N : p.ldc;
         const float al = p.S > 1 ? 1.0f : alpha;
+        const bool vec_store = ((p.N | (int)ldc | (int)(p.S > 1 ? 0 : p.sCg)) & 3) == 0;
         // The bias of the wave's columns depends on the lane only through fkg: it comes through the SCALAR cache (two 16-float
         // loads per 32 columns, then a select).  A vector load here would do: but any VGPR-destination VMEM load inside the
         // persistent loop makes hipcc's waitcnt pass put a vmcnt(0) at the head of the K loop, which drains the DMA ring.
@@ -499,7 +500,14 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
 #if defined(BQ_LAB_NOEPI)
                     if (v.x == 123.456f)
 #endif
-                    if (m < p.M && n < p.N) *reinterpret_cast<float4*>(Crow + n) = v;
+                    if (vec_store) {
+                        if (m < p.M && n < p.N) *reinterpret_cast<float4*>(Crow + n) = v;
+                    } else if (m < p.M) {                 // N or ldc not a multiple of 4 (attention: 197 keys): element stores
+                        if (n < p.N) Crow[n] = v.x;
+                        if (n + 1 < p.N) Crow[n + 1] = v.y;
+                        if (n + 2 < p.N) Crow[n + 2] = v.z;
+                        if (n + 3 < p.N) Crow[n + 3] = v.w;
+                    }
                 }
             }
         }
@@ -513,6 +521,16 @@ __global__ __launch_bounds__(256) void k_bq_reduce(const float* __restrict__ par
                                                    float* __restrict__ C, int64_t ldc, int64_t sCg, const float* __restrict__ bias,
                                                    float alpha, const float* __restrict__ alpha_dev) {
     const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.0f);
+    if (((N | (int)ldc | (int)sCg) & 3) != 0) {          // element form (N, ldc or the group stride not a multiple of 4)
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < gmn; e += (int64_t)gridDim.x * 256) {
+            float acc = part[e];
+            for (int s = 1; s < S; ++s) acc += part[(int64_t)s * gmn + e];
+            const int64_t g = e / ((int64_t)M * N), r = e - g * (int64_t)M * N;
+            const int m = (int)(r / N), n = (int)(r - (int64_t)m * N);
+            C[g * sCg + (int64_t)m * ldc + n] = acc * a + (bias ? bias[n] : 0.0f);
+        }
+        return;
+    }
     const int64_t n4 = gmn >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 acc = reinterpret_cast<const float4*>(part)[i];
@@ -648,6 +666,8 @@ extern "C" int64_t adalog_gemm_f32x3_workspace_bytes(int M, int N, int K, int G,
 static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_t ldb, int transB, int64_t bplane, float* C,
                   int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, const float* bias, float alpha,
                   const float* alpha_dev, int allow_split, int pa, int pb, float* workspace, void* stream) {
+    // the integer forward form is built without the K-tail masking: with K % 16 != 0 it runs as a general product (same result)
+    if (pa == 1 && pb == 3 && (K & (BQ_KS - 1)) != 0) pa = 3;
     const int products = (pa == 3 && pb != 1) ? 6 : (pa == 1 && pb == 1) ? 1 : 3;
     const BqPlan pl = bq_plan(M, N, K, G, allow_split, products, pb == 0);
     ADALOG_ARG_CHECK(pl.S == 1 || workspace, "gemm_f32x3: the split product needs its workspace");
@@ -694,8 +714,9 @@ extern "C" int adalog_gemm_f32x3(const float* A, int64_t lda, int transA, const 
                                  float* workspace, void* stream) {
     if (M == 0 || N == 0 || G == 0) return 0;
     ADALOG_ARG_CHECK(A && B && C && M > 0 && N > 0 && K > 0 && G > 0, "gemm_f32x3: bad arguments");
+    // (rows need not be 16-byte aligned: the LDS-DMA requests are dword-aligned 16-byte loads; N, ldc or sCg off a multiple
+    // of 4 -- attention products with 197 tokens -- take the element-store epilogue)
     ADALOG_ARG_CHECK((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) == 0, "gemm_f32x3: operands must be 16-byte aligned");
-    ADALOG_ARG_CHECK(((lda | ldb | ldc | sAg | sBg | sCg) & 3) == 0 && (N & 3) == 0, "gemm_f32x3: strides and N must be multiples of 4");
     ADALOG_ARG_CHECK(!bias || (N & 15) == 0, "gemm_f32x3: a fused bias needs N to be a multiple of 16");
     ADALOG_ARG_CHECK(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, "gemm_f32x3: leading dimensions too small");
     ADALOG_ARG_CHECK((int64_t)(transA ? K : M) * lda * 4 < 0x7fffffffLL && (int64_t)(transB ? K : N) * ldb * 4 < 0x7fffffffLL,

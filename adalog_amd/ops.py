@@ -877,7 +877,7 @@ def _mat_layout(t: torch.Tensor):
         for (n0, s0), (n1, s1) in zip(lead[:-1], lead[1:]):
             if s0 != s1 * n1:
                 return None
-    if ld % 4 or gs % 4 or t.data_ptr() % 16:
+    if t.data_ptr() % 16:
         return None
     return trans, ld, G, gs
 
@@ -888,7 +888,7 @@ def gemm_f32x3_ok(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor]
     if la is None or lb is None or a.shape[-1] != b.shape[-1] or la[2] != lb[2]:
         return False
     M, N = a.shape[-2], b.shape[-2]
-    if N % 4 or a.numel() == 0 or b.numel() == 0:
+    if a.numel() == 0 or b.numel() == 0:
         return False
     if bias is not None and (N % 16 or bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16
                              or bias.numel() != N):

@@ -12,7 +12,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import backend, search
+from .. import backend, search, train_mm
 from ..ops import BF16, BF16_FP8, FP8, I8, Strided, pad_k  # noqa: F401
 from ..quantizers.logarithm import AdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
@@ -48,7 +48,10 @@ class MinMaxQuantMatMul(nn.Module):
 
     def quant_forward(self, A, B):
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
-        return self.quant_input_A(A) @ self.quant_input_B(B)
+        a_sim, b_sim = self.quant_input_A(A), self.quant_input_B(B)
+        if a_sim.requires_grad or b_sim.requires_grad:       # a BRECQ iteration: the contractions run on csrc/brecq_gemm.hip
+            return train_mm.matmul(a_sim, b_sim)
+        return a_sim @ b_sim
 
 
 class PTQSLQuantMatMul(MinMaxQuantMatMul):

@@ -22,7 +22,9 @@ import torch.nn.functional as F
 from . import backend
 
 ENABLED = os.environ.get("ADALOG_BRECQ_MM", "1") != "0"
-WEIGHT_PLANES = os.environ.get("ADALOG_BRECQ_WPLANES", "1") != "0"      # pre-split w_sim (0: split in the GEMM's registers)
+# pre-split w_sim planes (1) or the split in the GEMM's registers (0, default: measured 571 against 546 it/s on a deit_small block --
+# the eight packer launches per iteration cost more than the per-tile splits they save)
+WEIGHT_PLANES = os.environ.get("ADALOG_BRECQ_WPLANES", "0") != "0"
 INT_ACT = os.environ.get("ADALOG_BRECQ_INT_ACT", "1") != "0"            # integer activation operand (0: s_a * x_int as fp32)
 
 
@@ -121,3 +123,35 @@ def quant_linear(x, a_quantizer, w_sim, bias):
         return linear(aq(x), w_sim, bias)
     out = _QuantLinearFn.apply(x2.contiguous(), aq.scale.view(1), aq.zero_point.view(1), w_sim.contiguous(), bias, aq.n_bits)
     return out.view(*lead, w_sim.shape[0])
+
+
+class _MatmulFn(torch.autograd.Function):
+    """A @ B batched over the leading dims (the attention products q.k^T and softmax.v, reference quant_layers/matmul.py:41-44):
+    forward and both backward products on adalog_gemm_f32x3, every operand read in place (K-contiguous or K-major)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        return backend.get().gemm_f32x3(A, B.transpose(-1, -2))
+
+    @staticmethod
+    def backward(ctx, gy):
+        A, B = ctx.saved_tensors
+        be = backend.get()
+        gy = gy.contiguous()
+        gA = be.gemm_f32x3(gy, B) if ctx.needs_input_grad[0] else None                       # gy . B^T
+        gB = be.gemm_f32x3(A.transpose(-1, -2), gy.transpose(-1, -2)) if ctx.needs_input_grad[1] else None   # A^T . gy
+        return gA, gB
+
+
+def matmul(A_sim, B_sim):
+    """A_sim @ B_sim for a BRECQ iteration."""
+    ok = (ENABLED and torch.is_grad_enabled() and A_sim.is_cuda and A_sim.dtype == torch.float32 and B_sim.dtype == torch.float32
+          and A_sim.dim() >= 3 and A_sim.shape[:-2] == B_sim.shape[:-2] and hasattr(backend.get(), "gemm_f32x3"))
+    if ok:
+        A_sim, B_sim = A_sim.contiguous(), B_sim.contiguous()
+        be = backend.get()
+        ok = be.gemm_f32x3_ok(A_sim, B_sim.transpose(-1, -2)) and be.gemm_f32x3_ok(A_sim.transpose(-1, -2), A_sim.transpose(-1, -2))
+    if not ok:
+        return A_sim @ B_sim
+    return _MatmulFn.apply(A_sim, B_sim)

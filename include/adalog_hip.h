@@ -339,8 +339,8 @@ int adalog_brecq_init(void);
  *     opA(A)[m][k] = transA ? A[k*lda + m] : A[m*lda + k],   opB(B)[n][k] = transB ? B[k*ldb + n] : B[n*ldb + k]
  *   fp32 operands, fp32 result, fp32-class accuracy: each operand element is split in registers into three bf16 terms
  *   (exact: 24 significand bits) and the six bf16 MFMA products of weight >= 2^-24 are accumulated in fp32.
- *   Requirements: pointers 16-byte aligned; lda, ldb, ldc, sAg, sBg, sCg (element strides between the G groups) multiples of
- *   4; N % 4 == 0, with a bias N % 16 == 0; an operand matrix below 2 GiB.  allow_split: the library may split K into
+ *   Requirements: base pointers 16-byte aligned; with a bias N % 16 == 0; an operand matrix below 2 GiB.  Rows need not be
+ *   16-byte aligned (the attention products have 197 tokens); N, ldc or sCg off a multiple of 4 take an element-store epilogue.  allow_split: the library may split K into
  *   fixed ranges (few-tile, long-K products such as dL/dw) and add the partial tiles in a fixed order; workspace then holds
  *   adalog_gemm_f32x3_workspace_bytes(...) bytes (0 = none needed).  exactA / exactB: the caller guarantees that the operand's
  *   values are exact in bf16 (integers |v| <= 256: the integer part q - z of a uniformly fake-quantised activation, whose

@@ -1239,3 +1239,127 @@ def test_round_loss_multi_matches_per_tensor(ops):
             torch.testing.assert_close(gg.cpu(), gr, rtol=1e-3, atol=1e-7)
     loss_b, _ = ops.round_loss_multi([a.to(DEV) for a in alphas], torch.tensor([2.0]).to(DEV), 0.01)    # exponent on the device
     torch.testing.assert_close(loss_b, loss)
+
+
+# ------------------------------------------------------------------------------------------------ K17b: BRECQ contractions
+def _last_kernel():
+    from adalog_amd import _lib
+    return _lib.load().adalog_last_kernel().decode()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 16), (100, 36, 40), (300, 260, 52), (1000, 16, 1000), (33, 1000, 384), (129, 1028, 36),
+                                   (197, 197, 64), (6304, 384, 384)])
+def test_gemm_f32x3_every_orientation(ops, M, N, K):
+    """adalog_gemm_f32x3 against its fp64 specification: both operands in both memory orientations, with and without the
+    fused bias, ragged M / N / K (K tails, N off a multiple of 4), at fp32-class accuracy (rocBLAS fp32 is at 5e-7 .. 3e-6)."""
+    gen = g(7000 + M + N + K)
+    for ta in (0, 1):
+        for tb in (0, 1):
+            for with_bias in (False, True):
+                if with_bias and N % 16:
+                    continue
+                a = (torch.randn(K, M, generator=gen).to(DEV).t() if ta else torch.randn(M, K, generator=gen).to(DEV))
+                b = (torch.randn(K, N, generator=gen).to(DEV).t() if tb else torch.randn(N, K, generator=gen).to(DEV))
+                bias = torch.randn(N, generator=gen).to(DEV) if with_bias else None
+                assert ops.gemm_f32x3_ok(a, b, bias)
+                out = ops.gemm_f32x3(a, b, bias)
+                assert _last_kernel().startswith("bq_gemm<")
+                ref = CB.gemm_f32x3(a.cpu(), b.cpu(), None if bias is None else bias.cpu()).double()
+                assert rel_err(out.cpu().double(), ref) <= 2e-6, (M, N, K, ta, tb, with_bias)
+
+
+def test_gemm_f32x3_integer_operand_and_planes(ops):
+    """The integer-activation forms (forward: A = x_int K-contiguous; dL/dw: B = x_int K-major; scale as a device scalar) and the
+    pre-split weight planes give the same product as the general form."""
+    gen = g(7100)
+    for (M, N, K) in [(300, 64, 48), (6304, 384, 384), (200, 144, 40)]:
+        xi = torch.randint(-15, 16, (M, K), generator=gen).float().to(DEV)
+        w = torch.randn(N, K, generator=gen).to(DEV)
+        sc = torch.tensor([0.37], device=DEV)
+        bias = torch.randn(N, generator=gen).to(DEV) if N % 16 == 0 else None
+        ref = CB.gemm_f32x3(xi.cpu(), w.cpu(), None if bias is None else bias.cpu(), alpha_dev=sc.cpu()).double()
+        out = ops.gemm_f32x3(xi, w, bias, alpha_dev=sc, exact_a=True)
+        assert rel_err(out.cpu().double(), ref) <= 2e-6
+        wp = ops.pack_split3(w.view(1, N, K), 64)
+        for ex in (False, True):
+            outp = ops.gemm_f32x3_planes(xi, wp, K, bias, alpha_dev=sc, exact_a=ex)
+            assert rel_err(outp.cpu().double(), ref) <= 2e-6
+        gy = torch.randn(M, N, generator=gen).to(DEV)                      # dL/dw = s * gy^T . x_int
+        gw = ops.gemm_f32x3(gy.t(), xi.t(), alpha_dev=sc, exact_b=True)
+        refw = CB.gemm_f32x3(gy.cpu().t(), xi.cpu().t(), alpha_dev=sc.cpu()).double()
+        assert rel_err(gw.cpu().double(), refw) <= 2e-6
+
+
+def test_gemm_f32x3_split_k_is_bit_reproducible(ops):
+    """dL/dw-shaped products are split along K and reduced in a fixed order: two launches give identical bits."""
+    gen = g(7200)
+    gy = torch.randn(6304, 1152, generator=gen).to(DEV)
+    x = torch.randn(6304, 384, generator=gen).to(DEV)
+    o1 = ops.gemm_f32x3(gy.t(), x.t())
+    o2 = ops.gemm_f32x3(gy.t(), x.t())
+    assert torch.equal(o1, o2)
+    ref = (gy.double().t() @ x.double()).cpu()
+    assert rel_err(o1.cpu().double(), ref) <= 2e-6
+
+
+def test_gemm_f32x3_attention_products(ops):
+    """The four attention products of a BRECQ iteration at 197 tokens (rows not 16-byte aligned, N off a multiple of 4)."""
+    gen = g(7300)
+    for (G, S, C) in [((2, 6), 197, 64), ((3, 4), 49, 32)]:
+        q = torch.randn(*G, S, C, generator=gen).to(DEV)
+        kt = torch.randn(*G, C, S, generator=gen).to(DEV)
+        v = torch.randn(*G, S, C, generator=gen).to(DEV)
+        s_ = ops.gemm_f32x3(q, kt.transpose(-1, -2))
+        assert rel_err(s_.cpu().double(), (q.double() @ kt.double()).cpu()) <= 2e-6
+        pr = torch.softmax(s_, -1)
+        o = ops.gemm_f32x3(pr, v.transpose(-1, -2))
+        assert rel_err(o.cpu().double(), (pr.double() @ v.double()).cpu()) <= 2e-6
+        gy = torch.randn(*G, S, C, generator=gen).to(DEV)
+        gp = ops.gemm_f32x3(gy, v)
+        assert rel_err(gp.cpu().double(), (gy.double() @ v.double().transpose(-1, -2)).cpu()) <= 2e-6
+        gv = ops.gemm_f32x3(pr.transpose(-1, -2), gy.transpose(-1, -2))
+        assert rel_err(gv.cpu().double(), (pr.double().transpose(-1, -2) @ gy.double()).cpu()) <= 2e-6
+
+
+def test_brecq_iteration_runs_no_library_gemm():
+    """Every contraction of a BRECQ iteration of a transformer block runs on csrc/brecq_gemm.hip: the kernel trace of one
+    forward/backward holds k_bq_gemm launches and no rocBLAS / hipBLASLt (`Cijk_*`) kernel."""
+    import copy
+    from torch.profiler import ProfilerActivity, profile
+    from adalog_amd import backend
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import VisionTransformer
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    import importlib.util, os
+    backend.set_backend(None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cfg4k", os.path.join(root, "configs", "4bit.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cfg = mod.Config()
+    cfg.search_round, cfg.steps = 1, 2
+    torch.manual_seed(3)
+    model = VisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=1, num_heads=2, num_classes=16).eval()
+    for p_ in model.parameters():
+        p_.data.mul_(6.0)
+    model.to(DEV)
+    full = copy.deepcopy(model)
+    x = torch.randn(16, 3, 64, 64).to(DEV)
+    loader = [(x[:8], None), (x[8:], None)]
+    model = wrap_modules_in_net(model, cfg, reparam=True)
+    QuantCalibrator(model, loader).batching_quant_calib()
+    model = wrap_reparamed_modules_in_net(model)
+    rec = BlockReconstructor(model, full, loader)
+    name = "blocks.0"
+    block, fblock = rec.blocks[name], rec.full_blocks[name]
+    rec.init_block_raw_data(block, fblock, name, torch.device(DEV))
+    os.environ["ADALOG_BRECQ_GRAPH"] = "0"
+    try:
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            rec.reconstruct_single_block(name, block, torch.device(DEV), batch_size=8, iters=3, quant_act=True)
+            torch.cuda.synchronize()
+    finally:
+        os.environ.pop("ADALOG_BRECQ_GRAPH", None)
+    names = [e.key for e in prof.key_averages()]
+    assert any("k_bq_gemm" in n for n in names), names
+    assert not any(n.startswith("Cijk_") for n in names), [n for n in names if n.startswith("Cijk_")]

@@ -18,6 +18,21 @@ for (M,N,K) in [(64,128,16),(100,36,40),(197,64,197*0+200),(300,260,52),(1000,16
         err = ((out.double()-ex).abs().max()/ex.abs().max()).item()
         worst=max(worst,err)
         if err>2e-6: print('BAD',M,N,K,ta,tb,bias,err)
+# attention shapes: 197 tokens, head dim 64, unaligned rows / N
+for (G,S,C) in [(12,197,64),(6,49,32)]:
+    q=torch.randn(G,S,C,device=dev); k=torch.randn(G,S,C,device=dev); v=torch.randn(G,S,C,device=dev)
+    kt=k.transpose(-1,-2).contiguous()          # [G, C, S] as the layer hands it over
+    out=ops.gemm_f32x3(q, kt.transpose(-1,-2)); ex=q.double()@kt.double()
+    e1=((out.double()-ex).abs().max()/ex.abs().max()).item()
+    pr=torch.softmax(out,-1)
+    o2=ops.gemm_f32x3(pr, v.transpose(-1,-2)); ex2=pr.double()@v.double()
+    e2=((o2.double()-ex2).abs().max()/ex2.abs().max()).item()
+    gy=torch.randn(G,S,C,device=dev)
+    gp=ops.gemm_f32x3(gy, v); ex3=gy.double()@v.double().transpose(-1,-2)            # dL/dprobs = gy . v^T
+    e3=((gp.double()-ex3).abs().max()/ex3.abs().max()).item()
+    gv=ops.gemm_f32x3(pr.transpose(-1,-2), gy.transpose(-1,-2)); ex4=pr.double().transpose(-1,-2)@gy.double()   # dL/dv = probs^T . gy
+    e4=((gv.double()-ex4).abs().max()/ex4.abs().max()).item()
+    print('attention', G,S,C, e1,e2,e3,e4); worst=max(worst,e1,e2,e3,e4)
 # batched
 a=torch.randn(6,197,64,device=dev); b=torch.randn(6,200,64,device=dev)
 out=ops.gemm_f32x3(a,b); ex=a.double()@b.double().transpose(-1,-2)
