@@ -339,17 +339,23 @@ __global__ __launch_bounds__(256) void k_uniform_int(const float* __restrict__ x
     }
 }
 
-// Ticket counters for the "last block finishes" reductions: a ring of zeroed device words, one handed to each launch
-// (the last block puts its word back to zero).  Launches that overlap in time hold different slots as long as fewer
-// than RING of them are in flight.
+// Ticket counters for the "last block finishes" reductions: zeroed device words, handed out round-robin at enqueue time (the
+// launch's last block puts its words back to zero).  A word may be re-issued only to a launch that runs AFTER the one holding
+// it, which stream order guarantees on ONE stream; launches enqueued far ahead on two streams (the calibrator's lanes) could
+// otherwise hold the same words at the same time.  So the ring of a device is cut into SUB sub-rings and every stream gets its
+// own (first come, first served; streams beyond SUB share the last one, as all streams did before).
 constexpr int RING = 1024;
+constexpr int SUB = 4;                      // sub-rings per device (streams that enqueue "last block finishes" kernels concurrently)
+constexpr int SUBLEN = RING / SUB;          // 256 words: >= 4 requests of the largest size (64) before a word comes round again
 constexpr int MAX_DEV = 16;
 // One ring per device (a ring allocated on device 0 would be a foreign pointer for a kernel on device 1); the table is
 // guarded by a mutex on every call (a few ns against a kernel launch).  The first call for a device allocates and
 // synchronises, which a stream capture does not survive: adalog_brecq_init() makes that call ahead of any capture.
-unsigned int* ticket_slots(int n) {
+unsigned int* ticket_slots(int n, void* stream) {
     static unsigned int* rings[MAX_DEV] = {};
-    static unsigned next[MAX_DEV] = {};
+    static unsigned next[MAX_DEV][SUB] = {};
+    static void* owner[MAX_DEV][SUB] = {};
+    static int owners[MAX_DEV] = {};
     static std::mutex mu;
     int dev = 0;
     if (n < 1 || n > 64 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
@@ -361,12 +367,20 @@ unsigned int* ticket_slots(int n) {
             return nullptr;
         rings[dev] = p;
     }
-    if (next[dev] % RING + n > RING) next[dev] += RING - next[dev] % RING;      // n consecutive words: do not wrap inside a request
-    unsigned int* r = rings[dev] + next[dev] % RING;
-    next[dev] += n;
+    int sub = -1;
+    for (int i = 0; i < owners[dev]; ++i)
+        if (owner[dev][i] == stream) { sub = i; break; }
+    if (sub < 0) {
+        if (owners[dev] < SUB) { sub = owners[dev]++; owner[dev][sub] = stream; }
+        else sub = SUB - 1;
+    }
+    unsigned& nx = next[dev][sub];
+    if (nx % SUBLEN + n > SUBLEN) nx += SUBLEN - nx % SUBLEN;      // n consecutive words: do not wrap inside a request
+    unsigned int* r = rings[dev] + sub * SUBLEN + nx % SUBLEN;
+    nx += n;
     return r;
 }
-unsigned int* ticket_slot() { return ticket_slots(1); }
+unsigned int* ticket_slot(void* stream) { return ticket_slots(1, stream); }
 
 inline int grid1(int64_t n, int cap = 2048) {
     int64_t b = (n + 255) / 256;
@@ -379,13 +393,14 @@ inline int grid1(int64_t n, int cap = 2048) {
 
 // One zeroed device word of the current device's ring (the launch's last block puts it back to zero): shared with the fused
 // finish + top-k kernel of gemm_score.hip.  nullptr when the ring cannot be allocated.
-extern "C" unsigned int* adalog_ticket_slot(void) { return ticket_slot(); }
-extern "C" unsigned int* adalog_ticket_slots(int n) { return ticket_slots(n); }
+extern "C" unsigned int* adalog_ticket_slot(void) { return ticket_slot(nullptr); }
+extern "C" unsigned int* adalog_ticket_slots(int n) { return ticket_slots(n, nullptr); }
+extern "C" unsigned int* adalog_ticket_slots_on(int n, void* stream) { return ticket_slots(n, stream); }
 
 // Allocates the current device's ticket ring (idempotent).  Call once per device before capturing BRECQ launches into a
 // HIP graph: the allocation synchronises the device, which would invalidate a capture in progress.
 extern "C" int adalog_brecq_init(void) {
-    ADALOG_ARG_CHECK(ticket_slot() != nullptr, "brecq_init: cannot allocate the ticket counters");
+    ADALOG_ARG_CHECK(ticket_slot(nullptr) != nullptr, "brecq_init: cannot allocate the ticket counters");
     return 0;
 }
 
@@ -429,7 +444,7 @@ extern "C" int adalog_uniform_fq_backward(const float* gy, const float* x, float
     float* ps = (gscale || gzp) ? workspace : nullptr;
     float* pz = (gzp && !symmetric) ? workspace + rows * nb : nullptr;
     // per-tensor parameters: the kernel's last block reduces the partials itself (no finish launches)
-    unsigned int* ticket = (ps && n_channels == 1) ? ticket_slot() : nullptr;
+    unsigned int* ticket = (ps && n_channels == 1) ? ticket_slot(stream) : nullptr;
     ADALOG_ARG_CHECK(!(ps && n_channels == 1) || ticket, "uniform_fq_backward: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_uniform_bwd, dim3(nb, gy_), dim3(256), 0, st, gy, x, gx, rows, inner, scale,
                        symmetric ? nullptr : zero_point, n_channels, qmin, qmax, ps, pz, ticket, gscale, gzp);
@@ -451,7 +466,7 @@ extern "C" int adalog_log_fq_backward(const float* gy, const float* x, const flo
     ADALOG_ARG_CHECK(!gscale || workspace, "log_fq_backward: the scale gradient needs a workspace");
     const int nb = grid1(n, 1024);
     hipStream_t st = (hipStream_t)stream;
-    unsigned int* ticket = gscale ? ticket_slot() : nullptr;
+    unsigned int* ticket = gscale ? ticket_slot(stream) : nullptr;
     ADALOG_ARG_CHECK(!gscale || ticket, "log_fq_backward: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_adalog_bwd, dim3(nb), dim3(256), 0, st, gy, x, y, gx, n, scale, q, 1 << n_bits, shift, sub_shift,
                        gscale ? workspace : nullptr, ticket, gscale);
@@ -478,7 +493,7 @@ extern "C" int adalog_round_loss(const float* alpha, int64_t n, float b, const f
     ADALOG_ARG_CHECK(alpha && n >= 1 && (loss == nullptr || workspace), "round_loss: bad arguments");
     const int nb = grid1(n, 1024);
     hipStream_t st = (hipStream_t)stream;
-    unsigned int* ticket = loss ? ticket_slot() : nullptr;
+    unsigned int* ticket = loss ? ticket_slot(stream) : nullptr;
     ADALOG_ARG_CHECK(!loss || ticket, "round_loss: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_round_loss, dim3(nb), dim3(256), 0, st, alpha, n, b, b_dev, loss ? workspace : nullptr, galpha, gscale,
                        gmul, overwrite, ticket, loss);
@@ -492,7 +507,7 @@ extern "C" int adalog_rec_loss(const float* pred, const float* tgt, int64_t n, f
                                void* stream) {
     ADALOG_ARG_CHECK(pred && tgt && loss && workspace && n >= 1, "rec_loss: bad arguments");
     ADALOG_ARG_CHECK((((uintptr_t)pred | (uintptr_t)tgt) & 15) == 0, "rec_loss: pred / tgt must be 16-byte aligned");
-    unsigned int* ticket = ticket_slot();
+    unsigned int* ticket = ticket_slot(stream);
     ADALOG_ARG_CHECK(ticket, "rec_loss: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_rec_loss, dim3(grid1(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, pred, tgt, n, scale, workspace,
                        ticket, loss);
@@ -535,7 +550,7 @@ extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const*
     }
     a.first_block[count] = blocks;
     a.count = count;
-    unsigned int* ticket = ticket_slot();
+    unsigned int* ticket = ticket_slot(stream);
     ADALOG_ARG_CHECK(ticket, "round_loss_multi: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_round_loss_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, b_dev, weight, workspace, ticket,
                        loss);

@@ -13,6 +13,7 @@ extern "C" void adalog_set_error_msg(const char* msg);
 extern "C" void adalog_note_kernel(const char* name);
 extern "C" unsigned int* adalog_ticket_slot(void);      // brecq.hip: a zeroed device word for "last block finishes" kernels
 extern "C" unsigned int* adalog_ticket_slots(int n);    // ... n <= 64 consecutive zeroed words
+extern "C" unsigned int* adalog_ticket_slots_on(int n, void* stream);   // ... from the sub-ring of that stream
 
 #define ADALOG_LAUNCH_CHECK(name)                                   \
     do {                                                            \

@@ -787,7 +787,7 @@ extern "C" int adalog_finish_topk_next(const float* partial, float* scores, int 
     hipStream_t st = (hipStream_t)stream;
     const bool c_ok = (C == 64 || C == 128 || C == 256);
     if (use_fused && cand_inner == 2 && !keep_n && c_ok && Npad == 256 && nh <= 64) {
-        unsigned int* ticket = adalog_ticket_slots(nh);
+        unsigned int* ticket = adalog_ticket_slots_on(nh, stream);
         if (ticket) {
             hipLaunchKernelGGL(k_finish_wgacc_topk, dim3((unsigned)(C * nh)), dim3(256), 0, st, p, (const double*)partial, MT, t, ticket);
             ADALOG_LAUNCH_CHECK("adalog_finish_topk_next");

@@ -603,8 +603,16 @@ def sorted_prefix(x2):
     return SortedPrefix(x2)
 
 
+# the sorted copy + fp64 prefix sums + sort temporaries of a captured tensor cost ~6x its size for the length of a search: above
+# this many bytes (ADALOG_SORTED_MAX_GIB, default 16 of the 288 GB) the self-MSE search falls back to the one-pass kernel
+_SORTED_MAX_BYTES = int(float(__import__("os").environ.get("ADALOG_SORTED_MAX_GIB", "16")) * (1 << 30))
+
+
 def sorted_prefix_ok(S: int, n: int, n_bits: int) -> bool:
-    return 1 <= n_bits <= 8 and S <= 65535 and _lib.load().adalog_sorted_prefix_workspace_bytes(int(S), int(n)) >= 0
+    if not (1 <= n_bits <= 8 and S <= 65535):
+        return False
+    ws = _lib.load().adalog_sorted_prefix_workspace_bytes(int(S), int(n))
+    return ws >= 0 and ws + 20 * int(S) * int(n) <= _SORTED_MAX_BYTES
 
 
 def score_self_sorted(sp: SortedPrefix, scale, zp, n_bits: int, norm: float):

@@ -12,9 +12,38 @@ import threading
 import torch
 import torch.distributed as dist
 
+_tls = threading.local()
+
+
+def _real_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
 
 def is_dist() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """Several ranks AND the calling thread is not inside solo() (rank-local work such as a block owner's BRECQ training)."""
+    return _real_dist() and not getattr(_tls, "solo", False)
+
+
+class solo:
+    """Context: the calling thread behaves as a single process (world_size() == 1, rank() == 0, collectives are no-ops).
+    Used where the work is partitioned over the ranks with no exchange at all: block-parallel BRECQ (each rank trains the
+    blocks it owns exactly as one process would)."""
+
+    def __enter__(self):
+        self._prev = getattr(_tls, "solo", False)
+        _tls.solo = True
+        return self
+
+    def __exit__(self, *exc):
+        _tls.solo = self._prev
+
+
+def real_world_size() -> int:
+    return dist.get_world_size() if _real_dist() else 1
+
+
+def real_rank() -> int:
+    return dist.get_rank() if _real_dist() else 0
 
 
 def world_size() -> int:
@@ -42,7 +71,6 @@ def shard_slice(n_images: int):
 # while one lane waits for its all-reduce the other lane's GEMMs keep the GPU busy.  Within a lane the sequence of collectives
 # is the same on every rank (modules are dealt to the lanes round-robin in named_modules() order), and RCCL gives every rank
 # bit-identical sums, so the results are those of the sequential schedule.
-_tls = threading.local()
 _LANE_GROUPS = []
 STATS = {"collectives": 0, "bytes": 0}
 _EVENTS = []                               # (start, end) device events around every collective (HIP streams only)
@@ -56,9 +84,48 @@ def lane_groups(n: int):
     return _LANE_GROUPS[:n]
 
 
-def set_lane(group):
-    """Collectives of the calling THREAD use `group` from now on (None: the default group)."""
+class Sequencer:
+    """One global issue order for the collectives of all lanes: call c of lane L goes out after call c of every lane before L
+    and call c - 1 of every lane after L -- a pure function of (call index, lane), hence the same on every rank.  RCCL / NCCL
+    require collectives on DIFFERENT communicators of one device to be issued in the same relative order everywhere; per-lane
+    order alone (what the two host threads give) leaves lane A against lane B to thread timing.  A lane that has finished its
+    modules retires (the number of its collectives is the same on every rank, so it retires at the same point everywhere)."""
+
+    def __init__(self, n):
+        self.n, self.count, self.done = n, [0] * n, [False] * n
+        self.cv = threading.Condition()
+        self.order = []                                    # (lane, call index) in issue order (tests read it)
+
+    def _my_turn(self, lane):
+        c = self.count[lane]
+        for o in range(self.n):
+            if o == lane or self.done[o]:
+                continue
+            if self.count[o] < (c + 1 if o < lane else c):
+                return False
+        return True
+
+    def issue(self, lane, fn):
+        with self.cv:
+            self.cv.wait_for(lambda: self._my_turn(lane))
+            try:
+                return fn()                                # enqueued while holding the turn: host order == the global order
+            finally:
+                self.order.append((lane, self.count[lane]))
+                self.count[lane] += 1
+                self.cv.notify_all()
+
+    def finish(self, lane):
+        with self.cv:
+            self.done[lane] = True
+            self.cv.notify_all()
+
+
+def set_lane(group, sequencer=None, lane=0):
+    """Collectives of the calling THREAD use `group` from now on (None: the default group), issued through `sequencer`."""
     _tls.group = group
+    _tls.seq = sequencer if group is not None else None
+    _tls.lane = lane
 
 
 def _group():
@@ -72,7 +139,11 @@ def _all_reduce(t: torch.Tensor, op) -> torch.Tensor:
     if t.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    dist.all_reduce(t, op=op, group=_group())
+    seq = getattr(_tls, "seq", None)
+    if seq is not None:
+        seq.issue(_tls.lane, lambda: dist.all_reduce(t, op=op, group=_group()))
+    else:
+        dist.all_reduce(t, op=op, group=_group())
     if ev is not None:
         ev[1].record()
     with _stats_lock:
@@ -140,6 +211,12 @@ def gather_images(x: torch.Tensor) -> torch.Tensor:
     out = torch.empty((x.shape[0] * world_size(),) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(out, x)
     return out
+
+
+def broadcast(t: torch.Tensor, src: int) -> torch.Tensor:
+    if is_dist():
+        dist.broadcast(t, src=src)
+    return t
 
 
 def barrier():

@@ -66,10 +66,16 @@ def quantizer_state(*quantizers):
     flat int32 tensor: a state comparison is then one kernel and one host read"""
     parts = []
     for q in quantizers:
-        for t in (getattr(q, "scale", None), getattr(q, "zero_point", None), getattr(q, "q", None)):
+        # every tensor a search reads from the other operand's quantiser: scale, zero point, AdaLog base and the shift
+        for t in (getattr(q, "scale", None), getattr(q, "zero_point", None), getattr(q, "q", None), getattr(q, "shift", None)):
             if torch.is_tensor(t):
                 t = t.detach().reshape(-1)
                 parts.append(t.view(torch.int32) if t.dtype == torch.float32 else t.to(torch.int32))
+        parts_bits = getattr(q, "n_bits", None)
+        if parts_bits is not None and parts:
+            parts.append(torch.full((1,), int(parts_bits), dtype=torch.int32, device=parts[-1].device))
+    if not parts:
+        raise ValueError("quantizer_state: no calibrated tensor to snapshot")
     return torch.cat(parts) if len(parts) != 1 else parts[0].clone()
 
 

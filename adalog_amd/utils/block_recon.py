@@ -232,16 +232,76 @@ class BlockReconstructor(QuantCalibrator):
         del block.raw_input, block.raw_out
         return loss_func
 
+    def _trained_tensors(self, block, quant_act):
+        """What a block's reconstruction trains (block_recon.py:97-108), in named_modules() order."""
+        out = []
+        for _, module in block.named_modules():
+            if hasattr(module, 'mode'):
+                if isinstance(module, (MinMaxQuantLinear, MinMaxQuantConv2d)):
+                    out.append(module.w_quantizer.alpha)
+                    if quant_act:
+                        out.append(module.a_quantizer.scale)
+                elif isinstance(module, MinMaxQuantMatMul) and quant_act:
+                    out += [module.A_quantizer.scale, module.B_quantizer.scale]
+        return out
+
+    def _reconstruct_blocks_parallel(self, device, quant_act, keep_gpu, iters):
+        """Block-parallel BRECQ over the ranks.  A block's inputs AND targets come from the FP model (block_recon.py:62-82), so
+        the blocks are independent: they are dealt to the ranks round-robin, every rank trains the blocks it owns exactly as a
+        single process would (full mini-batch, full HIP-graph replay, no collective inside the 20 000 iterations), and the
+        trained tensors are broadcast from their owners at the end.  The only exchanges are, per block, one all-gather of its
+        captured inputs / targets (the optimisation images are sharded over the ranks) before the training and one broadcast of
+        alpha / activation scales after it.  The batch-split mode (one gradient all-reduce per iteration: at 32 / 8 = 4 images per
+        rank and ~1.8 ms per iteration it is latency-bound and slower on 8 GPUs than on one) stays behind ADALOG_BRECQ_DP=batch."""
+        ws, rk = parallel.world_size(), parallel.rank()
+        names = list(self.blocks.keys())
+        owned = {}
+        for i, name in enumerate(names):                     # captures first: collectives, in the same order on every rank
+            block, full_block = self.blocks[name], self.full_blocks[name]
+            self.init_block_raw_inp_outp(block, full_block, name, device)
+            xin, xout = parallel.gather_images(block.raw_input), parallel.gather_images(block.raw_out)
+            del block.raw_input, block.raw_out
+            if i % ws == rk:
+                owned[name] = (xin, xout) if keep_gpu else (xin.cpu(), xout.cpu())
+            del xin, xout
+        for name in names:                                   # every rank: AdaRound quantisers exist everywhere (to receive alpha)
+            if name not in owned:
+                self.wrap_quantizers_in_net(self.blocks[name], name)
+        with parallel.solo():
+            for name, (xin, xout) in owned.items():
+                block = self.blocks[name]
+                logging.info('rank {}: reconstructing {} ...'.format(rk, name))
+                block.raw_input, block.raw_out = xin, xout
+                self.reconstruct_single_block(name, block, device, quant_act=quant_act, iters=iters)
+        owned.clear()
+        for i, name in enumerate(names):                     # results from their owners
+            block = self.blocks[name]
+            for t in self._trained_tensors(block, quant_act):
+                parallel.broadcast(t.data, src=i % ws)
+            if i % ws != rk:                                 # the state reconstruct_single_block leaves behind
+                for _, module in block.named_modules():
+                    if hasattr(module, 'w_quantizer'):
+                        module.w_quantizer.soft_targets = False
+                    if hasattr(module, 'mode'):
+                        module.mode = 'raw'
+
     def reconstruct_model(self, quant_act: bool = False, keep_gpu: bool = True, iters: int = 20000):
         device = next(self.model.parameters()).device
         for _, module in self.model.named_modules():
             if hasattr(module, 'mode'):
                 module.mode = 'raw'
-        for name in self.blocks.keys():
-            block, full_block = self.blocks[name], self.full_blocks[name]
-            logging.info('reconstructing {} ...'.format(name))
-            self.init_block_raw_data(block, full_block, name, device, keep_gpu=keep_gpu)
-            self.reconstruct_single_block(name, block, device, quant_act=quant_act, iters=iters)
+        self.dp_mode = 'single'
+        if parallel.world_size() > 1 and os.environ.get("ADALOG_BRECQ_DP", "block") != "batch":
+            self.dp_mode = 'block'
+            self._reconstruct_blocks_parallel(device, quant_act, keep_gpu, iters)
+        else:
+            if parallel.world_size() > 1:
+                self.dp_mode = 'batch'
+            for name in self.blocks.keys():
+                block, full_block = self.blocks[name], self.full_blocks[name]
+                logging.info('reconstructing {} ...'.format(name))
+                self.init_block_raw_data(block, full_block, name, device, keep_gpu=keep_gpu)
+                self.reconstruct_single_block(name, block, device, quant_act=quant_act, iters=iters)
         for _, module in self.model.named_modules():
             if hasattr(module, 'mode'):
                 module.mode = 'quant_forward'

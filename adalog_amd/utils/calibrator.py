@@ -47,7 +47,10 @@ class QuantCalibrator:
         # output for calibration batch i is a constant: it is recorded the first time the block runs after being finished (during
         # the NEXT block's capture pass) and returned from then on instead of being recomputed -- the tensors downstream are
         # bit for bit the ones a full forward produces.  ADALOG_CAPTURE_CACHE=0: recompute.
-        self._cache_blocks = capture == "block" and os.environ.get("ADALOG_CAPTURE_CACHE", "1") != "0"
+        # the cache replays a block's outputs by batch POSITION: it needs a loader that yields the same batches on every pass
+        # (an in-memory list, which is what test_quant.py / bench.py hand over) -- a DataLoader with a random transform does not
+        self._cache_blocks = (capture == "block" and os.environ.get("ADALOG_CAPTURE_CACHE", "1") != "0"
+                              and isinstance(calib_loader, (list, tuple)))
         self._finished = []                  # finished blocks not cached yet
         self._patched = []                   # blocks whose forward returns the cached outputs
         self._bi = 0                         # index of the calibration batch in flight
@@ -112,7 +115,16 @@ class QuantCalibrator:
             h.remove()
         for block, outs in recording:
             if len(outs) == n_batches:                       # (the pass ran through it for every batch)
+                # Only the most recently patched block's cache is ever consumed (a patched block ignores its input): the
+                # blocks patched before it keep ONE batch of theirs, sliced to the incoming batch size, so that the glue code
+                # between blocks still sees tensors of the right shape -- depth x calib_size x tokens x dim of cache (7 GB for
+                # vit_base at 1024 images) becomes one block's worth.
+                for old in self._patched:
+                    first = getattr(old, "_adalog_cache_first", None)
+                    if first is not None and torch.is_tensor(first):
+                        old.forward = lambda *a, _o=first, **k: _o[:a[0].shape[0]] if torch.is_tensor(a[0]) else _o
                 block.forward = lambda *a, _outs=outs, **k: _outs[self._bi]
+                block._adalog_cache_first = outs[0] if outs and torch.is_tensor(outs[0]) else None
                 self._patched.append(block)
                 self._finished.remove(block)
         for _, module in group:
@@ -173,7 +185,12 @@ class QuantCalibrator:
             # one process: ADALOG_LANES=n (>= 2) runs n modules' searches side by side on n streams (no communicators)
             n = int(os.environ.get("ADALOG_LANES", "1"))
             return [(None, torch.cuda.Stream(device=device)) for _ in range(n)] if n >= 2 and on_gpu else None
-        if os.environ.get("ADALOG_INTERLEAVE", "1") == "0":
+        # Two communicators driven from two host threads are opt-in (ADALOG_INTERLEAVE=1): the schedule has run under gloo and
+        # with two ranks sharing one GPU only, never on a multi-GPU RCCL node, and concurrent collectives on different
+        # communicators must reach the device in the same relative order on every rank (parallel.Sequencer enforces one global
+        # host-side issue order, a pure function of (lane, call index)) -- until that is measured on hardware the default is
+        # the sequential schedule: one communicator, one stream, one order.
+        if os.environ.get("ADALOG_INTERLEAVE", "0") != "1":
             return None
         groups = parallel.lane_groups(2)
         return [(g, torch.cuda.Stream(device=device) if on_gpu else None) for g in groups]
@@ -189,10 +206,11 @@ class QuantCalibrator:
         if on_gpu:
             ready.record()                                     # the captures were written on the calling stream
         errors, done = [], []
+        seq = parallel.Sequencer(len(lanes)) if parallel.is_dist() else None
 
         def work(li):
             grp, stream = lanes[li]
-            parallel.set_lane(grp)
+            parallel.set_lane(grp, seq, li)
             try:
                 if on_gpu:
                     torch.cuda.set_device(device)
@@ -211,6 +229,8 @@ class QuantCalibrator:
             except BaseException as ex:                        # re-raised on the calling thread
                 errors.append(ex)
             finally:
+                if seq is not None:
+                    seq.finish(li)
                 parallel.set_lane(None)
 
         threads = [threading.Thread(target=work, args=(li,), name=f"adalog-lane{li}") for li in range(len(lanes))]
@@ -257,6 +277,7 @@ class QuantCalibrator:
         finally:
             for block in self._patched:                      # back to computing (the instance attribute shadowed the method)
                 del block.forward
+                block.__dict__.pop("_adalog_cache_first", None)
             self._patched, self._finished = [], []
         for _, module in self.model.named_modules():
             if hasattr(module, 'mode'):

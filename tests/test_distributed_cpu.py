@@ -229,3 +229,91 @@ def test_interleaved_calibration_is_the_sequential_one(world):
             n_scale += v.numel()
             n_off += int(((v - runs[(1, 0)][k]).abs() > 2e-3 * v.abs()).sum())
     assert n_off <= 0.05 * n_scale, (n_off, n_scale)
+
+
+def _brecq_blocks_worker(rank, world, port, outdir):
+    """reconstruct_model over `world` gloo ranks with the optimisation images sharded: block-parallel mode (each rank trains the
+    blocks it owns as a single process would, results broadcast)."""
+    import copy
+    import importlib.util
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from adalog_amd import backend
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import VisionTransformer
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    from tests import cpu_backend
+    torch.set_num_threads(1)
+    backend.set_backend(cpu_backend)
+    spec = importlib.util.spec_from_file_location("cfg4d", os.path.join(ROOT, "configs", "4bit.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = mod.Config()
+    cfg.search_round, cfg.steps = 1, 2
+    torch.manual_seed(7)
+    model = VisionTransformer(img_size=32, patch_size=8, embed_dim=32, depth=2, num_heads=2, num_classes=10).eval()
+    for p_ in model.parameters():
+        p_.data.mul_(8.0)
+    full = copy.deepcopy(model)
+    x = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    model = wrap_modules_in_net(model, cfg, reparam=True)
+    QuantCalibrator(model, [(x[:8], None), (x[8:], None)]).batching_quant_calib()     # (calibration itself: every rank, all images)
+    model = wrap_reparamed_modules_in_net(model)
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    per = 16 // world
+    xs = x[rank * per:(rank + 1) * per]
+    br = BlockReconstructor(model, full, [(xs, None)])
+    br.reconstruct_model(quant_act=True, keep_gpu=True, iters=10)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    sd["__mode"] = torch.tensor({"single": 0, "block": 1, "batch": 2}[br.dp_mode])
+    torch.save(sd, os.path.join(outdir, f"brecq_blocks_w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_block_parallel_brecq_equals_the_single_process_run():
+    """Blocks dealt to 2 ranks, images sharded: every rank ends with the model the single process trains (bit for bit: an owner
+    trains its block exactly as one process would, on the all-gathered block data)."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_brecq_blocks_worker, args=(2, _free_port(), d), nprocs=2, join=True)
+        mp.spawn(_brecq_blocks_worker, args=(1, _free_port(), d), nprocs=1, join=True)
+        r0, r1 = (torch.load(os.path.join(d, f"brecq_blocks_w2_r{r}.pt")) for r in (0, 1))
+        single = torch.load(os.path.join(d, "brecq_blocks_w1_r0.pt"))
+    assert int(r0["__mode"]) == 1 and int(single["__mode"]) == 0
+    for k in single:
+        if k == "__mode":
+            continue
+        assert torch.equal(r0[k], r1[k]), f"ranks disagree on {k}"
+        assert torch.equal(r0[k], single[k]), f"block-parallel and single-process runs disagree on {k}"
+
+
+def test_sequencer_issues_one_global_order():
+    """parallel.Sequencer: whatever the thread timing, the collectives of two lanes go out in the order (call index, lane)."""
+    import random
+    import threading
+    import time
+    from adalog_amd import parallel
+    for trial in range(5):
+        seq = parallel.Sequencer(2)
+        counts = (7, 4)                                   # lane 1 retires early
+        issued = []
+
+        def lane(li):
+            rnd = random.Random(100 * trial + li)
+            for _ in range(counts[li]):
+                time.sleep(rnd.random() * 0.003)
+                seq.issue(li, lambda: issued.append(li))
+            seq.finish(li)
+        ts = [threading.Thread(target=lane, args=(li,)) for li in (0, 1)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(timeout=10)
+        assert not any(t.is_alive() for t in ts)
+        assert seq.order == sorted(seq.order, key=lambda lc: (lc[1], lc[0])), seq.order
+        assert seq.order == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 2), (1, 2), (0, 3), (1, 3), (0, 4), (0, 5), (0, 6)]
