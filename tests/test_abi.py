@@ -110,3 +110,56 @@ def test_brecq_ticket_is_ordered_after_the_partial_stores(tmp_path):
         between = lines[j + 1:i]
         assert any("s_waitcnt" in ln and "vmcnt(0)" in ln for ln in between), \
             f"ticket at line {i} is not ordered after the store at line {j}"
+
+
+def test_slab_register_loads_are_not_touched_before_their_wait(tmp_path):
+    """ISA shape of the slab kernel's register path (csrc/gemm_k_slab.inc: 24 inline-asm `buffer_load_dwordx4` into the first
+    six accumulator blocks, then an asm `s_waitcnt vmcnt(0)` naming them).  hipcc does not know the loads are asynchronous:
+    nothing in the language stops it from copying, spilling or re-using a destination register between a load and the wait
+    (it would read or clobber a register the memory system has not written yet).  The compiled kernels must show the 24
+    loads and their wait with nothing but scalar instructions in between: no VALU, no `v_accvgpr_*`, no scratch access."""
+    import re
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    asm = tmp_path / "gemm_score.s"
+    csrc = os.path.join(ROOT, "adalog_amd", "csrc")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
+                    os.path.join(csrc, "gemm_score.hip"), "-o", str(asm)], check=True, capture_output=True)
+    lines = [ln.strip() for ln in open(asm).read().splitlines()]
+    is_reg_load = lambda ln: ln.startswith("buffer_load_dwordx4") and " lds" not in ln
+    runs, i, fn = 0, 0, ""
+    while i < len(lines):
+        mfn = re.match(r"(_Z\S+):", lines[i])                 # a function label (a comment may follow it)
+        if mfn:
+            fn = mfn.group(1)
+        if "k_gemm_slab" not in fn or not is_reg_load(lines[i]):
+            i += 1
+            continue
+        j, loads, pending, first_bad = i, 0, set(), None
+        while j < len(lines) and not (lines[j].startswith("s_waitcnt") and "vmcnt(0)" in lines[j]):
+            ln = lines[j]
+            if is_reg_load(ln):
+                loads += 1
+                m = re.match(r"buffer_load_dwordx4 v\[(\d+):(\d+)\], (\S+),", ln)
+                assert m, ln
+                dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+                assert not dst & pending, f"line {j}: a destination is loaded twice in one run"
+                addr = {int(x) for x in re.findall(r"v(\d+)", m.group(3))}
+                if addr & pending and first_bad is None:
+                    first_bad = (j, ln)
+                pending |= dst
+            elif ln and not ln.startswith((";", ".", "s_")):
+                # VALU / scratch / accvgpr traffic is fine as long as it stays off the registers still in flight
+                used = set()
+                for lo, hi in re.findall(r"[va]\[(\d+):(\d+)\]", ln):
+                    used |= set(range(int(lo), int(hi) + 1))
+                used |= {int(x) for x in re.findall(r"\bv(\d+)\b", ln)}
+                if used & pending and first_bad is None:
+                    first_bad = (j, ln)
+            j += 1
+        if loads >= 24:
+            runs += 1
+            assert first_bad is None, f"line {first_bad[0]}: {first_bad[1]!r} touches a register whose load is still in flight"
+        i = j + 1
+    assert runs >= 1, "no run of 24 register loads found in k_gemm_slab: has the slab register path changed?"

@@ -46,6 +46,30 @@ def _log(name, **kw):
         pass
 
 
+# ---- which kernel served a scoring call.  The tiny golden traces never reach the production kernels; here every case records
+# adalog_last_kernel() after each call, refuses the general-purpose fallbacks at production shapes and -- last test of the
+# file -- checks that every production label was hit by some case, so a dispatch regression cannot stay green.
+FALLBACK = {"k_gemm_cand", "k_gemm_cand_glds", "k_gemm_score", ""}
+SEEN = {}
+REQUIRED = {"k_gemm_slab<fp8>", "k_gemm_slab<i8>", "k_gemm_slab128<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
+            "k_gemm_slab128_gen<fp8>", "k_act_fused_asm<12,4,bf16>", "k_act_fused_asm<12,3,bf16>", "k_act_fused_asm<8,4,bf16>",
+            "k_act_fused_asm<4,4,bf16>", "k_gemm_stream<bf16xfp8>", "k_gemm_stream<bf16>", "k_gemm_grpw<fp8>", "k_gemm_grpw<i8>",
+            "k_gemm_grpk8<bf16xfp8>", "k_gemm_grpk<bf16>", "k_gemm_win<fp8>", "k_gemm_winb<bf16xfp8>"}
+
+
+def _kern(case, search):
+    from adalog_amd import _lib
+    k = _lib.load().adalog_last_kernel().decode()
+    SEEN.setdefault(case, {})[search] = k
+    assert k not in FALLBACK, f"{case}/{search}: served by the fallback kernel {k!r}"
+    return k
+
+
+def _expect(case, search, *labels):
+    k = SEEN[case][search]
+    assert k in labels, f"{case}/{search}: ran {k}, expected one of {labels}"
+
+
 def _rel(got, ref):
     got, ref = got.detach().float().cpu().reshape(ref.shape), ref.float()
     return ((got - ref).abs() / ref.abs().clamp_min(1e-30)).max().item()
@@ -68,7 +92,21 @@ LINEAR = [  # tag, I, O, n_V, tokens per image, images, bits
     ("swin_base.l0.fc1", 128, 512, 1, 3136, 32, 3),
     # BASELINE config 4's per-rank share: 1024 calibration images over 8 GPUs = 128 images per rank (401 408 tokens in stage 0)
     ("swin_base.l0.fc1@128img", 128, 512, 1, 3136, 128, 3),
+    # W6A6 (configs/6bit.py): the int8 forms of the slab kernels
+    ("deit_small.qkv", 384, 1152, 3, 197, 32, 6),
+    ("deit_small.fc1", 384, 1536, 1, 197, 32, 6),
+    # the classifier head: one token per image (32 x 384 -> 1000)
+    ("deit_small.head", 384, 1000, 1, 1, 32, 4),
+    # K = 1024: swin stage 3 (7 x 7 tokens per image)
+    ("swin_base.l3.qkv", 1024, 3072, 3, 49, 32, 3),
 ]
+LINEAR_KERNELS = {          # case -> (weight search, activation search) labels that production dispatches there
+    "deit_small.qkv-w4": (("k_gemm_slab<fp8>",), ("k_gemm_slab_gen<fp8>",)),
+    "deit_small.proj-w4": (("k_gemm_slab<fp8>",), ("k_gemm_slab_gen<fp8>",)),
+    "vit_base.qkv-w4": (("k_gemm_slab128<fp8>",), ("k_gemm_slab128_gen<fp8>",)),
+    "deit_small.qkv-w6": (("k_gemm_slab<i8>",), ("k_gemm_slab_gen<i8>",)),
+    "deit_small.fc1-w6": (("k_gemm_slab<i8>",), ("k_gemm_slab_gen<i8>",)),
+}
 
 
 @pytest.mark.parametrize("tag,I,Oc,n_V,T,N,bits", LINEAR, ids=[c[0] + f"-w{c[6]}" for c in LINEAR])
@@ -100,17 +138,25 @@ def test_linear_scores_full_shape(tag, I, Oc, n_V, T, N, bits):
     _set(lay.w_quantizer, w_s.to(DEV), w_z.to(DEV))
     cw_s, cw_z = scw.reshape(128, -1).to(DEV), zpw.reshape(128, -1).float().to(DEV)
     ca_s, ca_z = sca.t().contiguous().to(DEV), zpa.t().contiguous().float().to(DEV)
+    case = f"{tag}-w{bits}"
+    small = N * T < 64                                               # (the head: too few rows for the production kernels)
     with torch.no_grad():
         got_w = lay._score_w(lay._pack_x_fixed(), cw_s, cw_z)[SUB]
-        dt = lay._int_dt(N * T)
+        kw = _kern(case, "w") if not small else ""
+        from adalog_amd.quant_layers.linear import FP8_WEIGHT_SEARCH_MAX_K
+        dt = lay._int_dt(N * T, prefer_fp8=I <= FP8_WEIGHT_SEARCH_MAX_K)          # as activation_fpcs picks it (linear.py)
         wp = lay._pack_w_fixed(dt)
         wp.int_dt = dt
         got_a = lay._score_a(wp, ca_s, ca_z)[SUB]
+        ka = _kern(case, "a") if not small else ""
         got_ws = lay._score_w_self(cw_s, cw_z)[SUB]
         got_as = lay._score_a_self(ca_s, ca_z)[SUB]
     errs = dict(w=_rel(got_w, ref_w), a=_rel(got_a, ref_a), w_self=_rel(got_ws, ref_ws), a_self=_rel(got_as, ref_as))
-    _log(f"{tag}-w{bits}", **errs)
+    _log(case, kernel_w=kw, kernel_a=ka, **errs)
     assert max(errs.values()) <= RTOL, errs
+    if case in LINEAR_KERNELS:
+        _expect(case, "w", *LINEAR_KERNELS[case][0])
+        _expect(case, "a", *LINEAR_KERNELS[case][1])
 
 
 @pytest.mark.parametrize("tag,I,T,N,bits", [("vit_base.qkv_cw", 768, 197, 32, 4), ("swin_base.reduction_cw", 512, 784, 32, 3)])
@@ -134,7 +180,15 @@ def test_channelwise_self_scores_full_shape(tag, I, T, N, bits):
 
 
 POSTGELU = [("deit_small.fc2", 1536, 384, 197, 32, 4), ("vit_base.fc2", 3072, 768, 197, 32, 4),
-            ("deit_base.fc2", 3072, 768, 197, 32, 3), ("swin_base.l0.fc2", 512, 128, 3136, 32, 3)]
+            ("deit_base.fc2", 3072, 768, 197, 32, 3), ("swin_base.l0.fc2", 512, 128, 3136, 32, 3),
+            ("deit_small.fc2", 1536, 384, 197, 32, 6), ("swin_base.l1.fc2", 1024, 256, 784, 32, 4)]
+POSTGELU_KERNELS = {
+    "deit_small.fc2-w4": (("k_act_fused_asm<12,4,bf16>",), ("k_gemm_stream<bf16xfp8>",)),
+    "vit_base.fc2-w4": (("k_act_fused_asm<12,4,bf16>",), ("k_gemm_stream<bf16xfp8>",)),
+    "deit_small.fc2-w6": (("k_act_fused_asm<12,3,bf16>",), ("k_gemm_stream<bf16>",)),
+    "swin_base.l0.fc2-w3": (("k_act_fused_asm<4,4,bf16>",), None),
+    "swin_base.l1.fc2-w4": (("k_act_fused_asm<8,4,bf16>",), None),
+}
 
 
 @pytest.mark.parametrize("tag,I,Oc,T,N,bits", POSTGELU, ids=[c[0] + f"-w{c[5]}" for c in POSTGELU])
@@ -174,14 +228,21 @@ def test_postgelu_scores_full_shape(tag, I, Oc, T, N, bits):
         wp, rowsum = lay._pack_w_fixed(BF16, want_rowsum=True)
         fold = be.shift_fold(rowsum.view(1, -1), lay.w_quantizer.scale.data.view(1, -1), aq.shift.data, lay.bias.data).view(-1)
         got_j = lay._score_scale_logbase(wp, fold, scs.t().contiguous().to(DEV), qs.t().float().contiguous().to(DEV))[SUB]
+        kj = _kern(f"{tag}-w{bits}", "joint")
         aq.scale.data.copy_(a_s.to(DEV))
         aq.q.data.fill_(a_q)
         aq.inited = True
         lay._q_host = a_q
         got_w = lay._score_w(lay._pack_x_fixed(), scw.reshape(128, -1).to(DEV), zpw.reshape(128, -1).float().to(DEV))[SUB]
+        kw = _kern(f"{tag}-w{bits}", "w")
     errs = dict(joint=_rel(got_j, ref_j), w=_rel(got_w, ref_w))
-    _log(f"{tag}-w{bits}", **errs)
+    _log(f"{tag}-w{bits}", kernel_joint=kj, kernel_w=kw, **errs)
     assert max(errs.values()) <= RTOL, errs
+    exp = POSTGELU_KERNELS.get(f"{tag}-w{bits}")
+    if exp:
+        _expect(f"{tag}-w{bits}", "joint", *exp[0])
+        if exp[1]:
+            _expect(f"{tag}-w{bits}", "w", *exp[1])
 
 
 MATMUL = [  # tag, batch (images x windows), heads, S, head_dim, bits
@@ -190,7 +251,13 @@ MATMUL = [  # tag, batch (images x windows), heads, S, head_dim, bits
     ("deit_base.attn", 32, 12, 197, 64, 3),
     ("swin_base.l0.attn", 32 * 64, 4, 49, 32, 3),
     ("swin_base.l2.attn", 32 * 4, 16, 49, 32, 3),
+    ("deit_small.attn", 32, 6, 197, 64, 6),
 ]
+QK_KERNELS = {"deit_small.attn-a4": ("k_gemm_grpw<fp8>",), "vit_base.attn-a4": ("k_gemm_grpw<fp8>",),
+              "deit_small.attn-a6": ("k_gemm_grpw<i8>",), "swin_base.l0.attn-a3": ("k_gemm_win<fp8>",)}
+AV_KERNELS = {"deit_small.attn-a4": (("k_gemm_stream<bf16>",), ("k_gemm_grpk8<bf16xfp8>",)),
+              "deit_small.attn-a6": (("k_gemm_stream<bf16>",), ("k_gemm_grpk<bf16>",)),
+              "swin_base.l0.attn-a3": (None, ("k_gemm_winb<bf16xfp8>",))}
 
 
 @pytest.mark.parametrize("tag,Bn,H,S,hd,bits", MATMUL, ids=[c[0] + f"-a{c[5]}" for c in MATMUL])
@@ -218,11 +285,17 @@ def test_qk_matmul_scores_full_shape(tag, Bn, H, S, hd, bits):
     _set(lay.B_quantizer, pB[0].to(DEV), pB[1].to(DEV))
     with torch.no_grad():
         dt = _mm_dt(lay)
+        case = f"{tag}-a{bits}"
         got_A = lay._score("A", lay._pack_fixed("B", dt), sA.reshape(128, H).to(DEV), zA.reshape(128, H).float().to(DEV), dt)[SUB]
+        kA = _kern(case, "qk_A")
         got_B = lay._score("B", lay._pack_fixed("A", dt), sB.reshape(128, H).to(DEV), zB.reshape(128, H).float().to(DEV), dt)[SUB]
+        kB = _kern(case, "qk_B")
     errs = dict(A=_rel(got_A, ref_A), B=_rel(got_B, ref_B), dtype=int(dt))
-    _log(f"{tag}-a{bits}", **errs)
+    _log(case, kernel_A=kA, kernel_B=kB, **errs)
     assert max(errs["A"], errs["B"]) <= RTOL, errs
+    if case in QK_KERNELS:
+        _expect(case, "qk_A", *QK_KERNELS[case])
+        _expect(case, "qk_B", *QK_KERNELS[case])
 
 
 @pytest.mark.parametrize("tag,Bn,H,S,hd,bits", MATMUL, ids=[c[0] + f"-a{c[5]}" for c in MATMUL])
@@ -254,16 +327,27 @@ def test_av_matmul_scores_full_shape(tag, Bn, H, S, hd, bits):
     aq = lay.A_quantizer
     with torch.no_grad():
         _, got_q = lay._score_A_log_base()
+        kq = _kern(f"{tag}-a{bits}", "av_logbase")
         got_q = got_q[SUB]
         aq.q.data.fill_(a_q)
         lay._q_host = a_q
         qv = search.const_tensor([float(a_q)], torch.device(DEV))
-        ap = lay._pack_A_adalog(lay._a3(lay.raw_input[0]), qv, aq.scale.data.view(-1), 1, True, k_align=lay._kalign())
-        got_B = lay._score("B", ap, sB.reshape(128, H).to(DEV), zB.reshape(128, H).float().to(DEV), BF16,
+        # operand form and dtype as hyperparameter_searching picks them (matmul.py: mixed bf16 x fp8 when the shape allows)
+        from adalog_amd.ops import BF16_FP8
+        mixed = lay._mixed_B_search()
+        ap = lay._pack_A_adalog(lay._a3(lay.raw_input[0]), qv, aq.scale.data.view(-1), 1, True,
+                                k_align=(128 if S <= 64 else 512) if mixed else lay._kalign())
+        got_B = lay._score("B", ap, sB.reshape(128, H).to(DEV), zB.reshape(128, H).float().to(DEV), BF16_FP8 if mixed else BF16,
                            fixed_sa=Strided(aq.scale.data.view(-1)), sa_mul=lay._ts32())[SUB]
+        kB = _kern(f"{tag}-a{bits}", "av_B")
     errs = dict(A_logbase=_rel(got_q, ref_q), B=_rel(got_B, ref_B))
-    _log(f"{tag}-av-a{bits}", **errs)
+    _log(f"{tag}-av-a{bits}", kernel_logbase=kq, kernel_B=kB, **errs)
     assert max(errs.values()) <= RTOL, errs
+    exp = AV_KERNELS.get(f"{tag}-a{bits}")
+    if exp:
+        if exp[0]:
+            _expect(f"{tag}-a{bits}", "av_logbase", *exp[0])
+        _expect(f"{tag}-a{bits}", "av_B", *exp[1])
 
 
 @pytest.mark.parametrize("tag,ic,oc,k,hw,N,bits", [("vit_base.patch_embed", 3, 768, 16, 224, 32, 4),
@@ -311,3 +395,14 @@ def test_quantile_above_2_pow_24_on_hip(golden):
     err = _rel(s, ref_s)
     _log("quantile_large", grid=err)
     assert err <= 1e-6 and torch.equal(z.cpu(), ref_z)
+
+
+def test_every_production_kernel_label_was_hit():
+    """Last in the file: the union of the kernels that served the cases above covers every label the benchmarked models
+    dispatch (profiles/r03_bench*.json: `scoring_kernels`).  A case that silently fell to another kernel shows up here."""
+    if len(SEEN) < 20:
+        pytest.skip("needs the whole file to have run")
+    hit = {k for d in SEEN.values() for k in d.values()}
+    missing = REQUIRED - hit
+    _log("kernel_coverage", hit=sorted(hit), missing=sorted(missing))
+    assert not missing, f"production kernels no full-shape case reached: {sorted(missing)}"
