@@ -194,6 +194,7 @@ def pack_split3(x3, k_align: int = 128):
     rc = _lib.load().adalog_pack_split3_bf16(x3.data_ptr(), G, R, K, sg, sr, sk, out.data_ptr(), Kt, _stream())
     _lib.check(rc, "adalog_pack_split3_bf16")
     out.k_valid = 2 * Kt + K
+    out.flops_k = K                                     # the ALGORITHM's K (flops of the product, not of its three-term decomposition)
     return out
 
 
@@ -314,7 +315,8 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
         n_part, MT, Npad, mode = _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid, ref_transposed)
         # reduced column axis: one partial per n-tile (Npad = NT) / per workgroup
         return n_part, MT, Npad, mode, (Npad if (reduce_cols and mode != 1) else N)
-    meta = (dtype, M, N, k_valid, C, G)                               # k_valid: un-padded K
+    k_alg = min(getattr(A, "flops_k", k_valid), getattr(B, "flops_k", k_valid))   # (an operand split into exact terms counts once)
+    meta = (dtype, M, N, k_alg, C, G)                                 # un-padded, algorithmic K
     if _torch_ops.available():
         args = (int(dtype), A, B, int(M), int(N), int(C), int(G), int(gmod), int(k_valid), ref, sa.t, sa.c, sa.g,
                 float(sa_mul), sb.t, sb.c, sb.g, sb.n, None if bias is None else bias.t, 0 if bias is None else bias.c,
@@ -343,7 +345,7 @@ def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref,
                                partial.data_ptr(), n_part, None, 0, 0, 0, int(order), reduce_cols, _stream())
     if GEMM_EVENTS is not None:
         ev1.record()
-        GEMM_EVENTS.append((dtype, M, N, k_valid, C, G, ev0, ev1, lib.adalog_last_kernel().decode()))   # k_valid: un-padded K
+        GEMM_EVENTS.append((dtype, M, N, k_alg, C, G, ev0, ev1, lib.adalog_last_kernel().decode()))     # un-padded, algorithmic K
     _lib.check(rc, "adalog_gemm_score")
     pend = PendingScores(partial, MT, n_last, Npad, C, G, gmod, keep_h, keep_n, mode, norm, N)
     return pend if defer else pend.finish()

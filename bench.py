@@ -74,6 +74,26 @@ class GemmProfiler:
                  "launches_per_step": v[2] / steps, "ms_per_step": round(v[1] / steps, 2),
                  "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in rows]
 
+    @staticmethod
+    def template_of(label):
+        """`k_gemm_slab128_gen<fp8>` -> `k_gemm_slab<fp8>`: the generated-operand (GEN) and 128-column forms are instantiations of
+        one kernel template; `k_act_fused_asm<12,4,bf16>` -> `k_act_fused_asm<bf16>`."""
+        import re
+        head, _, tail = label.partition("<")
+        head = head.replace("128", "").replace("_gen", "")
+        args = tail.rstrip(">").split(",")
+        return f"{head}<{args[-1]}>" if tail else head
+
+    def by_template(self, steps):
+        """Kernel TEMPLATES, largest summed launch time first, each with its instantiations as sub-rows."""
+        groups = {}
+        for (name, dt), v in self.kernels.items():
+            g = groups.setdefault((self.template_of(name), dt), {"flops": 0.0, "ms": 0.0, "n": 0, "rows": []})
+            g["flops"] += v[0]; g["ms"] += v[1]; g["n"] += v[2]
+            g["rows"].append({"kernel": name, "launches_per_step": v[2] / steps, "ms_per_step": round(v[1] / steps, 2),
+                              "frac_of_peak": round(v[0] / (v[1] * 1e-3) / 1e12 / PEAK_TOPS[dt], 3)})
+        return sorted(groups.items(), key=lambda kv: -kv[1]["ms"])
+
     def by_kernel(self, steps):
         rows = sorted(self.kernels.items(), key=lambda kv: -kv[1][1])
         return [{"kernel": k[0], "dtype": DT_NAME[k[1]], "launches_per_step": v[2] / steps, "ms_per_step": round(v[1] / steps, 2),
@@ -185,7 +205,7 @@ def hbm_kernels(ops, dev):
     return out
 
 
-def brecq_rate(model_name, bits, dev, iters=2000):
+def brecq_rate(model_name, bits, dev, iters=2000, depth=None):
     """BRECQ (utils/block_recon.py:84-137) iterations per second on blocks.0 of the benchmarked model: a bounded sample
     (the reference runs 20 000 iterations per block) with the reference's schedule in proportion (first 20 % without the
     rounding regulariser); wall time for one block and the whole model follow by scaling."""
@@ -195,7 +215,11 @@ def brecq_rate(model_name, bits, dev, iters=2000):
     from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
     cfg = load_cfg(bits)
     torch.manual_seed(5)
-    base = create_model(model_name).eval()
+    from adalog_amd import train_mm
+    nblk_full = None
+    if depth is not None:                                     # a shallow copy of the architecture: the block itself is the same
+        nblk_full = len(BlockReconstructor(create_model(model_name).eval(), create_model(model_name).eval(), []).blocks)
+    base = (create_model(model_name) if depth is None else create_model(model_name, depth=depth)).eval()
     full = copy.deepcopy(base).to(dev).eval()
     model = wrap_modules_in_net(base, cfg, reparam=True).to(dev)
     imgs = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(dev)
@@ -216,9 +240,12 @@ def brecq_rate(model_name, bits, dev, iters=2000):
     rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=iters)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    nblk = len(rec.blocks)
-    return {"iters_per_s": round(iters / dt, 1), "ms_per_iter": round(dt / iters * 1e3, 3), "block": name, "batch": 32,
+    nblk = nblk_full if nblk_full is not None else len(rec.blocks)
+    return {"model": model_name, "iters_per_s": round(iters / dt, 1), "ms_per_iter": round(dt / iters * 1e3, 3), "block": name, "batch": 32,
             "sample_iters": iters, "blocks_in_model": nblk,
+            "contractions": ("csrc/brecq_gemm.hip (adalog_gemm_f32x3: fp32 operands as three bf16 terms, six MFMA products, fp32 "
+                             "accumulation; integer activation operands three products)" if train_mm.ENABLED else "rocBLAS fp32"),
+            "multi_gpu": "block-parallel (blocks dealt to ranks, no collective inside an iteration); ADALOG_BRECQ_DP=batch = batch split",
             "extrapolated_s_per_block_20000_iters": round(20000 * dt / iters, 1),
             "extrapolated_s_whole_model": round(20000 * dt / iters * nblk, 1)}
 
@@ -569,8 +596,17 @@ def main():
         ms_per_step = wall * 1e3 / args.steps
         value = cfg.calib_size * args.steps / wall
         # the dominant KERNEL (largest summed launch time over the timed steps) carries the roofline object
-        (dom_name, dom), (fl, ms, n) = max(prof.kernels.items(), key=lambda kv: kv[1][1]) if prof.kernels else (("", 0), (0.0, 1.0, 1))
+        # the dominant kernel TEMPLATE (largest summed launch time over the timed steps; the generated-operand and packed forms
+        # of the slab kernel are one template) carries the roofline object, its instantiations are listed as sub-rows
+        templ = prof.by_template(args.steps)
+        if templ:
+            (dom_name, dom), gdom = templ[0]
+            fl, ms, n, dom_rows = gdom["flops"], gdom["ms"], gdom["n"], gdom["rows"]
+        else:
+            (dom_name, dom), (fl, ms, n), dom_rows = ("", 0), (0.0, 1.0, 1), []
         achieved = fl / (ms * 1e-3) / 1e12
+        # the instantiation with the largest time stands for the template in the PMC replay
+        dom_label = max(dom_rows, key=lambda r: r["ms_per_step"])["kernel"] if dom_rows else dom_name
         gemm_ms_total = sum(v[1] for v in by.values())
         timed = cals[args.warmup:args.warmup + args.steps]
         fpcs = [sum(c.fpcs_seconds().values()) for c in timed]
@@ -601,8 +637,8 @@ def main():
                        "collectives": {"per_step": coll["collectives"] / args.steps, "bytes_per_step": coll["bytes"] / args.steps,
                                        "stream_ms_per_step": None if coll["device_ms"] is None else coll["device_ms"] / args.steps,
                                        "schedule": "two lanes (two modules' searches side by side, each on its own stream and "
-                                                   "communicator)" if world > 1 and os.environ.get("ADALOG_INTERLEAVE", "1") != "0"
-                                                   else "sequential",
+                                                   "communicator, one global issue order)" if world > 1 and os.environ.get("ADALOG_INTERLEAVE", "0") == "1"
+                                                   else "sequential (one communicator, one stream; ADALOG_INTERLEAVE=1 = two lanes)",
                                        "note": "score / min-max / histogram all-reduces of rank 0 during the timed steps; stream_ms = "
                                                "summed event time around them on their lane's stream (includes waiting for the peers)"},
                        "schedule": {
@@ -624,7 +660,8 @@ def main():
                        "depth_override": args.depth},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],
-                         "traffic": pmc_traffic(dom_name, default_workload),
+                         "instantiations": dom_rows,
+                         "traffic": pmc_traffic(dom_label, default_workload), "traffic_kernel": dom_label,
                          "traffic_source": "REPLAYED, not measured by this run: profiles/r03_pmc_bench_traffic.json holds the rocprofv3 --pmc "
                                            "passes of this same command (tools/pmc_bench.sh; FETCH_SIZE x2 per the gfx950 note + "
                                            "WRITE_SIZE, per launch); null for any other workload",
@@ -634,6 +671,8 @@ def main():
             result["hbm_kernels"] = hbm_kernels(ops, dev)
             try:
                 result["brecq"] = brecq_rate(args.model, args.bits, dev)
+                if args.model != "vit_base":                  # BASELINE configs 3 and 5 reconstruct base-width blocks
+                    result["brecq"]["vit_base_block"] = brecq_rate("vit_base", args.bits, dev, iters=1000, depth=1)
             except Exception as ex:
                 result["brecq"] = {"error": repr(ex)[:300]}
             result["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
