@@ -103,11 +103,13 @@ class GemmProfiler:
 
 def pmc_traffic(kernel, workload_is_default):
     """HBM bytes per launch of `kernel`, REPLAYED from the committed PMC passes of this same command
-    (tools/pmc_bench.sh -> profiles/r03_pmc_bench_traffic.json: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged
+    (tools/pmc_bench.sh -> profiles/r0N_pmc_bench_traffic.json, the latest round: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE, averaged
     over every dispatch of one calibration step).  None for any other workload or when the summary is absent."""
     if not workload_is_default:
         return None
-    path = os.path.join(ROOT, "profiles", "r03_pmc_bench_traffic.json")
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_bench_traffic.json")))
+    path = found[-1] if found else os.path.join(ROOT, "profiles", "r03_pmc_bench_traffic.json")     # the latest round's passes
     try:
         with open(path) as f:
             rows = json.load(f)
@@ -662,7 +664,7 @@ def main():
                          "peak": PEAK_TOPS[dom], "unit": "TFLOP/s", "frac": achieved / PEAK_TOPS[dom],
                          "instantiations": dom_rows,
                          "traffic": pmc_traffic(dom_label, default_workload), "traffic_kernel": dom_label,
-                         "traffic_source": "REPLAYED, not measured by this run: profiles/r03_pmc_bench_traffic.json holds the rocprofv3 --pmc "
+                         "traffic_source": "REPLAYED, not measured by this run: profiles/r0N_pmc_bench_traffic.json (latest round) holds the rocprofv3 --pmc "
                                            "passes of this same command (tools/pmc_bench.sh; FETCH_SIZE x2 per the gfx950 note + "
                                            "WRITE_SIZE, per launch); null for any other workload",
                          "launches": n, "avg_launch_ms": ms / max(n, 1)},

@@ -4,7 +4,7 @@
 import csv
 import sys
 
-r = sys.argv[1] if len(sys.argv) > 1 else "r03"
+r = sys.argv[1] if len(sys.argv) > 1 else "r04"
 GROUPS = [
     ("`k_act_fused_asm` (fc2 activation search)", ["k_act_fused_asm"]),
     ("`k_gemm_slab<…, GEN>` (qkv / proj / fc1 activation searches)", ["k_gemm_slab<2, true", "k_gemm_slab<1, true"]),
