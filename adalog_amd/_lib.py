@@ -70,6 +70,7 @@ SIGNATURES = {
     "adalog_rec_loss": (i32, [p, p, i64, f32, p, p, p]),
     "adalog_rec_loss_backward": (i32, [p, p, i64, f32, p, p, p]),
     "adalog_brecq_init": (i32, []),
+    "adalog_adam_multi": (i32, [p, p, p, p, p, i32, f32, p, f32, f32, f32, p, p]),
     "adalog_gemm_f32x3_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32, i32, i32, i32]),
     "adalog_gemm_f32x3_planes_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "adalog_gemm_f32x3_planes": (i32, [p, i64, p, i64, p, i64, i32, i32, i32, i32, i64, i64, p, f32, p, i32, i32, p, p]),

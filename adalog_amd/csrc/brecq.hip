@@ -284,6 +284,51 @@ __global__ __launch_bounds__(256) void k_round_loss_multi(RoundLossMulti a, floa
     }
 }
 
+// One Adam step (torch.optim.Adam defaults: no weight decay, no amsgrad) for up to ADAM_MAX tensors in ONE launch.  The
+// reference's two optimisers (utils/block_recon.py:108-109) step ~10 tensors per iteration; torch's fused multi-tensor kernel
+// gives a 65 536-element chunk to a block, i.e. ~40 blocks for a block's 2.4 M trained values (52 us); here every block takes
+// 1024 elements.  step_dev holds the number of steps taken so far (the kernel uses step_dev[0] + 1; k_adam_count advances it
+// afterwards, so a captured HIP graph keeps counting); lr_dev (optional) overrides lr: the cosine schedule writes it on the host.
+constexpr int ADAM_MAX = 16;
+struct AdamMulti {
+    float* param[ADAM_MAX];
+    const float* grad[ADAM_MAX];
+    float* m[ADAM_MAX];
+    float* v[ADAM_MAX];
+    int64_t n[ADAM_MAX];
+    int first_block[ADAM_MAX + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void k_adam_multi(AdamMulti a, float lr, const float* __restrict__ lr_dev, float beta1, float beta2,
+                                                    float eps, const float* __restrict__ step_dev) {
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
+    if (lr_dev) lr = lr_dev[0];
+    const float step = step_dev[0] + 1.0f;
+    const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
+    const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+    float* __restrict__ pp = a.param[t];
+    const float* __restrict__ gg = a.grad[t];
+    float* __restrict__ mm = a.m[t];
+    float* __restrict__ vv = a.v[t];
+    const int64_t n = a.n[t];
+    const int64_t base = (int64_t)(blockIdx.x - a.first_block[t]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            const float g = gg[i];
+            const float m_ = mm[i] + (1.0f - beta1) * (g - mm[i]);            // exp_avg.lerp_(grad, 1 - beta1)
+            const float v_ = beta2 * vv[i] + (1.0f - beta2) * g * g;          // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+            const float denom = sqrtf(v_) / bc2s + eps;
+            mm[i] = m_; vv[i] = v_;
+            pp[i] = pp[i] - step_size * (m_ / denom);                         // param.addcdiv_(exp_avg, denom, value=-step_size)
+        }
+    }
+}
+__global__ void k_adam_count(float* step_dev) { step_dev[0] += 1.0f; }
+
 // reconstruction loss  scale * sum_i (pred_i - tgt_i)^2  (block_recon.py:186-199 with p = 2) and its gradient
 __global__ __launch_bounds__(256) void k_rec_loss(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t n,
                                                   float scale, float* __restrict__ part, unsigned int* counter,
@@ -555,5 +600,29 @@ extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const*
     hipLaunchKernelGGL(k_round_loss_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, b_dev, weight, workspace, ticket,
                        loss);
     ADALOG_LAUNCH_CHECK("adalog_round_loss_multi");
+    return 0;
+}
+
+// One Adam step for `count` (<= 16) fp32 tensors in one launch (torch.optim.Adam with default options; reference
+// utils/block_recon.py:108-109,122-125).  params / grads / exp_avg / exp_avg_sq / ns: HOST arrays of device pointers / lengths.
+// step_dev: device fp32 [1], steps taken so far (advanced by one here).  lr_dev: optional device fp32 [1] overriding lr.
+extern "C" int adalog_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                                 const int64_t* ns, int count, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                                 float* step_dev, void* stream) {
+    ADALOG_ARG_CHECK(params && grads && exp_avg && exp_avg_sq && ns && step_dev && count >= 1 && count <= ADAM_MAX, "adam_multi: bad arguments");
+    AdamMulti a;
+    int blocks = 0;
+    for (int t = 0; t < count; ++t) {
+        ADALOG_ARG_CHECK(params[t] && grads[t] && exp_avg[t] && exp_avg_sq[t] && ns[t] >= 1, "adam_multi: bad tensor");
+        a.param[t] = params[t]; a.grad[t] = grads[t]; a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.n[t] = ns[t];
+        a.first_block[t] = blocks;
+        blocks += (int)((ns[t] + 1023) / 1024);
+    }
+    a.first_block[count] = blocks;
+    a.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, st, a, lr, lr_dev, beta1, beta2, eps, step_dev);
+    hipLaunchKernelGGL(k_adam_count, dim3(1), dim3(1), 0, st, step_dev);
+    ADALOG_LAUNCH_CHECK("adalog_adam_multi");
     return 0;
 }

@@ -958,3 +958,20 @@ def uniform_int(x: torch.Tensor, scale: torch.Tensor, zero_point: torch.Tensor, 
                                             _f32c(zero_point, "zero_point").data_ptr(), int(n_bits), _stream())
     _lib.check(rc, "adalog_uniform_int_f32")
     return y
+
+
+def adam_multi(params, grads, exp_avg, exp_avg_sq, step_dev, lr, beta1: float, beta2: float, eps: float):
+    """One Adam step (torch.optim.Adam defaults) for up to 16 fp32 tensors in one launch; ``lr``: float or device tensor [1];
+    ``step_dev``: device fp32 [1] holding the steps taken so far (advanced here)."""
+    import ctypes
+    n = len(params)
+    PA, NA = ctypes.c_void_p * n, ctypes.c_int64 * n
+    for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.AdalogHipError("adam_multi: contiguous fp32 device tensors expected")
+    lr_dev = lr if torch.is_tensor(lr) else None
+    rc = _lib.load().adalog_adam_multi(PA(*[t.data_ptr() for t in params]), PA(*[t.data_ptr() for t in grads]),
+                                      PA(*[t.data_ptr() for t in exp_avg]), PA(*[t.data_ptr() for t in exp_avg_sq]),
+                                      NA(*[t.numel() for t in params]), n, 0.0 if lr_dev is not None else float(lr), _ptr(lr_dev),
+                                      float(beta1), float(beta2), float(eps), step_dev.data_ptr(), _stream())
+    _lib.check(rc, "adalog_adam_multi")

@@ -326,6 +326,13 @@ int adalog_round_loss_multi(const float* const* alphas, float* const* grads, con
 int adalog_rec_loss(const float* pred, const float* tgt, int64_t n, float scale, float* loss, float* workspace, void* stream);
 int adalog_rec_loss_backward(const float* pred, const float* tgt, int64_t n, float scale, const float* gmul, float* gpred,
                              void* stream);
+/* One Adam step (torch.optim.Adam defaults; reference utils/block_recon.py:108-109,122-125) for `count` <= 16 fp32 tensors in ONE
+ *   launch:  m = m + (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t =
+ *   step_dev[0] + 1; step_dev[0] is advanced by one.  params / grads / exp_avg / exp_avg_sq / ns are HOST arrays (device
+ *   pointers / element counts); lr_dev (optional device fp32 [1]) overrides lr (the cosine schedule writes it). */
+int adalog_adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const int64_t* ns, int count, float lr, const float* lr_dev, float beta1, float beta2, float eps,
+                      float* step_dev, void* stream);
 /* Allocates the current device's ticket counters of the BRECQ kernels' in-kernel reductions (idempotent, one ring per
  *   device).  The allocation synchronises the device: call it before capturing BRECQ launches into a HIP graph
  *   (the training loop of reference utils/block_recon.py:114-127 is replayed from one). */

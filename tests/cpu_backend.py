@@ -522,3 +522,16 @@ def gemm_f32x3_planes(a, bp, K, bias=None, alpha=1.0, allow_split=True, alpha_de
 def uniform_int(x, scale, zero_point, n_bits):
     z = torch.round(zero_point.reshape(()))
     return (torch.round(x / scale.reshape(())) + z).clamp(0, 2 ** n_bits - 1) - z
+
+
+def adam_multi(params, grads, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps):
+    """Specification of adalog_adam_multi: torch.optim.Adam's default single-tensor update."""
+    step = float(step_dev.item()) + 1.0
+    lr_ = float(lr.item()) if torch.is_tensor(lr) else float(lr)
+    bc1, bc2 = 1.0 - beta1 ** step, 1.0 - beta2 ** step
+    for p_, g_, m_, v_ in zip(params, grads, exp_avg, exp_avg_sq):
+        m_.lerp_(g_, 1.0 - beta1)
+        v_.mul_(beta2).addcmul_(g_, g_, value=1.0 - beta2)
+        denom = (v_.sqrt() / math.sqrt(bc2)).add_(eps)
+        p_.addcdiv_(m_, denom, value=-(lr_ / bc1))
+    step_dev.add_(1.0)

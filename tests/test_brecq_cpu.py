@@ -21,5 +21,11 @@ def test_brecq_trajectory_matches_reference_loop(golden):
     LC.case_brecq_traj(golden)
 
 
+def test_brecq_trajectory_with_the_one_launch_adam(golden, monkeypatch):
+    """The loop with HipAdam (host logic over the CPU specification of adalog_adam_multi) lands on the reference's trajectory."""
+    monkeypatch.setenv("ADALOG_BRECQ_ADAM", "hip")
+    LC.case_brecq_traj(golden)
+
+
 def test_brecq_reconstruct_model():
     LC.case_brecq_reconstruct(iters=30)
