@@ -35,6 +35,8 @@ SIGNATURES = {
     "adalog_score_act_gen_wgs": (i32, [i32, i32, i64, i32, i64, i32]),
     "adalog_score_act_gen_workspace_bytes": (i64, [i32, i32, i64, i32, i64, i32]),
     "adalog_score_act_gen": (i32, [i32, p, i32, i64, p, i64, i32, i64, p, p, i32, i32, p, p, p, f64, p, i64, p, p]),
+    "adalog_score_w_gen_ok": (i32, [i32, i32, i32, i32, i64, i32]),
+    "adalog_score_w_gen": (i32, [i32, p, i32, i64, p, i32, i32, i64, p, p, i32, i32, p, p, p, p, i64, p]),
     "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p, i64, p]),
     "adalog_finish_topk_next": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p, i64, i32, p, p, p, i32, p, p, i32, f32,
                                       p, p, p, p]),

@@ -680,7 +680,7 @@ extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp
     p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad; p.order = 2; p.reduce_cols = 0;
     p.partial = partial; p.wg_acc = (double*)partial; p.timeline = g_timeline;
     p.slab_U = L.slab_U; p.slab_R = L.slab_R;
-    p.gen_x = x; p.gen_ldx = ldx; p.gen_K = K; p.gen_scale = scale; p.gen_zp = zp;
+    p.gen_x = x; p.gen_ldx = ldx; p.gen_K = K; p.gen_scale = scale; p.gen_zp = zp; p.gen_sc = 1; p.gen_sn = 0; p.gen_sa = nullptr;
     p.gen_qmax = (float)((1 << n_bits) - 1);
     // tie zone: the reciprocal-multiply quotient is within ~2 ulp of the IEEE one; only |quotient| <= 2^bits matters (beyond it
     // both clamp alike), so 6e-7 * 2^bits bounds the difference with a factor of 2.5 to spare; never narrower than 1e-5
@@ -714,6 +714,82 @@ extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp
     // accumulators -- the start of the workspace -- to adalog_finish_scores / adalog_finish_topk_next with MT = adalog_score_act_gen_wgs)
     if (!scores) return 0;
     return adalog_finish_scores(partial, scores, L.wgs, BN2, BN2, P, 1, 1, 0, 0, 2, norm, nullptr, 0, stream);
+}
+
+// ---- weight-candidate scoring call with the candidate operand GENERATED inside the slab kernel
+// reference linear.py:355-392 (_search_best_w_scale): score[p][o] = -norm * sum_t (raw_out[t][o] - bias[o] -
+//   s_a * s_w[p][o] * sum_k (q_a(x) - z_a)[t][k] * (clamp(rne(W[o][k] / s_w[p][o]) + z_w[p][o], 0, 2^bits - 1) - z_w[p][o]))^2
+// Xp: packed activation image (q_a - z_a) [T][Kp] int8 (dtype 0) or fp8 e4m3 (dtype 3); W: fp32 [O][ldw] (K valid); scale / zp:
+// the P (64, 128 or 256) candidates of every output row, [P][O]; ref: raw_out TRANSPOSED [O][T]; sa: device scalar s_a; bias [O]
+// or null.  The packed [O * P][Kp] candidate operand (56-117 MB per call) is neither written nor read.  partial: the layout of
+// adalog_gemm_score_layout(T, O * P, 1, 1, 1, P, 0, dtype, Kp, K, 1) (per-column partial sums, kept axis = (o, p)).
+static Layout wgen_layout(int dtype, int T, int O, int K, int64_t Kp, int P) {
+    Layout L{};
+    if (!(dtype == 0 || dtype == 3) || !(P == 64 || P == 128 || P == 256) || O < 1 || (int64_t)O * P >= ((int64_t)1 << 31) || K < 16 || K % 16 != 0 ||
+        Kp < K) return L;
+    return layout_of(T, O * P, 1, 1, 1, P, 0, true, (int64_t)K, Kp, true, dtype, false);
+}
+
+extern "C" int adalog_score_w_gen_ok(int dtype, int T, int O, int K, int64_t Kp, int P) {
+    static const int use_gen = getenv("ADALOG_SLAB_WGEN") ? atoi(getenv("ADALOG_SLAB_WGEN")) : 1;
+    if (!use_gen || Kp % BK3 != 0) return 0;
+    const Layout L = wgen_layout(dtype, T, O, K, Kp, P);
+    return (L.slab && !L.acc) ? 1 : 0;
+}
+
+extern "C" int adalog_score_w_gen(int dtype, const void* Xp, int T, int64_t Kp, const float* W, int O, int K, int64_t ldw,
+                                  const float* scale, const float* zp, int P, int n_bits, const float* ref, const float* sa,
+                                  const float* bias, float* partial, int64_t partial_elems, void* stream) {
+    ADALOG_ARG_CHECK(Xp && W && scale && zp && ref && sa && partial, "score_w_gen: null pointer");
+    ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7 && (dtype != 3 || n_bits <= 4), "score_w_gen: bad bit width for the operand type");
+    ADALOG_ARG_CHECK(ldw >= K && (ldw % 4 == 0) && ((uintptr_t)W & 15) == 0, "score_w_gen: weight rows must be 16-byte aligned");
+    const Layout L = wgen_layout(dtype, T, O, K, Kp, P);
+    ADALOG_ARG_CHECK(L.slab && !L.acc && Kp % BK3 == 0, "score_w_gen: shape not taken by the slab kernel (adalog_score_w_gen_ok)");
+    ADALOG_ARG_CHECK(partial_elems >= L.elems, "score_w_gen: partial buffer too small");
+    hipStream_t st = (hipStream_t)stream;
+    GemmArgs p{};
+    p.A = (const uint8_t*)Xp; p.B = nullptr;
+    p.M = T; p.N = O * P; p.Kb = Kp; p.Kvb = K; p.C = 1; p.G = 1; p.gmod = 1;
+    p.ref = ref; p.ldr = 1; p.sRg = 0; p.ref_cs = T; p.ref_div = P;
+    ADALOG_ARG_CHECK((int64_t)(O - 1) * T + T < ((int64_t)1 << 31), "score_w_gen: reference exceeds 32-bit addressing");
+    p.sa = sa; p.sa_c = 0; p.sa_mul = 1.0f; p.sb = scale; p.sb_c = O; p.sb_n = 1;
+    p.bias = bias; p.bi_c = 0; p.bi_g = 0; p.bi_n = 1;
+    p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad; p.order = 2; p.reduce_cols = 0;
+    p.partial = partial; p.timeline = g_timeline;
+    p.slab_U = L.slab_U; p.slab_R = L.slab_R;
+    p.gen_x = W; p.gen_ldx = ldw; p.gen_K = K; p.gen_scale = scale; p.gen_zp = zp; p.gen_sc = O; p.gen_sn = 1; p.gen_sa = sa;
+    p.gen_qmax = (float)((1 << n_bits) - 1);
+    const float zone = 6e-7f * (float)(1 << n_bits);
+    p.gen_tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
+    const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
+    const int SBN = 32 * L.slab_nb;
+    const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4;
+    const int nref = SBN / P;
+    {   // a slab that is not cut has unused pieces: they must read as zero
+        const hipError_t me = hipMemsetAsync(partial, 0, (size_t)L.elems * sizeof(float), st);
+        if (me != hipSuccess) { adalog_set_error("adalog_score_w_gen (clear partials)", me); return (int)me; }
+    }
+#define LAUNCH_WGEN(NREFV, DTV, NBV)                                                                              \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, false, DTV, NBV, true>),  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        adalog_note_kernel(DTV == 3 ? (NBV == 8 ? "k_gemm_slab_wgen<fp8>" : "k_gemm_slab128_wgen<fp8>") : (NBV == 8 ? "k_gemm_slab_wgen<i8>" : "k_gemm_slab128_wgen<i8>")); \
+        hipLaunchKernelGGL((k_gemm_slab<NREFV, false, DTV, NBV, true>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
+    } while (0)
+#define LAUNCH_WGEN_DT(DTV)                                                                                       \
+    do {                                                                                                          \
+        if (L.slab_nb == 8) { if (nref == 1) LAUNCH_WGEN(1, DTV, 8); else if (nref == 2) LAUNCH_WGEN(2, DTV, 8); else LAUNCH_WGEN(4, DTV, 8); } \
+        else { if (nref == 1) LAUNCH_WGEN(1, DTV, 4); else LAUNCH_WGEN(2, DTV, 4); }                              \
+    } while (0)
+    if (dtype == 3) LAUNCH_WGEN_DT(3); else LAUNCH_WGEN_DT(0);
+#undef LAUNCH_WGEN_DT
+#undef LAUNCH_WGEN
+    ADALOG_LAUNCH_CHECK("adalog_score_w_gen");
+    return 0;
 }
 
 // scores[c][h?][n?] = -norm * sum over (image, [h], m_tile, [n]) of partial[c][g][m_tile][n] with the layout returned by

@@ -478,6 +478,45 @@ def score_act_gen(dtype: int, wp, x2, scale, zp, n_bits: int, ref2, row_scale, r
     return PendingScores(ws, wgs, 256, 256, P, 1, 1, False, False, 2, norm, T) if defer else scores
 
 
+_WGEN_LAYOUT = {}
+
+
+def score_w_gen_ok(dtype: int, T: int, O: int, K: int, Kp: int, P: int) -> bool:
+    return bool(_lib.load().adalog_score_w_gen_ok(int(dtype), int(T), int(O), int(K), int(Kp), int(P)))
+
+
+def score_w_gen(dtype: int, xp, w2, scale, zp, n_bits: int, ref_t, sa, bias, norm: float, defer: bool = False):
+    """Weight-candidate scores [P, O] of a uniformly quantised Linear layer (reference linear.py:355-392) with the candidate
+    operand generated inside the slab kernel: xp = packed activation image [1, 1, T, Kp] (int8 / fp8), w2 = weight [O, K] fp32,
+    (scale, zp) = the P candidates of every output row [P, O], ref_t = raw_out transposed [O, T], sa = activation scale [1]."""
+    lib = _lib.load()
+    T, Kp = xp.shape[-2], xp.shape[-1]
+    w2, ref_t = _f32c(w2, "weight"), _f32c(ref_t, "ref")
+    O, K = w2.shape
+    scale, zp = _f32c(scale, "scale"), _f32c(zp, "zp")
+    P = scale.shape[0]
+    assert xp.dtype == _TORCH_DT[dtype] and xp.is_contiguous() and tuple(ref_t.shape[-2:]) == (O, T)
+    assert scale.numel() == P * O and zp.numel() == P * O
+    sa = _f32c(sa, "sa").reshape(-1)
+    bias = None if bias is None else _f32c(bias, "bias")
+    key = (T, O, P, dtype, Kp, K)
+    if key not in _WGEN_LAYOUT:
+        _WGEN_LAYOUT[key] = _layout(T, O * P, 1, 1, 1, P, 0, dtype, Kp, K, True)
+    n_part, MT, Npad, mode = _WGEN_LAYOUT[key]
+    partial = torch.empty((n_part + 1) // 2, dtype=torch.float64, device=w2.device).view(torch.float32)
+    if GEMM_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.adalog_score_w_gen(dtype, xp.data_ptr(), T, Kp, w2.data_ptr(), O, K, K, scale.data_ptr(), zp.data_ptr(), P, int(n_bits),
+                                ref_t.data_ptr(), sa.data_ptr(), _ptr(bias), partial.data_ptr(), n_part, _stream())
+    if GEMM_EVENTS is not None:
+        ev1.record()
+        GEMM_EVENTS.append((dtype, T, O, K, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
+    _lib.check(rc, "adalog_score_w_gen")
+    pend = PendingScores(partial, MT, O, Npad, P, 1, 1, False, True, mode, norm, O)
+    return pend if defer else pend.finish()
+
+
 # ------------------------------------------------------------------------------------------------ FPCS pieces
 def topk(scores, k: int):
     scores = _f32c(scores, "scores")

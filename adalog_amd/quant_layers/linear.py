@@ -40,6 +40,8 @@ FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
 # self-MSE searches scored from the sorted tensor (csrc/sorted_score.hip); 0 = one pass over the tensor per step (round 1/2)
 # uniform activation searches: candidate operand generated in the slab kernel (1) or packed to HBM first (0, rounds 1-2)
 GEN_ACT_SEARCH = os.environ.get('ADALOG_GEN_ACT', '1') != '0'
+# uniform weight searches on the slab kernel: candidate operand generated in the kernel from the fp32 weight rows (1) or packed (0)
+GEN_W_SEARCH = os.environ.get('ADALOG_GEN_W', '1') != '0'
 SORTED_SELF_SEARCH = os.environ.get('ADALOG_SORTED_SELF', '1') != '0'
 RUN_DEAD_W_SELF = os.environ.get('ADALOG_DEAD_W_SELF', '0') == '1'
 MIXED_W_SEARCH = os.environ.get('ADALOG_MIXED_W', '1') != '0'     # bf16 activations x fp8 weight candidates (wide streaming kernel)
@@ -232,6 +234,11 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         mixed = (dt == BF16 and MIXED_W_SEARCH and wq.n_bits <= 4 and chunk >= P and xp.shape[-1] % 64 == 0
                  and hasattr(be, "gemm_mixed_ok") and be.gemm_mixed_ok(M, self.out_features, 1, 1, P, self.in_features))
         cdt, gdt, kal = (FP8, BF16_FP8, 64) if mixed else (dt, dt, 128)
+        if (GEN_W_SEARCH and shift is None and dt in (I8, FP8) and chunk >= P and hasattr(be, "score_w_gen")
+                and be.score_w_gen_ok(dt, M, self.out_features, self.in_features, xp.shape[-1], P)):
+            # the candidate operand is generated inside the slab kernel from the fp32 weight rows: nothing is packed
+            return be.score_w_gen(dt, xp, self._w2(), scale, zp, wq.n_bits, self._ref2_t(), sa.t, None if self.bias is None else self.bias.data,
+                                  1.0 / self._tokens_per_image(), defer=defer)
         for s in range(0, P, chunk):
             e = min(P, s + chunk)
             sc, zc = scale[s:e].contiguous(), zp[s:e].contiguous()

@@ -76,11 +76,11 @@ class GemmProfiler:
 
     @staticmethod
     def template_of(label):
-        """`k_gemm_slab128_gen<fp8>` -> `k_gemm_slab<fp8>`: the generated-operand (GEN) and 128-column forms are instantiations of
+        """`k_gemm_slab128_gen<fp8>` / `k_gemm_slab_wgen<fp8>` -> `k_gemm_slab<fp8>`: the generated-operand and 128-column forms are instantiations of
         one kernel template; `k_act_fused_asm<12,4,bf16>` -> `k_act_fused_asm<bf16>`."""
         import re
         head, _, tail = label.partition("<")
-        head = head.replace("128", "").replace("_gen", "")
+        head = head.replace("128", "").replace("_wgen", "").replace("_gen", "")
         args = tail.rstrip(">").split(",")
         return f"{head}<{args[-1]}>" if tail else head
 
@@ -124,8 +124,10 @@ def pmc_traffic(kernel, workload_is_default):
         if label.startswith("k_gemm_slab"):                        # k_gemm_slab<NREF, ROWS, DT, NB, GEN>
             if base != "k_gemm_slab" or len(targs) < 5:
                 return False
-            gen, nb128 = label.endswith("_gen"), "128" in label
-            return (targs[4] == "true") == gen and (targs[3] == "4") == nb128 and targs[2] == {"fp8": "3", "i8": "0"}.get(ldt, targs[2])
+            wgen, gen, nb128 = label.endswith("_wgen"), label.endswith("_gen"), "128" in label
+            # GEN = true: ROWS = true is the activation form (`_gen`), ROWS = false the weight form (`_wgen`)
+            return ((targs[4] == "true") == (gen or wgen) and (not (gen or wgen) or (targs[1] == "true") == gen)
+                    and (targs[3] == "4") == nb128 and targs[2] == {"fp8": "3", "i8": "0"}.get(ldt, targs[2]))
         return pmc_name.startswith(label)
     tot, n = 0.0, 0
     for name, v in rows.items():

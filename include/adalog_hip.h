@@ -217,6 +217,17 @@ int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp, const flo
                          const float* scale, const float* zp, int P, int n_bits, const float* ref, const float* row_scale,
                          const float* row_bias, double norm, void* workspace, int64_t workspace_bytes, float* scores,
                          void* stream);
+/* The weight-candidate scoring call of a uniformly quantised Linear (reference quant_layers/linear.py:355-392) with the candidate
+ *   operand GENERATED inside the slab kernel: score[p][o] = -norm * sum_t (raw_out[t][o] - bias[o] - s_a * s_w[p][o] *
+ *   sum_k (q_a(x) - z_a)[t][k] * (clamp(rne(W[o][k] / s_w[p][o]) + z_w[p][o], 0, 2^bits - 1) - z_w[p][o]))^2.
+ *   Xp: packed activation image [T][Kp] (dtype 0 int8 / 3 fp8); W fp32 [O][ldw]; scale / zp [P][O]; ref = raw_out transposed
+ *   [O][T]; sa: device scalar s_a; bias [O] or null.  No packed [O*P][Kp] candidate operand is written or read.  partial: the
+ *   buffer adalog_gemm_score_layout(T, O*P, 1, 1, 1, P, 0, dtype, Kp, K, 1) describes (finish with adalog_finish_scores /
+ *   adalog_finish_topk_next, keep_n = 1).  adalog_score_w_gen_ok: whether the shape is taken (K % 16 == 0, T % 32 == 0, ...). */
+int adalog_score_w_gen_ok(int dtype, int T, int O, int K, int64_t Kp, int P);
+int adalog_score_w_gen(int dtype, const void* Xp, int T, int64_t Kp, const float* W, int O, int K, int64_t ldw, const float* scale,
+                       const float* zp, int P, int n_bits, const float* ref, const float* sa, const float* bias, float* partial,
+                       int64_t partial_elems, void* stream);
 
 /* ---- K9   _search_best_w_scale_self                                   reference linear.py:296-309
  * scores[p][row] = -mean_i (w[row][i] - fq_p(w[row][i]))^2,  w: [rows][I], scale/zp: [P][rows]. */

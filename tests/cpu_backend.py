@@ -535,3 +535,22 @@ def adam_multi(params, grads, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, e
         denom = (v_.sqrt() / math.sqrt(bc2)).add_(eps)
         p_.addcdiv_(m_, denom, value=-(lr_ / bc1))
     step_dev.add_(1.0)
+
+
+def score_w_gen_ok(dtype, T, O, K, Kp, P):
+    return K % 16 == 0 and P in (64, 128, 256)            # (permissive: the CPU tier exercises the host path at toy shapes)
+
+
+def score_w_gen(dtype, xp, w2, scale, zp, n_bits, ref_t, sa, bias, norm, defer=False):
+    """spec of ops.score_w_gen: scores[p][o] = -norm * sum_t (ref[t][o] - bias[o] - s_a * s_w[p][o] * xq[t] . wq_p[o])^2
+    (linear.py:355-384), the candidate weights quantised from the fp32 rows."""
+    O, K = w2.shape
+    P = scale.shape[0]
+    xq = xp.reshape(xp.shape[-2], xp.shape[-1])[:, :K].to(torch.float64)                  # q_a - z_a [T, K]
+    sc, z = scale.reshape(P, O, 1), torch.round(zp.reshape(P, O, 1))
+    wq = ((torch.round(w2.unsqueeze(0) / sc) + z).clamp(0, 2 ** n_bits - 1) - z).double()   # [P, O, K]
+    sim = torch.einsum("tk,pok->pot", xq, wq) * (sc.double() * float(sa.reshape(-1)[0]))
+    if bias is not None:
+        sim = sim + bias.double().view(1, O, 1)
+    s = (-norm * ((ref_t.double().reshape(1, O, -1) - sim) ** 2).sum(-1)).float()         # [P, O]
+    return PendingScores(s) if defer else s

@@ -51,7 +51,7 @@ def _log(name, **kw):
 # file -- checks that every production label was hit by some case, so a dispatch regression cannot stay green.
 FALLBACK = {"k_gemm_cand", "k_gemm_cand_glds", "k_gemm_score", ""}
 SEEN = {}
-REQUIRED = {"k_gemm_slab<fp8>", "k_gemm_slab<i8>", "k_gemm_slab128<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
+REQUIRED = {"k_gemm_slab_wgen<fp8>", "k_gemm_slab_wgen<i8>", "k_gemm_slab128_wgen<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
             "k_gemm_slab128_gen<fp8>", "k_act_fused_asm<12,4,bf16>", "k_act_fused_asm<12,3,bf16>", "k_act_fused_asm<8,4,bf16>",
             "k_act_fused_asm<4,4,bf16>", "k_gemm_stream<bf16xfp8>", "k_gemm_stream<bf16>", "k_gemm_grpw<fp8>", "k_gemm_grpw<i8>",
             "k_gemm_grpk8<bf16xfp8>", "k_gemm_grpk<bf16>", "k_gemm_win<fp8>", "k_gemm_winb<bf16xfp8>"}
@@ -101,11 +101,11 @@ LINEAR = [  # tag, I, O, n_V, tokens per image, images, bits
     ("swin_base.l3.qkv", 1024, 3072, 3, 49, 32, 3),
 ]
 LINEAR_KERNELS = {          # case -> (weight search, activation search) labels that production dispatches there
-    "deit_small.qkv-w4": (("k_gemm_slab<fp8>",), ("k_gemm_slab_gen<fp8>",)),
-    "deit_small.proj-w4": (("k_gemm_slab<fp8>",), ("k_gemm_slab_gen<fp8>",)),
-    "vit_base.qkv-w4": (("k_gemm_slab128<fp8>",), ("k_gemm_slab128_gen<fp8>",)),
-    "deit_small.qkv-w6": (("k_gemm_slab<i8>",), ("k_gemm_slab_gen<i8>",)),
-    "deit_small.fc1-w6": (("k_gemm_slab<i8>",), ("k_gemm_slab_gen<i8>",)),
+    "deit_small.qkv-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),
+    "deit_small.proj-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),
+    "vit_base.qkv-w4": (("k_gemm_slab128_wgen<fp8>",), ("k_gemm_slab128_gen<fp8>",)),
+    "deit_small.qkv-w6": (("k_gemm_slab_wgen<i8>",), ("k_gemm_slab_gen<i8>",)),
+    "deit_small.fc1-w6": (("k_gemm_slab_wgen<i8>",), ("k_gemm_slab_gen<i8>",)),
 }
 
 

@@ -1363,3 +1363,37 @@ def test_brecq_iteration_runs_no_library_gemm():
     names = [e.key for e in prof.key_averages()]
     assert any("k_bq_gemm" in n for n in names), names
     assert not any(n.startswith("Cijk_") for n in names), [n for n in names if n.startswith("Cijk_")]
+
+
+@pytest.mark.parametrize("bits,dt_name", [(4, "fp8"), (3, "fp8"), (6, "i8")])
+@pytest.mark.parametrize("T,O,K", [(6304, 1152, 384), (6304, 384, 384), (1568, 768, 768)])
+def test_score_w_gen_matches_packed_path(ops, bits, dt_name, T, O, K):
+    """Weight-candidate scores with the candidate operand generated in the slab kernel (adalog_score_w_gen) against the packed
+    path (pack_uniform + gemm_score) on the same candidates, with weight values planted on rounding ties."""
+    from adalog_amd.ops import FP8, I8, Strided
+    dt = FP8 if dt_name == "fp8" else I8
+    gen = g(8000 + bits + T + O)
+    P = 128
+    x = torch.randn(T, K, generator=gen)
+    W = torch.randn(O, K, generator=gen) * 0.05
+    b = torch.randn(O, generator=gen) * 0.1
+    qmax = 2 ** bits - 1
+    w_lo, w_hi = W.min(1).values, W.max(1).values
+    sc = ((w_hi - w_lo) / qmax).view(1, O) * torch.linspace(0.6, 1.2, P).view(P, 1)
+    zp = torch.round(-w_lo.view(1, O) / sc).clamp(0, qmax)
+    W[:, 5] = sc[17] * 2.5                                              # exact ties of candidate 17 (and near-ties of its neighbours)
+    W[:, 9] = sc[90] * -1.5
+    a_s = torch.tensor([x.abs().max().item() * 2 / qmax])
+    a_z = torch.tensor([float(2 ** (bits - 1))])
+    ref = torch.nn.functional.linear(x, W, b)
+    xd, Wd = x.to(DEV), W.to(DEV)
+    xp = ops.pack_uniform(xd.unsqueeze(0), a_s.to(DEV), a_z.to(DEV), 1, 0, 1, 0, 0, bits, dt)
+    assert ops.score_w_gen_ok(dt, T, O, K, xp.shape[-1], P)
+    ref_t = ref.t().contiguous().to(DEV)
+    got = ops.score_w_gen(dt, xp, Wd, sc.to(DEV).contiguous(), zp.to(DEV).contiguous(), bits, ref_t, a_s.to(DEV), b.to(DEV), 1.0 / 197)
+    assert _last_kernel().startswith(("k_gemm_slab_wgen<", "k_gemm_slab128_wgen<"))
+    wp = ops.pack_uniform(Wd.unsqueeze(0), sc.to(DEV).contiguous(), zp.to(DEV).contiguous(), P, O, 1, 0, 1, bits, dt, c_inner=True)
+    want = ops.gemm_score(dt, xp, wp, T, O, P, 1, 1, ref_t, Strided(a_s.to(DEV)), Strided(sc.to(DEV).contiguous(), c=O, n=1),
+                          Strided(b.to(DEV), n=1), False, True, 1.0 / 197, ref_div=P, order=2, ref_transposed=True)
+    assert got.shape == want.shape == (P, O)
+    assert rel_err(got.cpu(), want.cpu()) <= 2e-6
