@@ -60,6 +60,8 @@ SIGNATURES = {
     "adalog_select_quantile_out": (i32, [p, i64, i32, p, i32, p, p]),
     "adalog_select_value_out": (i32, [p, i64, i32, p, p]),
     "adalog_uniform_int_f32": (i32, [p, p, i64, p, p, i32, p]),
+    "adalog_permute_heads": (i32, [p, p, i64, i64, i32, i32, i32, i32, p]),
+    "adalog_merge_heads": (i32, [p, p, p, p, p, i64, i64, i32, i32, i32, p]),
     "adalog_uniform_fq_backward_blocks": (i32, [i64, i64, i64]),
     "adalog_uniform_fq_backward": (i32, [p, p, p, i64, p, p, i64, i64, i32, i32, p, p, p, p]),
     "adalog_log_fq_backward": (i32, [p, p, p, p, i64, p, p, i32, p, i32, p, p, p]),
@@ -77,6 +79,8 @@ SIGNATURES = {
     "adalog_gemm_f32x3_planes_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "adalog_gemm_f32x3_planes": (i32, [p, i64, p, i64, p, i64, i32, i32, i32, i32, i64, i64, p, f32, p, i32, i32, p, p]),
     "adalog_gemm_f32x3": (i32, [p, i64, i32, p, i64, i32, p, i64, i32, i32, i32, i32, i64, i64, i64, p, f32, p, i32, i32, i32, p, p]),
+    "adalog_gemm_f32x3_g2": (i32, [p, i64, i32, p, i64, i32, p, i64, i32, i32, i32, i32, i64, i64, i64, i32, i64, i64, i64, p, f32, p,
+                             i32, i32, i32, p, p]),
     "adalog_shift_fold": (i32, [p, p, p, p, i32, i32, p, p]),
     "adalog_minmax_rows": (i32, [p, i32, i32, i32, p, p, p]),
     "adalog_absminmax_cols": (i32, [p, i64, i32, i32, p, p, p]),

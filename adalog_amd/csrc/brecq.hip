@@ -33,8 +33,17 @@ __device__ __forceinline__ void store_agent(float* p, float v) {
 __device__ __forceinline__ float load_agent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Call after thread 0 issued its store_agent()s.  True in exactly one block; that block puts the counter back to zero.
-__device__ __forceinline__ bool last_block_arrives(unsigned int* counter, unsigned total) {
+// Call after thread 0 issued its store_agent()s.  True in exactly one block; the counters are back at zero afterwards.
+// Device-scope atomics on ONE word serialise (~10 ns each, measured: a 4 096-block launch spent 41 us of 62 drawing tickets), so
+// the ticket has two levels: a block draws from one of TW_GROUPS first-level words (by block index, so that blocks finishing
+// together hit different words; the words lie TW_STRIDE apart -- another 4 KiB page and another 256-byte slot, whichever the
+// memory channels interleave on), and the last block of a group draws from the top word.  Every draw waits for the value of the
+// one before it, and a block's partial stores are acknowledged before its first draw: when the last top ticket is drawn, all
+// partials are visible.
+constexpr int TW_GROUPS = 16;
+constexpr int TW_STRIDE = 1088;                         // words
+constexpr int TW_WORDS = (TW_GROUPS + 1) * TW_STRIDE;   // one wide ticket
+__device__ __forceinline__ bool last_block_arrives(unsigned int* tw, unsigned total) {
     __shared__ int is_last;
     if (threadIdx.x == 0) {
         // the partial stores must be acknowledged before the ticket is drawn.  A workgroup-scope fence compiles to
@@ -42,9 +51,23 @@ __device__ __forceinline__ bool last_block_arrives(unsigned int* counter, unsign
         // ticket, so without the explicit vmcnt wait the ticket could become visible first (tests/test_abi.py greps the ISA)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == total - 1) ? 1 : 0;
-        if (is_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned ng = total < (unsigned)TW_GROUPS ? total : (unsigned)TW_GROUPS;
+        const unsigned gi = lin % ng;
+        const unsigned cnt = total / ng + (gi < total % ng ? 1u : 0u);
+        unsigned int* c1 = tw + gi * TW_STRIDE;
+        unsigned int* top = tw + TW_GROUPS * TW_STRIDE;
+        int last = 0;
+        const unsigned t = __hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == cnt - 1) {
+            const unsigned t2 = __hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(c1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t2 == ng - 1) {
+                __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
+        }
+        is_last = last;
     }
     __syncthreads();
     return is_last != 0;
@@ -156,8 +179,8 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
     float as = 0.0f;
     // k is the forward's bin (same exact-with-fallback evaluation); the gradient factors use reciprocals: they are smooth
     // in their inputs, so a last-ulp difference from the IEEE quotients moves the gradient by ~1e-7 relative.
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float xs = shift ? x[i] + sh : x[i];
+    auto one = [&](float xv, float g, float& gxo) {
+        const float xs = shift ? xv + sh : xv;
         const float ur = xs / s;
         const bool iu = (ur >= 1e-15f) && (ur <= 1.0f);
         const float u = fminf(fmaxf(ur, 1e-15f), 1.0f);
@@ -165,10 +188,22 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
         const bool ik = (k >= 0.0f) && (k <= kmax);
         // y before the "- shift", recomputed from k (adding the shift back to the stored output would cancel small y)
         const float yv = (k <= kmax) ? __builtin_amdgcn_exp2f(-fminf(fmaxf(k, 0.0f), kmax) * q37) * s : 0.0f;
-        const float g = gy[i];
         const float dydx = (iu && ik) ? yv * __builtin_amdgcn_rcpf(u * s) : 0.0f;
-        if (gx) gx[i] = g * dydx;
+        gxo = g * dydx;
         as += g * inv_s * (yv - dydx * xs);
+    };
+    // four elements per thread and turn (16-byte loads; x, gy, gx come from the allocator: 16-byte aligned)
+    const int64_t n4 = ((((uintptr_t)gy | (uintptr_t)x | (uintptr_t)gx) & 15) == 0) ? (n >> 2) : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 xv = reinterpret_cast<const float4*>(x)[i], g = reinterpret_cast<const float4*>(gy)[i];
+        float4 o;
+        one(xv.x, g.x, o.x); one(xv.y, g.y, o.y); one(xv.z, g.z, o.z); one(xv.w, g.w, o.w);
+        if (gx) reinterpret_cast<float4*>(gx)[i] = o;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float o;
+        one(x[i], gy[i], o);
+        if (gx) gx[i] = o;
     }
     if (part_s) {
         const float ts = block_sum(as, sm);
@@ -384,6 +419,46 @@ __global__ __launch_bounds__(256) void k_uniform_int(const float* __restrict__ x
     }
 }
 
+// The head split of an attention block as ONE pass: x [B][N][P][H][D] (the qkv Linear's output, P = 3) -> y [P][B][H][N][D]
+// (contiguous q, k, v), and the inverse for the gradient.  Autograd's own route is three strided copies forward and a stack +
+// copies backward.  D % 4 == 0; a thread moves one float4; consecutive threads walk D, then H (forward: reads of H * D contiguous
+// floats, writes of D-float runs).
+__global__ __launch_bounds__(256) void k_permute_heads(const float* __restrict__ src, float* __restrict__ dst, int64_t B, int64_t N,
+                                                       int P, int H, int D4, int inverse) {
+    const int64_t total = B * N * P * H * D4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // i indexes the [B][N][P][H][D4] side
+        int64_t r = i;
+        const int d = (int)(r % D4); r /= D4;
+        const int h = (int)(r % H); r /= H;
+        const int pp = (int)(r % P); r /= P;
+        const int64_t n = r % N, b = r / N;
+        const int64_t j = ((((int64_t)pp * B + b) * H + h) * N + n) * D4 + d;       // the [P][B][H][N][D4] side
+        if (inverse) d4[i] = s4[j]; else d4[j] = s4[i];
+    }
+}
+
+// The inverse of the head split with the P parts given as separate tensors [B][H][N][D] (the gradients of q, k, v as autograd
+// hands them over: no stack in front); a null part counts as zeros.
+struct HeadParts { const float* p[4]; };
+__global__ __launch_bounds__(256) void k_merge_heads(HeadParts src, float* __restrict__ dst, int64_t B, int64_t N, int P, int H,
+                                                     int D4) {
+    const int64_t total = B * N * P * H * D4;
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int d = (int)(r % D4); r /= D4;
+        const int h = (int)(r % H); r /= H;
+        const int pp = (int)(r % P); r /= P;
+        const int64_t n = r % N, b = r / N;
+        const float* part = src.p[pp];
+        const int64_t j = ((b * H + h) * N + n) * D4 + d;
+        d4[i] = part ? reinterpret_cast<const float4*>(part)[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
 // Ticket counters for the "last block finishes" reductions: zeroed device words, handed out round-robin at enqueue time (the
 // launch's last block puts its words back to zero).  A word may be re-issued only to a launch that runs AFTER the one holding
 // it, which stream order guarantees on ONE stream; launches enqueued far ahead on two streams (the calibrator's lanes) could
@@ -427,6 +502,42 @@ unsigned int* ticket_slots(int n, void* stream) {
 }
 unsigned int* ticket_slot(void* stream) { return ticket_slots(1, stream); }
 
+// Wide (two-level) tickets of this file's own reductions (last_block_arrives): TW_WORDS zeroed words each, WIDE per sub-ring.
+// Launches of one stream run one after the other and every launch leaves its ticket zeroed, so a stream could reuse one ticket
+// for ever; the sub-rings keep concurrently enqueuing streams (the calibrator's lanes) apart, as above.
+constexpr int WIDE = 4;
+unsigned int* ticket_wide(void* stream) {
+    static unsigned int* rings[MAX_DEV] = {};
+    static unsigned next[MAX_DEV][SUB] = {};
+    static void* owner[MAX_DEV][SUB] = {};
+    static int owners[MAX_DEV] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!rings[dev]) {
+        unsigned int* p = nullptr;
+        const size_t bytes = (size_t)SUB * WIDE * TW_WORDS * sizeof(unsigned int);
+        if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            return nullptr;
+        rings[dev] = p;
+    }
+    int sub = -1;
+    for (int i = 0; i < owners[dev]; ++i)
+        if (owner[dev][i] == stream) { sub = i; break; }
+    if (sub < 0) {
+        if (owners[dev] < SUB) { sub = owners[dev]++; owner[dev][sub] = stream; }
+        else sub = SUB - 1;
+    }
+    return rings[dev] + ((size_t)sub * WIDE + (next[dev][sub]++ % WIDE)) * TW_WORDS;
+}
+
+// lab switch (tools/lab/brecq_small_bench.py): cap on the blocks of the "last block finishes" reductions
+inline int red_cap(int dflt) {
+    static const int v = getenv("ADALOG_RED_CAP") ? atoi(getenv("ADALOG_RED_CAP")) : 0;
+    return v > 0 && v < dflt ? v : dflt;
+}
+
 inline int grid1(int64_t n, int cap = 2048) {
     int64_t b = (n + 255) / 256;
     if (b < 1) b = 1;
@@ -445,7 +556,7 @@ extern "C" unsigned int* adalog_ticket_slots_on(int n, void* stream) { return ti
 // Allocates the current device's ticket ring (idempotent).  Call once per device before capturing BRECQ launches into a
 // HIP graph: the allocation synchronises the device, which would invalidate a capture in progress.
 extern "C" int adalog_brecq_init(void) {
-    ADALOG_ARG_CHECK(ticket_slot(nullptr) != nullptr, "brecq_init: cannot allocate the ticket counters");
+    ADALOG_ARG_CHECK(ticket_slot(nullptr) != nullptr && ticket_wide(nullptr) != nullptr, "brecq_init: cannot allocate the ticket counters");
     return 0;
 }
 
@@ -456,6 +567,7 @@ extern "C" int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, 
     const int64_t want = rows >= 4096 ? 1 : (4096 + rows - 1) / rows;      // blocks per row so that rows * nb >= 4096
     int64_t nb = (inner + 2047) / 2048;
     if (nb > want) nb = want;
+    if (rows == 1 && nb > red_cap(4096)) nb = red_cap(4096);
     if (nb < 1) nb = 1;
     return (int)nb;
 }
@@ -469,6 +581,29 @@ extern "C" int adalog_uniform_int_f32(const float* x, float* y, int64_t n, const
     hipLaunchKernelGGL(k_uniform_int, dim3(grid1(n / 4 + 1, 4096)), dim3(256), 0, (hipStream_t)stream, x, y, n, scale, zero_point,
                        (float)((1 << n_bits) - 1));
     ADALOG_LAUNCH_CHECK("adalog_uniform_int_f32");
+    return 0;
+}
+
+extern "C" int adalog_permute_heads(const float* src, float* dst, int64_t B, int64_t N, int P, int H, int D, int inverse,
+                                    void* stream) {
+    if (B * N * P * H * D == 0) return 0;
+    ADALOG_ARG_CHECK(src && dst && B > 0 && N > 0 && P > 0 && H > 0 && D > 0 && D % 4 == 0, "permute_heads: bad arguments");
+    hipLaunchKernelGGL(k_permute_heads, dim3(grid1(B * N * P * H * (D / 4), 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
+                       N, P, H, D / 4, inverse);
+    ADALOG_LAUNCH_CHECK("adalog_permute_heads");
+    return 0;
+}
+
+extern "C" int adalog_merge_heads(const float* p0, const float* p1, const float* p2, const float* p3, float* dst, int64_t B,
+                                  int64_t N, int P, int H, int D, void* stream) {
+    if (B * N * P * H * D == 0) return 0;
+    ADALOG_ARG_CHECK(dst && B > 0 && N > 0 && P > 0 && P <= 4 && H > 0 && D > 0 && D % 4 == 0, "merge_heads: bad arguments");
+    ADALOG_ARG_CHECK((((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2 | (uintptr_t)p3 | (uintptr_t)dst) & 15) == 0,
+                     "merge_heads: tensors must be 16-byte aligned");
+    HeadParts hp = {{p0, p1, p2, p3}};
+    hipLaunchKernelGGL(k_merge_heads, dim3(grid1(B * N * P * H * (D / 4), 8192)), dim3(256), 0, (hipStream_t)stream, hp, dst, B, N, P,
+                       H, D / 4);
+    ADALOG_LAUNCH_CHECK("adalog_merge_heads");
     return 0;
 }
 
@@ -489,7 +624,7 @@ extern "C" int adalog_uniform_fq_backward(const float* gy, const float* x, float
     float* ps = (gscale || gzp) ? workspace : nullptr;
     float* pz = (gzp && !symmetric) ? workspace + rows * nb : nullptr;
     // per-tensor parameters: the kernel's last block reduces the partials itself (no finish launches)
-    unsigned int* ticket = (ps && n_channels == 1) ? ticket_slot(stream) : nullptr;
+    unsigned int* ticket = (ps && n_channels == 1) ? ticket_wide(stream) : nullptr;
     ADALOG_ARG_CHECK(!(ps && n_channels == 1) || ticket, "uniform_fq_backward: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_uniform_bwd, dim3(nb, gy_), dim3(256), 0, st, gy, x, gx, rows, inner, scale,
                        symmetric ? nullptr : zero_point, n_channels, qmin, qmax, ps, pz, ticket, gscale, gzp);
@@ -509,9 +644,9 @@ extern "C" int adalog_log_fq_backward(const float* gy, const float* x, const flo
     if (n == 0) return 0;
     ADALOG_ARG_CHECK(gy && x && y && scale && q, "log_fq_backward: bad arguments");
     ADALOG_ARG_CHECK(!gscale || workspace, "log_fq_backward: the scale gradient needs a workspace");
-    const int nb = grid1(n, 1024);
+    const int nb = grid1(n, red_cap(1024));
     hipStream_t st = (hipStream_t)stream;
-    unsigned int* ticket = gscale ? ticket_slot(stream) : nullptr;
+    unsigned int* ticket = gscale ? ticket_wide(stream) : nullptr;
     ADALOG_ARG_CHECK(!gscale || ticket, "log_fq_backward: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_adalog_bwd, dim3(nb), dim3(256), 0, st, gy, x, y, gx, n, scale, q, 1 << n_bits, shift, sub_shift,
                        gscale ? workspace : nullptr, ticket, gscale);
@@ -538,7 +673,7 @@ extern "C" int adalog_round_loss(const float* alpha, int64_t n, float b, const f
     ADALOG_ARG_CHECK(alpha && n >= 1 && (loss == nullptr || workspace), "round_loss: bad arguments");
     const int nb = grid1(n, 1024);
     hipStream_t st = (hipStream_t)stream;
-    unsigned int* ticket = loss ? ticket_slot(stream) : nullptr;
+    unsigned int* ticket = loss ? ticket_wide(stream) : nullptr;
     ADALOG_ARG_CHECK(!loss || ticket, "round_loss: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_round_loss, dim3(nb), dim3(256), 0, st, alpha, n, b, b_dev, loss ? workspace : nullptr, galpha, gscale,
                        gmul, overwrite, ticket, loss);
@@ -552,9 +687,9 @@ extern "C" int adalog_rec_loss(const float* pred, const float* tgt, int64_t n, f
                                void* stream) {
     ADALOG_ARG_CHECK(pred && tgt && loss && workspace && n >= 1, "rec_loss: bad arguments");
     ADALOG_ARG_CHECK((((uintptr_t)pred | (uintptr_t)tgt) & 15) == 0, "rec_loss: pred / tgt must be 16-byte aligned");
-    unsigned int* ticket = ticket_slot(stream);
+    unsigned int* ticket = ticket_wide(stream);
     ADALOG_ARG_CHECK(ticket, "rec_loss: cannot allocate the ticket counters");
-    hipLaunchKernelGGL(k_rec_loss, dim3(grid1(n / 4 + 1, 2048)), dim3(256), 0, (hipStream_t)stream, pred, tgt, n, scale, workspace,
+    hipLaunchKernelGGL(k_rec_loss, dim3(grid1(n / 4 + 1, red_cap(2048))), dim3(256), 0, (hipStream_t)stream, pred, tgt, n, scale, workspace,
                        ticket, loss);
     ADALOG_LAUNCH_CHECK("adalog_rec_loss");
     return 0;
@@ -595,7 +730,7 @@ extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const*
     }
     a.first_block[count] = blocks;
     a.count = count;
-    unsigned int* ticket = ticket_slot(stream);
+    unsigned int* ticket = ticket_wide(stream);
     ADALOG_ARG_CHECK(ticket, "round_loss_multi: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_round_loss_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, b_dev, weight, workspace, ticket,
                        loss);

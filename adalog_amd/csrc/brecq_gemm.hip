@@ -31,6 +31,7 @@ typedef void __attribute__((address_space(3)))* las_ptr;
 struct BqArgs {
     const float* A; const float* B; float* C;
     int64_t lda, ldb, ldc, sAg, sBg, sCg;      // element strides
+    int Gi; int64_t sAo, sBo, sCo;             // two-level groups: group g sits at (g % Gi) * s?g + (g / Gi) * s?o  (Gi = G: one level)
     int M, N, K, G, S;                         // S = K splits (S > 1: C is the partial buffer [S][G][M][N], ldc = N)
     int MT, NT, nk;                            // tiles, 16-element K-steps
     const float* bias;                         // [N] or null (S == 1 only)
@@ -171,8 +172,9 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
         int lo;
         k_range(t.s, lo, i_hi);
         i_k = lo;
-        const float* Ab = p.A + (int64_t)t.g * p.sAg;
-        [[maybe_unused]] const float* Bb = p.B + (int64_t)t.g * p.sBg;
+        const int go = __builtin_amdgcn_readfirstlane((unsigned)t.g / (unsigned)p.Gi), gi = t.g - go * p.Gi;
+        const float* Ab = p.A + (int64_t)gi * p.sAg + (int64_t)go * p.sAo;
+        [[maybe_unused]] const float* Bb = p.B + (int64_t)gi * p.sBg + (int64_t)go * p.sBo;
         if constexpr (TA) {
             // rows k >= K are out of range of the resource: they read as zero
             const int64_t bytes = ((int64_t)(p.K - 1) * p.lda + p.M - m0) * 4;     // ends with the last valid element
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
             sa_step = BQ_KS * 4;
         }
         if constexpr (BP) {
-            const uint16_t* Bp = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)t.g * p.sBg;
+            const uint16_t* Bp = reinterpret_cast<const uint16_t*>(p.B) + (int64_t)gi * p.sBg + (int64_t)go * p.sBo;
             rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Bp + (int64_t)n0 * p.ldb), 0, 0x7ffffffe, 0x00020000);
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
@@ -453,10 +455,11 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
 
         // ---- epilogue: a lane owns, per accumulator quad, 4 consecutive n of one m.  The bias values of the wave's columns are
         // fetched first, then the stores issue back to back.
-        float* Cb = p.C + (p.S > 1 ? ((int64_t)tl.s * p.G + tl.g) * (int64_t)p.M * p.N : (int64_t)tl.g * p.sCg);
+        const int cgo = __builtin_amdgcn_readfirstlane((unsigned)tl.g / (unsigned)p.Gi), cgi = tl.g - cgo * p.Gi;
+        float* Cb = p.C + (p.S > 1 ? ((int64_t)tl.s * p.G + tl.g) * (int64_t)p.M * p.N : (int64_t)cgi * p.sCg + (int64_t)cgo * p.sCo);
         const int64_t ldc = p.S > 1 ? p.N : p.ldc;
         const float al = p.S > 1 ? 1.0f : alpha;
-        const bool vec_store = ((p.N | (int)ldc | (int)(p.S > 1 ? 0 : p.sCg)) & 3) == 0;
+        const bool vec_store = ((p.N | (int)ldc | (int)(p.S > 1 ? 0 : (p.sCg | p.sCo))) & 3) == 0;
         // The bias of the wave's columns depends on the lane only through fkg: it comes through the SCALAR cache (two 16-float
         // loads per 32 columns, then a select).  A vector load here would do: but any VGPR-destination VMEM load inside the
         // persistent loop makes hipcc's waitcnt pass put a vmcnt(0) at the head of the K loop, which drains the DMA ring.
@@ -518,16 +521,16 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
 
 // C[g][m][n] = alpha * sum_s part[s][g][m][n] + bias[n]   (fixed order: bit-reproducible)
 __global__ __launch_bounds__(256) void k_bq_reduce(const float* __restrict__ part, int S, int64_t gmn, int M, int N,
-                                                   float* __restrict__ C, int64_t ldc, int64_t sCg, const float* __restrict__ bias,
-                                                   float alpha, const float* __restrict__ alpha_dev) {
+                                                   float* __restrict__ C, int64_t ldc, int64_t sCg, int Gi, int64_t sCo,
+                                                   const float* __restrict__ bias, float alpha, const float* __restrict__ alpha_dev) {
     const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.0f);
-    if (((N | (int)ldc | (int)sCg) & 3) != 0) {          // element form (N, ldc or the group stride not a multiple of 4)
+    if (((N | (int)ldc | (int)(sCg | sCo)) & 3) != 0) {          // element form (N, ldc or the group stride not a multiple of 4)
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < gmn; e += (int64_t)gridDim.x * 256) {
             float acc = part[e];
             for (int s = 1; s < S; ++s) acc += part[(int64_t)s * gmn + e];
             const int64_t g = e / ((int64_t)M * N), r = e - g * (int64_t)M * N;
             const int m = (int)(r / N), n = (int)(r - (int64_t)m * N);
-            C[g * sCg + (int64_t)m * ldc + n] = acc * a + (bias ? bias[n] : 0.0f);
+            C[(g % Gi) * sCg + (g / Gi) * sCo + (int64_t)m * ldc + n] = acc * a + (bias ? bias[n] : 0.0f);
         }
         return;
     }
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(256) void k_bq_reduce(const float* __restrict__ par
             const float4 b = *reinterpret_cast<const float4*>(bias + n);
             acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
         }
-        *reinterpret_cast<float4*>(C + g * sCg + (int64_t)m * ldc + n) = acc;
+        *reinterpret_cast<float4*>(C + (g % Gi) * sCg + (g / Gi) * sCo + (int64_t)m * ldc + n) = acc;
     }
 }
 
@@ -634,6 +637,7 @@ int bq_launch(const BqArgs& a, int transA, int transB, int pa, int pb, bool kt, 
         return kt ? bq_go<RI, CJ, WN, false, false, 3, 0, true>(a, wgs, st) : bq_go<RI, CJ, WN, false, false, 3, 0, false>(a, wgs, st);
     }
     if (pa == 1 && pb == 3 && !transA && !transB && !kt) return bq_go<RI, CJ, WN, false, false, 1, 3, false>(a, wgs, st);
+    if (pa == 1 && pb == 3 && !transA && transB && !kt) return bq_go<RI, CJ, WN, false, true, 1, 3, false>(a, wgs, st);
     if (pa == 3 && pb == 1 && transA && transB) return bq_go<RI, CJ, WN, true, true, 3, 1, false>(a, wgs, st);
     if (pa != 3 || pb != 3) return -3;
     if (transA && transB) return bq_go<RI, CJ, WN, true, true, 3, 3, false>(a, wgs, st);
@@ -650,7 +654,7 @@ int bq_launch(const BqArgs& a, int transA, int transB, int pa, int pb, bool kt, 
 }  // namespace
 
 static int bq_products(int exactA, int exactB, int transA, int transB) {
-    if (exactA && !exactB && !transA && !transB) return 3;
+    if (exactA && !exactB && !transA) return 3;              // forward: A = x_int K-contiguous, B either orientation
     if (exactB && !exactA && transA && transB) return 3;
     return 6;
 }
@@ -665,7 +669,8 @@ extern "C" int64_t adalog_gemm_f32x3_workspace_bytes(int M, int N, int K, int G,
 
 static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_t ldb, int transB, int64_t bplane, float* C,
                   int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, const float* bias, float alpha,
-                  const float* alpha_dev, int allow_split, int pa, int pb, float* workspace, void* stream) {
+                  const float* alpha_dev, int allow_split, int pa, int pb, float* workspace, void* stream, int Gi = 0,
+                  int64_t sAo = 0, int64_t sBo = 0, int64_t sCo = 0) {
     // the integer forward form is built without the K-tail masking: with K % 16 != 0 it runs as a general product (same result)
     if (pa == 1 && pb == 3 && (K & (BQ_KS - 1)) != 0) pa = 3;
     const int products = (pa == 3 && pb != 1) ? 6 : (pa == 1 && pb == 1) ? 1 : 3;
@@ -675,6 +680,7 @@ static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_
     BqArgs a;
     a.A = A; a.B = (const float*)B; a.C = pl.S > 1 ? workspace : C;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.sAg = sAg; a.sBg = sBg; a.sCg = sCg; a.bplane = bplane;
+    a.Gi = (Gi > 0 && Gi < G) ? Gi : G; a.sAo = sAo; a.sBo = sBo; a.sCo = sCo;
     a.M = M; a.N = N; a.K = K; a.G = G; a.S = pl.S; a.MT = pl.MT; a.NT = pl.NT; a.nk = pl.nk;
     a.bias = pl.S > 1 ? nullptr : bias; a.alpha = alpha; a.alpha_dev = alpha_dev;
     for (int s = 0; s <= pl.S; ++s) a.kb[s] = (int)(((int64_t)pl.nk * s) / pl.S);
@@ -694,7 +700,7 @@ static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_
         const int64_t gmn = (int64_t)G * M * N;
         int blocks = (int)((gmn / 4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_bq_reduce, dim3(blocks), dim3(256), 0, st, workspace, pl.S, gmn, M, N, C, ldc, sCg, bias, alpha, alpha_dev);
+        hipLaunchKernelGGL(k_bq_reduce, dim3(blocks), dim3(256), 0, st, workspace, pl.S, gmn, M, N, C, ldc, sCg, a.Gi, sCo, bias, alpha, alpha_dev);
         ADALOG_LAUNCH_CHECK("adalog_gemm_f32x3/reduce");
     }
     return 0;
@@ -703,16 +709,31 @@ static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_
 // C[g] = alpha * alpha_dev[0] * opA(A[g]) . opB(B[g])^T + bias        (fp32 in, fp32 out, fp32-class accuracy: see the header)
 //   opA(A)[m][k] = transA ? A[k * lda + m] : A[m * lda + k]         opB(B)[n][k] = transB ? B[k * ldb + n] : B[n * ldb + k]
 // exactA / exactB: the caller guarantees that operand's values are exactly representable in bf16 (integers of magnitude
-//   <= 256: the integer part of a uniformly fake-quantised activation); honoured for the forward (exactA, both K-contiguous)
+//   <= 256: the integer part of a uniformly fake-quantised activation); honoured for the forward (exactA, A K-contiguous)
 //   and the dL/dw (exactB, both K-major) forms -- 3 products instead of 6 -- and ignored otherwise (the split of such a value is
 //   (x, 0, 0), so the result is the same).
 // Requirements: A, B, C, bias 16-byte aligned; lda, ldb, ldc, sAg, sBg, sCg multiples of 4 elements; N a multiple of 4.
 // workspace: adalog_gemm_f32x3_workspace_bytes(...) bytes (may be null when that is 0).
+// Two-level groups (adalog_gemm_f32x3_g2): group g = go * Gi + gi sits at gi * s?g + go * s?o in each operand -- a [B][H] batch whose
+//   two strides do not collapse, e.g. the softmax.v product writing its [B][N][H][D] result in place (no transposed copy before
+//   the projection layer).  Gi <= 0 or Gi >= G: one level (the outer strides are ignored).
+extern "C" int adalog_gemm_f32x3_g2(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                                    int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, int Gi,
+                                    int64_t sAo, int64_t sBo, int64_t sCo, const float* bias, float alpha, const float* alpha_dev,
+                                    int allow_split, int exactA, int exactB, float* workspace, void* stream);
 extern "C" int adalog_gemm_f32x3(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                                  int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg,
                                  const float* bias, float alpha, const float* alpha_dev, int allow_split, int exactA, int exactB,
                                  float* workspace, void* stream) {
+    return adalog_gemm_f32x3_g2(A, lda, transA, B, ldb, transB, C, ldc, M, N, K, G, sAg, sBg, sCg, 0, 0, 0, 0, bias, alpha, alpha_dev,
+                                allow_split, exactA, exactB, workspace, stream);
+}
+extern "C" int adalog_gemm_f32x3_g2(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                                    int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, int Gi,
+                                    int64_t sAo, int64_t sBo, int64_t sCo, const float* bias, float alpha, const float* alpha_dev,
+                                    int allow_split, int exactA, int exactB, float* workspace, void* stream) {
     if (M == 0 || N == 0 || G == 0) return 0;
+    ADALOG_ARG_CHECK(Gi <= 0 || Gi >= G || G % Gi == 0, "gemm_f32x3: the inner group count must divide G");
     ADALOG_ARG_CHECK(A && B && C && M > 0 && N > 0 && K > 0 && G > 0, "gemm_f32x3: bad arguments");
     // (rows need not be 16-byte aligned: the LDS-DMA requests are dword-aligned 16-byte loads; N, ldc or sCg off a multiple
     // of 4 -- attention products with 197 tokens -- take the element-store epilogue)
@@ -724,7 +745,7 @@ extern "C" int adalog_gemm_f32x3(const float* A, int64_t lda, int transA, const 
     const int products = bq_products(exactA, exactB, transA, transB);
     const int pa = (products == 3 && exactA) ? 1 : 3, pb = (products == 3 && exactB) ? 1 : 3;
     return bq_run(A, lda, transA, B, ldb, transB, 0, C, ldc, M, N, K, G, sAg, sBg, sCg, bias, alpha, alpha_dev, allow_split, pa, pb,
-                  workspace, stream);
+                  workspace, stream, Gi, sAo, sBo, sCo);
 }
 
 // The same product with B handed over ALREADY SPLIT into three bf16 planes (adalog_pack_split3_bf16's layout: row n of group g

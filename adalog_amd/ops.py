@@ -903,9 +903,9 @@ def round_loss_multi(alphas, b, weight: float):
 
 # ---------------------------------------------------------------------------------------------- BRECQ training-mode GEMMs
 def _mat_layout(t: torch.Tensor):
-    """How the kernel reads a logical [..., R, K] operand: (trans, ld, groups, group_stride) or None.
-    trans = 0: K contiguous (rows of ld elements); trans = 1: R contiguous (K-major).  Leading dims must collapse to one
-    group index with a uniform stride."""
+    """How the kernel reads a logical [..., R, K] operand: (trans, ld, groups, group_stride, Gi, outer_stride) or None.
+    trans = 0: K contiguous (rows of ld elements); trans = 1: R contiguous (K-major).  The leading dims form the group index
+    g = go * Gi + gi at gi * group_stride + go * outer_stride: they must collapse into one level (Gi = groups) or two."""
     if t.dtype != torch.float32 or not t.is_cuda or t.dim() < 2:
         return None
     R, K = t.shape[-2:]
@@ -916,27 +916,52 @@ def _mat_layout(t: torch.Tensor):
         trans, ld = 1, (sk if K > 1 else max(R, 4))
     else:
         return None
-    G, gs = 1, 0
+    G, gs, Gi, go = 1, 0, 1, 0
     lead = [(t.shape[i], t.stride(i)) for i in range(t.dim() - 2) if t.shape[i] != 1]
     if lead:
-        G = 1
-        for n_, _ in lead:
-            G *= n_
-        gs = lead[-1][1]
-        for (n0, s0), (n1, s1) in zip(lead[:-1], lead[1:]):
-            if s0 != s1 * n1:
-                return None
+        levels = []                                  # innermost first: [count, stride] of each run of collapsing dims
+        for n_, s_ in reversed(lead):
+            if levels and s_ == levels[-1][0] * levels[-1][1]:
+                levels[-1][0] *= n_
+            else:
+                levels.append([n_, s_])
+        if len(levels) > 2:
+            return None
+        Gi, gs = levels[0]
+        G = Gi
+        if len(levels) == 2:
+            G, go = Gi * levels[1][0], levels[1][1]
     if t.data_ptr() % 16:
         return None
-    return trans, ld, G, gs
+    return trans, ld, G, gs, Gi, go
 
 
-def gemm_f32x3_ok(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None) -> bool:
-    """Whether a @ b^T (a: [..., M, K], b: [..., N, K], same leading shape) runs on adalog_gemm_f32x3."""
+def _group_levels(layouts):
+    """A common two-level description (Gi, [(inner, outer) stride per operand]) of operands laid out by _mat_layout, or None."""
+    G = layouts[0][2]
+    if any(l[2] != G for l in layouts):
+        return None
+    two = {l[4] for l in layouts if l[4] != G}
+    if len(two) > 1:
+        return None
+    Gi = two.pop() if two else G
+    return Gi, [(l[3], l[5] if l[4] != G else Gi * l[3]) for l in layouts]
+
+
+def gemm_f32x3_ok(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> bool:
+    """Whether a @ b^T (a: [..., M, K], b: [..., N, K], same leading shape) runs on adalog_gemm_f32x3[_g2]."""
     la, lb = _mat_layout(a), _mat_layout(b)
-    if la is None or lb is None or a.shape[-1] != b.shape[-1] or la[2] != lb[2]:
+    if la is None or lb is None or a.shape[-1] != b.shape[-1]:
         return False
+    lays = [la, lb]
     M, N = a.shape[-2], b.shape[-2]
+    if out is not None:
+        lo = _mat_layout(out)
+        if lo is None or lo[0] != 0 or tuple(out.shape[-2:]) != (M, N):
+            return False
+        lays.append(lo)
+    if _group_levels(lays) is None:
+        return False
     if a.numel() == 0 or b.numel() == 0:
         return False
     if bias is not None and (N % 16 or bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16
@@ -948,22 +973,27 @@ def gemm_f32x3_ok(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor]
 
 def gemm_f32x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
                allow_split: bool = True, alpha_dev: Optional[torch.Tensor] = None, exact_a: bool = False,
-               exact_b: bool = False) -> torch.Tensor:
+               exact_b: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """alpha * alpha_dev[0] * a @ b^T (+ bias) for fp32 operands of either memory orientation, at fp32 accuracy on the bf16
-    matrix cores (csrc/brecq_gemm.hip).  a: [..., M, K], b: [..., N, K] -> [..., M, N] (contiguous).
+    matrix cores (csrc/brecq_gemm.hip).  a: [..., M, K], b: [..., N, K] -> [..., M, N] (contiguous, or written into ``out``: any
+    view whose last dim is contiguous and whose leading dims form at most two stride levels).
     exact_a / exact_b: that operand holds integers exactly representable in bf16 (3 products instead of 6 where supported)."""
-    la, lb = _mat_layout(a), _mat_layout(b)
-    if not gemm_f32x3_ok(a, b, bias):
+    if not gemm_f32x3_ok(a, b, bias, out):
         raise _lib.AdalogHipError(f"gemm_f32x3: unsupported operand layout {tuple(a.shape)}/{a.stride()} x {tuple(b.shape)}/{b.stride()}")
+    la, lb = _mat_layout(a), _mat_layout(b)
     M, K, N, G = a.shape[-2], a.shape[-1], b.shape[-2], la[2]
-    out = torch.empty(a.shape[:-2] + (M, N), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty(a.shape[:-2] + (M, N), dtype=torch.float32, device=a.device)
+    lo = _mat_layout(out)
+    Gi, ((sa, sao), (sb, sbo), (sc, sco)) = _group_levels([la, lb, lo])
     lib = _lib.load()
     sp, ea, eb = (1 if allow_split else 0), (1 if exact_a else 0), (1 if exact_b else 0)
     wsb = int(lib.adalog_gemm_f32x3_workspace_bytes(M, N, K, G, sp, ea, eb, la[0], lb[0]))
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device) if wsb else None
-    rc = lib.adalog_gemm_f32x3(a.data_ptr(), la[1], la[0], b.data_ptr(), lb[1], lb[0], out.data_ptr(), N, M, N, K, G,
-                               la[3], lb[3], M * N, _ptr(bias), float(alpha), _ptr(alpha_dev), sp, ea, eb, _ptr(ws), _stream())
-    _lib.check(rc, "adalog_gemm_f32x3")
+    rc = lib.adalog_gemm_f32x3_g2(a.data_ptr(), la[1], la[0], b.data_ptr(), lb[1], lb[0], out.data_ptr(), lo[1], M, N, K, G,
+                                  sa, sb, sc, Gi, sao, sbo, sco, _ptr(bias), float(alpha), _ptr(alpha_dev), sp, ea, eb, _ptr(ws),
+                                  _stream())
+    _lib.check(rc, "adalog_gemm_f32x3_g2")
     return out
 
 
@@ -972,7 +1002,7 @@ def gemm_f32x3_planes(a: torch.Tensor, bp: torch.Tensor, K: int, bias: Optional[
     """a @ B^T (+ bias) with B handed over pre-split by pack_split3(): bp is its [1, G, N, 3*Kt] bf16 image (hi | mid | lo per
     row).  a: [..., M, K] fp32, K-contiguous -> [..., M, N]."""
     la = _mat_layout(a)
-    if la is None or la[0] != 0 or a.shape[-1] != K or bp.dtype != torch.bfloat16 or not bp.is_contiguous():
+    if la is None or la[0] != 0 or la[4] != la[2] or a.shape[-1] != K or bp.dtype != torch.bfloat16 or not bp.is_contiguous():
         raise _lib.AdalogHipError(f"gemm_f32x3_planes: unsupported operand layout {tuple(a.shape)}/{a.stride()}")
     G, N, Kt = bp.shape[-3], bp.shape[-2], bp.shape[-1] // 3
     M = a.shape[-2]
@@ -997,6 +1027,38 @@ def uniform_int(x: torch.Tensor, scale: torch.Tensor, zero_point: torch.Tensor, 
                                             _f32c(zero_point, "zero_point").data_ptr(), int(n_bits), _stream())
     _lib.check(rc, "adalog_uniform_int_f32")
     return y
+
+
+def permute_heads(x: torch.Tensor, P: int, H: int, inverse: bool = False) -> torch.Tensor:
+    """x [B, N, P*H*D] -> [P, B, H, N, D] in one pass (q, k, v of an attention block: the reshape / permute / unbind of
+    reference utils/wrap_net.py:19-33 as contiguous tensors); ``inverse``: [P, B, H, N, D] -> [B, N, P*H*D]."""
+    x = _f32c(x, "x")
+    if inverse:
+        P_, B, H_, N, D = x.shape
+        if (P_, H_) != (P, H):
+            raise _lib.AdalogHipError("permute_heads: shape does not match P, H")
+        out = torch.empty((B, N, P * H * D), dtype=torch.float32, device=x.device)
+    else:
+        B, N, C = x.shape
+        if C % (P * H) or (C // (P * H)) % 4:
+            raise _lib.AdalogHipError("permute_heads: the head dimension must be a multiple of 4")
+        D = C // (P * H)
+        out = torch.empty((P, B, H, N, D), dtype=torch.float32, device=x.device)
+    rc = _lib.load().adalog_permute_heads(x.data_ptr(), out.data_ptr(), B, N, int(P), int(H), int(D), int(bool(inverse)), _stream())
+    _lib.check(rc, "adalog_permute_heads")
+    return out
+
+
+def merge_heads(parts, B: int, N: int, H: int, D: int) -> torch.Tensor:
+    """The P <= 4 tensors [B, H, N, D] (None = zeros) -> [B, N, P*H*D]: the gradient of permute_heads from its parts' gradients."""
+    P = len(parts)
+    ps = [None if t is None else _f32c(t, "part") for t in parts]
+    dev = next(t for t in ps if t is not None).device
+    out = torch.empty((B, N, P * H * D), dtype=torch.float32, device=dev)
+    ptr = [_ptr(t) for t in ps] + [None] * (4 - P)
+    rc = _lib.load().adalog_merge_heads(ptr[0], ptr[1], ptr[2], ptr[3], out.data_ptr(), B, N, P, int(H), int(D), _stream())
+    _lib.check(rc, "adalog_merge_heads")
+    return out
 
 
 def adam_multi(params, grads, exp_avg, exp_avg_sq, step_dev, lr, beta1: float, beta2: float, eps: float):

@@ -50,7 +50,7 @@ class MinMaxQuantMatMul(nn.Module):
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
         a_sim, b_sim = self.quant_input_A(A), self.quant_input_B(B)
         if a_sim.requires_grad or b_sim.requires_grad:       # a BRECQ iteration: the contractions run on csrc/brecq_gemm.hip
-            return train_mm.matmul(a_sim, b_sim)
+            return train_mm.matmul(a_sim, b_sim, heads_last=getattr(self, 'out_heads_last', False))
         return a_sim @ b_sim
 
 

@@ -21,6 +21,13 @@ class _UniformSTE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, zero_point, n_bits, sym):
         be = backend.get()
+        # A transposed view of a contiguous tensor (k^T of an attention block) is quantised in its storage order and handed back
+        # as the same view: the quantiser is elementwise and its parameters do not vary along the last two dims.
+        ctx.swap = (x.dim() >= 2 and not x.is_contiguous() and x.transpose(-1, -2).is_contiguous()
+                    and all(t is None or t.numel() == 1 or (t.dim() == x.dim() and t.shape[-1] == 1 and t.shape[-2] == 1)
+                            for t in (scale, None if sym else zero_point)))
+        if ctx.swap:
+            x = x.transpose(-1, -2)
         x = x.contiguous()                               # saved in the layout the backward kernel reads (one copy, not two)
         if sym:
             y = be.uniform_fake_quant(x, scale, None, n_bits, sym=True)
@@ -29,15 +36,17 @@ class _UniformSTE(torch.autograd.Function):
             y = be.uniform_fake_quant(x, scale, zero_point, n_bits, sym=False)
             ctx.save_for_backward(x, scale, zero_point)
         ctx.n_bits, ctx.sym = n_bits, sym
-        return y
+        return y.transpose(-1, -2) if ctx.swap else y
 
     @staticmethod
     def backward(ctx, gy):
         x, scale, zp = ctx.saved_tensors
         be = backend.get()
+        if ctx.swap:
+            gy = gy.transpose(-1, -2)
         gx, gs, gz = be.uniform_fake_quant_backward(gy, x, scale, zp, ctx.n_bits, ctx.sym,
                                                     ctx.needs_input_grad[1], ctx.needs_input_grad[2] and zp is not None)
-        return gx, gs, gz, None, None
+        return (gx.transpose(-1, -2) if ctx.swap else gx), gs, gz, None, None
 
 
 class UniformQuantizer(nn.Module):

@@ -25,6 +25,11 @@ ENABLED = os.environ.get("ADALOG_BRECQ_MM", "1") != "0"
 # pre-split w_sim planes (1) or the split in the GEMM's registers (0, default: measured 571 against 546 it/s on a deit_small block --
 # the eight packer launches per iteration cost more than the per-tile splits they save)
 WEIGHT_PLANES = os.environ.get("ADALOG_BRECQ_WPLANES", "0") != "0"
+SPLIT_HEADS = os.environ.get("ADALOG_BRECQ_SPLIT_HEADS", "1") != "0"      # q, k, v by one permute launch each way
+HEADS_LAST = os.environ.get("ADALOG_BRECQ_HEADS_LAST", "1") != "0"        # softmax.v writes [B, N, H, D] in place
+# forward products read the weights K-major (from a transposed copy made once per iteration): with BOTH operands K-contiguous every
+# LDS-DMA request of a 16-element K-step fetches half cache lines -- measured 13-24 % slower than any form with one K-major operand
+W_KMAJOR = os.environ.get("ADALOG_BRECQ_WT", "1") != "0"
 INT_ACT = os.environ.get("ADALOG_BRECQ_INT_ACT", "1") != "0"            # integer activation operand (0: s_a * x_int as fp32)
 
 
@@ -46,6 +51,14 @@ def _planes(be, w2):
     return be.pack_split3(w2.unsqueeze(0), 64)
 
 
+def _kmajor(w2):
+    """w2 [N, K] as the same logical matrix over K-major storage (a [K, N] copy, viewed back)."""
+    if not W_KMAJOR or w2.shape[0] % 4:
+        return w2
+    wt = getattr(w2, "_adalog_kmajor", None)           # made by the producer of w_sim when it has one
+    return (wt if wt is not None else w2.t().contiguous()).t()
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x2 @ w2^T + bias with general fp32 operands (x2 [M, K], w2 [N, K])."""
 
@@ -55,7 +68,7 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w2)
         if WEIGHT_PLANES:
             return be.gemm_f32x3_planes(x2, _planes(be, w2), x2.shape[1], bias)
-        return be.gemm_f32x3(x2, w2, bias)
+        return be.gemm_f32x3(x2, _kmajor(w2), bias)
 
     @staticmethod
     def backward(ctx, gy):
@@ -83,7 +96,7 @@ class _QuantLinearFn(torch.autograd.Function):
         ctx.n_bits = n_bits
         if WEIGHT_PLANES:
             return be.gemm_f32x3_planes(xi, _planes(be, w2), x2.shape[1], bias, alpha_dev=a_scale, exact_a=True)
-        return be.gemm_f32x3(xi, w2, bias, alpha_dev=a_scale, exact_a=True)
+        return be.gemm_f32x3(xi, _kmajor(w2), bias, alpha_dev=a_scale, exact_a=True)
 
     @staticmethod
     def backward(ctx, gy):
@@ -125,33 +138,85 @@ def quant_linear(x, a_quantizer, w_sim, bias):
     return out.view(*lead, w_sim.shape[0])
 
 
-class _MatmulFn(torch.autograd.Function):
-    """A @ B batched over the leading dims (the attention products q.k^T and softmax.v, reference quant_layers/matmul.py:41-44):
-    forward and both backward products on adalog_gemm_f32x3, every operand read in place (K-contiguous or K-major)."""
+class _SplitHeadsFn(torch.autograd.Function):
+    """x [B, N, P*H*D] -> the P tensors [B, H, N, D]: q, k, v of an attention block as contiguous tensors in one pass
+    (adalog_permute_heads); the gradient is assembled from the P parts' gradients by one pass (adalog_merge_heads).  Autograd's
+    own route through reshape / permute / unbind hands strided views to the quantisers (three copies) and stacks + copies the
+    three gradients."""
 
     @staticmethod
-    def forward(ctx, A, B):
+    def forward(ctx, x, P, H):
+        B, N, C = x.shape
+        ctx.dims = (B, N, H, C // (P * H))
+        out = backend.get().permute_heads(x, P, H)
+        return tuple(out[i] for i in range(P))
+
+    @staticmethod
+    def backward(ctx, *gys):
+        B, N, H, D = ctx.dims
+        return backend.get().merge_heads([None if g_ is None else g_.contiguous() for g_ in gys], B, N, H, D), None, None
+
+
+def split_heads(x, P, H):
+    """x [B, N, P*H*D] -> the P tensors [B, H, N, D]  (x.reshape(B, N, P, H, D).permute(2, 0, 3, 1, 4).unbind(0), reference
+    utils/wrap_net.py:21-22).  In a BRECQ iteration on the GPU: one launch each way instead of views + copies."""
+    B, N, C = x.shape
+    D = C // (P * H)
+    if (ENABLED and SPLIT_HEADS and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()
+            and D % 4 == 0 and P <= 4 and hasattr(backend.get(), "merge_heads")):
+        return _SplitHeadsFn.apply(x.contiguous(), P, H)
+    return x.reshape(B, N, P, H, D).permute(2, 0, 3, 1, 4).unbind(0)   # one backward node (a stack) instead of P zero-filled selects
+
+
+class _MatmulFn(torch.autograd.Function):
+    """A @ B batched over the leading dims (the attention products q.k^T and softmax.v, reference quant_layers/matmul.py:41-44):
+    forward and both backward products on adalog_gemm_f32x3, every operand read in place (K-contiguous or K-major).
+    heads_last (4-D operands [B, H, R, K] @ [B, H, K, D]): the result is written as [B, R, H, D] storage and returned as its
+    [B, H, R, D] view, so the transpose(1, 2).reshape(B, R, H * D) that follows softmax.v in an attention block (reference
+    utils/wrap_net.py:31) is a view, and so is the gradient that comes back through it (two-level group strides in the kernel)."""
+
+    @staticmethod
+    def forward(ctx, A, B, heads_last):
         ctx.save_for_backward(A, B)
-        return backend.get().gemm_f32x3(A, B.transpose(-1, -2))
+        be = backend.get()
+        Bt = B.transpose(-1, -2)
+        if heads_last:
+            b_, h_, r_, d_ = A.shape[0], A.shape[1], A.shape[2], B.shape[-1]
+            out = torch.empty((b_, r_, h_, d_), dtype=torch.float32, device=A.device).permute(0, 2, 1, 3)
+            if be.gemm_f32x3_ok(A, Bt, None, out):
+                return be.gemm_f32x3(A, Bt, out=out)
+        return be.gemm_f32x3(A, Bt)
 
     @staticmethod
     def backward(ctx, gy):
         A, B = ctx.saved_tensors
         be = backend.get()
-        gy = gy.contiguous()
+        At, gyt = A.transpose(-1, -2), gy.transpose(-1, -2)
+        if not (be.gemm_f32x3_ok(gy, B) and be.gemm_f32x3_ok(At, gyt)):
+            gy = gy.contiguous()
+            gyt = gy.transpose(-1, -2)
         gA = be.gemm_f32x3(gy, B) if ctx.needs_input_grad[0] else None                       # gy . B^T
-        gB = be.gemm_f32x3(A.transpose(-1, -2), gy.transpose(-1, -2)) if ctx.needs_input_grad[1] else None   # A^T . gy
-        return gA, gB
+        gB = None
+        if ctx.needs_input_grad[1]:
+            if not B.is_contiguous() and B.transpose(-1, -2).is_contiguous():
+                gB = be.gemm_f32x3(gyt, At).transpose(-1, -2)      # B is a transposed view (k^T): its gradient in the same storage order
+            else:
+                gB = be.gemm_f32x3(At, gyt)                                                  # A^T . gy
+        return gA, gB, None
 
 
-def matmul(A_sim, B_sim):
+def matmul(A_sim, B_sim, heads_last=False):
     """A_sim @ B_sim for a BRECQ iteration."""
     ok = (ENABLED and torch.is_grad_enabled() and A_sim.is_cuda and A_sim.dtype == torch.float32 and B_sim.dtype == torch.float32
           and A_sim.dim() >= 3 and A_sim.shape[:-2] == B_sim.shape[:-2] and hasattr(backend.get(), "gemm_f32x3"))
     if ok:
-        A_sim, B_sim = A_sim.contiguous(), B_sim.contiguous()
         be = backend.get()
-        ok = be.gemm_f32x3_ok(A_sim, B_sim.transpose(-1, -2)) and be.gemm_f32x3_ok(A_sim.transpose(-1, -2), A_sim.transpose(-1, -2))
+
+        def fits(a_, b_):
+            return be.gemm_f32x3_ok(a_, b_.transpose(-1, -2)) and be.gemm_f32x3_ok(a_.transpose(-1, -2), a_.transpose(-1, -2))
+        if not fits(A_sim, B_sim):                          # operands the kernel cannot read in place: contiguous copies
+            A_sim, B_sim = A_sim.contiguous(), B_sim.contiguous()
+        ok = fits(A_sim, B_sim)
     if not ok:
         return A_sim @ B_sim
-    return _MatmulFn.apply(A_sim, B_sim)
+    return _MatmulFn.apply(A_sim, B_sim, bool(heads_last and HEADS_LAST and A_sim.dim() == 4))

@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import train_mm
+
 
 class MatMul(nn.Module):
     """A @ B as a module, the hook point that quantised matmuls replace (wrap_net.py:14-16)."""
@@ -63,8 +65,7 @@ class Attention(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         x = self.qkv(x)
-        qkv = x.reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv.unbind(0)                    # one backward node (a stack) instead of three zero-filled selects
+        q, k, v = train_mm.split_heads(x, 3, self.num_heads)
         q, k = self.q_norm(q), self.k_norm(k)
         attn = self.matmul1(q, k.transpose(-2, -1)) * self.scale
         attn = attn.softmax(dim=-1)
@@ -217,8 +218,7 @@ class WindowAttention(nn.Module):
     def forward(self, x, mask=None):
         B_, N, C = x.shape
         x = self.qkv(x)
-        qkv = x.reshape(B_, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
-        q, k, v = qkv.unbind(0)                    # one backward node (a stack) instead of three zero-filled selects
+        q, k, v = train_mm.split_heads(x, 3, self.num_heads)
         q = q * self.scale
         attn = self.matmul1(q, k.transpose(-2, -1))
         attn = attn + self._get_rel_pos_bias()

@@ -48,6 +48,8 @@ def wrap_modules_in_net(model, cfg, reparam=False):
             if 'matmul2' in name:
                 new_module = PostSoftmaxAsymmetricallyBatchingQuantMatMul(A_bit=cfg.s_bit, **kw,
                                                                          quantizer=cfg.post_softmax_quantizer)
+                new_module.out_heads_last = True       # layout hint for BRECQ iterations (train_mm.matmul): the result is merged
+                                                       # over heads right after (models.py: transpose(1, 2).reshape)
             else:
                 new_module = AsymmetricallyBatchingQuantMatMul(A_bit=cfg.a_bit, **kw)
         elif isinstance(module, nn.Linear):

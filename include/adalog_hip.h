@@ -313,6 +313,14 @@ int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, 
  *   quantizers/uniform.py:29-35, i.e. the fake-quantised activation before its scale -- the integer operand of adalog_gemm_f32x3. */
 int adalog_uniform_int_f32(const float* x, float* y, int64_t n, const float* scale, const float* zero_point, int n_bits,
                            void* stream);
+/* Head split of an attention block in one pass: src [B][N][P][H][D] (the qkv Linear's output, P = 3) -> dst [P][B][H][N][D]
+ *   (contiguous q, k, v); inverse != 0: the other way (the gradient).  Replaces the reshape / permute / unbind copies of the
+ *   reference's attention forward (utils/wrap_net.py:19-33) and their autograd transposes in a BRECQ iteration.  D % 4 == 0. */
+int adalog_permute_heads(const float* src, float* dst, int64_t B, int64_t N, int P, int H, int D, int inverse, void* stream);
+/* The inverse with the P <= 4 parts as separate tensors [B][H][N][D] (the gradients of q, k, v as autograd delivers them);
+ *   a null part counts as zeros.  dst [B][N][P][H][D]. */
+int adalog_merge_heads(const float* p0, const float* p1, const float* p2, const float* p3, float* dst, int64_t B, int64_t N, int P,
+                       int H, int D, void* stream);
 int adalog_uniform_fq_backward_blocks(int64_t n, int64_t n_channels, int64_t inner);
 int adalog_uniform_fq_backward(const float* gy, const float* x, float* gx, int64_t n, const float* scale,
                                const float* zero_point, int64_t n_channels, int64_t inner, int n_bits, int symmetric,
@@ -369,6 +377,13 @@ int64_t adalog_gemm_f32x3_workspace_bytes(int M, int N, int K, int G, int allow_
 int adalog_gemm_f32x3(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C, int64_t ldc,
                       int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, const float* bias, float alpha,
                       const float* alpha_dev, int allow_split, int exactA, int exactB, float* workspace, void* stream);
+/* The same product over TWO-LEVEL groups: group g = go * Gi + gi sits at gi * s?g + go * s?o in each operand (a [B][H] batch whose
+ *   strides do not collapse into one: q / k / v read in place from the qkv output, or softmax.v writing [B][N][H][D] directly, so
+ *   that the transpose(1, 2).reshape of reference utils/wrap_net.py:31 is a view).  Gi <= 0 or >= G: one level. */
+int adalog_gemm_f32x3_g2(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                         int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, int Gi, int64_t sAo,
+                         int64_t sBo, int64_t sCo, const float* bias, float alpha, const float* alpha_dev, int allow_split,
+                         int exactA, int exactB, float* workspace, void* stream);
 /* The same product with B ALREADY SPLIT into three bf16 planes by adalog_pack_split3_bf16 (row n of group g at
  *   Bp + (g*N + n)*3*Kt: hi | mid | lo of Kt >= K elements each, zero beyond K, Kt % 32 == 0) -- for an operand that every row
  *   tile re-reads (the soft-rounded weights w_sim / w_sim^T of reference quant_layers/linear.py:46-50): the split then runs

@@ -495,18 +495,22 @@ def gemm_win_ok(dtype, M, N, G, gmod, ref_div, k_valid):
     return False                                       # the CPU stand-in has one GEMM path: 64-byte rows everywhere
 
 
-def gemm_f32x3_ok(a, b, bias=None):
+def gemm_f32x3_ok(a, b, bias=None, out=None):
     return a.shape[-1] == b.shape[-1]
 
 
-def gemm_f32x3(a, b, bias=None, alpha=1.0, allow_split=True, alpha_dev=None, exact_a=False, exact_b=False):
+def gemm_f32x3(a, b, bias=None, alpha=1.0, allow_split=True, alpha_dev=None, exact_a=False, exact_b=False, out=None):
     """Specification of adalog_gemm_f32x3: a @ b^T (+ bias) in fp64, rounded once (the kernel's result is within fp32
     accumulation noise of it)."""
+    out_ = out
     out = alpha * (a.double() @ b.double().transpose(-2, -1))
     if alpha_dev is not None:
         out = out * alpha_dev.double().reshape(())
     if bias is not None:
         out = out + bias.double()
+    if out_ is not None:
+        out_.copy_(out.float())
+        return out_
     return out.float()
 
 
@@ -522,6 +526,21 @@ def gemm_f32x3_planes(a, bp, K, bias=None, alpha=1.0, allow_split=True, alpha_de
 def uniform_int(x, scale, zero_point, n_bits):
     z = torch.round(zero_point.reshape(()))
     return (torch.round(x / scale.reshape(())) + z).clamp(0, 2 ** n_bits - 1) - z
+
+
+def permute_heads(x, P, H, inverse=False):
+    """Specification of adalog_permute_heads."""
+    if inverse:
+        P_, B, H_, N, D = x.shape
+        return x.permute(1, 3, 0, 2, 4).reshape(B, N, P * H * D).contiguous()
+    B, N, C = x.shape
+    return x.reshape(B, N, P, H, C // (P * H)).permute(2, 0, 3, 1, 4).contiguous()
+
+
+def merge_heads(parts, B, N, H, D):
+    """Specification of adalog_merge_heads."""
+    ps = [torch.zeros(B, H, N, D) if t is None else t for t in parts]
+    return torch.stack(ps, 0).permute(1, 3, 0, 2, 4).reshape(B, N, len(ps) * H * D).contiguous()
 
 
 def adam_multi(params, grads, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, eps):

@@ -1321,6 +1321,68 @@ def test_gemm_f32x3_attention_products(ops):
         assert rel_err(gv.cpu().double(), (pr.double().transpose(-1, -2) @ gy.double()).cpu()) <= 2e-6
 
 
+@pytest.mark.parametrize("B,H,N,D", [(32, 6, 197, 64), (3, 4, 49, 32), (2, 3, 70, 20)])
+def test_gemm_f32x3_two_level_groups(ops, B, H, N, D):
+    """adalog_gemm_f32x3_g2: operands whose [B][H] strides do not collapse -- q / k / v read in place from a [B, N, 3, H, D]
+    tensor, and a result written as [B, N, H, D] storage through its [B, H, N, D] view -- against fp64; then the two backward
+    products of softmax.v with the gradient arriving as such a view (what train_mm._MatmulFn does with heads_last)."""
+    gen = torch.Generator().manual_seed(B * H + N)
+    qkv = torch.randn(B, N, 3, H, D, generator=gen).to(DEV)
+    q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)                    # [B, H, N, D] views: strides (N*3HD, D, 3HD, 1)
+    assert not q.is_contiguous()
+    if ops.gemm_f32x3_ok(q, k):
+        s = ops.gemm_f32x3(q, k)                                        # q . k^T, both read in place
+        assert rel_err(s.cpu().double(), (q.double() @ k.double().transpose(-1, -2)).cpu()) <= 2e-6
+    else:
+        assert (3 * H * D) % 4 or qkv.data_ptr() % 16 or (D * 4) % 16
+    pr = torch.softmax(torch.randn(B, H, N, N, generator=gen), -1).to(DEV)
+    vc = v.contiguous()
+    out = torch.empty(B, N, H, D, device=DEV).permute(0, 2, 1, 3)
+    assert ops.gemm_f32x3_ok(pr, vc.transpose(-1, -2), None, out)
+    r = ops.gemm_f32x3(pr, vc.transpose(-1, -2), out=out)
+    assert r.data_ptr() == out.data_ptr()
+    want = (pr.double() @ vc.double()).cpu()
+    assert rel_err(out.cpu().double(), want) <= 2e-6
+    merged = out.transpose(1, 2).reshape(B, N, H * D)                   # the view the projection layer reads
+    assert merged.data_ptr() == out.data_ptr()
+    gy = torch.randn(B, N, H, D, generator=gen).to(DEV).permute(0, 2, 1, 3)     # gradient arriving as the [B, H, N, D] view
+    assert ops.gemm_f32x3_ok(gy, vc) and ops.gemm_f32x3_ok(pr.transpose(-1, -2), gy.transpose(-1, -2))
+    gp = ops.gemm_f32x3(gy, vc)
+    assert rel_err(gp.cpu().double(), (gy.double() @ vc.double().transpose(-1, -2)).cpu()) <= 2e-6
+    gv = ops.gemm_f32x3(pr.transpose(-1, -2), gy.transpose(-1, -2))
+    assert rel_err(gv.cpu().double(), (pr.double().transpose(-1, -2) @ gy.double()).cpu()) <= 2e-6
+
+
+@pytest.mark.parametrize("shape", [(32, 197, 3, 6, 64), (5, 49, 3, 4, 32), (2, 7, 1, 3, 4)])
+def test_permute_heads_matches_the_view_route(ops, shape):
+    """adalog_permute_heads ([B, N, P*H*D] -> [P, B, H, N, D] and back) moves exactly what reshape / permute / unbind move
+    (reference utils/wrap_net.py:21-22), and train_mm.split_heads' gradient is the view route's gradient bit for bit."""
+    from adalog_amd import train_mm
+    B, N, P, H, D = shape
+    gen = torch.Generator().manual_seed(B * N + D)
+    x = torch.randn(B, N, P * H * D, generator=gen).to(DEV)
+    y = ops.permute_heads(x, P, H)
+    assert torch.equal(y.cpu(), CB.permute_heads(x.cpu(), P, H))
+    assert torch.equal(ops.permute_heads(y, P, H, inverse=True), x)
+    assert torch.equal(ops.merge_heads([y[i] for i in range(P)], B, N, H, D), x)
+    if P > 1:                                                            # a missing part counts as zeros
+        got = ops.merge_heads([None] + [y[i] for i in range(1, P)], B, N, H, D).cpu()
+        assert torch.equal(got, CB.merge_heads([None] + [y[i].cpu() for i in range(1, P)], B, N, H, D))
+    ws = [torch.randn(B, H, N, D, generator=gen).to(DEV) for _ in range(P)]
+    grads = []
+    for on in (True, False):
+        old, train_mm.SPLIT_HEADS = train_mm.SPLIT_HEADS, on
+        try:
+            xr = x.clone().requires_grad_(True)
+            parts = train_mm.split_heads(xr, P, H)
+            assert all(pt.shape == (B, H, N, D) for pt in parts)
+            sum((pt * w).sum() for pt, w in zip(parts, ws)).backward()
+            grads.append(xr.grad.clone())
+        finally:
+            train_mm.SPLIT_HEADS = old
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_brecq_iteration_runs_no_library_gemm():
     """Every contraction of a BRECQ iteration of a transformer block runs on csrc/brecq_gemm.hip: the kernel trace of one
     forward/backward holds k_bq_gemm launches and no rocBLAS / hipBLASLt (`Cijk_*`) kernel."""

@@ -50,6 +50,14 @@ def main():
     name = args.block
     block, fblock = rec.blocks[name], rec.full_blocks[name]
     rec.init_block_raw_data(block, fblock, name, dev)
+    # steady state: the clock is read (after a device synchronisation) when iteration iters / 4 and the last one have finished
+    marks = {}
+
+    def hook(it, loss_func):
+        if it in (args.iters // 4, args.iters):
+            torch.cuda.synchronize()
+            marks[it] = time.perf_counter()
+    rec.iter_hook = hook
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=args.iters)
@@ -57,6 +65,10 @@ def main():
     dt = time.perf_counter() - t0
     print(f"{args.model} W{args.bits}A{args.bits} {name}: {args.iters} iterations in {dt:.2f} s = {args.iters / dt:.1f} it/s "
           f"({dt / args.iters * 1e3:.2f} ms per iteration)")
+    if len(marks) == 2:
+        n_ = args.iters - args.iters // 4
+        ds = marks[args.iters] - marks[args.iters // 4]
+        print(f"steady state (last {n_} iterations): {n_ / ds:.1f} it/s ({ds / n_ * 1e3:.3f} ms per iteration)")
 
 
 if __name__ == "__main__":

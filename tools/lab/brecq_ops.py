@@ -27,10 +27,16 @@ block, fblock = rec.blocks[name], rec.full_blocks[name]
 rec.init_block_raw_data(block, fblock, name, dev)
 from torch.profiler import profile, ProfilerActivity
 N = int(os.environ.get("ITERS", "40"))
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+SHAPES = os.environ.get("SHAPES", "0") != "0"
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=SHAPES) as prof:
     rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=N)
     torch.cuda.synchronize()
 rows = prof.key_averages()
+if SHAPES:          # the small ATen ops by input shape: which copies / adds / fills an iteration still holds
+    for r in sorted(prof.key_averages(group_by_input_shape=True), key=lambda r: -getattr(r, "device_time_total", 0)):
+        if r.key in ("aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::fill_", "aten::cat", "aten::clone", "aten::sum",
+                     "aten::contiguous", "aten::zero_", "aten::zeros", "aten::index_select", "aten::mul_", "aten::div", "aten::stack"):
+            print(f"{r.count / N:6.2f}/it dev {r.device_time_total / N:7.1f} us/it  {r.key:18s} {str(r.input_shapes)[:110]}")
 out = []
 for r in sorted(rows, key=lambda r: -getattr(r, "device_time_total", 0)):
     dt = getattr(r, "device_time_total", 0)
