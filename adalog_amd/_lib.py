@@ -70,6 +70,9 @@ SIGNATURES = {
     "adalog_round_loss_multi_workspace": (i64, [p, i32]),
     "adalog_round_loss_multi": (i32, [p, p, p, i32, f32, p, f32, p, p, p]),
     "adalog_gemm_win_ok": (i32, [i32, i32, i32, i32, i32, i32, i64]),
+    "adalog_gemm_score_gen": (i32, [i32, p, i64, i32, i32, i64, i64, i32, i32, p, i64, i64, p, i32, p, i64, i32, p, i64, i64, f32, p, i64,
+                              i64, p, i64, p]),
+    "adalog_gemm_score_gen_ok": (i32, [i32, i32, i32, i32, i32, i32, i64, i64]),
     "adalog_gemm_mixed_ok": (i32, [i32, i32, i32, i32, i32, i64]),
     "adalog_rec_loss": (i32, [p, p, i64, f32, p, p, p]),
     "adalog_rec_loss_backward": (i32, [p, p, i64, f32, p, p, p]),

@@ -40,7 +40,12 @@ struct BqArgs {
     int64_t bplane;                            // PB == 0 (B = three bf16 planes, ldb = row stride in bf16 elements): plane stride
 };
 
+#if defined(BQ_LAB_NS)                           // tools/lab only
+constexpr int BQ_NS = BQ_LAB_NS;
+#else
 constexpr int BQ_NS = 4;                        // ring stages: compute s | fragments of s + 1 | two steps of requests in flight
+#endif
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 constexpr int BQ_KS = 16;                       // fp32 elements per K-step (64 bytes of an N row)
 
 __device__ __forceinline__ int swz64(int row, int slot) { return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4); }
@@ -328,11 +333,7 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
 
     // ---- prologue: the carry of the first step, from stage 0 (exposed once per workgroup)
     {
-        if constexpr (MAXQ * (BQ_NS - 2) == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if constexpr (MAXQ * (BQ_NS - 2) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if constexpr (MAXQ * (BQ_NS - 2) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr (MAXQ * (BQ_NS - 2) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_vm<MAXQ * (BQ_NS - 2)>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const Tile t0 = decode(j0);
@@ -370,11 +371,7 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
 
         for (int kt = k_lo; kt < k_hi; ++kt) {
             // stage st + 1 has landed once only this wave's newest BQ_NS - 3 steps of requests are outstanding
-            if constexpr (MAXQ * (BQ_NS - 3) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if constexpr (MAXQ * (BQ_NS - 3) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if constexpr (MAXQ * (BQ_NS - 3) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else if constexpr (MAXQ * (BQ_NS - 3) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_vm<MAXQ * (BQ_NS - 3)>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const uint8_t* cur = ring + st * STAGE;
@@ -567,11 +564,12 @@ int bq_cus() {
 
 // Tile shapes: (RI, CJ, WN) -> rows x columns, workgroups that fit a CU, relative rate of a full tile
 struct BqShape { int ri, cj, wn, bm, bn, per_cu; double speed; const char* name; };
-static const BqShape BQ_SHAPES[4] = {
+static const BqShape BQ_SHAPES[5] = {
     {2, 2, 4, 128, 256, 1, 1.00, "bq_gemm<128x256,8w>"},    // 8 waves: two per SIMD in ONE workgroup
     {2, 4, 2, 128, 256, 1, 1.00, "bq_gemm<128x256,4w>"},    // one wave per SIMD, 128 accumulator registers (fewest splits per MFMA)
     {2, 2, 2, 128, 128, 2, 0.80, "bq_gemm<128x128,4w>"},
     {1, 2, 2, 64, 128, 3, 0.60, "bq_gemm<64x128,4w>"},
+    {3, 2, 2, 192, 128, 2, 0.90, "bq_gemm<192x128,4w>"},    // for tile counts that 128 x 128 leaves just over one round of the chip
 };
 
 // workgroups of a shape that fit the chip at once
@@ -591,10 +589,20 @@ BqPlan bq_plan(int M, int N, int K, int G, int allow_split, int products, int bp
     (void)products;
     const int nk = cdiv(K, BQ_KS);
     int shape = 2;
-    if (const char* e = getenv("ADALOG_BQ_SHAPE")) { const int v = atoi(e); if (v >= 0 && v < 4) shape = v; else shape = -1; }
+    if (const char* e = getenv("ADALOG_BQ_SHAPE")) { const int v = atoi(e); if (v >= 0 && v < 5) shape = v; else shape = -1; }
     else {
         const int64_t t2 = (int64_t)cdiv(M, 128) * cdiv(N, 128) * G;
         shape = t2 >= 64 ? 2 : 3;
+        // a tile count just over a whole number of rounds of the chip (600 tiles on 512 slots: the second round runs at 17 %):
+        // 192 x 128 tiles when they take fewer rounds (a 192-row tile costs ~1.6 of a 128-row one; measured fc1 forward
+        // 53 -> 44 us, tools/lab/bq_lab)
+        static const int use_s4 = getenv("ADALOG_BQ_S4") ? atoi(getenv("ADALOG_BQ_S4")) : 1;
+        if (t2 >= 400 && !bp && use_s4) {
+            const int64_t t4 = (int64_t)cdiv(M, 192) * cdiv(N, 128) * G;
+            const int s2 = bq_slots(2, false), s4 = bq_slots(4, false);
+            const double c2 = (double)cdiv(t2, s2), c4 = 1.6 * (double)cdiv(t4, s4);
+            if (c4 < 0.95 * c2) shape = 4;
+        }
     }
     if (shape < 0) shape = 2;
     const BqShape& sh = BQ_SHAPES[shape];
@@ -691,6 +699,7 @@ static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_
         case 0: rc = bq_launch<2, 2, 4>(a, transA, transB, pa, pb, kt, pl.wgs, st); break;
         case 1: rc = bq_launch<2, 4, 2>(a, transA, transB, pa, pb, kt, pl.wgs, st); break;
         case 2: rc = bq_launch<2, 2, 2>(a, transA, transB, pa, pb, kt, pl.wgs, st); break;
+        case 4: rc = bq_launch<3, 2, 2>(a, transA, transB, pa, pb, kt, pl.wgs, st); break;
         default: rc = bq_launch<1, 2, 2>(a, transA, transB, pa, pb, kt, pl.wgs, st); break;
     }
     ADALOG_ARG_CHECK(rc == 0, "gemm_f32x3: cannot launch (LDS size attribute / unsupported operand form)");

@@ -252,14 +252,21 @@ extern "C" int adalog_gemm_mixed_ok(int M, int N, int G, int gmod, int ref_div, 
     return grpk8_ok(M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M) ? 1 : 0;
 }
 
-extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
-                                 int64_t sBg, int M, int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref,
-                                 int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c,
-                                 int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
-                                 const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, const float* row_scale,
-                                 const float* row_bias, float* partial, int64_t partial_elems, float* out, int64_t ldo,
-                                 int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream) {
-    ADALOG_ARG_CHECK(A && B && sa && sb, "gemm_score: null operand/scale pointer");
+// GEN form of the attention searches (adalog_gemm_score_gen): the candidate operand B is not read but generated in the kernel
+// from the fp32 tensor x [G][N / ref_div][K] with the candidates' (sb, zp) pairs
+struct MmGen { const float* x; int64_t ldx, sg; const float* zp; int n_bits; };
+
+static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
+                           int64_t sBg, int M, int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref,
+                           int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c,
+                           int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
+                           const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, const float* row_scale,
+                           const float* row_bias, float* partial, int64_t partial_elems, float* out, int64_t ldo,
+                           int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream, const MmGen* gen) {
+    ADALOG_ARG_CHECK(A && (B || gen) && sa && sb, "gemm_score: null operand/scale pointer");
+    ADALOG_ARG_CHECK(!gen || ((dtype == 0 || dtype == 3) && gen->x && gen->zp && k_valid > 0 && k_valid % 16 == 0 && k_valid <= 64 &&
+                              gen->ldx % 4 == 0 && gen->sg % 4 == 0 && (((uintptr_t)gen->x) & 15) == 0),
+                     "gemm_score_gen: int8 / fp8 candidates of K = 16, 32, 48 or 64 from a 16-byte aligned fp32 tensor");
     ADALOG_ARG_CHECK(dtype >= 0 && dtype <= 4, "gemm_score: dtype must be 0 (i8), 1 (bf16), 2 (f32), 3 (fp8 e4m3) or 4 (bf16 rows x fp8 columns)");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && C >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && ref_div >= 1, "gemm_score: bad sizes");
     if (dtype == 4 && k_valid > 256) {
@@ -399,6 +406,16 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
     if (partial) ADALOG_ARG_CHECK(partial_elems >= L.elems, "gemm_score: partial buffer too small");
     if (L.acc) { ADALOG_ARG_CHECK(((uintptr_t)partial & 7) == 0, "gemm_score: accumulator buffer must be 8-byte aligned"); p.wg_acc = (double*)partial; }
+    if (gen) {
+        const bool win = L.stream && !out && L.acc && !L.slab && win_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs, L.wgs);
+        const bool grpw = L.stream && !out && L.acc && !L.slab && grp_ok(dtype, M, N, G, gmod, ref_div, p.Kvb, bias, row_scale, sb_n, ref_cs) &&
+                          grpw_on() && L.wgs * 4 >= gmod && ref_cs >= M;
+        ADALOG_ARG_CHECK(win || grpw, "gemm_score_gen: not a shape of the window / wave-private group kernels (adalog_gemm_score_gen_ok)");
+        p.gen_x = gen->x; p.gen_ldx = gen->ldx; p.gen_sg = gen->sg; p.gen_K = (int)k_valid; p.gen_zp = gen->zp;
+        p.gen_qmax = (float)((1 << gen->n_bits) - 1);
+        const float tie = 6e-7f * (float)(1 << gen->n_bits);
+        p.gen_tie = 0.5f - (tie > 1e-5f ? tie : 1e-5f);
+    }
     const int64_t nwg = (int64_t)L.MT * L.NT * G * C;
     ADALOG_ARG_CHECK(nwg < (int64_t)1 << 31, "gemm_score: grid too large");
     hipStream_t st = (hipStream_t)stream;
@@ -458,8 +475,19 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
                 attr_set = true;                                                                                  \
             }                                                                                                     \
-            adalog_note_kernel(DTV == 3 ? "k_gemm_win<fp8>" : "k_gemm_win<i8>");                                   \
-            hipLaunchKernelGGL((k_gemm_win<NJV, DTV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);             \
+            if (gen) {                                                                                            \
+                static bool attr_gen = false;                                                                     \
+                if (!attr_gen) {                                                                                  \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<NJV, DTV, true>),         \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);             \
+                    attr_gen = true;                                                                              \
+                }                                                                                                 \
+                adalog_note_kernel(DTV == 3 ? "k_gemm_win_gen<fp8>" : "k_gemm_win_gen<i8>");                       \
+                hipLaunchKernelGGL((k_gemm_win<NJV, DTV, true>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);   \
+            } else {                                                                                              \
+                adalog_note_kernel(DTV == 3 ? "k_gemm_win<fp8>" : "k_gemm_win<i8>");                               \
+                hipLaunchKernelGGL((k_gemm_win<NJV, DTV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);         \
+            }                                                                                                     \
         } while (0)
         if (dtype == 3) { if (ref_div == 64) LAUNCH_WIN(2, 3); else if (ref_div == 128) LAUNCH_WIN(4, 3); else LAUNCH_WIN(8, 3); }
         else { if (ref_div == 64) LAUNCH_WIN(2, 0); else if (ref_div == 128) LAUNCH_WIN(4, 0); else LAUNCH_WIN(8, 0); }
@@ -477,8 +505,13 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
         const size_t shm = ref_lds > acc_lds ? ref_lds : acc_lds;
 #define LAUNCH_GRPW(NJV, DTV)                                                                                     \
         do {                                                                                                      \
-            adalog_note_kernel(DTV == 3 ? "k_gemm_grpw<fp8>" : "k_gemm_grpw<i8>");                                 \
-            hipLaunchKernelGGL((k_gemm_grpw<NJV, DTV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);            \
+            if (gen) {                                                                                            \
+                adalog_note_kernel(DTV == 3 ? "k_gemm_grpw_gen<fp8>" : "k_gemm_grpw_gen<i8>");                     \
+                hipLaunchKernelGGL((k_gemm_grpw<NJV, DTV, true>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);  \
+            } else {                                                                                              \
+                adalog_note_kernel(DTV == 3 ? "k_gemm_grpw<fp8>" : "k_gemm_grpw<i8>");                             \
+                hipLaunchKernelGGL((k_gemm_grpw<NJV, DTV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);        \
+            }                                                                                                     \
         } while (0)
         if (dtype == 3) { if (ref_div == 64) LAUNCH_GRPW(2, 3); else if (ref_div == 128) LAUNCH_GRPW(4, 3); else LAUNCH_GRPW(8, 3); }
         else { if (ref_div == 64) LAUNCH_GRPW(2, 0); else if (ref_div == 128) LAUNCH_GRPW(4, 0); else LAUNCH_GRPW(8, 0); }
@@ -615,6 +648,45 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
     }
     ADALOG_LAUNCH_CHECK("adalog_gemm_score");
     return 0;
+}
+
+extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
+                                 int64_t sBg, int M, int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref,
+                                 int64_t ldr, int64_t sRg, int64_t ref_cs, int ref_div, const float* sa, int64_t sa_c,
+                                 int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
+                                 const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, const float* row_scale,
+                                 const float* row_bias, float* partial, int64_t partial_elems, float* out, int64_t ldo,
+                                 int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream) {
+    return gemm_score_impl(dtype, A, B, sAc, sAg, sBc, sBg, M, N, Kp, k_valid, C, G, gmod, ref, ldr, sRg, ref_cs, ref_div, sa, sa_c, sa_g,
+                           sa_mul, sb, sb_c, sb_g, sb_n, bias, bi_c, bi_g, bi_n, row_scale, row_bias, partial, partial_elems, out, ldo,
+                           sOc, sOg, order, reduce_cols, stream, nullptr);
+}
+
+// Attention searches with uniform candidates (reference quant_layers/matmul.py:135-163 / 173-201), GEN form: scores of the
+// ref_div candidates (sb, zp)[c * sb_c + head * sb_g] of the operand x [G][N / ref_div][K = k_valid] (fp32, rows ldx apart, groups
+// sg apart) against the packed fixed operand A [G][M][Kp] -- what adalog_gemm_score computes from the packed candidate operand
+// [G][N][Kp] (candidates innermost), without that operand: the kernels quantise x in registers (k_gemm_win / k_gemm_grpw, GEN).
+// Transposed reference (ref_cs = M), per-workgroup fp64 accumulators: the partial-buffer layout of adalog_gemm_score_layout.
+// Shapes: adalog_gemm_score_gen_ok.
+extern "C" int adalog_gemm_score_gen(int dtype, const void* A, int64_t sAg, int M, int N, int64_t Kp, int64_t k_valid, int G, int gmod,
+                                     const float* x, int64_t ldx, int64_t sg, const float* zp, int n_bits, const float* ref,
+                                     int64_t sRg, int ref_div, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul,
+                                     const float* sb, int64_t sb_c, int64_t sb_g, float* partial, int64_t partial_elems,
+                                     void* stream) {
+    ADALOG_ARG_CHECK(n_bits >= 1 && n_bits <= 8 && (dtype != 3 || n_bits <= 4), "gemm_score_gen: fp8 candidates hold <= 4-bit values");
+    const MmGen gen{x, ldx, sg, zp, n_bits};
+    return gemm_score_impl(dtype, A, nullptr, 0, sAg, 0, 0, M, N, Kp, k_valid, 1, G, gmod, ref, 1, sRg, M, ref_div, sa, sa_c, sa_g, sa_mul,
+                           sb, sb_c, sb_g, 0, nullptr, 0, 0, 0, nullptr, nullptr, partial, partial_elems, nullptr, 0, 0, 0, 2, 1, stream,
+                           &gen);
+}
+
+// 1 when adalog_gemm_score_gen takes this shape (M rows of the fixed operand, N = source rows x ref_div candidate columns).
+extern "C" int adalog_gemm_score_gen_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t k_valid, int64_t Kp) {
+    if (!(dtype == 0 || dtype == 3) || k_valid < 16 || k_valid > 64 || k_valid % 16 || ref_div < 1 || N % ref_div != 0 || G % gmod) return 0;
+    const Layout L = layout_of(M, N, 1, G, gmod, ref_div, 1, true, k_valid, Kp, true, dtype);
+    if (!(L.stream && L.acc) || L.slab) return 0;
+    if (win_ok(dtype, M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M, L.wgs)) return 1;
+    return (grp_ok(dtype, M, N, G, gmod, ref_div, k_valid, nullptr, nullptr, 0, M) && grpw_on() && L.wgs * 4 >= gmod) ? 1 : 0;
 }
 
 // ---- activation-candidate scoring call with the candidate operand GENERATED inside the slab kernel (k_gemm_slab<.., GEN>)

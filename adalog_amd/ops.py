@@ -363,6 +363,45 @@ def gemm_win_ok(dtype: int, M: int, N: int, G: int, gmod: int, ref_div: int, k_v
     return bool(_lib.load().adalog_gemm_win_ok(int(dtype), int(M), int(N) * int(ref_div), int(G), int(gmod), int(ref_div), int(k_valid)))
 
 
+def gemm_score_gen_ok(dtype: int, M: int, N: int, G: int, gmod: int, ref_div: int, k_valid: int, Kp: int) -> bool:
+    """True when gemm_score_gen takes this attention-search shape (N = source rows; ref_div candidates)."""
+    return bool(_lib.load().adalog_gemm_score_gen_ok(int(dtype), int(M), int(N) * int(ref_div), int(G), int(gmod), int(ref_div),
+                                                     int(k_valid), int(Kp)))
+
+
+def gemm_score_gen(dtype: int, A, src3, zp, n_bits: int, M: int, N: int, P: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
+                   keep_h: bool, norm: float, sa_mul: float = 1.0):
+    """gemm_score(dtype, A, pack_uniform(src3, sb.t, zp, ...), M, N, P, ..., ref_div=P, ref_transposed=True, defer=True) without
+    the packed candidate operand: src3 [G, N, K] fp32 is quantised inside the kernel (adalog_gemm_score_gen).  sb: the candidates'
+    scales as the epilogue's column factors (Strided(scale [P, H], c=H, g=0|1)); zp: their zero points, same layout.
+    -> PendingScores."""
+    lib = _lib.load()
+    sa, sb = sa.checked(), sb.checked()
+    src3 = _f32c(src3, "src")
+    zp = _f32c(zp, "zero_point")
+    Gs, Ns, K = src3.shape
+    Kp = A.shape[-1]
+    assert (Gs, Ns) == (G, N) and A.shape[-2] == M and A.is_contiguous() and A.dtype == _TORCH_DT[dtype] and zp.shape == sb.t.shape
+    ref = _f32c(ref, "ref")
+    assert ref.shape[-1] == M and ref.shape[-2] == N
+    sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
+    sRg = 0 if G == 1 else M * N
+    n_part, MT, Npad, mode = _layout(M, N * P, 1, G, gmod, P, 1, dtype, Kp, K, True)
+    n_last = Npad if mode != 1 else N
+    partial = torch.empty((n_part + 1) // 2, dtype=torch.float64, device=A.device).view(torch.float32)
+    if GEMM_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.adalog_gemm_score_gen(int(dtype), A.data_ptr(), sAg, M, N * P, Kp, K, G, gmod, src3.data_ptr(), K, N * K, zp.data_ptr(),
+                                   int(n_bits), ref.data_ptr(), sRg, P, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul), sb.t.data_ptr(),
+                                   sb.c, sb.g, partial.data_ptr(), n_part, _stream())
+    if GEMM_EVENTS is not None:
+        ev1.record()
+        GEMM_EVENTS.append((dtype, M, N, K, P, G, ev0, ev1, lib.adalog_last_kernel().decode()))
+    _lib.check(rc, "adalog_gemm_score_gen")
+    return PendingScores(partial, MT, n_last, Npad, P, G, gmod, keep_h, False, mode, norm, N)
+
+
 def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, sb: Strided, bias: Optional[Strided],
              sa_mul: float = 1.0):
     """Quantised forward: out[g] = (A[g] . B[g]^T) * sa * sb[n] + bias[n]   -> fp32 [G, M, N]."""

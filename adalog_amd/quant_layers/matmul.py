@@ -18,6 +18,10 @@ from ..quantizers.logarithm import AdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
 MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
+# uniform attention candidates generated inside the scoring kernel instead of packed (adalog_gemm_score_gen): 'win' = where the
+# window kernel serves the search (swin: it is bound by streaming the 0.4-1.1 GB candidate operand), 'all' = the wave-private
+# q.k^T kernel of 197-token ViTs too (measured neutral there: the generation VALU costs what the pack launch saved), '0' = never
+GEN_MM = os.environ.get('ADALOG_GEN_MM', 'win')
 MIXED_B_SEARCH = os.environ.get('ADALOG_MIXED_B', '1') != '0'     # softmax.v weight search: fp8 candidates against the bf16 probabilities
 
 
@@ -204,6 +208,21 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         if mixed and chunk < P:
             raise RuntimeError("the mixed softmax.v search scores all candidates in one launch")
         pg = 1 if H > 1 else 0
+        mrows, ncols = (Sp, S) if which == "A" else (S, Sp)
+        if (GEN_MM != '0' and dt in (I8, FP8) and chunk >= P and K % 16 == 0 and K <= 64 and hasattr(be, "gemm_score_gen")
+                and (dt != FP8 or bits <= 4) and src.dtype == torch.float32
+                and be.gemm_score_gen_ok(dt, mrows, ncols, G, H, P, K, fixed.shape[-1])
+                and (GEN_MM == 'all' or be.gemm_win_ok(dt, mrows, ncols, G, H, P, K))):
+            sc, zc = scale.contiguous(), zp.contiguous()
+            sb = Strided(sc, c=H, g=pg)
+            if which == "A":
+                sa, ref = Strided(self.B_quantizer.scale.data.view(-1), g=pg), self._ref3()
+            else:
+                sa = fixed_sa if fixed_sa is not None else Strided(self.A_quantizer.scale.data.view(-1), g=pg)
+                ref = self._ref3_t()
+            pend = be.gemm_score_gen(dt, fixed, src, zc, bits, mrows, ncols, P, G, H, ref, sa, sb, self.head_channel_wise,
+                                     self._norm(A, S, Sp), sa_mul=sa_mul)
+            return pend if defer else pend.finish()
         out = []
         for s0 in range(0, P, chunk):
             e = min(P, s0 + chunk)

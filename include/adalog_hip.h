@@ -140,6 +140,20 @@ int64_t adalog_gemm_score_layout(int M, int N, int C, int G, int gmod, int ref_d
  * small groups of <= 64 rows with one K-step, e.g. swin's 49 x 49 x 32 attention windows (reference matmul.py:135-209 on
  * window attention) -- in which case int8 / fp8 operands of K <= 32 may be packed with 32-byte rows (Kp = 32). */
 int adalog_gemm_win_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t k_valid);
+/* Attention searches with uniform candidates (reference quant_layers/matmul.py:135-163 for operand A, :173-201 for B), GEN form:
+ *   what adalog_gemm_score computes from the packed candidate operand [G][N][Kp] (N = source rows x ref_div candidates,
+ *   candidates innermost) without that operand -- the window / wave-private group kernels quantise the fp32 tensor
+ *   x [G][N / ref_div][K = k_valid] (rows ldx, groups sg apart; 16-byte aligned, multiples of 4) in registers with the candidates'
+ *   (sb, zp)[c * sb_c + head * sb_g] and n_bits, bit for bit what adalog_pack_uniform would have written (int8: dtype 0; fp8:
+ *   dtype 3, n_bits <= 4).  A: the packed fixed operand [G][M][Kp] (groups sAg elements apart); ref: [G][N / ref_div][M]
+ *   (transposed, groups sRg apart); partial: the per-workgroup fp64 accumulators of adalog_gemm_score_layout (reduce_cols = 1).
+ *   adalog_gemm_score_gen_ok: 1 for the shapes taken (K = 16, 32, 48 or 64; the shapes of adalog_gemm_win_ok and of the
+ *   wave-private q.k^T kernel). */
+int adalog_gemm_score_gen(int dtype, const void* A, int64_t sAg, int M, int N, int64_t Kp, int64_t k_valid, int G, int gmod,
+                          const float* x, int64_t ldx, int64_t sg, const float* zp, int n_bits, const float* ref, int64_t sRg,
+                          int ref_div, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
+                          int64_t sb_g, float* partial, int64_t partial_elems, void* stream);
+int adalog_gemm_score_gen_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t k_valid, int64_t Kp);
 int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
                          int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes, void* stream);
 /* Scratch for the two-stage form used when cand_inner = 1 and keep_n = 0 (sums of 10^4..10^5 terms per candidate): bytes

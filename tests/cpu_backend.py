@@ -179,6 +179,17 @@ def _gemm_score(dtype, A, B, M, N, C, G, gmod, ref, sa, sb, bias, keep_h, keep_n
     return s.reshape(C, -1).float()
 
 
+def gemm_score_gen_ok(dtype, M, N, G, gmod, ref_div, k_valid, Kp):
+    return dtype in (I8, FP8) and k_valid % 16 == 0 and k_valid <= 64 and M <= 224
+
+
+def gemm_score_gen(dtype, A, src3, zp, n_bits, M, N, P, G, gmod, ref, sa, sb, keep_h, norm, sa_mul=1.0):
+    """Specification of adalog_gemm_score_gen: the packed-candidate scoring call on the operand pack_uniform would have made."""
+    pg = sb.g
+    cand = pack_uniform(src3, sb.t, zp, P, gmod, gmod, pg, 0, n_bits, dtype, c_inner=True, k_align=A.shape[-1])
+    return PendingScores(_gemm_score(dtype, A, cand, M, N, P, G, gmod, ref, sa, sb, None, keep_h, False, norm, sa_mul, P, 2, True))
+
+
 def gemm_out(dtype, A, B, M, N, G, gmod, sa, sb, bias, sa_mul=1.0):
     D = _gemm(dtype, A, B, 1, G)
     alpha = (_epi(sa, 1, G, gmod, 1) * float(torch.tensor(sa_mul, dtype=torch.float32))) * _epi(sb, 1, G, gmod, N)

@@ -168,6 +168,45 @@ def case_matmul_search(golden, bits, device="cpu"):
         close(lay(A, Bv), out0, 0, 0)
 
 
+def case_matmul_gen_route(device="cpu", bits=4, dims=(8, 2, 12, 16), gen="all"):
+    """The attention searches with the candidate operand generated inside the scoring kernel (adalog_gemm_score_gen, layer switch
+    quant_layers.matmul.GEN_MM) commit exactly the parameters the packed-operand route commits (K = 16: a shape both take)."""
+    import adalog_amd.quant_layers.matmul as MM
+    from adalog_amd import backend
+    DEV[0] = torch.device(device)
+    N, H, S, K = dims
+    gen_ = torch.Generator().manual_seed(11)
+    A = (torch.randn(N, H, S, K, generator=gen_) * 1.7).to(DEV[0])
+    B = (torch.randn(N, H, K, S, generator=gen_) * 0.9 + 0.2).to(DEV[0])
+    res, calls = {}, {}
+    be = backend.get()
+    orig = be.gemm_score_gen
+    for mode in ("0", gen):
+        old, MM.GEN_MM = MM.GEN_MM, mode
+        n = [0]
+
+        def spy(*a, **k):
+            n[0] += 1
+            return orig(*a, **k)
+        be.gemm_score_gen = spy
+        try:
+            lay = Q.AsymmetricallyBatchingQuantMatMul(A_bit=bits, B_bit=bits, mode="raw", calib_batch_size=N, search_round=2,
+                                                      eq_n=128, head_channel_wise=True, num_heads=H, fpcs=True, steps=4)
+            lay.to(DEV[0])
+            with torch.no_grad():
+                lay.raw_input, lay.raw_out = [A, B], lay(A, B)
+                lay.hyperparameter_searching()
+            res[mode] = {k: v.detach().cpu().clone() for k, v in lay.state_dict().items()}
+            calls[mode] = n[0]
+        finally:
+            MM.GEN_MM = old
+            be.gemm_score_gen = orig
+    assert calls["0"] == 0
+    for k in res["0"]:
+        assert torch.equal(res["0"][k], res[gen][k]), k
+    return calls[gen]
+
+
 def case_postsoftmax_search(golden, bits, device="cpu"):
     DEV[0] = torch.device(device)
     g = golden(f"postsoftmax_a{bits}b{bits}")

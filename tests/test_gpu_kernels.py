@@ -1459,3 +1459,43 @@ def test_score_w_gen_matches_packed_path(ops, bits, dt_name, T, O, K):
                           Strided(b.to(DEV), n=1), False, True, 1.0 / 197, ref_div=P, order=2, ref_transposed=True)
     assert got.shape == want.shape == (P, O)
     assert rel_err(got.cpu(), want.cpu()) <= 2e-6
+
+
+@pytest.mark.parametrize("bits,dt_name", [(4, "fp8"), (3, "fp8"), (6, "i8")])
+@pytest.mark.parametrize("shape", [("win", 2048, 4, 49, 32, 32), ("win", 512, 8, 49, 32, 32), ("grpw", 192, 6, 197, 64, 64)])
+def test_gemm_score_gen_matches_packed_path(ops, bits, dt_name, shape):
+    """Attention-search scores with the candidate operand generated in the kernel (adalog_gemm_score_gen: window kernel for swin's
+    49 x 49 x 32 windows, wave-private group kernel for 197 x 197 x 64) against the packed route (pack_uniform + gemm_score) on the
+    same candidates, with source values planted on rounding ties.  Both searched operands: rows = queries and rows = keys."""
+    from adalog_amd.ops import FP8, I8, Strided
+    kind, G, H, S, K, al = shape
+    dt = FP8 if dt_name == "fp8" else I8
+    gen = g(9100 + bits + G + S)
+    P = 128
+    qmax = 2 ** bits - 1
+    src = torch.randn(G, S, K, generator=gen) * 1.3 + 0.4                 # the searched operand
+    fix = torch.randn(G, S, K, generator=gen)                            # the other operand
+    lo, hi = src.amin(), src.amax()
+    sc = ((hi - lo) / qmax) * torch.linspace(0.5, 1.1, P).view(P, 1) * torch.linspace(0.9, 1.1, H).view(1, H)
+    zp = torch.round(-lo / sc).clamp(0, qmax)
+    src[:, 3, 5] = (sc[17, 0] * 2.5).item()                              # exact ties of candidate 17 / head 0, near-ties of neighbours
+    src[:, 7, 20] = (sc[90, H - 1] * -1.5).item()
+    f_s = torch.full((H,), fix.abs().max().item() * 2 / qmax)
+    f_z = torch.full((H,), float(2 ** (bits - 1)))
+    pg = 1 if H > 1 else 0
+    ref = torch.einsum("gsk,gtk->gst", src, fix)                          # [G, S(src rows), S(fixed rows)] = the transposed reference
+    d = lambda t_: t_.to(DEV).contiguous()
+    fp = ops.pack_uniform(d(fix), d(f_s), d(f_z), 1, 0, H, pg, 0, bits, dt, k_align=al)
+    assert ops.gemm_score_gen_ok(dt, S, S, G, H, P, K, fp.shape[-1])
+    sb = Strided(d(sc), c=H, g=pg)
+    sa = Strided(d(f_s), g=pg)
+    got = ops.gemm_score_gen(dt, fp, d(src), d(zp), bits, S, S, P, G, H, d(ref), sa, sb, True, 1.0 / (S * S)).finish()
+    label = _last_kernel()
+    assert label.startswith("k_gemm_win_gen<" if kind == "win" else "k_gemm_grpw_gen<"), label
+    cand = ops.pack_uniform(d(src), d(sc), d(zp), P, H, H, pg, 0, bits, dt, c_inner=True, k_align=al)
+    want = ops.gemm_score(dt, fp, cand, S, S, P, G, H, d(ref), sa, sb, None, True, False, 1.0 / (S * S), ref_div=P, order=2,
+                          ref_transposed=True)
+    assert not _last_kernel().endswith("_gen<fp8>") and "_gen" not in _last_kernel()
+    assert got.shape == want.shape == (P, H)
+    assert rel_err(got.cpu(), want.cpu()) <= 2e-6
+

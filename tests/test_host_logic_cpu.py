@@ -40,6 +40,10 @@ def test_matmul_search(golden, bits):
     LC.case_matmul_search(golden, bits)
 
 
+def test_matmul_searches_with_generated_candidates_commit_the_same_parameters():
+    assert LC.case_matmul_gen_route() > 0
+
+
 @pytest.mark.parametrize("bits", [3, 4, 6])
 def test_postsoftmax_search(golden, bits):
     LC.case_postsoftmax_search(golden, bits)
