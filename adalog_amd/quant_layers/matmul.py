@@ -18,10 +18,11 @@ from ..quantizers.logarithm import AdaLogQuantizer
 from ..quantizers.uniform import UniformQuantizer
 
 MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
-# uniform attention candidates generated inside the scoring kernel instead of packed (adalog_gemm_score_gen): 'win' = where the
-# window kernel serves the search (swin: it is bound by streaming the 0.4-1.1 GB candidate operand), 'all' = the wave-private
-# q.k^T kernel of 197-token ViTs too (measured neutral there: the generation VALU costs what the pack launch saved), '0' = never
-GEN_MM = os.environ.get('ADALOG_GEN_MM', 'win')
+# uniform attention candidates generated inside the scoring kernel instead of packed (adalog_gemm_score_gen): 'all' = wherever the
+# window kernel (swin) or the wave-private q.k^T kernel (197-token ViTs) serves the search, 'win' = windows only, '0' = never.
+# Same-box A/Bs: the kernels get slower (VALU: swin_base 148 -> 176 ms, deit_small 51 -> 69 ms per calibration) but the 0.3-1.1 GB
+# operand is neither written nor read: swin_base 2 978 -> 2 863 ms, deit_small 1 052 -> 1 033 ms per calibration
+GEN_MM = os.environ.get('ADALOG_GEN_MM', 'all')
 MIXED_B_SEARCH = os.environ.get('ADALOG_MIXED_B', '1') != '0'     # softmax.v weight search: fp8 candidates against the bf16 probabilities
 
 
