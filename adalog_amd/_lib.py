@@ -73,6 +73,9 @@ SIGNATURES = {
     "adalog_gemm_score_gen": (i32, [i32, p, i64, i32, i32, i64, i64, i32, i32, p, i64, i64, p, i32, p, i64, i32, p, i64, i64, f32, p, i64,
                               i64, p, i64, p]),
     "adalog_gemm_score_gen_ok": (i32, [i32, i32, i32, i32, i32, i32, i64, i64]),
+    "adalog_gemm_score_avq": (i32, [p, i64, i32, i32, i64, i64, i32, i32, p, i64, i64, p, p, i32, p, i64, i32, p, i64, i64, f32, p, i64, i64,
+                              p, i64, p]),
+    "adalog_gemm_score_avq_ok": (i32, [i32, i32, i32, i32, i32, i64, i64, i32]),
     "adalog_gemm_mixed_ok": (i32, [i32, i32, i32, i32, i32, i64]),
     "adalog_rec_loss": (i32, [p, p, i64, f32, p, p, p]),
     "adalog_rec_loss_backward": (i32, [p, p, i64, f32, p, p, p]),

@@ -680,6 +680,72 @@ extern "C" int adalog_gemm_score_gen(int dtype, const void* A, int64_t sAg, int 
                            &gen);
 }
 
+// softmax.v, log-base search of the post-softmax AdaLog quantiser (reference quant_layers/matmul.py:321-351): scores of the P = 128
+// candidate bases q against the reference, with the candidate operand (P AdaLog quantisations of the probabilities x [G][N][K]:
+// scale 1, no clamp) generated inside the kernel (k_gemm_avq) instead of packed by adalog_pack_adalog_bf16 and streamed.
+//   A: the fixed operand v^T, bf16 [G][M <= 64][Kp] (K-contiguous, zero past K);  q: the bases [P];
+//   lut: dword table [2^n_bits + 1][P], entry [k][c] = bf16 bits of the value of bin k under base q[c] (numerator * 2^-t, what
+//        the packer writes), row 2^n_bits = 0 (the masked code);  ref [G][N][M];  sa / sb / sa_mul / partial as adalog_gemm_score
+//        (C = 1, ref_div = P, reduce_cols = 1: the per-workgroup fp64 accumulators of adalog_gemm_score_layout with dtype 1).
+static bool avq_ok(int M, int N, int G, int gmod, int P, int64_t k_valid, int64_t Kp, int n_bits) {
+    static const int use_avq = getenv("ADALOG_GEMM_AVQ") ? atoi(getenv("ADALOG_GEMM_AVQ")) : 1;
+    if (!use_avq || P != 128 || M < 1 || M > 64 || N < 1 || k_valid < 1 || k_valid > 208 || n_bits < 1 || n_bits > 6 || gmod < 1 || gmod > 16 ||
+        G % gmod || G < 8)
+        return false;
+    const int nks = k_valid <= 64 ? 4 : 13;
+    if (Kp < nks * 16 || (Kp * 2) % 16) return false;
+    const Layout L = layout_of(M, N * P, 1, G, gmod, P, 1, true, k_valid * 2, Kp * 2, true, 1);
+    return L.stream && L.acc && !L.slab && L.wgs * 4 >= gmod;
+}
+extern "C" int adalog_gemm_score_avq_ok(int M, int N, int G, int gmod, int P, int64_t k_valid, int64_t Kp, int n_bits) {
+    return avq_ok(M, N, G, gmod, P, k_valid, Kp, n_bits) ? 1 : 0;
+}
+extern "C" int adalog_gemm_score_avq(const void* A, int64_t sAg, int M, int N, int64_t Kp, int64_t k_valid, int G, int gmod,
+                                     const float* x, int64_t ldx, int64_t sg, const float* q, const uint32_t* lut, int n_bits,
+                                     const float* ref, int64_t sRg, int P, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul,
+                                     const float* sb, int64_t sb_c, int64_t sb_g, float* partial, int64_t partial_elems,
+                                     void* stream) {
+    ADALOG_ARG_CHECK(A && x && q && lut && ref && sa && sb && partial, "gemm_score_avq: null pointer");
+    ADALOG_ARG_CHECK(avq_ok(M, N, G, gmod, P, k_valid, Kp, n_bits), "gemm_score_avq: shape not taken (adalog_gemm_score_avq_ok)");
+    ADALOG_ARG_CHECK((((uintptr_t)A) & 15) == 0 && (((uintptr_t)partial) & 7) == 0, "gemm_score_avq: operand / accumulator alignment");
+    const Layout L = layout_of(M, N * P, 1, G, gmod, P, 1, true, k_valid * 2, Kp * 2, true, 1);
+    ADALOG_ARG_CHECK(partial_elems >= L.elems, "gemm_score_avq: partial buffer too small");
+    GemmArgs p{};
+    p.A = (const uint8_t*)A; p.sAg = sAg * 2; p.M = M; p.N = N * P; p.Kb = Kp * 2; p.Kvb = k_valid * 2; p.C = 1; p.G = G; p.gmod = gmod;
+    p.ref = ref; p.ldr = 1; p.sRg = sRg; p.ref_cs = M; p.ref_div = P;
+    p.sa = sa; p.sa_c = sa_c; p.sa_g = sa_g; p.sa_mul = sa_mul; p.sb = sb; p.sb_c = sb_c; p.sb_g = sb_g;
+    p.wg_acc = (double*)partial; p.partial = partial;
+    p.gen_x = x; p.gen_ldx = ldx; p.gen_sg = sg; p.gen_K = (int)k_valid; p.gen_q = q; p.gen_lut = lut; p.gen_nb = 1 << n_bits;
+    const int64_t waves = (int64_t)L.wgs * 4;
+    int nch = (int)cdiv(3 * waves, G);
+    if (nch < cdiv(N, AVQ_ROWS)) nch = cdiv(N, AVQ_ROWS);           // <= AVQ_ROWS attention rows per item (they are staged in LDS)
+    nch = nch < 1 ? 1 : nch > N ? N : nch;
+    const int cbc = cdiv(N, nch);
+    p.slab_R = cbc; p.slab_U = cdiv(N, cbc);
+    const int nks = k_valid <= 64 ? 4 : 13;
+    const size_t lut_b = (((size_t)(p.gen_nb + 1) * P + 3) & ~(size_t)3) * 4;
+    const size_t rows_b = (size_t)4 * ((size_t)AVQ_ROWS * (nks * 16 + 64) + 4 * 64 * 2) * 4;
+    const size_t acc_b = (size_t)gmod * 256 * 8;
+    const size_t shm = lut_b + rows_b > acc_b ? lut_b + rows_b : acc_b;
+    hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_AVQ(NKSV, RBV)                                                                                     \
+    do {                                                                                                          \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_avq<4, NKSV, RBV>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                     \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        adalog_note_kernel(NKSV == 13 ? "k_gemm_avq<13,bf16>" : "k_gemm_avq<4,bf16>");                              \
+        hipLaunchKernelGGL((k_gemm_avq<4, NKSV, RBV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);             \
+    } while (0)
+    if (nks == 13) { if (M > 32) LAUNCH_AVQ(13, 2); else LAUNCH_AVQ(13, 1); }
+    else { if (M > 32) LAUNCH_AVQ(4, 2); else LAUNCH_AVQ(4, 1); }
+#undef LAUNCH_AVQ
+    ADALOG_LAUNCH_CHECK("adalog_gemm_score_avq");
+    return 0;
+}
+
 // 1 when adalog_gemm_score_gen takes this shape (M rows of the fixed operand, N = source rows x ref_div candidate columns).
 extern "C" int adalog_gemm_score_gen_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t k_valid, int64_t Kp) {
     if (!(dtype == 0 || dtype == 3) || k_valid < 16 || k_valid > 64 || k_valid % 16 || ref_div < 1 || N % ref_div != 0 || G % gmod) return 0;

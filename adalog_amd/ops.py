@@ -402,6 +402,55 @@ def gemm_score_gen(dtype: int, A, src3, zp, n_bits: int, M: int, N: int, P: int,
     return PendingScores(partial, MT, n_last, Npad, P, G, gmod, keep_h, False, mode, norm, N)
 
 
+def adalog_value_lut(q_all: torch.Tensor, n_bits: int, mant37: torch.Tensor) -> torch.Tensor:
+    """[2^n_bits + 1, P] int32: entry [k][c] = bf16 bits of the value of bin k under base q_all[c] -- mant37[(k q) mod 37] * 2^-((k q) // 37),
+    0 beyond 2^-100 -- exactly what pack_adalog writes for that bin; the last row (the masked code) is 0.  (Host-side table of the
+    log-base kernel; reference logarithm.py:77-81.)"""
+    nb = 1 << n_bits
+    k = torch.arange(nb, device=q_all.device, dtype=torch.float32).view(nb, 1)
+    kq = (k * q_all.view(1, -1).float()).long()
+    t, j = kq // 37, kq % 37
+    v = torch.ldexp(mant37.float()[j], (-t).to(torch.int32))
+    v = torch.where(t > 100, torch.zeros_like(v), v)
+    vb = v.to(torch.bfloat16)
+    bits = vb.view(torch.int16).to(torch.int32) & 0xFFFF
+    return torch.cat([bits, torch.zeros(1, bits.shape[1], dtype=torch.int32, device=bits.device)], 0).contiguous()
+
+
+def gemm_score_avq_ok(M: int, N: int, G: int, gmod: int, P: int, k_valid: int, Kp: int, n_bits: int) -> bool:
+    return bool(_lib.load().adalog_gemm_score_avq_ok(int(M), int(N), int(G), int(gmod), int(P), int(k_valid), int(Kp), int(n_bits)))
+
+
+def gemm_score_avq(A, src3, q_all, lut, n_bits: int, M: int, N: int, P: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
+                   norm: float, sa_mul: float = 1.0):
+    """The log-base search's scoring call (gemm_score(BF16, A, pack_adalog(src3, 1, q_all, ...), M, N, P, ..., keep_h=False)) without
+    the packed candidate operand: src3 [G, N, K] fp32 probabilities are quantised inside the kernel (adalog_gemm_score_avq).
+    -> scores [P, 1]."""
+    lib = _lib.load()
+    sa, sb = sa.checked(), sb.checked()
+    src3, q_all, ref = _f32c(src3, "src"), _f32c(q_all, "q"), _f32c(ref, "ref")
+    Gs, Ns, K = src3.shape
+    Kp = A.shape[-1]
+    assert (Gs, Ns) == (G, N) and A.shape[-2] == M and A.is_contiguous() and A.dtype == torch.bfloat16
+    assert lut.dtype == torch.int32 and lut.is_contiguous() and lut.shape == ((1 << n_bits) + 1, P)
+    assert ref.shape[-1] == M and ref.shape[-2] == N
+    sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
+    sRg = 0 if G == 1 else M * N
+    n_part, MT, Npad, mode = _layout(M, N * P, 1, G, gmod, P, 1, BF16, Kp, K, True)
+    partial = torch.empty((n_part + 1) // 2, dtype=torch.float64, device=A.device).view(torch.float32)
+    if GEMM_EVENTS is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    rc = lib.adalog_gemm_score_avq(A.data_ptr(), sAg, M, N, Kp, K, G, gmod, src3.data_ptr(), K, N * K, q_all.data_ptr(), lut.data_ptr(),
+                                   int(n_bits), ref.data_ptr(), sRg, P, sa.t.data_ptr(), sa.c, sa.g, float(sa_mul), sb.t.data_ptr(),
+                                   sb.c, sb.g, partial.data_ptr(), n_part, _stream())
+    if GEMM_EVENTS is not None:
+        ev1.record()
+        GEMM_EVENTS.append((BF16, M, N, K, P, G, ev0, ev1, lib.adalog_last_kernel().decode()))
+    _lib.check(rc, "adalog_gemm_score_avq")
+    return PendingScores(partial, MT, Npad if mode != 1 else N, Npad, P, G, gmod, False, False, mode, norm, N).finish()
+
+
 def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, sb: Strided, bias: Optional[Strided],
              sa_mul: float = 1.0):
     """Quantised forward: out[g] = (A[g] . B[g]^T) * sa * sb[n] + bias[n]   -> fp32 [G, M, N]."""

@@ -23,6 +23,8 @@ MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
 # Same-box A/Bs: the kernels get slower (VALU: swin_base 148 -> 176 ms, deit_small 51 -> 69 ms per calibration) but the 0.3-1.1 GB
 # operand is neither written nor read: swin_base 2 978 -> 2 863 ms, deit_small 1 052 -> 1 033 ms per calibration
 GEN_MM = os.environ.get('ADALOG_GEN_MM', 'all')
+# the log-base search of softmax.v with its 128 AdaLog quantisations generated inside the kernel (adalog_gemm_score_avq); 0 = packed
+GEN_AVQ = os.environ.get('ADALOG_GEN_AVQ', '1') != '0'
 MIXED_B_SEARCH = os.environ.get('ADALOG_MIXED_B', '1') != '0'     # softmax.v weight search: fp8 candidates against the bf16 probabilities
 
 
@@ -355,6 +357,15 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         q_all = search.const_tensor([float(i) for i in range(10, 11 + self.eq_n)], dev)[:self.eq_n]
         P = self.eq_n
         ones = search.const_tensor([1.0] * P, dev)
+        if (GEN_AVQ and hasattr(be, "gemm_score_avq") and A.dtype == torch.float32
+                and be.gemm_score_avq_ok(Sp, S, G, H, P, K, bp.shape[-1], self.A_quantizer.n_bits)):
+            # the 128 quantisations of the probabilities are generated inside the kernel (adalog_gemm_score_avq): nothing is packed
+            key = (P, self.A_quantizer.n_bits, str(dev))
+            if getattr(self, "_avq_lut_key", None) != key:
+                self._avq_lut, self._avq_lut_key = be.adalog_value_lut(q_all, self.A_quantizer.n_bits, self._mant37(dev)), key
+            return q_all, be.gemm_score_avq(bp, self._a3(A), q_all, self._avq_lut, self.A_quantizer.n_bits, Sp, S, P, G, H,
+                                            self._ref3(), Strided(self.B_quantizer.scale.data.view(-1), g=pg), Strided(ones, c=1),
+                                            1.0 / (A.shape[1] * S * Sp), sa_mul=self._ts32())
         chunk = self._cand_chunk(G * S * pad_k(K, BF16, self._kalign()) * 2)
         out = []
         for s0 in range(0, P, chunk):

@@ -154,6 +154,19 @@ int adalog_gemm_score_gen(int dtype, const void* A, int64_t sAg, int M, int N, i
                           int ref_div, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
                           int64_t sb_g, float* partial, int64_t partial_elems, void* stream);
 int adalog_gemm_score_gen_ok(int dtype, int M, int N, int G, int gmod, int ref_div, int64_t k_valid, int64_t Kp);
+/* softmax.v, log-base search of the post-softmax AdaLog quantiser (reference quant_layers/matmul.py:321-351): scores of the P = 128
+ *   candidate bases q[P] with the candidate operand -- P AdaLog quantisations (scale 1, no clamp: logarithm.py:83-99 as the search
+ *   applies it) of the probabilities x [G][N][K] (fp32, rows ldx, groups sg apart) -- generated inside the kernel instead of
+ *   packed by adalog_pack_adalog_bf16 and streamed (2.2 GB per launch for deit_small).  A: the fixed operand v^T as packed bf16
+ *   [G][M <= 64][Kp] (groups sAg elements apart); lut: dword table [2^n_bits + 1][P], entry [k][c] = bf16 bits of bin k's value
+ *   under base q[c] (numerator * 2^-t, exactly what the packer writes), last row 0 (the masked code); ref [G][N][M] (groups sRg
+ *   apart); sa / sa_mul / sb: the epilogue factors of adalog_gemm_score; partial: the per-workgroup fp64 accumulators of
+ *   adalog_gemm_score_layout(M, N * P, 1, G, gmod, P, 1, dtype 1, Kp, k_valid, 1).  K <= 208 (197-token ViTs: 13 K-steps; windows: 4). */
+int adalog_gemm_score_avq(const void* A, int64_t sAg, int M, int N, int64_t Kp, int64_t k_valid, int G, int gmod, const float* x,
+                          int64_t ldx, int64_t sg, const float* q, const uint32_t* lut, int n_bits, const float* ref, int64_t sRg,
+                          int P, const float* sa, int64_t sa_c, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c,
+                          int64_t sb_g, float* partial, int64_t partial_elems, void* stream);
+int adalog_gemm_score_avq_ok(int M, int N, int G, int gmod, int P, int64_t k_valid, int64_t Kp, int n_bits);
 int adalog_finish_scores(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
                          int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes, void* stream);
 /* Scratch for the two-stage form used when cand_inner = 1 and keep_n = 0 (sums of 10^4..10^5 terms per candidate): bytes

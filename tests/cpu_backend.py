@@ -190,6 +190,32 @@ def gemm_score_gen(dtype, A, src3, zp, n_bits, M, N, P, G, gmod, ref, sa, sb, ke
     return PendingScores(_gemm_score(dtype, A, cand, M, N, P, G, gmod, ref, sa, sb, None, keep_h, False, norm, sa_mul, P, 2, True))
 
 
+def adalog_value_lut(q_all, n_bits, mant37):
+    from adalog_amd import ops as _ops                     # plain torch arithmetic, device-agnostic: the same function is the spec
+    return _ops.adalog_value_lut(q_all, n_bits, mant37)
+
+
+def gemm_score_avq_ok(M, N, G, gmod, P, k_valid, Kp, n_bits):
+    return P == 128 and M <= 64 and k_valid <= 208 and n_bits <= 6
+
+
+def gemm_score_avq(A, src3, q_all, lut, n_bits, M, N, P, G, gmod, ref, sa, sb, norm, sa_mul=1.0):
+    """Specification of adalog_gemm_score_avq: the candidate operand rebuilt from the bins and the value table, then the packed
+    scoring call."""
+    Gs, Ns, K = src3.shape
+    Kp = A.shape[-1]
+    nb = 1 << n_bits
+    u = src3.unsqueeze(0)                                             # [1, G, N, K], scale 1, no clamp
+    kk = torch.round(-u.log2() * 37.0 / q_all.view(P, 1, 1, 1))
+    kk = torch.where(kk < nb, kk.clamp(min=0), torch.full_like(kk, float(nb)))
+    kk = torch.nan_to_num(kk, nan=float(nb)).long()                  # [P, G, N, K]
+    vals = (lut[kk, torch.arange(P).view(P, 1, 1, 1)].to(torch.int16)).view(torch.bfloat16)
+    cand = torch.zeros((P, G, N, Kp), dtype=torch.bfloat16)
+    cand[..., :K] = vals
+    cand = cand.permute(1, 2, 0, 3).reshape(1, G, N * P, Kp).contiguous()
+    return _gemm_score(BF16, A, cand, M, N, P, G, gmod, ref, sa, sb, None, False, False, norm, sa_mul, P, 2, True)
+
+
 def gemm_out(dtype, A, B, M, N, G, gmod, sa, sb, bias, sa_mul=1.0):
     D = _gemm(dtype, A, B, 1, G)
     alpha = (_epi(sa, 1, G, gmod, 1) * float(torch.tensor(sa_mul, dtype=torch.float32))) * _epi(sb, 1, G, gmod, N)

@@ -54,7 +54,8 @@ SEEN = {}
 REQUIRED = {"k_gemm_slab_wgen<fp8>", "k_gemm_slab_wgen<i8>", "k_gemm_slab128_wgen<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
             "k_gemm_slab128_gen<fp8>", "k_act_fused_asm<12,4,bf16>", "k_act_fused_asm<12,3,bf16>", "k_act_fused_asm<8,4,bf16>",
             "k_act_fused_asm<4,4,bf16>", "k_gemm_stream<bf16xfp8>", "k_gemm_stream<bf16>", "k_gemm_grpw_gen<fp8>", "k_gemm_grpw_gen<i8>",
-            "k_gemm_grpk8<bf16xfp8>", "k_gemm_grpk<bf16>", "k_gemm_win_gen<fp8>", "k_gemm_winb<bf16xfp8>"}
+            "k_gemm_grpk8<bf16xfp8>", "k_gemm_grpk<bf16>", "k_gemm_win_gen<fp8>", "k_gemm_winb<bf16xfp8>", "k_gemm_avq<13,bf16>",
+            "k_gemm_avq<4,bf16>"}
 
 
 def _kern(case, search):
@@ -256,9 +257,9 @@ MATMUL = [  # tag, batch (images x windows), heads, S, head_dim, bits
 QK_KERNELS = {"deit_small.attn-a4": ("k_gemm_grpw_gen<fp8>",), "vit_base.attn-a4": ("k_gemm_grpw_gen<fp8>",),
               "deit_small.attn-a6": ("k_gemm_grpw_gen<i8>",), "swin_base.l0.attn-a3": ("k_gemm_win_gen<fp8>",),
               "swin_base.l2.attn-a3": ("k_gemm_win_gen<fp8>",)}
-AV_KERNELS = {"deit_small.attn-a4": (("k_gemm_stream<bf16>",), ("k_gemm_grpk8<bf16xfp8>",)),
-              "deit_small.attn-a6": (("k_gemm_stream<bf16>",), ("k_gemm_grpk<bf16>",)),
-              "swin_base.l0.attn-a3": (None, ("k_gemm_winb<bf16xfp8>",))}
+AV_KERNELS = {"deit_small.attn-a4": (("k_gemm_avq<13,bf16>",), ("k_gemm_grpk8<bf16xfp8>",)),
+              "deit_small.attn-a6": (("k_gemm_avq<13,bf16>",), ("k_gemm_grpk<bf16>",)),
+              "swin_base.l0.attn-a3": (("k_gemm_avq<4,bf16>",), ("k_gemm_winb<bf16xfp8>",))}
 
 
 @pytest.mark.parametrize("tag,Bn,H,S,hd,bits", MATMUL, ids=[c[0] + f"-a{c[5]}" for c in MATMUL])

@@ -1499,3 +1499,43 @@ def test_gemm_score_gen_matches_packed_path(ops, bits, dt_name, shape):
     assert got.shape == want.shape == (P, H)
     assert rel_err(got.cpu(), want.cpu()) <= 2e-6
 
+
+@pytest.mark.parametrize("bits", [4, 3, 6])
+@pytest.mark.parametrize("shape", [("vit", 192, 6, 197, 64), ("win", 2048, 4, 49, 32), ("win16", 512, 16, 49, 32)])
+def test_gemm_score_avq_matches_packed_path(ops, bits, shape):
+    """Log-base scores of softmax.v with the 128 AdaLog quantisations of the probabilities generated in the kernel
+    (adalog_gemm_score_avq) against the packed route (pack_adalog + bf16 gemm_score) on the same bases; probabilities planted on
+    bin ties of some bases, exact zeros (masked) and values below the last bin included."""
+    from adalog_amd.ops import BF16, Strided
+    kind, G, H, S, D = shape
+    gen = g(9300 + bits + G + S)
+    P = 128
+    A = torch.softmax(4.0 * torch.randn(G, S, S, generator=gen), dim=-1)
+    A[:, 3, 5] = 0.0                                                     # masked code
+    A[:, 4, 6] = 1e-30                                                   # below the last bin of every base
+    for qq, kk in ((17, 2.5), (90, 0.5), (137, 1.5)):                    # t = k + 0.5 exactly representable -> the tie zone
+        A[:, 7, qq % S] = float(2.0 ** (-(kk * qq / 37.0)))
+    v = torch.randn(G, S, D, generator=gen) * (0.5 + torch.rand(1, 1, 1, generator=gen))
+    b_s = torch.full((H,), v.abs().max().item() * 2 / (2 ** bits - 1))
+    b_z = torch.full((H,), float(2 ** (bits - 1)))
+    pg = 1 if H > 1 else 0
+    ref = torch.einsum("gsk,gkd->gsd", A, v)                             # [G, S, D] = the transposed reference of D^T = v^T . A^T
+    d = lambda t_: t_.to(DEV).contiguous()
+    q_all = torch.arange(10, 10 + P).float()
+    mant = torch.round(torch.tensor([2 ** (-j / 37.0) for j in range(37)]) * (4 * 2 ** (bits - 1) - 2))
+    ones = torch.ones(P)
+    vt = d(v.transpose(1, 2))                                            # [G, D, S]: rows = head-dim columns of v
+    bp = ops.pack_uniform(vt, d(b_s), d(b_z), 1, 0, H, pg, 0, bits, BF16, k_align=64)
+    assert ops.gemm_score_avq_ok(D, S, G, H, P, S, bp.shape[-1], bits)
+    lut = ops.adalog_value_lut(d(q_all), bits, d(mant))
+    sa, sb = Strided(d(b_s), g=pg), Strided(d(ones), c=1)
+    ts = 1.0 / (4 * 2 ** (bits - 1) - 2)
+    got = ops.gemm_score_avq(bp, d(A), d(q_all), lut, bits, D, S, P, G, H, d(ref), sa, sb, 1.0 / (S * D), sa_mul=ts)
+    assert _last_kernel() == ("k_gemm_avq<13,bf16>" if S > 64 else "k_gemm_avq<4,bf16>")
+    ap = ops.pack_adalog(d(A), d(ones), d(q_all), P, 1, 1, 0, bits, d(mant), shift=None, clamp_u=False, c_inner=True, k_align=64)
+    want = ops.gemm_score(BF16, bp, ap, D, S, P, G, H, d(ref), sa, sb, None, False, False, 1.0 / (S * D), sa_mul=ts, ref_div=P,
+                          order=2, ref_transposed=True)
+    assert "avq" not in _last_kernel()
+    assert got.shape == want.shape == (P, 1)
+    assert rel_err(got.cpu(), want.cpu()) <= 2e-6
+
