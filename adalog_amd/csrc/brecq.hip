@@ -246,6 +246,39 @@ __global__ __launch_bounds__(256) void k_adaround(const float* __restrict__ w, c
     }
 }
 
+// The AdaRound forward writing its result in BOTH orientations: out [rows][inner] and out_t [inner][rows] (the K-major image the
+// forward product of a BRECQ iteration reads: brecq_gemm.hip fetches a K-contiguous operand as half cache lines).  A block moves a
+// 32 x 32 tile through LDS so that both stores are coalesced.
+__global__ __launch_bounds__(256) void k_adaround_t(const float* __restrict__ w, const float* __restrict__ alpha,
+                                                    float* __restrict__ out, float* __restrict__ out_t, int64_t rows, int64_t inner,
+                                                    const float* __restrict__ scale, const float* __restrict__ zp, float qmax,
+                                                    int soft) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < inner) {
+            const int64_t idx = r * inner + c;
+            const float s = scale[r], z = zp[r];
+            const float fl = floorf(w[idx] / s);
+            float dh = 0.0f;
+            const float a = alpha[idx];
+            const float h = soft ? soft_h(a, dh) : (a >= 0.0f ? 1.0f : 0.0f);
+            const float v = (fminf(fmaxf(fl + h + z, 0.0f), qmax) - z) * s;
+            out[idx] = v;
+            tile[ty + 8 * i][tx] = v;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < inner) out_t[c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
 // round loss value (block partials) and, when galpha != null, galpha[i] += gscale * d/d alpha
 __global__ __launch_bounds__(256) void k_round_loss(const float* __restrict__ alpha, int64_t n, float b,
                                                     const float* __restrict__ b_dev, float* __restrict__ part,
@@ -668,6 +701,16 @@ extern "C" int adalog_adaround(const float* w, const float* alpha, const float* 
 // loss[0] = sum_i (1 - |2 h(alpha_i) - 1|^b) (when loss != null).  When galpha != null, with
 // g_i = gscale * (gmul ? gmul[0] : 1) * dloss/dalpha_i:  galpha[i] = g_i (overwrite) or galpha[i] += g_i.
 // workspace: 1024 floats (needed for the loss value only)
+extern "C" int adalog_adaround_t(const float* w, const float* alpha, float* out, float* out_t, int64_t rows, int64_t inner,
+                                 const float* scale, const float* zero_point, int n_bits, int soft, void* stream) {
+    if (rows * inner == 0) return 0;
+    ADALOG_ARG_CHECK(w && alpha && out && out_t && scale && zero_point, "adaround_t: bad arguments");
+    hipLaunchKernelGGL(k_adaround_t, dim3((unsigned)((inner + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
+                       w, alpha, out, out_t, rows, inner, scale, zero_point, (float)((1 << n_bits) - 1), soft);
+    ADALOG_LAUNCH_CHECK("adalog_adaround_t");
+    return 0;
+}
+
 extern "C" int adalog_round_loss(const float* alpha, int64_t n, float b, const float* b_dev, float* loss, float* galpha,
                                  float gscale, const float* gmul, int overwrite, float* workspace, void* stream) {
     ADALOG_ARG_CHECK(alpha && n >= 1 && (loss == nullptr || workspace), "round_loss: bad arguments");

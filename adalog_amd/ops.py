@@ -931,6 +931,19 @@ def adaround(w2, alpha2, scale, zero_point, n_bits: int, soft: bool, gy=None):
     return out
 
 
+def adaround_t(w2, alpha2, scale, zero_point, n_bits: int, soft: bool):
+    """Forward value of the AdaRound weight quantiser in both orientations: (out [rows, inner], out_t [inner, rows])."""
+    w2, alpha2 = _f32c(w2, "w"), _f32c(alpha2, "alpha")
+    rows, inner = w2.shape
+    out = torch.empty_like(w2)
+    out_t = torch.empty((inner, rows), dtype=torch.float32, device=w2.device)
+    rc = _lib.load().adalog_adaround_t(w2.data_ptr(), alpha2.data_ptr(), out.data_ptr(), out_t.data_ptr(), rows, inner,
+                                      _f32c(scale, "scale").data_ptr(), _f32c(zero_point, "zero_point").data_ptr(), int(n_bits),
+                                      int(bool(soft)), _stream())
+    _lib.check(rc, "adalog_adaround_t")
+    return out, out_t
+
+
 def round_loss(alpha, b, galpha=None, gscale: float = 1.0, want_loss: bool = True, gmul=None, overwrite: bool = False):
     """``b``: python float, or a device fp32 tensor of one element (read by the kernel: HIP-graph friendly).
     ``galpha`` (optional) receives gscale * gmul * d/d alpha: added to it, or written over it (``overwrite``);

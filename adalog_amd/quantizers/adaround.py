@@ -5,7 +5,7 @@ used by BRECQ block reconstruction.  Forward, d/d alpha and the rounding regular
 import torch
 from torch import nn
 
-from .. import backend
+from .. import backend, train_mm
 from .uniform import UniformQuantizer
 
 
@@ -14,7 +14,13 @@ class _AdaRoundFn(torch.autograd.Function):
     def forward(ctx, w2, alpha2, scale, zero_point, n_bits, soft):
         ctx.save_for_backward(w2, alpha2, scale, zero_point)
         ctx.n_bits, ctx.soft = n_bits, soft
-        return backend.get().adaround(w2, alpha2, scale, zero_point, n_bits, soft)
+        be = backend.get()
+        if train_mm.W_KMAJOR and w2.is_cuda and alpha2.requires_grad and hasattr(be, "adaround_t"):
+            # a BRECQ iteration: the same launch leaves the K-major image the layer's forward product reads (train_mm._kmajor)
+            y, y_t = be.adaround_t(w2, alpha2, scale, zero_point, n_bits, soft)
+            train_mm.offer_kmajor(y, y_t)
+            return y
+        return be.adaround(w2, alpha2, scale, zero_point, n_bits, soft)
 
     @staticmethod
     def backward(ctx, gy):

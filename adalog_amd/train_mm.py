@@ -51,12 +51,29 @@ def _planes(be, w2):
     return be.pack_split3(w2.unsqueeze(0), 64)
 
 
+_KMAJOR_OFFER = {}                                    # data_ptr of a [N, K] tensor -> (its [K, N] image, N, K): one entry per layer
+
+
+def offer_kmajor(w2, w2_t):
+    """The producer of w2 [N, K] (the AdaRound forward) hands over its [K, N] image; the next forward product on w2 takes it."""
+    if len(_KMAJOR_OFFER) > 64:
+        _KMAJOR_OFFER.clear()
+    _KMAJOR_OFFER[w2.data_ptr()] = (w2_t, w2.shape[0], w2.shape[1])
+
+
+def reset_offers():
+    """Start of a BRECQ iteration: forget images nobody took (their keys are addresses that may be reused)."""
+    _KMAJOR_OFFER.clear()
+
+
 def _kmajor(w2):
     """w2 [N, K] as the same logical matrix over K-major storage (a [K, N] copy, viewed back)."""
     if not W_KMAJOR or w2.shape[0] % 4:
         return w2
-    wt = getattr(w2, "_adalog_kmajor", None)           # made by the producer of w_sim when it has one
-    return (wt if wt is not None else w2.t().contiguous()).t()
+    hit = _KMAJOR_OFFER.pop(w2.data_ptr(), None)       # made by the producer of w_sim when it has one (views share the pointer)
+    if hit is not None and hit[1:] == (w2.shape[0], w2.shape[1]) and w2.is_contiguous():
+        return hit[0].t()
+    return w2.t().contiguous().t()
 
 
 class _LinearFn(torch.autograd.Function):

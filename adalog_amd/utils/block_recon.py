@@ -17,7 +17,7 @@ import os
 import torch
 import torch.nn.functional as F
 
-from .. import backend, parallel
+from .. import backend, parallel, train_mm
 from ..quant_layers import MinMaxQuantConv2d, MinMaxQuantLinear, MinMaxQuantMatMul
 from ..quantizers.adaround import AdaRoundQuantizer
 from .calibrator import QuantCalibrator
@@ -198,6 +198,7 @@ class BlockReconstructor(QuantCalibrator):
                 a_optimizer.step()
 
         def eager_step(cur_inp, cur_out):
+            train_mm.reset_offers()
             for prm in params:
                 prm.grad = None
             out_quant = block(cur_inp)
@@ -255,6 +256,7 @@ class BlockReconstructor(QuantCalibrator):
                         prm.grad = None
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
+                    train_mm.reset_offers()
                     with torch.cuda.graph(graph):
                         static_rec = loss_func.rec_term(block(static_inp), static_out)
                         static_rnd = (loss_func.round_sum(b_dev) * rw_dev).sum()

@@ -357,6 +357,10 @@ int adalog_log_fq_backward(const float* gy, const float* x, const float* y, floa
                            void* stream);
 int adalog_adaround(const float* w, const float* alpha, const float* gy, float* out, int64_t rows, int64_t inner,
                     const float* scale, const float* zero_point, int n_bits, int soft, int backward, void* stream);
+/* adalog_adaround's forward writing both orientations: out [rows][inner] and out_t [inner][rows] (the K-major image of the
+ *   soft-rounded weights that the forward product of a BRECQ iteration reads; adaround.py:38-57 otherwise unchanged). */
+int adalog_adaround_t(const float* w, const float* alpha, float* out, float* out_t, int64_t rows, int64_t inner, const float* scale,
+                      const float* zero_point, int n_bits, int soft, void* stream);
 int adalog_round_loss(const float* alpha, int64_t n, float b, const float* b_dev, float* loss, float* galpha, float gscale,
                       const float* gmul, int overwrite, float* workspace, void* stream);
 /* The regulariser of a whole block in one launch: loss[0] = weight * sum_t sum_i (1 - |2h(alpha_t[i])-1|^b) over `count`

@@ -498,6 +498,12 @@ def round_loss(alpha, b, galpha=None, gscale=1.0, want_loss=True, gmul=None, ove
     return loss.detach().view(1) if want_loss else None
 
 
+def adaround_t(w2, alpha2, scale, zero_point, n_bits, soft):
+    """Specification of adalog_adaround_t."""
+    y = adaround(w2, alpha2, scale, zero_point, n_bits, soft)
+    return y, y.t().contiguous()
+
+
 def rec_loss(pred, tgt, scale):
     return (((pred - tgt) ** 2).sum() * scale).view(1)
 

@@ -1539,3 +1539,18 @@ def test_gemm_score_avq_matches_packed_path(ops, bits, shape):
     assert got.shape == want.shape == (P, 1)
     assert rel_err(got.cpu(), want.cpu()) <= 2e-6
 
+
+@pytest.mark.parametrize("rows,inner", [(1152, 384), (384, 1536), (100, 70), (33, 5)])
+def test_adaround_t_writes_both_orientations(ops, rows, inner):
+    """adalog_adaround_t: the AdaRound forward and its [inner][rows] image in one launch, both bit-equal to adalog_adaround."""
+    gen = g(9500 + rows)
+    w = torch.randn(rows, inner, generator=gen) * 0.05
+    al = torch.randn(rows, inner, generator=gen) * 3.0
+    s_ = (torch.rand(rows, generator=gen) * 0.01 + 0.005)
+    z_ = torch.randint(4, 12, (rows,), generator=gen).float()
+    d = lambda t_: t_.to(DEV)
+    for soft in (True, False):
+        want = ops.adaround(d(w), d(al), d(s_), d(z_), 4, soft)
+        y, yt = ops.adaround_t(d(w), d(al), d(s_), d(z_), 4, soft)
+        assert torch.equal(y, want) and torch.equal(yt, want.t().contiguous())
+
