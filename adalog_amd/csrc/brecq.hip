@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void k_round_loss_multi(RoundLossMulti a, floa
         const float pm1 = ad > 0.0f ? powf(ad, b - 1.0f) : 0.0f;
         acc += 1.0f - pm1 * ad;
         const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-        gr[i] = weight * (-b * pm1 * sgn * 2.0f * dh);
+        if (gr) gr[i] = weight * (-b * pm1 * sgn * 2.0f * dh);
     }
     const float ts = block_sum(acc, sm);
     if (threadIdx.x == 0) store_agent(part + blockIdx.x, ts);
@@ -396,6 +396,78 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamMulti a, float lr, const
     }
 }
 __global__ void k_adam_count(float* step_dev) { step_dev[0] += 1.0f; }
+
+// The whole update of AdaRound's alpha in one launch (a captured BRECQ iteration, one GPU): the gradient through the soft-rounded
+// weights (k_adaround's backward form, from dL/dw_sim), the gradient of the rounding regulariser (k_round_loss_multi's, times its
+// upstream factor) and the Adam step (k_adam_multi's), element by element with the same operations in the same order -- what
+// autograd does with four backward launches, a multiply, four accumulations and the optimiser's launch.  gw[t] may be null (a
+// layer whose weights took no gradient this iteration).
+struct AlphaStepMulti {
+    float* alpha[ADAM_MAX];
+    const float* w[ADAM_MAX];
+    const float* gw[ADAM_MAX];
+    const float* scale[ADAM_MAX];
+    const float* zp[ADAM_MAX];
+    float* m[ADAM_MAX];
+    float* v[ADAM_MAX];
+    int64_t n[ADAM_MAX];
+    int64_t inner[ADAM_MAX];
+    float qmax[ADAM_MAX];
+    int first_block[ADAM_MAX + 1];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void k_alpha_step_multi(AlphaStepMulti a, float lr, const float* __restrict__ lr_dev, float beta1,
+                                                          float beta2, float eps, const float* __restrict__ step_dev, float b,
+                                                          const float* __restrict__ b_dev, float weight,
+                                                          const float* __restrict__ gmul) {
+    int t = 0;
+    while (t + 1 < a.count && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
+    if (lr_dev) lr = lr_dev[0];
+    if (b_dev) b = b_dev[0];
+    const float g_rl = gmul ? gmul[0] : 0.0f;                  // upstream gradient of the regulariser (0: not part of the loss yet)
+    const float step = step_dev[0] + 1.0f;
+    const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
+    const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+    float* __restrict__ al = a.alpha[t];
+    const float* __restrict__ ww = a.w[t];
+    const float* __restrict__ gw = a.gw[t];
+    const float* __restrict__ sc = a.scale[t];
+    const float* __restrict__ zz = a.zp[t];
+    float* __restrict__ mm = a.m[t];
+    float* __restrict__ vv = a.v[t];
+    const int64_t n = a.n[t], inner = a.inner[t];
+    const float qmax = a.qmax[t];
+    const int64_t base = (int64_t)(blockIdx.x - a.first_block[t]) * 1024;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < n) {
+            const int64_t row = i / inner;
+            const float s = sc[row], z = zz[row];
+            const float av = al[i];
+            float dh;
+            const float h = soft_h(av, dh);
+            // d/d alpha through w_sim (k_adaround, backward form, soft targets)
+            const float tt = floorf(ww[i] / s) + h + z;
+            const bool inside = (tt >= 0.0f) && (tt <= qmax);
+            const float ga = (gw && inside) ? gw[i] * s * dh : 0.0f;
+            // d/d alpha of the regulariser (k_round_loss_multi) times its upstream factor
+            const float d = 2.0f * (h - 0.5f);
+            const float ad = fabsf(d);
+            const float pm1 = ad > 0.0f ? powf(ad, b - 1.0f) : 0.0f;
+            const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+            const float grl = weight * (-b * pm1 * sgn * 2.0f * dh);
+            const float g = ga + grl * g_rl;
+            // Adam (k_adam_multi)
+            const float m_ = mm[i] + (1.0f - beta1) * (g - mm[i]);
+            const float v_ = beta2 * vv[i] + (1.0f - beta2) * g * g;
+            const float denom = sqrtf(v_) / bc2s + eps;
+            mm[i] = m_; vv[i] = v_;
+            al[i] = av - step_size * (m_ / denom);
+        }
+    }
+}
 
 // reconstruction loss  scale * sum_i (pred_i - tgt_i)^2  (block_recon.py:186-199 with p = 2) and its gradient
 __global__ __launch_bounds__(256) void k_rec_loss(const float* __restrict__ pred, const float* __restrict__ tgt, int64_t n,
@@ -760,13 +832,13 @@ extern "C" int64_t adalog_round_loss_multi_workspace(const int64_t* ns, int coun
 
 extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const* grads, const int64_t* ns, int count, float b,
                                        const float* b_dev, float weight, float* loss, float* workspace, void* stream) {
-    ADALOG_ARG_CHECK(alphas && grads && ns && loss && workspace && count >= 1 && count <= RL_MAX, "round_loss_multi: bad arguments");
+    ADALOG_ARG_CHECK(alphas && ns && loss && workspace && count >= 1 && count <= RL_MAX, "round_loss_multi: bad arguments");
     RoundLossMulti a;
     int blocks = 0;
     for (int t = 0; t < count; ++t) {
-        ADALOG_ARG_CHECK(alphas[t] && grads[t] && ns[t] >= 1, "round_loss_multi: bad tensor");
+        ADALOG_ARG_CHECK(alphas[t] && ns[t] >= 1, "round_loss_multi: bad tensor");
         a.alpha[t] = alphas[t];
-        a.grad[t] = grads[t];
+        a.grad[t] = grads ? grads[t] : nullptr;                 // no gradients wanted (adalog_alpha_step_multi computes them itself)
         a.n[t] = ns[t];
         a.first_block[t] = blocks;
         blocks += grid1(ns[t], 256);
@@ -778,6 +850,38 @@ extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const*
     hipLaunchKernelGGL(k_round_loss_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, b_dev, weight, workspace, ticket,
                        loss);
     ADALOG_LAUNCH_CHECK("adalog_round_loss_multi");
+    return 0;
+}
+
+// AdaRound's alpha of `count` (<= 16) layers: gradient (through w_sim from gws[t] = dL/dw_sim, plus the rounding regulariser's,
+// scaled by the device scalar gmul[0]) and Adam step in one launch (reference quantizers/adaround.py:38-57 under autograd,
+// utils/block_recon.py:108-125,205-210).  HOST arrays of device pointers; ns[t] = rows * inners[t] elements; gws[t] may be null.
+// gmul may be null (regulariser not in the loss).  step_dev: steps taken so far (advanced here).  soft targets only.
+extern "C" int adalog_alpha_step_multi(float* const* alphas, const float* const* ws, const float* const* gws, const float* const* scales,
+                                       const float* const* zps, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* ns,
+                                       const int64_t* inners, const int* n_bits, int count, float lr, const float* lr_dev, float beta1,
+                                       float beta2, float eps, float* step_dev, float b, const float* b_dev, float weight,
+                                       const float* gmul, void* stream) {
+    ADALOG_ARG_CHECK(alphas && ws && gws && scales && zps && exp_avg && exp_avg_sq && ns && inners && n_bits && step_dev && count >= 1 &&
+                     count <= ADAM_MAX, "alpha_step_multi: bad arguments");
+    AlphaStepMulti a;
+    int blocks = 0;
+    for (int t = 0; t < count; ++t) {
+        ADALOG_ARG_CHECK(alphas[t] && ws[t] && scales[t] && zps[t] && exp_avg[t] && exp_avg_sq[t] && ns[t] >= 1 && inners[t] >= 1 &&
+                         ns[t] % inners[t] == 0, "alpha_step_multi: bad tensor");
+        a.alpha[t] = alphas[t]; a.w[t] = ws[t]; a.gw[t] = gws[t]; a.scale[t] = scales[t]; a.zp[t] = zps[t];
+        a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.n[t] = ns[t]; a.inner[t] = inners[t];
+        a.qmax[t] = (float)((1 << n_bits[t]) - 1);
+        a.first_block[t] = blocks;
+        blocks += (int)((ns[t] + 1023) / 1024);
+    }
+    a.first_block[count] = blocks;
+    a.count = count;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_alpha_step_multi, dim3(blocks), dim3(256), 0, st, a, lr, lr_dev, beta1, beta2, eps, step_dev, b, b_dev, weight,
+                       gmul);
+    hipLaunchKernelGGL(k_adam_count, dim3(1), dim3(1), 0, st, step_dev);
+    ADALOG_LAUNCH_CHECK("adalog_alpha_step_multi");
     return 0;
 }
 

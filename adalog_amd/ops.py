@@ -982,15 +982,16 @@ def rec_loss_backward(pred, tgt, scale: float, gmul):
     return gp
 
 
-def round_loss_multi(alphas, b, weight: float):
+def round_loss_multi(alphas, b, weight: float, want_grads: bool = True):
     """weight * sum_t sum(1 - |2h(alpha_t)-1|^b) and its gradients, one launch for all tensors of a block.
-    Returns (loss [1], [grad_t])."""
+    Returns (loss [1], [grad_t]) -- grads None with ``want_grads=False`` (alpha_step_multi computes them itself)."""
     import ctypes
     alphas = [_f32c(a, "alpha") for a in alphas]
     n = len(alphas)
-    grads = [torch.empty_like(a) for a in alphas]
+    grads = [torch.empty_like(a) for a in alphas] if want_grads else None
     PA, NA = ctypes.c_void_p * n, ctypes.c_int64 * n
-    ap, gp, ns = PA(*[a.data_ptr() for a in alphas]), PA(*[g_.data_ptr() for g_ in grads]), NA(*[a.numel() for a in alphas])
+    ap, ns = PA(*[a.data_ptr() for a in alphas]), NA(*[a.numel() for a in alphas])
+    gp = PA(*[g_.data_ptr() for g_ in grads]) if want_grads else None
     lib = _lib.load()
     dev = alphas[0].device
     ws = torch.empty(int(lib.adalog_round_loss_multi_workspace(ns, n)), dtype=torch.float32, device=dev)
@@ -1160,6 +1161,31 @@ def merge_heads(parts, B: int, N: int, H: int, D: int) -> torch.Tensor:
     rc = _lib.load().adalog_merge_heads(ptr[0], ptr[1], ptr[2], ptr[3], out.data_ptr(), B, N, P, int(H), int(D), _stream())
     _lib.check(rc, "adalog_merge_heads")
     return out
+
+
+def alpha_step_multi(alphas, ws, gws, scales, zps, exp_avg, exp_avg_sq, inners, n_bits, step_dev, lr, beta1: float, beta2: float,
+                     eps: float, b, weight: float, gmul):
+    """AdaRound's alpha of up to 16 layers: gradient (through w_sim from gws[t] = dL/dw_sim or None, plus ``gmul`` times the
+    rounding regulariser's) and Adam step in ONE launch.  ``b``: float or device tensor [1]; ``gmul``: device tensor [1] or None;
+    ``lr``: float or device tensor [1]; ``step_dev``: device fp32 [1], steps taken so far (advanced here)."""
+    import ctypes
+    n = len(alphas)
+    PA, NA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    for t in list(alphas) + list(ws) + [g_ for g_ in gws if g_ is not None] + list(scales) + list(zps) + list(exp_avg) + list(exp_avg_sq):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise _lib.AdalogHipError("alpha_step_multi: contiguous fp32 device tensors expected")
+    for a_, w_, g_ in zip(alphas, ws, gws):
+        if w_.numel() != a_.numel() or (g_ is not None and g_.numel() != a_.numel()):
+            raise _lib.AdalogHipError("alpha_step_multi: alpha, w and dL/dw_sim must have the same number of elements")
+    lr_dev = lr if torch.is_tensor(lr) else None
+    b_dev = b if torch.is_tensor(b) else None
+    rc = _lib.load().adalog_alpha_step_multi(
+        PA(*[t.data_ptr() for t in alphas]), PA(*[t.data_ptr() for t in ws]), PA(*[None if t is None else t.data_ptr() for t in gws]),
+        PA(*[t.data_ptr() for t in scales]), PA(*[t.data_ptr() for t in zps]), PA(*[t.data_ptr() for t in exp_avg]),
+        PA(*[t.data_ptr() for t in exp_avg_sq]), NA(*[t.numel() for t in alphas]), NA(*[int(i) for i in inners]),
+        IA(*[int(i) for i in n_bits]), n, 0.0 if lr_dev is not None else float(lr), _ptr(lr_dev), float(beta1), float(beta2), float(eps),
+        step_dev.data_ptr(), 0.0 if b_dev is not None else float(b), _ptr(b_dev), float(weight), _ptr(gmul), _stream())
+    _lib.check(rc, "adalog_alpha_step_multi")
 
 
 def adam_multi(params, grads, exp_avg, exp_avg_sq, step_dev, lr, beta1: float, beta2: float, eps: float):

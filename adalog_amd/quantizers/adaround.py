@@ -9,6 +9,45 @@ from .. import backend, train_mm
 from .uniform import UniformQuantizer
 
 
+class AlphaCollector:
+    """A captured BRECQ iteration on one GPU (utils/block_recon.py): instead of materialising d/d alpha per layer (one launch
+    each), the regulariser's gradients, their product with the upstream factor, four accumulations and the optimiser's launch,
+    the backward nodes hand their inputs to this collector and ``flush`` issues ONE launch (adalog_alpha_step_multi) that
+    computes the gradient of every alpha and takes its Adam step.  Active only while ``COLLECT`` is set (the graph capture)."""
+
+    def __init__(self, quantizers, state_of, step_dev, lr, betas, eps):
+        self.q = list(quantizers)                              # the block's AdaRoundQuantizers, in the regulariser's order
+        self.ptr = {q_.alpha.data_ptr(): i for i, q_ in enumerate(self.q)}
+        self.state_of, self.step_dev, self.lr, self.betas, self.eps = state_of, step_dev, lr, betas, eps
+        self.begin()
+
+    def begin(self):
+        self.gw = [None] * len(self.q)
+        self.w = [None] * len(self.q)
+        self.round = None                                      # (b, weight, upstream gradient) of the regulariser
+
+    def take(self, alpha2, w2, gy):
+        i = self.ptr.get(alpha2.data_ptr())
+        if i is None or not self.q[i].soft_targets:
+            return False
+        self.gw[i], self.w[i] = gy.contiguous(), w2
+        return True
+
+    def flush(self):
+        be = backend.get()
+        qs = self.q
+        ws = [w_ if w_ is not None else q_._w_last for w_, q_ in zip(self.w, qs)]
+        sts = [self.state_of(q_.alpha) for q_ in qs]
+        b, weight, g = self.round if self.round is not None else (1.0, 0.0, None)
+        be.alpha_step_multi([q_.alpha.data for q_ in qs], ws, self.gw, [q_.scale.data.view(-1) for q_ in qs],
+                            [q_.zero_point.data.view(-1) for q_ in qs], [st['exp_avg'] for st in sts], [st['exp_avg_sq'] for st in sts],
+                            [q_.alpha.numel() // q_.scale.numel() for q_ in qs], [q_.n_bits for q_ in qs], self.step_dev, self.lr,
+                            self.betas[0], self.betas[1], self.eps, b, weight, g)
+
+
+COLLECT = None                                                 # the AlphaCollector in force (set around a graph capture only)
+
+
 class _AdaRoundFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w2, alpha2, scale, zero_point, n_bits, soft):
@@ -25,6 +64,8 @@ class _AdaRoundFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         w2, alpha2, scale, zero_point = ctx.saved_tensors
+        if COLLECT is not None and ctx.soft and COLLECT.take(alpha2, w2, gy):
+            return None, None, None, None, None, None          # the collector's launch computes and applies d/d alpha
         ga = backend.get().adaround(w2, alpha2, scale, zero_point, ctx.n_bits, ctx.soft, gy=gy.contiguous())
         return None, ga, None, None, None, None
 
@@ -86,8 +127,9 @@ class AdaRoundQuantizer(nn.Module):
         if self.round_mode != 'learned_hard_sigmoid':
             raise ValueError('Wrong rounding mode')
         shp = x.shape
-        y = _AdaRoundFn.apply(self._rows(x), self._rows(self.alpha), self.scale.view(-1), self.zero_point.view(-1),
-                              self.n_bits, bool(self.soft_targets))
+        self._w_last = self._rows(x).detach()                   # (the collector's launch reads the weights of a layer without gradient)
+        y = _AdaRoundFn.apply(self._w_last if not x.requires_grad else self._rows(x), self._rows(self.alpha), self.scale.view(-1),
+                              self.zero_point.view(-1), self.n_bits, bool(self.soft_targets))
         return y.view(shp)
 
     def get_soft_targets(self):

@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from .. import backend, parallel, train_mm
 from ..quant_layers import MinMaxQuantConv2d, MinMaxQuantLinear, MinMaxQuantMatMul
 from ..quantizers.adaround import AdaRoundQuantizer
+from ..quantizers import adaround as adaround_mod
 from .calibrator import QuantCalibrator
 from . import models as M
 
@@ -75,6 +76,29 @@ class BlockReconstructor(QuantCalibrator):
     def _prepare_module_data_init(module):
         module.raw_input = module.tmp_input = None
         module.raw_out = module.tmp_out = None
+
+    @staticmethod
+    def _alpha_collector(block, loss_func, w_optimizer, w_params):
+        """The one-launch alpha update of a captured iteration (quantizers/adaround.py AlphaCollector), or None when it does not
+        apply: HipAdam over exactly the block's soft-target AdaRound alphas (<= 16, fp32, contiguous), ADALOG_BRECQ_ALPHA_STEP != 0."""
+        be = backend.get()
+        if os.environ.get("ADALOG_BRECQ_ALPHA_STEP", "1") == "0" or not isinstance(w_optimizer, HipAdam) \
+                or not hasattr(be, "alpha_step_multi") or loss_func.round_loss != 'relaxation':
+            return None
+        qs = [m.w_quantizer for _, m in block.named_modules()
+              if hasattr(m, 'w_quantizer') and isinstance(m.w_quantizer, AdaRoundQuantizer)]
+        if not (1 <= len(qs) <= 16) or len(w_optimizer.param_groups) != 1:
+            return None
+        if {id(q_.alpha) for q_ in qs} != {id(p_) for p_ in w_params} or len(w_params) != len(qs):
+            return None
+        if not all(q_.soft_targets and q_.round_mode == 'learned_hard_sigmoid' and not q_.sym and q_.alpha.is_cuda
+                   and q_.alpha.dtype == torch.float32 and q_.alpha.is_contiguous() for q_ in qs):
+            return None
+        group = w_optimizer.param_groups[0]
+        if (0, 0) not in w_optimizer._steps or any(not w_optimizer.state[q_.alpha] for q_ in qs):
+            return None                                      # the eager warm-up iterations create the Adam state
+        return adaround_mod.AlphaCollector(qs, lambda p_: w_optimizer.state[p_], w_optimizer._steps[(0, 0)], group['lr'],
+                                           group['betas'], group['eps'])
 
     def set_block_mode(self, block, mode='raw'):
         for _, module in block.named_modules():
@@ -257,12 +281,19 @@ class BlockReconstructor(QuantCalibrator):
                     torch.cuda.synchronize()
                     graph = torch.cuda.CUDAGraph()
                     train_mm.reset_offers()
+                    collector = self._alpha_collector(block, loss_func, w_optimizer, w_params) if full_graph else None
                     with torch.cuda.graph(graph):
-                        static_rec = loss_func.rec_term(block(static_inp), static_out)
-                        static_rnd = (loss_func.round_sum(b_dev) * rw_dev).sum()
-                        (static_rec + static_rnd).backward()
+                        adaround_mod.COLLECT = collector
+                        try:
+                            static_rec = loss_func.rec_term(block(static_inp), static_out)
+                            static_rnd = (loss_func.round_sum(b_dev) * rw_dev).sum()
+                            (static_rec + static_rnd).backward()
+                        finally:
+                            adaround_mod.COLLECT = None
                         if full_graph:
-                            optim_steps()
+                            if collector is not None:
+                                collector.flush()            # d/d alpha of every layer and its Adam step: one launch
+                            optim_steps()                    # (w_optimizer finds no gradient on the collected alphas)
                 graph.replay()                               # grads are overwritten, not accumulated (none existed at capture)
                 if not full_graph:
                     parallel.all_reduce_mean_bucket([prm.grad for prm in params if prm.grad is not None])
@@ -388,12 +419,19 @@ class _RoundLossAllFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, b, weight, *alphas):
-        loss, grads = backend.get().round_loss_multi(alphas, b, weight)
-        ctx.save_for_backward(*grads)
+        ctx.collect = adaround_mod.COLLECT is not None
+        loss, grads = backend.get().round_loss_multi(alphas, b, weight, **({"want_grads": False} if ctx.collect else {}))
+        if ctx.collect:
+            ctx.b, ctx.weight, ctx.n = b, weight, len(alphas)
+        else:
+            ctx.save_for_backward(*grads)
         return loss.view(())
 
     @staticmethod
     def backward(ctx, g):
+        if ctx.collect:                                      # the collector's launch computes these gradients itself
+            adaround_mod.COLLECT.round = (ctx.b, ctx.weight, g.reshape(1).contiguous())
+            return (None, None) + (None,) * ctx.n
         return (None, None) + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 

@@ -376,6 +376,15 @@ int adalog_round_loss_multi(const float* const* alphas, float* const* grads, con
 int adalog_rec_loss(const float* pred, const float* tgt, int64_t n, float scale, float* loss, float* workspace, void* stream);
 int adalog_rec_loss_backward(const float* pred, const float* tgt, int64_t n, float scale, const float* gmul, float* gpred,
                              void* stream);
+/* AdaRound's alpha of <= 16 layers, gradient AND Adam step in one launch (a captured BRECQ iteration on one GPU): per element
+ *   g = [inside] gw * s * h'(alpha)  +  gmul[0] * weight * d/d alpha (1 - |2 h(alpha) - 1|^b)      (quantizers/adaround.py:38-57 under
+ *   autograd; utils/block_recon.py:205-210), then torch.optim.Adam's default update (utils/block_recon.py:108-109,122-125) -- the
+ *   operations of adalog_adaround (backward form), adalog_round_loss_multi's gradients and adalog_adam_multi, in their order.
+ *   HOST arrays of device pointers; gws[t] = dL/dw_sim of layer t or null; ns[t] = rows * inners[t]; gmul null = no regulariser. */
+int adalog_alpha_step_multi(float* const* alphas, const float* const* ws, const float* const* gws, const float* const* scales,
+                            const float* const* zps, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* ns,
+                            const int64_t* inners, const int* n_bits, int count, float lr, const float* lr_dev, float beta1, float beta2,
+                            float eps, float* step_dev, float b, const float* b_dev, float weight, const float* gmul, void* stream);
 /* One Adam step (torch.optim.Adam defaults; reference utils/block_recon.py:108-109,122-125) for `count` <= 16 fp32 tensors in ONE
  *   launch:  m = m + (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t =
  *   step_dev[0] + 1; step_dev[0] is advanced by one.  params / grads / exp_avg / exp_avg_sq / ns are HOST arrays (device

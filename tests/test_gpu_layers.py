@@ -142,3 +142,69 @@ def test_brecq_block_converges_at_reference_length():
     except OSError:
         pass
     assert r["mse_after"] < r["mse_before"], r
+
+
+def test_brecq_one_launch_alpha_update_is_bit_identical(monkeypatch):
+    """The captured BRECQ iteration updates AdaRound's alpha with ONE launch (adalog_alpha_step_multi: gradient through w_sim,
+    the regulariser's gradient and the Adam step).  It performs autograd's operations in autograd's order: a block trained with it
+    ends bit-identical -- alpha, activation scales, Adam state -- to the block trained with the per-layer backward launches and
+    the optimiser's own launch (ADALOG_BRECQ_ALPHA_STEP=0); and the launch is actually taken."""
+    import copy
+    import importlib.util
+    import os
+    from adalog_amd import backend
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import VisionTransformer
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    backend.set_backend(None)
+    be = backend.get()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cfg4s", os.path.join(root, "configs", "4bit.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cfg = mod.Config()
+    cfg.search_round, cfg.steps = 1, 2
+    calls = [0]
+    orig = be.alpha_step_multi
+
+    def spy(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(be, "alpha_step_multi", spy)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ADALOG_BRECQ_ALPHA_STEP", mode)
+        torch.manual_seed(3)
+        model = VisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=1, num_heads=2, num_classes=16).eval()
+        for p_ in model.parameters():
+            p_.data.mul_(6.0)
+        model.to(DEV)
+        full = copy.deepcopy(model)
+        x = torch.randn(16, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(DEV)
+        loader = [(x[:8], None), (x[8:], None)]
+        model = wrap_modules_in_net(model, cfg, reparam=True)
+        QuantCalibrator(model, loader).batching_quant_calib()
+        model = wrap_reparamed_modules_in_net(model)
+        rec = BlockReconstructor(model, full, loader)
+        name = "blocks.0"
+        block, fblock = rec.blocks[name], rec.full_blocks[name]
+        rec.init_block_raw_data(block, fblock, name, torch.device(DEV))
+        n0 = calls[0]
+        got = {}
+
+        def hook(it, loss_func, block=block, got=got):
+            if it == 40:
+                torch.cuda.synchronize()
+                for n_, m_ in block.named_modules():
+                    if hasattr(m_, "w_quantizer") and hasattr(m_.w_quantizer, "alpha"):
+                        got[n_ + ".alpha"] = m_.w_quantizer.alpha.detach().clone()
+                    if hasattr(m_, "a_quantizer") and hasattr(m_.a_quantizer, "scale"):
+                        got[n_ + ".a_scale"] = m_.a_quantizer.scale.detach().clone()
+        rec.iter_hook = hook
+        rec.reconstruct_single_block(name, block, torch.device(DEV), batch_size=8, iters=40, quant_act=True)
+        out[mode] = (got, calls[0] - n0)
+    assert out["0"][1] == 0 and out["1"][1] >= 1, (out["0"][1], out["1"][1])
+    assert out["0"][0].keys() == out["1"][0].keys() and len(out["0"][0]) >= 6
+    for k in out["0"][0]:
+        assert torch.equal(out["0"][0][k], out["1"][0][k]), k
+
