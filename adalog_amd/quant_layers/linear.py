@@ -37,6 +37,7 @@ MAX_PACK_BYTES = int(os.environ.get('ADALOG_MAX_PACK_GIB', '8')) << 30
 # int -> float conversion per output (K <= 384: 256-column slabs; K <= 768: 128-column slabs).  Weight searches gain 10-20 %,
 # activation searches (row scale in the epilogue) 2-4 % -- in round 1 the latter lost 4 %, the compiler spilled there
 FP8_WEIGHT_SEARCH_MAX_K = int(os.environ.get('ADALOG_FP8_WEIGHT_MAX_K', '768'))
+FIXED_GRID_ONLY = os.environ.get('ADALOG_FIXED_GRID_ONLY', '1') != '0'   # fp8 decided by the fixed operand's quantiser alone (_int_dt)
 # self-MSE searches scored from the sorted tensor (csrc/sorted_score.hip); 0 = one pass over the tensor per step (round 1/2)
 # uniform activation searches: candidate operand generated in the slab kernel (1) or packed to HBM first (0, rounds 1-2)
 GEN_ACT_SEARCH = os.environ.get('ADALOG_GEN_ACT', '1') != '0'
@@ -200,10 +201,15 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         self.a_quantizer.inited = True
         self.a_quantizer._zp_on_grid = True
 
-    def _int_dt(self, rows, prefer_fp8=False):
-        """Storage type of the integer operand pair of an output-based search over `rows` candidate rows."""
+    def _int_dt(self, rows, prefer_fp8=False, fixed=None):
+        """Storage type of the integer operand pair of an output-based search over `rows` candidate rows.  fp8 needs every
+        zero point inside [0, 2^bits - 1]: the candidates' always are (FPCS grids), so what decides is the quantiser of the FIXED
+        operand (``fixed``: the activation quantiser for a weight search, the weight quantiser for an activation search) -- the
+        searched operand's own current parameters never enter the product.  (Asking both made the first round's weight search of
+        the default schedule, which skips the dead weight self-search, run on int8: 26-39 % slower launches.)"""
         chunk = self._cand_chunk(rows, pad_k(self.in_features, I8))
-        on_grid = getattr(self.w_quantizer, "_zp_on_grid", False) and getattr(self.a_quantizer, "_zp_on_grid", False)
+        qs = (self.w_quantizer, self.a_quantizer) if (fixed is None or not FIXED_GRID_ONLY) else (fixed,)
+        on_grid = all(getattr(q_, "_zp_on_grid", False) for q_ in qs)
         return search.int_operand_dtype(self.w_quantizer.n_bits, self.a_quantizer.n_bits, chunk, on_grid, prefer_fp8)
 
     def _cand_chunk(self, rows, kp_bytes):
@@ -216,7 +222,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         aq = self.a_quantizer
         x3 = self._x2().unsqueeze(0)
         # weight searches of short-K layers run on the slab kernel, where fp8 storage saves the epilogue's conversions
-        dt = self._int_dt(self.out_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K)
+        dt = self._int_dt(self.out_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K, fixed=aq)
         xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, dt)
         return dt, xp, Strided(aq.scale.data.view(-1)), 1.0, None
 
@@ -346,7 +352,8 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_a_self(s, z)
         else:
-            dt = self._int_dt(self.raw_input.numel() // self.in_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K)
+            dt = self._int_dt(self.raw_input.numel() // self.in_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K,
+                              fixed=self.w_quantizer)
             wp = self._pack_w_fixed(dt)
             wp.int_dt = dt
             fn = lambda s, z, t: self._score_a(wp, s, z, defer=True)
