@@ -524,6 +524,69 @@ __global__ __launch_bounds__(256) void k_uniform_int(const float* __restrict__ x
     }
 }
 
+// softmax(x * scale) over the last dim and its gradient, one pass each (an attention block's `attn * scale` + softmax under
+// autograd is four passes: reference utils/wrap_net.py:26-27).  A wave owns a row of n <= 1024 values (lane l: elements l, l + 64,
+// ...).  Forward as ATen evaluates it: t = fl(x * scale), m = max t, e = exp(t - m), y = e / sum e (fp32 sums, accurate expf).
+// Backward: gx = scale * y * (gy - sum_j gy_j y_j)   (ATen: (gy - sum(gy * y)) * y, then the multiply's gradient).
+constexpr int SM_MAX = 16;                                     // elements per lane at most
+__global__ __launch_bounds__(256) void k_scaled_softmax(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int n,
+                                                        float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * n;
+    float t[SM_MAX];
+    float m = -__builtin_inff();
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int e = lane + 64 * i;
+        t[i] = e < n ? xr[e] * scale : -__builtin_inff();
+        m = fmaxf(m, t[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        t[i] = (lane + 64 * i) < n ? expf(t[i] - m) : 0.0f;
+        sum += t[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    float* yr = y + row * n;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int e = lane + 64 * i;
+        if (e < n) yr[e] = t[i] / sum;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scaled_softmax_bwd(const float* __restrict__ gy, const float* __restrict__ y,
+                                                            float* __restrict__ gx, int64_t rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* gr = gy + row * n;
+    const float* yr = y + row * n;
+    float g[SM_MAX], p[SM_MAX];
+    float dot = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int e = lane + 64 * i;
+        g[i] = e < n ? gr[e] : 0.0f;
+        p[i] = e < n ? yr[e] : 0.0f;
+        dot += g[i] * p[i];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    float* xr = gx + row * n;
+#pragma unroll
+    for (int i = 0; i < SM_MAX; ++i) {
+        const int e = lane + 64 * i;
+        if (e < n) xr[e] = ((g[i] - dot) * p[i]) * scale;
+    }
+}
+
 // The head split of an attention block as ONE pass: x [B][N][P][H][D] (the qkv Linear's output, P = 3) -> y [P][B][H][N][D]
 // (contiguous q, k, v), and the inverse for the gradient.  Autograd's own route is three strided copies forward and a stack +
 // copies backward.  D % 4 == 0; a thread moves one float4; consecutive threads walk D, then H (forward: reads of H * D contiguous
@@ -696,6 +759,24 @@ extern "C" int adalog_permute_heads(const float* src, float* dst, int64_t B, int
     hipLaunchKernelGGL(k_permute_heads, dim3(grid1(B * N * P * H * (D / 4), 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
                        N, P, H, D / 4, inverse);
     ADALOG_LAUNCH_CHECK("adalog_permute_heads");
+    return 0;
+}
+
+extern "C" int adalog_scaled_softmax(const float* x, float* y, int64_t rows, int n, float scale, void* stream) {
+    if (rows == 0 || n == 0) return 0;
+    ADALOG_ARG_CHECK(x && y && rows > 0 && n >= 1 && n <= 64 * SM_MAX, "scaled_softmax: rows of 1 .. 1024 values");
+    hipLaunchKernelGGL(k_scaled_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, n, scale);
+    ADALOG_LAUNCH_CHECK("adalog_scaled_softmax");
+    return 0;
+}
+
+extern "C" int adalog_scaled_softmax_backward(const float* gy, const float* y, float* gx, int64_t rows, int n, float scale,
+                                              void* stream) {
+    if (rows == 0 || n == 0) return 0;
+    ADALOG_ARG_CHECK(gy && y && gx && rows > 0 && n >= 1 && n <= 64 * SM_MAX, "scaled_softmax_backward: rows of 1 .. 1024 values");
+    hipLaunchKernelGGL(k_scaled_softmax_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gy, y, gx, rows, n,
+                       scale);
+    ADALOG_LAUNCH_CHECK("adalog_scaled_softmax_backward");
     return 0;
 }
 

@@ -1151,6 +1151,27 @@ def permute_heads(x: torch.Tensor, P: int, H: int, inverse: bool = False) -> tor
     return out
 
 
+def scaled_softmax(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """softmax(x * scale, dim=-1) in one pass (rows of <= 1024 values)."""
+    x = _f32c(x, "x")
+    y = torch.empty_like(x)
+    n = x.shape[-1]
+    rc = _lib.load().adalog_scaled_softmax(x.data_ptr(), y.data_ptr(), x.numel() // max(n, 1), n, float(scale), _stream())
+    _lib.check(rc, "adalog_scaled_softmax")
+    return y
+
+
+def scaled_softmax_backward(gy: torch.Tensor, y: torch.Tensor, scale: float) -> torch.Tensor:
+    """d/dx of softmax(x * scale) given y = its output: scale * y * (gy - sum(gy * y))."""
+    gy, y = _f32c(gy, "gy"), _f32c(y, "y")
+    gx = torch.empty_like(y)
+    n = y.shape[-1]
+    rc = _lib.load().adalog_scaled_softmax_backward(gy.data_ptr(), y.data_ptr(), gx.data_ptr(), y.numel() // max(n, 1), n, float(scale),
+                                                   _stream())
+    _lib.check(rc, "adalog_scaled_softmax_backward")
+    return gx
+
+
 def merge_heads(parts, B: int, N: int, H: int, D: int) -> torch.Tensor:
     """The P <= 4 tensors [B, H, N, D] (None = zeros) -> [B, N, P*H*D]: the gradient of permute_heads from its parts' gradients."""
     P = len(parts)

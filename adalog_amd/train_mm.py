@@ -30,6 +30,7 @@ HEADS_LAST = os.environ.get("ADALOG_BRECQ_HEADS_LAST", "1") != "0"        # soft
 # forward products read the weights K-major (from a transposed copy made once per iteration): with BOTH operands K-contiguous every
 # LDS-DMA request of a 16-element K-step fetches half cache lines -- measured 13-24 % slower than any form with one K-major operand
 W_KMAJOR = os.environ.get("ADALOG_BRECQ_WT", "1") != "0"
+FUSED_SOFTMAX = os.environ.get("ADALOG_BRECQ_SOFTMAX", "1") != "0"         # attn * scale + softmax as one pass each way
 INT_ACT = os.environ.get("ADALOG_BRECQ_INT_ACT", "1") != "0"            # integer activation operand (0: s_a * x_int as fp32)
 
 
@@ -183,6 +184,31 @@ def split_heads(x, P, H):
             and D % 4 == 0 and P <= 4 and hasattr(backend.get(), "merge_heads")):
         return _SplitHeadsFn.apply(x.contiguous(), P, H)
     return x.reshape(B, N, P, H, D).permute(2, 0, 3, 1, 4).unbind(0)   # one backward node (a stack) instead of P zero-filled selects
+
+
+class _ScaledSoftmaxFn(torch.autograd.Function):
+    """softmax(x * scale, dim=-1): one pass forward, one backward (adalog_scaled_softmax[_backward]) instead of ATen's multiply,
+    softmax, softmax backward and the multiply's gradient."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        y = backend.get().scaled_softmax(x, scale)
+        ctx.save_for_backward(y)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return backend.get().scaled_softmax_backward(gy.contiguous(), y, ctx.scale), None
+
+
+def scaled_softmax(x, scale):
+    """(x * scale).softmax(dim=-1)  (reference utils/wrap_net.py:26-27); fused inside a BRECQ iteration on the GPU."""
+    if (ENABLED and FUSED_SOFTMAX and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()
+            and x.shape[-1] <= 1024 and hasattr(backend.get(), "scaled_softmax")):
+        return _ScaledSoftmaxFn.apply(x.contiguous(), float(scale))
+    return (x * scale).softmax(dim=-1)
 
 
 class _MatmulFn(torch.autograd.Function):

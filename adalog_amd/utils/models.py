@@ -67,8 +67,7 @@ class Attention(nn.Module):
         x = self.qkv(x)
         q, k, v = train_mm.split_heads(x, 3, self.num_heads)
         q, k = self.q_norm(q), self.k_norm(k)
-        attn = self.matmul1(q, k.transpose(-2, -1)) * self.scale
-        attn = attn.softmax(dim=-1)
+        attn = train_mm.scaled_softmax(self.matmul1(q, k.transpose(-2, -1)), self.scale)
         attn = self.attn_drop(attn)
         x = self.matmul2(attn, v)
         x = x.transpose(1, 2).reshape(B, N, C)

@@ -340,6 +340,11 @@ int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, 
  *   quantizers/uniform.py:29-35, i.e. the fake-quantised activation before its scale -- the integer operand of adalog_gemm_f32x3. */
 int adalog_uniform_int_f32(const float* x, float* y, int64_t n, const float* scale, const float* zero_point, int n_bits,
                            void* stream);
+/* y = softmax(x * scale) over rows of n <= 1024 values, and gx = scale * y * (gy - sum_j gy_j y_j): the `attn * scale` +
+ *   softmax of an attention block (reference utils/wrap_net.py:26-27) and its autograd transposes as one pass each way inside a
+ *   BRECQ iteration (ATen's order of operations: fl(x * scale), max, exp, fp32 sum, divide). */
+int adalog_scaled_softmax(const float* x, float* y, int64_t rows, int n, float scale, void* stream);
+int adalog_scaled_softmax_backward(const float* gy, const float* y, float* gx, int64_t rows, int n, float scale, void* stream);
 /* Head split of an attention block in one pass: src [B][N][P][H][D] (the qkv Linear's output, P = 3) -> dst [P][B][H][N][D]
  *   (contiguous q, k, v); inverse != 0: the other way (the gradient).  Replaces the reshape / permute / unbind copies of the
  *   reference's attention forward (utils/wrap_net.py:19-33) and their autograd transposes in a BRECQ iteration.  D % 4 == 0. */

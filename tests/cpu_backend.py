@@ -580,6 +580,14 @@ def permute_heads(x, P, H, inverse=False):
     return x.reshape(B, N, P, H, C // (P * H)).permute(2, 0, 3, 1, 4).contiguous()
 
 
+def scaled_softmax(x, scale):
+    return torch.softmax(x * scale, dim=-1)
+
+
+def scaled_softmax_backward(gy, y, scale):
+    return ((gy - (gy * y).sum(-1, keepdim=True)) * y) * scale
+
+
 def merge_heads(parts, B, N, H, D):
     """Specification of adalog_merge_heads."""
     ps = [torch.zeros(B, H, N, D) if t is None else t for t in parts]

@@ -1554,3 +1554,25 @@ def test_adaround_t_writes_both_orientations(ops, rows, inner):
         y, yt = ops.adaround_t(d(w), d(al), d(s_), d(z_), 4, soft)
         assert torch.equal(y, want) and torch.equal(yt, want.t().contiguous())
 
+
+@pytest.mark.parametrize("shape", [(32, 6, 197, 197), (7, 3, 49, 49), (5, 1000), (3, 2, 1)])
+def test_scaled_softmax_forward_and_backward(ops, shape):
+    """adalog_scaled_softmax / _backward against ATen's (x * scale).softmax(-1) and its autograd gradient (bar 2e-6 of the
+    largest value: the two evaluate exp with different routines)."""
+    from adalog_amd import train_mm
+    gen = g(9700 + shape[-1])
+    x = (torch.randn(*shape, generator=gen) * 3.0).to(DEV)
+    gy = torch.randn(*shape, generator=gen).to(DEV)
+    scale = 0.125
+    xr = x.clone().requires_grad_(True)
+    want = (xr * scale).softmax(dim=-1)
+    want.backward(gy)
+    y = ops.scaled_softmax(x, scale)
+    assert rel_err(y.cpu(), want.detach().cpu()) <= 2e-6
+    gx = ops.scaled_softmax_backward(gy, y, scale)
+    assert rel_err(gx.cpu(), xr.grad.cpu()) <= 4e-6
+    x2 = x.clone().requires_grad_(True)
+    y2 = train_mm.scaled_softmax(x2, scale)
+    y2.backward(gy)
+    assert torch.equal(y2.detach(), y) and torch.equal(x2.grad, gx)
+
