@@ -62,6 +62,9 @@ SIGNATURES = {
     "adalog_uniform_int_f32": (i32, [p, p, i64, p, p, i32, p]),
     "adalog_permute_heads": (i32, [p, p, i64, i64, i32, i32, i32, i32, p]),
     "adalog_merge_heads": (i32, [p, p, p, p, p, i64, i64, i32, i32, i32, p]),
+    "adalog_qkv_quant_chunks": (i32, [i64, i64, i32]),
+    "adalog_qkv_split_quant": (i32, [p, p, p, p, i64, i64, i32, i32, p, p, p, p, p]),
+    "adalog_qkv_merge_quant_backward": (i32, [p, p, p, p, p, i64, i64, i32, i32, p, p, p, p, p, p, p]),
     "adalog_scaled_softmax": (i32, [p, p, i64, i32, f32, p]),
     "adalog_scaled_softmax_backward": (i32, [p, p, p, i64, i32, f32, p]),
     "adalog_uniform_fq_backward_blocks": (i32, [i64, i64, i64]),

@@ -627,6 +627,82 @@ __global__ __launch_bounds__(256) void k_merge_heads(HeadParts src, float* __res
     }
 }
 
+// q, k, v of an attention block split AND fake-quantised in one pass (a BRECQ iteration: the three tensors go straight into the
+// quantisers of the two attention products -- q.k^T's A and B quantiser, softmax.v's B quantiser: asymmetric uniform, per tensor or
+// per head; reference utils/wrap_net.py:21-22 + quant_layers/matmul.py:43-47), and the straight-through gradients the other way:
+//   forward:  y_p[b][h][n][d] = (clamp(rne(x / s) + z, 0, qmax) - z) * s      x = src[b][n][p][h][d], (s, z) = part p, head h
+//   backward: gx = inside ? gy_p : 0  into [B][N][3][H][D];  gscale_p[h] = sum gy_p * ((q - z) - inside * x / s)
+// Same IEEE operations per element as k_uniform_rows / k_uniform_bwd.  grid = (row chunks, 3 * H): a block owns one (part, head)
+// for a chunk of (b, n) rows, 16 rows x D / 4 float4 per pass; D in {32, 64}.  Block partials of the scale gradients go to
+// part[(p * H + h) * nchunks + chunk]; k_param_grad_finish sums them (fp64, fixed order).
+struct QkvQuant {
+    const float* scale[3]; const float* zp[3];
+    int sstride[3];                                            // 1: per head, 0: per tensor
+    float qmax[3];
+};
+template <int D>
+__global__ __launch_bounds__(256) void k_qkv_split_quant(const float* __restrict__ src, float* __restrict__ y0, float* __restrict__ y1,
+                                                         float* __restrict__ y2, int64_t B, int64_t N, int H, QkvQuant q) {
+    constexpr int D4 = D / 4, RPP = 256 / D4;                  // float4 per row, rows per pass
+    const int ph = blockIdx.y, pp = ph / H, h = ph % H;
+    const float s = q.scale[pp][h * q.sstride[pp]], z = rintf(q.zp[pp][h * q.sstride[pp]]), qmax = q.qmax[pp];
+    float* __restrict__ y = pp == 0 ? y0 : (pp == 1 ? y1 : y2);
+    const int d4 = threadIdx.x % D4, rl = threadIdx.x / D4;
+    const int64_t rows = B * N;
+    for (int64_t r = (int64_t)blockIdx.x * RPP + rl; r < rows; r += (int64_t)gridDim.x * RPP) {
+        const int64_t b = r / N, n = r - b * N;
+        const float4 v = reinterpret_cast<const float4*>(src + ((r * 3 + pp) * H + h) * D)[d4];
+        const float q0 = fminf(fmaxf(rintf(v.x / s) + z, 0.0f), qmax), q1 = fminf(fmaxf(rintf(v.y / s) + z, 0.0f), qmax);
+        const float q2 = fminf(fmaxf(rintf(v.z / s) + z, 0.0f), qmax), q3 = fminf(fmaxf(rintf(v.w / s) + z, 0.0f), qmax);
+        reinterpret_cast<float4*>(y + ((b * H + h) * N + n) * D)[d4] = make_float4((q0 - z) * s, (q1 - z) * s, (q2 - z) * s, (q3 - z) * s);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_qkv_merge_quant_bwd(const float* __restrict__ g0, const float* __restrict__ g1,
+                                                             const float* __restrict__ g2, const float* __restrict__ src,
+                                                             float* __restrict__ gx, int64_t B, int64_t N, int H, QkvQuant q,
+                                                             float* __restrict__ part) {
+    __shared__ float sm[4];
+    constexpr int D4 = D / 4, RPP = 256 / D4;
+    const int ph = blockIdx.y, pp = ph / H, h = ph % H;
+    const float s = q.scale[pp][h * q.sstride[pp]], z = rintf(q.zp[pp][h * q.sstride[pp]]), qmax = q.qmax[pp];
+    const float* __restrict__ gy = pp == 0 ? g0 : (pp == 1 ? g1 : g2);
+    const int d4 = threadIdx.x % D4, rl = threadIdx.x / D4;
+    const int64_t rows = B * N;
+    float as = 0.0f, az = 0.0f;
+    for (int64_t r = (int64_t)blockIdx.x * RPP + rl; r < rows; r += (int64_t)gridDim.x * RPP) {
+        const int64_t b = r / N, n = r - b * N;
+        const int64_t xo = ((r * 3 + pp) * H + h) * D;
+        const float4 xv = reinterpret_cast<const float4*>(src + xo)[d4];
+        const float4 g = gy ? reinterpret_cast<const float4*>(gy + ((b * H + h) * N + n) * D)[d4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float4 o;
+        uniform_bwd_one(xv.x, g.x, s, z, 0.0f, qmax, o.x, as, az);
+        uniform_bwd_one(xv.y, g.y, s, z, 0.0f, qmax, o.y, as, az);
+        uniform_bwd_one(xv.z, g.z, s, z, 0.0f, qmax, o.z, as, az);
+        uniform_bwd_one(xv.w, g.w, s, z, 0.0f, qmax, o.w, as, az);
+        if (gx) reinterpret_cast<float4*>(gx + xo)[d4] = o;
+    }
+    if (part) {
+        const float ts = block_sum(as, sm);
+        if (threadIdx.x == 0) part[(int64_t)ph * gridDim.x + blockIdx.x] = ts;
+    }
+}
+
+// scale gradients of the three parts from the block partials of k_qkv_merge_quant_bwd (fp64, fixed order): block = (part, head)
+struct QkvGrads { float* g[3]; int per_head[3]; };
+__global__ __launch_bounds__(64) void k_qkv_grad_finish(const float* __restrict__ part, int H, int nch, QkvGrads o) {
+    const int pp = blockIdx.x / H, h = blockIdx.x % H, lane = threadIdx.x;
+    if (!o.g[pp] || (!o.per_head[pp] && h != 0)) return;
+    const float* src = part + ((int64_t)pp * H + (o.per_head[pp] ? h : 0)) * nch;
+    const int64_t cnt = o.per_head[pp] ? nch : (int64_t)H * nch;
+    double acc = 0.0;
+    for (int64_t i = lane; i < cnt; i += 64) acc += (double)src[i];
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) acc += __shfl_xor(acc, sft);
+    if (lane == 0) o.g[pp][o.per_head[pp] ? h : 0] = (float)acc;
+}
+
 // Ticket counters for the "last block finishes" reductions: zeroed device words, handed out round-robin at enqueue time (the
 // launch's last block puts its words back to zero).  A word may be re-issued only to a launch that runs AFTER the one holding
 // it, which stream order guarantees on ONE stream; launches enqueued far ahead on two streams (the calibrator's lanes) could
@@ -759,6 +835,61 @@ extern "C" int adalog_permute_heads(const float* src, float* dst, int64_t B, int
     hipLaunchKernelGGL(k_permute_heads, dim3(grid1(B * N * P * H * (D / 4), 8192)), dim3(256), 0, (hipStream_t)stream, src, dst, B,
                        N, P, H, D / 4, inverse);
     ADALOG_LAUNCH_CHECK("adalog_permute_heads");
+    return 0;
+}
+
+static int qkv_fill(QkvQuant& q, const float* const* scales, const float* const* zps, const int* per_head, const int* n_bits) {
+    for (int p = 0; p < 3; ++p) {
+        if (!scales[p] || !zps[p] || n_bits[p] < 1 || n_bits[p] > 8) return 1;
+        q.scale[p] = scales[p]; q.zp[p] = zps[p]; q.sstride[p] = per_head[p] ? 1 : 0; q.qmax[p] = (float)((1 << n_bits[p]) - 1);
+    }
+    return 0;
+}
+static int qkv_chunks(int64_t rows, int D) {
+    const int rpp = 256 / (D / 4);
+    int64_t c = (rows + (int64_t)rpp * 4 - 1) / ((int64_t)rpp * 4);          // >= 4 passes per block
+    return (int)(c < 1 ? 1 : c > 512 ? 512 : c);
+}
+// Blocks per (part, head) of adalog_qkv_merge_quant_backward: its workspace holds 3 * H * that many floats.
+extern "C" int adalog_qkv_quant_chunks(int64_t B, int64_t N, int D) { return (D == 32 || D == 64) ? qkv_chunks(B * N, D) : 0; }
+
+// src [B][N][3][H][D] -> y0, y1, y2 [B][H][N][D]: split and asymmetric uniform fake-quant (part p with scales[p] / zps[p]:
+// H values when per_head[p], else one).  HOST arrays of 3 pointers / flags.  D = 32 or 64.
+extern "C" int adalog_qkv_split_quant(const float* src, float* y0, float* y1, float* y2, int64_t B, int64_t N, int H, int D,
+                                      const float* const* scales, const float* const* zps, const int* per_head, const int* n_bits,
+                                      void* stream) {
+    if (B * N * H == 0) return 0;
+    ADALOG_ARG_CHECK(src && y0 && y1 && y2 && scales && zps && per_head && n_bits && H >= 1 && (D == 32 || D == 64), "qkv_split_quant: bad arguments");
+    QkvQuant q;
+    ADALOG_ARG_CHECK(qkv_fill(q, scales, zps, per_head, n_bits) == 0, "qkv_split_quant: bad quantiser parameters");
+    const dim3 grid((unsigned)qkv_chunks(B * N, D), (unsigned)(3 * H));
+    if (D == 64) hipLaunchKernelGGL(k_qkv_split_quant<64>, grid, dim3(256), 0, (hipStream_t)stream, src, y0, y1, y2, B, N, H, q);
+    else hipLaunchKernelGGL(k_qkv_split_quant<32>, grid, dim3(256), 0, (hipStream_t)stream, src, y0, y1, y2, B, N, H, q);
+    ADALOG_LAUNCH_CHECK("adalog_qkv_split_quant");
+    return 0;
+}
+
+// The gradients of adalog_qkv_split_quant: g0, g1, g2 [B][H][N][D] (null = zeros), src as above -> gx [B][N][3][H][D] (optional) and
+// gscales[p] ([H] or [1], optional per part).  workspace: 3 * H * adalog_qkv_quant_chunks(B, N, D) floats.
+extern "C" int adalog_qkv_merge_quant_backward(const float* g0, const float* g1, const float* g2, const float* src, float* gx,
+                                               int64_t B, int64_t N, int H, int D, const float* const* scales,
+                                               const float* const* zps, const int* per_head, const int* n_bits,
+                                               float* const* gscales, float* workspace, void* stream) {
+    if (B * N * H == 0) return 0;
+    ADALOG_ARG_CHECK(src && scales && zps && per_head && n_bits && gscales && workspace && H >= 1 && (D == 32 || D == 64),
+                     "qkv_merge_quant_backward: bad arguments");
+    QkvQuant q;
+    ADALOG_ARG_CHECK(qkv_fill(q, scales, zps, per_head, n_bits) == 0, "qkv_merge_quant_backward: bad quantiser parameters");
+    const int nch = qkv_chunks(B * N, D);
+    const dim3 grid((unsigned)nch, (unsigned)(3 * H));
+    hipStream_t st = (hipStream_t)stream;
+    if (D == 64) hipLaunchKernelGGL(k_qkv_merge_quant_bwd<64>, grid, dim3(256), 0, st, g0, g1, g2, src, gx, B, N, H, q, workspace);
+    else hipLaunchKernelGGL(k_qkv_merge_quant_bwd<32>, grid, dim3(256), 0, st, g0, g1, g2, src, gx, B, N, H, q, workspace);
+    // the scale gradients: part p per head -> H sums of nch partials; per tensor -> one sum of H * nch partials
+    QkvGrads og;
+    for (int p = 0; p < 3; ++p) { og.g[p] = gscales[p]; og.per_head[p] = per_head[p]; }
+    hipLaunchKernelGGL(k_qkv_grad_finish, dim3((unsigned)(3 * H)), dim3(64), 0, st, workspace, H, nch, og);
+    ADALOG_LAUNCH_CHECK("adalog_qkv_merge_quant_backward");
     return 0;
 }
 

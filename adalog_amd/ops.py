@@ -1151,6 +1151,55 @@ def permute_heads(x: torch.Tensor, P: int, H: int, inverse: bool = False) -> tor
     return out
 
 
+def _qkv_params(scales, zps, n_bits, H):
+    import ctypes
+    PA, IA = ctypes.c_void_p * 3, ctypes.c_int * 3
+    sc = [_f32c(t.reshape(-1), "scale") for t in scales]
+    zp = [_f32c(t.reshape(-1), "zero_point") for t in zps]
+    for a_, b_ in zip(sc, zp):
+        if a_.numel() not in (1, H) or b_.numel() != a_.numel():
+            raise _lib.AdalogHipError("qkv quantisers: one (scale, zero point) per tensor or per head")
+    ph = [1 if t.numel() == H and H > 1 else 0 for t in sc]
+    return sc, zp, PA(*[t.data_ptr() for t in sc]), PA(*[t.data_ptr() for t in zp]), IA(*ph), IA(*[int(b) for b in n_bits])
+
+
+def qkv_split_quant(x: torch.Tensor, H: int, scales, zps, n_bits):
+    """x [B, N, 3*H*D] -> (q_sim, k_sim, v_sim) [B, H, N, D]: the head split and the three asymmetric uniform fake-quantisations
+    (per tensor or per head) in one pass.  D = 32 or 64."""
+    x = _f32c(x, "x")
+    B, N, C = x.shape
+    D = C // (3 * H)
+    if C != 3 * H * D or D not in (32, 64):
+        raise _lib.AdalogHipError("qkv_split_quant: head dimension 32 or 64")
+    ys = [torch.empty((B, H, N, D), dtype=torch.float32, device=x.device) for _ in range(3)]
+    sc, zp, psc, pzp, ph, nb = _qkv_params(scales, zps, n_bits, H)
+    rc = _lib.load().adalog_qkv_split_quant(x.data_ptr(), ys[0].data_ptr(), ys[1].data_ptr(), ys[2].data_ptr(), B, N, int(H), int(D), psc,
+                                           pzp, ph, nb, _stream())
+    _lib.check(rc, "adalog_qkv_split_quant")
+    return tuple(ys)
+
+
+def qkv_merge_quant_backward(gys, x: torch.Tensor, H: int, scales, zps, n_bits, want_gx: bool = True):
+    """Gradients of qkv_split_quant: gys = 3 tensors [B, H, N, D] (None = zeros) -> (gx [B, N, 3*H*D] | None, [gscale_p] shaped like
+    scales[p])."""
+    import ctypes
+    x = _f32c(x, "x")
+    B, N, C = x.shape
+    D = C // (3 * H)
+    gs = [None if g_ is None else _f32c(g_, "gy") for g_ in gys]
+    lib = _lib.load()
+    sc, zp, psc, pzp, ph, nb = _qkv_params(scales, zps, n_bits, H)
+    gx = torch.empty_like(x) if want_gx else None
+    gsc = [torch.empty_like(t) for t in sc]
+    nch = int(lib.adalog_qkv_quant_chunks(B, N, int(D)))
+    ws = torch.empty(3 * H * nch, dtype=torch.float32, device=x.device)
+    PA = ctypes.c_void_p * 3
+    rc = lib.adalog_qkv_merge_quant_backward(_ptr(gs[0]), _ptr(gs[1]), _ptr(gs[2]), x.data_ptr(), _ptr(gx), B, N, int(H), int(D), psc, pzp,
+                                             ph, nb, PA(*[t.data_ptr() for t in gsc]), ws.data_ptr(), _stream())
+    _lib.check(rc, "adalog_qkv_merge_quant_backward")
+    return gx, [g_.view_as(s_) for g_, s_ in zip(gsc, scales)]
+
+
 def scaled_softmax(x: torch.Tensor, scale: float) -> torch.Tensor:
     """softmax(x * scale, dim=-1) in one pass (rows of <= 1024 values)."""
     x = _f32c(x, "x")

@@ -40,11 +40,13 @@ class MinMaxQuantMatMul(nn.Module):
         self.tmp_out = None
         self.calibrated = False
 
-    def forward(self, A, B):
+    def forward(self, A, B, a_pre=False, b_pre=False):
+        """a_pre / b_pre (quant_forward only): that operand already went through this module's input quantiser (an attention
+        block quantises q, k, v in the pass that splits them, train_mm.qkv_split_quant)."""
         if self.mode == 'raw':
             return A @ B
         if self.mode == "quant_forward":
-            return self.quant_forward(A, B)
+            return self.quant_forward(A, B, a_pre, b_pre)
         raise NotImplementedError
 
     def quant_input_A(self, x):
@@ -53,9 +55,10 @@ class MinMaxQuantMatMul(nn.Module):
     def quant_input_B(self, x):
         return self.B_quantizer(x)
 
-    def quant_forward(self, A, B):
+    def quant_forward(self, A, B, a_pre=False, b_pre=False):
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
-        a_sim, b_sim = self.quant_input_A(A), self.quant_input_B(B)
+        a_sim = A if a_pre else self.quant_input_A(A)
+        b_sim = B if b_pre else self.quant_input_B(B)
         if a_sim.requires_grad or b_sim.requires_grad:       # a BRECQ iteration: the contractions run on csrc/brecq_gemm.hip
             return train_mm.matmul(a_sim, b_sim, heads_last=getattr(self, 'out_heads_last', False))
         return a_sim @ b_sim
@@ -297,10 +300,10 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
     def _training(self):
         return torch.is_grad_enabled() and (self.A_quantizer.training_mode or self.B_quantizer.training_mode)
 
-    def quant_forward(self, A, B):
+    def quant_forward(self, A, B, a_pre=False, b_pre=False):
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
-        if self._training() or self.A_quantizer.n_bits > 7 or self.B_quantizer.n_bits > 7:
-            return super().quant_forward(A, B)
+        if a_pre or b_pre or self._training() or self.A_quantizer.n_bits > 7 or self.B_quantizer.n_bits > 7:
+            return super().quant_forward(A, B, a_pre, b_pre)
         be = backend.get()
         H = self._heads()
         pg = 1 if H > 1 else 0
@@ -436,10 +439,10 @@ class PostSoftmaxAsymmetricallyBatchingQuantMatMul(AsymmetricallyBatchingQuantMa
         self._bt_c = self._bt_key = None
         return None
 
-    def quant_forward(self, A, B):
+    def quant_forward(self, A, B, a_pre=False, b_pre=False):
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
-        if self._training() or self.A_quantizer.training_mode:
-            return MinMaxQuantMatMul.quant_forward(self, A, B)
+        if a_pre or b_pre or self._training() or self.A_quantizer.training_mode:
+            return MinMaxQuantMatMul.quant_forward(self, A, B, a_pre, b_pre)
         be = backend.get()
         H = self._heads()
         pg = 1 if H > 1 else 0

@@ -30,6 +30,7 @@ HEADS_LAST = os.environ.get("ADALOG_BRECQ_HEADS_LAST", "1") != "0"        # soft
 # forward products read the weights K-major (from a transposed copy made once per iteration): with BOTH operands K-contiguous every
 # LDS-DMA request of a 16-element K-step fetches half cache lines -- measured 13-24 % slower than any form with one K-major operand
 W_KMAJOR = os.environ.get("ADALOG_BRECQ_WT", "1") != "0"
+QKV_FUSED = os.environ.get("ADALOG_BRECQ_QKV_QUANT", "1") != "0"          # q / k / v split + their three quantisers as one pass
 FUSED_SOFTMAX = os.environ.get("ADALOG_BRECQ_SOFTMAX", "1") != "0"         # attn * scale + softmax as one pass each way
 INT_ACT = os.environ.get("ADALOG_BRECQ_INT_ACT", "1") != "0"            # integer activation operand (0: s_a * x_int as fp32)
 
@@ -184,6 +185,50 @@ def split_heads(x, P, H):
             and D % 4 == 0 and P <= 4 and hasattr(backend.get(), "merge_heads")):
         return _SplitHeadsFn.apply(x.contiguous(), P, H)
     return x.reshape(B, N, P, H, D).permute(2, 0, 3, 1, 4).unbind(0)   # one backward node (a stack) instead of P zero-filled selects
+
+
+class _QkvQuantFn(torch.autograd.Function):
+    """x [B, N, 3*H*D] -> (q_sim, k_sim, v_sim) [B, H, N, D]: the head split fused with the three straight-through uniform
+    quantisers that follow it (q.k^T's A and B quantiser, softmax.v's B quantiser): adalog_qkv_split_quant forward,
+    adalog_qkv_merge_quant_backward for the gradient of x and of the three scales."""
+
+    @staticmethod
+    def forward(ctx, x, s0, z0, s1, z1, s2, z2, H, bits):
+        be = backend.get()
+        ctx.save_for_backward(x, s0, z0, s1, z1, s2, z2)
+        ctx.H, ctx.bits = H, bits
+        return be.qkv_split_quant(x, H, [s0, s1, s2], [z0, z1, z2], bits)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        x, s0, z0, s1, z1, s2, z2 = ctx.saved_tensors
+        gx, gs = backend.get().qkv_merge_quant_backward([g0, g1, g2], x, ctx.H, [s0, s1, s2], [z0, z1, z2], ctx.bits,
+                                                        want_gx=ctx.needs_input_grad[0])
+        need = ctx.needs_input_grad
+        return gx, (gs[0] if need[1] else None), None, (gs[1] if need[3] else None), None, (gs[2] if need[5] else None), None, None, None
+
+
+def qkv_split_quant(x, H, mm1, mm2):
+    """The fused route of an attention block inside a BRECQ iteration: q, k, v split from x [B, N, 3*H*D] AND passed through the
+    input quantisers of the two attention products (mm1.A_quantizer for q, mm1.B_quantizer for k -- elementwise per head, so it
+    commutes with the transpose that follows -- and mm2.B_quantizer for v).  -> (q_sim, k_sim, v_sim), or None when the route does
+    not apply (the caller then splits and lets the products quantise their inputs)."""
+    from .quantizers.uniform import UniformQuantizer
+    if not (ENABLED and QKV_FUSED and x.is_cuda and x.dtype == torch.float32 and x.requires_grad and torch.is_grad_enabled()
+            and x.dim() == 3 and hasattr(backend.get(), "qkv_split_quant")):
+        return None
+    D = x.shape[-1] // (3 * H)
+    if x.shape[-1] != 3 * H * D or D not in (32, 64):
+        return None
+    if getattr(mm1, "mode", None) != "quant_forward" or getattr(mm2, "mode", None) != "quant_forward":
+        return None
+    qs = (getattr(mm1, "A_quantizer", None), getattr(mm1, "B_quantizer", None), getattr(mm2, "B_quantizer", None))
+    for q_ in qs:
+        if not (type(q_) is UniformQuantizer and q_.training_mode and q_.inited and not q_.sym and q_.n_bits <= 8
+                and q_.scale.numel() in (1, H) and q_.zero_point.numel() == q_.scale.numel() and not q_.zero_point.requires_grad):
+            return None
+    return _QkvQuantFn.apply(x.contiguous(), qs[0].scale, qs[0].zero_point, qs[1].scale, qs[1].zero_point, qs[2].scale,
+                             qs[2].zero_point, H, tuple(q_.n_bits for q_ in qs))
 
 
 class _ScaledSoftmaxFn(torch.autograd.Function):

@@ -65,11 +65,19 @@ class Attention(nn.Module):
     def forward(self, x):
         B, N, C = x.shape
         x = self.qkv(x)
-        q, k, v = train_mm.split_heads(x, 3, self.num_heads)
-        q, k = self.q_norm(q), self.k_norm(k)
-        attn = train_mm.scaled_softmax(self.matmul1(q, k.transpose(-2, -1)), self.scale)
-        attn = self.attn_drop(attn)
-        x = self.matmul2(attn, v)
+        fused = None
+        if isinstance(self.q_norm, nn.Identity) and isinstance(self.k_norm, nn.Identity):
+            fused = train_mm.qkv_split_quant(x, self.num_heads, self.matmul1, self.matmul2)   # a BRECQ iteration on the GPU
+        if fused is not None:
+            q, k, v = fused                                    # already through the products' input quantisers
+            attn = train_mm.scaled_softmax(self.matmul1(q, k.transpose(-2, -1), a_pre=True, b_pre=True), self.scale)
+            x = self.matmul2(self.attn_drop(attn), v, b_pre=True)
+        else:
+            q, k, v = train_mm.split_heads(x, 3, self.num_heads)
+            q, k = self.q_norm(q), self.k_norm(k)
+            attn = train_mm.scaled_softmax(self.matmul1(q, k.transpose(-2, -1)), self.scale)
+            attn = self.attn_drop(attn)
+            x = self.matmul2(attn, v)
         x = x.transpose(1, 2).reshape(B, N, C)
         x = self.proj(x)
         return self.proj_drop(x)

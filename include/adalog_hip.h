@@ -340,6 +340,19 @@ int adalog_absminmax_cols(const float* x, int64_t rows, int I, int per_channel, 
  *   quantizers/uniform.py:29-35, i.e. the fake-quantised activation before its scale -- the integer operand of adalog_gemm_f32x3. */
 int adalog_uniform_int_f32(const float* x, float* y, int64_t n, const float* scale, const float* zero_point, int n_bits,
                            void* stream);
+/* q, k, v of an attention block split AND fake-quantised in one pass, and the straight-through gradients the other way (a BRECQ
+ *   iteration; reference utils/wrap_net.py:21-22 followed by the input quantisers of the two attention products,
+ *   quant_layers/matmul.py:43-47: asymmetric uniform, per tensor or per head).  src [B][N][3][H][D] -> y0, y1, y2 [B][H][N][D];
+ *   part p uses scales[p] / zps[p] (H values when per_head[p], else one) and n_bits[p]; HOST arrays of three.  D = 32 or 64.
+ *   backward: g0, g1, g2 (null = zeros) -> gx [B][N][3][H][D] (optional) and gscales[p] (optional; [H] or [1]);
+ *   workspace: 3 * H * adalog_qkv_quant_chunks(B, N, D) floats.  Per element the operations of adalog_uniform_fake_quant_f32 /
+ *   adalog_uniform_fq_backward. */
+int adalog_qkv_quant_chunks(int64_t B, int64_t N, int D);
+int adalog_qkv_split_quant(const float* src, float* y0, float* y1, float* y2, int64_t B, int64_t N, int H, int D,
+                           const float* const* scales, const float* const* zps, const int* per_head, const int* n_bits, void* stream);
+int adalog_qkv_merge_quant_backward(const float* g0, const float* g1, const float* g2, const float* src, float* gx, int64_t B,
+                                    int64_t N, int H, int D, const float* const* scales, const float* const* zps, const int* per_head,
+                                    const int* n_bits, float* const* gscales, float* workspace, void* stream);
 /* y = softmax(x * scale) over rows of n <= 1024 values, and gx = scale * y * (gy - sum_j gy_j y_j): the `attn * scale` +
  *   softmax of an attention block (reference utils/wrap_net.py:26-27) and its autograd transposes as one pass each way inside a
  *   BRECQ iteration (ATen's order of operations: fl(x * scale), max, exp, fp32 sum, divide). */

@@ -580,6 +580,43 @@ def permute_heads(x, P, H, inverse=False):
     return x.reshape(B, N, P, H, C // (P * H)).permute(2, 0, 3, 1, 4).contiguous()
 
 
+def qkv_split_quant(x, H, scales, zps, n_bits):
+    """Specification of adalog_qkv_split_quant."""
+    B, N, C = x.shape
+    D = C // (3 * H)
+    parts = x.reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    out = []
+    for p_ in range(3):
+        s_ = scales[p_].reshape(1, -1, 1, 1)
+        z_ = zps[p_].reshape(1, -1, 1, 1)
+        out.append(uniform_fake_quant(parts[p_].contiguous(), s_, z_, n_bits[p_]))
+    return tuple(out)
+
+
+def qkv_merge_quant_backward(gys, x, H, scales, zps, n_bits, want_gx=True):
+    """Specification of adalog_qkv_merge_quant_backward (straight-through gradients, as uniform_fake_quant_backward)."""
+    B, N, C = x.shape
+    D = C // (3 * H)
+    parts = x.reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    gxs, gss = [], []
+    for p_ in range(3):
+        s_ = scales[p_].reshape(1, -1, 1, 1).double()
+        z_ = torch.round(zps[p_].reshape(1, -1, 1, 1)).double()
+        xp = parts[p_].double()
+        g_ = torch.zeros_like(xp) if gys[p_] is None else gys[p_].double()
+        r = (xp.float() / s_.float()).double()
+        t = torch.round(r) + z_
+        qmax = 2 ** n_bits[p_] - 1
+        inside = (t >= 0) & (t <= qmax)
+        q_ = t.clamp(0, qmax)
+        gxs.append(torch.where(inside, g_, torch.zeros_like(g_)).float())
+        gsum = (g_ * ((q_ - z_) - torch.where(inside, r, torch.zeros_like(r))))
+        gs_ = gsum.sum(dim=(0, 2, 3)) if scales[p_].numel() > 1 else gsum.sum().reshape(1)
+        gss.append(gs_.float().view_as(scales[p_]))
+    gx = torch.stack(gxs, 0).permute(1, 3, 0, 2, 4).reshape(B, N, C).contiguous() if want_gx else None
+    return gx, gss
+
+
 def scaled_softmax(x, scale):
     return torch.softmax(x * scale, dim=-1)
 

@@ -1576,3 +1576,38 @@ def test_scaled_softmax_forward_and_backward(ops, shape):
     y2.backward(gy)
     assert torch.equal(y2.detach(), y) and torch.equal(x2.grad, gx)
 
+
+@pytest.mark.parametrize("shape", [(32, 197, 6, 64, 4), (8, 49, 4, 32, 3), (2, 7, 1, 32, 6)])
+def test_qkv_split_quant_matches_the_separate_route(ops, shape):
+    """adalog_qkv_split_quant / adalog_qkv_merge_quant_backward against the head split followed by three uniform straight-through
+    quantisers (per head for q and k, per tensor for v): values and dL/dx bit-equal (same IEEE operations per element), the scale
+    gradients to 1e-5 (different partial-sum order)."""
+    B, N, H, D, bits = shape
+    gen = g(9900 + B + N)
+    x = (torch.randn(B, N, 3 * H * D, generator=gen) * 1.5).to(DEV)
+    qmax = 2 ** bits - 1
+    scales = [(torch.rand(1, H, 1, 1, generator=gen) * 0.2 + 0.2).to(DEV), (torch.rand(1, H, 1, 1, generator=gen) * 0.2 + 0.2).to(DEV),
+              (torch.rand(1, 1, 1, 1, generator=gen) * 0.2 + 0.2).to(DEV)]
+    zps = [torch.randint(1, qmax, (1, H, 1, 1), generator=gen).float().to(DEV), torch.randint(1, qmax, (1, H, 1, 1), generator=gen).float().to(DEV),
+           torch.randint(1, qmax, (1, 1, 1, 1), generator=gen).float().to(DEV)]
+    nb = (bits, bits, bits)
+    ys = ops.qkv_split_quant(x, H, scales, zps, nb)
+    parts = x.reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4)
+    gys = [torch.randn(B, H, N, D, generator=gen).to(DEV) for _ in range(3)]
+    gx, gs = ops.qkv_merge_quant_backward(gys, x, H, scales, zps, nb)
+    gx_want = []
+    for p_ in range(3):
+        xp = parts[p_].contiguous()
+        want = ops.uniform_fake_quant(xp, scales[p_], zps[p_], bits)
+        assert torch.equal(ys[p_], want), p_
+        wgx, wgs, _ = ops.uniform_fake_quant_backward(gys[p_], xp, scales[p_], zps[p_], bits, False, True, False)
+        gx_want.append(wgx)
+        assert rel_err(gs[p_].cpu().double(), wgs.cpu().double()) <= 1e-5, p_
+    gx_ref = torch.stack(gx_want, 0).permute(1, 3, 0, 2, 4).reshape(B, N, 3 * H * D)
+    assert torch.equal(gx, gx_ref)
+    cb_y = CB.qkv_split_quant(x.cpu(), H, [t.cpu() for t in scales], [t.cpu() for t in zps], nb)
+    for p_ in range(3):
+        assert torch.equal(ys[p_].cpu(), cb_y[p_])
+    gx2, gs2 = ops.qkv_merge_quant_backward([gys[0], None, gys[2]], x, H, scales, zps, nb)      # a part without gradient
+    assert torch.equal(gx2.reshape(B, N, 3, H, D)[:, :, 1], torch.zeros(B, N, H, D, device=DEV)) and float(gs2[1].abs().max()) == 0.0
+

@@ -144,6 +144,81 @@ def test_brecq_block_converges_at_reference_length():
     assert r["mse_after"] < r["mse_before"], r
 
 
+def _train_vit_block(monkeypatch, env, iters=40, spy=None):
+    """Calibrates a tiny ViT and trains blocks.0 for `iters` BRECQ iterations under the environment `env`; -> the trained tensors."""
+    import copy
+    import importlib.util
+    import os
+    from adalog_amd import backend, train_mm
+    from adalog_amd.utils.block_recon import BlockReconstructor
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import VisionTransformer
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    backend.set_backend(None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cfg4v", os.path.join(root, "configs", "4bit.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cfg = mod.Config()
+    cfg.search_round, cfg.steps = 1, 2
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(train_mm, "QKV_FUSED", env.get("ADALOG_BRECQ_QKV_QUANT", "1") != "0")
+    monkeypatch.setattr(train_mm, "FUSED_SOFTMAX", env.get("ADALOG_BRECQ_SOFTMAX", "1") != "0")
+    torch.manual_seed(3)
+    model = VisionTransformer(img_size=64, patch_size=16, embed_dim=64, depth=1, num_heads=2, num_classes=16).eval()
+    for p_ in model.parameters():
+        p_.data.mul_(6.0)
+    model.to(DEV)
+    full = copy.deepcopy(model)
+    x = torch.randn(16, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(DEV)
+    loader = [(x[:8], None), (x[8:], None)]
+    model = wrap_modules_in_net(model, cfg, reparam=True)
+    QuantCalibrator(model, loader).batching_quant_calib()
+    model = wrap_reparamed_modules_in_net(model)
+    rec = BlockReconstructor(model, full, loader)
+    name = "blocks.0"
+    block, fblock = rec.blocks[name], rec.full_blocks[name]
+    rec.init_block_raw_data(block, fblock, name, torch.device(DEV))
+    got = {}
+
+    def hook(it, loss_func):
+        if it == iters:
+            torch.cuda.synchronize()
+            for n_, m_ in block.named_modules():
+                if hasattr(m_, "w_quantizer") and hasattr(m_.w_quantizer, "alpha"):
+                    got[n_ + ".alpha"] = m_.w_quantizer.alpha.detach().clone()
+                for qn in ("a_quantizer", "A_quantizer", "B_quantizer"):
+                    if hasattr(m_, qn) and hasattr(getattr(m_, qn), "scale"):
+                        got[n_ + "." + qn + ".scale"] = getattr(m_, qn).scale.detach().clone()
+    rec.iter_hook = hook
+    rec.reconstruct_single_block(name, block, torch.device(DEV), batch_size=8, iters=iters, quant_act=True)
+    return got
+
+
+def test_brecq_fused_attention_routes_train_the_same_block(monkeypatch):
+    """The fused routes of an attention block inside a BRECQ iteration -- q / k / v split together with their three quantisers
+    (adalog_qkv_split_quant) and attn * scale + softmax in one pass (adalog_scaled_softmax) -- train the block the separate
+    launches train: after 20 iterations every alpha and every activation scale within 1e-3 (values and dL/dx are bit-equal per
+    launch; the scale gradients are summed in a different order and exp is evaluated by a different routine)."""
+    from adalog_amd import backend
+    be = backend.get()
+    calls = [0]
+    orig = be.qkv_split_quant
+
+    def spy(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(be, "qkv_split_quant", spy)
+    base = _train_vit_block(monkeypatch, {"ADALOG_BRECQ_QKV_QUANT": "0", "ADALOG_BRECQ_SOFTMAX": "0"}, iters=20)
+    assert calls[0] == 0
+    fused = _train_vit_block(monkeypatch, {"ADALOG_BRECQ_QKV_QUANT": "1", "ADALOG_BRECQ_SOFTMAX": "1"}, iters=20)
+    assert calls[0] >= 1
+    assert base.keys() == fused.keys() and len(base) >= 10
+    for k in base:
+        ref = base[k].abs().max().clamp(min=1e-12)
+        assert float((base[k] - fused[k]).abs().max() / ref) <= 1e-3, k
+
+
 def test_brecq_one_launch_alpha_update_is_bit_identical(monkeypatch):
     """The captured BRECQ iteration updates AdaRound's alpha with ONE launch (adalog_alpha_step_multi: gradient through w_sim,
     the regulariser's gradient and the Adam step).  It performs autograd's operations in autograd's order: a block trained with it
