@@ -72,10 +72,10 @@ SIGNATURES = {
     "adalog_log_fq_backward": (i32, [p, p, p, p, i64, p, p, i32, p, i32, p, p, p]),
     "adalog_adaround": (i32, [p, p, p, p, i64, i64, p, p, i32, i32, i32, p]),
     "adalog_adaround_t": (i32, [p, p, p, p, i64, i64, p, p, i32, i32, p]),
-    "adalog_alpha_step_multi": (i32, [p, p, p, p, p, p, p, p, p, p, i32, f32, p, f32, f32, f32, p, f32, p, f32, p, p]),
+    "adalog_alpha_step_multi": (i32, [p, p, p, p, p, p, p, p, p, p, i32, f32, p, f32, f32, f32, p, f32, p, f32, p, p, p]),
     "adalog_round_loss": (i32, [p, i64, f32, p, p, p, f32, p, i32, p, p]),
     "adalog_round_loss_multi_workspace": (i64, [p, i32]),
-    "adalog_round_loss_multi": (i32, [p, p, p, i32, f32, p, f32, p, p, p]),
+    "adalog_round_loss_multi": (i32, [p, p, p, i32, f32, p, f32, p, p, p, p]),
     "adalog_gemm_win_ok": (i32, [i32, i32, i32, i32, i32, i32, i64]),
     "adalog_gemm_score_gen": (i32, [i32, p, i64, i32, i32, i64, i64, i32, i32, p, i64, i64, p, i32, p, i64, i32, p, i64, i64, f32, p, i64,
                               i64, p, i64, p]),

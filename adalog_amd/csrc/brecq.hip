@@ -323,7 +323,7 @@ struct RoundLossMulti {
 
 __global__ __launch_bounds__(256) void k_round_loss_multi(RoundLossMulti a, float b, const float* __restrict__ b_dev,
                                                           float weight, float* __restrict__ part, unsigned int* counter,
-                                                          float* __restrict__ loss) {
+                                                          float* __restrict__ loss, const float* __restrict__ gate) {
     __shared__ float sm[4];
     __shared__ double smd[4];
     if (b_dev) b = b_dev[0];
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void k_round_loss_multi(RoundLossMulti a, floa
     if (threadIdx.x == 0) store_agent(part + blockIdx.x, ts);
     if (last_block_arrives(counter, gridDim.x)) {
         const float v = block_total_f64(part, gridDim.x, smd, (double)weight);
-        if (threadIdx.x == 0) loss[0] = v;
+        if (threadIdx.x == 0) loss[0] = gate ? v * gate[0] : v;      // (gate: the 0 / 1 switch of the warm-up, read on the device)
     }
 }
 
@@ -420,12 +420,12 @@ struct AlphaStepMulti {
 __global__ __launch_bounds__(256) void k_alpha_step_multi(AlphaStepMulti a, float lr, const float* __restrict__ lr_dev, float beta1,
                                                           float beta2, float eps, const float* __restrict__ step_dev, float b,
                                                           const float* __restrict__ b_dev, float weight,
-                                                          const float* __restrict__ gmul) {
+                                                          const float* __restrict__ gmul, const float* __restrict__ gate) {
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
     if (lr_dev) lr = lr_dev[0];
     if (b_dev) b = b_dev[0];
-    const float g_rl = gmul ? gmul[0] : 0.0f;                  // upstream gradient of the regulariser (0: not part of the loss yet)
+    const float g_rl = gmul ? (gate ? gmul[0] * gate[0] : gmul[0]) : 0.0f;      // upstream gradient of the regulariser (times its 0 / 1 gate)
     const float step = step_dev[0] + 1.0f;
     const float bc1 = 1.0f - powf(beta1, step), bc2 = 1.0f - powf(beta2, step);
     const float step_size = lr / bc1, bc2s = sqrtf(bc2);
@@ -529,16 +529,17 @@ __global__ __launch_bounds__(256) void k_uniform_int(const float* __restrict__ x
 // ...).  Forward as ATen evaluates it: t = fl(x * scale), m = max t, e = exp(t - m), y = e / sum e (fp32 sums, accurate expf).
 // Backward: gx = scale * y * (gy - sum_j gy_j y_j)   (ATen: (gy - sum(gy * y)) * y, then the multiply's gradient).
 constexpr int SM_MAX = 16;                                     // elements per lane at most
+template <int NPL>                                          // elements per lane of this instantiation: ceil(n / 64) rounded up
 __global__ __launch_bounds__(256) void k_scaled_softmax(const float* __restrict__ x, float* __restrict__ y, int64_t rows, int n,
                                                         float scale) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + row * n;
-    float t[SM_MAX];
+    float t[NPL];
     float m = -__builtin_inff();
 #pragma unroll
-    for (int i = 0; i < SM_MAX; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         const int e = lane + 64 * i;
         t[i] = e < n ? xr[e] * scale : -__builtin_inff();
         m = fmaxf(m, t[i]);
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void k_scaled_softmax(const float* __restrict_
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     float sum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < SM_MAX; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         t[i] = (lane + 64 * i) < n ? expf(t[i] - m) : 0.0f;
         sum += t[i];
     }
@@ -555,12 +556,13 @@ __global__ __launch_bounds__(256) void k_scaled_softmax(const float* __restrict_
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     float* yr = y + row * n;
 #pragma unroll
-    for (int i = 0; i < SM_MAX; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         const int e = lane + 64 * i;
         if (e < n) yr[e] = t[i] / sum;
     }
 }
 
+template <int NPL>
 __global__ __launch_bounds__(256) void k_scaled_softmax_bwd(const float* __restrict__ gy, const float* __restrict__ y,
                                                             float* __restrict__ gx, int64_t rows, int n, float scale) {
     const int lane = threadIdx.x & 63;
@@ -568,10 +570,10 @@ __global__ __launch_bounds__(256) void k_scaled_softmax_bwd(const float* __restr
     if (row >= rows) return;
     const float* gr = gy + row * n;
     const float* yr = y + row * n;
-    float g[SM_MAX], p[SM_MAX];
+    float g[NPL], p[NPL];
     float dot = 0.0f;
 #pragma unroll
-    for (int i = 0; i < SM_MAX; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         const int e = lane + 64 * i;
         g[i] = e < n ? gr[e] : 0.0f;
         p[i] = e < n ? yr[e] : 0.0f;
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(256) void k_scaled_softmax_bwd(const float* __restr
     for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
     float* xr = gx + row * n;
 #pragma unroll
-    for (int i = 0; i < SM_MAX; ++i) {
+    for (int i = 0; i < NPL; ++i) {
         const int e = lane + 64 * i;
         if (e < n) xr[e] = ((g[i] - dot) * p[i]) * scale;
     }
@@ -896,7 +898,13 @@ extern "C" int adalog_qkv_merge_quant_backward(const float* g0, const float* g1,
 extern "C" int adalog_scaled_softmax(const float* x, float* y, int64_t rows, int n, float scale, void* stream) {
     if (rows == 0 || n == 0) return 0;
     ADALOG_ARG_CHECK(x && y && rows > 0 && n >= 1 && n <= 64 * SM_MAX, "scaled_softmax: rows of 1 .. 1024 values");
-    hipLaunchKernelGGL(k_scaled_softmax, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, n, scale);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 64) hipLaunchKernelGGL(k_scaled_softmax<1>, grid, dim3(256), 0, st, x, y, rows, n, scale);
+    else if (n <= 128) hipLaunchKernelGGL(k_scaled_softmax<2>, grid, dim3(256), 0, st, x, y, rows, n, scale);
+    else if (n <= 256) hipLaunchKernelGGL(k_scaled_softmax<4>, grid, dim3(256), 0, st, x, y, rows, n, scale);
+    else if (n <= 512) hipLaunchKernelGGL(k_scaled_softmax<8>, grid, dim3(256), 0, st, x, y, rows, n, scale);
+    else hipLaunchKernelGGL(k_scaled_softmax<16>, grid, dim3(256), 0, st, x, y, rows, n, scale);
     ADALOG_LAUNCH_CHECK("adalog_scaled_softmax");
     return 0;
 }
@@ -905,8 +913,13 @@ extern "C" int adalog_scaled_softmax_backward(const float* gy, const float* y, f
                                               void* stream) {
     if (rows == 0 || n == 0) return 0;
     ADALOG_ARG_CHECK(gy && y && gx && rows > 0 && n >= 1 && n <= 64 * SM_MAX, "scaled_softmax_backward: rows of 1 .. 1024 values");
-    hipLaunchKernelGGL(k_scaled_softmax_bwd, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, gy, y, gx, rows, n,
-                       scale);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 64) hipLaunchKernelGGL(k_scaled_softmax_bwd<1>, grid, dim3(256), 0, st, gy, y, gx, rows, n, scale);
+    else if (n <= 128) hipLaunchKernelGGL(k_scaled_softmax_bwd<2>, grid, dim3(256), 0, st, gy, y, gx, rows, n, scale);
+    else if (n <= 256) hipLaunchKernelGGL(k_scaled_softmax_bwd<4>, grid, dim3(256), 0, st, gy, y, gx, rows, n, scale);
+    else if (n <= 512) hipLaunchKernelGGL(k_scaled_softmax_bwd<8>, grid, dim3(256), 0, st, gy, y, gx, rows, n, scale);
+    else hipLaunchKernelGGL(k_scaled_softmax_bwd<16>, grid, dim3(256), 0, st, gy, y, gx, rows, n, scale);
     ADALOG_LAUNCH_CHECK("adalog_scaled_softmax_backward");
     return 0;
 }
@@ -1043,7 +1056,8 @@ extern "C" int64_t adalog_round_loss_multi_workspace(const int64_t* ns, int coun
 }
 
 extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const* grads, const int64_t* ns, int count, float b,
-                                       const float* b_dev, float weight, float* loss, float* workspace, void* stream) {
+                                       const float* b_dev, float weight, float* loss, float* workspace, const float* gate_dev,
+                                       void* stream) {
     ADALOG_ARG_CHECK(alphas && ns && loss && workspace && count >= 1 && count <= RL_MAX, "round_loss_multi: bad arguments");
     RoundLossMulti a;
     int blocks = 0;
@@ -1060,7 +1074,7 @@ extern "C" int adalog_round_loss_multi(const float* const* alphas, float* const*
     unsigned int* ticket = ticket_wide(stream);
     ADALOG_ARG_CHECK(ticket, "round_loss_multi: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_round_loss_multi, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b, b_dev, weight, workspace, ticket,
-                       loss);
+                       loss, gate_dev);
     ADALOG_LAUNCH_CHECK("adalog_round_loss_multi");
     return 0;
 }
@@ -1073,7 +1087,7 @@ extern "C" int adalog_alpha_step_multi(float* const* alphas, const float* const*
                                        const float* const* zps, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* ns,
                                        const int64_t* inners, const int* n_bits, int count, float lr, const float* lr_dev, float beta1,
                                        float beta2, float eps, float* step_dev, float b, const float* b_dev, float weight,
-                                       const float* gmul, void* stream) {
+                                       const float* gmul, const float* gate, void* stream) {
     ADALOG_ARG_CHECK(alphas && ws && gws && scales && zps && exp_avg && exp_avg_sq && ns && inners && n_bits && step_dev && count >= 1 &&
                      count <= ADAM_MAX, "alpha_step_multi: bad arguments");
     AlphaStepMulti a;
@@ -1091,7 +1105,7 @@ extern "C" int adalog_alpha_step_multi(float* const* alphas, const float* const*
     a.count = count;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_alpha_step_multi, dim3(blocks), dim3(256), 0, st, a, lr, lr_dev, beta1, beta2, eps, step_dev, b, b_dev, weight,
-                       gmul);
+                       gmul, gate);
     hipLaunchKernelGGL(k_adam_count, dim3(1), dim3(1), 0, st, step_dev);
     ADALOG_LAUNCH_CHECK("adalog_alpha_step_multi");
     return 0;

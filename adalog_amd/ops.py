@@ -982,9 +982,10 @@ def rec_loss_backward(pred, tgt, scale: float, gmul):
     return gp
 
 
-def round_loss_multi(alphas, b, weight: float, want_grads: bool = True):
+def round_loss_multi(alphas, b, weight: float, want_grads: bool = True, gate=None):
     """weight * sum_t sum(1 - |2h(alpha_t)-1|^b) and its gradients, one launch for all tensors of a block.
-    Returns (loss [1], [grad_t]) -- grads None with ``want_grads=False`` (alpha_step_multi computes them itself)."""
+    Returns (loss [1], [grad_t]) -- grads None with ``want_grads=False`` (alpha_step_multi computes them itself).  ``gate``: optional
+    one-element device tensor multiplied into the VALUE (the gradients stay ungated: the caller's backward applies it)."""
     import ctypes
     alphas = [_f32c(a, "alpha") for a in alphas]
     n = len(alphas)
@@ -998,7 +999,7 @@ def round_loss_multi(alphas, b, weight: float, want_grads: bool = True):
     loss = torch.empty(1, dtype=torch.float32, device=dev)
     b_dev = _f32c(b, "b") if torch.is_tensor(b) else None
     rc = lib.adalog_round_loss_multi(ap, gp, ns, n, 0.0 if b_dev is not None else float(b), _ptr(b_dev), float(weight),
-                                     loss.data_ptr(), ws.data_ptr(), _stream())
+                                     loss.data_ptr(), ws.data_ptr(), _ptr(None if gate is None else _f32c(gate, "gate")), _stream())
     _lib.check(rc, "adalog_round_loss_multi")
     return loss, grads
 
@@ -1234,7 +1235,7 @@ def merge_heads(parts, B: int, N: int, H: int, D: int) -> torch.Tensor:
 
 
 def alpha_step_multi(alphas, ws, gws, scales, zps, exp_avg, exp_avg_sq, inners, n_bits, step_dev, lr, beta1: float, beta2: float,
-                     eps: float, b, weight: float, gmul):
+                     eps: float, b, weight: float, gmul, gate=None):
     """AdaRound's alpha of up to 16 layers: gradient (through w_sim from gws[t] = dL/dw_sim or None, plus ``gmul`` times the
     rounding regulariser's) and Adam step in ONE launch.  ``b``: float or device tensor [1]; ``gmul``: device tensor [1] or None;
     ``lr``: float or device tensor [1]; ``step_dev``: device fp32 [1], steps taken so far (advanced here)."""
@@ -1254,7 +1255,7 @@ def alpha_step_multi(alphas, ws, gws, scales, zps, exp_avg, exp_avg_sq, inners, 
         PA(*[t.data_ptr() for t in scales]), PA(*[t.data_ptr() for t in zps]), PA(*[t.data_ptr() for t in exp_avg]),
         PA(*[t.data_ptr() for t in exp_avg_sq]), NA(*[t.numel() for t in alphas]), NA(*[int(i) for i in inners]),
         IA(*[int(i) for i in n_bits]), n, 0.0 if lr_dev is not None else float(lr), _ptr(lr_dev), float(beta1), float(beta2), float(eps),
-        step_dev.data_ptr(), 0.0 if b_dev is not None else float(b), _ptr(b_dev), float(weight), _ptr(gmul), _stream())
+        step_dev.data_ptr(), 0.0 if b_dev is not None else float(b), _ptr(b_dev), float(weight), _ptr(gmul), _ptr(gate), _stream())
     _lib.check(rc, "adalog_alpha_step_multi")
 
 

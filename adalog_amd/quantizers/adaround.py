@@ -24,7 +24,7 @@ class AlphaCollector:
     def begin(self):
         self.gw = [None] * len(self.q)
         self.w = [None] * len(self.q)
-        self.round = None                                      # (b, weight, upstream gradient) of the regulariser
+        self.round = None                                      # (b, weight, upstream gradient, gate) of the regulariser
 
     def take(self, alpha2, w2, gy):
         i = self.ptr.get(alpha2.data_ptr())
@@ -38,11 +38,11 @@ class AlphaCollector:
         qs = self.q
         ws = [w_ if w_ is not None else q_._w_last for w_, q_ in zip(self.w, qs)]
         sts = [self.state_of(q_.alpha) for q_ in qs]
-        b, weight, g = self.round if self.round is not None else (1.0, 0.0, None)
+        b, weight, g, gate = self.round if self.round is not None else (1.0, 0.0, None, None)
         be.alpha_step_multi([q_.alpha.data for q_ in qs], ws, self.gw, [q_.scale.data.view(-1) for q_ in qs],
                             [q_.zero_point.data.view(-1) for q_ in qs], [st['exp_avg'] for st in sts], [st['exp_avg_sq'] for st in sts],
                             [q_.alpha.numel() // q_.scale.numel() for q_ in qs], [q_.n_bits for q_ in qs], self.step_dev, self.lr,
-                            self.betas[0], self.betas[1], self.eps, b, weight, g)
+                            self.betas[0], self.betas[1], self.eps, b, weight, g, gate)
 
 
 COLLECT = None                                                 # the AlphaCollector in force (set around a graph capture only)

@@ -286,7 +286,7 @@ class BlockReconstructor(QuantCalibrator):
                         adaround_mod.COLLECT = collector
                         try:
                             static_rec = loss_func.rec_term(block(static_inp), static_out)
-                            static_rnd = (loss_func.round_sum(b_dev) * rw_dev).sum()
+                            static_rnd = loss_func.round_sum(b_dev, gate=rw_dev)
                             (static_rec + static_rnd).backward()
                         finally:
                             adaround_mod.COLLECT = None
@@ -418,9 +418,15 @@ class _RoundLossAllFn(torch.autograd.Function):
     (csrc/brecq.hip k_round_loss_multi); the reference builds ~10 autograd nodes per quantiser."""
 
     @staticmethod
-    def forward(ctx, b, weight, *alphas):
+    def forward(ctx, b, weight, gate, *alphas):
+        """gate: None or a one-element device tensor (the 0 / 1 switch of the warm-up): value and gradients are multiplied by it
+        inside the kernels instead of by a multiply and a sum around this node (four launches per iteration)."""
         ctx.collect = adaround_mod.COLLECT is not None
-        loss, grads = backend.get().round_loss_multi(alphas, b, weight, **({"want_grads": False} if ctx.collect else {}))
+        kw = {"want_grads": False} if ctx.collect else {}
+        if gate is not None:
+            kw["gate"] = gate
+        loss, grads = backend.get().round_loss_multi(alphas, b, weight, **kw)
+        ctx.gate = gate
         if ctx.collect:
             ctx.b, ctx.weight, ctx.n = b, weight, len(alphas)
         else:
@@ -430,9 +436,11 @@ class _RoundLossAllFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         if ctx.collect:                                      # the collector's launch computes these gradients itself
-            adaround_mod.COLLECT.round = (ctx.b, ctx.weight, g.reshape(1).contiguous())
-            return (None, None) + (None,) * ctx.n
-        return (None, None) + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
+            adaround_mod.COLLECT.round = (ctx.b, ctx.weight, g.reshape(1).contiguous(), ctx.gate)
+            return (None, None, None) + (None,) * ctx.n
+        if ctx.gate is not None:
+            g = g * ctx.gate.reshape(())
+        return (None, None, None) + tuple(torch._foreach_mul(list(ctx.saved_tensors), g))
 
 
 class LossFunction:
@@ -483,17 +491,18 @@ class LossFunction:
             raise NotImplementedError
         return True
 
-    def round_sum(self, b):
-        """weight * sum over the block's AdaRound quantisers of sum(1 - |2h-1|^b); b: float or one-element device tensor."""
+    def round_sum(self, b, gate=None):
+        """weight * sum over the block's AdaRound quantisers of sum(1 - |2h-1|^b); b: float or one-element device tensor;
+        gate: optional one-element device tensor multiplied in (captured iterations: 0 during the warm-up, then 1)."""
         alphas = [module.w_quantizer.alpha for _, module in self.block.named_modules()
                   if hasattr(module, 'w_quantizer') and isinstance(module.w_quantizer, AdaRoundQuantizer)]
         if 1 <= len(alphas) <= 16 and all(a.dtype == torch.float32 for a in alphas):
-            return _RoundLossAllFn.apply(b, float(self.weight), *alphas)
+            return _RoundLossAllFn.apply(b, float(self.weight), gate, *alphas)
         round_loss = 0
         for _, module in self.block.named_modules():
             if hasattr(module, 'w_quantizer') and isinstance(module.w_quantizer, AdaRoundQuantizer):
                 round_loss = round_loss + self.weight * module.w_quantizer.round_loss(b)
-        return round_loss
+        return round_loss if gate is None else (round_loss * gate).sum()
 
     def round_term(self):
         """Advances the iteration counter; returns the rounding regulariser of this iteration (0 during the warm-up)."""

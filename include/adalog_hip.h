@@ -387,7 +387,7 @@ int adalog_round_loss(const float* alpha, int64_t n, float b, const float* b_dev
  *   adalog_round_loss_multi_workspace(ns, count) floats. */
 int64_t adalog_round_loss_multi_workspace(const int64_t* ns, int count);
 int adalog_round_loss_multi(const float* const* alphas, float* const* grads, const int64_t* ns, int count, float b,
-                            const float* b_dev, float weight, float* loss, float* workspace, void* stream);
+                            const float* b_dev, float weight, float* loss, float* workspace, const float* gate_dev, void* stream);
 /* Reconstruction loss of a BRECQ iteration, LossFunction.lp_loss with p = 2 (reference utils/block_recon.py:186-199):
  *   loss[0] = scale * sum (pred - tgt)^2, the caller folding 1/(batch*channels) of `.sum(1).mean()` and the /10 into scale;
  *   backward: gpred = 2 * scale * gmul[0] * (pred - tgt).  workspace: 2048 floats. */
@@ -398,11 +398,13 @@ int adalog_rec_loss_backward(const float* pred, const float* tgt, int64_t n, flo
  *   g = [inside] gw * s * h'(alpha)  +  gmul[0] * weight * d/d alpha (1 - |2 h(alpha) - 1|^b)      (quantizers/adaround.py:38-57 under
  *   autograd; utils/block_recon.py:205-210), then torch.optim.Adam's default update (utils/block_recon.py:108-109,122-125) -- the
  *   operations of adalog_adaround (backward form), adalog_round_loss_multi's gradients and adalog_adam_multi, in their order.
- *   HOST arrays of device pointers; gws[t] = dL/dw_sim of layer t or null; ns[t] = rows * inners[t]; gmul null = no regulariser. */
+ *   HOST arrays of device pointers; gws[t] = dL/dw_sim of layer t or null; ns[t] = rows * inners[t]; gmul null = no regulariser;
+ *   gate (optional): a device 0 / 1 factor on gmul (the regulariser's warm-up switch).  adalog_round_loss_multi's gate_dev likewise
+ *   multiplies its value. */
 int adalog_alpha_step_multi(float* const* alphas, const float* const* ws, const float* const* gws, const float* const* scales,
                             const float* const* zps, float* const* exp_avg, float* const* exp_avg_sq, const int64_t* ns,
                             const int64_t* inners, const int* n_bits, int count, float lr, const float* lr_dev, float beta1, float beta2,
-                            float eps, float* step_dev, float b, const float* b_dev, float weight, const float* gmul, void* stream);
+                            float eps, float* step_dev, float b, const float* b_dev, float weight, const float* gmul, const float* gate, void* stream);
 /* One Adam step (torch.optim.Adam defaults; reference utils/block_recon.py:108-109,122-125) for `count` <= 16 fp32 tensors in ONE
  *   launch:  m = m + (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps), t =
  *   step_dev[0] + 1; step_dev[0] is advanced by one.  params / grads / exp_avg / exp_avg_sq / ns are HOST arrays (device

@@ -512,14 +512,17 @@ def rec_loss_backward(pred, tgt, scale, gmul):
     return (pred - tgt) * (2.0 * scale * gmul.reshape(()))
 
 
-def round_loss_multi(alphas, b, weight):
+def round_loss_multi(alphas, b, weight, want_grads=True, gate=None):
     bb = float(b.reshape(()).item()) if torch.is_tensor(b) else float(b)
     total, grads = 0.0, []
     for al in alphas:
         g_ = torch.zeros_like(al)
         total = total + round_loss(al, bb, galpha=g_, gscale=weight)
         grads.append(g_)
-    return (total * weight).view(1), grads
+    val = (total * weight).view(1)
+    if gate is not None:
+        val = val * gate.reshape(1)
+    return val, (grads if want_grads else None)
 
 
 def gemm_mixed_ok(M, N, G, gmod, ref_div, k_valid):
