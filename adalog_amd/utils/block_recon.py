@@ -181,6 +181,16 @@ class BlockReconstructor(QuantCalibrator):
         # CPU tier by default) keeps torch.optim.Adam
         hip_adam = os.environ.get("ADALOG_BRECQ_ADAM", "hip" if torch.device(device).type == 'cuda' else "torch") == "hip"
         a_lr = torch.tensor(lr, dtype=torch.float32, device=device) if full_graph else lr
+        # Captured iterations with HipAdam: what changes from one iteration to the next besides the mini-batch -- the
+        # regulariser's exponent b, its 0 / 1 warm-up gate and the cosine learning rate of the activation scales -- lives in ONE
+        # device triple the captured kernels read, refreshed by one 12-byte copy per iteration from a table uploaded 256 rows at
+        # a time (two fills and the scheduler's tensor arithmetic, ~7 launches, before).  The rows are computed on the host in
+        # python floats by the reference's own objects (LinearTempDecay, torch's CosineAnnealingLR on a float learning rate).
+        table_mode = full_graph and hip_adam
+        sched_dev = torch.zeros(3, dtype=torch.float32, device=device) if table_mode else None
+        if table_mode:
+            a_lr = sched_dev[2:3]
+            a_lr.fill_(lr)
         if hip_adam:
             w_optimizer = HipAdam(w_params)
             a_optimizer = HipAdam(a_params, lr=a_lr) if len(a_params) != 0 else None
@@ -188,7 +198,12 @@ class BlockReconstructor(QuantCalibrator):
             w_optimizer = torch.optim.Adam(w_params, **okw)
             a_optimizer = torch.optim.Adam(a_params, lr=a_lr, **okw) if len(a_params) != 0 else None
         a_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(a_optimizer, T_max=iters, eta_min=0.) \
-            if len(a_params) != 0 else None
+            if len(a_params) != 0 and not table_mode else None
+        twin_opt = twin = None
+        if table_mode:
+            twin_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+            twin_opt.step()
+            twin = torch.optim.lr_scheduler.CosineAnnealingLR(twin_opt, T_max=iters, eta_min=0.)
         loss_func = LossFunction(block, round_loss='relaxation', weight=weight, max_count=iters,
                                  rec_loss='mse' if 'head' not in name else 'kl_div', b_range=b_range, decay_start=0,
                                  warmup=warmup, p=p)
@@ -253,9 +268,29 @@ class BlockReconstructor(QuantCalibrator):
                 idx_block, idx_base = host.to(idx_dev, non_blocking=True), it
             return idx_block[it - idx_base]
 
+        sched_block, sched_base = None, 0
+
+        def next_schedule(it):
+            """Row `it` of the schedule table -> sched_dev (b of iteration it, its gate, the learning rate it steps with)."""
+            nonlocal sched_block, sched_base
+            if sched_block is None or it >= sched_base + sched_block.shape[0]:
+                cnt = min(IDX_AHEAD, iters - it)
+                rows = []
+                for k in range(cnt):
+                    count = it + k + 1                       # LossFunction.advance(): the counter of that iteration
+                    active = not (count < loss_func.loss_start or loss_func.round_loss == 'none')
+                    rows.append([float(loss_func.temp_decay(count)) if active else 0.0, 1.0 if active else 0.0,
+                                 float(twin_opt.param_groups[0]['lr'])])
+                    twin.step()                              # (block_recon.py:124-125: the scheduler steps after the optimiser)
+                host = torch.tensor(rows, dtype=torch.float32).pin_memory()
+                sched_block, sched_base = host.to(device, non_blocking=True), it
+            sched_dev.copy_(sched_block[it - sched_base])
+
         try:
             for it in range(iters):
                 idx = next_indices(it)
+                if table_mode:
+                    next_schedule(it)
                 if not use_graph or it < 3:                  # eager (and the warm-up iterations before the capture)
                     eager_step(block.raw_input[idx].to(device), block.raw_out[idx].to(device))
                     if iter_hook is not None:
@@ -263,8 +298,11 @@ class BlockReconstructor(QuantCalibrator):
                     continue
                 if graph is None:
                     static_inp, static_out = block.raw_input[idx].to(device).clone(), block.raw_out[idx].to(device).clone()
-                    b_dev = torch.zeros(1, dtype=torch.float32, device=device)
-                    rw_dev = torch.zeros(1, dtype=torch.float32, device=device)
+                    if table_mode:
+                        b_dev, rw_dev = sched_dev[0:1], sched_dev[1:2]
+                    else:
+                        b_dev = torch.zeros(1, dtype=torch.float32, device=device)
+                        rw_dev = torch.zeros(1, dtype=torch.float32, device=device)
                 else:
                     if block.raw_input.device == static_inp.device:
                         torch.index_select(block.raw_input, 0, idx, out=static_inp)
@@ -273,8 +311,9 @@ class BlockReconstructor(QuantCalibrator):
                         static_inp.copy_(block.raw_input[idx])
                         static_out.copy_(block.raw_out[idx])
                 active = loss_func.advance()                 # iteration counter, b of this iteration
-                b_dev.fill_(float(loss_func.b))
-                rw_dev.fill_(1.0 if active else 0.0)
+                if not table_mode:
+                    b_dev.fill_(float(loss_func.b))
+                    rw_dev.fill_(1.0 if active else 0.0)
                 if graph is None:
                     for prm in params:
                         prm.grad = None
