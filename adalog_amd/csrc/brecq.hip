@@ -279,6 +279,11 @@ __global__ __launch_bounds__(256) void k_adaround_t(const float* __restrict__ w,
     }
 }
 
+// x^e for x in (0, 1] through the hardware log2 / exp2 (~1e-5 relative at the largest exponent the schedule uses, b = 20; the
+// library powf is ~100 instructions and made the regulariser's kernels compute-bound: 47 us for the 7 M alphas of a vit_base
+// block whose bytes take 8).  Every kernel of the regulariser uses this one form, so the routes agree bit for bit.
+__device__ __forceinline__ float pow01(float x, float e) { return __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(x)); }
+
 // round loss value (block partials) and, when galpha != null, galpha[i] += gscale * d/d alpha
 __global__ __launch_bounds__(256) void k_round_loss(const float* __restrict__ alpha, int64_t n, float b,
                                                     const float* __restrict__ b_dev, float* __restrict__ part,
@@ -294,10 +299,10 @@ __global__ __launch_bounds__(256) void k_round_loss(const float* __restrict__ al
         const float h = soft_h(alpha[i], dh);
         const float d = 2.0f * (h - 0.5f);
         const float ad = fabsf(d);
-        acc += 1.0f - powf(ad, b);
+        acc += 1.0f - (ad > 0.0f ? pow01(ad, b) : 0.0f);
         if (galpha) {
             const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-            const float dl = ad > 0.0f ? -b * powf(ad, b - 1.0f) * sgn * 2.0f * dh : 0.0f;
+            const float dl = ad > 0.0f ? -b * pow01(ad, b - 1.0f) * sgn * 2.0f * dh : 0.0f;
             galpha[i] = overwrite ? gscale * dl : galpha[i] + gscale * dl;
         }
     }
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256) void k_round_loss_multi(RoundLossMulti a, floa
         const float h = soft_h(al[i], dh);
         const float d = 2.0f * (h - 0.5f);
         const float ad = fabsf(d);
-        const float pm1 = ad > 0.0f ? powf(ad, b - 1.0f) : 0.0f;
+        const float pm1 = ad > 0.0f ? pow01(ad, b - 1.0f) : 0.0f;
         acc += 1.0f - pm1 * ad;
         const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
         if (gr) gr[i] = weight * (-b * pm1 * sgn * 2.0f * dh);
@@ -420,7 +425,7 @@ struct AlphaStepMulti {
 __global__ __launch_bounds__(256) void k_alpha_step_multi(AlphaStepMulti a, float lr, const float* __restrict__ lr_dev, float beta1,
                                                           float beta2, float eps, const float* __restrict__ step_dev, float b,
                                                           const float* __restrict__ b_dev, float weight,
-                                                          const float* __restrict__ gmul, const float* __restrict__ gate) {
+                                                          const float* __restrict__ gmul, const float* __restrict__ gate, int epb) {
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
     if (lr_dev) lr = lr_dev[0];
@@ -438,9 +443,10 @@ __global__ __launch_bounds__(256) void k_alpha_step_multi(AlphaStepMulti a, floa
     float* __restrict__ vv = a.v[t];
     const int64_t n = a.n[t], inner = a.inner[t];
     const float qmax = a.qmax[t];
-    const int64_t base = (int64_t)(blockIdx.x - a.first_block[t]) * 1024;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    // (epb = 1 024 or 4 096 values per block: the two powf of the bias corrections above are per-wave work worth ~4 values, so
+    // large blocks pay -- once there are enough of them to fill the chip)
+    const int64_t base = (int64_t)(blockIdx.x - a.first_block[t]) * epb;
+    for (int u = 0; u < epb / 256; ++u) {
         const int64_t i = base + u * 256 + threadIdx.x;
         if (i < n) {
             const int64_t row = i / inner;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(256) void k_alpha_step_multi(AlphaStepMulti a, floa
             // d/d alpha of the regulariser (k_round_loss_multi) times its upstream factor
             const float d = 2.0f * (h - 0.5f);
             const float ad = fabsf(d);
-            const float pm1 = ad > 0.0f ? powf(ad, b - 1.0f) : 0.0f;
+            const float pm1 = ad > 0.0f ? pow01(ad, b - 1.0f) : 0.0f;
             const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
             const float grl = weight * (-b * pm1 * sgn * 2.0f * dh);
             const float g = ga + grl * g_rl;
@@ -1092,6 +1098,9 @@ extern "C" int adalog_alpha_step_multi(float* const* alphas, const float* const*
                      count <= ADAM_MAX, "alpha_step_multi: bad arguments");
     AlphaStepMulti a;
     int blocks = 0;
+    int64_t total = 0;
+    for (int t = 0; t < count; ++t) total += ns[t] > 0 ? ns[t] : 0;
+    const int epb = total >= ((int64_t)4 << 20) ? 4096 : 1024;
     for (int t = 0; t < count; ++t) {
         ADALOG_ARG_CHECK(alphas[t] && ws[t] && scales[t] && zps[t] && exp_avg[t] && exp_avg_sq[t] && ns[t] >= 1 && inners[t] >= 1 &&
                          ns[t] % inners[t] == 0, "alpha_step_multi: bad tensor");
@@ -1099,13 +1108,13 @@ extern "C" int adalog_alpha_step_multi(float* const* alphas, const float* const*
         a.m[t] = exp_avg[t]; a.v[t] = exp_avg_sq[t]; a.n[t] = ns[t]; a.inner[t] = inners[t];
         a.qmax[t] = (float)((1 << n_bits[t]) - 1);
         a.first_block[t] = blocks;
-        blocks += (int)((ns[t] + 1023) / 1024);
+        blocks += (int)((ns[t] + epb - 1) / epb);
     }
     a.first_block[count] = blocks;
     a.count = count;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_alpha_step_multi, dim3(blocks), dim3(256), 0, st, a, lr, lr_dev, beta1, beta2, eps, step_dev, b, b_dev, weight,
-                       gmul, gate);
+                       gmul, gate, epb);
     hipLaunchKernelGGL(k_adam_count, dim3(1), dim3(1), 0, st, step_dev);
     ADALOG_LAUNCH_CHECK("adalog_alpha_step_multi");
     return 0;

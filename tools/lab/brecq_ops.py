@@ -11,7 +11,7 @@ mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
 cfg = mod.Config()
 dev = torch.device("cuda")
 torch.manual_seed(5)
-base = create_model("deit_small", depth=1).eval()
+base = create_model(os.environ.get("MODEL", "deit_small"), depth=1).eval()
 full = copy.deepcopy(base).to(dev).eval()
 model = wrap_modules_in_net(base, cfg, reparam=True).to(dev)
 imgs = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(dev)
