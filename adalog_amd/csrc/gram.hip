@@ -1,0 +1,686 @@
+// K7 (Gram form) -- output-MSE weight searches of the uniformly quantised Linear layers scored from the Gram matrix of the
+// quantised activation instead of from its tokens.
+//
+// Reference: quant_layers/linear.py:355-392 (_search_best_w_scale).  For candidate p and output row o it scores
+//     sum_t ( r[t,o] - sigma * x_int[t,:] . w_int_p[o,:] )^2,   r = raw_out - bias,  sigma = s_a * s_w[p,o],
+// with the activation quantiser FIXED for the whole weight_fpcs call (linear.py:483-503: six such calls).  That is a
+// quadratic form in the candidate's integer row w = w_int_p[o,:]:
+//     S0[o] - 2 sigma (w . c[o,:]) + sigma^2 (w^T G w),    G = X_int^T X_int  [K,K],  c[o,:] = X_int^T r[:,o],  S0 = sum_t r^2.
+// G, c and S0 are built ONCE per weight_fpcs call (adalog_gram_build: 2 T K^2 + 2 T K O multiply-adds); every candidate row
+// then costs K^2 multiply-adds per limb of G instead of T K: (limbs K / T) of the work -- 0.18 for deit_small qkv, 0.005 for
+// swin_base stage 0.
+//
+// Exactness.  The three terms are each ~ |r|^2 and cancel to the score (1e-2 ... 1e-4 of it), so they are carried exactly:
+//   * x_int = q - z (|.| <= 2^bits - 1) is int8; G = X^T X is an exact integer, accumulated in int32 per token chunk and int64
+//     across chunks, then split into balanced int8 limbs (3 for 4-bit activations of 6 304 tokens): w^T G w runs on
+//     v_mfma_i32_32x32x32_i8 once per limb with exact int32 accumulators; the row dot with w and the limb recombination are exact
+//     integers folded into fp64 below 2^53 ... 2^56 (relative rounding 1e-16);
+//   * r is rounded ONCE per output column to 30-bit fixed point relative to the column's largest magnitude (four balanced int8
+//     limbs; |delta r| <= 2^-30 max|r|: far below fp32's own 2^-24 relative spacing for every element within 2^6 of the
+//     maximum), after which c = X^T r_fix and S0 = sum r_fix^2 are exact integers too (int8 MFMA, int64); the score returned
+//     is the EXACT score of the rounded reference up to the final fp64 combination;
+//   * sigma = fl32(s_a * s_w) as in the token-form kernels' epilogue (gemm_k_slab.inc), the combination in fp64.
+// Against the fp32 ATen evaluation (~5e-6 relative noise of its own) the difference is <= 1e-6 (tests/test_gpu_kernels.py).
+//
+// Kernels:
+//   k_gram_pack_xt   x [T,K] fp32 -> (q - z) int8, TRANSPOSED [K][Tp] (token-contiguous: the contraction runs over tokens)
+//   k_gram_rfix      raw_out^T [O,T] fp32, bias -> four int8 limb planes [4][O][Tp], S0[o], 2^-e_o
+//   k_gram_mm        C[i,j] = sum_t A[i,t] B[j,t]  (int8 MFMA, int32 per chunk -> int64 partial per token split); A optionally in
+//                    limb planes (recombined with shifts): G = xt.xt^T and c = rfix.xt^T
+//   k_gram_fin_g     sum of the split partials -> balanced limbs in MFMA A-fragment order (rows permuted so that a lane's
+//                    accumulator rows are the k of its own B fragment)
+//   k_gram_fin_c     sum of the split partials -> 8 balanced limbs [O][8][K] (the rows of a 9th "panel": w . c on the MFMA too)
+//   k_gram_score     per FPCS step: a wave owns up to CB blocks of 32 candidates; a lane IS a candidate: it quantises its weight
+//                    row into the B fragments (registers, all of K) with the slab GEN form's exact-bin arithmetic, then streams
+//                    the (row tile, limb) panels of G through an LDS ring shared by the workgroup's four waves:
+//                    12 MFMAs per panel and block, then sum_e acc[e] * w[e] over the lane's own 16 rows (v_mad_i32_i24).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// compile-time loop: f(integral_constant<int, 0>), ..., f(integral_constant<int, N - 1>).  (#pragma unroll is a request the optimiser
+// declines for bodies this large; an index that stays dynamic sends the register-resident fragment array to scratch.)
+template <typename F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+constexpr int RLIMBS = 4;          // int8 limbs of the fixed-point reference (30 bits + sign)
+constexpr int CLIMBS = 8;          // int8 limbs of c = X^T r_fix (<= 2^62)
+constexpr int RFIX_BITS = 29;      // |r_fix| < 2^30
+
+// ------------------------------------------------------------------------------------------------ pack x^T
+// bins exactly as uni_bin_fast (common.h), value = bin - z
+__global__ __launch_bounds__(256) void k_gram_pack_xt(const float* __restrict__ x, int T, int K, int64_t ldx, const float* __restrict__ sa,
+                                                      const float* __restrict__ za, float qmax, int8_t* __restrict__ xt, int64_t Tp) {
+#pragma clang fp contract(off)
+    __shared__ uint32_t tile[64][17];                       // [token][16 dwords of 4 channels] (+1: bank spread)
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+    const float s = sa[0], z = rintf(za[0]), inv = 1.0f / s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty + 16 * i, k = k0 + 4 * tx;
+        uint32_t pk = 0;
+        if (m < T && k < K) {
+            const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)m * ldx + k);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int q = (int)(uni_bin_fast(e[j], s, inv, z, qmax) - z);
+                pk |= ((uint32_t)(q & 0xff)) << (8 * j);
+            }
+        }
+        tile[ty + 16 * i][tx] = pk;
+    }
+    __syncthreads();
+    const int c = tid >> 2, part = tid & 3;                 // channel within the tile, 16-token part
+    if (k0 + c < K) {
+        uint32_t o[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t u = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t d = tile[part * 16 + w * 4 + j][c >> 2];
+                u |= ((d >> (8 * (c & 3))) & 0xffu) << (8 * j);
+            }
+            o[w] = u;
+        }
+        *reinterpret_cast<uint4*>(xt + (int64_t)(k0 + c) * Tp + m0 + part * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fixed-point reference
+__device__ __forceinline__ double block_sum_d(double v, double* sm) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+__global__ __launch_bounds__(256) void k_gram_rfix(const float* __restrict__ ref_t, int T, int64_t Tp, int O, const float* __restrict__ bias,
+                                                   int8_t* __restrict__ rl, double* __restrict__ s0, double* __restrict__ cscl) {
+#pragma clang fp contract(off)
+    __shared__ double smd[4];
+    __shared__ float smf[4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const float* r = ref_t + (int64_t)o * T;
+    const float b = bias ? bias[o] : 0.0f;
+    float am = 0.0f;
+    for (int m = tid; m < T; m += 256) am = fmaxf(am, fabsf(r[m] - b));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) am = fmaxf(am, __shfl_xor(am, d));
+    if ((tid & 63) == 0) smf[tid >> 6] = am;
+    __syncthreads();
+    am = fmaxf(fmaxf(smf[0], smf[1]), fmaxf(smf[2], smf[3]));
+    // e: am * 2^e in [2^29, 2^30)   (am == 0 or non-finite: e = 0, every limb 0 / garbage in, garbage out as in the token form)
+    int e = 0;
+    if (am > 0.0f && am < 3.0e38f) e = RFIX_BITS - ilogbf(am);
+    double acc = 0.0;
+    int8_t* l0 = rl + (int64_t)o * Tp;
+    const int64_t plane = (int64_t)O * Tp;
+    for (int m = tid; m < Tp; m += 256) {
+        int v = 0;
+        if (m < T) v = (int)rint((double)(r[m] - b) * ldexp(1.0, e));     // exact product; one rounding to the 2^-e grid
+        acc += (double)v * (double)v;
+        int rest = v;
+#pragma unroll
+        for (int l = 0; l < RLIMBS; ++l) {
+            const int d = (int)(int8_t)(rest & 0xff);
+            l0[l * plane + m] = (int8_t)d;
+            rest = (rest - d) >> 8;
+        }
+    }
+    const double tot = block_sum_d(acc, smd);
+    if (tid == 0) { s0[o] = ldexp(tot, -2 * e); cscl[o] = ldexp(1.0, -e); }
+}
+
+// ------------------------------------------------------------------------------------------------ C = A . B^T over tokens (int8)
+// A [NL planes][RA][ld], B [RB][ld] int8, token-contiguous; part[z][RA][RB] int64 = sum over the z-th token range.  A lane
+// (row = lane & 31, half = lane >> 5) loads 64 consecutive tokens of its row per 128-token step (the order of the contraction index
+// is free as long as A and B agree): four MFMAs per block pair.  Workgroup = 4 waves = 128 x 128 outputs, wave = 64 x 64.
+template <int NL>
+__global__ __launch_bounds__(256) void k_gram_mm(const int8_t* __restrict__ A, const int8_t* __restrict__ B, int RA, int RB, int64_t ld,
+                                                 int64_t plane, int steps_per_split, int steps_total, long long* __restrict__ part) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int ra0 = blockIdx.x * 128 + (w >> 1) * 64, rb0 = blockIdx.y * 128 + (w & 1) * 64;
+    const int z = blockIdx.z;
+    const int st0 = z * steps_per_split, st1 = min(st0 + steps_per_split, steps_total);
+    long long acc64[2][2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc64[i][j][e] = 0;
+    const int8_t* pa[2];
+    const int8_t* pb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        pa[i] = A + (int64_t)min(ra0 + 32 * i + r, RA - 1) * ld + h * 64;
+        pb[i] = B + (int64_t)min(rb0 + 32 * i + r, RB - 1) * ld + h * 64;
+    }
+    for (int l = 0; l < NL; ++l) {
+        v16i acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+        // int32 safety: |sum| <= 128 * 127 * 128 * steps: the host keeps steps_per_split <= 512
+        for (int st = st0; st < st1; ++st) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v4i fa[2], fb[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i] = *reinterpret_cast<const v4i*>(pa[i] + l * plane + (int64_t)st * 128 + q * 16);
+                    fb[i] = *reinterpret_cast<const v4i*>(pb[i] + (int64_t)st * 128 + q * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc64[i][j][e] += ((long long)acc[i][j][e]) << (8 * l);
+    }
+    long long* out = part + (int64_t)z * RA * RB;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = rb0 + 32 * j + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = ra0 + 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
+                if (row < RA && col < RB) out[(int64_t)row * RB + col] = acc64[i][j][e];
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------ finalise G and c
+// gfrag[l][kt][jt][lane][16]: lane = (tile row r', half h); tile row r' = 8 i + 4 h' + j holds G row 32 kt + 16 h' + 4 i + j, so
+// that accumulator element e = 4 i + j of lane (., h') is G row 32 kt + 16 h' + e -- the k of byte e of that lane's B fragment kt.
+__global__ __launch_bounds__(256) void k_gram_fin_g(const long long* __restrict__ part, int splits, int K, int NL, int8_t* __restrict__ gfrag) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread per (tile row slot, column) of G
+    if (idx >= (int64_t)K * K) return;
+    const int col = (int)(idx % K), slot = (int)(idx / K);                // slot = 32 kt + r'
+    const int kt = slot >> 5, rp = slot & 31;
+    const int row = 32 * kt + 16 * ((rp >> 2) & 1) + 4 * (rp >> 3) + (rp & 3);
+    long long g = 0;
+    for (int z = 0; z < splits; ++z) g += part[((int64_t)z * K + row) * K + col];
+    const int nj = K >> 5, jt = col >> 5, h = (col >> 4) & 1, e = col & 15;
+    long long rest = g;
+    for (int l = 0; l < NL; ++l) {
+        const int d = (int)(int8_t)(rest & 0xff);
+        gfrag[((((int64_t)l * nj + kt) * nj + jt) * 64 + (rp + 32 * h)) * 16 + e] = (int8_t)d;
+        rest = (rest - d) >> 8;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gram_fin_c(const long long* __restrict__ part, int splits, int O, int K, int8_t* __restrict__ clim) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)O * K) return;
+    const int o = (int)(idx / K), k = (int)(idx % K);
+    long long c = 0;
+    for (int z = 0; z < splits; ++z) c += part[(int64_t)z * O * K + idx];
+    long long rest = c;
+#pragma unroll
+    for (int l = 0; l < CLIMBS; ++l) {
+        const int d = (int)(int8_t)(rest & 0xff);
+        clim[((int64_t)o * CLIMBS + l) * K + k] = (int8_t)d;
+        rest = (rest - d) >> 8;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per-step scoring kernel
+// LDS fragment reads of the panel pipeline as volatile asm (the compiler keeps their order and places no waits of its own);
+// gram_wait<N> ties a fragment to the counted wait that makes it valid; gram_rd_after names the accumulators an earlier MFMA
+// writes as a nominal input, so the read cannot be moved above the MFMAs that still use its destination registers.
+template <int OFF> __device__ __forceinline__ v4i gram_rd(uint32_t addr) {
+    v4i r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ v4i gram_rd_after(uint32_t addr, v16i& tie) {
+    v4i r;
+    asm volatile("ds_read_b128 %0, %2 offset:%3" : "=v"(r), "+v"(tie) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int N> __device__ __forceinline__ void gram_wait(v4i& f) {
+    if constexpr (N >= 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f));
+    else if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f));
+}
+
+struct GramScoreArgs {
+    const float* W; int64_t ldw; int O, K, P;
+    const float* scale; const float* zp;       // [P][O]
+    const int8_t* gfrag; int NL;               // [NL][NJ][NJ][64][16]
+    const int8_t* clim;                        // [O][8][K]
+    const double* s0; const double* cscl;      // [O]
+    const float* sa;                           // device scalar
+    double norm;
+    float qmax, tie;
+    float* scores;                             // [P][O]
+    int nblk;                                  // O * P / 32
+    long long* timeline;                       // lab only (tools/lab/gram_check.py): cycle stamps of wave 0 of each workgroup, else null
+};
+
+// One pass of a wave over NB (<= CB) blocks of 32 candidates; every wave of the workgroup runs the same panel sequence (NB = 0: it
+// only helps moving the panels).  Two workgroups share a CU and run unsynchronised: one's row dots (VALU) issue under the other's MFMAs.
+template <int NJ, int NB, bool BIG>
+__device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, int blk0, int w, int lane, float sa, int stamp_slot) {
+    constexpr int NPW = (NJ + 3) / 4;                      // 1 KiB pieces of a panel per wave
+    constexpr int NRING = 4;                               // panels in the ring; the same LDS is the waves' staging area while generating
+    constexpr int NBA = NB > 0 ? NB : 1;
+    const int c = lane & 31, h = lane >> 5;
+    const int PB = p.P >> 5;
+    const int npanel = NJ * p.NL;
+#define GRAM_STAMP(i_) do { if (p.timeline && stamp_slot >= 0 && w == 0 && lane == 0) p.timeline[stamp_slot * 8 + (i_)] = (long long)__builtin_readcyclecounter(); } while (0)
+    GRAM_STAMP(0);
+
+    // ---- B fragments: this lane's candidate of each block, all of K (int8 q - z; exact bins, gemm_k_slab.inc GEN form).  The
+    // generating loop is rolled (its index is dynamic) and hands the fragments over through the wave's NJ KiB of LDS, from where they
+    // are read back into statically named registers.
+    v4i bf[NBA][NJ];
+    int orow[NBA];
+    float sig[NBA];
+    uint8_t* stage = lds + w * (NJ * 1024) + lane * 16;
+    __syncthreads();                                       // the previous pass's ring is dead (all waves): it is the staging area now
+    {
+#pragma clang fp contract(off)
+        static_for<NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const int blk = blk0 + b;
+            const int o = blk / PB, cand = (blk - o * PB) * 32 + c;
+            orow[b] = o;
+            const int64_t gpi = (int64_t)cand * p.O + o;
+            const float gs = p.scale[gpi], gz = rintf(p.zp[gpi]);
+            sig[b] = sa * gs;
+            const float ginv = __builtin_amdgcn_rcpf(gs);
+            const float glo = 128.0f - gz, ghi = 128.0f + (p.qmax - gz);
+            const float* __restrict__ wr = p.W + (int64_t)o * p.ldw + 16 * h;
+#pragma unroll 1
+            for (int jt = 0; jt < NJ; ++jt) {
+                float xv[16];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(wr + 32 * jt + 4 * j);
+                    xv[4 * j] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;
+                }
+                float kq[16], dm = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float t = xv[e] * ginv;
+                    kq[e] = rintf(t);
+                    dm = fmaxf(dm, fabsf(t - kq[e]));
+                }
+                if (__builtin_expect(dm > p.tie, 0)) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) kq[e] = rintf(xv[e] / gs);
+                }
+                v4i pk;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned u = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e] + 128.0f, glo, ghi), e, u);
+                    pk[j] = (int)(u ^ 0x80808080u);
+                }
+                *reinterpret_cast<v4i*>(stage + jt * 1024) = pk;
+            }
+            static_for<NJ>([&](auto jtc) { bf[b][decltype(jtc)::value] = *reinterpret_cast<const v4i*>(stage + decltype(jtc)::value * 1024); });
+        });
+    }
+    GRAM_STAMP(1);
+
+    // ---- w . c on the MFMA: the 8 limb rows of c[o,:] are rows 0..7 of a 32-row A tile (straight from global memory)
+    double lin[NBA];
+    static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        v16i acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0;
+        const int8_t* cr = p.clim + ((int64_t)orow[b] * CLIMBS + (c & 7)) * p.K + 16 * h;
+        static_for<NJ>([&](auto jtc) {
+            constexpr int jt = decltype(jtc)::value;
+            v4i a = *reinterpret_cast<const v4i*>(cr + 32 * jt);
+            if (c >= CLIMBS) a = v4i{0, 0, 0, 0};
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[b][jt], acc, 0, 0, 0);
+        });
+        // rows 4 h + j (j < 4) = limbs 4 h + j of this lane's candidate
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += (double)acc[j] * (h ? 4294967296.0 : 1.0) * (double)(1 << (8 * j));
+        v += __shfl_xor(v, 32);
+        lin[b] = v;
+    });
+    GRAM_STAMP(2);
+
+    // ---- w^T G w: stream the (l, kt) panels of G through the LDS ring
+    double quad[NBA];
+#pragma unroll
+    for (int b = 0; b < NBA; ++b) quad[b] = 0.0;
+    v4i stg[NPW];
+    auto fetch = [&](int pn) {                            // this wave's pieces of panel pn -> registers
+        const int pc = min(pn, npanel - 1);
+        const int8_t* src = p.gfrag + (int64_t)pc * NJ * 1024;            // panel (l, kt) = gfrag[l][kt]: pn = l * NJ + kt
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int piece = min(w + 4 * i, NJ - 1);
+            stg[i] = *reinterpret_cast<const v4i*>(src + (int64_t)piece * 1024 + lane * 16);
+        }
+    };
+    auto stash = [&](int pn) {                            // registers -> ring slot of panel pn
+        uint8_t* dst = lds + (pn % NRING) * (NJ * 1024);
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int piece = min(w + 4 * i, NJ - 1);
+            *reinterpret_cast<v4i*>(dst + piece * 1024 + lane * 16) = stg[i];
+        }
+    };
+    __syncthreads();                                       // every wave has read its fragments back: the staging area becomes the ring
+    fetch(0); stash(0);
+    fetch(1); stash(1);
+    int kt = 0;
+    double sh = 1.0;
+#pragma unroll 1
+    for (int pn = 0; pn < npanel; ++pn) {
+        __syncthreads();                                   // panel pn is complete; panel pn - 2's slot is free
+        fetch(pn + 2);
+        if constexpr (NB > 0) {
+            const uint8_t* pan = lds + (pn % NRING) * (NJ * 1024) + lane * 16;
+            v16i acc[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[b][e] = 0;
+            // A fragments three reads ahead of their MFMAs (left to itself the compiler reads each one into the same registers right
+            // before its use: an LDS round trip per pair of MFMAs)
+            constexpr int AD = NJ < 3 ? NJ : 3;
+            v4i af[AD];
+            const uint32_t pa = (uint32_t)(uintptr_t)pan;
+            static_for<AD>([&](auto ic) { af[decltype(ic)::value] = gram_rd<decltype(ic)::value * 1024>(pa); });
+            static_for<NJ>([&](auto jtc) {
+                constexpr int jt = decltype(jtc)::value;
+                constexpr int left = (NJ - 1 - jt) < (AD - 1) ? (NJ - 1 - jt) : (AD - 1);     // reads younger than fragment jt
+                gram_wait<left>(af[jt % AD]);
+                static_for<NB>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value;
+                    acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[jt % AD], bf[b][jt], acc[b], 0, 0, 0);
+                });
+                if constexpr (jt + AD < NJ) af[jt % AD] = gram_rd_after<(jt + AD) * 1024>(pa, acc[NB - 1]);
+            });
+            // row dot: accumulator element e = G row 32 kt + 16 h + e = byte e of this lane's own fragment kt (kt is wave-uniform:
+            // a branch picks the registers)
+            static_for<NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                v4i wv = bf[b][0];
+                switch (kt) {
+#define GRAM_CASE(i_) case i_: if constexpr ((i_) < NJ) wv = bf[b][(i_) < NJ ? (i_) : 0]; break;
+                    GRAM_CASE(1) GRAM_CASE(2) GRAM_CASE(3) GRAM_CASE(4) GRAM_CASE(5) GRAM_CASE(6) GRAM_CASE(7) GRAM_CASE(8)
+                    GRAM_CASE(9) GRAM_CASE(10) GRAM_CASE(11) GRAM_CASE(12) GRAM_CASE(13) GRAM_CASE(14) GRAM_CASE(15) GRAM_CASE(16)
+                    GRAM_CASE(17) GRAM_CASE(18) GRAM_CASE(19) GRAM_CASE(20) GRAM_CASE(21) GRAM_CASE(22) GRAM_CASE(23)
+#undef GRAM_CASE
+                    default: break;
+                }
+                constexpr int GRP = BIG ? 4 : 16;
+#pragma unroll
+                for (int g0 = 0; g0 < 16; g0 += GRP) {
+                    int ts = 0;
+#pragma unroll
+                    for (int e = g0; e < g0 + GRP; ++e) {
+                        const int we = __builtin_amdgcn_sbfe(wv[e >> 2], 8 * (e & 3), 8);
+                        ts += __mul24(acc[b][e], we);
+                    }
+                    quad[b] += (double)ts * sh;
+                }
+            });
+        }
+        if (pn + 2 < npanel) stash(pn + 2);
+        if (++kt == NJ) { kt = 0; sh *= 256.0; }
+    }
+    GRAM_STAMP(3);
+
+    // ---- scores
+    static_for<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        const double q = quad[b] + __shfl_xor(quad[b], 32);
+        const int o = orow[b];
+        const double s = (double)sig[b];
+        const double tot = p.s0[o] - 2.0 * s * (lin[b] * p.cscl[o]) + s * s * q;
+        const int blk = blk0 + b;
+        const int cand = (blk - o * PB) * 32 + c;
+        if (h == 0) p.scores[(int64_t)cand * p.O + o] = (float)(-p.norm * tot);
+    });
+    GRAM_STAMP(4);
+#undef GRAM_STAMP
+}
+
+template <int NJ, int CB, bool BIG>
+__global__ __launch_bounds__(256, 2) void k_gram_score(GramScoreArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // [4][NJ][64][16]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwg = gridDim.x;
+    const int b_begin = (int)(((int64_t)p.nblk * blockIdx.x) / nwg), b_end = (int)(((int64_t)p.nblk * (blockIdx.x + 1)) / nwg);
+    const float sa = p.sa[0];
+    int pass_no = 0;
+    for (int pass0 = b_begin; pass0 < b_end; pass0 += 4 * CB, ++pass_no) {
+        const int n = min(4 * CB, b_end - pass0);
+        const int nbw = n / 4 + (w < (n & 3) ? 1 : 0);     // this wave's blocks (wave-uniform)
+        const int blk0 = pass0 + w * (n / 4) + min(w, n & 3);
+        const int slot = pass_no < 2 ? (int)blockIdx.x * 2 + pass_no : -1;
+        if (nbw == CB) gram_pass<NJ, CB, BIG>(p, lds, blk0, w, lane, sa, slot);
+        else if (nbw == 0) gram_pass<NJ, 0, BIG>(p, lds, blk0, w, lane, sa, slot);
+        else if (nbw == 1) gram_pass<NJ, 1, BIG>(p, lds, blk0, w, lane, sa, slot);
+        else if (CB > 2 && nbw == 2) gram_pass<NJ, (CB > 2 ? 2 : 1), BIG>(p, lds, blk0, w, lane, sa, slot);
+        else if (CB > 3 && nbw == 3) gram_pass<NJ, (CB > 3 ? 3 : 1), BIG>(p, lds, blk0, w, lane, sa, slot);
+    }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct GramPlan {
+    int T, O, K, NJ, NL;
+    int64_t Tp;
+    int steps_total, sg_steps, sg_splits, sc_steps, sc_splits;
+    // byte offsets into the workspace
+    int64_t off_gfrag, off_clim, off_s0, off_cscl, off_xt, off_rl, off_gpart, off_cpart, total;
+    bool ok;
+};
+
+static int g_limbs(int64_t T, int a_bits) {
+    const double gmax = (double)T * (double)((1 << a_bits) - 1) * (double)((1 << a_bits) - 1);
+    double cover = 127.0;                                   // largest magnitude of L balanced limbs: 127 * (256^L - 1) / 255
+    for (int L = 1; L <= 7; ++L) {
+        if (gmax <= cover) return L;
+        cover = cover * 256.0 + 127.0;
+    }
+    return 8;
+}
+
+static int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
+
+static int pick_steps(int steps_total, int tiles, int target_wgs) {
+    // token steps (of 128) per split: enough splits to fill the chip, at most 512 steps per split (int32 accumulators)
+    int splits = (target_wgs + tiles - 1) / tiles;
+    if (splits < 1) splits = 1;
+    if (splits > steps_total) splits = steps_total;
+    int per = (steps_total + splits - 1) / splits;
+    if (per > 512) per = 512;
+    return per;
+}
+
+static GramPlan gram_plan(int T, int O, int K, int a_bits) {
+    GramPlan g{};
+    g.T = T; g.O = O; g.K = K;
+    g.ok = T >= 1 && O >= 1 && K >= 32 && K % 32 == 0 && a_bits >= 2 && a_bits <= 7;
+    if (!g.ok) return g;
+    g.NJ = K / 32;
+    g.NL = g_limbs(T, a_bits);
+    g.Tp = ((int64_t)T + 127) / 128 * 128;
+    g.steps_total = (int)(g.Tp / 128);
+    const int tg = ((K + 127) / 128) * ((K + 127) / 128), tc = ((O + 127) / 128) * ((K + 127) / 128);
+    g.sg_steps = pick_steps(g.steps_total, tg, 512);
+    g.sg_splits = (g.steps_total + g.sg_steps - 1) / g.sg_steps;
+    g.sc_steps = pick_steps(g.steps_total, tc, 256);
+    g.sc_splits = (g.steps_total + g.sc_steps - 1) / g.sc_steps;
+    int64_t off = 0;
+    g.off_gfrag = off; off += al256((int64_t)g.NL * K * K);
+    g.off_clim = off; off += al256((int64_t)O * CLIMBS * K);
+    g.off_s0 = off; off += al256((int64_t)O * 8);
+    g.off_cscl = off; off += al256((int64_t)O * 8);
+    g.off_xt = off; off += al256((int64_t)K * g.Tp);
+    g.off_rl = off; off += al256((int64_t)RLIMBS * O * g.Tp);
+    g.off_gpart = off; off += al256((int64_t)g.sg_splits * K * K * 8);
+    g.off_cpart = off; off += al256((int64_t)g.sc_splits * O * K * 8);
+    g.total = off;
+    return g;
+}
+
+static bool nj_supported(int nj) { return nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12 || nj == 16 || nj == 24; }
+
+}  // namespace
+
+// Whether the Gram form takes this weight search AND pays: K a supported multiple of 32, <= 7-bit operands, and at most half the
+// multiply-adds of the token form (limbs * K <= T / 2).  ADALOG_GRAM_W=0 switches it off, =2 drops the profitability test.
+extern "C" int adalog_gram_ok(int T, int O, int K, int a_bits, int w_bits, int P) {
+    static const int use = getenv("ADALOG_GRAM_W") ? atoi(getenv("ADALOG_GRAM_W")) : 1;
+    if (!use) return 0;
+    const GramPlan g = gram_plan(T, O, K, a_bits);
+    if (!g.ok || !nj_supported(g.NJ) || w_bits < 2 || w_bits > 7 || P < 32 || P % 32 != 0) return 0;
+    if ((int64_t)128 * ((1 << w_bits) - 1) * K >= (1 << 23)) return 0;           // accumulators must fit 24 bits (v_mul_i32_i24)
+    if ((int64_t)O * P / 32 >= ((int64_t)1 << 30)) return 0;
+    if (use != 2 && (int64_t)g.NL * K * 2 > T) return 0;
+    return 1;
+}
+
+extern "C" int64_t adalog_gram_workspace_bytes(int T, int O, int K, int a_bits) {
+    const GramPlan g = gram_plan(T, O, K, a_bits);
+    return g.ok ? g.total : -1;
+}
+
+/* Built once per weight_fpcs call (reference linear.py:483-503 re-enters _search_best_w_scale six times with the same activation
+ * quantiser).  x [T][ldx] fp32 (K valid), sa / za: the activation quantiser's scale / zero point (device scalars), ref_t = raw_out
+ * TRANSPOSED [O][T], bias [O] or null. */
+extern "C" int adalog_gram_build(const float* x, int T, int K, int64_t ldx, const float* sa, const float* za, int a_bits,
+                                 const float* ref_t, int O, const float* bias, void* ws, int64_t ws_bytes, void* stream) {
+    ADALOG_ARG_CHECK(x && sa && za && ref_t && ws, "gram_build: null pointer");
+    const GramPlan g = gram_plan(T, O, K, a_bits);
+    ADALOG_ARG_CHECK(g.ok && nj_supported(g.NJ), "gram_build: shape not supported (adalog_gram_ok)");
+    ADALOG_ARG_CHECK(ws_bytes >= g.total, "gram_build: workspace too small");
+    ADALOG_ARG_CHECK(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 255) == 0, "gram_build: x rows / workspace must be aligned");
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* base = (uint8_t*)ws;
+    int8_t* xt = (int8_t*)(base + g.off_xt);
+    int8_t* rl = (int8_t*)(base + g.off_rl);
+    long long* gpart = (long long*)(base + g.off_gpart);
+    long long* cpart = (long long*)(base + g.off_cpart);
+    hipLaunchKernelGGL(k_gram_pack_xt, dim3((unsigned)(g.Tp / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, x, T, K, ldx, sa, za,
+                       (float)((1 << a_bits) - 1), xt, g.Tp);
+    hipLaunchKernelGGL(k_gram_rfix, dim3((unsigned)O), dim3(256), 0, st, ref_t, T, g.Tp, O, bias, rl, (double*)(base + g.off_s0),
+                       (double*)(base + g.off_cscl));
+    hipLaunchKernelGGL((k_gram_mm<1>), dim3((unsigned)((K + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)g.sg_splits), dim3(256), 0, st,
+                       xt, xt, K, K, g.Tp, (int64_t)0, g.sg_steps, g.steps_total, gpart);
+    hipLaunchKernelGGL((k_gram_mm<RLIMBS>), dim3((unsigned)((O + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)g.sc_splits), dim3(256), 0, st,
+                       rl, xt, O, K, g.Tp, (int64_t)O * g.Tp, g.sc_steps, g.steps_total, cpart);
+    hipLaunchKernelGGL(k_gram_fin_g, dim3((unsigned)(((int64_t)K * K + 255) / 256)), dim3(256), 0, st, gpart, g.sg_splits, K, g.NL,
+                       (int8_t*)(base + g.off_gfrag));
+    hipLaunchKernelGGL(k_gram_fin_c, dim3((unsigned)(((int64_t)O * K + 255) / 256)), dim3(256), 0, st, cpart, g.sc_splits, O, K,
+                       (int8_t*)(base + g.off_clim));
+    ADALOG_LAUNCH_CHECK("adalog_gram_build");
+    return 0;
+}
+
+static long long* g_gram_timeline = nullptr;
+// lab only: cycle stamps [workgroup][pass < 2][8] of the next adalog_gram_score_w launches (null switches them off)
+extern "C" void adalog_gram_set_timeline(long long* buf) { g_gram_timeline = buf; }
+
+static int device_cus_gram() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
+
+/* One FPCS step: scores [P][O] = -norm * sum_t (raw_out - b - q_a(x) . fq_p(W)^T)^2 for the P candidates (scale, zp) [P][O] of every
+ * output row, from the workspace adalog_gram_build left.  W fp32 [O][ldw].  (T, O, K, a_bits) must be those of the build. */
+extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
+                                   const void* ws, int T, int a_bits, const float* sa, double norm, float* scores, void* stream) {
+    ADALOG_ARG_CHECK(W && scale && zp && ws && sa && scores, "gram_score_w: null pointer");
+    ADALOG_ARG_CHECK(adalog_gram_ok(T, O, K, a_bits, w_bits, P) || (getenv("ADALOG_GRAM_W") && atoi(getenv("ADALOG_GRAM_W")) == 0),
+                     "gram_score_w: shape not supported (adalog_gram_ok)");
+    ADALOG_ARG_CHECK(ldw >= K && ldw % 4 == 0 && ((uintptr_t)W & 15) == 0, "gram_score_w: weight rows must be 16-byte aligned");
+    const GramPlan g = gram_plan(T, O, K, a_bits);
+    ADALOG_ARG_CHECK(g.ok && nj_supported(g.NJ) && P % 32 == 0, "gram_score_w: shape not supported");
+    const uint8_t* base = (const uint8_t*)ws;
+    GramScoreArgs a{};
+    a.W = W; a.ldw = ldw; a.O = O; a.K = K; a.P = P; a.scale = scale; a.zp = zp;
+    a.gfrag = (const int8_t*)(base + g.off_gfrag); a.NL = g.NL; a.clim = (const int8_t*)(base + g.off_clim);
+    a.s0 = (const double*)(base + g.off_s0); a.cscl = (const double*)(base + g.off_cscl);
+    a.sa = sa; a.norm = norm; a.scores = scores;
+    a.qmax = (float)((1 << w_bits) - 1);
+    const float zone = 6e-7f * (float)(1 << w_bits);
+    a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
+    a.nblk = (int)((int64_t)O * P / 32);
+    a.timeline = g_gram_timeline;
+    const bool big = w_bits > 4;
+    hipStream_t st = (hipStream_t)stream;
+    const int ncu = device_cus_gram();
+#define GRAM_LAUNCH(NJV, CBV, BIGV)                                                                               \
+    do {                                                                                                          \
+        const int per = 4 * CBV;                                                                                  \
+        int wgs = (a.nblk + per - 1) / per;                                                                       \
+        if (wgs > 2 * ncu) wgs = 2 * ncu;                                                                         \
+        const size_t shm = (size_t)4 * NJV * 1024;                                                                \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_score<NJV, CBV, BIGV>),               \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        adalog_note_kernel("k_gram_score<i8>");                                                                   \
+        hipLaunchKernelGGL((k_gram_score<NJV, CBV, BIGV>), dim3((unsigned)wgs), dim3(256), shm, st, a);           \
+    } while (0)
+#define GRAM_LAUNCH_B(NJV, CBV) do { if (big) GRAM_LAUNCH(NJV, CBV, true); else GRAM_LAUNCH(NJV, CBV, false); } while (0)
+    switch (g.NJ) {
+        case 3: GRAM_LAUNCH_B(3, 4); break;
+        case 4: GRAM_LAUNCH_B(4, 4); break;
+        case 6: GRAM_LAUNCH_B(6, 4); break;
+        case 8: GRAM_LAUNCH_B(8, 2); break;
+        case 12: GRAM_LAUNCH_B(12, 2); break;
+        case 16: GRAM_LAUNCH_B(16, 2); break;
+        case 24: GRAM_LAUNCH_B(24, 1); break;
+        default: ADALOG_ARG_CHECK(false, "gram_score_w: K not instantiated");
+    }
+#undef GRAM_LAUNCH_B
+#undef GRAM_LAUNCH
+    ADALOG_LAUNCH_CHECK("adalog_gram_score_w");
+    return 0;
+}

@@ -605,6 +605,65 @@ def score_w_gen(dtype: int, xp, w2, scale, zp, n_bits: int, ref_t, sa, bias, nor
     return pend if defer else pend.finish()
 
 
+# ------------------------------------------------------------------------------------------------ Gram-form weight search
+def gram_ok(T: int, O: int, K: int, a_bits: int, w_bits: int, P: int) -> bool:
+    """True when the Gram form takes this output-MSE weight search and pays (csrc/gram.hip: adalog_gram_ok)."""
+    return bool(_lib.load().adalog_gram_ok(int(T), int(O), int(K), int(a_bits), int(w_bits), int(P)))
+
+
+class GramState:
+    """G = X_int^T X_int, c = X_int^T (raw_out - bias), S0 = sum (raw_out - bias)^2 of one weight_fpcs call (csrc/gram.hip), built
+    once from the captured activation, the activation quantiser and raw_out; ``score_w`` then scores an FPCS step from it."""
+    __slots__ = ("ws", "T", "O", "K", "a_bits", "sa", "build_ms")
+
+    def __init__(self, x2, sa, za, a_bits: int, ref_t, bias):
+        lib = _lib.load()
+        x2, ref_t = _f32c(x2, "x"), _f32c(ref_t, "ref")
+        self.T, self.K = x2.shape
+        self.O = ref_t.shape[-2]
+        assert ref_t.shape[-1] == self.T
+        self.a_bits = int(a_bits)
+        self.sa = _f32c(sa, "sa").reshape(-1)
+        za = _f32c(za, "za").reshape(-1)
+        assert self.sa.numel() == 1 and za.numel() == 1, "Gram form: per-tensor activation quantiser"
+        nb = lib.adalog_gram_workspace_bytes(self.T, self.O, self.K, self.a_bits)
+        if nb < 0:
+            raise _lib.AdalogHipError("gram_build: shape not supported (gram_ok)")
+        self.ws = torch.empty((nb + 255) // 8 + 32, dtype=torch.float64, device=x2.device)
+        off = (-self.ws.data_ptr()) % 256                     # the kernels want a 256-byte aligned base
+        self.ws = self.ws.view(torch.uint8)[off:off + nb]
+        bias = None if bias is None else _f32c(bias, "bias")
+        if GEMM_EVENTS is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = lib.adalog_gram_build(x2.data_ptr(), self.T, self.K, x2.stride(0), self.sa.data_ptr(), za.data_ptr(), self.a_bits,
+                                   ref_t.data_ptr(), self.O, _ptr(bias), self.ws.data_ptr(), nb, _stream())
+        if GEMM_EVENTS is not None:
+            ev1.record()
+            GEMM_EVENTS.append((I8, self.T, self.O, self.K, 1, 1, ev0, ev1, "k_gram_build"))
+        _lib.check(rc, "adalog_gram_build")
+
+    def score_w(self, w2, scale, zp, w_bits: int, norm: float):
+        """scores [P, O] (final: no partial sums) for the candidates (scale, zp) [P, O] of every output row of w2 [O, K]."""
+        lib = _lib.load()
+        w2 = _f32c(w2, "weight")
+        scale, zp = _f32c(scale, "scale"), _f32c(zp, "zp")
+        P = scale.shape[0]
+        assert tuple(w2.shape) == (self.O, self.K) and scale.numel() == P * self.O and zp.numel() == P * self.O
+        scores = torch.empty((P, self.O), dtype=torch.float32, device=w2.device)
+        if GEMM_EVENTS is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = lib.adalog_gram_score_w(w2.data_ptr(), self.O, self.K, w2.stride(0), scale.data_ptr(), zp.data_ptr(), P, int(w_bits),
+                                     self.ws.data_ptr(), self.T, self.a_bits, self.sa.data_ptr(), float(norm), scores.data_ptr(),
+                                     _stream())
+        if GEMM_EVENTS is not None:
+            ev1.record()
+            GEMM_EVENTS.append((I8, self.T, self.O, self.K, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
+        _lib.check(rc, "adalog_gram_score_w")
+        return scores
+
+
 # ------------------------------------------------------------------------------------------------ FPCS pieces
 def topk(scores, k: int):
     scores = _f32c(scores, "scores")

@@ -43,6 +43,9 @@ FIXED_GRID_ONLY = os.environ.get('ADALOG_FIXED_GRID_ONLY', '1') != '0'   # fp8 d
 GEN_ACT_SEARCH = os.environ.get('ADALOG_GEN_ACT', '1') != '0'
 # uniform weight searches on the slab kernel: candidate operand generated in the kernel from the fp32 weight rows (1) or packed (0)
 GEN_W_SEARCH = os.environ.get('ADALOG_GEN_W', '1') != '0'
+# output-MSE weight searches against a per-tensor uniform activation quantiser: scored from the Gram matrix of the quantised
+# activation (csrc/gram.hip: built once per weight_fpcs call, K^2 instead of tokens * K multiply-adds per candidate row) where
+# backend.gram_ok says it pays; ADALOG_GRAM_W=0 keeps every such search on the token-form kernels
 SORTED_SELF_SEARCH = os.environ.get('ADALOG_SORTED_SELF', '1') != '0'
 RUN_DEAD_W_SELF = os.environ.get('ADALOG_DEAD_W_SELF', '0') == '1'
 MIXED_W_SEARCH = os.environ.get('ADALOG_MIXED_W', '1') != '0'     # bf16 activations x fp8 weight candidates (wide streaming kernel)
@@ -338,11 +341,30 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_w_self(s, z)
         else:
-            fixed = self._pack_x_fixed()
-            fn = lambda s, z, t: self._score_w(fixed, s, z, defer=True)
+            gram = self._gram_state()
+            if gram is not None:
+                norm = 1.0 / self._tokens_per_image()
+                fn = lambda s, z, t: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm)
+            else:
+                fixed = self._pack_x_fixed()
+                fn = lambda s, z, t: self._score_w(fixed, s, z, defer=True)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
         if res is not None:
             self._commit_w(res[0], res[1])
+
+    def _gram_state(self):
+        """The Gram-form state of an output-MSE weight search (linear.py:355-392 with the activation quantiser fixed for the whole
+        weight_fpcs call), or None where the token-form kernels serve the search: a non-uniform or per-channel activation
+        quantiser, a shape adalog_gram_ok declines (K not a multiple of 32, too few tokens per K for the form to pay)."""
+        be = backend.get()
+        aq = self.a_quantizer
+        if not hasattr(be, "gram_ok") or type(aq) is not UniformQuantizer or aq.channel_wise or aq.scale.numel() != 1:
+            return None
+        x2 = self._x2()
+        if not be.gram_ok(x2.shape[0], self.out_features, self.in_features, aq.n_bits, self.w_quantizer.n_bits, self.eq_n):
+            return None
+        return be.GramState(x2, aq.scale.data, aq.zero_point.data, aq.n_bits, self._ref2_t(),
+                            None if self.bias is None else self.bias.data)
 
     def activation_fpcs(self, fpcs_width=16, steps=6, search_strategy="output"):
         aq = self.a_quantizer

@@ -256,6 +256,24 @@ int adalog_score_w_gen(int dtype, const void* Xp, int T, int64_t Kp, const float
                        const float* zp, int P, int n_bits, const float* ref, const float* sa, const float* bias, float* partial,
                        int64_t partial_elems, void* stream);
 
+/* ---- K7, Gram form   _search_best_w_scale scored from the Gram matrix       reference quant_layers/linear.py:355-392,483-503
+ * The activation quantiser is fixed for the six scoring calls of a weight_fpcs call, and the score of candidate p for output row o
+ *   sum_t (r[t][o] - sigma x_int[t][:] . w[:])^2,  r = raw_out - bias, sigma = s_a s_w[p][o], w = clamp(rne(W[o]/s_w)+z_w, 0, 2^b-1) - z_w
+ * is the quadratic form  S0[o] - 2 sigma (w . c[o]) + sigma^2 (w^T G w)  with G = X_int^T X_int [K][K], c[o] = X_int^T r[:, o],
+ * S0[o] = sum_t r^2.  adalog_gram_build computes G, c, S0 ONCE per weight_fpcs call into `workspace` (exact integers: G in balanced
+ * int8 limbs, r rounded once per column to 30-bit fixed point; csrc/gram.hip has the error analysis); adalog_gram_score_w then scores
+ * one FPCS step's P candidates of every output row from it: K^2 multiply-adds per candidate row and limb instead of T K.
+ *   x fp32 [T][ldx] (K valid); sa / za: activation scale / zero point (device scalars); ref_t = raw_out TRANSPOSED [O][T];
+ *   bias [O] or null; W fp32 [O][ldw]; scale / zp [P][O]; scores [P][O] = -norm * (the sum above) -- final scores, no partials.
+ * adalog_gram_ok: whether the shape is taken AND pays (K % 32 == 0 and instantiated, <= 7-bit operands, limbs * K <= T / 2);
+ * the (T, O, K, a_bits) of a score call must be those of the build that filled the workspace (256-byte aligned). */
+int adalog_gram_ok(int T, int O, int K, int a_bits, int w_bits, int P);
+int64_t adalog_gram_workspace_bytes(int T, int O, int K, int a_bits);
+int adalog_gram_build(const float* x, int T, int K, int64_t ldx, const float* sa, const float* za, int a_bits, const float* ref_t,
+                      int O, const float* bias, void* workspace, int64_t workspace_bytes, void* stream);
+int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
+                        const void* workspace, int T, int a_bits, const float* sa, double norm, float* scores, void* stream);
+
 /* ---- K9   _search_best_w_scale_self                                   reference linear.py:296-309
  * scores[p][row] = -mean_i (w[row][i] - fq_p(w[row][i]))^2,  w: [rows][I], scale/zp: [P][rows]. */
 int adalog_score_w_self(const float* w, int rows, int I, const float* scale, const float* zp, int P, int n_bits,

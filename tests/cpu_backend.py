@@ -647,6 +647,41 @@ def adam_multi(params, grads, exp_avg, exp_avg_sq, step_dev, lr, beta1, beta2, e
     step_dev.add_(1.0)
 
 
+def gram_ok(T, O, K, a_bits, w_bits, P):
+    return K % 32 == 0 and a_bits <= 7 and w_bits <= 7 and P % 32 == 0   # (permissive: the CPU tier exercises the host path at toy shapes)
+
+
+class GramState:
+    """spec of ops.GramState (csrc/gram.hip): the Gram form of linear.py:355-392 in exact integer arithmetic -- x_int = q_a - z_a,
+    G = X^T X, the reference rounded once per output column to 30-bit fixed point, c = X^T r_fix, S0 = sum r_fix^2 -- and per step
+    scores[p][o] = -norm * (S0[o] - 2 sigma (w . c[o]) + sigma^2 (w^T G w)),  sigma = fl32(s_a * s_w[p][o])."""
+
+    def __init__(self, x2, sa, za, a_bits, ref_t, bias):
+        self.T, self.K = x2.shape
+        self.O = ref_t.shape[-2]
+        self.sa = sa.reshape(-1)[:1].clone()
+        z = torch.round(za.reshape(-1)[0])
+        X = ((torch.round(x2 / self.sa) + z).clamp(0, 2 ** a_bits - 1) - z).to(torch.int64)        # [T, K]
+        self.G = X.t() @ X
+        rb = ref_t.reshape(self.O, self.T) - (bias.view(-1, 1) if bias is not None else 0.0)        # fp32 subtract
+        am = rb.abs().amax(1)
+        e = torch.where(am > 0, 29 - torch.floor(torch.log2(am.double())), torch.zeros_like(am, dtype=torch.float64))
+        self.e = e
+        v = torch.round(rb.double() * torch.exp2(e).view(-1, 1)).to(torch.int64)                    # [O, T]
+        self.c = v @ X                                                                             # [O, K] int64
+        self.S0 = (v.double() ** 2).sum(1) * torch.exp2(-2 * e)
+
+    def score_w(self, w2, scale, zp, w_bits, norm):
+        O, K = w2.shape
+        P = scale.shape[0]
+        sc, z = scale.reshape(P, O, 1), torch.round(zp.reshape(P, O, 1))
+        wq = ((torch.round(w2.unsqueeze(0) / sc) + z).clamp(0, 2 ** w_bits - 1) - z).to(torch.int64)   # [P, O, K]
+        quad = torch.einsum("pok,kj,poj->po", wq, self.G, wq).double()
+        lin = torch.einsum("pok,ok->po", wq, self.c).double() * torch.exp2(-self.e).view(1, O)
+        sig = (self.sa.float() * sc.reshape(P, O).float()).double()
+        return (-norm * (self.S0.view(1, O) - 2.0 * sig * lin + sig * sig * quad)).float()
+
+
 def score_w_gen_ok(dtype, T, O, K, Kp, P):
     return K % 16 == 0 and P in (64, 128, 256)            # (permissive: the CPU tier exercises the host path at toy shapes)
 
