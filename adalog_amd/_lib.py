@@ -37,8 +37,10 @@ SIGNATURES = {
     "adalog_score_act_gen": (i32, [i32, p, i32, i64, p, i64, i32, i64, p, p, i32, i32, p, p, p, f64, p, i64, p, p]),
     "adalog_score_w_gen_ok": (i32, [i32, i32, i32, i32, i64, i32]),
     "adalog_score_w_gen": (i32, [i32, p, i32, i64, p, i32, i32, i64, p, p, i32, i32, p, p, p, p, i64, p]),
+    "adalog_gram_supported": (i32, [i32, i32, i32, i32, i32, i32]),
     "adalog_gram_ok": (i32, [i32, i32, i32, i32, i32, i32]),
     "adalog_gram_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "adalog_gram_limbs": (i32, [i32, i32]),
     "adalog_gram_build": (i32, [p, i32, i32, i64, p, p, i32, p, i32, p, p, i64, p]),
     "adalog_gram_score_w": (i32, [p, i32, i32, i64, p, p, i32, i32, p, i32, i32, p, f64, p, p]),
     "adalog_finish_scores": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p, i64, p]),

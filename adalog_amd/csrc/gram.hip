@@ -288,7 +288,7 @@ struct GramScoreArgs {
 
 // One pass of a wave over NB (<= CB) blocks of 32 candidates; every wave of the workgroup runs the same panel sequence (NB = 0: it
 // only helps moving the panels).  Two workgroups share a CU and run unsynchronised: one's row dots (VALU) issue under the other's MFMAs.
-template <int NJ, int NB, bool BIG>
+template <int NJ, int NB, bool BIG, bool TIE>
 __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, int blk0, int w, int lane, float sa, int stamp_slot) {
     constexpr int NPW = (NJ + 3) / 4;                      // 1 KiB pieces of a panel per wave
     constexpr int NRING = 4;                               // panels in the ring; the same LDS is the waves' staging area while generating
@@ -320,13 +320,18 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
             const float ginv = __builtin_amdgcn_rcpf(gs);
             const float glo = 128.0f - gz, ghi = 128.0f + (p.qmax - gz);
             const float* __restrict__ wr = p.W + (int64_t)o * p.ldw + 16 * h;
+            float4 nx[4];                                  // the row one 16-value slot ahead of the arithmetic
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nx[j] = *reinterpret_cast<const float4*>(wr + 4 * j);
 #pragma unroll 1
             for (int jt = 0; jt < NJ; ++jt) {
                 float xv[16];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v = *reinterpret_cast<const float4*>(wr + 32 * jt + 4 * j);
-                    xv[4 * j] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w;
+                for (int j = 0; j < 4; ++j) { xv[4 * j] = nx[j].x; xv[4 * j + 1] = nx[j].y; xv[4 * j + 2] = nx[j].z; xv[4 * j + 3] = nx[j].w; }
+                {
+                    const int jn = min(jt + 1, NJ - 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nx[j] = *reinterpret_cast<const float4*>(wr + 32 * jn + 4 * j);
                 }
                 float kq[16], dm = 0.0f;
 #pragma unroll
@@ -403,12 +408,15 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
     __syncthreads();                                       // every wave has read its fragments back: the staging area becomes the ring
     fetch(0); stash(0);
     fetch(1); stash(1);
+    fetch(2);
     int kt = 0;
     double sh = 1.0;
 #pragma unroll 1
     for (int pn = 0; pn < npanel; ++pn) {
         __syncthreads();                                   // panel pn is complete; panel pn - 2's slot is free
-        fetch(pn + 2);
+        // panel pn + 2 was fetched a whole panel ago (its L2 round trip is over); panel pn + 3's fetch gets the same lead
+        if (pn + 2 < npanel) stash(pn + 2);
+        fetch(pn + 3);
         if constexpr (NB > 0) {
             const uint8_t* pan = lds + (pn % NRING) * (NJ * 1024) + lane * 16;
             v16i acc[NB];
@@ -430,7 +438,12 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                     constexpr int b = decltype(bc)::value;
                     acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[jt % AD], bf[b][jt], acc[b], 0, 0, 0);
                 });
-                if constexpr (jt + AD < NJ) af[jt % AD] = gram_rd_after<(jt + AD) * 1024>(pa, acc[NB - 1]);
+                if constexpr (jt + AD < NJ) {
+                    // (TIE: accumulators in VGPRs -- naming them keeps the read behind the MFMAs that use its destination; with the
+                    // accumulators in AGPRs the tie would cost a copy out and back per read)
+                    if constexpr (TIE) af[jt % AD] = gram_rd_after<(jt + AD) * 1024>(pa, acc[NB - 1]);
+                    else af[jt % AD] = gram_rd<(jt + AD) * 1024>(pa);
+                }
             });
             // row dot: accumulator element e = G row 32 kt + 16 h + e = byte e of this lane's own fragment kt (kt is wave-uniform:
             // a branch picks the registers)
@@ -458,7 +471,6 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                 }
             });
         }
-        if (pn + 2 < npanel) stash(pn + 2);
         if (++kt == NJ) { kt = 0; sh *= 256.0; }
     }
     GRAM_STAMP(3);
@@ -478,8 +490,8 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
 #undef GRAM_STAMP
 }
 
-template <int NJ, int CB, bool BIG>
-__global__ __launch_bounds__(256, 2) void k_gram_score(GramScoreArgs p) {
+template <int NJ, int CB, bool BIG, int WGS_PER_CU>
+__global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // [4][NJ][64][16]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -493,11 +505,11 @@ __global__ __launch_bounds__(256, 2) void k_gram_score(GramScoreArgs p) {
         const int nbw = n / 4 + (w < (n & 3) ? 1 : 0);     // this wave's blocks (wave-uniform)
         const int blk0 = pass0 + w * (n / 4) + min(w, n & 3);
         const int slot = pass_no < 2 ? (int)blockIdx.x * 2 + pass_no : -1;
-        if (nbw == CB) gram_pass<NJ, CB, BIG>(p, lds, blk0, w, lane, sa, slot);
-        else if (nbw == 0) gram_pass<NJ, 0, BIG>(p, lds, blk0, w, lane, sa, slot);
-        else if (nbw == 1) gram_pass<NJ, 1, BIG>(p, lds, blk0, w, lane, sa, slot);
-        else if (CB > 2 && nbw == 2) gram_pass<NJ, (CB > 2 ? 2 : 1), BIG>(p, lds, blk0, w, lane, sa, slot);
-        else if (CB > 3 && nbw == 3) gram_pass<NJ, (CB > 3 ? 3 : 1), BIG>(p, lds, blk0, w, lane, sa, slot);
+        if (nbw == CB) gram_pass<NJ, CB, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (nbw == 0) gram_pass<NJ, 0, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (nbw == 1) gram_pass<NJ, 1, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (CB > 2 && nbw == 2) gram_pass<NJ, (CB > 2 ? 2 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (CB > 3 && nbw == 3) gram_pass<NJ, (CB > 3 ? 3 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
     }
 #endif
 }
@@ -561,22 +573,29 @@ static GramPlan gram_plan(int T, int O, int K, int a_bits) {
     return g;
 }
 
-static bool nj_supported(int nj) { return nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12 || nj == 16 || nj == 24; }
+static bool nj_supported(int nj) { return nj == 1 || nj == 2 || nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12 || nj == 16 || nj == 24; }
 
 }  // namespace
 
-// Whether the Gram form takes this weight search AND pays: K a supported multiple of 32, <= 7-bit operands, and at most half the
-// multiply-adds of the token form (limbs * K <= T / 2).  ADALOG_GRAM_W=0 switches it off, =2 drops the profitability test.
-extern "C" int adalog_gram_ok(int T, int O, int K, int a_bits, int w_bits, int P) {
-    static const int use = getenv("ADALOG_GRAM_W") ? atoi(getenv("ADALOG_GRAM_W")) : 1;
-    if (!use) return 0;
+// adalog_gram_supported: the Gram form can score this weight search (K a multiple of 32 with an instantiated kernel, <= 7-bit
+// operands, P a multiple of 32).  adalog_gram_ok: ... and it pays: at most half the multiply-adds of the token form
+// (limbs * K <= T / 2).
+extern "C" int adalog_gram_supported(int T, int O, int K, int a_bits, int w_bits, int P) {
     const GramPlan g = gram_plan(T, O, K, a_bits);
     if (!g.ok || !nj_supported(g.NJ) || w_bits < 2 || w_bits > 7 || P < 32 || P % 32 != 0) return 0;
     if ((int64_t)128 * ((1 << w_bits) - 1) * K >= (1 << 23)) return 0;           // accumulators must fit 24 bits (v_mul_i32_i24)
     if ((int64_t)O * P / 32 >= ((int64_t)1 << 30)) return 0;
-    if (use != 2 && (int64_t)g.NL * K * 2 > T) return 0;
     return 1;
 }
+
+extern "C" int adalog_gram_ok(int T, int O, int K, int a_bits, int w_bits, int P) {
+    if (!adalog_gram_supported(T, O, K, a_bits, w_bits, P)) return 0;
+    return (int64_t)g_limbs(T, a_bits) * K * 2 <= T ? 1 : 0;
+}
+
+/* int8 limbs of G = X_int^T X_int for T tokens of an a_bits-bit activation (what adalog_gram_score_w issues per candidate row:
+ * limbs * K^2 + 32 K multiply-adds -- measurement aid for the roofline accounting) */
+extern "C" int adalog_gram_limbs(int T, int a_bits) { return (T >= 1 && a_bits >= 2 && a_bits <= 7) ? g_limbs(T, a_bits) : -1; }
 
 extern "C" int64_t adalog_gram_workspace_bytes(int T, int O, int K, int a_bits) {
     const GramPlan g = gram_plan(T, O, K, a_bits);
@@ -590,7 +609,7 @@ extern "C" int adalog_gram_build(const float* x, int T, int K, int64_t ldx, cons
                                  const float* ref_t, int O, const float* bias, void* ws, int64_t ws_bytes, void* stream) {
     ADALOG_ARG_CHECK(x && sa && za && ref_t && ws, "gram_build: null pointer");
     const GramPlan g = gram_plan(T, O, K, a_bits);
-    ADALOG_ARG_CHECK(g.ok && nj_supported(g.NJ), "gram_build: shape not supported (adalog_gram_ok)");
+    ADALOG_ARG_CHECK(g.ok && nj_supported(g.NJ), "gram_build: shape not supported (adalog_gram_supported)");
     ADALOG_ARG_CHECK(ws_bytes >= g.total, "gram_build: workspace too small");
     ADALOG_ARG_CHECK(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 255) == 0, "gram_build: x rows / workspace must be aligned");
     hipStream_t st = (hipStream_t)stream;
@@ -634,8 +653,7 @@ static int device_cus_gram() {
 extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
                                    const void* ws, int T, int a_bits, const float* sa, double norm, float* scores, void* stream) {
     ADALOG_ARG_CHECK(W && scale && zp && ws && sa && scores, "gram_score_w: null pointer");
-    ADALOG_ARG_CHECK(adalog_gram_ok(T, O, K, a_bits, w_bits, P) || (getenv("ADALOG_GRAM_W") && atoi(getenv("ADALOG_GRAM_W")) == 0),
-                     "gram_score_w: shape not supported (adalog_gram_ok)");
+    ADALOG_ARG_CHECK(adalog_gram_supported(T, O, K, a_bits, w_bits, P), "gram_score_w: shape not supported (adalog_gram_supported)");
     ADALOG_ARG_CHECK(ldw >= K && ldw % 4 == 0 && ((uintptr_t)W & 15) == 0, "gram_score_w: weight rows must be 16-byte aligned");
     const GramPlan g = gram_plan(T, O, K, a_bits);
     ADALOG_ARG_CHECK(g.ok && nj_supported(g.NJ) && P % 32 == 0, "gram_score_w: shape not supported");
@@ -653,30 +671,31 @@ extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, co
     const bool big = w_bits > 4;
     hipStream_t st = (hipStream_t)stream;
     const int ncu = device_cus_gram();
-#define GRAM_LAUNCH(NJV, CBV, BIGV)                                                                               \
+#define GRAM_LAUNCH(NJV, CBV, BIGV, WPC)                                                                          \
     do {                                                                                                          \
-        const int per = 4 * CBV;                                                                                  \
-        int wgs = (a.nblk + per - 1) / per;                                                                       \
-        if (wgs > 2 * ncu) wgs = 2 * ncu;                                                                         \
+        /* every workgroup slot of the chip gets blocks (a workgroup with fewer than 4 CBV blocks runs one thin pass) */ \
+        int wgs = a.nblk < WPC * ncu ? a.nblk : WPC * ncu;                                                        \
         const size_t shm = (size_t)4 * NJV * 1024;                                                                \
         static bool attr_set = false;                                                                             \
         if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_score<NJV, CBV, BIGV>),               \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_score<NJV, CBV, BIGV, WPC>),          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
             attr_set = true;                                                                                      \
         }                                                                                                         \
         adalog_note_kernel("k_gram_score<i8>");                                                                   \
-        hipLaunchKernelGGL((k_gram_score<NJV, CBV, BIGV>), dim3((unsigned)wgs), dim3(256), shm, st, a);           \
+        hipLaunchKernelGGL((k_gram_score<NJV, CBV, BIGV, WPC>), dim3((unsigned)wgs), dim3(256), shm, st, a);      \
     } while (0)
-#define GRAM_LAUNCH_B(NJV, CBV) do { if (big) GRAM_LAUNCH(NJV, CBV, true); else GRAM_LAUNCH(NJV, CBV, false); } while (0)
+#define GRAM_LAUNCH_B(NJV, CBV, WPC) do { if (big) GRAM_LAUNCH(NJV, CBV, true, WPC); else GRAM_LAUNCH(NJV, CBV, false, WPC); } while (0)
     switch (g.NJ) {
-        case 3: GRAM_LAUNCH_B(3, 4); break;
-        case 4: GRAM_LAUNCH_B(4, 4); break;
-        case 6: GRAM_LAUNCH_B(6, 4); break;
-        case 8: GRAM_LAUNCH_B(8, 2); break;
-        case 12: GRAM_LAUNCH_B(12, 2); break;
-        case 16: GRAM_LAUNCH_B(16, 2); break;
-        case 24: GRAM_LAUNCH_B(24, 1); break;
+        case 1: GRAM_LAUNCH_B(1, 4, 2); break;
+        case 2: GRAM_LAUNCH_B(2, 4, 2); break;
+        case 3: GRAM_LAUNCH_B(3, 4, 2); break;
+        case 4: GRAM_LAUNCH_B(4, 4, 2); break;
+        case 6: GRAM_LAUNCH_B(6, 4, 2); break;
+        case 8: GRAM_LAUNCH_B(8, 2, 2); break;
+        case 12: GRAM_LAUNCH_B(12, 2, 2); break;
+        case 16: GRAM_LAUNCH_B(16, 2, 2); break;
+        case 24: GRAM_LAUNCH_B(24, 2, 1); break;
         default: ADALOG_ARG_CHECK(false, "gram_score_w: K not instantiated");
     }
 #undef GRAM_LAUNCH_B

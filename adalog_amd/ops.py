@@ -6,6 +6,7 @@ stream.  No function here computes anything with torch ops, and none synchronise
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -607,8 +608,14 @@ def score_w_gen(dtype: int, xp, w2, scale, zp, n_bits: int, ref_t, sa, bias, nor
 
 # ------------------------------------------------------------------------------------------------ Gram-form weight search
 def gram_ok(T: int, O: int, K: int, a_bits: int, w_bits: int, P: int) -> bool:
-    """True when the Gram form takes this output-MSE weight search and pays (csrc/gram.hip: adalog_gram_ok)."""
-    return bool(_lib.load().adalog_gram_ok(int(T), int(O), int(K), int(a_bits), int(w_bits), int(P)))
+    """True when the Gram form scores this output-MSE weight search (csrc/gram.hip): the shape is supported and it pays
+    (adalog_gram_ok).  ADALOG_GRAM_W=0: never; ADALOG_GRAM_W=2: wherever the shape is supported (tests drive the kernels at the
+    golden traces' toy shapes with it)."""
+    mode = os.environ.get("ADALOG_GRAM_W", "1")
+    if mode == "0":
+        return False
+    fn = _lib.load().adalog_gram_supported if mode == "2" else _lib.load().adalog_gram_ok
+    return bool(fn(int(T), int(O), int(K), int(a_bits), int(w_bits), int(P)))
 
 
 class GramState:
@@ -640,7 +647,8 @@ class GramState:
                                    ref_t.data_ptr(), self.O, _ptr(bias), self.ws.data_ptr(), nb, _stream())
         if GEMM_EVENTS is not None:
             ev1.record()
-            GEMM_EVENTS.append((I8, self.T, self.O, self.K, 1, 1, ev0, ev1, "k_gram_build"))
+            # issued work: G (K x K, symmetry not used) + four reference limbs x (O x K), each over the T tokens
+            GEMM_EVENTS.append((I8, self.T, self.K + 4 * self.O, self.K, 1, 1, ev0, ev1, "k_gram_build"))
         _lib.check(rc, "adalog_gram_build")
 
     def score_w(self, w2, scale, zp, w_bits: int, norm: float):
@@ -659,7 +667,10 @@ class GramState:
                                      _stream())
         if GEMM_EVENTS is not None:
             ev1.record()
-            GEMM_EVENTS.append((I8, self.T, self.O, self.K, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
+            # flops as ISSUED (limbs * K^2 + the 32-row w.c panel per candidate row), not the token form's 2 T K O P: a roofline
+            # fraction of this kernel is a fraction of the work it does
+            rows = lib.adalog_gram_limbs(self.T, self.a_bits) * self.K + 32
+            GEMM_EVENTS.append((I8, rows, self.O, self.K, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
         _lib.check(rc, "adalog_gram_score_w")
         return scores
 

@@ -341,16 +341,22 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_w_self(s, z)
         else:
-            gram = self._gram_state()
-            if gram is not None:
-                norm = 1.0 / self._tokens_per_image()
-                fn = lambda s, z, t: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm)
-            else:
-                fixed = self._pack_x_fixed()
-                fn = lambda s, z, t: self._score_w(fixed, s, z, defer=True)
+            score = self._w_scorer()
+            fn = lambda s, z, t: score(s, z, defer=True)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
         if res is not None:
             self._commit_w(res[0], res[1])
+
+    def _w_scorer(self):
+        """The scoring function (scale, zp, defer=False) -> scores [P, O] | PendingScores of one output-MSE weight_fpcs call, with
+        whatever is fixed for the call (the activation quantiser: linear.py:483-503) prepared once: the Gram-form state where it
+        pays, else the packed activation image of the token-form kernels."""
+        gram = self._gram_state()
+        if gram is not None:
+            norm = 1.0 / self._tokens_per_image()
+            return lambda s, z, defer=False: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm)
+        fixed = self._pack_x_fixed()
+        return lambda s, z, defer=False: self._score_w(fixed, s, z, defer=defer)
 
     def _gram_state(self):
         """The Gram-form state of an output-MSE weight search (linear.py:355-392 with the activation quantiser fixed for the whole

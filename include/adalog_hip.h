@@ -265,10 +265,13 @@ int adalog_score_w_gen(int dtype, const void* Xp, int T, int64_t Kp, const float
  * one FPCS step's P candidates of every output row from it: K^2 multiply-adds per candidate row and limb instead of T K.
  *   x fp32 [T][ldx] (K valid); sa / za: activation scale / zero point (device scalars); ref_t = raw_out TRANSPOSED [O][T];
  *   bias [O] or null; W fp32 [O][ldw]; scale / zp [P][O]; scores [P][O] = -norm * (the sum above) -- final scores, no partials.
- * adalog_gram_ok: whether the shape is taken AND pays (K % 32 == 0 and instantiated, <= 7-bit operands, limbs * K <= T / 2);
- * the (T, O, K, a_bits) of a score call must be those of the build that filled the workspace (256-byte aligned). */
+ * adalog_gram_supported: the shape can be scored this way (K % 32 == 0 and instantiated, <= 7-bit operands, P % 32 == 0);
+ * adalog_gram_ok: ... and it pays (limbs * K <= T / 2: at most half the token form's multiply-adds).
+ * The (T, O, K, a_bits) of a score call must be those of the build that filled the workspace (256-byte aligned). */
+int adalog_gram_supported(int T, int O, int K, int a_bits, int w_bits, int P);
 int adalog_gram_ok(int T, int O, int K, int a_bits, int w_bits, int P);
 int64_t adalog_gram_workspace_bytes(int T, int O, int K, int a_bits);
+int adalog_gram_limbs(int T, int a_bits);   /* int8 limbs of G: a score call issues limbs * K^2 + 32 K multiply-adds per candidate row */
 int adalog_gram_build(const float* x, int T, int K, int64_t ldx, const float* sa, const float* za, int a_bits, const float* ref_t,
                       int O, const float* bias, void* workspace, int64_t workspace_bytes, void* stream);
 int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,

@@ -676,8 +676,10 @@ class GramState:
         P = scale.shape[0]
         sc, z = scale.reshape(P, O, 1), torch.round(zp.reshape(P, O, 1))
         wq = ((torch.round(w2.unsqueeze(0) / sc) + z).clamp(0, 2 ** w_bits - 1) - z).to(torch.int64)   # [P, O, K]
-        quad = torch.einsum("pok,kj,poj->po", wq, self.G, wq).double()
-        lin = torch.einsum("pok,ok->po", wq, self.c).double() * torch.exp2(-self.e).view(1, O)
+        # (fp64 BLAS on integers: G < 2^31, |w| < 2^7, K <= 2^11 -- every product and partial sum stays below 2^53, i.e. exact)
+        wd = wq.double()
+        quad = ((wd.view(P * O, K) @ self.G.double()).view(P, O, K) * wd).sum(-1)
+        lin = (wd * self.c.double().view(1, O, K)).sum(-1) * torch.exp2(-self.e).view(1, O)
         sig = (self.sa.float() * sc.reshape(P, O).float()).double()
         return (-norm * (self.S0.view(1, O) - 2.0 * sig * lin + sig * sig * quad)).float()
 

@@ -51,7 +51,7 @@ def _log(name, **kw):
 # file -- checks that every production label was hit by some case, so a dispatch regression cannot stay green.
 FALLBACK = {"k_gemm_cand", "k_gemm_cand_glds", "k_gemm_score", ""}
 SEEN = {}
-REQUIRED = {"k_gemm_slab_wgen<fp8>", "k_gemm_slab_wgen<i8>", "k_gemm_slab128_wgen<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
+REQUIRED = {"k_gram_score<i8>", "k_gemm_slab_wgen<fp8>", "k_gemm_slab_wgen<i8>", "k_gemm_slab128_wgen<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
             "k_gemm_slab128_gen<fp8>", "k_act_fused_asm<12,4,bf16>", "k_act_fused_asm<12,3,bf16>", "k_act_fused_asm<8,4,bf16>",
             "k_act_fused_asm<4,4,bf16>", "k_gemm_stream<bf16xfp8>", "k_gemm_stream<bf16>", "k_gemm_grpw_gen<fp8>", "k_gemm_grpw_gen<i8>",
             "k_gemm_grpk8<bf16xfp8>", "k_gemm_grpk<bf16>", "k_gemm_win_gen<fp8>", "k_gemm_winb<bf16xfp8>", "k_gemm_avq<13,bf16>",
@@ -101,7 +101,10 @@ LINEAR = [  # tag, I, O, n_V, tokens per image, images, bits
     # K = 1024: swin stage 3 (7 x 7 tokens per image)
     ("swin_base.l3.qkv", 1024, 3072, 3, 49, 32, 3),
 ]
-LINEAR_KERNELS = {          # case -> (weight search, activation search) labels that production dispatches there
+# cases whose weight search production scores from the Gram matrix (K % 32 == 0 and limbs * K <= tokens / 2: csrc/gram.hip)
+GRAM_CASES = {"deit_small.qkv-w4", "deit_small.proj-w4", "vit_base.qkv-w4", "deit_base.proj-w3", "vit_base.fc1-w4", "swin_base.reduction-w3",
+              "swin_base.l0.fc1-w3", "swin_base.l0.fc1@128img-w3", "deit_small.qkv-w6", "deit_small.fc1-w6"}
+LINEAR_KERNELS = {          # case -> (weight search [token form], activation search) labels dispatched there
     "deit_small.qkv-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),
     "deit_small.proj-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),
     "vit_base.qkv-w4": (("k_gemm_slab128_wgen<fp8>",), ("k_gemm_slab128_gen<fp8>",)),
@@ -142,6 +145,10 @@ def test_linear_scores_full_shape(tag, I, Oc, n_V, T, N, bits):
     case = f"{tag}-w{bits}"
     small = N * T < 64                                               # (the head: too few rows for the production kernels)
     with torch.no_grad():
+        # the weight search as weight_fpcs dispatches it (round 5: the Gram form where adalog_gram_ok takes the shape) ...
+        got_wp = lay._w_scorer()(cw_s, cw_z)[SUB]
+        kwp = _kern(case, "w_production") if not small else ""
+        # ... and the token form (what runs where the Gram form declines: ADALOG_GRAM_W=0, few tokens per K, K % 32 != 0)
         got_w = lay._score_w(lay._pack_x_fixed(), cw_s, cw_z)[SUB]
         kw = _kern(case, "w") if not small else ""
         from adalog_amd.quant_layers.linear import FP8_WEIGHT_SEARCH_MAX_K
@@ -152,9 +159,12 @@ def test_linear_scores_full_shape(tag, I, Oc, n_V, T, N, bits):
         ka = _kern(case, "a") if not small else ""
         got_ws = lay._score_w_self(cw_s, cw_z)[SUB]
         got_as = lay._score_a_self(ca_s, ca_z)[SUB]
-    errs = dict(w=_rel(got_w, ref_w), a=_rel(got_a, ref_a), w_self=_rel(got_ws, ref_ws), a_self=_rel(got_as, ref_as))
-    _log(case, kernel_w=kw, kernel_a=ka, **errs)
+    errs = dict(w=_rel(got_w, ref_w), w_production=_rel(got_wp, ref_w), a=_rel(got_a, ref_a), w_self=_rel(got_ws, ref_ws),
+                a_self=_rel(got_as, ref_as))
+    _log(case, kernel_w=kw, kernel_w_production=kwp, kernel_a=ka, **errs)
     assert max(errs.values()) <= RTOL, errs
+    if case in GRAM_CASES:
+        _expect(case, "w_production", "k_gram_score<i8>")
     if case in LINEAR_KERNELS:
         _expect(case, "w", *LINEAR_KERNELS[case][0])
         _expect(case, "a", *LINEAR_KERNELS[case][1])

@@ -1611,3 +1611,70 @@ def test_qkv_split_quant_matches_the_separate_route(ops, shape):
     gx2, gs2 = ops.qkv_merge_quant_backward([gys[0], None, gys[2]], x, H, scales, zps, nb)      # a part without gradient
     assert torch.equal(gx2.reshape(B, N, 3, H, D)[:, :, 1], torch.zeros(B, N, H, D, device=DEV)) and float(gs2[1].abs().max()) == 0.0
 
+
+
+# ------------------------------------------------------------------------------------------------ Gram-form weight search (round 5)
+GRAM_SHAPES = [  # T, O, K, tokens per image
+    (6304, 1152, 384, 197),      # deit_small qkv
+    (6304, 384, 384, 197),       # deit_small proj: 3 blocks per workgroup (thin passes)
+    (6304, 576, 192, 197),       # deit_tiny qkv (NJ = 6, four blocks per wave)
+    (1000, 200, 96, 125),        # NJ = 3, tokens and rows that are no multiple of any tile, no bias
+    (25088, 768, 256, 784),      # swin_base stage 1 (NJ = 8)
+    (6272, 1536, 512, 196),      # swin_base stage 2 (NJ = 16)
+    (3136, 96, 32, 3136),        # NJ = 1
+    (1568, 100, 64, 49),         # NJ = 2
+]
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+@pytest.mark.parametrize("T,O,K,tok", GRAM_SHAPES)
+def test_gram_score_matches_spec_and_token_form(ops, bits, T, O, K, tok):
+    """adalog_gram_build + adalog_gram_score_w (G = X^T X, c = X^T r, S0 once; K^2 multiply-adds per candidate row and limb) against
+    (1) the integer-arithmetic specification tests/cpu_backend.GramState -- the two must agree to fp64 rounding, i.e. the kernels'
+    integer pipeline is exact -- and (2) the token-form slab kernel where it takes the shape; weight values planted on rounding ties."""
+    from adalog_amd.ops import FP8, I8
+    gen = g(12000 + bits + T + O + K)
+    P = 128
+    x = torch.randn(T, K, generator=gen)
+    x[:, : max(1, K // 8)] *= 3.0
+    W = torch.randn(O, K, generator=gen) * 0.05
+    b = torch.randn(O, generator=gen) * 0.1 if K != 96 else None
+    qmax = 2 ** bits - 1
+    w_lo, w_hi = W.min(1).values, W.max(1).values
+    sc = ((w_hi - w_lo) / qmax).view(1, O) * torch.linspace(0.6, 1.2, P).view(P, 1)
+    zp = torch.round(-w_lo.view(1, O) / sc).clamp(0, qmax)
+    W[:, 5] = sc[17] * 2.5                                              # exact ties of candidate 17 (and near-ties of its neighbours)
+    W[:, 9] = sc[90] * -1.5
+    a_s = torch.tensor([x.abs().max().item() * 1.2 / qmax])
+    a_z = torch.tensor([float(2 ** (bits - 1) - 1)])
+    ref = torch.nn.functional.linear(x, W, b)
+    ref[:, 3] *= 40.0                                                   # one loud output column: the per-column fixed-point exponent
+    d = lambda t_: t_.to(DEV).contiguous()
+    assert ops._lib.load().adalog_gram_supported(T, O, K, bits, bits, P)
+    ref_t = d(ref.t())
+    st = ops.GramState(d(x), d(a_s), d(a_z), bits, ref_t, None if b is None else d(b))
+    got = st.score_w(d(W), d(sc), d(zp), bits, 1.0 / tok)
+    assert _last_kernel() == "k_gram_score<i8>"
+    spec = CB.GramState(x, a_s, a_z, bits, ref.t().contiguous(), b).score_w(W, sc, zp, bits, 1.0 / tok)
+    assert got.shape == spec.shape == (P, O)
+    assert rel_err(got.cpu(), spec) <= 2e-7                             # fp32 output rounding only
+    dt = FP8 if bits <= 4 else I8
+    xp = ops.pack_uniform(d(x).unsqueeze(0), d(a_s), d(a_z), 1, 0, 1, 0, 0, bits, dt)
+    if ops.score_w_gen_ok(dt, T, O, K, xp.shape[-1], P):
+        want = ops.score_w_gen(dt, xp, d(W), d(sc), d(zp), bits, ref_t, d(a_s), None if b is None else d(b), 1.0 / tok)
+        assert rel_err(got.cpu(), want.cpu()) <= 2e-6
+    # a second step from the same state (the FPCS loop re-uses it) with other candidates, and determinism of the first
+    got2 = st.score_w(d(W), d(sc * 1.01), d(zp), bits, 1.0 / tok)
+    spec2 = CB.GramState(x, a_s, a_z, bits, ref.t().contiguous(), b).score_w(W, sc * 1.01, zp, bits, 1.0 / tok)
+    assert rel_err(got2.cpu(), spec2) <= 2e-7
+    assert torch.equal(got, st.score_w(d(W), d(sc), d(zp), bits, 1.0 / tok))
+
+
+def test_gram_form_rejects_what_it_cannot_score(ops):
+    lib = ops._lib.load()
+    assert not lib.adalog_gram_supported(6304, 1152, 400, 4, 4, 128)    # K % 32
+    assert not lib.adalog_gram_supported(6304, 1152, 384, 8, 4, 128)    # q - z of an 8-bit activation does not fit int8
+    assert not lib.adalog_gram_supported(6304, 1152, 384, 4, 4, 100)    # candidates per row: multiples of 32
+    assert lib.adalog_gram_supported(197, 1152, 384, 4, 4, 128) and not lib.adalog_gram_ok(197, 1152, 384, 4, 4, 128)   # one image: does not pay
+    assert lib.adalog_gram_ok(6304, 1152, 384, 4, 4, 128) and lib.adalog_gram_limbs(6304, 4) == 3 and lib.adalog_gram_limbs(6304, 6) == 4
+    assert lib.adalog_gram_build(None, 6304, 384, 384, None, None, 4, None, 1152, None, None, 0, None) == -1

@@ -51,6 +51,28 @@ def test_linear_traces_int8_storage(golden, bits, monkeypatch):
     _log(f"linear_w{bits}a{bits}_i8", r)
 
 
+@pytest.mark.parametrize("name", ["linear_w3a3", "linear_w4a4", "linear_w6a6"])     # (the ragged fixture has K = 24: token form)
+def test_linear_traces_gram_form(golden, name, monkeypatch):
+    """The reference's golden weight-search traces through the Gram-form kernels (csrc/gram.hip; ADALOG_GRAM_W=2 takes every
+    supported shape, also these toy ones): same bars as the token form."""
+    from adalog_amd import _lib
+    monkeypatch.setenv("ADALOG_GRAM_W", "2")
+    seen = []
+    orig = _lib.load().adalog_last_kernel
+    from adalog_amd import ops
+    real = ops.GramState.score_w
+
+    def spy(self, *a, **k):
+        r = real(self, *a, **k)
+        seen.append(orig().decode())
+        return r
+    monkeypatch.setattr(ops.GramState, "score_w", spy)
+    r = TR.replay_linear(golden, name, DEV)
+    assert r["calls"] == 48
+    assert len(seen) >= 18 and set(seen) == {"k_gram_score<i8>"}, seen[:3]
+    _log(name + "_gram", r)
+
+
 @pytest.mark.parametrize("bits", [3, 4, 6])
 def test_channelwise_traces(golden, bits):
     r = TR.replay_channelwise(golden, bits, DEV)

@@ -133,7 +133,9 @@ def _linear_observer(lay, rp, dev):
         elif kind == "w_out":
             _set_uniform(lay.a_quantizer, p.a_scale, p.a_zp)
             lay.w_quantizer._zp_on_grid = True
-            rp.check(lay._score_w(lay._pack_x_fixed(), _pc(a, dev), _pc(b, dev)), True, en["w_out"])
+            # (as weight_fpcs dispatches it: the Gram form where backend.gram_ok takes the shape -- ADALOG_GRAM_W=2 at these toy
+            # sizes --, else the token-form kernels)
+            rp.check(lay._w_scorer()(_pc(a, dev), _pc(b, dev)), True, en["w_out"])
         elif kind == "a_out":
             _set_uniform(lay.w_quantizer, p.w_scale, p.w_zp)
             dt = lay._int_dt(lay.raw_input.numel() // lay.in_features)

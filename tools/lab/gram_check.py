@@ -88,7 +88,12 @@ def case(T, O, K, bits, P=128, tokens=197, check_oracle=False, seed=0):
     return res
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "prof":
+    case(6304, 1152, 384, 4)
+    case(6304, 384, 384, 4)
+    case(6304, 2304, 768, 4)
+    case(100352, 384, 128, 4, tokens=3136)
+elif __name__ == "__main__":
     case(197 * 4, 96, 96, 4, check_oracle=True)
     case(197 * 8, 384, 384, 4, check_oracle=True)
     case(197 * 8, 384, 384, 6, check_oracle=True)
