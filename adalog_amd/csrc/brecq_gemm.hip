@@ -191,7 +191,11 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
             }
             sa_step = BQ_KS * (int)p.lda * 4;
         } else {
-            ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Ab + (int64_t)m0 * p.lda), 0, 0x7ffffffe, 0x00020000);
+            // the resource ends with the last valid element of this group's matrix: with K % 16 != 0 the last K-step of the LAST row
+            // would otherwise fetch up to 60 bytes past the tensor (masked by ktail, but still an out-of-bounds address); dwords
+            // past the end read as zero, like the T form's
+            const int64_t abytes = ((int64_t)(p.M - 1 - m0) * p.lda + p.K) * 4;
+            ra = __builtin_amdgcn_make_buffer_rsrc((void*)(Ab + (int64_t)m0 * p.lda), 0, (int)(abytes > 0x7ffffffe ? 0x7ffffffe : abytes), 0x00020000);
 #pragma unroll
             for (int q = 0; q < QA; ++q) {
                 const int row = min((w + NW * q) * 16 + lrow, p.M - 1 - m0);  // edge rows: re-read the last valid row (never stored)
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
             }
             sb_step = BQ_KS * (int)p.ldb * 4;
         } else {
-            rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Bb + (int64_t)n0 * p.ldb), 0, 0x7ffffffe, 0x00020000);
+            const int64_t bbytes = ((int64_t)(p.N - 1 - n0) * p.ldb + p.K) * 4;           // (as for A: ends with the last valid element)
+            rb = __builtin_amdgcn_make_buffer_rsrc((void*)(Bb + (int64_t)n0 * p.ldb), 0, (int)(bbytes > 0x7ffffffe ? 0x7ffffffe : bbytes), 0x00020000);
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const int row = min((w + NW * q) * 16 + lrow, p.N - 1 - n0);
@@ -625,11 +630,14 @@ BqPlan bq_plan(int M, int N, int K, int G, int allow_split, int products, int bp
 template <int RI, int CJ, int WN, bool TA, bool TB, int PA, int PB, bool KT>
 int bq_go(const BqArgs& a, int wgs, hipStream_t st) {
     const size_t lds = (size_t)BQ_NS * (64 * RI * 64 + 32 * CJ * WN * (PB == 0 ? 96 : 64));
-    static bool attr_done = false;
-    if (!attr_done) {
+    static unsigned long long attr_done = 0;                 // one bit per device: the attribute is per device, not per process
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done & bit)) {
         if (hipFuncSetAttribute((const void*)k_bq_gemm<RI, CJ, WN, TA, TB, PA, PB, KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return -2;
-        attr_done = true;
+        attr_done |= bit;
     }
     hipLaunchKernelGGL((k_bq_gemm<RI, CJ, WN, TA, TB, PA, PB, KT>), dim3(wgs), dim3(128 * WN), lds, st, a);
     return 0;

@@ -108,30 +108,48 @@ __device__ __forceinline__ double block_sum_d(double v, double* sm) {
     return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-__global__ __launch_bounds__(256) void k_gram_rfix(const float* __restrict__ ref_t, int T, int64_t Tp, int O, const float* __restrict__ bias,
-                                                   int8_t* __restrict__ rl, double* __restrict__ s0, double* __restrict__ cscl) {
+// pass 1: amax[o] = max_t |raw_out[t][o] - bias[o]| as the bits of a non-negative float (integer order = float order)
+__global__ __launch_bounds__(256) void k_gram_rmax(const float* __restrict__ ref_t, int T, int chunk, const float* __restrict__ bias,
+                                                   unsigned int* __restrict__ amax) {
 #pragma clang fp contract(off)
-    __shared__ double smd[4];
     __shared__ float smf[4];
     const int o = blockIdx.x, tid = threadIdx.x;
+    const int m0 = blockIdx.y * chunk, m1 = min(T, m0 + chunk);
     const float* r = ref_t + (int64_t)o * T;
     const float b = bias ? bias[o] : 0.0f;
     float am = 0.0f;
-    for (int m = tid; m < T; m += 256) am = fmaxf(am, fabsf(r[m] - b));
+    for (int m = m0 + tid; m < m1; m += 256) am = fmaxf(am, fabsf(r[m] - b));
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) am = fmaxf(am, __shfl_xor(am, d));
     if ((tid & 63) == 0) smf[tid >> 6] = am;
     __syncthreads();
-    am = fmaxf(fmaxf(smf[0], smf[1]), fmaxf(smf[2], smf[3]));
+    if (tid == 0) {
+        am = fmaxf(fmaxf(smf[0], smf[1]), fmaxf(smf[2], smf[3]));
+        if (am == am) atomicMax(amax + o, __float_as_uint(am));          // (NaN: left out, as fmaxf does)
+    }
+}
+
+// pass 2: the limb planes of chunk blockIdx.y of row o, and that chunk's share of S0 (s0p[o][chunk]: summed in a fixed order later)
+__global__ __launch_bounds__(256) void k_gram_rfix(const float* __restrict__ ref_t, int T, int64_t Tp, int O, int chunk, int nchunk,
+                                                   const float* __restrict__ bias, const unsigned int* __restrict__ amax,
+                                                   int8_t* __restrict__ rl, double* __restrict__ s0p, double* __restrict__ cscl) {
+#pragma clang fp contract(off)
+    __shared__ double smd[4];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int m0 = blockIdx.y * chunk, m1 = (int)min((int64_t)Tp, (int64_t)m0 + chunk);       // chunk is a multiple of 128: the last one pads
+    const float* r = ref_t + (int64_t)o * T;
+    const float b = bias ? bias[o] : 0.0f;
+    const float am = __uint_as_float(amax[o]);
     // e: am * 2^e in [2^29, 2^30)   (am == 0 or non-finite: e = 0, every limb 0 / garbage in, garbage out as in the token form)
     int e = 0;
     if (am > 0.0f && am < 3.0e38f) e = RFIX_BITS - ilogbf(am);
+    const double sc = ldexp(1.0, e);
     double acc = 0.0;
     int8_t* l0 = rl + (int64_t)o * Tp;
     const int64_t plane = (int64_t)O * Tp;
-    for (int m = tid; m < Tp; m += 256) {
+    for (int m = m0 + tid; m < m1; m += 256) {
         int v = 0;
-        if (m < T) v = (int)rint((double)(r[m] - b) * ldexp(1.0, e));     // exact product; one rounding to the 2^-e grid
+        if (m < T) v = (int)rint((double)(r[m] - b) * sc);               // exact product; one rounding to the 2^-e grid
         acc += (double)v * (double)v;
         int rest = v;
 #pragma unroll
@@ -142,77 +160,64 @@ __global__ __launch_bounds__(256) void k_gram_rfix(const float* __restrict__ ref
         }
     }
     const double tot = block_sum_d(acc, smd);
-    if (tid == 0) { s0[o] = ldexp(tot, -2 * e); cscl[o] = ldexp(1.0, -e); }
+    if (tid == 0) {
+        s0p[(int64_t)o * nchunk + blockIdx.y] = ldexp(tot, -2 * e);
+        if (blockIdx.y == 0) cscl[o] = ldexp(1.0, -e);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ C = A . B^T over tokens (int8)
-// A [NL planes][RA][ld], B [RB][ld] int8, token-contiguous; part[z][RA][RB] int64 = sum over the z-th token range.  A lane
-// (row = lane & 31, half = lane >> 5) loads 64 consecutive tokens of its row per 128-token step (the order of the contraction index
-// is free as long as A and B agree): four MFMAs per block pair.  Workgroup = 4 waves = 128 x 128 outputs, wave = 64 x 64.
-template <int NL>
-__global__ __launch_bounds__(256) void k_gram_mm(const int8_t* __restrict__ A, const int8_t* __restrict__ B, int RA, int RB, int64_t ld,
-                                                 int64_t plane, int steps_per_split, int steps_total, long long* __restrict__ part) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// A [RA][ld], B [RB][ld] int8, token-contiguous; part[z][RA][RB] int32 = the sum over the z-th token range (<= 512 steps of 128
+// tokens: |sum| < 2^31).  ONE wave per workgroup owns a (32 BI) x (32 BJ) tile in registers and streams both operands straight
+// from memory: a lane (row = lane & 31, half = lane >> 5) loads 64 consecutive tokens of each of its rows per step (the order of the
+// contraction index is free as long as A and B agree) -- four MFMAs per block pair and step.  No LDS, no barrier.  The reference's
+// limb planes are simply more rows of A (RA = 4 O); the limbs are recombined when the splits are summed (k_gram_fin_c).
+template <int BI, int BJ>
+__global__ __launch_bounds__(64) void k_gram_mm(const int8_t* __restrict__ A, const int8_t* __restrict__ B, int RA, int RB, int64_t ld,
+                                                int steps_per_split, int steps_total, int* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const int ra0 = blockIdx.x * 128 + (w >> 1) * 64, rb0 = blockIdx.y * 128 + (w & 1) * 64;
+    const int ra0 = blockIdx.x * (32 * BI), rb0 = blockIdx.y * (32 * BJ);
     const int z = blockIdx.z;
     const int st0 = z * steps_per_split, st1 = min(st0 + steps_per_split, steps_total);
-    long long acc64[2][2][16];
+    v16i acc[BI][BJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < BJ; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc64[i][j][e] = 0;
-    const int8_t* pa[2];
-    const int8_t* pb[2];
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
+    const int8_t* pa[BI];
+    const int8_t* pb[BJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        pa[i] = A + (int64_t)min(ra0 + 32 * i + r, RA - 1) * ld + h * 64;
-        pb[i] = B + (int64_t)min(rb0 + 32 * i + r, RB - 1) * ld + h * 64;
-    }
-    for (int l = 0; l < NL; ++l) {
-        v16i acc[2][2];
+    for (int i = 0; i < BI; ++i) pa[i] = A + (int64_t)min(ra0 + 32 * i + r, RA - 1) * ld + h * 64;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < BJ; ++j) pb[j] = B + (int64_t)min(rb0 + 32 * j + r, RB - 1) * ld + h * 64;
+    for (int st = st0; st < st1; ++st) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int q = 0; q < 4; ++q) {
+            v4i fa[BI], fb[BJ];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-        // int32 safety: |sum| <= 128 * 127 * 128 * steps: the host keeps steps_per_split <= 512
-        for (int st = st0; st < st1; ++st) {
+            for (int i = 0; i < BI; ++i) fa[i] = *reinterpret_cast<const v4i*>(pa[i] + (int64_t)st * 128 + q * 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                v4i fa[2], fb[2];
+            for (int j = 0; j < BJ; ++j) fb[j] = *reinterpret_cast<const v4i*>(pb[j] + (int64_t)st * 128 + q * 16);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    fa[i] = *reinterpret_cast<const v4i*>(pa[i] + l * plane + (int64_t)st * 128 + q * 16);
-                    fb[i] = *reinterpret_cast<const v4i*>(pb[i] + (int64_t)st * 128 + q * 16);
-                }
+            for (int i = 0; i < BI; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            }
+                for (int j = 0; j < BJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc64[i][j][e] += ((long long)acc[i][j][e]) << (8 * l);
     }
-    long long* out = part + (int64_t)z * RA * RB;
+    int* out = part + (int64_t)z * RA * RB;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < BI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < BJ; ++j) {
             const int col = rb0 + 32 * j + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = ra0 + 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                if (row < RA && col < RB) out[(int64_t)row * RB + col] = acc64[i][j][e];
+                if (row < RA && col < RB) out[(int64_t)row * RB + col] = acc[i][j][e];
             }
         }
 }
@@ -220,14 +225,14 @@ __global__ __launch_bounds__(256) void k_gram_mm(const int8_t* __restrict__ A, c
 // ------------------------------------------------------------------------------------------------ finalise G and c
 // gfrag[l][kt][jt][lane][16]: lane = (tile row r', half h); tile row r' = 8 i + 4 h' + j holds G row 32 kt + 16 h' + 4 i + j, so
 // that accumulator element e = 4 i + j of lane (., h') is G row 32 kt + 16 h' + e -- the k of byte e of that lane's B fragment kt.
-__global__ __launch_bounds__(256) void k_gram_fin_g(const long long* __restrict__ part, int splits, int K, int NL, int8_t* __restrict__ gfrag) {
+__global__ __launch_bounds__(256) void k_gram_fin_g(const int* __restrict__ part, int splits, int K, int NL, int8_t* __restrict__ gfrag) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread per (tile row slot, column) of G
     if (idx >= (int64_t)K * K) return;
     const int col = (int)(idx % K), slot = (int)(idx / K);                // slot = 32 kt + r'
     const int kt = slot >> 5, rp = slot & 31;
     const int row = 32 * kt + 16 * ((rp >> 2) & 1) + 4 * (rp >> 3) + (rp & 3);
     long long g = 0;
-    for (int z = 0; z < splits; ++z) g += part[((int64_t)z * K + row) * K + col];
+    for (int z = 0; z < splits; ++z) g += (long long)part[((int64_t)z * K + row) * K + col];
     const int nj = K >> 5, jt = col >> 5, h = (col >> 4) & 1, e = col & 15;
     long long rest = g;
     for (int l = 0; l < NL; ++l) {
@@ -237,12 +242,20 @@ __global__ __launch_bounds__(256) void k_gram_fin_g(const long long* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void k_gram_fin_c(const long long* __restrict__ part, int splits, int O, int K, int8_t* __restrict__ clim) {
+__global__ __launch_bounds__(256) void k_gram_fin_c(const int* __restrict__ part, int splits, int O, int K, int8_t* __restrict__ clim,
+                                                    const double* __restrict__ s0p, int nchunk, double* __restrict__ s0) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < O) {                                          // S0[o]: the chunks' shares in a fixed order
+        double t = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) t += s0p[idx * nchunk + ch];
+        s0[idx] = t;
+    }
     if (idx >= (int64_t)O * K) return;
     const int o = (int)(idx / K), k = (int)(idx % K);
     long long c = 0;
-    for (int z = 0; z < splits; ++z) c += part[(int64_t)z * O * K + idx];
+    for (int z = 0; z < splits; ++z)
+#pragma unroll
+        for (int l = 0; l < RLIMBS; ++l) c += ((long long)part[((int64_t)z * RLIMBS * O + (int64_t)l * O + o) * K + k]) << (8 * l);
     long long rest = c;
 #pragma unroll
     for (int l = 0; l < CLIMBS; ++l) {
@@ -252,7 +265,6 @@ __global__ __launch_bounds__(256) void k_gram_fin_c(const long long* __restrict_
     }
 }
 
-// ------------------------------------------------------------------------------------------------ per-step scoring kernel
 // LDS fragment reads of the panel pipeline as volatile asm (the compiler keeps their order and places no waits of its own);
 // gram_wait<N> ties a fragment to the counted wait that makes it valid; gram_rd_after names the accumulators an earlier MFMA
 // writes as a nominal input, so the read cannot be moved above the MFMAs that still use its destination registers.
@@ -518,9 +530,9 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
 struct GramPlan {
     int T, O, K, NJ, NL;
     int64_t Tp;
-    int steps_total, sg_steps, sg_splits, sc_steps, sc_splits;
+    int steps_total, sg_steps, sg_splits, sc_steps, sc_splits, r_chunk, r_nchunk;
     // byte offsets into the workspace
-    int64_t off_gfrag, off_clim, off_s0, off_cscl, off_xt, off_rl, off_gpart, off_cpart, total;
+    int64_t off_gfrag, off_clim, off_s0, off_cscl, off_xt, off_rl, off_gpart, off_cpart, off_amax, off_s0p, total;
     bool ok;
 };
 
@@ -536,39 +548,48 @@ static int g_limbs(int64_t T, int a_bits) {
 
 static int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
 
-static int pick_steps(int steps_total, int tiles, int target_wgs) {
-    // token steps (of 128) per split: enough splits to fill the chip, at most 512 steps per split (int32 accumulators)
-    int splits = (target_wgs + tiles - 1) / tiles;
+static int pick_steps(int steps_total, int tiles, int target_waves) {
+    // token steps (of 128) per split: enough splits to fill the chip with one-wave tiles, at least 4 steps per split (the partials are
+    // summed afterwards), at most 512 (int32 accumulators)
+    int splits = (target_waves + tiles - 1) / tiles;
     if (splits < 1) splits = 1;
-    if (splits > steps_total) splits = steps_total;
     int per = (steps_total + splits - 1) / splits;
+    if (per < 4) per = 4;
     if (per > 512) per = 512;
+    if (per > steps_total) per = steps_total;
     return per;
 }
+
+constexpr int MM_BI = 4, MM_BJ = 4;                         // k_gram_mm wave tile: 128 x 128
 
 static GramPlan gram_plan(int T, int O, int K, int a_bits) {
     GramPlan g{};
     g.T = T; g.O = O; g.K = K;
-    g.ok = T >= 1 && O >= 1 && K >= 32 && K % 32 == 0 && a_bits >= 2 && a_bits <= 7;
+    g.ok = T >= 1 && O >= 1 && K >= 32 && K % 32 == 0 && a_bits >= 2 && a_bits <= 7 && (int64_t)RLIMBS * O < ((int64_t)1 << 30);
     if (!g.ok) return g;
     g.NJ = K / 32;
     g.NL = g_limbs(T, a_bits);
     g.Tp = ((int64_t)T + 127) / 128 * 128;
     g.steps_total = (int)(g.Tp / 128);
-    const int tg = ((K + 127) / 128) * ((K + 127) / 128), tc = ((O + 127) / 128) * ((K + 127) / 128);
-    g.sg_steps = pick_steps(g.steps_total, tg, 512);
+    const int tk = (K + 32 * MM_BJ - 1) / (32 * MM_BJ);
+    const int tg = ((K + 32 * MM_BI - 1) / (32 * MM_BI)) * tk, tc = ((RLIMBS * O + 32 * MM_BI - 1) / (32 * MM_BI)) * tk;
+    g.sg_steps = pick_steps(g.steps_total, tg, 1024);
     g.sg_splits = (g.steps_total + g.sg_steps - 1) / g.sg_steps;
-    g.sc_steps = pick_steps(g.steps_total, tc, 256);
+    g.sc_steps = pick_steps(g.steps_total, tc, 1024);
     g.sc_splits = (g.steps_total + g.sc_steps - 1) / g.sc_steps;
+    g.r_chunk = 8192;                                       // tokens per k_gram_rfix workgroup (a multiple of 128)
+    g.r_nchunk = (int)((g.Tp + g.r_chunk - 1) / g.r_chunk);
     int64_t off = 0;
     g.off_gfrag = off; off += al256((int64_t)g.NL * K * K);
     g.off_clim = off; off += al256((int64_t)O * CLIMBS * K);
     g.off_s0 = off; off += al256((int64_t)O * 8);
     g.off_cscl = off; off += al256((int64_t)O * 8);
+    g.off_amax = off; off += al256((int64_t)O * 4);
+    g.off_s0p = off; off += al256((int64_t)O * g.r_nchunk * 8);
     g.off_xt = off; off += al256((int64_t)K * g.Tp);
     g.off_rl = off; off += al256((int64_t)RLIMBS * O * g.Tp);
-    g.off_gpart = off; off += al256((int64_t)g.sg_splits * K * K * 8);
-    g.off_cpart = off; off += al256((int64_t)g.sc_splits * O * K * 8);
+    g.off_gpart = off; off += al256((int64_t)g.sg_splits * K * K * 4);
+    g.off_cpart = off; off += al256((int64_t)g.sc_splits * RLIMBS * O * K * 4);
     g.total = off;
     return g;
 }
@@ -616,20 +637,28 @@ extern "C" int adalog_gram_build(const float* x, int T, int K, int64_t ldx, cons
     uint8_t* base = (uint8_t*)ws;
     int8_t* xt = (int8_t*)(base + g.off_xt);
     int8_t* rl = (int8_t*)(base + g.off_rl);
-    long long* gpart = (long long*)(base + g.off_gpart);
-    long long* cpart = (long long*)(base + g.off_cpart);
+    int* gpart = (int*)(base + g.off_gpart);
+    int* cpart = (int*)(base + g.off_cpart);
+    unsigned int* amax = (unsigned int*)(base + g.off_amax);
+    double* s0p = (double*)(base + g.off_s0p);
+    {
+        const hipError_t me = hipMemsetAsync(amax, 0, (size_t)O * 4, st);
+        if (me != hipSuccess) { adalog_set_error("adalog_gram_build (clear)", me); return (int)me; }
+    }
     hipLaunchKernelGGL(k_gram_pack_xt, dim3((unsigned)(g.Tp / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, x, T, K, ldx, sa, za,
                        (float)((1 << a_bits) - 1), xt, g.Tp);
-    hipLaunchKernelGGL(k_gram_rfix, dim3((unsigned)O), dim3(256), 0, st, ref_t, T, g.Tp, O, bias, rl, (double*)(base + g.off_s0),
-                       (double*)(base + g.off_cscl));
-    hipLaunchKernelGGL((k_gram_mm<1>), dim3((unsigned)((K + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)g.sg_splits), dim3(256), 0, st,
-                       xt, xt, K, K, g.Tp, (int64_t)0, g.sg_steps, g.steps_total, gpart);
-    hipLaunchKernelGGL((k_gram_mm<RLIMBS>), dim3((unsigned)((O + 127) / 128), (unsigned)((K + 127) / 128), (unsigned)g.sc_splits), dim3(256), 0, st,
-                       rl, xt, O, K, g.Tp, (int64_t)O * g.Tp, g.sc_steps, g.steps_total, cpart);
+    hipLaunchKernelGGL(k_gram_rmax, dim3((unsigned)O, (unsigned)g.r_nchunk), dim3(256), 0, st, ref_t, T, g.r_chunk, bias, amax);
+    hipLaunchKernelGGL(k_gram_rfix, dim3((unsigned)O, (unsigned)g.r_nchunk), dim3(256), 0, st, ref_t, T, g.Tp, O, g.r_chunk, g.r_nchunk, bias,
+                       amax, rl, s0p, (double*)(base + g.off_cscl));
+    const unsigned tk = (unsigned)((K + 32 * MM_BJ - 1) / (32 * MM_BJ));
+    hipLaunchKernelGGL((k_gram_mm<MM_BI, MM_BJ>), dim3((unsigned)((K + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sg_splits), dim3(64), 0, st,
+                       xt, xt, K, K, g.Tp, g.sg_steps, g.steps_total, gpart);
+    hipLaunchKernelGGL((k_gram_mm<MM_BI, MM_BJ>), dim3((unsigned)((RLIMBS * O + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sc_splits), dim3(64), 0,
+                       st, rl, xt, RLIMBS * O, K, g.Tp, g.sc_steps, g.steps_total, cpart);
     hipLaunchKernelGGL(k_gram_fin_g, dim3((unsigned)(((int64_t)K * K + 255) / 256)), dim3(256), 0, st, gpart, g.sg_splits, K, g.NL,
                        (int8_t*)(base + g.off_gfrag));
     hipLaunchKernelGGL(k_gram_fin_c, dim3((unsigned)(((int64_t)O * K + 255) / 256)), dim3(256), 0, st, cpart, g.sc_splits, O, K,
-                       (int8_t*)(base + g.off_clim));
+                       (int8_t*)(base + g.off_clim), s0p, g.r_nchunk, (double*)(base + g.off_s0));
     ADALOG_LAUNCH_CHECK("adalog_gram_build");
     return 0;
 }

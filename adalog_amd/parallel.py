@@ -219,6 +219,15 @@ def broadcast(t: torch.Tensor, src: int) -> torch.Tensor:
     return t
 
 
+def dist_timeout():
+    """The timeout test_quant.py / bench.py hand to init_process_group: block-parallel BRECQ lets a rank wait in a collective for as
+    long as another rank trains a block (minutes for Swin stage 0 at 20 000 iterations); the library default of 10 minutes would
+    abort such a job.  ADALOG_DIST_TIMEOUT_MIN (default 120)."""
+    import datetime
+    import os
+    return datetime.timedelta(minutes=int(os.environ.get("ADALOG_DIST_TIMEOUT_MIN", "120")))
+
+
 def barrier():
     if is_dist():
         dist.barrier()

@@ -54,7 +54,10 @@ class _AdaRoundFn(torch.autograd.Function):
         ctx.save_for_backward(w2, alpha2, scale, zero_point)
         ctx.n_bits, ctx.soft = n_bits, soft
         be = backend.get()
-        if train_mm.W_KMAJOR and w2.is_cuda and alpha2.requires_grad and hasattr(be, "adaround_t"):
+        # (only where a BRECQ iteration will consume it: under no_grad -- evaluation after BRECQ -- or with the training
+        # contractions switched off, the extra transposed image would be written for nobody)
+        if (train_mm.W_KMAJOR and train_mm.ENABLED and torch.is_grad_enabled() and w2.is_cuda and alpha2.requires_grad
+                and hasattr(be, "adaround_t")):
             # a BRECQ iteration: the same launch leaves the K-major image the layer's forward product reads (train_mm._kmajor)
             y, y_t = be.adaround_t(w2, alpha2, scale, zero_point, n_bits, soft)
             train_mm.offer_kmajor(y, y_t)

@@ -15,6 +15,7 @@ bf16 terms, six bf16 MFMA products, fp32 accumulation -- fp32-class accuracy), w
 ADALOG_BRECQ_MM=0 falls back to the fp32 library GEMMs (torch / rocBLAS) for A/B measurements.
 """
 import os
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -60,7 +61,9 @@ def offer_kmajor(w2, w2_t):
     """The producer of w2 [N, K] (the AdaRound forward) hands over its [K, N] image; the next forward product on w2 takes it."""
     if len(_KMAJOR_OFFER) > 64:
         _KMAJOR_OFFER.clear()
-    _KMAJOR_OFFER[w2.data_ptr()] = (w2_t, w2.shape[0], w2.shape[1])
+    # (keyed by address: the entry remembers WHICH tensor stood there -- a weak reference and its version -- so that a later tensor
+    # of the same shape allocated at the same address cannot pick up a stale image)
+    _KMAJOR_OFFER[w2.data_ptr()] = (w2_t, w2.shape[0], w2.shape[1], weakref.ref(w2), w2._version)
 
 
 def reset_offers():
@@ -73,8 +76,10 @@ def _kmajor(w2):
     if not W_KMAJOR or w2.shape[0] % 4:
         return w2
     hit = _KMAJOR_OFFER.pop(w2.data_ptr(), None)       # made by the producer of w_sim when it has one (views share the pointer)
-    if hit is not None and hit[1:] == (w2.shape[0], w2.shape[1]) and w2.is_contiguous():
-        return hit[0].t()
+    if hit is not None and hit[1:3] == (w2.shape[0], w2.shape[1]) and w2.is_contiguous():
+        src = hit[3]()                                   # the offering tensor must still be alive (nothing else can then sit at its
+        if src is not None and src._version == hit[4]:   # address) and unmodified since the offer
+            return hit[0].t()
     return w2.t().contiguous().t()
 
 

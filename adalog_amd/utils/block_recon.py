@@ -34,26 +34,46 @@ class HipAdam(torch.optim.Optimizer):
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._steps = {}
+        self._steps = {}               # (group, ids of the chunk's tensors) -> device step counter of that chunk
+        self._hstep = {}               # id(param) -> steps taken so far (host mirror: decides which tensors may share a counter)
+
+    def step_counter(self, params, group_index=0):
+        """the device counter of the chunk made of exactly these tensors (None before their first step)"""
+        return self._steps.get((group_index, tuple(id(p) for p in params)))
 
     @torch.no_grad()
     def step(self, closure=None):
         be = backend.get()
         for gi, group in enumerate(self.param_groups):
-            ps = [p for p in group['params'] if p.grad is not None]
-            for c0 in range(0, len(ps), 16):
-                chunk = ps[c0:c0 + 16]
-                for p in chunk:
-                    st = self.state[p]
-                    if not st:
-                        st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p), torch.zeros_like(p)
-                key = (gi, c0)
-                if key not in self._steps:
-                    self._steps[key] = torch.zeros(1, dtype=torch.float32, device=chunk[0].device)
-                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
-                be.adam_multi([p.data for p in chunk], grads, [self.state[p]['exp_avg'] for p in chunk],
-                              [self.state[p]['exp_avg_sq'] for p in chunk], self._steps[key], group['lr'],
-                              group['betas'][0], group['betas'][1], group['eps'])
+            # torch.optim.Adam skips a tensor without a gradient and counts steps per tensor: tensors are chunked with others of the
+            # SAME step count only, and a chunk's device counter is keyed by its exact members -- a tensor that sits an iteration out
+            # can neither shift others into a counter with a different history nor inherit one (in BRECQ every trained tensor has a
+            # gradient in every iteration: one bucket, the same chunks and counters each time, nothing allocated after the first step)
+            buckets = {}
+            for p in group['params']:
+                if p.grad is not None:
+                    buckets.setdefault(self._hstep.get(id(p), 0), []).append(p)
+            for hs, ps in buckets.items():
+                for c0 in range(0, len(ps), 16):
+                    chunk = ps[c0:c0 + 16]
+                    for p in chunk:
+                        st = self.state[p]
+                        if not st:
+                            st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p), torch.zeros_like(p)
+                    key = (gi, tuple(id(p) for p in chunk))
+                    if key not in self._steps:
+                        self._steps[key] = torch.full((1,), float(hs), dtype=torch.float32, device=chunk[0].device)
+                    grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in chunk]
+                    be.adam_multi([p.data for p in chunk], grads, [self.state[p]['exp_avg'] for p in chunk],
+                                  [self.state[p]['exp_avg_sq'] for p in chunk], self._steps[key], group['lr'],
+                                  group['betas'][0], group['betas'][1], group['eps'])
+                    for p in chunk:
+                        self._hstep[id(p)] = hs + 1
+
+    def note_external_steps(self, params, n=1):
+        """steps of these tensors taken outside step() on their shared device counter (the one-launch alpha update)"""
+        for p in params:
+            self._hstep[id(p)] = self._hstep.get(id(p), 0) + n
 
 
 class BlockReconstructor(QuantCalibrator):
@@ -95,9 +115,10 @@ class BlockReconstructor(QuantCalibrator):
                    and q_.alpha.dtype == torch.float32 and q_.alpha.is_contiguous() for q_ in qs):
             return None
         group = w_optimizer.param_groups[0]
-        if (0, 0) not in w_optimizer._steps or any(not w_optimizer.state[q_.alpha] for q_ in qs):
+        counter = w_optimizer.step_counter(group['params'])  # all alphas in one chunk, in the optimiser's order (<= 16 tensors)
+        if counter is None or any(not w_optimizer.state[q_.alpha] for q_ in qs):
             return None                                      # the eager warm-up iterations create the Adam state
-        return adaround_mod.AlphaCollector(qs, lambda p_: w_optimizer.state[p_], w_optimizer._steps[(0, 0)], group['lr'],
+        return adaround_mod.AlphaCollector(qs, lambda p_: w_optimizer.state[p_], counter, group['lr'],
                                            group['betas'], group['eps'])
 
     def set_block_mode(self, block, mode='raw'):
@@ -381,35 +402,72 @@ class BlockReconstructor(QuantCalibrator):
         rank and ~1.8 ms per iteration it is latency-bound and slower on 8 GPUs than on one) stays behind ADALOG_BRECQ_DP=batch."""
         ws, rk = parallel.world_size(), parallel.rank()
         names = list(self.blocks.keys())
-        owned = {}
-        for i, name in enumerate(names):                     # captures first: collectives, in the same order on every rank
+        local = {}
+        for name in names:                                   # captures first (rank-local shards; collectives, same order on every rank)
             block, full_block = self.blocks[name], self.full_blocks[name]
             self.init_block_raw_inp_outp(block, full_block, name, device)
-            xin, xout = parallel.gather_images(block.raw_input), parallel.gather_images(block.raw_out)
+            local[name] = (block.raw_input, block.raw_out) if keep_gpu else (block.raw_input.cpu(), block.raw_out.cpu())
             del block.raw_input, block.raw_out
-            if i % ws == rk:
-                owned[name] = (xin, xout) if keep_gpu else (xin.cpu(), xout.cpu())
-            del xin, xout
+        # deal the blocks by estimated cost (an iteration is dominated by the Linear products: tokens x weights), heaviest first
+        # to the least loaded rank -- the same pure function of shapes on every rank.  Round-robin dealing left ranks with the
+        # cheap Swin stage-3 blocks waiting in the result broadcast while others still trained stage-0 blocks.
+        cost = {n: self._block_cost(self.blocks[n], local[n][0]) for n in names}
+        owner, load = {}, [0.0] * ws
+        for n in sorted(names, key=lambda n_: (-cost[n_], names.index(n_))):
+            r = min(range(ws), key=lambda i: (load[i], i))
+            owner[n] = r
+            load[r] += cost[n]
+        self.block_owner = dict(owner)
+        rounds = max(sum(1 for n in names if owner[n] == r) for r in range(ws))
+        queue = {r: [n for n in names if owner[n] == r] for r in range(ws)}
         for name in names:                                   # every rank: AdaRound quantisers exist everywhere (to receive alpha)
-            if name not in owned:
+            if owner[name] != rk:
                 self.wrap_quantizers_in_net(self.blocks[name], name)
-        with parallel.solo():
-            for name, (xin, xout) in owned.items():
+        for rd in range(rounds):
+            # one block per rank and round: its data is gathered right before its owner trains it (all blocks' gathered inputs and
+            # targets resident at once was 8x the footprint), every rank joins every gather in the same order
+            mine = None
+            for r in range(ws):
+                if rd >= len(queue[r]):
+                    continue
+                name = queue[r][rd]
+                xin, xout = (t.to(device) for t in local.pop(name))
+                gin, gout = parallel.gather_images(xin), parallel.gather_images(xout)
+                del xin, xout
+                if r == rk:
+                    mine = (name, gin, gout)
+                del gin, gout
+            if mine is not None:
+                name, gin, gout = mine
                 block = self.blocks[name]
                 logging.info('rank {}: reconstructing {} ...'.format(rk, name))
-                block.raw_input, block.raw_out = xin, xout
-                self.reconstruct_single_block(name, block, device, quant_act=quant_act, iters=iters)
-        owned.clear()
-        for i, name in enumerate(names):                     # results from their owners
+                block.raw_input, block.raw_out = gin, gout
+                del mine, gin, gout
+                with parallel.solo():
+                    self.reconstruct_single_block(name, block, device, quant_act=quant_act, iters=iters)
+            # the ranks meet here once per round: a wait is at most one block's training (the process group's timeout -- 
+            # ADALOG_DIST_TIMEOUT_MIN, default 120 -- is what bounds it, not the library's 10 minutes)
+            parallel.barrier()
+        for name in names:                                   # results from their owners
             block = self.blocks[name]
             for t in self._trained_tensors(block, quant_act):
-                parallel.broadcast(t.data, src=i % ws)
-            if i % ws != rk:                                 # the state reconstruct_single_block leaves behind
+                parallel.broadcast(t.data, src=owner[name])
+            if owner[name] != rk:                            # the state reconstruct_single_block leaves behind
                 for _, module in block.named_modules():
                     if hasattr(module, 'w_quantizer'):
                         module.w_quantizer.soft_targets = False
                     if hasattr(module, 'mode'):
                         module.mode = 'raw'
+
+    @staticmethod
+    def _block_cost(block, shard_input):
+        """tokens of the block's input (per image) x quantised weights it multiplies them with: what an iteration's contractions
+        scale with; the same number on every rank (shapes only)."""
+        tokens = max(1, shard_input.numel() // max(1, shard_input.shape[0] * shard_input.shape[-1]))
+        weights = sum(m.weight.numel() for m in block.modules() if isinstance(m, (MinMaxQuantLinear, MinMaxQuantConv2d)))
+        if isinstance(block, (MinMaxQuantLinear, MinMaxQuantConv2d)):
+            weights = max(weights, block.weight.numel())
+        return float(tokens) * float(max(1, weights))
 
     def reconstruct_model(self, quant_act: bool = False, keep_gpu: bool = True, iters: int = 20000):
         device = next(self.model.parameters()).device

@@ -513,6 +513,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         import torch.distributed as dist
+        from adalog_amd import parallel
         if os.environ.get("ADALOG_DIST_BACKEND", "nccl") != "nccl":
             local_rank = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
@@ -520,9 +521,9 @@ def main():
         # the sharded code path on a single-GPU box (collectives then stage through the host: not a performance mode)
         be_name = os.environ.get("ADALOG_DIST_BACKEND", "nccl")
         if be_name == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=parallel.dist_timeout())
         else:
-            dist.init_process_group(backend=be_name)
+            dist.init_process_group(backend=be_name, timeout=parallel.dist_timeout())
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

@@ -181,11 +181,11 @@ def main(args):
         be_name = os.environ.get("ADALOG_DIST_BACKEND", "nccl")
         if args.device.startswith("cuda") and be_name == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), timeout=parallel.dist_timeout())
         else:
             if args.device.startswith("cuda"):
                 torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", timeout=parallel.dist_timeout())
     root_path = args.output_dir or './checkpoints/quant_result/{}'.format(datetime.now().strftime("%Y%m%d_%H%M"))
     if parallel.rank() == 0:
         os.makedirs(root_path, exist_ok=True)
