@@ -275,6 +275,18 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         return be.pack_uniform(self._w2().unsqueeze(0), wq.scale.data.view(-1), wq.zero_point.data.view(-1), 1, 0, 1, 0, 1,
                                wq.n_bits, dt, want_rowsum=want_rowsum)
 
+    def _pack_w_cached(self, dt=I8, want_rowsum=False):
+        """_pack_w_fixed for quant_forward (linear.py:46-51 re-quantises the weight on every call): the packed image is a pure
+        function of (weight, scale, zero point), so it is kept until one of them changes -- storage address and in-place version
+        of each are the key (validate() runs thousands of forwards on unchanged weights)."""
+        wq = self.w_quantizer
+        key = (dt, want_rowsum, wq.n_bits) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self.weight, wq.scale, wq.zero_point))
+        hit = self.__dict__.get("_wp_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, self._pack_w_fixed(dt, want_rowsum))
+            self.__dict__["_wp_cache"] = hit
+        return hit[1]
+
     def _score_a(self, wp, scale, zp, defer=False):
         """linear.py:394-423 -> scores [P, 1] = -sum_images mean_{tokens,out} (raw_out - fq_p(x) . q_w(W)^T - b)^2.
 
@@ -425,7 +437,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         lead = x.shape[:-1]
         x3 = x.reshape(1, -1, self.in_features)
         xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
-        wp = self._pack_w_fixed()
+        wp = self._pack_w_cached()
         out = be.gemm_out(I8, xp, wp, x3.shape[1], self.out_features, 1, 1, Strided(aq.scale.data.view(-1)),
                           Strided(self.w_quantizer.scale.data.view(-1), n=1),
                           None if self.bias is None else Strided(self.bias.data, n=1))
@@ -699,11 +711,11 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
                             shift=aq.shift.data, clamp_u=True)
         _, sub = aq._shift_args()
         if sub:
-            wp, rowsum = self._pack_w_fixed(BF16, want_rowsum=True)
+            wp, rowsum = self._pack_w_cached(BF16, want_rowsum=True)
             bias = be.shift_fold(rowsum.view(1, -1), self.w_quantizer.scale.data.view(1, -1), aq.shift.data,
                                  None if self.bias is None else self.bias.data).view(-1)
         else:
-            wp = self._pack_w_fixed(BF16)
+            wp = self._pack_w_cached(BF16)
             bias = None if self.bias is None else self.bias.data
         out = be.gemm_out(BF16, xp, wp, x3.shape[1], self.out_features, 1, 1, Strided(aq.scale.data.view(-1)),
                           Strided(self.w_quantizer.scale.data.view(-1), n=1),

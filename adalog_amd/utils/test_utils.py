@@ -30,9 +30,13 @@ def accuracy(output, target, topk=(1,)):
 
 
 @torch.no_grad()
-def validate(val_loader, model, criterion, print_freq=10, device='cuda:0'):
+def validate(val_loader, model, criterion, print_freq=10, device='cuda:0', graph=True):
+    """reference test_utils.py:10-54.  ``graph``: replay the forward as a captured HIP graph per batch shape
+    (utils/graph_forward.py; the forward is launch-bound at validation batch sizes) -- same kernels, same results."""
+    from .graph_forward import GraphedForward
     losses, top1, top5, batch_time = AverageMeter(), AverageMeter(), AverageMeter(), AverageMeter()
     model.eval()
+    model = GraphedForward(model, enabled=graph and str(device).startswith('cuda'))
     t_start = t_last = time.time()
     n_batches = len(val_loader)
     for i, (data, target) in enumerate(val_loader):

@@ -260,15 +260,90 @@ def brecq_rate(model_name, bits, dev, iters=2000, depth=None):
     setup = max(0.0, t_call - iters * dt_it)
     dt = setup + iters * dt_it                                                   # (= t_call)
     nblk = nblk_full if nblk_full is not None else len(rec.blocks)
-    return {"model": model_name, "iters_per_s": round(1.0 / dt_it, 1), "ms_per_iter": round(dt_it * 1e3, 3),
-            "how": f"steady state: iterations {iters // 4 + 1}..{iters} of one reconstruct_single_block call (HIP-graph replay)",
-            "whole_call_iters_per_s": round(iters / t_call, 1), "setup_s_per_block": round(setup, 3), "block": name, "batch": 32,
+    # iters_per_s is the WHOLE-CALL figure (set-up, eager iterations and graph capture included), as rounds 1-3 reported it;
+    # steady_iters_per_s is the steady state (round 4 had put that one under the name iters_per_s)
+    return {"model": model_name, "iters_per_s": round(iters / t_call, 1), "steady_iters_per_s": round(1.0 / dt_it, 1),
+            "ms_per_iter": round(dt_it * 1e3, 3),
+            "how": f"iters_per_s: one whole reconstruct_single_block call of {iters} iterations; steady_iters_per_s: its iterations "
+                   f"{iters // 4 + 1}..{iters} (HIP-graph replay)",
+            "setup_s_per_block": round(setup, 3), "block": name, "batch": 32,
             "sample_iters": iters, "blocks_in_model": nblk,
             "contractions": ("csrc/brecq_gemm.hip (adalog_gemm_f32x3: fp32 operands as three bf16 terms, six MFMA products, fp32 "
                              "accumulation; integer activation operands three products)" if train_mm.ENABLED else "rocBLAS fp32"),
             "multi_gpu": "block-parallel (blocks dealt to ranks, no collective inside an iteration); ADALOG_BRECQ_DP=batch = batch split",
             "extrapolated_s_per_block_20000_iters": round(setup + 20000 * dt_it, 1),
             "extrapolated_s_whole_model": round((setup + 20000 * dt_it) * nblk, 1)}
+
+
+def quant_forward_rate(calibrated, images, dev, reps=5):
+    """K15 (reference linear.py:46-51, matmul.py:43-45, conv.py:60-65): a validate()-style forward of the calibrated model with
+    every layer in quant_forward mode (test_quant.py's flow: un-wrap the channel-wise layers, fold the post-GELU shift into the
+    biases), against the same model in raw mode.  Bounded sample: `reps` forwards of the calibration batch each."""
+    from adalog_amd import _lib
+    from adalog_amd.utils.wrap_net import wrap_reparamed_modules_in_net
+    model = wrap_reparamed_modules_in_net(copy.deepcopy(calibrated)).to(dev).eval()
+    for m in model.modules():
+        if hasattr(m, "reparam_bias"):
+            m.reparam_bias()
+    lib = _lib.load()
+    labels = {}
+
+    def run(mode):
+        for m in model.modules():
+            if hasattr(m, "mode"):
+                m.mode = mode
+        with torch.no_grad():
+            model(images)                                         # warm-up (packs the weights once: they are cached)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                out = model(images)
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps, out
+
+    hooks = []
+    if True:                                                       # which GEMM kernel served each layer class (adalog_last_kernel)
+        def mk(cls):
+            def hook(mod, inp, out):
+                if getattr(mod, "mode", "") == "quant_forward":
+                    labels.setdefault(cls, set()).add(lib.adalog_last_kernel().decode())
+            return hook
+        for m in model.modules():
+            if hasattr(m, "mode"):
+                hooks.append(m.register_forward_hook(mk(type(m).__name__)))
+    ms_q, out_q = run("quant_forward")
+    for h in hooks:
+        h.remove()
+    ms_r, out_r = run("raw")
+    # the same quant_forward as a captured HIP graph (what validate() replays per batch shape: utils/graph_forward.py)
+    from adalog_amd.utils.graph_forward import GraphedForward
+    for m in model.modules():
+        if hasattr(m, "mode"):
+            m.mode = "quant_forward"
+    gf = GraphedForward(model)
+    out_g = gf(images)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out_g = gf(images)
+    e1.record()
+    torch.cuda.synchronize()
+    ms_g = e0.elapsed_time(e1) / reps
+    graph_equal = bool(torch.equal(out_g, out_q))
+    n = images.shape[0]
+    rel = float((out_q - out_r).norm() / out_r.norm())
+    return {"images": n, "ms_per_forward": round(ms_g, 3), "images_per_s": round(n / ms_g * 1e3, 1),
+            "how": "HIP-graph replay of the quant_forward pass (validate()'s route); eager launches of the same kernels below",
+            "eager_ms_per_forward": round(ms_q, 3), "eager_images_per_s": round(n / ms_q * 1e3, 1),
+            "graph_output_equals_eager": graph_equal,
+            "raw_ms_per_forward": round(ms_r, 3), "raw_images_per_s": round(n / ms_r * 1e3, 1),
+            "kernels_by_layer_class": {k: sorted(v) for k, v in labels.items()},
+            "output_rel_diff_vs_fp": round(rel, 4),
+            "note": "per layer: operand pack(s) + integer / bf16 MFMA product with the dequantising epilogue (packed weights cached across "
+                    "calls); raw = the FP32 model (rocBLAS)"}
 
 
 def _cpu_sample(threads, n_cand, min_seconds=0.0):
@@ -697,6 +772,10 @@ def main():
                     result["brecq"]["vit_base_block"] = brecq_rate("vit_base", args.bits, dev, iters=1000, depth=1)
             except Exception as ex:
                 result["brecq"] = {"error": repr(ex)[:300]}
+            try:
+                result["quant_forward"] = quant_forward_rate(models[-1], local[:32], dev)
+            except Exception as ex:
+                result["quant_forward"] = {"error": repr(ex)[:300]}
             result["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
         print(json.dumps(result))
     if world > 1:

@@ -159,7 +159,9 @@ def validate_dataset(loader, model, full_model, device):
 @torch.no_grad()
 def validate_fidelity(loader, model, full_model):
     """Synthetic-data stand-in for test_utils.validate: agreement of the quantised model with the FP model."""
+    from adalog_amd.utils.graph_forward import GraphedForward
     agree, total, num, den = 0, 0, 0.0, 0.0
+    model = GraphedForward(model)                                # (launch-bound at these batch sizes: captured once per shape)
     for x, _ in loader:
         q, f = model(x), full_model(x)
         agree += (q.argmax(-1) == f.argmax(-1)).sum().item()
