@@ -300,8 +300,16 @@ struct GramScoreArgs {
 
 // One pass of a wave over NB (<= CB) blocks of 32 candidates; every wave of the workgroup runs the same panel sequence (NB = 0: it
 // only helps moving the panels).  Two workgroups share a CU and run unsynchronised: one's row dots (VALU) issue under the other's MFMAs.
-template <int NJ, int NB, bool BIG, bool TIE>
+// COOP >= 0 (= the wave's index): the thin tail of a workgroup's range -- at most CB blocks are left, three waves would idle through
+// all NJ NL panels -- is run COOPERATIVELY: all four waves take the SAME blocks and split the contraction index, wave COOP owning
+// the K chunks [COOP NJ/4, (COOP + 1) NJ/4).  The row dot is linear in the accumulators, so each wave applies it to its partial
+// products and only the per-candidate sums (quad, lin) are added across the waves at the end.
+template <int NJ, int NB, bool BIG, bool TIE, int COOP = -1>
 __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, int blk0, int w, int lane, float sa, int stamp_slot) {
+    constexpr bool CO = COOP >= 0;
+    constexpr int QN = CO ? NJ / 4 : NJ;                   // K chunks this wave multiplies
+    constexpr int J0 = CO ? COOP * (NJ / 4) : 0;           // ... starting here
+    static_assert(!CO || (NJ % 4 == 0 && NB >= 1), "the cooperative pass splits NJ four ways");
     constexpr int NPW = (NJ + 3) / 4;                      // 1 KiB pieces of a panel per wave
     constexpr int NRING = 4;                               // panels in the ring; the same LDS is the waves' staging area while generating
     constexpr int NBA = NB > 0 ? NB : 1;
@@ -317,7 +325,8 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
     v4i bf[NBA][NJ];
     int orow[NBA];
     float sig[NBA];
-    uint8_t* stage = lds + w * (NJ * 1024) + lane * 16;
+    // staging: a private NJ KiB per wave, or (cooperative) NJ KiB per BLOCK shared by the four waves, each writing its chunks
+    uint8_t* stage = lds + (CO ? 0 : w * (NJ * 1024)) + lane * 16;
     __syncthreads();                                       // the previous pass's ring is dead (all waves): it is the staging area now
     {
 #pragma clang fp contract(off)
@@ -332,11 +341,12 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
             const float ginv = __builtin_amdgcn_rcpf(gs);
             const float glo = 128.0f - gz, ghi = 128.0f + (p.qmax - gz);
             const float* __restrict__ wr = p.W + (int64_t)o * p.ldw + 16 * h;
+            uint8_t* stb = stage + (CO ? b * (NJ * 1024) : 0);
             float4 nx[4];                                  // the row one 16-value slot ahead of the arithmetic
 #pragma unroll
-            for (int j = 0; j < 4; ++j) nx[j] = *reinterpret_cast<const float4*>(wr + 4 * j);
+            for (int j = 0; j < 4; ++j) nx[j] = *reinterpret_cast<const float4*>(wr + 32 * J0 + 4 * j);
 #pragma unroll 1
-            for (int jt = 0; jt < NJ; ++jt) {
+            for (int jt = J0; jt < J0 + QN; ++jt) {
                 float xv[16];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { xv[4 * j] = nx[j].x; xv[4 * j + 1] = nx[j].y; xv[4 * j + 2] = nx[j].z; xv[4 * j + 3] = nx[j].w; }
@@ -365,10 +375,20 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                         u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e] + 128.0f, glo, ghi), e, u);
                     pk[j] = (int)(u ^ 0x80808080u);
                 }
-                *reinterpret_cast<v4i*>(stage + jt * 1024) = pk;
+                *reinterpret_cast<v4i*>(stb + jt * 1024) = pk;
             }
-            static_for<NJ>([&](auto jtc) { bf[b][decltype(jtc)::value] = *reinterpret_cast<const v4i*>(stage + decltype(jtc)::value * 1024); });
+            if constexpr (!CO)
+                static_for<NJ>([&](auto jtc) { bf[b][decltype(jtc)::value] = *reinterpret_cast<const v4i*>(stb + decltype(jtc)::value * 1024); });
         });
+        if constexpr (CO) {                                // every wave needs every chunk (the row dot walks all of K)
+            __syncthreads();
+            static_for<NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                static_for<NJ>([&](auto jtc) {
+                    bf[b][decltype(jtc)::value] = *reinterpret_cast<const v4i*>(stage + (b * NJ + decltype(jtc)::value) * 1024);
+                });
+            });
+        }
     }
     GRAM_STAMP(1);
 
@@ -380,8 +400,8 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0;
         const int8_t* cr = p.clim + ((int64_t)orow[b] * CLIMBS + (c & 7)) * p.K + 16 * h;
-        static_for<NJ>([&](auto jtc) {
-            constexpr int jt = decltype(jtc)::value;
+        static_for<QN>([&](auto jtc) {
+            constexpr int jt = J0 + decltype(jtc)::value;
             v4i a = *reinterpret_cast<const v4i*>(cr + 32 * jt);
             if (c >= CLIMBS) a = v4i{0, 0, 0, 0};
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bf[b][jt], acc, 0, 0, 0);
@@ -438,23 +458,23 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                 for (int e = 0; e < 16; ++e) acc[b][e] = 0;
             // A fragments three reads ahead of their MFMAs (left to itself the compiler reads each one into the same registers right
             // before its use: an LDS round trip per pair of MFMAs)
-            constexpr int AD = NJ < 3 ? NJ : 3;
+            constexpr int AD = QN < 3 ? QN : 3;
             v4i af[AD];
             const uint32_t pa = (uint32_t)(uintptr_t)pan;
-            static_for<AD>([&](auto ic) { af[decltype(ic)::value] = gram_rd<decltype(ic)::value * 1024>(pa); });
-            static_for<NJ>([&](auto jtc) {
-                constexpr int jt = decltype(jtc)::value;
-                constexpr int left = (NJ - 1 - jt) < (AD - 1) ? (NJ - 1 - jt) : (AD - 1);     // reads younger than fragment jt
-                gram_wait<left>(af[jt % AD]);
+            static_for<AD>([&](auto ic) { af[decltype(ic)::value] = gram_rd<(J0 + decltype(ic)::value) * 1024>(pa); });
+            static_for<QN>([&](auto jtc) {
+                constexpr int ji = decltype(jtc)::value, jt = J0 + ji;
+                constexpr int left = (QN - 1 - ji) < (AD - 1) ? (QN - 1 - ji) : (AD - 1);     // reads younger than fragment ji
+                gram_wait<left>(af[ji % AD]);
                 static_for<NB>([&](auto bc) {
                     constexpr int b = decltype(bc)::value;
-                    acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[jt % AD], bf[b][jt], acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[ji % AD], bf[b][jt], acc[b], 0, 0, 0);
                 });
-                if constexpr (jt + AD < NJ) {
+                if constexpr (ji + AD < QN) {
                     // (TIE: accumulators in VGPRs -- naming them keeps the read behind the MFMAs that use its destination; with the
                     // accumulators in AGPRs the tie would cost a copy out and back per read)
-                    if constexpr (TIE) af[jt % AD] = gram_rd_after<(jt + AD) * 1024>(pa, acc[NB - 1]);
-                    else af[jt % AD] = gram_rd<(jt + AD) * 1024>(pa);
+                    if constexpr (TIE) af[ji % AD] = gram_rd_after<(jt + AD) * 1024>(pa, acc[NB - 1]);
+                    else af[ji % AD] = gram_rd<(jt + AD) * 1024>(pa);
                 }
             });
             // row dot: accumulator element e = G row 32 kt + 16 h + e = byte e of this lane's own fragment kt (kt is wave-uniform:
@@ -488,16 +508,38 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
     GRAM_STAMP(3);
 
     // ---- scores
-    static_for<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        const double q = quad[b] + __shfl_xor(quad[b], 32);
-        const int o = orow[b];
-        const double s = (double)sig[b];
-        const double tot = p.s0[o] - 2.0 * s * (lin[b] * p.cscl[o]) + s * s * q;
-        const int blk = blk0 + b;
-        const int cand = (blk - o * PB) * 32 + c;
-        if (h == 0) p.scores[(int64_t)cand * p.O + o] = (float)(-p.norm * tot);
-    });
+    if constexpr (CO) {
+        // the four waves' shares of (quad, lin) of the same candidates: added in wave order by wave 0 (fixed order: reproducible)
+        double* red = reinterpret_cast<double*>(lds);       // [wave][block][2][64 lanes]
+        __syncthreads();                                    // the ring is dead
+        static_for<NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            red[((w * NB + b) * 2 + 0) * 64 + lane] = quad[b];
+            red[((w * NB + b) * 2 + 1) * 64 + lane] = lin[b];
+        });
+        __syncthreads();
+        if (w == 0) {
+            static_for<NB>([&](auto bc) {
+                constexpr int b = decltype(bc)::value;
+                double q = 0.0, l = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < 4; ++ww) { q += red[((ww * NB + b) * 2 + 0) * 64 + lane]; l += red[((ww * NB + b) * 2 + 1) * 64 + lane]; }
+                quad[b] = q; lin[b] = l;
+            });
+        }
+    }
+    if (!CO || w == 0) {
+        static_for<NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            const double q = quad[b] + __shfl_xor(quad[b], 32);
+            const int o = orow[b];
+            const double s = (double)sig[b];
+            const double tot = p.s0[o] - 2.0 * s * (lin[b] * p.cscl[o]) + s * s * q;
+            const int blk = blk0 + b;
+            const int cand = (blk - o * PB) * 32 + c;
+            if (h == 0) p.scores[(int64_t)cand * p.O + o] = (float)(-p.norm * tot);
+        });
+    }
     GRAM_STAMP(4);
 #undef GRAM_STAMP
 }
@@ -514,9 +556,29 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
     int pass_no = 0;
     for (int pass0 = b_begin; pass0 < b_end; pass0 += 4 * CB, ++pass_no) {
         const int n = min(4 * CB, b_end - pass0);
+        const int slot = pass_no < 2 ? (int)blockIdx.x * 2 + pass_no : -1;
+        // (measured: pays from NJ = 8 -- below, a panel is so little work that the per-panel barrier dominates either way and the final
+        // cross-wave sum only adds to it: swin stage 0, K = 128, 12.4 -> 17.7 us; NJ = 16 sits at the register limit of two
+        // workgroups per CU already)
+        if constexpr (NJ % 4 == 0 && NJ >= 8 && NJ != 16) {
+            if (n <= CB) {                                 // the thin tail: all four waves on the same n blocks, K split four ways
+#define GRAM_COOP(NBV)                                                                                            \
+                do {                                                                                              \
+                    if (w == 0) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 0>(p, lds, pass0, w, lane, sa, slot);     \
+                    else if (w == 1) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 1>(p, lds, pass0, w, lane, sa, slot); \
+                    else if (w == 2) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 2>(p, lds, pass0, w, lane, sa, slot); \
+                    else gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 3>(p, lds, pass0, w, lane, sa, slot);            \
+                } while (0)
+                if (n == 1) GRAM_COOP(1);
+                else if (CB >= 2 && n == 2) GRAM_COOP((CB >= 2 ? 2 : 1));
+                else if (CB >= 3 && n == 3) GRAM_COOP((CB >= 3 ? 3 : 1));
+                else if (CB >= 4 && n == 4) GRAM_COOP((CB >= 4 ? 4 : 1));
+#undef GRAM_COOP
+                continue;
+            }
+        }
         const int nbw = n / 4 + (w < (n & 3) ? 1 : 0);     // this wave's blocks (wave-uniform)
         const int blk0 = pass0 + w * (n / 4) + min(w, n & 3);
-        const int slot = pass_no < 2 ? (int)blockIdx.x * 2 + pass_no : -1;
         if (nbw == CB) gram_pass<NJ, CB, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
         else if (nbw == 0) gram_pass<NJ, 0, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
         else if (nbw == 1) gram_pass<NJ, 1, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);

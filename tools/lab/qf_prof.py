@@ -24,7 +24,7 @@ for m in model.modules():
 with torch.no_grad():
     model(x)
     torch.cuda.synchronize()
-    print("QF_BEGIN", flush=True)
+    torch.tril(torch.ones(64, 64, device=dev))          # marker kernel (triu_tril): the passes after it are the measured ones
     for _ in range(int(os.environ.get("QF_REPS", "20"))):
         model(x)
     torch.cuda.synchronize()
