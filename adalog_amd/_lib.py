@@ -39,6 +39,14 @@ SIGNATURES = {
     "adalog_score_w_gen": (i32, [i32, p, i32, i64, p, i32, i32, i64, p, p, i32, i32, p, p, p, p, i64, p]),
     "adalog_gram_supported": (i32, [i32, i32, i32, i32, i32, i32]),
     "adalog_gram_ok": (i32, [i32, i32, i32, i32, i32, i32]),
+    "adalog_gram_act_supported": (i32, [i32, i32, i32, i32, i32, i32]),
+    "adalog_gram_act_ok": (i32, [i32, i32, i32, i32, i32, i32]),
+    "adalog_gram_act_workspace_bytes": (i64, [i32, i32, i32, i32]),
+    "adalog_gram_act_sort_bytes": (i64, [i64]),
+    "adalog_gram_act_splits": (i32, [i32, i32, i32, i32]),
+    "adalog_gram_act_prepare": (i32, [p, i32, i32, i64, p, p, p, p, i64, p]),
+    "adalog_gram_act_build": (i32, [p, i32, i32, p, p, i32, i64, p, p, i32, p, i32, p, i64, p]),
+    "adalog_gram_act_score": (i32, [p, p, i32, i32, i32, p, p, i32, i32, p, f64, p, p, p]),
     "adalog_gram_workspace_bytes": (i64, [i32, i32, i32, i32]),
     "adalog_gram_limbs": (i32, [i32, i32]),
     "adalog_gram_build": (i32, [p, i32, i32, i64, p, p, i32, p, i32, p, p, i64, p]),

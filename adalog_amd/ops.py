@@ -675,6 +675,98 @@ class GramState:
         return scores
 
 
+# ------------------------------------------------------------------------------------------------ Gram-form activation search
+def gram_act_ok(T: int, O: int, K: int, a_bits: int, w_bits: int, P: int) -> bool:
+    """True when the Gram form scores this per-tensor output-MSE activation search (csrc/gram_act.hip).  ADALOG_GRAM_A=0: never;
+    ADALOG_GRAM_A=2: wherever the shape is supported (tests drive the kernels at the golden traces' toy shapes with it)."""
+    mode = os.environ.get("ADALOG_GRAM_A", "1")
+    if mode == "0":
+        return False
+    fn = _lib.load().adalog_gram_act_supported if mode == "2" else _lib.load().adalog_gram_act_ok
+    return bool(fn(int(T), int(O), int(K), int(a_bits), int(w_bits), int(P)))
+
+
+def _aligned_bytes(nbytes: int, device):
+    buf = torch.empty((nbytes + 255) // 8 + 32, dtype=torch.float64, device=device)
+    off = (-buf.data_ptr()) % 256
+    return buf.view(torch.uint8)[off:off + nbytes]
+
+
+class GramActPrepared:
+    """Per captured activation x [T, K]: its transposed fp32 image, the sorted values and the sorting permutation (memoised by the
+    caller across the rounds of a module's search: the captured tensor does not change)."""
+    __slots__ = ("xt", "sorted", "perm", "T", "K")
+
+    def __init__(self, x2):
+        lib = _lib.load()
+        x2 = _f32c(x2, "x")
+        self.T, self.K = x2.shape
+        n = self.T * self.K
+        Tp = (self.T + 127) // 128 * 128
+        self.xt = torch.empty((self.K, Tp), dtype=torch.float32, device=x2.device)
+        self.sorted = torch.empty(n, dtype=torch.float32, device=x2.device)
+        self.perm = torch.empty(n, dtype=torch.int32, device=x2.device)
+        nb = lib.adalog_gram_act_sort_bytes(n)
+        if nb < 0:
+            raise _lib.AdalogHipError("gram_act_prepare: tensor too large")
+        ws = _aligned_bytes(nb, x2.device)
+        rc = lib.adalog_gram_act_prepare(x2.data_ptr(), self.T, self.K, x2.stride(0), self.xt.data_ptr(), self.sorted.data_ptr(),
+                                         self.perm.data_ptr(), ws.data_ptr(), nb, _stream())
+        _lib.check(rc, "adalog_gram_act_prepare")
+
+
+class GramActState:
+    """One activation_fpcs call (reference linear.py:505-523) in the Gram form: H = Wq^T Wq, the prefix sums of C = r . Wq along the
+    sorted activation and S0, built once from raw_out and the fixed weight quantiser; ``score`` then scores an FPCS step."""
+    __slots__ = ("prep", "ws", "qpart", "T", "O", "K", "P", "a_bits")
+
+    def __init__(self, prep: GramActPrepared, raw_out2, bias, w2, sw, zw, w_bits: int, a_bits: int, P: int):
+        lib = _lib.load()
+        raw_out2, w2 = _f32c(raw_out2, "raw_out"), _f32c(w2, "weight")
+        self.prep, self.T, self.K, self.P, self.a_bits = prep, prep.T, prep.K, int(P), int(a_bits)
+        self.O = w2.shape[0]
+        assert tuple(raw_out2.shape) == (self.T, self.O) and w2.shape[1] == self.K
+        sw, zw = _f32c(sw, "s_w").reshape(-1), _f32c(zw, "z_w").reshape(-1)
+        assert sw.numel() == self.O and zw.numel() == self.O
+        bias = None if bias is None else _f32c(bias, "bias")
+        nb = lib.adalog_gram_act_workspace_bytes(self.T, self.O, self.K, self.P)
+        if nb < 0:
+            raise _lib.AdalogHipError("gram_act_build: shape not supported (gram_act_ok)")
+        self.ws = _aligned_bytes(nb, w2.device)
+        self.qpart = torch.empty(self.P * lib.adalog_gram_act_splits(self.T, self.O, self.K, self.P), dtype=torch.float64, device=w2.device)
+        if GEMM_EVENTS is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = lib.adalog_gram_act_build(raw_out2.data_ptr(), self.T, self.O, _ptr(bias), w2.data_ptr(), self.K, w2.stride(0), sw.data_ptr(),
+                                       zw.data_ptr(), int(w_bits), prep.perm.data_ptr(), self.P, self.ws.data_ptr(), nb, _stream())
+        if GEMM_EVENTS is not None:
+            ev1.record()
+            # issued matrix work: four reference limbs x (T x O x K)
+            GEMM_EVENTS.append((I8, 4 * self.T, self.K, self.O, 1, 1, ev0, ev1, "k_gram_act_build"))
+        _lib.check(rc, "adalog_gram_act_build")
+
+    def score(self, scale, zp, norm: float):
+        """scores [P, 1] (final) for the per-tensor candidates (scale, zp) [P, 1]."""
+        lib = _lib.load()
+        scale, zp = _f32c(scale, "scale").reshape(-1), _f32c(zp, "zp").reshape(-1)
+        P = scale.numel()
+        assert P == self.P and zp.numel() == P
+        scores = torch.empty((P, 1), dtype=torch.float32, device=scale.device)
+        if GEMM_EVENTS is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        rc = lib.adalog_gram_act_score(self.prep.xt.data_ptr(), self.prep.sorted.data_ptr(), self.T, self.O, self.K, scale.data_ptr(),
+                                       zp.data_ptr(), P, self.a_bits, self.ws.data_ptr(), float(norm), self.qpart.data_ptr(),
+                                       scores.data_ptr(), _stream())
+        if GEMM_EVENTS is not None:
+            ev1.record()
+            # flops as ISSUED: the upper triangle of X_p^T X_p in 32 x 32 blocks, per candidate
+            nj = self.K // 32
+            GEMM_EVENTS.append((I8, self.T, 32 * nj * (nj + 1) // 2, 32, P, 1, ev0, ev1, lib.adalog_last_kernel().decode()))
+        _lib.check(rc, "adalog_gram_act_score")
+        return scores
+
+
 # ------------------------------------------------------------------------------------------------ FPCS pieces
 def topk(scores, k: int):
     scores = _f32c(scores, "scores")

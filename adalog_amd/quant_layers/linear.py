@@ -370,6 +370,27 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         fixed = self._pack_x_fixed()
         return lambda s, z, defer=False: self._score_w(fixed, s, z, defer=defer)
 
+    def _a_scorer(self):
+        """The scoring function (scale, zp, defer=False) -> scores [P, 1] | PendingScores of one output-MSE activation_fpcs call, with
+        whatever is fixed for the call (the weight quantiser: linear.py:505-523) prepared once: the Gram-form state (csrc/gram_act.hip:
+        the candidates' own Gram matrices X_p^T X_p against H = Wq^T Wq, K^2 / 2 instead of O K multiply-adds per token) where
+        backend.gram_act_ok takes the search, else the packed weight image of the token-form kernels."""
+        be = backend.get()
+        aq, wq = self.a_quantizer, self.w_quantizer
+        x2 = self._x2()
+        if (hasattr(be, "gram_act_ok") and type(aq) is UniformQuantizer and not aq.channel_wise and aq.scale.numel() == 1
+                and be.gram_act_ok(x2.shape[0], self.out_features, self.in_features, aq.n_bits, wq.n_bits, self.eq_n)):
+            prep = search.memo_tensor_fn("gact", self.raw_input, (), lambda: be.GramActPrepared(x2))
+            st = be.GramActState(prep, self.raw_out.reshape(-1, self.out_features), None if self.bias is None else self.bias.data,
+                                 self._w2(), wq.scale.data.view(-1), wq.zero_point.data.view(-1), wq.n_bits, aq.n_bits, self.eq_n)
+            norm = 1.0 / (self._tokens_per_image() * self.out_features)
+            return lambda s, z, defer=False: st.score(s, z, norm)
+        dt = self._int_dt(self.raw_input.numel() // self.in_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K,
+                          fixed=wq)
+        wp = self._pack_w_fixed(dt)
+        wp.int_dt = dt
+        return lambda s, z, defer=False: self._score_a(wp, s, z, defer=defer)
+
     def _gram_state(self):
         """The Gram-form state of an output-MSE weight search (linear.py:355-392 with the activation quantiser fixed for the whole
         weight_fpcs call), or None where the token-form kernels serve the search: a non-uniform or per-channel activation
@@ -392,11 +413,8 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if search_strategy == "self":
             fn = lambda s, z, t: self._score_a_self(s, z)
         else:
-            dt = self._int_dt(self.raw_input.numel() // self.in_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K,
-                              fixed=self.w_quantizer)
-            wp = self._pack_w_fixed(dt)
-            wp.int_dt = dt
-            fn = lambda s, z, t: self._score_a(wp, s, z, defer=True)
+            score = self._a_scorer()
+            fn = lambda s, z, t: score(s, z, defer=True)
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, 1e-4)
         if res is not None:
             self._commit_a(res[0], res[1])

@@ -277,6 +277,35 @@ int adalog_gram_build(const float* x, int T, int K, int64_t ldx, const float* sa
 int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
                         const void* workspace, int T, int a_bits, const float* sa, double norm, float* scores, void* stream);
 
+/* ---- K8, Gram form   _search_best_a_scale scored from the candidates' Gram matrices   reference quant_layers/linear.py:394-430,505-523
+ * The weight quantiser is fixed for the six scoring calls of an activation_fpcs call, and the score of the per-tensor candidate
+ * p = (s_p, z_p),  sum_{t,o} (r[t][o] - s_p sum_k Wq[o][k] x_p[t][k])^2  with r = raw_out - bias, Wq = diag(s_w) W_int and
+ * x_p = clamp(rne(x / s_p) + z_p, 0, 2^b - 1) - z_p, expands to  S0 - 2 s_p <X_p, C> + s_p^2 <H, X_p^T X_p>  with C = r . Wq [T][K],
+ * H = Wq^T Wq [K][K].  Per candidate only G_p = X_p^T X_p is a product: K x K x T / 2 multiply-adds (symmetric) instead of O x K x T,
+ * exact on the int8 MFMA; <X_p, C> comes from prefix sums of C along the SORTED activation (a uniform quantiser's levels are runs of
+ * it): 2^b + 2 bisections per candidate.  csrc/gram_act.hip has the error analysis.
+ *   adalog_gram_act_prepare   once per captured activation x [T][K] (contiguous): xt fp32 [K][Tp] (Tp = T rounded up to 128), the
+ *                             sorted values [T K] and the sorting permutation (uint32 flat indices); sort_ws of
+ *                             adalog_gram_act_sort_bytes(T K) bytes
+ *   adalog_gram_act_build     once per activation_fpcs call: raw_out [T][O], bias [O] | null, W [O][ldw] + its quantiser (s_w, z_w) [O]
+ *                             -> workspace (adalog_gram_act_workspace_bytes, 256-byte aligned): H, prefix sums of C, S0
+ *   adalog_gram_act_score     one FPCS step: scores [P] = -norm * (the sum above) for candidates (scale, zp) [P]; qpart: scratch of
+ *                             P * adalog_gram_act_splits(T, O, K, P) doubles
+ * adalog_gram_act_supported: per-tensor candidates, K % 32 == 0 and <= 384 (instantiated), <= 7-bit operands; adalog_gram_act_ok: ... and
+ * enough tokens for it to pay. */
+int adalog_gram_act_supported(int T, int O, int K, int a_bits, int w_bits, int P);
+int adalog_gram_act_ok(int T, int O, int K, int a_bits, int w_bits, int P);
+int64_t adalog_gram_act_workspace_bytes(int T, int O, int K, int P);
+int64_t adalog_gram_act_sort_bytes(int64_t n);
+int adalog_gram_act_splits(int T, int O, int K, int P);
+int adalog_gram_act_prepare(const float* x, int T, int K, int64_t ldx, float* xt, float* sorted, unsigned int* perm, void* sort_ws,
+                            int64_t sort_ws_bytes, void* stream);
+int adalog_gram_act_build(const float* raw_out, int T, int O, const float* bias, const float* W, int K, int64_t ldw, const float* sw,
+                          const float* zw, int w_bits, const unsigned int* perm, int P, void* workspace, int64_t workspace_bytes,
+                          void* stream);
+int adalog_gram_act_score(const float* xt, const float* sorted, int T, int O, int K, const float* scale, const float* zp, int P, int a_bits,
+                          const void* workspace, double norm, double* qpart, float* scores, void* stream);
+
 /* ---- K9   _search_best_w_scale_self                                   reference linear.py:296-309
  * scores[p][row] = -mean_i (w[row][i] - fq_p(w[row][i]))^2,  w: [rows][I], scale/zp: [P][rows]. */
 int adalog_score_w_self(const float* w, int rows, int I, const float* scale, const float* zp, int P, int n_bits,

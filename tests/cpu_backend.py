@@ -684,6 +684,41 @@ class GramState:
         return (-norm * (self.S0.view(1, O) - 2.0 * sig * lin + sig * sig * quad)).float()
 
 
+def gram_act_ok(T, O, K, a_bits, w_bits, P):
+    return K % 32 == 0 and K <= 384 and a_bits <= 7 and w_bits <= 7   # (permissive: the CPU tier exercises the host path at toy shapes)
+
+
+class GramActPrepared:
+    """spec of ops.GramActPrepared: the captured activation (the kernels' transposed / sorted images are layout only)"""
+
+    def __init__(self, x2):
+        self.x = x2
+        self.T, self.K = x2.shape
+
+
+class GramActState:
+    """spec of ops.GramActState (csrc/gram_act.hip): scores[p] = -norm * sum_{t,o} (raw_out - bias - s_p Wq . x_p)^2 evaluated in fp64 --
+    what S0 - 2 s_p <X_p, C> + s_p^2 <H, X_p^T X_p> equals in exact arithmetic (the kernels carry every term exactly or in fp64)."""
+
+    def __init__(self, prep, raw_out2, bias, w2, sw, zw, w_bits, a_bits, P):
+        self.prep, self.a_bits = prep, a_bits
+        z = torch.round(zw.reshape(-1, 1))
+        s = sw.reshape(-1, 1)
+        wq = ((torch.round(w2 / s) + z).clamp(0, 2 ** w_bits - 1) - z)
+        self.Wq = wq.double() * s.double()                                        # [O, K]
+        self.r = (raw_out2 - (bias.view(1, -1) if bias is not None else 0.0)).double()   # fp32 subtract, then fp64
+
+    def score(self, scale, zp, norm):
+        scale, zp = scale.reshape(-1), torch.round(zp.reshape(-1))
+        out = []
+        for s_, z_ in zip(scale.tolist(), zp.tolist()):
+            s32 = torch.tensor(s_, dtype=torch.float32)
+            xq = ((torch.round(self.prep.x / s32) + z_).clamp(0, 2 ** self.a_bits - 1) - z_).double()
+            o = (xq @ self.Wq.t()) * float(s32)
+            out.append(-norm * ((self.r - o) ** 2).sum())
+        return torch.stack(out).float().view(-1, 1)
+
+
 def score_w_gen_ok(dtype, T, O, K, Kp, P):
     return K % 16 == 0 and P in (64, 128, 256)            # (permissive: the CPU tier exercises the host path at toy shapes)
 

@@ -51,7 +51,7 @@ def _log(name, **kw):
 # file -- checks that every production label was hit by some case, so a dispatch regression cannot stay green.
 FALLBACK = {"k_gemm_cand", "k_gemm_cand_glds", "k_gemm_score", ""}
 SEEN = {}
-REQUIRED = {"k_gram_score<i8>", "k_gemm_slab_wgen<fp8>", "k_gemm_slab_wgen<i8>", "k_gemm_slab128_wgen<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
+REQUIRED = {"k_gram_score<i8>", "k_gram_act<i8>", "k_gemm_slab_wgen<fp8>", "k_gemm_slab_wgen<i8>", "k_gemm_slab128_wgen<fp8>", "k_gemm_slab_gen<fp8>", "k_gemm_slab_gen<i8>",
             "k_gemm_slab128_gen<fp8>", "k_act_fused_asm<12,4,bf16>", "k_act_fused_asm<12,3,bf16>", "k_act_fused_asm<8,4,bf16>",
             "k_act_fused_asm<4,4,bf16>", "k_gemm_stream<bf16xfp8>", "k_gemm_stream<bf16>", "k_gemm_grpw_gen<fp8>", "k_gemm_grpw_gen<i8>",
             "k_gemm_grpk8<bf16xfp8>", "k_gemm_grpk<bf16>", "k_gemm_win_gen<fp8>", "k_gemm_winb<bf16xfp8>", "k_gemm_avq<13,bf16>",
@@ -104,6 +104,9 @@ LINEAR = [  # tag, I, O, n_V, tokens per image, images, bits
 # cases whose weight search production scores from the Gram matrix (K % 32 == 0 and limbs * K <= tokens / 2: csrc/gram.hip)
 GRAM_CASES = {"deit_small.qkv-w4", "deit_small.proj-w4", "vit_base.qkv-w4", "deit_base.proj-w3", "vit_base.fc1-w4", "swin_base.reduction-w3",
               "swin_base.l0.fc1-w3", "swin_base.l0.fc1@128img-w3", "deit_small.qkv-w6", "deit_small.fc1-w6"}
+# cases whose activation search production scores from the candidates' Gram matrices (K % 32 == 0, K <= 384: csrc/gram_act.hip)
+GRAM_ACT_CASES = {"deit_small.qkv-w4", "deit_small.proj-w4", "swin_base.l0.fc1-w3", "swin_base.l0.fc1@128img-w3", "deit_small.qkv-w6",
+                  "deit_small.fc1-w6"}
 LINEAR_KERNELS = {          # case -> (weight search [token form], activation search) labels dispatched there
     "deit_small.qkv-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),
     "deit_small.proj-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),
@@ -151,6 +154,10 @@ def test_linear_scores_full_shape(tag, I, Oc, n_V, T, N, bits):
         # ... and the token form (what runs where the Gram form declines: ADALOG_GRAM_W=0, few tokens per K, K % 32 != 0)
         got_w = lay._score_w(lay._pack_x_fixed(), cw_s, cw_z)[SUB]
         kw = _kern(case, "w") if not small else ""
+        # the activation search as activation_fpcs dispatches it (round 5: the Gram form where adalog_gram_act_ok takes the shape) ...
+        got_ap = lay._a_scorer()(ca_s, ca_z)[SUB]
+        kap = _kern(case, "a_production") if not small else ""
+        # ... and the token form
         from adalog_amd.quant_layers.linear import FP8_WEIGHT_SEARCH_MAX_K
         dt = lay._int_dt(N * T, prefer_fp8=I <= FP8_WEIGHT_SEARCH_MAX_K)          # as activation_fpcs picks it (linear.py)
         wp = lay._pack_w_fixed(dt)
@@ -159,12 +166,14 @@ def test_linear_scores_full_shape(tag, I, Oc, n_V, T, N, bits):
         ka = _kern(case, "a") if not small else ""
         got_ws = lay._score_w_self(cw_s, cw_z)[SUB]
         got_as = lay._score_a_self(ca_s, ca_z)[SUB]
-    errs = dict(w=_rel(got_w, ref_w), w_production=_rel(got_wp, ref_w), a=_rel(got_a, ref_a), w_self=_rel(got_ws, ref_ws),
-                a_self=_rel(got_as, ref_as))
-    _log(case, kernel_w=kw, kernel_w_production=kwp, kernel_a=ka, **errs)
+    errs = dict(w=_rel(got_w, ref_w), w_production=_rel(got_wp, ref_w), a=_rel(got_a, ref_a), a_production=_rel(got_ap, ref_a),
+                w_self=_rel(got_ws, ref_ws), a_self=_rel(got_as, ref_as))
+    _log(case, kernel_w=kw, kernel_w_production=kwp, kernel_a=ka, kernel_a_production=kap, **errs)
     assert max(errs.values()) <= RTOL, errs
     if case in GRAM_CASES:
         _expect(case, "w_production", "k_gram_score<i8>")
+    if case in GRAM_ACT_CASES:
+        _expect(case, "a_production", "k_gram_act<i8>")
     if case in LINEAR_KERNELS:
         _expect(case, "w", *LINEAR_KERNELS[case][0])
         _expect(case, "a", *LINEAR_KERNELS[case][1])

@@ -1678,3 +1678,58 @@ def test_gram_form_rejects_what_it_cannot_score(ops):
     assert lib.adalog_gram_supported(197, 1152, 384, 4, 4, 128) and not lib.adalog_gram_ok(197, 1152, 384, 4, 4, 128)   # one image: does not pay
     assert lib.adalog_gram_ok(6304, 1152, 384, 4, 4, 128) and lib.adalog_gram_limbs(6304, 4) == 3 and lib.adalog_gram_limbs(6304, 6) == 4
     assert lib.adalog_gram_build(None, 6304, 384, 384, None, None, 4, None, 1152, None, None, 0, None) == -1
+
+
+# ------------------------------------------------------------------------------------------------ Gram-form activation search (round 5)
+GRAM_ACT_SHAPES = [  # T, O, K, tokens per image
+    (6304, 1152, 384, 197),      # deit_small qkv
+    (6304, 384, 384, 197),       # deit_small proj
+    (6304, 576, 192, 197),       # deit_tiny qkv (NJ = 6)
+    (1000, 200, 96, 125),        # NJ = 3, tokens / rows that are no multiple of any tile, no bias
+    (25088, 768, 256, 784),      # swin_base stage 1 (NJ = 8)
+    (3136, 96, 32, 3136),        # NJ = 1
+    (1568, 100, 64, 49),         # NJ = 2
+    (12544, 384, 128, 3136),     # NJ = 4
+]
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+@pytest.mark.parametrize("T,O,K,tok", GRAM_ACT_SHAPES)
+def test_gram_act_score_matches_fp64_and_token_form(ops, bits, T, O, K, tok):
+    """adalog_gram_act_{prepare,build,score} (per candidate X_p^T X_p on the int8 MFMA against H = Wq^T Wq in fp64; the linear term
+    from prefix sums of C = r . Wq along the sorted activation) against (1) the fp64 evaluation of the same sum
+    (tests/cpu_backend.GramActState) on a subset of candidates and (2) the token-form slab kernel where it takes the shape;
+    activation values planted on rounding ties of one candidate."""
+    from adalog_amd.ops import FP8, I8
+    gen = g(13000 + bits + T + O + K)
+    P = 128
+    x = torch.randn(T, K, generator=gen)
+    x[:, : max(1, K // 8)] *= 3.0
+    W = torch.randn(O, K, generator=gen) * 0.05
+    b = torch.randn(O, generator=gen) * 0.1 if K != 96 else None
+    qmax = 2 ** bits - 1
+    w_lo, w_hi = W.min(1).values, W.max(1).values
+    sw = (w_hi - w_lo) / qmax
+    zw = torch.round(-w_lo / sw).clamp(0, qmax)
+    sc = (2 * x.abs().max().item() / qmax) * torch.linspace(0.5, 1.1, P)
+    zp = torch.round(torch.linspace(qmax / 2 - 2, qmax / 2 + 2, P)).clamp(0, qmax)
+    x[5, 3] = (sc[17] * 2.5).item()                                       # exact ties of candidate 17
+    x[7, 1] = (sc[90] * -1.5).item()
+    ref = torch.nn.functional.linear(x, W, b)
+    d = lambda t_: t_.to(DEV).contiguous()
+    lib = ops._lib.load()
+    assert lib.adalog_gram_act_supported(T, O, K, bits, bits, P)
+    norm = 1.0 / (tok * O)
+    prep = ops.GramActPrepared(d(x))
+    st = ops.GramActState(prep, d(ref), None if b is None else d(b), d(W), d(sw), d(zw), bits, bits, P)
+    got = st.score(d(sc).view(P, 1), d(zp).view(P, 1), norm)
+    assert _last_kernel() == "k_gram_act<i8>" and got.shape == (P, 1)
+    sub = [0, 17, 18, 63, 90, 127]
+    spec = CB.GramActState(CB.GramActPrepared(x), ref, b, W, sw, zw, bits, bits, P).score(sc[sub], zp[sub], norm)
+    assert rel_err(got.cpu()[sub], spec) <= 3e-6
+    dt = FP8 if bits <= 4 else I8
+    wp = ops.pack_uniform(d(W).unsqueeze(0), d(sw), d(zw), 1, 0, 1, 0, 1, bits, dt)
+    if ops.score_act_gen_ok(dt, O, T, K, wp.shape[-1], P):
+        want = ops.score_act_gen(dt, wp, d(x), d(sc).view(P, 1), d(zp).view(P, 1), bits, d(ref), d(sw), None if b is None else d(b), norm)
+        assert rel_err(got.cpu(), want.cpu()) <= 3e-6
+    assert torch.equal(got, st.score(d(sc).view(P, 1), d(zp).view(P, 1), norm))     # bit-reproducible

@@ -73,6 +73,26 @@ def test_linear_traces_gram_form(golden, name, monkeypatch):
     _log(name + "_gram", r)
 
 
+@pytest.mark.parametrize("name", ["linear_w3a3", "linear_w4a4", "linear_w6a6"])     # (the ragged fixture has K = 24: token form)
+def test_linear_traces_gram_act_form(golden, name, monkeypatch):
+    """The reference's golden activation-search traces through the Gram-form activation kernels (csrc/gram_act.hip; ADALOG_GRAM_A=2
+    takes every supported shape, also these toy ones): same bars as the token form."""
+    from adalog_amd import _lib, ops
+    monkeypatch.setenv("ADALOG_GRAM_A", "2")
+    seen = []
+    real = ops.GramActState.score
+
+    def spy(self, *a, **k):
+        r = real(self, *a, **k)
+        seen.append(_lib.load().adalog_last_kernel().decode())
+        return r
+    monkeypatch.setattr(ops.GramActState, "score", spy)
+    r = TR.replay_linear(golden, name, DEV)
+    assert r["calls"] == 48
+    assert len(seen) >= 18 and set(seen) == {"k_gram_act<i8>"}, seen[:3]
+    _log(name + "_gram_act", r)
+
+
 @pytest.mark.parametrize("bits", [3, 4, 6])
 def test_channelwise_traces(golden, bits):
     r = TR.replay_channelwise(golden, bits, DEV)

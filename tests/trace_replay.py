@@ -138,10 +138,9 @@ def _linear_observer(lay, rp, dev):
             rp.check(lay._w_scorer()(_pc(a, dev), _pc(b, dev)), True, en["w_out"])
         elif kind == "a_out":
             _set_uniform(lay.w_quantizer, p.w_scale, p.w_zp)
-            dt = lay._int_dt(lay.raw_input.numel() // lay.in_features)
-            wp = lay._pack_w_fixed(dt)
-            wp.int_dt = dt
-            rp.check(lay._score_a(wp, _pl(a, dev), _pl(b, dev)), False, en["a_out"])
+            # (as activation_fpcs dispatches it: the Gram form where backend.gram_act_ok takes the shape -- ADALOG_GRAM_A=2 at these
+            # toy sizes --, else the token-form kernels)
+            rp.check(lay._a_scorer()(_pl(a, dev), _pl(b, dev)), False, en["a_out"])
         else:
             raise AssertionError(kind)
     return obs
