@@ -45,7 +45,6 @@ namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <typename F, int... I> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -341,7 +340,7 @@ struct GaQuadArgs {
     const double* hfrag;                           // [NBT][64][16]
     double* qpart;                                 // [P][S]
     int S, chunks_per_split, nchunk;               // 32-token chunks
-    float qmax, tie, tie_f;                        // tie_f: the threshold of the fma form (zone widened by the fma's own rounding)
+    float qmax, tie;
     long long* timeline;                           // lab only: per workgroup [4 waves][8] cycle sums (mfma phase, generation, barrier, total)
 };
 
@@ -469,30 +468,20 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
             // behind them, sched_barrier or not).
             if constexpr (b < 16) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(fi), "v"(fj));
             else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(fi), "v"(fj));
-            // ... and behind each MFMA its share of the generator's elements (fast path), pinned there.  Two elements at a time:
-            // t' = fma(x, 1/s, 128) and the tie distance t' - rne(t') as packed fp32 operations (the + 128 of the biased u8
-            // conversion rides in the fma: its extra rounding, half an ulp of a value below 256, is inside the widened tie zone)
+            // ... and behind each MFMA its share of the generator's elements (fast path), pinned there.  (Tried and dropped, same box:
+            // t' = fma(x, 1/s, 128) saving the biased conversion's add -- 182 -> 191 us per launch; the same as packed fp32
+            // operations -- 196 us: packed fp32 issues badly beside MFMAs, as the guide's filler table says.)
             {
 #pragma clang fp contract(off)
-                constexpr int NPR = NEL / 2;
-                constexpr int lo = (b * NPR) / NOWN, hi = ((b + 1) * NPR) / NOWN;
+                constexpr int lo = (b * NEL) / NOWN, hi = ((b + 1) * NEL) / NOWN;
                 sfor<hi - lo>([&](auto kc) {
-                    constexpr int idx = 2 * (lo + decltype(kc)::value), g = idx >> 4, e = idx & 15;      // elements e, e + 1 of fragment g
+                    constexpr int idx = lo + decltype(kc)::value, g = idx >> 4, e = idx & 15;
                     const float4 q4 = xr[g][e >> 2];
-                    // (scalar VALU on purpose: the packed forms v_pk_fma_f32 / v_pk_add_f32 were measured here -- 182 -> 196 us per
-                    // launch; packed fp32 issues badly beside MFMAs, as the guide's filler table says)
-                    const float x0 = (e & 3) == 0 ? q4.x : q4.z, x1 = (e & 3) == 0 ? q4.y : q4.w;
-                    struct { float x, y; } t, k, dd;
-                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.x) : "v"(x0), "v"(ginv), "v"(128.0f));
-                    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t.y) : "v"(x1), "v"(ginv), "v"(128.0f));
-                    k.x = rintf(t.x); k.y = rintf(t.y);
-                    asm("v_sub_f32 %0, %1, %2" : "=v"(dd.x) : "v"(t.x), "v"(k.x));
-                    asm("v_sub_f32 %0, %1, %2" : "=v"(dd.y) : "v"(t.y), "v"(k.y));
-                    dmn[g] = fmaxf(dmn[g], fmaxf(fabsf(dd.x), fabsf(dd.y)));
-                    unsigned u = (unsigned)pkn[g][e >> 2];
-                    u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k.x, glo, ghi), e & 3, u);
-                    u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k.y, glo, ghi), (e & 3) + 1, u);
-                    pkn[g][e >> 2] = (int)u;
+                    const float xv = (e & 3) == 0 ? q4.x : (e & 3) == 1 ? q4.y : (e & 3) == 2 ? q4.z : q4.w;
+                    const float t = xv * ginv;
+                    const float k = rintf(t);
+                    dmn[g] = fmaxf(dmn[g], fabsf(t - k));
+                    pkn[g][e >> 2] = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k + 128.0f, glo, ghi), e & 3, (unsigned)pkn[g][e >> 2]);
                     if constexpr (decltype(kc)::value == hi - lo - 1) asm volatile("" : "+v"(dmn[g]), "+v"(pkn[g]));
                 });
             }
@@ -504,10 +493,10 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
                 constexpr int idx = decltype(kc)::value, g = idx >> 4, e = idx & 15;
                 const float4 q4 = xr[g][e >> 2];
                 const float xv = (e & 3) == 0 ? q4.x : (e & 3) == 1 ? q4.y : (e & 3) == 2 ? q4.z : q4.w;
-                const float t = __builtin_fmaf(xv, ginv, 128.0f);
+                const float t = xv * ginv;
                 const float k = rintf(t);
                 dmn[g] = fmaxf(dmn[g], fabsf(t - k));
-                pkn[g][e >> 2] = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k, glo, ghi), e & 3, (unsigned)pkn[g][e >> 2]);
+                pkn[g][e >> 2] = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k + 128.0f, glo, ghi), e & 3, (unsigned)pkn[g][e >> 2]);
             });
         }
 #pragma unroll
@@ -518,7 +507,7 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
         if (p.timeline) { asm volatile("s_nop 0" ::: "memory"); tb = GA_T(); }
         sfor<NGEN>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if (__builtin_expect(dmn[g] > p.tie_f, 0)) gen_exact(gc, pkn[g]);
+            if (__builtin_expect(dmn[g] > p.tie, 0)) gen_exact(gc, pkn[g]);
             *reinterpret_cast<v4i*>(frag_addr((c + 1) & 1, g)) = pkn[g];
         });
         load_x(c + 2);                                      // a whole iteration ahead of the generator that consumes it
@@ -786,7 +775,6 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
     a.qmax = (float)((1 << a_bits) - 1);
     const float zone = 6e-7f * (float)(1 << a_bits);
     a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
-    a.tie_f = a.tie - 1e-5f;                                // t' < 256: half an ulp is 7.6e-6
     a.timeline = g_ga_timeline;
     hipStream_t st = (hipStream_t)stream;
 #define GA_LAUNCH(NJV)                                                                                            \
