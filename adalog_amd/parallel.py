@@ -132,7 +132,17 @@ def _group():
     return getattr(_tls, "group", None)
 
 
+# what this rank WOULD put on the fabric with several ranks: every all-reduce site is counted even in a one-rank run (the payloads --
+# [P, cols] score tensors, min / max scalars, radix histograms -- do not depend on the world size), so that a one-GPU bench line
+# already states the collective count and bytes of the N-GPU job (bench.py: collectives.planned_per_step)
+PLANNED = {"collectives": 0, "bytes": 0}
+
+
 def _all_reduce(t: torch.Tensor, op) -> torch.Tensor:
+    if not getattr(_tls, "solo", False):
+        with _stats_lock:
+            PLANNED["collectives"] += 1
+            PLANNED["bytes"] += t.numel() * t.element_size()
     if not is_dist():
         return t
     ev = None
@@ -158,6 +168,8 @@ def reset_stats():
     with _stats_lock:
         STATS["collectives"] = 0
         STATS["bytes"] = 0
+        PLANNED["collectives"] = 0
+        PLANNED["bytes"] = 0
         _EVENTS.clear()
 
 
@@ -167,6 +179,7 @@ def collective_stats():
     with _stats_lock:
         evs = list(_EVENTS)
         out = dict(STATS)
+        out["planned_collectives"], out["planned_bytes"] = PLANNED["collectives"], PLANNED["bytes"]
     if evs:
         torch.cuda.synchronize()
         out["device_ms"] = sum(a.elapsed_time(b) for a, b in evs)

@@ -732,6 +732,10 @@ def main():
                        "fpcs_note": "device events on the search stream around every module's hyperparameter_searching (+ reparam), "
                                     "summed over the modules (rank 0); capture = the FP forward passes that record the activations",
                        "collectives": {"per_step": coll["collectives"] / args.steps, "bytes_per_step": coll["bytes"] / args.steps,
+                                       # every all-reduce SITE this rank passed, also in a one-rank run (payloads do not depend on the
+                                       # world size): what each rank of an N-GPU job puts on the fabric per calibration
+                                       "planned_per_step": coll.get("planned_collectives", 0) / args.steps,
+                                       "planned_bytes_per_step": coll.get("planned_bytes", 0) / args.steps,
                                        "stream_ms_per_step": None if coll["device_ms"] is None else coll["device_ms"] / args.steps,
                                        "schedule": "two lanes (two modules' searches side by side, each on its own stream and "
                                                    "communicator, one global issue order)" if world > 1 and os.environ.get("ADALOG_INTERLEAVE", "0") == "1"
