@@ -1,6 +1,6 @@
 #!/bin/bash
 # copies the summaries of tools/final_run.sh (gpurun_out/final, scratch) into profiles/ (tracked), named per round
-r=${1:-r04}
+r=${1:-r05}
 f=gpurun_out/final
 cp $f/bench.json profiles/${r}_bench.json
 for m in deit_tiny vit_base swin_small swin_base w3 w6 swin_base_w3_128img; do [ -f $f/bench_$m.json ] && cp $f/bench_$m.json profiles/${r}_bench_$m.json; done
@@ -12,6 +12,8 @@ for m in vit_base swin_base; do [ -f $f/prof_$m/p_kernel_stats.csv ] && cp $f/pr
 [ -f $f/pmc/traffic.json ] && cp $f/pmc/traffic.json profiles/${r}_pmc_bench_traffic.json
 [ -f $f/pmc_fused/summary.json ] && cp $f/pmc_fused/summary.json profiles/${r}_pmc_fused_summary.json
 [ -f $f/pmc_slab/summary.json ] && cp $f/pmc_slab/summary.json profiles/${r}_pmc_slab_summary.json
+[ -f $f/pmc_gram/summary.json ] && cp $f/pmc_gram/summary.json profiles/${r}_pmc_gram_summary.json
+[ -f gpurun_out/e2e_outcomes.jsonl ] && cp gpurun_out/e2e_outcomes.jsonl profiles/${r}_e2e_outcomes.jsonl
 tail -5 $f/pytest_gpu.log > profiles/${r}_pytest_gpu_tail.log
 for n in trace_parity fullshape_parity golden_forward_parity wrapper_flow_parity brecq_traj_parity; do [ -f gpurun_out/$n.jsonl ] && cp gpurun_out/$n.jsonl profiles/${r}_$n.jsonl; done
 [ -f gpurun_out/brecq_convergence.json ] && cp gpurun_out/brecq_convergence.json profiles/${r}_brecq_convergence.json

@@ -2,7 +2,7 @@
 # End-of-round validation on the GPU box (run from the repo root, e.g. gpurun -- 'bash tools/final_run.sh'):
 # the -m gpu test suite, the default bench line, a rocprofv3 kernel-stats pass, the PMC traffic passes, the 2-rank gloo
 # launch path, and one calibration each of the other model families / bit widths.  Everything lands under
-# gpurun_out/final/; the summaries that are kept go to profiles/r04_* (tools/collect_profiles.sh r04).
+# gpurun_out/final/; the summaries that are kept go to profiles/r05_* (tools/collect_profiles.sh r05).
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 mkdir -p gpurun_out/final
 rm -f gpurun_out/trace_parity.jsonl gpurun_out/fullshape_parity.jsonl gpurun_out/golden_forward_parity.jsonl gpurun_out/wrapper_flow_parity.jsonl gpurun_out/brecq_traj_parity.jsonl
@@ -16,6 +16,7 @@ rm -f gpurun_out/final/prof_all/p_kernel_trace.csv gpurun_out/final/prof_all/*/p
 timeout 600 bash tools/pmc_bench.sh gpurun_out/final/pmc > gpurun_out/final/pmc.log 2>&1; tail -5 gpurun_out/final/pmc.log
 timeout 300 bash tools/pmc_fused.sh gpurun_out/final/pmc_fused > gpurun_out/final/pmc_fused.log 2>&1
 PROF_DT=fp8 timeout 600 bash tools/pmc_gemm.sh gpurun_out/final/pmc_slab "qkv fc1" > gpurun_out/final/pmc_slab.log 2>&1
+timeout 600 bash tools/pmc_gram.sh gpurun_out/final/pmc_gram > gpurun_out/final/pmc_gram.log 2>&1
 ADALOG_DIST_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/final/bench_gloo2.json 2> gpurun_out/final/bench_gloo2.err; head -c 200 gpurun_out/final/bench_gloo2.json; echo
 for m in deit_tiny vit_base swin_small swin_base; do timeout 300 python bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_$m.json 2> gpurun_out/final/bench_$m.err; head -c 200 gpurun_out/final/bench_$m.json; echo; done
 for b in 3 6; do timeout 300 python bench.py --bits $b --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_w${b}.json 2> gpurun_out/final/bench_w${b}.err; head -c 200 gpurun_out/final/bench_w${b}.json; echo; done

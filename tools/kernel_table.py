@@ -4,11 +4,13 @@
 import csv
 import sys
 
-r = sys.argv[1] if len(sys.argv) > 1 else "r04"
+r = sys.argv[1] if len(sys.argv) > 1 else "r05"
 GROUPS = [
     ("`k_act_fused_asm` (fc2 activation search)", ["k_act_fused_asm"]),
-    ("`k_gemm_slab<…, GEN>` (qkv / proj / fc1 activation searches)", ["k_gemm_slab<2, true", "k_gemm_slab<1, true"]),
-    ("`k_gemm_slab<…, GEN>` weight form (qkv / proj / fc1 weight searches)", ["k_gemm_slab<2, false", "k_gemm_slab<1, false"]),
+    ("`k_ga_quad` + build + finish (Gram form: qkv / proj / fc1 activation searches)", ["k_ga_"]),
+    ("`k_gram_score` + build (Gram form: qkv / proj / fc1 weight searches)", ["k_gram_"]),
+    ("`k_gemm_slab<…, GEN>` (token-form activation searches)", ["k_gemm_slab<2, true", "k_gemm_slab<1, true"]),
+    ("`k_gemm_slab<…, GEN>` weight form (token-form weight searches)", ["k_gemm_slab<2, false", "k_gemm_slab<1, false"]),
     ("`k_gemm_stream` (fc2 weight search `MX`, patch embedding)", ["k_gemm_stream"]),
     ("`k_gemm_grpw<GEN>` / `k_gemm_grpk8` / `k_gemm_avq` (attention)", ["k_gemm_grp", "k_gemm_avq", "k_gemm_win"]),
     ("operand packs", ["k_pack"]),

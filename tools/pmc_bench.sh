@@ -18,7 +18,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for f in glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
-            if ("k_gemm_" not in name and "k_act_fused" not in name) or row["Counter_Name"] != c:
+            if ("k_gemm_" not in name and "k_act_fused" not in name and "k_gram_" not in name and "k_ga_" not in name) or row["Counter_Name"] != c:
                 continue
             key = name.split("(anonymous namespace)::")[1].split("(")[0]
             a = acc.setdefault(key, {}).setdefault(c, [0.0, 0])
