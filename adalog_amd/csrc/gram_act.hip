@@ -304,16 +304,22 @@ __global__ void k_ga_sw2(const float* __restrict__ sw, int O, double* __restrict
 __host__ __device__ constexpr int tri_index(int i, int j, int NJ) { return i * NJ - (i * (i - 1)) / 2 + (j - i); }
 
 // hfrag[n][lane][e] = (i == j ? 1 : 2) * H[32 i + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 j + (lane & 31)],  H = sum_o s_w[o]^2 w[o][k1] w[o][k2]
-__global__ __launch_bounds__(256) void k_ga_h(const int8_t* __restrict__ wt, int K, int O, int64_t Op, const double* __restrict__ sw2,
-                                              double* __restrict__ hfrag) {
-    const int NJ = K >> 5;
+// for the blocks of one ROLE of the score kernels: tri != 0: the upper triangle of the nj k-blocks from i0 (row-major, i <= j);
+// else the ni x nj rectangle of rows i0 .. against columns j0 .. (row-major)
+__global__ __launch_bounds__(256) void k_ga_h(const int8_t* __restrict__ wt, int O, int64_t Op, const double* __restrict__ sw2,
+                                              double* __restrict__ hfrag, int i0, int j0, int ni, int nj, int tri) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int nblk = NJ * (NJ + 1) / 2;
+    const int nblk = tri ? nj * (nj + 1) / 2 : ni * nj;
     if (idx >= (int64_t)nblk * 1024) return;
     const int n = (int)(idx >> 10), lane = (int)((idx >> 4) & 63), e = (int)(idx & 15);
-    int i = 0, rem = n;
-    while (rem >= NJ - i) { rem -= NJ - i; ++i; }
-    const int j = i + rem;
+    int i, j;
+    if (tri) {
+        int li = 0, rem = n;
+        while (rem >= nj - li) { rem -= nj - li; ++li; }
+        i = i0 + li; j = i0 + li + rem;
+    } else {
+        i = i0 + n / nj; j = j0 + n % nj;
+    }
     const int k1 = 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3), k2 = 32 * j + (lane & 31);
     const int8_t* a = wt + (int64_t)k1 * Op;
     const int8_t* b = wt + (int64_t)k2 * Op;
@@ -337,9 +343,13 @@ __global__ __launch_bounds__(256) void k_ga_h(const int8_t* __restrict__ wt, int
 struct GaQuadArgs {
     const float* xt; int64_t Tp; int K;            // x in fragment order [chunk][k-block][piece][lane][4] (k_ga_fragorder)
     const float* scale; const float* zp; int P;    // candidates [P]
-    const double* hfrag;                           // [NBT][64][16]
-    double* qpart;                                 // [P][S]
+    const double* hfrag;                           // this launch's first role: [tiles of a role][64][16], roles back to back
+    double* qpart;                                 // [P][QS]: this launch writes columns q0 + role * S + split
     int S, chunks_per_split, nchunk;               // 32-token chunks
+    int NJT;                                       // k-blocks of the whole tensor (K / 32): the chunk stride of xt
+    int R;                                         // roles of this launch (workgroups per (candidate, split)): parts of the K x K triangle
+    int QS, q0;                                    // partial sums per candidate over all launches / this launch's first column
+    int kb_a, kb_b;                                // triangle role r: k-blocks kb_a + r NJ ..;  rectangle role r: rows kb_a .., columns kb_b + r NJC ..
     float qmax, tie;
     long long* timeline;                           // lab only: per workgroup [4 waves][8] cycle sums (mfma phase, generation, barrier, total)
 };
@@ -349,8 +359,9 @@ template <int NJ> __host__ __device__ constexpr int tri_row(int n) { int i = 0, 
 template <int NJ> __host__ __device__ constexpr int tri_col(int n) { const int i = tri_row<NJ>(n); return n - tri_index(i, i, NJ) + i; }
 
 template <int NJ, int W>
-__device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, int lane, int cand, int split) {
+__device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, int lane, int cand, int split, int role) {
     constexpr int NBT = NJ * (NJ + 1) / 2;                 // upper-triangle blocks
+    const int kb0 = p.kb_a + role * NJ;                    // this role's first k-block
     // this wave's blocks: a CONTIGUOUS range of the row-major list (runs of one row i: A fragment i stays in registers, the B
     // fragments j stream through two registers' worth -- all NJ fragments resident cost 48 registers the accumulators need)
     constexpr int N0 = (NBT * W) / 4, N1 = (NBT * (W + 1)) / 4;
@@ -374,7 +385,7 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
         const int cc = min(c, p.nchunk - 1);
         sfor<NGEN>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            const float* src = p.xt + (((int64_t)cc * NJ + (W + 4 * g)) * 4) * 256 + lane * 4;
+            const float* src = p.xt + (((int64_t)cc * p.NJT + (kb0 + W + 4 * g)) * 4) * 256 + lane * 4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) xr[g][j] = *reinterpret_cast<const float4*>(src + j * 256);
         });
@@ -526,7 +537,7 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
     sfor<NOWN>([&](auto bc) {
         constexpr int b = decltype(bc)::value;
         constexpr int n = N0 + b;
-        const double* hp = p.hfrag + ((int64_t)n * 64 + lane) * 16;
+        const double* hp = p.hfrag + (((int64_t)role * NBT + n) * 64 + lane) * 16;
 #pragma unroll
         for (int e = 0; e < 16; ++e) q += hp[e] * (double)acc[b][e];
     });
@@ -536,7 +547,7 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
     __syncthreads();
     if (lane == 0) red[W] = q;
     __syncthreads();
-    if (W == 0 && lane == 0) p.qpart[(int64_t)cand * p.S + split] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (W == 0 && lane == 0) p.qpart[(int64_t)cand * p.QS + p.q0 + role * p.S + split] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 template <int NJ>
@@ -545,11 +556,179 @@ __global__ __launch_bounds__(256, 1) void k_ga_quad(GaQuadArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // [2][NJ][64][16]
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cand = blockIdx.x / p.S, split = blockIdx.x % p.S;
-    if (w == 0) ga_quad_wave<NJ, 0>(p, lds, lane, cand, split);
-    else if (w == 1) ga_quad_wave<NJ, 1>(p, lds, lane, cand, split);
-    else if (w == 2) ga_quad_wave<NJ, 2>(p, lds, lane, cand, split);
-    else ga_quad_wave<NJ, 3>(p, lds, lane, cand, split);
+    const int cand = blockIdx.x / (p.S * p.R), rem = blockIdx.x % (p.S * p.R), role = rem / p.S, split = rem % p.S;
+    if (w == 0) ga_quad_wave<NJ, 0>(p, lds, lane, cand, split, role);
+    else if (w == 1) ga_quad_wave<NJ, 1>(p, lds, lane, cand, split, role);
+    else if (w == 2) ga_quad_wave<NJ, 2>(p, lds, lane, cand, split, role);
+    else ga_quad_wave<NJ, 3>(p, lds, lane, cand, split, role);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------ K > 384: the triangle in parts
+// The upper triangle of K = 512 (136 blocks) / 768 (300 blocks) does not fit one CU's registers.  The k-blocks are cut in two halves
+// A | B:  the triangles A x A and B x B are two ROLES of k_ga_quad<NJ / 2> (each generates only its own half of the fragments), and the
+// square A x B is scored by k_ga_rect: one role (8 x 8 blocks, K = 512) or two (12 x 6 each, K = 768); a wave owns NIW rows x NJC columns
+// of blocks and reads NIW + NJC fragments per chunk instead of all of them.  Generated fragments per candidate: 2 x K / 32 (K = 512),
+// 2.5 x K / 32 (K = 768) instead of K / 32 -- the generator is what bounds these kernels -- against O / 32 MFMAs per fragment of the
+// token form: the split forms pay for O >= 2 K (qkv, fc1).
+template <int NIW, int NJC, int W>
+__device__ __forceinline__ void ga_rect_wave(const GaQuadArgs& p, uint8_t* lds, int lane, int cand, int split, int role) {
+    constexpr int NF = 4 * NIW + NJC;                      // fragments per chunk in LDS: slots 0 .. 4 NIW - 1 the rows, then the columns
+    constexpr int NOWN = NIW * NJC;                        // this wave's blocks: rows NIW W .., all NJC columns
+    constexpr int NGEN = (NF - W + 3) / 4;                 // slots W, W + 4, ... this wave generates
+    constexpr int NRD = NIW + NJC;
+    static_assert(NOWN <= 20 && NGEN >= 1, "accumulator budget");
+    const int kbA = p.kb_a, kbB = p.kb_b + role * NJC;
+    const float gs = p.scale[cand], gz = rintf(p.zp[cand]);
+    const float ginv = __builtin_amdgcn_rcpf(gs);
+    const float glo = 128.0f - gz, ghi = 128.0f + (p.qmax - gz);
+    const int c0 = split * p.chunks_per_split, c1 = min(c0 + p.chunks_per_split, p.nchunk);
+
+    v16i acc[NOWN];
+#pragma unroll
+    for (int b = 0; b < NOWN; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[b][e] = 0;
+
+    float4 xr[NGEN][4];
+    auto load_x = [&](int c) {
+        const int cc = min(c, p.nchunk - 1);
+        sfor<NGEN>([&](auto gc) {
+            constexpr int g = decltype(gc)::value, f = W + 4 * g;
+            const int kb = f < 4 * NIW ? kbA + f : kbB + (f - 4 * NIW);
+            const float* src = p.xt + (((int64_t)cc * p.NJT + kb) * 4) * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr[g][j] = *reinterpret_cast<const float4*>(src + j * 256);
+        });
+    };
+    auto gen_fast = [&](auto gc, v4i& pk, float& dm) {
+#pragma clang fp contract(off)
+        constexpr int g = decltype(gc)::value;
+        float xv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xv[4 * j] = xr[g][j].x; xv[4 * j + 1] = xr[g][j].y; xv[4 * j + 2] = xr[g][j].z; xv[4 * j + 3] = xr[g][j].w; }
+        float kq[16];
+        dm = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float t = xv[e] * ginv;
+            kq[e] = rintf(t);
+            dm = fmaxf(dm, fabsf(t - kq[e]));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned u = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e] + 128.0f, glo, ghi), e, u);
+            pk[j] = (int)(u ^ 0x80808080u);
+        }
+    };
+    auto gen_exact = [&](auto gc, v4i& pk) {
+#pragma clang fp contract(off)
+        constexpr int g = decltype(gc)::value;
+        float xv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xv[4 * j] = xr[g][j].x; xv[4 * j + 1] = xr[g][j].y; xv[4 * j + 2] = xr[g][j].z; xv[4 * j + 3] = xr[g][j].w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned u = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(rintf(xv[4 * j + e] / gs) + 128.0f, glo, ghi), e, u);
+            pk[j] = (int)(u ^ 0x80808080u);
+        }
+    };
+    auto frag_addr = [&](int buf, int g) { return lds + (buf * NF + (W + 4 * g)) * 1024 + lane * 16; };
+
+    if (c0 < c1) {
+        load_x(c0);
+        sfor<NGEN>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            v4i pk; float dm;
+            gen_fast(gc, pk, dm);
+            if (dm > p.tie) gen_exact(gc, pk);
+            *reinterpret_cast<v4i*>(frag_addr(c0 & 1, g)) = pk;
+        });
+        load_x(c0 + 1);
+    }
+    __syncthreads();
+    for (int c = c0; c < c1; ++c) {
+        const uint8_t* fb = lds + ((c & 1) * NF) * 1024 + lane * 16;
+        v4i fr[NRD];                                        // the wave's NIW row fragments, then the NJC column fragments
+        sfor<NRD>([&](auto kc) {
+            constexpr int k = decltype(kc)::value, slot = k < NIW ? NIW * W + k : 4 * NIW + (k - NIW);
+            fr[k] = *reinterpret_cast<const v4i*>(fb + slot * 1024);
+        });
+        v4i pkn[NGEN];
+        float dmn[NGEN];
+#pragma unroll
+        for (int g = 0; g < NGEN; ++g) { pkn[g] = v4i{0, 0, 0, 0}; dmn[g] = 0.0f; }
+        constexpr int NEL = NGEN * 16;
+        sfor<NOWN>([&](auto bc) {                            // (the interleave of k_ga_quad: an MFMA, then its share of the generator)
+            constexpr int b = decltype(bc)::value;
+            const v4i fi = fr[b / NJC];
+            const v4i fj = fr[NIW + b % NJC];
+            if constexpr (b < 16) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(fi), "v"(fj));
+            else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(fi), "v"(fj));
+            {
+#pragma clang fp contract(off)
+                constexpr int lo = (b * NEL) / NOWN, hi = ((b + 1) * NEL) / NOWN;
+                sfor<hi - lo>([&](auto kc) {
+                    constexpr int idx = lo + decltype(kc)::value, g = idx >> 4, e = idx & 15;
+                    const float4 q4 = xr[g][e >> 2];
+                    const float xv = (e & 3) == 0 ? q4.x : (e & 3) == 1 ? q4.y : (e & 3) == 2 ? q4.z : q4.w;
+                    const float t = xv * ginv;
+                    const float k = rintf(t);
+                    dmn[g] = fmaxf(dmn[g], fabsf(t - k));
+                    pkn[g][e >> 2] = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k + 128.0f, glo, ghi), e & 3, (unsigned)pkn[g][e >> 2]);
+                    if constexpr (decltype(kc)::value == hi - lo - 1) asm volatile("" : "+v"(dmn[g]), "+v"(pkn[g]));
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#pragma unroll
+        for (int g = 0; g < NGEN; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pkn[g][j] ^= (int)0x80808080u;
+        sfor<NGEN>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            if (__builtin_expect(dmn[g] > p.tie, 0)) gen_exact(gc, pkn[g]);
+            *reinterpret_cast<v4i*>(frag_addr((c + 1) & 1, g)) = pkn[g];
+        });
+        load_x(c + 2);
+        __syncthreads();
+    }
+
+    // ---- <H, G_p> over this wave's blocks (row-major over the role's 4 NIW x NJC blocks; every one off the diagonal: H doubled)
+    double q = 0.0;
+    sfor<NOWN>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        constexpr int n = (NIW * W + b / NJC) * NJC + b % NJC;
+        const double* hp = p.hfrag + (((int64_t)role * (4 * NIW * NJC) + n) * 64 + lane) * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) q += hp[e] * (double)acc[b][e];
+    });
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    double* red = reinterpret_cast<double*>(lds);
+    __syncthreads();
+    if (lane == 0) red[W] = q;
+    __syncthreads();
+    if (W == 0 && lane == 0) p.qpart[(int64_t)cand * p.QS + p.q0 + role * p.S + split] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <int NIW, int NJC>
+__global__ __launch_bounds__(256, 1) void k_ga_rect(GaQuadArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];      // [2][4 NIW + NJC][64][16]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cand = blockIdx.x / (p.S * p.R), rem = blockIdx.x % (p.S * p.R), role = rem / p.S, split = rem % p.S;
+    if (w == 0) ga_rect_wave<NIW, NJC, 0>(p, lds, lane, cand, split, role);
+    else if (w == 1) ga_rect_wave<NIW, NJC, 1>(p, lds, lane, cand, split, role);
+    else if (w == 2) ga_rect_wave<NIW, NJC, 2>(p, lds, lane, cand, split, role);
+    else ga_rect_wave<NIW, NJC, 3>(p, lds, lane, cand, split, role);
 #endif
 }
 
@@ -568,14 +747,7 @@ __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sor
     const bool live = cand < P;
     const float s = live ? scale[cand] : 1.0f, z = live ? rintf(zp[cand]) : 0.0f;
     const float klo = ceilf(-z), khi = floorf(qmax - z);
-    auto lower = [&](float target) {                                   // first i with rne(x[i] / s) >= target
-        int64_t lo = 0, hi = n;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (rintf(sorted[mid] / s) >= target) hi = mid; else lo = mid + 1;
-        }
-        return lo;
-    };
+    auto lower = [&](float target) { return uni_level_lower(sorted, n, s, target); };   // (common.h: threshold + 16-ary search)
     if (live) {
         bnd[gi][t] = lower(fminf(klo + (float)t, khi + 1.0f));
         if (t == 0) bnd[gi][G] = lower(khi + 1.0f);
@@ -609,13 +781,16 @@ __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sor
 // ------------------------------------------------------------------------------------------------ host side
 struct GaPlan {
     int T, O, K, NJ; int64_t Tp, Op, n;
-    int nchunk, S, cps;
+    int nchunk, S, cps;                            // the triangle launch: token splits, chunks per split
+    int NJH, RT;                                   // k-blocks per triangle role, triangle roles (1: the whole triangle; 2: A x A and B x B)
+    int RR, NIW, NJC, SR, cpsr;                    // rectangle roles (0: none), their shape, token splits, chunks per split
+    int QS;                                        // partial sums per candidate: RT * S + RR * SR
     int64_t off_hfrag, off_prefix, off_s0, off_wt, off_rl, off_s0p, off_cscl, off_cpart, off_C, off_Cs, off_sw2, off_bsum, total;
     bool ok;
 };
 
 static int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
-static bool ga_nj_ok(int nj) { return nj == 1 || nj == 2 || nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12; }
+static bool ga_nj_ok(int nj) { return nj == 1 || nj == 2 || nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12 || nj == 16 || nj == 24; }
 
 static int ga_cus() {
     static int n_cu = 0;
@@ -639,12 +814,22 @@ static GaPlan ga_plan(int T, int O, int K, int P) {
     g.nchunk = (int)(g.Tp / 32);
     // token splits: P * S workgroups, one per CU at a time -- the smallest S that fills the chip, chunks <= 4096 (int32 accumulators:
     // 127^2 * 32 * 4096 < 2^31)
-    int S = (ga_cus() + P - 1) / P;
-    if (S < 1) S = 1;
-    while ((g.nchunk + S - 1) / S > 4096) ++S;
-    if (S > g.nchunk) S = g.nchunk;
-    g.S = S;
-    g.cps = (g.nchunk + S - 1) / S;
+    auto splits = [&](int wgs_per_split) {
+        int S = (ga_cus() + wgs_per_split - 1) / wgs_per_split;
+        if (S < 1) S = 1;
+        while ((g.nchunk + S - 1) / S > 4096) ++S;
+        if (S > g.nchunk) S = g.nchunk;
+        return S;
+    };
+    // K <= 384: one role, the whole triangle.  K = 512 / 768: halves A | B -- two triangle roles and the A x B square as one 8 x 8
+    // rectangle (a wave 2 x 8 blocks) / two 12 x 6 rectangles (a wave 3 x 6 blocks)
+    g.NJH = g.NJ; g.RT = 1; g.RR = 0; g.NIW = g.NJC = 0; g.SR = 0; g.cpsr = 0;
+    if (g.NJ == 16) { g.NJH = 8; g.RT = 2; g.RR = 1; g.NIW = 2; g.NJC = 8; }
+    if (g.NJ == 24) { g.NJH = 12; g.RT = 2; g.RR = 2; g.NIW = 3; g.NJC = 6; }
+    g.S = splits(P * g.RT);
+    g.cps = (g.nchunk + g.S - 1) / g.S;
+    if (g.RR) { g.SR = splits(P * g.RR); g.cpsr = (g.nchunk + g.SR - 1) / g.SR; }
+    g.QS = g.RT * g.S + g.RR * g.SR;
     const int nbt = g.NJ * (g.NJ + 1) / 2;
     int64_t off = 0;
     g.off_hfrag = off; off += al256((int64_t)nbt * 1024 * 8);
@@ -666,7 +851,8 @@ static GaPlan ga_plan(int T, int O, int K, int P) {
 }  // namespace
 
 // The Gram form of an output-MSE activation search is supported for a per-tensor uniform activation quantiser with <= 7-bit
-// operands, K % 32 == 0 up to 384 (the candidate's whole K x K upper triangle lives in one CU's registers) and an instantiated K.
+// operands, K % 32 == 0 up to 384 (the candidate's whole K x K upper triangle lives in one CU's registers) or K = 512 / 768 (the
+// triangle in three / four parts, k_ga_rect) and an instantiated K.
 extern "C" int adalog_gram_act_supported(int T, int O, int K, int a_bits, int w_bits, int P) {
     const GaPlan g = ga_plan(T, O, K, P);
     if (!g.ok || !ga_nj_ok(g.NJ) || a_bits < 2 || a_bits > 7 || w_bits < 2 || w_bits > 7 || P > 65535) return 0;
@@ -676,7 +862,8 @@ extern "C" int adalog_gram_act_supported(int T, int O, int K, int a_bits, int w_
 
 // ... and it pays: the candidate Gram matrices cost K / 2 multiply-adds per generated element against the token form's O
 extern "C" int adalog_gram_act_ok(int T, int O, int K, int a_bits, int w_bits, int P) {
-    return adalog_gram_act_supported(T, O, K, a_bits, w_bits, P) && T >= 256 ? 1 : 0;
+    if (!adalog_gram_act_supported(T, O, K, a_bits, w_bits, P) || T < 256) return 0;
+    return K <= 384 || O >= 2 * K ? 1 : 0;                 // the split forms generate every fragment 2 - 2.5 times
 }
 
 extern "C" int64_t adalog_gram_act_workspace_bytes(int T, int O, int K, int P) {
@@ -746,8 +933,17 @@ extern "C" int adalog_gram_act_build(const float* raw_out, int T, int O, const f
     const int nbt = g.NJ * (g.NJ + 1) / 2;
     double* sw2 = (double*)(base + g.off_sw2);
     hipLaunchKernelGGL(k_ga_sw2, dim3((unsigned)((O + 255) / 256)), dim3(256), 0, st, sw, O, sw2);
-    hipLaunchKernelGGL(k_ga_h, dim3((unsigned)(((int64_t)nbt * 1024 + 255) / 256)), dim3(256), 0, st, wt, K, O, g.Op, sw2,
-                       (double*)(base + g.off_hfrag));
+    double* hfrag = (double*)(base + g.off_hfrag);
+    const int ntt = g.NJH * (g.NJH + 1) / 2;
+    for (int r = 0; r < g.RT; ++r)                             // role order of the score launches: triangles, then rectangles
+        hipLaunchKernelGGL(k_ga_h, dim3((unsigned)(((int64_t)ntt * 1024 + 255) / 256)), dim3(256), 0, st, wt, O, g.Op, sw2,
+                           hfrag + (int64_t)r * ntt * 1024, r * g.NJH, 0, g.NJH, g.NJH, 1);
+    for (int r = 0; r < g.RR; ++r) {
+        const int ntr = 4 * g.NIW * g.NJC;
+        hipLaunchKernelGGL(k_ga_h, dim3((unsigned)(((int64_t)ntr * 1024 + 255) / 256)), dim3(256), 0, st, wt, O, g.Op, sw2,
+                           hfrag + ((int64_t)g.RT * ntt + (int64_t)r * ntr) * 1024, 0, g.NJH + r * g.NJC, 4 * g.NIW, g.NJC, 0);
+    }
+    (void)nbt;
     ADALOG_LAUNCH_CHECK("adalog_gram_act_build");
     return 0;
 }
@@ -756,7 +952,7 @@ extern "C" int adalog_gram_act_build(const float* raw_out, int T, int O, const f
  * xt / sorted from adalog_gram_act_prepare, ws from adalog_gram_act_build (same T, O, K, P); qpart: P * adalog_gram_act_splits doubles. */
 extern "C" int adalog_gram_act_splits(int T, int O, int K, int P) {
     const GaPlan g = ga_plan(T, O, K, P);
-    return g.ok ? g.S : -1;
+    return g.ok ? g.QS : -1;
 }
 
 static long long* g_ga_timeline = nullptr;
@@ -772,6 +968,7 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
     a.xt = xt; a.Tp = g.Tp; a.K = K; a.scale = scale; a.zp = zp; a.P = P;
     a.hfrag = (const double*)(base + g.off_hfrag); a.qpart = qpart;
     a.S = g.S; a.chunks_per_split = g.cps; a.nchunk = g.nchunk;
+    a.NJT = g.NJ; a.R = g.RT; a.QS = g.QS; a.q0 = 0; a.kb_a = 0; a.kb_b = 0;
     a.qmax = (float)((1 << a_bits) - 1);
     const float zone = 6e-7f * (float)(1 << a_bits);
     a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
@@ -781,9 +978,9 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
     do {                                                                                                          \
         const size_t shm = (size_t)2 * NJV * 1024 < 64 ? 64 : (size_t)2 * NJV * 1024;                             \
         adalog_note_kernel("k_gram_act<i8>");                                                                     \
-        hipLaunchKernelGGL((k_ga_quad<NJV>), dim3((unsigned)(P * g.S)), dim3(256), shm, st, a);                   \
+        hipLaunchKernelGGL((k_ga_quad<NJV>), dim3((unsigned)(P * g.S * g.RT)), dim3(256), shm, st, a);            \
     } while (0)
-    switch (g.NJ) {
+    switch (g.NJH) {
         case 1: GA_LAUNCH(1); break;
         case 2: GA_LAUNCH(2); break;
         case 3: GA_LAUNCH(3); break;
@@ -794,12 +991,23 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
         default: ADALOG_ARG_CHECK(false, "gram_act_score: K not instantiated");
     }
 #undef GA_LAUNCH
+    if (g.RR) {                                                // the A x B square
+        GaQuadArgs b = a;
+        const int ntt = g.NJH * (g.NJH + 1) / 2;
+        b.hfrag = a.hfrag + (int64_t)g.RT * ntt * 1024;
+        b.S = g.SR; b.chunks_per_split = g.cpsr; b.R = g.RR; b.q0 = g.RT * g.S; b.kb_a = 0; b.kb_b = g.NJH;
+        b.timeline = nullptr;
+        const size_t shm = (size_t)2 * (4 * g.NIW + g.NJC) * 1024;
+        const dim3 grid((unsigned)(P * g.SR * g.RR));
+        if (g.NIW == 2) hipLaunchKernelGGL((k_ga_rect<2, 8>), grid, dim3(256), shm, st, b);
+        else hipLaunchKernelGGL((k_ga_rect<3, 6>), grid, dim3(256), shm, st, b);
+    }
     const double* prefix = (const double*)(base + g.off_prefix);
     const double* s0 = (const double*)(base + g.off_s0);
     const int G = 1 << a_bits;
     const int gpb = 256 / G;
     const unsigned blocks = (unsigned)((P + gpb - 1) / gpb);
-#define GA_FIN(GV) hipLaunchKernelGGL((k_ga_finish<GV>), dim3(blocks), dim3(256), 0, st, sorted, prefix, g.n, scale, zp, P, a.qmax, qpart, g.S, s0, norm, scores)
+#define GA_FIN(GV) hipLaunchKernelGGL((k_ga_finish<GV>), dim3(blocks), dim3(256), 0, st, sorted, prefix, g.n, scale, zp, P, a.qmax, qpart, g.QS, s0, norm, scores)
     switch (a_bits) {
         case 2: GA_FIN(4); break;
         case 3: GA_FIN(8); break;

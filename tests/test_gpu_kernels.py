@@ -1690,6 +1690,9 @@ GRAM_ACT_SHAPES = [  # T, O, K, tokens per image
     (3136, 96, 32, 3136),        # NJ = 1
     (1568, 100, 64, 49),         # NJ = 2
     (12544, 384, 128, 3136),     # NJ = 4
+    (6272, 1536, 512, 196),      # swin_base stage 2 qkv: the triangle in three parts (two k_ga_quad<8> roles + k_ga_rect<2, 8>)
+    (6304, 2304, 768, 197),      # vit_base / deit_base qkv: four parts (two k_ga_quad<12> roles + two k_ga_rect<3, 6> roles)
+    (900, 300, 768, 100),        # ... ragged tokens / rows, one token split per role
 ]
 
 

@@ -85,7 +85,16 @@ def case(T, O, K, bits, P=128, tokens=197, seed=0):
     print(res, flush=True)
 
 
-if __name__ == "__main__" and len(sys.argv) > 1:
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "split":
+    case(6272, 1536, 512, 4, tokens=196)       # swin_base stage 2: qkv, fc1, proj
+    case(6272, 2048, 512, 4, tokens=196)
+    case(6272, 512, 512, 4, tokens=196)
+    case(6304, 2304, 768, 4)                   # vit_base: qkv, fc1, proj
+    case(6304, 3072, 768, 4)
+    case(6304, 768, 768, 4)
+    case(6304, 2304, 768, 6)
+    case(6304, 1152, 384, 4)
+elif __name__ == "__main__" and len(sys.argv) > 1:
     case(6304, 1152, 384, 4)
     case(25088, 768, 256, 4, tokens=784)
 elif __name__ == "__main__":
