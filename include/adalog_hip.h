@@ -291,7 +291,7 @@ int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* 
  *                             -> workspace (adalog_gram_act_workspace_bytes, 256-byte aligned): H, prefix sums of C, S0
  *   adalog_gram_act_score     one FPCS step: scores [P] = -norm * (the sum above) for candidates (scale, zp) [P]; qpart: scratch of
  *                             P * adalog_gram_act_splits(T, O, K, P) doubles
- * adalog_gram_act_supported: per-tensor candidates, K % 32 == 0 and <= 384 (instantiated), <= 7-bit operands; adalog_gram_act_ok: ... and
+ * adalog_gram_act_supported: per-tensor candidates, K % 32 == 0 and <= 384 or K = 512 / 768 (instantiated), <= 7-bit operands; adalog_gram_act_ok: ... and
  * enough tokens for it to pay. */
 int adalog_gram_act_supported(int T, int O, int K, int a_bits, int w_bits, int P);
 int adalog_gram_act_ok(int T, int O, int K, int a_bits, int w_bits, int P);
