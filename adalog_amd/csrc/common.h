@@ -51,54 +51,6 @@ __device__ __forceinline__ float adalog_k(float u, float qf) {
     return k;
 }
 
-// ---- first index i of an ascending array with rne(fl32(x[i] / s)) >= target (s > 0): the boundary of a uniform quantiser's level run
-// in a sorted tensor (sorted_score.hip, gram_act.hip).  The predicate is monotone in x, so it has a threshold -- the smallest float
-// x* with rne(fl32(x* / s)) >= target -- found by walking ulps from (target - 0.5) s with the IEEE quotient itself (the tie at
-// target - 0.5 spans a few neighbouring floats and goes to the even side: a closed form is not safe, the walk is).  The search then
-// compares values only and is 16-ary: 15 independent loads per round, 6 rounds + a tail over 2.4 M values, instead of 22
-// dependent load -> divide -> compare steps.
-__device__ __forceinline__ int64_t uni_level_lower(const float* __restrict__ x, int64_t n, float s, float target) {
-    auto P = [&](float v) { return rintf(v / s) >= target; };
-    auto step = [](float v, bool up) {                                  // the neighbouring float (finite; crosses zero through -0 / +0)
-        int b = __float_as_int(v);
-        if (up) b = b >= 0 ? b + 1 : (b == (int)0x80000000 ? 0 : b - 1);
-        else b = b > 0 ? b - 1 : (b == 0 ? (int)0x80000000 : b + 1);
-        return __int_as_float(b);
-    };
-    float xs = (target - 0.5f) * s;
-    bool ok = false;
-    if (P(xs)) {
-        for (int it = 0; it < 64; ++it) { const float y = step(xs, false); if (!P(y)) { ok = true; break; } xs = y; }
-    } else {
-        for (int it = 0; it < 64; ++it) { xs = step(xs, true); if (P(xs)) { ok = true; break; } }
-    }
-    int64_t lo = 0, hi = n;
-    if (!ok) {                                                          // (not seen: plain bisection on the quotient)
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (P(x[mid])) hi = mid; else lo = mid + 1;
-        }
-        return lo;
-    }
-    while (hi - lo > 15) {
-        const int64_t stp = (hi - lo + 15) >> 4;
-        float v[15];
-#pragma unroll
-        for (int j = 0; j < 15; ++j) { const int64_t q = lo + (int64_t)(j + 1) * stp; v[j] = x[(q < hi ? q : hi) - 1]; }
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < 15; ++j) c += v[j] < xs ? 1 : 0;              // ascending: a prefix of the pivots is below the threshold
-        const int64_t qa = lo + (int64_t)c * stp, qb = lo + (int64_t)(c + 1) * stp;
-        const int64_t nlo = c > 0 ? (qa < hi ? qa : hi) : lo;
-        const int64_t nhi = c < 15 ? (qb < hi ? qb : hi) - 1 : hi;
-        lo = nlo; hi = nhi;
-    }
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < 15; ++j) c += (lo + j < hi && x[lo + j] < xs) ? 1 : 0;
-    return lo + c;
-}
-
 // ---- fast forms used by the operand-packing kernels (hundreds of millions of elements per scoring call).
 // Both evaluate with a reciprocal multiply first and fall back to the exact IEEE sequence above only when the result
 // lands within 1e-3 of a rounding tie, so they return EXACTLY the same integer as the exact forms (the reciprocal path

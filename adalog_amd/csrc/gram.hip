@@ -25,7 +25,7 @@
 // Kernels:
 //   k_gram_pack_xt   x [T,K] fp32 -> (q - z) int8, TRANSPOSED [K][Tp] (token-contiguous: the contraction runs over tokens)
 //   k_gram_rfix      raw_out^T [O,T] fp32, bias -> four int8 limb planes [4][O][Tp], S0[o], 2^-e_o
-//   k_gram_mm        C[i,j] = sum_t A[i,t] B[j,t]  (int8 MFMA, int32 per chunk -> int64 partial per token split); A optionally in
+//   k_i8mm           (gram_mm.inc) C[i,j] = sum_t A[i,t] B[j,t]  (int8 MFMA, int32 per chunk -> int64 partial per token split); A optionally in
 //                    limb planes (recombined with shifts): G = xt.xt^T and c = rfix.xt^T
 //   k_gram_fin_g     sum of the split partials -> balanced limbs in MFMA A-fragment order (rows permuted so that a lane's
 //                    accumulator rows are the k of its own B fragment)
@@ -168,59 +168,9 @@ __global__ __launch_bounds__(256) void k_gram_rfix(const float* __restrict__ ref
 
 // ------------------------------------------------------------------------------------------------ C = A . B^T over tokens (int8)
 // A [RA][ld], B [RB][ld] int8, token-contiguous; part[z][RA][RB] int32 = the sum over the z-th token range (<= 512 steps of 128
-// tokens: |sum| < 2^31).  ONE wave per workgroup owns a (32 BI) x (32 BJ) tile in registers and streams both operands straight
-// from memory: a lane (row = lane & 31, half = lane >> 5) loads 64 consecutive tokens of each of its rows per step (the order of the
-// contraction index is free as long as A and B agree) -- four MFMAs per block pair and step.  No LDS, no barrier.  The reference's
-// limb planes are simply more rows of A (RA = 4 O); the limbs are recombined when the splits are summed (k_gram_fin_c).
-template <int BI, int BJ>
-__global__ __launch_bounds__(64) void k_gram_mm(const int8_t* __restrict__ A, const int8_t* __restrict__ B, int RA, int RB, int64_t ld,
-                                                int steps_per_split, int steps_total, int* __restrict__ part) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 31, h = lane >> 5;
-    const int ra0 = blockIdx.x * (32 * BI), rb0 = blockIdx.y * (32 * BJ);
-    const int z = blockIdx.z;
-    const int st0 = z * steps_per_split, st1 = min(st0 + steps_per_split, steps_total);
-    v16i acc[BI][BJ];
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-#pragma unroll
-        for (int j = 0; j < BJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-    const int8_t* pa[BI];
-    const int8_t* pb[BJ];
-#pragma unroll
-    for (int i = 0; i < BI; ++i) pa[i] = A + (int64_t)min(ra0 + 32 * i + r, RA - 1) * ld + h * 64;
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) pb[j] = B + (int64_t)min(rb0 + 32 * j + r, RB - 1) * ld + h * 64;
-    for (int st = st0; st < st1; ++st) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v4i fa[BI], fb[BJ];
-#pragma unroll
-            for (int i = 0; i < BI; ++i) fa[i] = *reinterpret_cast<const v4i*>(pa[i] + (int64_t)st * 128 + q * 16);
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) fb[j] = *reinterpret_cast<const v4i*>(pb[j] + (int64_t)st * 128 + q * 16);
-#pragma unroll
-            for (int i = 0; i < BI; ++i)
-#pragma unroll
-                for (int j = 0; j < BJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-    int* out = part + (int64_t)z * RA * RB;
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int col = rb0 + 32 * j + r;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = ra0 + 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                if (row < RA && col < RB) out[(int64_t)row * RB + col] = acc[i][j][e];
-            }
-        }
-}
+// tokens: |sum| < 2^31): gram_mm.inc.  The reference's limb planes are simply more rows of A (RA = 4 O); the limbs are recombined
+// when the splits are summed (k_gram_fin_c).
+#include "gram_mm.inc"          // k_i8mm
 
 // ------------------------------------------------------------------------------------------------ finalise G and c
 // gfrag[l][kt][jt][lane][16]: lane = (tile row r', half h); tile row r' = 8 i + 4 h' + j holds G row 32 kt + 16 h' + 4 i + j, so
@@ -611,7 +561,7 @@ static int g_limbs(int64_t T, int a_bits) {
 static int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
 
 static int pick_steps(int steps_total, int tiles, int target_waves) {
-    // token steps (of 128) per split: enough splits to fill the chip with one-wave tiles, at least 4 steps per split (the partials are
+    // token steps (of 128) per split: enough splits to fill the chip with 128 x 128 workgroup tiles, at least 4 steps per split (the partials are
     // summed afterwards), at most 512 (int32 accumulators)
     int splits = (target_waves + tiles - 1) / tiles;
     if (splits < 1) splits = 1;
@@ -622,7 +572,7 @@ static int pick_steps(int steps_total, int tiles, int target_waves) {
     return per;
 }
 
-constexpr int MM_BI = 4, MM_BJ = 4;                         // k_gram_mm wave tile: 128 x 128
+constexpr int MM_BI = 4, MM_BJ = 4;                         // k_i8mm workgroup tile: 128 x 128
 
 static GramPlan gram_plan(int T, int O, int K, int a_bits) {
     GramPlan g{};
@@ -635,9 +585,9 @@ static GramPlan gram_plan(int T, int O, int K, int a_bits) {
     g.steps_total = (int)(g.Tp / 128);
     const int tk = (K + 32 * MM_BJ - 1) / (32 * MM_BJ);
     const int tg = ((K + 32 * MM_BI - 1) / (32 * MM_BI)) * tk, tc = ((RLIMBS * O + 32 * MM_BI - 1) / (32 * MM_BI)) * tk;
-    g.sg_steps = pick_steps(g.steps_total, tg, 1024);
+    g.sg_steps = pick_steps(g.steps_total, tg, 512);
     g.sg_splits = (g.steps_total + g.sg_steps - 1) / g.sg_steps;
-    g.sc_steps = pick_steps(g.steps_total, tc, 1024);
+    g.sc_steps = pick_steps(g.steps_total, tc, 512);
     g.sc_splits = (g.steps_total + g.sc_steps - 1) / g.sc_steps;
     g.r_chunk = 8192;                                       // tokens per k_gram_rfix workgroup (a multiple of 128)
     g.r_nchunk = (int)((g.Tp + g.r_chunk - 1) / g.r_chunk);
@@ -713,9 +663,9 @@ extern "C" int adalog_gram_build(const float* x, int T, int K, int64_t ldx, cons
     hipLaunchKernelGGL(k_gram_rfix, dim3((unsigned)O, (unsigned)g.r_nchunk), dim3(256), 0, st, ref_t, T, g.Tp, O, g.r_chunk, g.r_nchunk, bias,
                        amax, rl, s0p, (double*)(base + g.off_cscl));
     const unsigned tk = (unsigned)((K + 32 * MM_BJ - 1) / (32 * MM_BJ));
-    hipLaunchKernelGGL((k_gram_mm<MM_BI, MM_BJ>), dim3((unsigned)((K + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sg_splits), dim3(64), 0, st,
+    hipLaunchKernelGGL(k_i8mm, dim3((unsigned)((K + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sg_splits), dim3(256), 0, st,
                        xt, xt, K, K, g.Tp, g.sg_steps, g.steps_total, gpart);
-    hipLaunchKernelGGL((k_gram_mm<MM_BI, MM_BJ>), dim3((unsigned)((RLIMBS * O + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sc_splits), dim3(64), 0,
+    hipLaunchKernelGGL(k_i8mm, dim3((unsigned)((RLIMBS * O + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sc_splits), dim3(256), 0,
                        st, rl, xt, RLIMBS * O, K, g.Tp, g.sc_steps, g.steps_total, cpart);
     hipLaunchKernelGGL(k_gram_fin_g, dim3((unsigned)(((int64_t)K * K + 255) / 256)), dim3(256), 0, st, gpart, g.sg_splits, K, g.NL,
                        (int8_t*)(base + g.off_gfrag));

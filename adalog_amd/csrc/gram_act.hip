@@ -24,10 +24,11 @@
 //   k_ga_fragorder   x [T,K] fp32 -> the score kernel's fragment order (once per captured tensor)
 //   k_ga_pack_wt     W [O,K] fp32, (s_w, z_w) per row -> W_int^T int8 [K][Op]
 //   k_ga_rmax/rfix   raw_out [T,O], bias, s_w -> per-token exponent, four int8 limb planes [4][T][Op], S0
-//   k_gram_mm        (gram.hip's one-wave 128 x 128 int8 tiles) C_fix = limbs . W_int
+//   k_i8mm           (gram_mm.inc: LDS-tiled int8 product, shared with gram.hip) C_fix = limbs . W_int
 //   k_ga_fin_c       limbs recombined -> C fp64 [T][K]
 //   k_ga_gather_sum / k_ga_scan / k_ga_prefix   prefix sums of C along the sorted order of x (three passes, fixed order)
-//   k_ga_h           H in fp64, written in the accumulator layout of the score kernel (off-diagonal blocks doubled)
+//   k_ga_h           H = Wq^T Wq in fp64 (register-tiled over the fp64 weight image), written in the accumulator layout of the
+//                    score kernels, role by role (off-diagonal blocks doubled)
 // Per FPCS step:
 //   k_ga_quad        one workgroup (4 waves x 512 registers: the whole upper triangle of G_p lives in the CU's registers) per
 //                    (candidate, token range): generates the candidate's int8 operand fragments from x_t with the exact-bin
@@ -78,9 +79,11 @@ __global__ __launch_bounds__(256) void k_ga_fragorder(const float* __restrict__ 
     *reinterpret_cast<float4*>(xf + ((((int64_t)c * NJ + b) * 4 + q) * 64 + lane) * 4) = v;
 }
 
-// W_int^T [K][Op] int8: column o of row k = clamp(rne(W[o][k] / s_w[o]) + z_w[o], 0, qmax) - z_w[o]   (exact bins: uni_bin_fast)
+// W_int^T [K][Op] int8: column o of row k = clamp(rne(W[o][k] / s_w[o]) + z_w[o], 0, qmax) - z_w[o]   (exact bins: uni_bin_fast);
+// wsd [O][K] fp64 = s_w[o] * that value (the quantised weight Wq, exact)
 __global__ __launch_bounds__(256) void k_ga_pack_wt(const float* __restrict__ W, int O, int K, int64_t ldw, const float* __restrict__ sw,
-                                                    const float* __restrict__ zw, float qmax, int8_t* __restrict__ wt, int64_t Op) {
+                                                    const float* __restrict__ zw, float qmax, int8_t* __restrict__ wt, int64_t Op,
+                                                    double* __restrict__ wsd) {
 #pragma clang fp contract(off)
     __shared__ int8_t tile[64][65];
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(256) void k_ga_pack_wt(const float* __restrict__ W,
         if (o < O && k < K) {
             const float s = sw[o], z = rintf(zw[o]);
             q = (int)(uni_bin_fast(W[(int64_t)o * ldw + k], s, 1.0f / s, z, qmax) - z);
+            wsd[(int64_t)o * K + k] = (double)s * (double)q;           // Wq[o][k] exactly (24 + 8 bits): the operand of k_ga_h
         }
         tile[ty + 4 * i][tx] = (int8_t)q;
     }
@@ -154,54 +158,7 @@ __global__ __launch_bounds__(256) void k_ga_rfix(const float* __restrict__ ref, 
     if (tid == 0) { s0p[t] = tot; cscl[t] = ldexp(1.0, -e); }
 }
 
-// the one-wave 128 x 128 int8 tile product of gram.hip (C[i,j] = sum over the contiguous index of A[i,.] B[j,.]), repeated here
-// because kernels cannot be shared across translation units without relocatable device code
-template <int BI, int BJ>
-__global__ __launch_bounds__(64) void k_ga_mm(const int8_t* __restrict__ A, const int8_t* __restrict__ B, int RA, int RB, int64_t ld,
-                                              int steps_total, int* __restrict__ part) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane & 31, h = lane >> 5;
-    const int ra0 = blockIdx.x * (32 * BI), rb0 = blockIdx.y * (32 * BJ);
-    v16i acc[BI][BJ];
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-#pragma unroll
-        for (int j = 0; j < BJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0;
-    const int8_t* pa[BI];
-    const int8_t* pb[BJ];
-#pragma unroll
-    for (int i = 0; i < BI; ++i) pa[i] = A + (int64_t)min(ra0 + 32 * i + r, RA - 1) * ld + h * 64;
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) pb[j] = B + (int64_t)min(rb0 + 32 * j + r, RB - 1) * ld + h * 64;
-    for (int st = 0; st < steps_total; ++st) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v4i fa[BI], fb[BJ];
-#pragma unroll
-            for (int i = 0; i < BI; ++i) fa[i] = *reinterpret_cast<const v4i*>(pa[i] + (int64_t)st * 128 + q * 16);
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) fb[j] = *reinterpret_cast<const v4i*>(pb[j] + (int64_t)st * 128 + q * 16);
-#pragma unroll
-            for (int i = 0; i < BI; ++i)
-#pragma unroll
-                for (int j = 0; j < BJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            const int col = rb0 + 32 * j + r;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = ra0 + 32 * i + 8 * (e >> 2) + 4 * h + (e & 3);
-                if (row < RA && col < RB) part[(int64_t)row * RB + col] = acc[i][j][e];
-            }
-        }
-}
+#include "gram_mm.inc"          // k_i8mm: the LDS-tiled int8 product shared with gram.hip
 
 // C[t][k] = (sum_l part[l T + t][k] << 8 l) * 2^-e_t   (fp64; |C_fix| < 2^53 for O < 2^15: 2^29 * 2^6..7 * O)
 __global__ __launch_bounds__(256) void k_ga_fin_c(const int* __restrict__ part, int T, int K, const double* __restrict__ cscl, double* __restrict__ C) {
@@ -246,9 +203,11 @@ __global__ __launch_bounds__(256) void k_ga_scan(double* __restrict__ bsum, int 
     }
     double carry = 0.0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    double nxt = (int)threadIdx.x < nb ? bsum[threadIdx.x] : 0.0;
     for (int base = 0; base < nb; base += 256) {
         const int i = base + threadIdx.x;
-        const double v = i < nb ? bsum[i] : 0.0;
+        const double v = nxt;
+        nxt = i + 256 < nb ? bsum[i + 256] : 0.0;               // the next chunk's load is in flight under this chunk's scan
         double a = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -294,24 +253,22 @@ __global__ __launch_bounds__(256) void k_ga_prefix(const double* __restrict__ Cs
     if (i0 + 4 == n) prefix[n] = o1;
 }
 
-__global__ void k_ga_sw2(const float* __restrict__ sw, int O, double* __restrict__ sw2) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < O) { const double s = (double)sw[o]; sw2[o] = s * s; }
-}
-
 // ------------------------------------------------------------------------------------------------ H in the accumulator layout
 // upper-triangle blocks (i <= j) in row-major order: n(i, j) = i NJ - i (i - 1) / 2 + (j - i)
 __host__ __device__ constexpr int tri_index(int i, int j, int NJ) { return i * NJ - (i * (i - 1)) / 2 + (j - i); }
 
-// hfrag[n][lane][e] = (i == j ? 1 : 2) * H[32 i + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 j + (lane & 31)],  H = sum_o s_w[o]^2 w[o][k1] w[o][k2]
+// hfrag[n][lane][e] = (i == j ? 1 : 2) * H[32 i + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)][32 j + (lane & 31)],  H = Wq^T Wq = sum_o Wq[o][k1] Wq[o][k2]
 // for the blocks of one ROLE of the score kernels: tri != 0: the upper triangle of the nj k-blocks from i0 (row-major, i <= j);
-// else the ni x nj rectangle of rows i0 .. against columns j0 .. (row-major)
-__global__ __launch_bounds__(256) void k_ga_h(const int8_t* __restrict__ wt, int O, int64_t Op, const double* __restrict__ sw2,
-                                              double* __restrict__ hfrag, int i0, int j0, int ni, int nj, int tri) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int nblk = tri ? nj * (nj + 1) / 2 : ni * nj;
-    if (idx >= (int64_t)nblk * 1024) return;
-    const int n = (int)(idx >> 10), lane = (int)((idx >> 4) & 63), e = (int)(idx & 15);
+// else the ni x nj rectangle of rows i0 .. against columns j0 .. (row-major).
+// One workgroup of eight waves per 32 x 32 block: a wave takes an eighth of the output channels, a lane a 4 x 4 patch of the block
+// (16 fp64 FMAs per two 32-byte loads of the fp64 weight image; the round's first form looped one thread per entry over all of O with
+// int8 loads and a conversion per product: 40 us at the qkv shape, 4 x 65 us at vit_base's); the eight partial blocks are summed in a
+// fixed order through LDS.
+constexpr int GA_H_WAVES = 8;
+__global__ __launch_bounds__(64 * GA_H_WAVES) void k_ga_h(const double* __restrict__ wsd, int O, int K, double* __restrict__ hfrag, int i0, int j0,
+                                                         int ni, int nj, int tri) {
+    __shared__ double red[GA_H_WAVES - 1][64][17];
+    const int n = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int i, j;
     if (tri) {
         int li = 0, rem = n;
@@ -320,23 +277,48 @@ __global__ __launch_bounds__(256) void k_ga_h(const int8_t* __restrict__ wt, int
     } else {
         i = i0 + n / nj; j = j0 + n % nj;
     }
-    const int k1 = 32 * i + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3), k2 = 32 * j + (lane & 31);
-    const int8_t* a = wt + (int64_t)k1 * Op;
-    const int8_t* b = wt + (int64_t)k2 * Op;
-    double h = 0.0;
-    for (int o0 = 0; o0 < O; o0 += 16) {                     // 16 output channels per load (Op is a multiple of 128; columns >= O are zero)
-        const uint4 va = *reinterpret_cast<const uint4*>(a + o0), vb = *reinterpret_cast<const uint4*>(b + o0);
-        const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+    const int a = lane >> 3, b = lane & 7;                  // rows 4 a .. 4 a + 3 of the block, columns 4 b .. 4 b + 3
+    const int per = (O + GA_H_WAVES - 1) / GA_H_WAVES;
+    const int o0 = w * per, o1 = min(O, o0 + per);
+    const double* pa = wsd + 32 * i + 4 * a;
+    const double* pb = wsd + 32 * j + 4 * b;
+    double acc[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int o = o0 + 4 * q + e;
-                const int pa = (int)(int8_t)(wa[q] >> (8 * e)), pb = (int)(int8_t)(wb[q] >> (8 * e));
-                h += sw2[o < O ? o : 0] * (double)(pa * pb);
+        for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+#pragma unroll 4
+    for (int o = o0; o < o1; ++o) {
+        const double2 a0 = *reinterpret_cast<const double2*>(pa + (int64_t)o * K), a1 = *reinterpret_cast<const double2*>(pa + (int64_t)o * K + 2);
+        const double2 b0 = *reinterpret_cast<const double2*>(pb + (int64_t)o * K), b1 = *reinterpret_cast<const double2*>(pb + (int64_t)o * K + 2);
+        const double av[4] = {a0.x, a0.y, a1.x, a1.y}, bv[4] = {b0.x, b0.y, b1.x, b1.y};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = fma(av[u], bv[v], acc[u][v]);
+    }
+    if (w > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[w - 1][lane][4 * u + v] = acc[u][v];
+    }
+    __syncthreads();
+    if (w == 0) {
+        const double f = i == j ? 1.0 : 2.0;
+        double* out = hfrag + (int64_t)n * 1024;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                double h = acc[u][v];
+#pragma unroll
+                for (int x = 0; x < GA_H_WAVES - 1; ++x) h += red[x][lane][4 * u + v];
+                // block row rr = 4 a + u = 8 (e >> 2) + 4 (lane' >> 5) + (e & 3), column 4 b + v = lane' & 31
+                const int lane2 = (a & 1) * 32 + 4 * b + v, e = 4 * (a >> 1) + u;
+                out[lane2 * 16 + e] = f * h;
             }
     }
-    hfrag[idx] = (i == j ? 1.0 : 2.0) * h;
 }
 
 // ------------------------------------------------------------------------------------------------ the per-step kernel
@@ -367,7 +349,6 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
     constexpr int N0 = (NBT * W) / 4, N1 = (NBT * (W + 1)) / 4;
     constexpr int NOWN = N1 - N0;
     constexpr int NGEN = (NJ - W + 3) / 4;                 // k-blocks W, W + 4, ... this wave generates
-    const int r = lane & 31, h = lane >> 5;
     const float gs = p.scale[cand], gz = rintf(p.zp[cand]);
     const float ginv = __builtin_amdgcn_rcpf(gs);
     const float glo = 128.0f - gz, ghi = 128.0f + (p.qmax - gz);
@@ -747,7 +728,22 @@ __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sor
     const bool live = cand < P;
     const float s = live ? scale[cand] : 1.0f, z = live ? rintf(zp[cand]) : 0.0f;
     const float klo = ceilf(-z), khi = floorf(qmax - z);
-    auto lower = [&](float target) { return uni_level_lower(sorted, n, s, target); };   // (common.h: threshold + 16-ary search)
+    // (everything that does not depend on the boundaries is requested now)
+    double quad = 0.0;
+    if (live && t == 0)
+        for (int sp = 0; sp < S; ++sp) quad += qpart[(int64_t)cand * S + sp];
+    const double s0v = s0[0];
+    // (tried on the same box and dropped: the boundary as a threshold float searched 16-ary with 15 loads in flight, a coarse table of
+    // the sorted tensor in LDS, both searches of thread 0 in lockstep -- 17.9 -> 19.3 us: whatever the search, the launch is a chain of
+    // ~8 dependent far-memory round trips on eight CUs, and the first ten steps of a bisection share their cache lines)
+    auto lower = [&](float target) {                                   // first i with rne(x[i] / s) >= target
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rintf(sorted[mid] / s) >= target) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
     if (live) {
         bnd[gi][t] = lower(fminf(klo + (float)t, khi + 1.0f));
         if (t == 0) bnd[gi][G] = lower(khi + 1.0f);
@@ -771,10 +767,8 @@ __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sor
         __syncthreads();
     }
     if (live && t == 0) {
-        double quad = 0.0;
-        for (int sp = 0; sp < S; ++sp) quad += qpart[(int64_t)cand * S + sp];
         const double sd = (double)s;
-        scores[cand] = (float)(-norm * (s0[0] - 2.0 * sd * red[threadIdx.x] + sd * sd * quad));
+        scores[cand] = (float)(-norm * (s0v - 2.0 * sd * red[threadIdx.x] + sd * sd * quad));
     }
 }
 
@@ -785,7 +779,7 @@ struct GaPlan {
     int NJH, RT;                                   // k-blocks per triangle role, triangle roles (1: the whole triangle; 2: A x A and B x B)
     int RR, NIW, NJC, SR, cpsr;                    // rectangle roles (0: none), their shape, token splits, chunks per split
     int QS;                                        // partial sums per candidate: RT * S + RR * SR
-    int64_t off_hfrag, off_prefix, off_s0, off_wt, off_rl, off_s0p, off_cscl, off_cpart, off_C, off_Cs, off_sw2, off_bsum, total;
+    int64_t off_hfrag, off_prefix, off_s0, off_wt, off_rl, off_s0p, off_cscl, off_cpart, off_C, off_Cs, off_wsd, off_bsum, total;
     bool ok;
 };
 
@@ -842,7 +836,7 @@ static GaPlan ga_plan(int T, int O, int K, int P) {
     g.off_cpart = off; off += al256((int64_t)RLIMBS * T * K * 4);
     g.off_C = off; off += al256(g.n * 8);
     g.off_Cs = off; off += al256(g.n * 8);
-    g.off_sw2 = off; off += al256((int64_t)O * 8);
+    g.off_wsd = off; off += al256((int64_t)O * K * 8);
     g.off_bsum = off; off += al256(((g.n + PBLK - 1) / PBLK) * 8);
     g.total = off;
     return g;
@@ -918,12 +912,13 @@ extern "C" int adalog_gram_act_build(const float* raw_out, int T, int O, const f
     int* cpart = (int*)(base + g.off_cpart);
     double* C = (double*)(base + g.off_C);
     double* bsum = (double*)(base + g.off_bsum);
+    double* wsd = (double*)(base + g.off_wsd);
     hipLaunchKernelGGL(k_ga_pack_wt, dim3((unsigned)(g.Op / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, W, O, K, ldw, sw, zw,
-                       (float)((1 << w_bits) - 1), wt, g.Op);
+                       (float)((1 << w_bits) - 1), wt, g.Op, wsd);
     hipLaunchKernelGGL(k_ga_rfix, dim3((unsigned)T), dim3(256), 0, st, raw_out, T, O, g.Op, bias, sw, rl, s0p, cscl);
     const int RA = RLIMBS * T;
-    hipLaunchKernelGGL((k_ga_mm<4, 4>), dim3((unsigned)((RA + 127) / 128), (unsigned)((K + 127) / 128)), dim3(64), 0, st, rl, wt, RA, K, g.Op,
-                       (int)(g.Op / 128), cpart);
+    hipLaunchKernelGGL(k_i8mm, dim3((unsigned)((RA + 127) / 128), (unsigned)((K + 127) / 128), 1), dim3(256), 0, st, rl, wt, RA, K, g.Op,
+                       (int)(g.Op / 128), (int)(g.Op / 128), cpart);
     hipLaunchKernelGGL(k_ga_fin_c, dim3((unsigned)((g.n + 255) / 256)), dim3(256), 0, st, cpart, T, K, cscl, C);
     const int nb = (int)((g.n + PBLK - 1) / PBLK);
     double* Cs = (double*)(base + g.off_Cs);
@@ -931,16 +926,14 @@ extern "C" int adalog_gram_act_build(const float* raw_out, int T, int O, const f
     hipLaunchKernelGGL(k_ga_scan, dim3(2), dim3(256), 0, st, bsum, nb, s0p, T, (double*)(base + g.off_s0));
     hipLaunchKernelGGL(k_ga_prefix, dim3((unsigned)nb), dim3(256), 0, st, Cs, g.n, bsum, (double*)(base + g.off_prefix));
     const int nbt = g.NJ * (g.NJ + 1) / 2;
-    double* sw2 = (double*)(base + g.off_sw2);
-    hipLaunchKernelGGL(k_ga_sw2, dim3((unsigned)((O + 255) / 256)), dim3(256), 0, st, sw, O, sw2);
     double* hfrag = (double*)(base + g.off_hfrag);
     const int ntt = g.NJH * (g.NJH + 1) / 2;
     for (int r = 0; r < g.RT; ++r)                             // role order of the score launches: triangles, then rectangles
-        hipLaunchKernelGGL(k_ga_h, dim3((unsigned)(((int64_t)ntt * 1024 + 255) / 256)), dim3(256), 0, st, wt, O, g.Op, sw2,
-                           hfrag + (int64_t)r * ntt * 1024, r * g.NJH, 0, g.NJH, g.NJH, 1);
+        hipLaunchKernelGGL(k_ga_h, dim3((unsigned)ntt), dim3(64 * GA_H_WAVES), 0, st, wsd, O, K, hfrag + (int64_t)r * ntt * 1024, r * g.NJH, 0,
+                           g.NJH, g.NJH, 1);
     for (int r = 0; r < g.RR; ++r) {
         const int ntr = 4 * g.NIW * g.NJC;
-        hipLaunchKernelGGL(k_ga_h, dim3((unsigned)(((int64_t)ntr * 1024 + 255) / 256)), dim3(256), 0, st, wt, O, g.Op, sw2,
+        hipLaunchKernelGGL(k_ga_h, dim3((unsigned)ntr), dim3(64 * GA_H_WAVES), 0, st, wsd, O, K,
                            hfrag + ((int64_t)g.RT * ntt + (int64_t)r * ntr) * 1024, 0, g.NJH + r * g.NJC, 4 * g.NIW, g.NJC, 0);
     }
     (void)nbt;

@@ -141,7 +141,14 @@ __global__ __launch_bounds__(256) void k_score_sorted(const float* __restrict__ 
     const float klo = ceilf(-z), khi = floorf(qmax - z);
     const float* x = sorted + seg * n;
     const d2* pf = prefix + seg * (n + 1);
-    auto lower = [&](float target) { return uni_level_lower(x, n, s, target); };       // (common.h: threshold + 16-ary search)
+    auto lower = [&](float target) {                                   // first i with rne(x[i] / s) >= target
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (rintf(x[mid] / s) >= target) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
     if (live) {
         bnd[gi][t] = lower(fminf(klo + (float)t, khi + 1.0f));
         if (t == 0) bnd[gi][G] = lower(khi + 1.0f);

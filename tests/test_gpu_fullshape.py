@@ -98,15 +98,18 @@ LINEAR = [  # tag, I, O, n_V, tokens per image, images, bits
     ("deit_small.fc1", 384, 1536, 1, 197, 32, 6),
     # the classifier head: one token per image (32 x 384 -> 1000)
     ("deit_small.head", 384, 1000, 1, 1, 32, 4),
+    # K = 512: swin_base stage 2 (14 x 14 tokens per image): the three-part Gram form of the activation search
+    ("swin_base.l2.fc1", 512, 2048, 1, 196, 32, 4),
     # K = 1024: swin stage 3 (7 x 7 tokens per image)
     ("swin_base.l3.qkv", 1024, 3072, 3, 49, 32, 3),
 ]
 # cases whose weight search production scores from the Gram matrix (K % 32 == 0 and limbs * K <= tokens / 2: csrc/gram.hip)
-GRAM_CASES = {"deit_small.qkv-w4", "deit_small.proj-w4", "vit_base.qkv-w4", "deit_base.proj-w3", "vit_base.fc1-w4", "swin_base.reduction-w3",
+GRAM_CASES = {"deit_small.qkv-w4", "deit_small.proj-w4", "vit_base.qkv-w4", "deit_base.proj-w3", "vit_base.fc1-w4", "swin_base.reduction-w3", "swin_base.l2.fc1-w4",
               "swin_base.l0.fc1-w3", "swin_base.l0.fc1@128img-w3", "deit_small.qkv-w6", "deit_small.fc1-w6"}
-# cases whose activation search production scores from the candidates' Gram matrices (K % 32 == 0, K <= 384: csrc/gram_act.hip)
+# cases whose activation search production scores from the candidates' Gram matrices (K % 32 == 0, K <= 384, or K = 512 / 768 with
+# O >= 2 K: csrc/gram_act.hip)
 GRAM_ACT_CASES = {"deit_small.qkv-w4", "deit_small.proj-w4", "swin_base.l0.fc1-w3", "swin_base.l0.fc1@128img-w3", "deit_small.qkv-w6",
-                  "deit_small.fc1-w6"}
+                  "deit_small.fc1-w6", "vit_base.qkv-w4", "vit_base.fc1-w4", "swin_base.l2.fc1-w4"}
 LINEAR_KERNELS = {          # case -> (weight search [token form], activation search) labels dispatched there
     "deit_small.qkv-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),
     "deit_small.proj-w4": (("k_gemm_slab_wgen<fp8>",), ("k_gemm_slab_gen<fp8>",)),

@@ -94,6 +94,12 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "split":
     case(6304, 768, 768, 4)
     case(6304, 2304, 768, 6)
     case(6304, 1152, 384, 4)
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "swin":
+    for T, K, tok in ((100352, 128, 3136), (25088, 256, 784)):          # swin_base stages 0 / 1: qkv, proj, fc1
+        for O in (3 * K, K, 4 * K):
+            case(T, O, K, 4, tokens=tok)
+    for O in (288, 96, 384):                                             # swin_small / tiny stage 0 (K = 96)
+        case(100352, O, 96, 4, tokens=3136)
 elif __name__ == "__main__" and len(sys.argv) > 1:
     case(6304, 1152, 384, 4)
     case(25088, 768, 256, 4, tokens=784)
