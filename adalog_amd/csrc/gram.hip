@@ -307,14 +307,15 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                 }
                 float kq[16], dm = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const float t = xv[e] * ginv;
-                    kq[e] = rintf(t);
-                    dm = fmaxf(dm, fabsf(t - kq[e]));
+                for (int e = 0; e < 16; e += 2) {               // (the conversion's bias of 128 rides in the fma; two distances per v_max3)
+                    const float t0 = __builtin_fmaf(xv[e], ginv, 128.0f), t1 = __builtin_fmaf(xv[e + 1], ginv, 128.0f);
+                    kq[e] = rintf(t0);
+                    kq[e + 1] = rintf(t1);
+                    dm = fmaxf(dm, fmaxf(fabsf(t0 - kq[e]), fabsf(t1 - kq[e + 1])));
                 }
                 if (__builtin_expect(dm > p.tie, 0)) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) kq[e] = rintf(xv[e] / gs);
+                    for (int e = 0; e < 16; ++e) kq[e] = rintf(xv[e] / gs) + 128.0f;
                 }
                 v4i pk;
 #pragma unroll
@@ -322,7 +323,7 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                     unsigned u = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e] + 128.0f, glo, ghi), e, u);
+                        u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e], glo, ghi), e, u);
                     pk[j] = (int)(u ^ 0x80808080u);
                 }
                 *reinterpret_cast<v4i*>(stb + jt * 1024) = pk;

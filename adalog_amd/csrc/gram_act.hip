@@ -52,6 +52,21 @@ template <typename F, int... I> __device__ __forceinline__ void sfor_impl(F&& f,
 }
 template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 
+// The fast path of the score kernels' generator for two neighbouring elements (xa, xb) of a fragment: bin by reciprocal multiply with
+// the conversion's bias of 128 folded in (fma), track the slot's largest distance from an integer (dm: the tie test; the pair's two
+// distances go into one v_max3), clamp, and put the two bytes at positions e0, e0 + 1 of the packed dword pk (bytes biased by 128:
+// one xor per dword afterwards).  5.75 VALU instructions per element.  Same-box A/B at the qkv / swin stage-1 shapes (us per step):
+// element by element with a separate add of 128 (7.25 per element) 183 / 391; pairs + v_max3 alone 184 / 397; this form 174 / 370;
+// clamp first, then ONE SDWA add of 1.5 * 2^23 that rounds, converts and writes the signed byte in place (5.5) 175 / 372.
+#define GA_GEN_PAIR(xa, xb, dm, pk, e0)                                                                                           \
+    do {                                                                                                                          \
+        const float ta_ = __builtin_fmaf((xa), ginv, 128.0f), ka_ = rintf(ta_);                                                   \
+        const float tb_ = __builtin_fmaf((xb), ginv, 128.0f), kb_ = rintf(tb_);                                                   \
+        dm = fmaxf(dm, fmaxf(fabsf(ta_ - ka_), fabsf(tb_ - kb_)));                                                                \
+        pk = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(ka_, glo, ghi), (e0), (unsigned)pk);                     \
+        pk = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kb_, glo, ghi), (e0) + 1, (unsigned)pk);                 \
+    } while (0)
+
 constexpr int RLIMBS = 4;
 constexpr int RFIX_BITS = 29;
 constexpr int PBLK = 1024;             // elements per prefix block
@@ -371,6 +386,16 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
             for (int j = 0; j < 4; ++j) xr[g][j] = *reinterpret_cast<const float4*>(src + j * 256);
         });
     };
+    // one fragment's share of load_x: issued inside the interleaved block as soon as the generator has consumed the fragment's
+    // registers instead of 12 vector loads back to back in front of the barrier (same box: K = 384 176 -> 175 us, K = 512 384 -> 373,
+    // K = 768 633 -> 628 us per step)
+    auto load_x_one = [&](int c, auto gc) {
+        constexpr int g = decltype(gc)::value;
+        const int cc = min(c, p.nchunk - 1);
+        const float* src = p.xt + (((int64_t)cc * p.NJT + (kb0 + W + 4 * g)) * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[g][j] = *reinterpret_cast<const float4*>(src + j * 256);
+    };
     // fast path of the generator for fragment g: bins by reciprocal multiply; returns the fragment and the slot's largest distance
     // from an integer (the tie test of the slab GEN form: above p.tie the IEEE quotient decides -- done afterwards, off the hot block)
     auto gen_fast = [&](auto gc, v4i& pk, float& dm) {
@@ -410,6 +435,17 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
                 u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(rintf(xv[4 * j + e] / gs) + 128.0f, glo, ghi), e, u);
             pk[j] = (int)(u ^ 0x80808080u);
         }
+    };
+    // ... for a fragment of chunk c whose registers already hold the chunk after it: the (rare) slot re-reads its x
+    auto gen_exact_at = [&](int c, auto gc, v4i& pk) {
+        float4 keep[4];
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep[j] = xr[g][j];
+        load_x_one(c, gc);
+        gen_exact(gc, pk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[g][j] = keep[j];
     };
     auto frag_addr = [&](int buf, int g) { return lds + (buf * NJ + (W + 4 * g)) * 1024 + lane * 16; };
 
@@ -460,36 +496,33 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
             // behind them, sched_barrier or not).
             if constexpr (b < 16) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+a"(acc[b]) : "v"(fi), "v"(fj));
             else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(fi), "v"(fj));
-            // ... and behind each MFMA its share of the generator's elements (fast path), pinned there.  (Tried and dropped, same box:
-            // t' = fma(x, 1/s, 128) saving the biased conversion's add -- 182 -> 191 us per launch; the same as packed fp32
-            // operations -- 196 us: packed fp32 issues badly beside MFMAs, as the guide's filler table says.)
+            // ... and behind each MFMA its share of the generator's element pairs (fast path, GA_GEN_PAIR), pinned there.  (Tried and
+            // dropped, same box: packed fp32 operations -- 196 against 182 us: packed fp32 issues badly beside MFMAs, as the guide's
+            // filler table says.)
             {
 #pragma clang fp contract(off)
-                constexpr int lo = (b * NEL) / NOWN, hi = ((b + 1) * NEL) / NOWN;
+                constexpr int NPR = NEL / 2;                    // the generator works on PAIRS of elements (GA_GEN_PAIR)
+                constexpr int lo = (b * NPR) / NOWN, hi = ((b + 1) * NPR) / NOWN;
                 sfor<hi - lo>([&](auto kc) {
-                    constexpr int idx = lo + decltype(kc)::value, g = idx >> 4, e = idx & 15;
+                    constexpr int pi = lo + decltype(kc)::value, g = pi >> 3, e = (pi & 7) * 2;
                     const float4 q4 = xr[g][e >> 2];
-                    const float xv = (e & 3) == 0 ? q4.x : (e & 3) == 1 ? q4.y : (e & 3) == 2 ? q4.z : q4.w;
-                    const float t = xv * ginv;
-                    const float k = rintf(t);
-                    dmn[g] = fmaxf(dmn[g], fabsf(t - k));
-                    pkn[g][e >> 2] = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k + 128.0f, glo, ghi), e & 3, (unsigned)pkn[g][e >> 2]);
+                    const float xa = (e & 2) ? q4.z : q4.x, xb = (e & 2) ? q4.w : q4.y;
+                    GA_GEN_PAIR(xa, xb, dmn[g], pkn[g][e >> 2], e & 3);
                     if constexpr (decltype(kc)::value == hi - lo - 1) asm volatile("" : "+v"(dmn[g]), "+v"(pkn[g]));
+                    if constexpr ((pi & 7) == 7) load_x_one(c + 2, std::integral_constant<int, g>{});    // fragment g consumed
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
         });
         if constexpr (NOWN == 0 && NGEN > 0) {             // (tiny K: a wave that generates but owns no block -- nothing to hide behind)
 #pragma clang fp contract(off)
-            sfor<NEL>([&](auto kc) {
-                constexpr int idx = decltype(kc)::value, g = idx >> 4, e = idx & 15;
+            sfor<NEL / 2>([&](auto kc) {
+                constexpr int pi = decltype(kc)::value, g = pi >> 3, e = (pi & 7) * 2;
                 const float4 q4 = xr[g][e >> 2];
-                const float xv = (e & 3) == 0 ? q4.x : (e & 3) == 1 ? q4.y : (e & 3) == 2 ? q4.z : q4.w;
-                const float t = xv * ginv;
-                const float k = rintf(t);
-                dmn[g] = fmaxf(dmn[g], fabsf(t - k));
-                pkn[g][e >> 2] = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k + 128.0f, glo, ghi), e & 3, (unsigned)pkn[g][e >> 2]);
+                const float xa = (e & 2) ? q4.z : q4.x, xb = (e & 2) ? q4.w : q4.y;
+                GA_GEN_PAIR(xa, xb, dmn[g], pkn[g][e >> 2], e & 3);
             });
+            load_x(c + 2);
         }
 #pragma unroll
         for (int g = 0; g < NGEN; ++g)
@@ -499,10 +532,9 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
         if (p.timeline) { asm volatile("s_nop 0" ::: "memory"); tb = GA_T(); }
         sfor<NGEN>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if (__builtin_expect(dmn[g] > p.tie, 0)) gen_exact(gc, pkn[g]);
+            if (__builtin_expect(dmn[g] > p.tie, 0)) gen_exact_at(c + 1, gc, pkn[g]);
             *reinterpret_cast<v4i*>(frag_addr((c + 1) & 1, g)) = pkn[g];
         });
-        load_x(c + 2);                                      // a whole iteration ahead of the generator that consumes it
         if (p.timeline) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tc = GA_T(); }
         __syncthreads();
         if (p.timeline) { const long long td = GA_T(); tl0 += tb - ta; tl1 += tc - tb; tl2 += td - tc; }
@@ -582,6 +614,14 @@ __device__ __forceinline__ void ga_rect_wave(const GaQuadArgs& p, uint8_t* lds, 
             for (int j = 0; j < 4; ++j) xr[g][j] = *reinterpret_cast<const float4*>(src + j * 256);
         });
     };
+    auto load_x_one = [&](int c, auto gc) {
+        constexpr int g = decltype(gc)::value, f = W + 4 * g;
+        const int cc = min(c, p.nchunk - 1);
+        const int kb = f < 4 * NIW ? kbA + f : kbB + (f - 4 * NIW);
+        const float* src = p.xt + (((int64_t)cc * p.NJT + kb) * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[g][j] = *reinterpret_cast<const float4*>(src + j * 256);
+    };
     auto gen_fast = [&](auto gc, v4i& pk, float& dm) {
 #pragma clang fp contract(off)
         constexpr int g = decltype(gc)::value;
@@ -620,6 +660,16 @@ __device__ __forceinline__ void ga_rect_wave(const GaQuadArgs& p, uint8_t* lds, 
             pk[j] = (int)(u ^ 0x80808080u);
         }
     };
+    auto gen_exact_at = [&](int c, auto gc, v4i& pk) {     // (the fragment's registers already hold the chunk after c: re-read its x)
+        float4 keep[4];
+        constexpr int g = decltype(gc)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep[j] = xr[g][j];
+        load_x_one(c, gc);
+        gen_exact(gc, pk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xr[g][j] = keep[j];
+    };
     auto frag_addr = [&](int buf, int g) { return lds + (buf * NF + (W + 4 * g)) * 1024 + lane * 16; };
 
     if (c0 < c1) {
@@ -654,16 +704,15 @@ __device__ __forceinline__ void ga_rect_wave(const GaQuadArgs& p, uint8_t* lds, 
             else asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc[b]) : "v"(fi), "v"(fj));
             {
 #pragma clang fp contract(off)
-                constexpr int lo = (b * NEL) / NOWN, hi = ((b + 1) * NEL) / NOWN;
+                constexpr int NPR = NEL / 2;                    // the generator works on PAIRS of elements (GA_GEN_PAIR)
+                constexpr int lo = (b * NPR) / NOWN, hi = ((b + 1) * NPR) / NOWN;
                 sfor<hi - lo>([&](auto kc) {
-                    constexpr int idx = lo + decltype(kc)::value, g = idx >> 4, e = idx & 15;
+                    constexpr int pi = lo + decltype(kc)::value, g = pi >> 3, e = (pi & 7) * 2;
                     const float4 q4 = xr[g][e >> 2];
-                    const float xv = (e & 3) == 0 ? q4.x : (e & 3) == 1 ? q4.y : (e & 3) == 2 ? q4.z : q4.w;
-                    const float t = xv * ginv;
-                    const float k = rintf(t);
-                    dmn[g] = fmaxf(dmn[g], fabsf(t - k));
-                    pkn[g][e >> 2] = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(k + 128.0f, glo, ghi), e & 3, (unsigned)pkn[g][e >> 2]);
+                    const float xa = (e & 2) ? q4.z : q4.x, xb = (e & 2) ? q4.w : q4.y;
+                    GA_GEN_PAIR(xa, xb, dmn[g], pkn[g][e >> 2], e & 3);
                     if constexpr (decltype(kc)::value == hi - lo - 1) asm volatile("" : "+v"(dmn[g]), "+v"(pkn[g]));
+                    if constexpr ((pi & 7) == 7) load_x_one(c + 2, std::integral_constant<int, g>{});    // fragment g consumed
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -674,10 +723,9 @@ __device__ __forceinline__ void ga_rect_wave(const GaQuadArgs& p, uint8_t* lds, 
             for (int j = 0; j < 4; ++j) pkn[g][j] ^= (int)0x80808080u;
         sfor<NGEN>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            if (__builtin_expect(dmn[g] > p.tie, 0)) gen_exact(gc, pkn[g]);
+            if (__builtin_expect(dmn[g] > p.tie, 0)) gen_exact_at(c + 1, gc, pkn[g]);
             *reinterpret_cast<v4i*>(frag_addr((c + 1) & 1, g)) = pkn[g];
         });
-        load_x(c + 2);
         __syncthreads();
     }
 
