@@ -707,7 +707,9 @@ extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, co
     a.sa = sa; a.norm = norm; a.scores = scores;
     a.qmax = (float)((1 << w_bits) - 1);
     const float zone = 6e-7f * (float)(1 << w_bits);
-    a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
+    // (the fast path bins fma(x, 1/s, 128): |error| <= 2^-17 from the sum's rounding at 128..256 + 1.2e-7 |x / s| from the reciprocal --
+    // 0.95e-5 for 4-bit operands, 2.3e-5 for 7-bit -- the zone must exceed it)
+    a.tie = 0.5f - (zone > 2e-5f ? zone : 2e-5f);
     a.nblk = (int)((int64_t)O * P / 32);
     a.timeline = g_gram_timeline;
     const bool big = w_bits > 4;

@@ -1012,7 +1012,9 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
     a.NJT = g.NJ; a.R = g.RT; a.QS = g.QS; a.q0 = 0; a.kb_a = 0; a.kb_b = 0;
     a.qmax = (float)((1 << a_bits) - 1);
     const float zone = 6e-7f * (float)(1 << a_bits);
-    a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
+    // (the fast path bins fma(x, 1/s, 128): |error| <= 2^-17 from the sum's rounding at 128..256 + 1.2e-7 |x / s| from the reciprocal --
+    // 0.95e-5 for 4-bit operands, 2.3e-5 for 7-bit -- the zone must exceed it)
+    a.tie = 0.5f - (zone > 2e-5f ? zone : 2e-5f);
     a.timeline = g_ga_timeline;
     hipStream_t st = (hipStream_t)stream;
 #define GA_LAUNCH(NJV)                                                                                            \

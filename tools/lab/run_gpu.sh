@@ -1,10 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-mkdir -p gpurun_out/r8
-for v in l0 new l0 new; do
-  echo "variant $v"
-  if [ $v = new ]; then L=$PWD/adalog_amd/csrc/libadalog_hip.so; else L=$PWD/tools/lab/variants/libadalog_$v.so; fi
-  ADALOG_LIB=$L timeout 300 python tools/lab/gram_act_check.py x 2>&1 | grep shape | cut -c1-260
-done
-ADALOG_LIB=$PWD/tools/lab/variants/libadalog_l0.so timeout 300 python tools/lab/gram_act_check.py split 2>&1 | grep shape | cut -c1-260 | head -5
-timeout 300 python tools/lab/gram_act_check.py split 2>&1 | grep shape | cut -c1-260 | head -5
-timeout 600 python -m pytest tests -m gpu -x -q -k "gram_act" 2>&1 | tail -2
+mkdir -p gpurun_out/r9
+(time timeout 2400 python -m pytest tests -m gpu -x -q) > gpurun_out/r9/pytest.log 2>&1; tail -4 gpurun_out/r9/pytest.log
+timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r9/bench.json 2> gpurun_out/r9/bench.err; head -c 250 gpurun_out/r9/bench.json; echo
+timeout 300 python bench.py --bits 6 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/r9/bench_w6.json 2> gpurun_out/r9/bench_w6.err; head -c 250 gpurun_out/r9/bench_w6.json; echo
