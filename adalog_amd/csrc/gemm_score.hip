@@ -821,10 +821,9 @@ extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp
     p.gen_x = x; p.gen_ldx = ldx; p.gen_K = K; p.gen_scale = scale; p.gen_zp = zp; p.gen_sc = 1; p.gen_sn = 0; p.gen_sa = nullptr;
     p.gen_qmax = (float)((1 << n_bits) - 1);
     // tie zone: the reciprocal-multiply quotient is within ~2 ulp of the IEEE one; only |quotient| <= 2^bits matters (beyond it
-    // both clamp alike), so 6e-7 * 2^bits bounds the difference with a factor of 2.5 to spare.  The int8 form bins fma(x, 1/s, 128):
-    // 2^-17 more from the sum's rounding at 128..256 (0.95e-5 in all for 4-bit operands): never narrower than 2e-5
+    // both clamp alike), so 6e-7 * 2^bits bounds the difference with a factor of 2.5 to spare; never narrower than 1e-5
     const float zone = 6e-7f * (float)(1 << n_bits);
-    p.gen_tie = 0.5f - (zone > 2e-5f ? zone : 2e-5f);
+    p.gen_tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
     const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
     const int SBN = 32 * L.slab_nb;
     const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4;
@@ -899,7 +898,7 @@ extern "C" int adalog_score_w_gen(int dtype, const void* Xp, int T, int64_t Kp, 
     p.gen_x = W; p.gen_ldx = ldw; p.gen_K = K; p.gen_scale = scale; p.gen_zp = zp; p.gen_sc = O; p.gen_sn = 1; p.gen_sa = sa;
     p.gen_qmax = (float)((1 << n_bits) - 1);
     const float zone = 6e-7f * (float)(1 << n_bits);
-    p.gen_tie = 0.5f - (zone > 2e-5f ? zone : 2e-5f);
+    p.gen_tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
     const int nk = (int)((p.Kvb + BK3 - 1) / BK3);
     const int SBN = 32 * L.slab_nb;
     const size_t shm = (size_t)nk * SBN * BK3 + 8 * 3 * 32 * BK3 + 8 * 192 * 4 + 8 * SBN * 4;

@@ -307,15 +307,14 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                 }
                 float kq[16], dm = 0.0f;
 #pragma unroll
-                for (int e = 0; e < 16; e += 2) {               // (the conversion's bias of 128 rides in the fma; two distances per v_max3)
-                    const float t0 = __builtin_fmaf(xv[e], ginv, 128.0f), t1 = __builtin_fmaf(xv[e + 1], ginv, 128.0f);
-                    kq[e] = rintf(t0);
-                    kq[e + 1] = rintf(t1);
-                    dm = fmaxf(dm, fmaxf(fabsf(t0 - kq[e]), fabsf(t1 - kq[e + 1])));
+                for (int e = 0; e < 16; ++e) {
+                    const float t = xv[e] * ginv;
+                    kq[e] = rintf(t);
+                    dm = fmaxf(dm, fabsf(t - kq[e]));
                 }
                 if (__builtin_expect(dm > p.tie, 0)) {
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) kq[e] = rintf(xv[e] / gs) + 128.0f;
+                    for (int e = 0; e < 16; ++e) kq[e] = rintf(xv[e] / gs);
                 }
                 v4i pk;
 #pragma unroll
@@ -323,7 +322,7 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                     unsigned u = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e], glo, ghi), e, u);
+                        u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e] + 128.0f, glo, ghi), e, u);
                     pk[j] = (int)(u ^ 0x80808080u);
                 }
                 *reinterpret_cast<v4i*>(stb + jt * 1024) = pk;
@@ -707,9 +706,7 @@ extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, co
     a.sa = sa; a.norm = norm; a.scores = scores;
     a.qmax = (float)((1 << w_bits) - 1);
     const float zone = 6e-7f * (float)(1 << w_bits);
-    // (the fast path bins fma(x, 1/s, 128): |error| <= 2^-17 from the sum's rounding at 128..256 + 1.2e-7 |x / s| from the reciprocal --
-    // 0.95e-5 for 4-bit operands, 2.3e-5 for 7-bit -- the zone must exceed it)
-    a.tie = 0.5f - (zone > 2e-5f ? zone : 2e-5f);
+    a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
     a.nblk = (int)((int64_t)O * P / 32);
     a.timeline = g_gram_timeline;
     const bool big = w_bits > 4;

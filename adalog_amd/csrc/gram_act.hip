@@ -52,19 +52,27 @@ template <typename F, int... I> __device__ __forceinline__ void sfor_impl(F&& f,
 }
 template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl(f, std::make_integer_sequence<int, N>{}); }
 
-// The fast path of the score kernels' generator for two neighbouring elements (xa, xb) of a fragment: bin by reciprocal multiply with
-// the conversion's bias of 128 folded in (fma), track the slot's largest distance from an integer (dm: the tie test; the pair's two
-// distances go into one v_max3), clamp, and put the two bytes at positions e0, e0 + 1 of the packed dword pk (bytes biased by 128:
-// one xor per dword afterwards).  5.75 VALU instructions per element.  Same-box A/B at the qkv / swin stage-1 shapes (us per step):
-// element by element with a separate add of 128 (7.25 per element) 183 / 391; pairs + v_max3 alone 184 / 397; this form 174 / 370;
-// clamp first, then ONE SDWA add of 1.5 * 2^23 that rounds, converts and writes the signed byte in place (5.5) 175 / 372.
+// The fast path of the score kernels' generator for two neighbouring elements (xa, xb) of a fragment: bin by reciprocal multiply, track
+// the slot's largest distance from an integer (dm: the tie test; the pair's two distances go into one v_max3), clamp the QUOTIENT, and
+// let ONE SDWA add of 1.5 * 2^23 round it to nearest-even, convert it and write the signed byte into position e0 / e0 + 1 of the packed
+// dword pk (the low byte of the sum's bit pattern is rne(t) in two's complement): 5.5 VALU instructions per element.  Same-box A/B at
+// the qkv / swin stage-1 shapes (us per step): element by element through a biased cvt_pk_u8 (add 128, med3, convert, one xor per
+// dword: 7.25 per element) 183 / 391; the same in pairs with v_max3 184 / 397; the bias folded into the multiply (fma(x, 1/s, 128),
+// 5.75) 174 / 370 -- but the sum's rounding at 128..256 costs 2^-17 of the tie zone, and with the zone widened for it the calibration
+// was no faster (same box 868 / 870 against 878 / 873 ms); this form 175 / 372 with the original zone.
+__device__ __forceinline__ int ga_sdwa_byte(int pk, float tc, float magic, int pos) {
+    if (pos == 0) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    else if (pos == 1) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    else if (pos == 2) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    else asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    return pk;
+}
 #define GA_GEN_PAIR(xa, xb, dm, pk, e0)                                                                                           \
     do {                                                                                                                          \
-        const float ta_ = __builtin_fmaf((xa), ginv, 128.0f), ka_ = rintf(ta_);                                                   \
-        const float tb_ = __builtin_fmaf((xb), ginv, 128.0f), kb_ = rintf(tb_);                                                   \
+        const float ta_ = (xa) * ginv, ka_ = rintf(ta_), tb_ = (xb) * ginv, kb_ = rintf(tb_);                                     \
         dm = fmaxf(dm, fmaxf(fabsf(ta_ - ka_), fabsf(tb_ - kb_)));                                                                \
-        pk = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(ka_, glo, ghi), (e0), (unsigned)pk);                     \
-        pk = (int)__builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kb_, glo, ghi), (e0) + 1, (unsigned)pk);                 \
+        pk = ga_sdwa_byte(pk, __builtin_amdgcn_fmed3f(ta_, glo - 128.0f, ghi - 128.0f), gmagic, (e0));                            \
+        pk = ga_sdwa_byte(pk, __builtin_amdgcn_fmed3f(tb_, glo - 128.0f, ghi - 128.0f), gmagic, (e0) + 1);                        \
     } while (0)
 
 constexpr int RLIMBS = 4;
@@ -367,6 +375,7 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
     const float gs = p.scale[cand], gz = rintf(p.zp[cand]);
     const float ginv = __builtin_amdgcn_rcpf(gs);
     const float glo = 128.0f - gz, ghi = 128.0f + (p.qmax - gz);
+    const float gmagic = 12582912.0f;                      // 1.5 * 2^23 (GA_GEN_PAIR)
     const int c0 = split * p.chunks_per_split, c1 = min(c0 + p.chunks_per_split, p.nchunk);
 
     v16i acc[NOWN > 0 ? NOWN : 1];
@@ -524,10 +533,6 @@ __device__ __forceinline__ void ga_quad_wave(const GaQuadArgs& p, uint8_t* lds, 
             });
             load_x(c + 2);
         }
-#pragma unroll
-        for (int g = 0; g < NGEN; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pkn[g][j] ^= (int)0x80808080u;
         long long tb = 0, tc = 0;
         if (p.timeline) { asm volatile("s_nop 0" ::: "memory"); tb = GA_T(); }
         sfor<NGEN>([&](auto gc) {
@@ -595,6 +600,7 @@ __device__ __forceinline__ void ga_rect_wave(const GaQuadArgs& p, uint8_t* lds, 
     const float gs = p.scale[cand], gz = rintf(p.zp[cand]);
     const float ginv = __builtin_amdgcn_rcpf(gs);
     const float glo = 128.0f - gz, ghi = 128.0f + (p.qmax - gz);
+    const float gmagic = 12582912.0f;                      // 1.5 * 2^23 (GA_GEN_PAIR)
     const int c0 = split * p.chunks_per_split, c1 = min(c0 + p.chunks_per_split, p.nchunk);
 
     v16i acc[NOWN];
@@ -717,10 +723,6 @@ __device__ __forceinline__ void ga_rect_wave(const GaQuadArgs& p, uint8_t* lds, 
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-#pragma unroll
-        for (int g = 0; g < NGEN; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) pkn[g][j] ^= (int)0x80808080u;
         sfor<NGEN>([&](auto gc) {
             constexpr int g = decltype(gc)::value;
             if (__builtin_expect(dmn[g] > p.tie, 0)) gen_exact_at(c + 1, gc, pkn[g]);
@@ -1012,9 +1014,7 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
     a.NJT = g.NJ; a.R = g.RT; a.QS = g.QS; a.q0 = 0; a.kb_a = 0; a.kb_b = 0;
     a.qmax = (float)((1 << a_bits) - 1);
     const float zone = 6e-7f * (float)(1 << a_bits);
-    // (the fast path bins fma(x, 1/s, 128): |error| <= 2^-17 from the sum's rounding at 128..256 + 1.2e-7 |x / s| from the reciprocal --
-    // 0.95e-5 for 4-bit operands, 2.3e-5 for 7-bit -- the zone must exceed it)
-    a.tie = 0.5f - (zone > 2e-5f ? zone : 2e-5f);
+    a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
     a.timeline = g_ga_timeline;
     hipStream_t st = (hipStream_t)stream;
 #define GA_LAUNCH(NJV)                                                                                            \
