@@ -51,6 +51,17 @@ __device__ __forceinline__ float adalog_k(float u, float qf) {
     return k;
 }
 
+// pk.byte[pos] = rne(tc) as a two's-complement int8 (|tc| <= 127; pos a compile-time constant after inlining): ONE SDWA add of
+// 1.5 * 2^23 rounds to nearest-even (the sum's ulp is 1), and the low byte of the sum's bit pattern IS the integer -- rounding,
+// conversion and the byte insert of a generated int8 MFMA operand in one VALU instruction (round 5; gram.hip, gram_act.hip).
+__device__ __forceinline__ int sdwa_rne_byte(int pk, float tc, float magic /* 12582912.0f */, int pos) {
+    if (pos == 0) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    else if (pos == 1) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    else if (pos == 2) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    else asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
+    return pk;
+}
+
 // ---- fast forms used by the operand-packing kernels (hundreds of millions of elements per scoring call).
 // Both evaluate with a reciprocal multiply first and fall back to the exact IEEE sequence above only when the result
 // lands within 1e-3 of a rounding tie, so they return EXACTLY the same integer as the exact forms (the reciprocal path

@@ -318,12 +318,12 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
                 }
                 v4i pk;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned u = 0;
+                for (int j = 0; j < 4; ++j) {                  // clamp, then one SDWA add converts and inserts the signed byte (common.h)
+                    int u = 0;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        u = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(kq[4 * j + e] + 128.0f, glo, ghi), e, u);
-                    pk[j] = (int)(u ^ 0x80808080u);
+                        u = sdwa_rne_byte(u, __builtin_amdgcn_fmed3f(kq[4 * j + e], glo - 128.0f, ghi - 128.0f), 12582912.0f, e);
+                    pk[j] = u;
                 }
                 *reinterpret_cast<v4i*>(stb + jt * 1024) = pk;
             }

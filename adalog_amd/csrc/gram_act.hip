@@ -60,19 +60,12 @@ template <int N, typename F> __device__ __forceinline__ void sfor(F&& f) { sfor_
 // dword: 7.25 per element) 183 / 391; the same in pairs with v_max3 184 / 397; the bias folded into the multiply (fma(x, 1/s, 128),
 // 5.75) 174 / 370 -- but the sum's rounding at 128..256 costs 2^-17 of the tie zone, and with the zone widened for it the calibration
 // was no faster (same box 868 / 870 against 878 / 873 ms); this form 175 / 372 with the original zone.
-__device__ __forceinline__ int ga_sdwa_byte(int pk, float tc, float magic, int pos) {
-    if (pos == 0) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
-    else if (pos == 1) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
-    else if (pos == 2) asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
-    else asm("v_add_f32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(pk) : "v"(tc), "v"(magic));
-    return pk;
-}
 #define GA_GEN_PAIR(xa, xb, dm, pk, e0)                                                                                           \
     do {                                                                                                                          \
         const float ta_ = (xa) * ginv, ka_ = rintf(ta_), tb_ = (xb) * ginv, kb_ = rintf(tb_);                                     \
         dm = fmaxf(dm, fmaxf(fabsf(ta_ - ka_), fabsf(tb_ - kb_)));                                                                \
-        pk = ga_sdwa_byte(pk, __builtin_amdgcn_fmed3f(ta_, glo - 128.0f, ghi - 128.0f), gmagic, (e0));                            \
-        pk = ga_sdwa_byte(pk, __builtin_amdgcn_fmed3f(tb_, glo - 128.0f, ghi - 128.0f), gmagic, (e0) + 1);                        \
+        pk = sdwa_rne_byte(pk, __builtin_amdgcn_fmed3f(ta_, glo - 128.0f, ghi - 128.0f), gmagic, (e0));                            \
+        pk = sdwa_rne_byte(pk, __builtin_amdgcn_fmed3f(tb_, glo - 128.0f, ghi - 128.0f), gmagic, (e0) + 1);                        \
     } while (0)
 
 constexpr int RLIMBS = 4;
