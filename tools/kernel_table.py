@@ -9,6 +9,7 @@ GROUPS = [
     ("`k_act_fused_asm` (fc2 activation search)", ["k_act_fused_asm"]),
     ("`k_ga_quad` + build + finish (Gram form: qkv / proj / fc1 activation searches)", ["k_ga_"]),
     ("`k_gram_score` + build (Gram form: qkv / proj / fc1 weight searches)", ["k_gram_"]),
+    ("`k_i8mm` (the int8 product of both Gram builds)", ["k_i8mm"]),
     ("`k_gemm_slab<…, GEN>` (token-form activation searches)", ["k_gemm_slab<2, true", "k_gemm_slab<1, true"]),
     ("`k_gemm_slab<…, GEN>` weight form (token-form weight searches)", ["k_gemm_slab<2, false", "k_gemm_slab<1, false"]),
     ("`k_gemm_stream` (fc2 weight search `MX`, patch embedding)", ["k_gemm_stream"]),
