@@ -26,6 +26,33 @@ extern "C" unsigned int* adalog_ticket_slots_on(int n, void* stream);   // ... f
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Raise a kernel's dynamic-LDS limit once PER DEVICE (the attribute belongs to the function's code object on one device: a
+// per-process "done" flag would leave the second device of a process without it).  ``done_mask``: a static per call site, one bit
+// per device ordinal.  Returns the error of hipFuncSetAttribute so that the caller fails instead of launching with 64 KiB.
+static inline hipError_t adalog_max_lds(const void* fn, int bytes, unsigned long long* done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*done_mask & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) *done_mask |= bit;
+    return e;
+}
+
+// compute units of the CURRENT device (cached per device ordinal, not per process)
+static inline int adalog_device_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cus[dev & 63];
+    if (c == 0) {
+        hipDeviceProp_t pr;
+        c = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    return c;
+}
+
 // ---------------------------------------------------------------------------------------------- device math
 // asymmetric uniform bin: clamp(rne(x / s) + z, 0, qmax)       (uniform.py:29-35; z already rounded)
 __device__ __forceinline__ float uni_bin(float x, float s, float z, float qmax) {

@@ -618,12 +618,9 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
     ADALOG_LAUNCH_CHECK("adalog_score_act_fused (thresholds)");
 #define LAUNCH_FUSED(NRBV, FNSV)                                                                               \
     do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_act_fused<NRBV, FNSV>),                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
+        static unsigned long long attr_dev = 0; \
+        { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_act_fused<NRBV, FNSV>), (int)(160 * 1024), &attr_dev); \
+          if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
         adalog_note_kernel("k_act_fused<bf16>");                                                             \
         hipLaunchKernelGGL((k_act_fused<NRBV, FNSV>), dim3((unsigned)nwg), dim3(256), shm, st, a);             \
     } while (0)
@@ -632,11 +629,9 @@ extern "C" int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const f
     const size_t shm_asm = 256 + shm;
 #define LAUNCH_ASM(KERNEL, TAG)                                                                                 \
     do {                                                                                                       \
-        static bool attr_set = false;                                                                          \
-        if (!attr_set) {                                                                                       \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-            attr_set = true;                                                                                   \
-        }                                                                                                      \
+        static unsigned long long attr_dev = 0; \
+        { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&KERNEL), (int)(160 * 1024), &attr_dev); \
+          if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
         adalog_note_kernel(TAG);                                                                               \
         hipLaunchKernelGGL(KERNEL, dim3((unsigned)nwg), dim3(512), shm_asm, st, a);                            \
     } while (0)

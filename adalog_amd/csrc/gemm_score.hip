@@ -302,12 +302,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = (size_t)3 * (2 * 64 * L.tm + BN2) * BK3;
 #define LAUNCH_STREAM_MX(RIV)                                                                                     \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<1, RIV, 8, 3, true>),      \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);                \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_stream<1, RIV, 8, 3, true>), (int)(150 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel("k_gemm_stream<bf16xfp8>");                                                        \
             hipLaunchKernelGGL((k_gemm_stream<1, RIV, 8, 3, true>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
         } while (0)
@@ -343,12 +340,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
             const size_t shm_w = ref_lds > acc_lds ? ref_lds : acc_lds;
 #define LAUNCH_WINB(NJV)                                                                                          \
             do {                                                                                                  \
-                static bool attr_set = false;                                                                     \
-                if (!attr_set) {                                                                                  \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_winb<NJV>),                   \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);             \
-                    attr_set = true;                                                                              \
-                }                                                                                                 \
+                static unsigned long long attr_dev = 0; \
+                { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_winb<NJV>), (int)(80 * 1024), &attr_dev); \
+                  if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
                 adalog_note_kernel("k_gemm_winb<bf16xfp8>");                                                      \
                 hipLaunchKernelGGL((k_gemm_winb<NJV>), dim3((unsigned)L.wgs), dim3(256), shm_w, st, p);           \
             } while (0)
@@ -364,12 +358,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = (size_t)3 * 4 * 4 * 32 * BK3 + (size_t)7 * ref_div * 4 + (size_t)gmod * 256 * 8;   // 3 stages of 4 K-steps x 4 blocks
 #define LAUNCH_GRPK8(NJV)                                                                                         \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_grpk8<NJV, 4>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_grpk8<NJV, 4>), (int)(160 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel("k_gemm_grpk8<bf16xfp8>");                                                         \
             hipLaunchKernelGGL((k_gemm_grpk8<NJV, 4>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);             \
         } while (0)
@@ -440,12 +431,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const int nref = SBN / ref_div;
 #define LAUNCH_SLAB(NREFV, ROWSV, DTV, NBV)                                                                       \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, ROWSV, DTV, NBV>),    \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, ROWSV, DTV, NBV>), (int)(160 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel(DTV == 3 ? (NBV == 8 ? "k_gemm_slab<fp8>" : "k_gemm_slab128<fp8>") : (NBV == 8 ? "k_gemm_slab<i8>" : "k_gemm_slab128<i8>")); \
             hipLaunchKernelGGL((k_gemm_slab<NREFV, ROWSV, DTV, NBV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
         } while (0)
@@ -469,19 +457,13 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = ref_lds > acc_lds ? ref_lds : acc_lds;
 #define LAUNCH_WIN(NJV, DTV)                                                                                      \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<NJV, DTV>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                 \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_win<NJV, DTV>), (int)(80 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             if (gen) {                                                                                            \
-                static bool attr_gen = false;                                                                     \
-                if (!attr_gen) {                                                                                  \
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_win<NJV, DTV, true>),         \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);             \
-                    attr_gen = true;                                                                              \
-                }                                                                                                 \
+                static unsigned long long attr_gen = 0; \
+                { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_win<NJV, DTV, true>), (int)(80 * 1024), &attr_gen); \
+                  if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
                 adalog_note_kernel(DTV == 3 ? "k_gemm_win_gen<fp8>" : "k_gemm_win_gen<i8>");                       \
                 hipLaunchKernelGGL((k_gemm_win<NJV, DTV, true>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);   \
             } else {                                                                                              \
@@ -525,12 +507,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = (size_t)3 * 8 * 32 * BK3 + 7 * 256 * 4 + (size_t)gmod * 256 * 8;
 #define LAUNCH_GRP(NJV, DTV)                                                                                      \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_grp<NJV, DTV>),                   \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);                 \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_grp<NJV, DTV>), (int)(96 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel(DTV == 3 ? "k_gemm_grp<fp8>" : "k_gemm_grp<i8>");                                   \
             hipLaunchKernelGGL((k_gemm_grp<NJV, DTV>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);             \
         } while (0)
@@ -546,12 +525,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = (size_t)3 * 7 * 2 * 32 * BK3 + (size_t)7 * ref_div * 4 + (size_t)gmod * 256 * 8;
 #define LAUNCH_GRPK(NJV)                                                                                          \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_grpk<NJV, 7>),                    \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_grpk<NJV, 7>), (int)(160 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel("k_gemm_grpk<bf16>");                                                              \
             hipLaunchKernelGGL((k_gemm_grpk<NJV, 7>), dim3((unsigned)L.wgs), dim3(512), shm, st, p);              \
         } while (0)
@@ -574,12 +550,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = (size_t)(L.wide ? 4 : 3) * (64 * L.tm + BN2) * BK3;
 #define LAUNCH_STREAM(DT, RIV, NWV, NSV)                                                                          \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_stream<DT, RIV, NWV, NSV>),       \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (NSV == 4 ? 128 : 80) * 1024); \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_stream<DT, RIV, NWV, NSV>), (int)((NSV == 4 ? 128 : 80) * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel(DT == 0 ? "k_gemm_stream<i8>" : DT == 1 ? "k_gemm_stream<bf16>" : DT == 2 ? "k_gemm_stream<f32>" : "k_gemm_stream<fp8>"); \
             hipLaunchKernelGGL((k_gemm_stream<DT, RIV, NWV, NSV>), pgrid, dim3(64 * NWV), shm, st, p);            \
         } while (0)
@@ -596,12 +569,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = (size_t)3 * (64 * L.tm + BN2) * BK2 + (512 + 256) * sizeof(float);
 #define LAUNCH_GLDS(DT, TMV)                                                                                      \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_cand_glds<DT, TMV>),              \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_cand_glds<DT, TMV>), (int)(160 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel("k_gemm_cand_glds");                                                               \
             hipLaunchKernelGGL((k_gemm_cand_glds<DT, TMV>), grid, dim3(512), shm, st, p);                         \
         } while (0)
@@ -613,12 +583,9 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         const size_t shm = (size_t)(64 * L.tm + BN2) * BK2 + (512 + 256) * sizeof(float);
 #define LAUNCH_BIG(DT, TMV, ST)                                                                                   \
         do {                                                                                                      \
-            static bool attr_set = false;                                                                         \
-            if (!attr_set) {                                                                                      \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_cand<DT, TMV, ST>),                   \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);                       \
-                attr_set = true;                                                                                  \
-            }                                                                                                     \
+            static unsigned long long attr_dev = 0; \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_cand<DT, TMV, ST>), (int)(72 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
             adalog_note_kernel("k_gemm_cand");                                                                    \
             hipLaunchKernelGGL((k_gemm_cand<DT, TMV, ST>), grid, dim3(512), shm, st, p);                          \
         } while (0)
@@ -730,12 +697,9 @@ extern "C" int adalog_gemm_score_avq(const void* A, int64_t sAg, int M, int N, i
     hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_AVQ(NKSV, RBV)                                                                                     \
     do {                                                                                                          \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_avq<4, NKSV, RBV>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);                     \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
+        static unsigned long long attr_dev = 0; \
+        { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_avq<4, NKSV, RBV>), (int)(80 * 1024), &attr_dev); \
+          if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
         adalog_note_kernel(NKSV == 13 ? "k_gemm_avq<13,bf16>" : "k_gemm_avq<4,bf16>");                              \
         hipLaunchKernelGGL((k_gemm_avq<4, NKSV, RBV>), dim3((unsigned)L.wgs), dim3(256), shm, st, p);             \
     } while (0)
@@ -830,12 +794,9 @@ extern "C" int adalog_score_act_gen(int dtype, const void* Wp, int M, int64_t Kp
     const int nref = SBN / P;
 #define LAUNCH_GEN(NREFV, DTV, NBV)                                                                               \
     do {                                                                                                          \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, true, DTV, NBV, true>),   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
+        static unsigned long long attr_dev = 0; \
+        { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, true, DTV, NBV, true>), (int)(160 * 1024), &attr_dev); \
+          if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
         adalog_note_kernel(DTV == 3 ? (NBV == 8 ? "k_gemm_slab_gen<fp8>" : "k_gemm_slab128_gen<fp8>") : (NBV == 8 ? "k_gemm_slab_gen<i8>" : "k_gemm_slab128_gen<i8>")); \
         hipLaunchKernelGGL((k_gemm_slab<NREFV, true, DTV, NBV, true>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
     } while (0)
@@ -909,12 +870,9 @@ extern "C" int adalog_score_w_gen(int dtype, const void* Xp, int T, int64_t Kp, 
     }
 #define LAUNCH_WGEN(NREFV, DTV, NBV)                                                                              \
     do {                                                                                                          \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, false, DTV, NBV, true>),  \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
+        static unsigned long long attr_dev = 0; \
+        { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_slab<NREFV, false, DTV, NBV, true>), (int)(160 * 1024), &attr_dev); \
+          if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
         adalog_note_kernel(DTV == 3 ? (NBV == 8 ? "k_gemm_slab_wgen<fp8>" : "k_gemm_slab128_wgen<fp8>") : (NBV == 8 ? "k_gemm_slab_wgen<i8>" : "k_gemm_slab128_wgen<i8>")); \
         hipLaunchKernelGGL((k_gemm_slab<NREFV, false, DTV, NBV, true>), dim3((unsigned)L.wgs), dim3(512), shm, st, p); \
     } while (0)

@@ -679,15 +679,7 @@ static long long* g_gram_timeline = nullptr;
 // lab only: cycle stamps [workgroup][pass < 2][8] of the next adalog_gram_score_w launches (null switches them off)
 extern "C" void adalog_gram_set_timeline(long long* buf) { g_gram_timeline = buf; }
 
-static int device_cus_gram() {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    return n_cu;
-}
+static int device_cus_gram() { return adalog_device_cus(); }   // per device ordinal (common.h)
 
 /* One FPCS step: scores [P][O] = -norm * sum_t (raw_out - b - q_a(x) . fq_p(W)^T)^2 for the P candidates (scale, zp) [P][O] of every
  * output row, from the workspace adalog_gram_build left.  W fp32 [O][ldw].  (T, O, K, a_bits) must be those of the build. */
@@ -717,12 +709,9 @@ extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, co
         /* every workgroup slot of the chip gets blocks (a workgroup with fewer than 4 CBV blocks runs one thin pass) */ \
         int wgs = a.nblk < WPC * ncu ? a.nblk : WPC * ncu;                                                        \
         const size_t shm = (size_t)4 * NJV * 1024;                                                                \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set) {                                                                                          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram_score<NJV, CBV, BIGV, WPC>),          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
+        static unsigned long long attr_dev = 0; \
+        { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gram_score<NJV, CBV, BIGV, WPC>), (int)(160 * 1024), &attr_dev); \
+          if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } } \
         adalog_note_kernel("k_gram_score<i8>");                                                                   \
         hipLaunchKernelGGL((k_gram_score<NJV, CBV, BIGV, WPC>), dim3((unsigned)wgs), dim3(256), shm, st, a);      \
     } while (0)

@@ -829,15 +829,7 @@ struct GaPlan {
 static int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
 static bool ga_nj_ok(int nj) { return nj == 1 || nj == 2 || nj == 3 || nj == 4 || nj == 6 || nj == 8 || nj == 12 || nj == 16 || nj == 24; }
 
-static int ga_cus() {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-        if (n_cu <= 0) n_cu = 256;
-    }
-    return n_cu;
-}
+static int ga_cus() { return adalog_device_cus(); }   // per device ordinal (common.h)
 
 static GaPlan ga_plan(int T, int O, int K, int P) {
     GaPlan g{};

@@ -156,6 +156,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         self.w_quantizer.scale.data.copy_(scale)
         self.w_quantizer.zero_point.data.copy_(-mn.view(self.n_V, self.crb_rows, 1) / scale)
         self.w_quantizer.inited = True
+        self.invalidate_packed_weight()
 
     def _initialize_activation_scale(self):
         self.a_quantizer._zp_on_grid = False
@@ -192,11 +193,18 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
     def _w2(self):
         return self.weight.data.view(self.out_features, self.in_features)
 
+    def invalidate_packed_weight(self):
+        """Drop quant_forward's cached packed weight image (_pack_w_cached).  Called wherever the weight or its quantiser is
+        written through ``.data`` / a raw pointer -- writes that do not bump the Parameter's ``_version``, which the cache key
+        cannot see: _commit_w, the min/max initialisation, reparam(), BRECQ's hard-rounding commit."""
+        self.__dict__.pop("_wp_cache", None)
+
     def _commit_w(self, scale, zp):
         self.w_quantizer.scale.data.copy_(scale.view(self.n_V, self.crb_rows, 1))
         self.w_quantizer.zero_point.data.copy_(zp.view(self.n_V, self.crb_rows, 1))
         self.w_quantizer.inited = True
         self.w_quantizer._zp_on_grid = True          # zero point taken from an FPCS grid: inside [0, 2^bits - 1]
+        self.invalidate_packed_weight()
 
     def _commit_a(self, scale, zp):
         self.a_quantizer.scale.data.copy_(scale.view(self.a_quantizer.scale.shape))
@@ -277,8 +285,10 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
 
     def _pack_w_cached(self, dt=I8, want_rowsum=False):
         """_pack_w_fixed for quant_forward (linear.py:46-51 re-quantises the weight on every call): the packed image is a pure
-        function of (weight, scale, zero point), so it is kept until one of them changes -- storage address and in-place version
-        of each are the key (validate() runs thousands of forwards on unchanged weights)."""
+        function of (weight, scale, zero point), so it is kept until one of them changes (validate() runs thousands of forwards
+        on unchanged weights).  The key -- storage address, in-place version and shape of each -- catches re-assigned tensors and
+        autograd-visible in-place writes; writes through ``.data`` or a raw pointer do NOT bump ``_version``, so every such
+        site calls invalidate_packed_weight()."""
         wq = self.w_quantizer
         key = (dt, want_rowsum, wq.n_bits) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in (self.weight, wq.scale, wq.zero_point))
         hit = self.__dict__.get("_wp_cache")
@@ -378,7 +388,9 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         be = backend.get()
         aq, wq = self.a_quantizer, self.w_quantizer
         x2 = self._x2()
+        # (the weight image enters the build's int8 product as q - z: its zero point must lie on the grid, like _gram_state's)
         if (hasattr(be, "gram_act_ok") and type(aq) is UniformQuantizer and not aq.channel_wise and aq.scale.numel() == 1
+                and getattr(wq, "_zp_on_grid", False)
                 and be.gram_act_ok(x2.shape[0], self.out_features, self.in_features, aq.n_bits, wq.n_bits, self.eq_n)):
             prep = search.memo_tensor_fn("gact", self.raw_input, (), lambda: be.GramActPrepared(x2))
             st = be.GramActState(prep, self.raw_out.reshape(-1, self.out_features), None if self.bias is None else self.bias.data,
@@ -398,6 +410,10 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         be = backend.get()
         aq = self.a_quantizer
         if not hasattr(be, "gram_ok") or type(aq) is not UniformQuantizer or aq.channel_wise or aq.scale.numel() != 1:
+            return None
+        # gram.hip stores (q - z) as int8 and bounds G by T (2^b - 1)^2: that needs the zero point inside [0, 2^bits - 1], which
+        # only a committed FPCS grid point guarantees (a min/max initialisation still in force, or a loaded quantiser, may not)
+        if not getattr(aq, "_zp_on_grid", False):
             return None
         x2 = self._x2()
         if not be.gram_ok(x2.shape[0], self.out_features, self.in_features, aq.n_bits, self.w_quantizer.n_bits, self.eq_n):
@@ -524,6 +540,7 @@ class AsymmetricallyChannelWiseBatchingQuantLinear(AsymmetricallyBatchingQuantLi
         """linear.py:614-621."""
         with torch.no_grad():
             r, b, t_scale, t_zp = self.reparam_step1()
+            self.invalidate_packed_weight()
             self.raw_input = self.raw_input / r - b
             del self.a_quantizer.scale, self.a_quantizer.zero_point
             self.a_quantizer.channel_wise = False

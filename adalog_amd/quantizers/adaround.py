@@ -50,14 +50,13 @@ COLLECT = None                                                 # the AlphaCollec
 
 class _AdaRoundFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, w2, alpha2, scale, zero_point, n_bits, soft):
+    def forward(ctx, w2, alpha2, scale, zero_point, n_bits, soft, want_t=False):
         ctx.save_for_backward(w2, alpha2, scale, zero_point)
         ctx.n_bits, ctx.soft = n_bits, soft
         be = backend.get()
-        # (only where a BRECQ iteration will consume it: under no_grad -- evaluation after BRECQ -- or with the training
-        # contractions switched off, the extra transposed image would be written for nobody)
-        if (train_mm.W_KMAJOR and train_mm.ENABLED and torch.is_grad_enabled() and w2.is_cuda and alpha2.requires_grad
-                and hasattr(be, "adaround_t")):
+        # ``want_t`` is decided by the caller: autograd runs Function.forward with grad mode OFF, so torch.is_grad_enabled()
+        # read in here is always False (round 5 read it here and the K-major image was never written)
+        if want_t and w2.is_cuda and hasattr(be, "adaround_t"):
             # a BRECQ iteration: the same launch leaves the K-major image the layer's forward product reads (train_mm._kmajor)
             y, y_t = be.adaround_t(w2, alpha2, scale, zero_point, n_bits, soft)
             train_mm.offer_kmajor(y, y_t)
@@ -68,9 +67,9 @@ class _AdaRoundFn(torch.autograd.Function):
     def backward(ctx, gy):
         w2, alpha2, scale, zero_point = ctx.saved_tensors
         if COLLECT is not None and ctx.soft and COLLECT.take(alpha2, w2, gy):
-            return None, None, None, None, None, None          # the collector's launch computes and applies d/d alpha
+            return None, None, None, None, None, None, None    # the collector's launch computes and applies d/d alpha
         ga = backend.get().adaround(w2, alpha2, scale, zero_point, ctx.n_bits, ctx.soft, gy=gy.contiguous())
-        return None, ga, None, None, None, None
+        return None, ga, None, None, None, None, None
 
 
 class _RoundLossFn(torch.autograd.Function):
@@ -131,8 +130,11 @@ class AdaRoundQuantizer(nn.Module):
             raise ValueError('Wrong rounding mode')
         shp = x.shape
         self._w_last = self._rows(x).detach()                   # (the collector's launch reads the weights of a layer without gradient)
+        # the K-major image of w_sim is written only where a BRECQ iteration will consume it (train_mm._kmajor): under no_grad
+        # -- evaluation after BRECQ -- or with the training contractions switched off it would be written for nobody
+        want_t = bool(train_mm.W_KMAJOR and train_mm.ENABLED and torch.is_grad_enabled() and self.alpha.requires_grad)
         y = _AdaRoundFn.apply(self._w_last if not x.requires_grad else self._rows(x), self._rows(self.alpha), self.scale.view(-1),
-                              self.zero_point.view(-1), self.n_bits, bool(self.soft_targets))
+                              self.zero_point.view(-1), self.n_bits, bool(self.soft_targets), want_t)
         return y.view(shp)
 
     def get_soft_targets(self):

@@ -12,6 +12,7 @@ mini-batch is split over the ranks and the gradients of alpha / activation scale
 (RCCL over xGMI; identical seeds keep randperm in lock-step).
 """
 import logging
+import math
 import os
 
 import torch
@@ -250,6 +251,7 @@ class BlockReconstructor(QuantCalibrator):
             torch.backends.cuda.matmul.allow_tf32 = True
         graph, static_inp, static_out, static_rec, static_rnd = None, None, None, None, None
         b_dev = rw_dev = None
+        captured_now, collector = False, None
         params = w_params + a_params
 
         def optim_steps():
@@ -354,7 +356,19 @@ class BlockReconstructor(QuantCalibrator):
                             if collector is not None:
                                 collector.flush()            # d/d alpha of every layer and its Adam step: one launch
                             optim_steps()                    # (w_optimizer finds no gradient on the collected alphas)
+                    captured_now = True
                 graph.replay()                               # grads are overwritten, not accumulated (none existed at capture)
+                if full_graph:
+                    # the replay stepped the optimisers' DEVICE counters; keep HipAdam's host mirror (which decides chunk
+                    # membership and seeds new counters) in step: every trained tensor, except that in the capture iteration
+                    # step() itself already counted the tensors it saw a gradient on (all but the collected alphas)
+                    for opt, prms in ((w_optimizer, w_params), (a_optimizer, a_params)):
+                        if isinstance(opt, HipAdam):
+                            if not captured_now:
+                                opt.note_external_steps(prms)
+                            elif collector is not None and opt is w_optimizer:
+                                opt.note_external_steps(prms)
+                    captured_now = False
                 if not full_graph:
                     parallel.all_reduce_mean_bucket([prm.grad for prm in params if prm.grad is not None])
                     optim_steps()
@@ -463,7 +477,10 @@ class BlockReconstructor(QuantCalibrator):
     def _block_cost(block, shard_input):
         """tokens of the block's input (per image) x quantised weights it multiplies them with: what an iteration's contractions
         scale with; the same number on every rank (shapes only)."""
-        tokens = max(1, shard_input.numel() // max(1, shard_input.shape[0] * shard_input.shape[-1]))
+        # from the PER-IMAGE shape (shape[1:]): a shard's image count differs between ranks and an empty shard (shape[0] == 0) must
+        # not make its rank price the block differently -- the owner map has to be the same pure function everywhere
+        assert shard_input.dim() >= 2, "block input: [images, ..., features]"
+        tokens = max(1, int(math.prod(shard_input.shape[1:-1])) if shard_input.dim() > 2 else 1)
         weights = sum(m.weight.numel() for m in block.modules() if isinstance(m, (MinMaxQuantLinear, MinMaxQuantConv2d)))
         if isinstance(block, (MinMaxQuantLinear, MinMaxQuantConv2d)):
             weights = max(weights, block.weight.numel())

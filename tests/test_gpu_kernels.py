@@ -1416,15 +1416,36 @@ def test_brecq_iteration_runs_no_library_gemm():
     block, fblock = rec.blocks[name], rec.full_blocks[name]
     rec.init_block_raw_data(block, fblock, name, torch.device(DEV))
     os.environ["ADALOG_BRECQ_GRAPH"] = "0"
+    from adalog_amd import train_mm
+    taken = {"offers": 0, "hits": 0}
+    real_offer, real_kmajor = train_mm.offer_kmajor, train_mm._kmajor
+
+    def offer(w2, w2_t):
+        taken["offers"] += 1
+        return real_offer(w2, w2_t)
+
+    def kmajor(w2):
+        had = w2.data_ptr() in train_mm._KMAJOR_OFFER
+        out = real_kmajor(w2)
+        taken["hits"] += int(had and w2.data_ptr() not in train_mm._KMAJOR_OFFER and out.data_ptr() != w2.data_ptr())
+        return out
+
+    train_mm.offer_kmajor, train_mm._kmajor = offer, kmajor
     try:
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             rec.reconstruct_single_block(name, block, torch.device(DEV), batch_size=8, iters=3, quant_act=True)
             torch.cuda.synchronize()
     finally:
         os.environ.pop("ADALOG_BRECQ_GRAPH", None)
+        train_mm.offer_kmajor, train_mm._kmajor = real_offer, real_kmajor
     names = [e.key for e in prof.key_averages()]
     assert any("k_bq_gemm" in n for n in names), names
     assert not any(n.startswith("Cijk_") for n in names), [n for n in names if n.startswith("Cijk_")]
+    # the AdaRound forward of a training iteration leaves the K-major image of w_sim (k_adaround_t) and the layer's forward product
+    # takes it: round 5 read the grad mode INSIDE the autograd Function (always off there) and every layer paid a transposing copy
+    if train_mm.W_KMAJOR and train_mm.ENABLED:
+        assert any("k_adaround_t" in n for n in names), [n for n in names if "adaround" in n]
+        assert taken["offers"] >= 4 and taken["hits"] >= taken["offers"] - 1, taken
 
 
 @pytest.mark.parametrize("bits,dt_name", [(4, "fp8"), (3, "fp8"), (6, "i8")])
