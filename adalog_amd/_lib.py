@@ -57,6 +57,11 @@ SIGNATURES = {
     "adalog_finish_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "adalog_topk": (i32, [p, i32, i32, i32, p, p]),
     "adalog_topk_next": (i32, [p, i32, i32, i32, p, p, p, i32, p, p, i32, f32, p, p, p, p, p]),
+    "adalog_topk_next_tail": (i32, [p, i32, i32, p, p, p]),
+    "adalog_finish_topk_next_tail": (i32, [p, p, i32, i32, i32, i32, i32, i32, i32, i32, i32, f64, p, i64, p, p]),
+    "adalog_gram_score_w_tail": (i32, [p, i32, i32, i64, p, p, i32, i32, p, i32, i32, p, f64, p, p, p]),
+    "adalog_gram_act_score_tail": (i32, [p, p, i32, i32, i32, p, p, i32, i32, p, f64, p, p, p, p]),
+    "adalog_score_self_sorted_tail": (i32, [p, p, i64, i64, p, p, i32, i32, f64, p, p, p]),
     "adalog_fpcs_next": (i32, [p, p, p, i32, p, i32, i32, p, p, i32, f32, p, p, p, p]),
     "adalog_candidate_grid": (i32, [p, i32, i32, i32, i32, i32, p, i32, f32, p, p, p, p]),
     "adalog_score_w_self": (i32, [p, i32, i32, p, p, i32, i32, p, p]),
@@ -112,6 +117,13 @@ SIGNATURES = {
     "adalog_minmax_rows": (i32, [p, i32, i32, i32, p, p, p]),
     "adalog_absminmax_cols": (i32, [p, i64, i32, i32, p, p, p]),
 }
+
+class FpcsTail(C.Structure):
+    """adalog_fpcs_tail of include/adalog_hip.h: the ranking + next grid / commit step of an FPCS step as arguments"""
+    _fields_ = [("k", C.c_int32), ("new_cnt", C.c_int32), ("has_clamp", C.c_int32), ("clamp_min", C.c_float),
+                ("scale", p), ("zp", p), ("third", p), ("lin", p), ("delta_in", p), ("delta_out", p),
+                ("out_scale", p), ("out_zp", p), ("out_third", p)]
+
 
 _lib = None
 

@@ -784,6 +784,36 @@ unsigned int* ticket_wide(void* stream) {
     return rings[dev] + ((size_t)sub * WIDE + (next[dev][sub]++ % WIDE)) * TW_WORDS;
 }
 
+// Per-column tickets of the fused FPCS tails (fpcs_tail.h: one counter per output row / segment, up to 65 536 of them): a pool of
+// POOL_SLABS x 65 536 zeroed words per sub-ring, handed out round-robin like the small ring -- a launch's last arrivals put their
+// words back to zero, and a range comes round again only after POOL_SLABS later requests of the same stream, which run after it.
+constexpr int POOL_WORDS = 65536, POOL_SLABS = 4;
+unsigned int* ticket_pool(int n, void* stream) {
+    static unsigned int* pools[MAX_DEV] = {};
+    static unsigned next[MAX_DEV][SUB] = {};
+    static void* owner[MAX_DEV][SUB] = {};
+    static int owners[MAX_DEV] = {};
+    static std::mutex mu;
+    int dev = 0;
+    if (n < 1 || n > POOL_WORDS || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pools[dev]) {
+        unsigned int* p = nullptr;
+        const size_t bytes = (size_t)SUB * POOL_SLABS * POOL_WORDS * sizeof(unsigned int);
+        if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+            return nullptr;
+        pools[dev] = p;
+    }
+    int sub = -1;
+    for (int i = 0; i < owners[dev]; ++i)
+        if (owner[dev][i] == stream) { sub = i; break; }
+    if (sub < 0) {
+        if (owners[dev] < SUB) { sub = owners[dev]++; owner[dev][sub] = stream; }
+        else sub = SUB - 1;
+    }
+    return pools[dev] + ((size_t)sub * POOL_SLABS + (next[dev][sub]++ % POOL_SLABS)) * POOL_WORDS;
+}
+
 // lab switch (tools/lab/brecq_small_bench.py): cap on the blocks of the "last block finishes" reductions
 inline int red_cap(int dflt) {
     static const int v = getenv("ADALOG_RED_CAP") ? atoi(getenv("ADALOG_RED_CAP")) : 0;
@@ -804,11 +834,13 @@ inline int grid1(int64_t n, int cap = 2048) {
 extern "C" unsigned int* adalog_ticket_slot(void) { return ticket_slot(nullptr); }
 extern "C" unsigned int* adalog_ticket_slots(int n) { return ticket_slots(n, nullptr); }
 extern "C" unsigned int* adalog_ticket_slots_on(int n, void* stream) { return ticket_slots(n, stream); }
+extern "C" unsigned int* adalog_ticket_pool_on(int n, void* stream) { return n <= 64 ? ticket_slots(n, stream) : ticket_pool(n, stream); }
 
 // Allocates the current device's ticket ring (idempotent).  Call once per device before capturing BRECQ launches into a
 // HIP graph: the allocation synchronises the device, which would invalidate a capture in progress.
 extern "C" int adalog_brecq_init(void) {
-    ADALOG_ARG_CHECK(ticket_slot(nullptr) != nullptr && ticket_wide(nullptr) != nullptr, "brecq_init: cannot allocate the ticket counters");
+    ADALOG_ARG_CHECK(ticket_slot(nullptr) != nullptr && ticket_wide(nullptr) != nullptr && ticket_pool(65, nullptr) != nullptr,
+                     "brecq_init: cannot allocate the ticket counters");
     return 0;
 }
 

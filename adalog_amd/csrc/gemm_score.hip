@@ -27,6 +27,7 @@
 // All stage operands through LDS with a 16-byte-slot XOR swizzle (0 bank conflicts measured) and order workgroups so that
 // tiles sharing an operand run on one XCD (its L2).
 #include "common.h"
+#include "fpcs_tail.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -933,29 +934,21 @@ extern "C" int adalog_finish_scores(const float* partial, float* scores, int MT,
 // finish + top-k + next grid in one launch where the layout allows it (see gemm_finish.inc); otherwise adalog_finish_scores
 // followed by adalog_topk_next.  Arguments: those of adalog_finish_scores, then those of adalog_topk_next (scores [C][cols],
 // cols = (keep_h ? gmod : 1) * (keep_n ? N : 1)).  Single-GPU only: with several ranks the scores are all-reduced between the two.
-extern "C" int adalog_topk_next(const float* scores, int P, int cols, int k, const float* scale, const float* zp, const float* third,
-                                int new_cnt, const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale,
-                                float* out_zp, float* out_third, int* idx_out, void* stream);
+extern "C" int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream);
 
-extern "C" int adalog_finish_topk_next(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
-                                       int keep_h, int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes,
-                                       int k, const float* scale, const float* zp, const float* third, int new_cnt,
-                                       const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale,
-                                       float* out_zp, float* out_third, void* stream) {
-    ADALOG_ARG_CHECK(partial && scores && scale && out_scale && MT >= 1 && N >= 1 && Npad >= N && C >= 1 && C <= 256 && G >= 1 &&
-                     gmod >= 1 && G % gmod == 0 && k >= 1 && k <= C, "finish_topk_next: bad arguments");
-    ADALOG_ARG_CHECK(new_cnt == 0 || (lin && delta), "finish_topk_next: expansion needs lin and delta");
-    ADALOG_ARG_CHECK(new_cnt > 0 || k == 1, "finish_topk_next: the commit form takes k = 1");
-    ADALOG_ARG_CHECK((zp == nullptr) == (out_zp == nullptr) && (third == nullptr) == (out_third == nullptr),
-                     "finish_topk_next: in/out parameter planes must match");
+extern "C" int adalog_finish_topk_next_tail(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
+                                            int keep_h, int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes,
+                                            const adalog_fpcs_tail* tail, void* stream) {
+    ADALOG_ARG_CHECK(partial && scores && tail && MT >= 1 && N >= 1 && Npad >= N && C >= 1 && C <= 256 && G >= 1 &&
+                     gmod >= 1 && G % gmod == 0, "finish_topk_next: bad arguments");
+    const char* why = fpcs::tail_problem(tail, C);
+    ADALOG_ARG_CHECK(why == nullptr, why);
     static const int use_fused = getenv("ADALOG_FINISH_TOPK") ? atoi(getenv("ADALOG_FINISH_TOPK")) : 1;
     const int nh = keep_h ? gmod : 1, nn = keep_n ? N : 1, cols = nh * nn;
     FinishArgs p{};
     p.partial = partial; p.scores = scores; p.C = C; p.G = G; p.gmod = gmod; p.MT = MT; p.N = N; p.Npad = Npad;
     p.keep_h = keep_h; p.keep_n = keep_n; p.norm = norm; p.cin = cand_inner ? C : 0;
-    TopkArgs t{};
-    t.k = k; t.new_cnt = new_cnt; t.has_clamp = has_clamp; t.clamp_min = clamp_min; t.scale = scale; t.zp = zp; t.third = third;
-    t.lin = lin; t.delta = delta; t.o_scale = out_scale; t.o_zp = out_zp; t.o_third = out_third;
+    const TopkArgs t = *tail;
     hipStream_t st = (hipStream_t)stream;
     const bool c_ok = (C == 64 || C == 128 || C == 256);
     if (use_fused && cand_inner == 2 && !keep_n && c_ok && Npad == 256 && nh <= 64) {
@@ -977,6 +970,15 @@ extern "C" int adalog_finish_topk_next(const float* partial, float* scores, int 
     const int rc = adalog_finish_scores(partial, scores, MT, N, Npad, C, G, gmod, keep_h, keep_n, cand_inner, norm, workspace,
                                         workspace_bytes, stream);
     if (rc) return rc;
-    return adalog_topk_next(scores, C, cols, k, scale, zp, third, new_cnt, lin, delta, has_clamp, clamp_min, out_scale, out_zp,
-                            out_third, nullptr, stream);
+    return adalog_topk_next_tail(scores, C, cols, tail, nullptr, stream);
+}
+
+extern "C" int adalog_finish_topk_next(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod,
+                                       int keep_h, int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes,
+                                       int k, const float* scale, const float* zp, const float* third, int new_cnt,
+                                       const float* lin, float* delta, int has_clamp, float clamp_min, float* out_scale,
+                                       float* out_zp, float* out_third, void* stream) {
+    const adalog_fpcs_tail t{k, new_cnt, has_clamp, clamp_min, scale, zp, third, lin, delta, delta, out_scale, out_zp, out_third};
+    return adalog_finish_topk_next_tail(partial, scores, MT, N, Npad, C, G, gmod, keep_h, keep_n, cand_inner, norm, workspace,
+                                        workspace_bytes, &t, stream);
 }

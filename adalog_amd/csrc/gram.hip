@@ -35,6 +35,7 @@
 //                    the (row tile, limb) panels of G through an LDS ring shared by the workgroup's four waves:
 //                    12 MFMAs per panel and block, then sum_e acc[e] * w[e] over the lane's own 16 rows (v_mad_i32_i24).
 #include "common.h"
+#include "fpcs_tail.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -246,7 +247,11 @@ struct GramScoreArgs {
     float* scores;                             // [P][O]
     int nblk;                                  // O * P / 32
     long long* timeline;                       // lab only (tools/lab/gram_check.py): cycle stamps of wave 0 of each workgroup, else null
+    // the FPCS step's tail in the same launch (fpcs_tail.h): a ticket per output row; the wave that stores the last of a row's P / 32
+    // blocks ranks the row's P scores and writes its next grid / commits its winner (after its last pass: no other wave waits for it)
+    int has_tail; fpcs::Tail tail; unsigned int* tickets;
 };
+constexpr int GRAM_PEND = 63;                  // rows a wave may have waiting for their tail (the host checks the plan against it)
 
 // One pass of a wave over NB (<= CB) blocks of 32 candidates; every wave of the workgroup runs the same panel sequence (NB = 0: it
 // only helps moving the panels).  Two workgroups share a CU and run unsynchronised: one's row dots (VALU) issue under the other's MFMAs.
@@ -255,7 +260,8 @@ struct GramScoreArgs {
 // the K chunks [COOP NJ/4, (COOP + 1) NJ/4).  The row dot is linear in the accumulators, so each wave applies it to its partial
 // products and only the per-candidate sums (quad, lin) are added across the waves at the end.
 template <int NJ, int NB, bool BIG, bool TIE, int COOP = -1>
-__device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, int blk0, int w, int lane, float sa, int stamp_slot) {
+__device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, int blk0, int w, int lane, float sa, int stamp_slot,
+                                          int* pend) {
     constexpr bool CO = COOP >= 0;
     constexpr int QN = CO ? NJ / 4 : NJ;                   // K chunks this wave multiplies
     constexpr int J0 = CO ? COOP * (NJ / 4) : 0;           // ... starting here
@@ -487,8 +493,20 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
             const double tot = p.s0[o] - 2.0 * s * (lin[b] * p.cscl[o]) + s * s * q;
             const int blk = blk0 + b;
             const int cand = (blk - o * PB) * 32 + c;
-            if (h == 0) p.scores[(int64_t)cand * p.O + o] = (float)(-p.norm * tot);
+            if (h == 0) {
+                if (p.has_tail) fpcs::score_publish(p.scores + (int64_t)cand * p.O + o, (float)(-p.norm * tot));
+                else p.scores[(int64_t)cand * p.O + o] = (float)(-p.norm * tot);
+            }
         });
+        if (p.has_tail) {
+            fpcs::publish_wait();                           // this wave's scores are at the coherence point: draw the rows' tickets
+            if (lane == 0) {                                // rows this wave completed wait in its LDS list (pend[0] = how many)
+                static_for<NB>([&](auto bc) {
+                    const int o = orow[decltype(bc)::value];
+                    if (fpcs::ticket_last(p.tickets + o, (unsigned)PB)) { const int n = pend[0]; pend[1 + n] = o; pend[0] = n + 1; }
+                });
+            }
+        }
     }
     GRAM_STAMP(4);
 #undef GRAM_STAMP
@@ -503,6 +521,11 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
     const int nwg = gridDim.x;
     const int b_begin = (int)(((int64_t)p.nblk * blockIdx.x) / nwg), b_end = (int)(((int64_t)p.nblk * (blockIdx.x + 1)) / nwg);
     const float sa = p.sa[0];
+    __shared__ float tail_s_all[4][256];
+    __shared__ int tail_top_all[4][32];
+    __shared__ int pend_all[4][GRAM_PEND + 1];
+    int* pend = pend_all[w];
+    if (lane == 0) pend[0] = 0;
     int pass_no = 0;
     for (int pass0 = b_begin; pass0 < b_end; pass0 += 4 * CB, ++pass_no) {
         const int n = min(4 * CB, b_end - pass0);
@@ -514,10 +537,10 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
             if (n <= CB) {                                 // the thin tail: all four waves on the same n blocks, K split four ways
 #define GRAM_COOP(NBV)                                                                                            \
                 do {                                                                                              \
-                    if (w == 0) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 0>(p, lds, pass0, w, lane, sa, slot);     \
-                    else if (w == 1) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 1>(p, lds, pass0, w, lane, sa, slot); \
-                    else if (w == 2) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 2>(p, lds, pass0, w, lane, sa, slot); \
-                    else gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 3>(p, lds, pass0, w, lane, sa, slot);            \
+                    if (w == 0) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 0>(p, lds, pass0, w, lane, sa, slot, pend);     \
+                    else if (w == 1) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 1>(p, lds, pass0, w, lane, sa, slot, pend); \
+                    else if (w == 2) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 2>(p, lds, pass0, w, lane, sa, slot, pend); \
+                    else gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 3>(p, lds, pass0, w, lane, sa, slot, pend);            \
                 } while (0)
                 if (n == 1) GRAM_COOP(1);
                 else if (CB >= 2 && n == 2) GRAM_COOP((CB >= 2 ? 2 : 1));
@@ -529,11 +552,20 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
         }
         const int nbw = n / 4 + (w < (n & 3) ? 1 : 0);     // this wave's blocks (wave-uniform)
         const int blk0 = pass0 + w * (n / 4) + min(w, n & 3);
-        if (nbw == CB) gram_pass<NJ, CB, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
-        else if (nbw == 0) gram_pass<NJ, 0, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
-        else if (nbw == 1) gram_pass<NJ, 1, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
-        else if (CB > 2 && nbw == 2) gram_pass<NJ, (CB > 2 ? 2 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
-        else if (CB > 3 && nbw == 3) gram_pass<NJ, (CB > 3 ? 3 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        if (nbw == CB) gram_pass<NJ, CB, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
+        else if (nbw == 0) gram_pass<NJ, 0, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
+        else if (nbw == 1) gram_pass<NJ, 1, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
+        else if (CB > 2 && nbw == 2) gram_pass<NJ, (CB > 2 ? 2 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
+        else if (CB > 3 && nbw == 3) gram_pass<NJ, (CB > 3 ? 3 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
+    }
+    if (p.has_tail) {                                       // the rows this wave completed: rank, next grid / commit (fpcs_tail.h)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int npend = __builtin_amdgcn_readfirstlane(pend[0]);
+#pragma unroll 1
+        for (int i = 0; i < npend; ++i)
+            fpcs::column<64, true>(p.scores, p.P, p.O, __builtin_amdgcn_readfirstlane(pend[1 + i]), lane, p.tail, tail_s_all[w], tail_top_all[w]);
     }
 #endif
 }
@@ -683,9 +715,17 @@ static int device_cus_gram() { return adalog_device_cus(); }   // per device ord
 
 /* One FPCS step: scores [P][O] = -norm * sum_t (raw_out - b - q_a(x) . fq_p(W)^T)^2 for the P candidates (scale, zp) [P][O] of every
  * output row, from the workspace adalog_gram_build left.  W fp32 [O][ldw].  (T, O, K, a_bits) must be those of the build. */
-extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
-                                   const void* ws, int T, int a_bits, const float* sa, double norm, float* scores, void* stream) {
+extern "C" int adalog_gram_score_w_tail(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
+                                        const void* ws, int T, int a_bits, const float* sa, double norm, float* scores,
+                                        const adalog_fpcs_tail* tail, void* stream) {
     ADALOG_ARG_CHECK(W && scale && zp && ws && sa && scores, "gram_score_w: null pointer");
+    const char* why = fpcs::tail_problem(tail, P);
+    ADALOG_ARG_CHECK(why == nullptr, why);
+    ADALOG_ARG_CHECK(!tail || (tail->k <= 32 && O <= 65536), "gram_score_w: the fused tail takes k <= 32, O <= 65536");
+    // a wave lists the rows it completed (GRAM_PEND entries): at most one per block it stores, <= ceil(blocks per workgroup / 4) + 2 passes' worth
+    ADALOG_ARG_CHECK(!tail || ((int64_t)O * P / 32 + 255) / 256 / 4 + 8 <= GRAM_PEND, "gram_score_w: too many blocks per wave for the fused tail");
+    unsigned int* tickets = tail ? adalog_ticket_pool_on(O, stream) : nullptr;
+    ADALOG_ARG_CHECK(!tail || tickets, "gram_score_w: no ticket counters");
     ADALOG_ARG_CHECK(adalog_gram_supported(T, O, K, a_bits, w_bits, P), "gram_score_w: shape not supported (adalog_gram_supported)");
     ADALOG_ARG_CHECK(ldw >= K && ldw % 4 == 0 && ((uintptr_t)W & 15) == 0, "gram_score_w: weight rows must be 16-byte aligned");
     const GramPlan g = gram_plan(T, O, K, a_bits);
@@ -696,6 +736,8 @@ extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, co
     a.gfrag = (const int8_t*)(base + g.off_gfrag); a.NL = g.NL; a.clim = (const int8_t*)(base + g.off_clim);
     a.s0 = (const double*)(base + g.off_s0); a.cscl = (const double*)(base + g.off_cscl);
     a.sa = sa; a.norm = norm; a.scores = scores;
+    a.has_tail = tail ? 1 : 0; a.tickets = tickets;
+    if (tail) a.tail = *tail;
     a.qmax = (float)((1 << w_bits) - 1);
     const float zone = 6e-7f * (float)(1 << w_bits);
     a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
@@ -732,4 +774,9 @@ extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, co
 #undef GRAM_LAUNCH
     ADALOG_LAUNCH_CHECK("adalog_gram_score_w");
     return 0;
+}
+
+extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
+                                   const void* ws, int T, int a_bits, const float* sa, double norm, float* scores, void* stream) {
+    return adalog_gram_score_w_tail(W, O, K, ldw, scale, zp, P, w_bits, ws, T, a_bits, sa, norm, scores, nullptr, stream);
 }

@@ -36,6 +36,7 @@
 //                    at the end contracts its accumulators with H
 //   k_ga_finish      per candidate: run boundaries by bisection on the sorted activation -> linear term; score
 #include "common.h"
+#include "fpcs_tail.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <utility>
@@ -762,10 +763,11 @@ template <int G>
 __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sorted, const double* __restrict__ prefix, int64_t n,
                                                    const float* __restrict__ scale, const float* __restrict__ zp, int P, float qmax,
                                                    const double* __restrict__ qpart, int S, const double* __restrict__ s0, double norm,
-                                                   float* __restrict__ scores) {
+                                                   float* __restrict__ scores, int has_tail, fpcs::Tail tail, unsigned int* ticket) {
     constexpr int GPB = 256 / G;
     __shared__ int64_t bnd[GPB][G + 1];
     __shared__ double red[256];
+    __shared__ int is_last;
     const int gi = threadIdx.x / G, t = threadIdx.x % G;
     const int cand = blockIdx.x * GPB + gi;
     const bool live = cand < P;
@@ -811,8 +813,20 @@ __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sor
     }
     if (live && t == 0) {
         const double sd = (double)s;
-        scores[cand] = (float)(-norm * (s0v - 2.0 * sd * red[threadIdx.x] + sd * sd * quad));
+        const float v = (float)(-norm * (s0v - 2.0 * sd * red[threadIdx.x] + sd * sd * quad));
+        if (has_tail) { fpcs::score_publish(scores + cand, v); fpcs::publish_wait(); }
+        else scores[cand] = v;
     }
+    if (!has_tail) return;
+    // the FPCS step's tail in the same launch (fpcs_tail.h): the last of the launch's blocks ranks the P scores of the one column
+    // and writes the next grid / the committed winner
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = fpcs::ticket_last(ticket, gridDim.x) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    float* sc = reinterpret_cast<float*>(red);                 // 256 floats + 256 ints of the dead reduction buffer
+    int* top = reinterpret_cast<int*>(red) + 256;
+    fpcs::column<256, false>(scores, P, 1, 0, (int)threadIdx.x, tail, sc, top);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -986,9 +1000,16 @@ extern "C" int adalog_gram_act_splits(int T, int O, int K, int P) {
 static long long* g_ga_timeline = nullptr;
 extern "C" void adalog_gram_act_set_timeline(long long* buf) { g_ga_timeline = buf; }   // lab only
 
-extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T, int O, int K, const float* scale, const float* zp, int P,
-                                     int a_bits, const void* ws, double norm, double* qpart, float* scores, void* stream) {
+// `tail` (may be null): the FPCS step's ranking + next grid / commit in the finish kernel's last block (fpcs_tail.h); scale / zp of the
+// tail are the candidates scored here ([P][1]).
+extern "C" int adalog_gram_act_score_tail(const float* xt, const float* sorted, int T, int O, int K, const float* scale, const float* zp, int P,
+                                          int a_bits, const void* ws, double norm, double* qpart, float* scores,
+                                          const adalog_fpcs_tail* tail, void* stream) {
     ADALOG_ARG_CHECK(xt && sorted && scale && zp && ws && qpart && scores, "gram_act_score: null pointer");
+    const char* why = fpcs::tail_problem(tail, P);
+    ADALOG_ARG_CHECK(why == nullptr, why);
+    unsigned int* ticket = tail ? adalog_ticket_pool_on(1, stream) : nullptr;
+    ADALOG_ARG_CHECK(!tail || ticket, "gram_act_score: no ticket counter");
     ADALOG_ARG_CHECK(adalog_gram_act_supported(T, O, K, a_bits, a_bits, P), "gram_act_score: shape not supported (adalog_gram_act_supported)");
     const GaPlan g = ga_plan(T, O, K, P);
     const uint8_t* base = (const uint8_t*)ws;
@@ -1035,7 +1056,8 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
     const int G = 1 << a_bits;
     const int gpb = 256 / G;
     const unsigned blocks = (unsigned)((P + gpb - 1) / gpb);
-#define GA_FIN(GV) hipLaunchKernelGGL((k_ga_finish<GV>), dim3(blocks), dim3(256), 0, st, sorted, prefix, g.n, scale, zp, P, a.qmax, qpart, g.QS, s0, norm, scores)
+    const fpcs::Tail tl = tail ? *tail : fpcs::Tail{};
+#define GA_FIN(GV) hipLaunchKernelGGL((k_ga_finish<GV>), dim3(blocks), dim3(256), 0, st, sorted, prefix, g.n, scale, zp, P, a.qmax, qpart, g.QS, s0, norm, scores, tail ? 1 : 0, tl, ticket)
     switch (a_bits) {
         case 2: GA_FIN(4); break;
         case 3: GA_FIN(8); break;
@@ -1047,4 +1069,9 @@ extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T
 #undef GA_FIN
     ADALOG_LAUNCH_CHECK("adalog_gram_act_score");
     return 0;
+}
+
+extern "C" int adalog_gram_act_score(const float* xt, const float* sorted, int T, int O, int K, const float* scale, const float* zp, int P,
+                                     int a_bits, const void* ws, double norm, double* qpart, float* scores, void* stream) {
+    return adalog_gram_act_score_tail(xt, sorted, T, O, K, scale, zp, P, a_bits, ws, norm, qpart, scores, nullptr, stream);
 }

@@ -6,6 +6,7 @@
 // Candidate tensors live on the device as fp32 [P][cols] (candidate-major), so one FPCS call is a chain of
 // launches on one stream with no host synchronisation; the winner is committed by the kernel itself.
 #include "common.h"
+#include "fpcs_tail.h"
 
 namespace {
 
@@ -74,60 +75,16 @@ __global__ __launch_bounds__(256) void k_fpcs_next(const float* __restrict__ sca
 }
 
 // top-k and the next grid in ONE launch (every FPCS step needs both, and each is a 5-10 us launch for microseconds of
-// work): one workgroup per column ranks its P <= 256 candidates in LDS (same deterministic order as k_topk), then the
-// same workgroup gathers the k survivors and writes the k * new_cnt grid points of its column (or commits the winner).
-__global__ __launch_bounds__(256) void k_topk_next(const float* __restrict__ scores, int P, int cols, int k,
-                                                   const float* __restrict__ scale, const float* __restrict__ zp,
-                                                   const float* __restrict__ third, int new_cnt,
-                                                   const float* __restrict__ lin, float* __restrict__ delta, float clamp_min,
-                                                   int has_clamp, float* __restrict__ o_scale, float* __restrict__ o_zp,
-                                                   float* __restrict__ o_third, int* __restrict__ idx_out) {
+// work): one workgroup per column ranks its P <= 256 candidates in LDS (deterministic order of k_topk), then the same workgroup
+// gathers the k survivors and writes the k * new_cnt grid points of its column (or commits the winner) -- fpcs_tail.h, the
+// code the scoring kernels run themselves where they produce final scores.
+__global__ __launch_bounds__(256) void k_topk_next(const float* __restrict__ scores, int P, int cols, fpcs::Tail t,
+                                                   int* __restrict__ idx_out) {
     __shared__ float s[256];
     __shared__ int top[256];
-    const int col = blockIdx.x, p = threadIdx.x;
-    if (p < P) s[p] = scores[(int64_t)p * cols + col];
-    __syncthreads();
-    if (p < P) {
-        const float me = s[p];
-        const bool me_nan = me != me;
-        int rank = 0;
-        for (int j = 0; j < P; ++j) {
-            const float o = s[j];
-            const bool o_nan = o != o;
-            bool before;
-            if (o_nan || me_nan) before = (o_nan && !me_nan) || (o_nan && me_nan && j < p);
-            else before = (o > me) || (o == me && j < p);
-            rank += before ? 1 : 0;
-        }
-        if (rank < k) {
-            top[rank] = p;
-            if (idx_out) idx_out[(int64_t)rank * cols + col] = p;
-        }
-    }
-    __syncthreads();
-    if (new_cnt == 0) {                                   // commit (topk == 1 branch, linear.py:387-391)
-        if (p == 0) {
-            const int w = top[0];
-            o_scale[col] = scale[(int64_t)w * cols + col];
-            if (zp) o_zp[col] = zp[(int64_t)w * cols + col];
-            if (third) o_third[col] = third[(int64_t)w * cols + col];
-        }
-        return;
-    }
-    const float d = delta[col];
-    const int total = k * new_cnt;
-    for (int o = p; o < total; o += 256) {
-        const int j = o / new_cnt, i = o - j * new_cnt;
-        const int w = top[j];
-        float v = scale[(int64_t)w * cols + col] + (lin[i] - 0.5f) * d;     // linear.py:492-495
-        if (has_clamp) v = fmaxf(v, clamp_min);                             // linear.py:516
-        const int64_t oo = (int64_t)o * cols + col;
-        o_scale[oo] = v;
-        if (zp) o_zp[oo] = zp[(int64_t)w * cols + col];
-        if (third) o_third[oo] = third[(int64_t)w * cols + col];
-    }
-    __syncthreads();                                          // every thread has read delta
-    if (p == 0) delta[col] = d / ((float)new_cnt - 0.5f);     // linear.py:493
+    const int col = blockIdx.x;
+    fpcs::column<256, false>(scores, P, cols, col, (int)threadIdx.x, t, s, top);
+    if (idx_out && (int)threadIdx.x < t.k) idx_out[(int64_t)threadIdx.x * cols + col] = top[threadIdx.x];
 }
 
 // initial percentile grid: quant = [4][cols] = {Q_hi0, Q_hi1, Q_lo0, Q_lo1} (e.g. Q.9, Q1.0, Q.1, Q0)
@@ -292,19 +249,20 @@ extern "C" int adalog_fpcs_next(const float* scale, const float* zp, const float
     return 0;
 }
 
+extern "C" int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream) {
+    ADALOG_ARG_CHECK(scores && tail && P >= 1 && P <= 256 && cols >= 1, "topk_next: bad arguments (P <= 256)");
+    const char* why = fpcs::tail_problem(tail, P);
+    ADALOG_ARG_CHECK(why == nullptr, why);
+    hipLaunchKernelGGL(k_topk_next, dim3(cols), dim3(256), 0, (hipStream_t)stream, scores, P, cols, *tail, idx_out);
+    ADALOG_LAUNCH_CHECK("adalog_topk_next");
+    return 0;
+}
+
 extern "C" int adalog_topk_next(const float* scores, int P, int cols, int k, const float* scale, const float* zp,
                                 const float* third, int new_cnt, const float* lin, float* delta, int has_clamp,
                                 float clamp_min, float* out_scale, float* out_zp, float* out_third, int* idx_out, void* stream) {
-    ADALOG_ARG_CHECK(scores && scale && out_scale && P >= 1 && P <= 256 && cols >= 1 && k >= 1 && k <= P,
-                     "topk_next: bad arguments (P <= 256, 1 <= k <= P)");
-    ADALOG_ARG_CHECK(new_cnt == 0 || (lin && delta), "topk_next: expansion needs lin and delta");
-    ADALOG_ARG_CHECK(new_cnt > 0 || k == 1, "topk_next: the commit form takes k = 1");
-    ADALOG_ARG_CHECK((zp == nullptr) == (out_zp == nullptr) && (third == nullptr) == (out_third == nullptr),
-                     "topk_next: in/out parameter planes must match");
-    hipLaunchKernelGGL(k_topk_next, dim3(cols), dim3(256), 0, (hipStream_t)stream, scores, P, cols, k, scale, zp, third,
-                       new_cnt, lin, delta, clamp_min, has_clamp, out_scale, out_zp, out_third, idx_out);
-    ADALOG_LAUNCH_CHECK("adalog_topk_next");
-    return 0;
+    const adalog_fpcs_tail t{k, new_cnt, has_clamp, clamp_min, scale, zp, third, lin, delta, delta, out_scale, out_zp, out_third};
+    return adalog_topk_next_tail(scores, P, cols, &t, idx_out, stream);
 }
 
 extern "C" int adalog_candidate_grid(const float* quant4, int cols, int num_scale, int num_zp, int zp_min, int n_bits,

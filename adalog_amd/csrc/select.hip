@@ -8,6 +8,8 @@
 //   pos = q*(n-1);  v = lerp(sorted[floor(pos)], sorted[ceil(pos)], pos - floor(pos))        
 // and, for per-tensor activations above 2**24 elements, the reference's mean over chunk quantiles.
 #include "common.h"
+#include "fpcs_tail.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -116,6 +118,162 @@ __global__ __launch_bounds__(256) void k_sel_pick(SelState* st, unsigned* hist, 
     if (lane == 0) st[i] = s;
 }
 
+// The descent of k_sel_pick as a device function of ONE wavefront over a 256-bin histogram held in four values per lane (bins
+// 4 lane .. 4 lane + 3), wherever it was read from (LDS: the one-block-per-segment kernel; global memory at agent scope: the last
+// block of a segment in k_sel_hist_pick).
+__device__ __forceinline__ SelState pick_wave(uint4 c, SelState s, int pass, int positive_only, float qf, int lane) {
+    const int64_t own = (int64_t)c.x + c.y + c.z + c.w;
+    int64_t incl = own;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int64_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    const int64_t total = __shfl(incl, 63);
+    if (pass == 0 && positive_only) {                      // (see k_sel_pick: linear.py:785-790 and the > 2^24 positives quirk)
+        const float cq = ceilf((float)total * qf);
+        const int64_t rk = (int64_t)cq - 1;
+        s.remaining = (total == 0 || rk >= total) ? -1 : (rk < 0 ? 0 : rk);
+    }
+    if (s.remaining >= 0) {
+        const unsigned long long hit = __ballot(incl > s.remaining);
+        int b = 255;
+        int64_t cum = total;
+        if (hit) {
+            const int fl = __ffsll(hit) - 1;
+            const int64_t excl = __shfl(incl - own, fl);
+            const unsigned cx = __shfl(c.x, fl), cy = __shfl(c.y, fl), cz = __shfl(c.z, fl);
+            cum = excl; b = 4 * fl;
+            if (cum + cx <= s.remaining) { cum += cx; ++b;
+                if (cum + cy <= s.remaining) { cum += cy; ++b;
+                    if (cum + cz <= s.remaining) { cum += cz; ++b; } } }
+        }
+        s.prefix = (s.prefix << 8) | (unsigned)b;
+        s.remaining -= cum;
+    }
+    return s;
+}
+
+// ATen lerp (vectorised CPU form): weight < 0.5 ? fma(w, b-a, a) : fma(w-1, b-a, b)
+__device__ __forceinline__ float aten_lerp(float a, float b, float wt) {
+    const float d = b - a;
+    return (fabsf(wt) < 0.5f) ? fmaf(wt, d, a) : fmaf(wt - 1.0f, d, b);
+}
+
+// ONE launch for a whole select (round 6): a workgroup per segment walks its row four times (the row is L2-resident after the first
+// pass), histograms into LDS, its waves descend the R states, and it writes the segment's outputs -- 11 launches (memset, init, 4 x
+// (count, pick), output) before.  For many short segments (weight rows: n = K) and for per-channel activations (S = channels, n =
+// tokens: S blocks fill the chip).  mode 0: quantiles out[j][seg] = lerp(v[2 j], v[2 j + 1], w[j]) (mbs == 1); mode 1: order
+// statistics out[r][seg] (0 where nothing was selected).
+__global__ __launch_bounds__(256) void k_sel_one_block(const float* __restrict__ x, int64_t n, int S, int R, const int64_t* __restrict__ ranks,
+                                                       const float* __restrict__ qfrac, int positive_only, int mode, int nq,
+                                                       const float* __restrict__ w, float* __restrict__ out) {
+    __shared__ unsigned h[MAXR][256];
+    __shared__ SelState sst[MAXR];
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < R) { sst[tid].prefix = 0; sst[tid].remaining = ranks ? ranks[tid] : 0; }
+    const float* xs = x + (int64_t)seg * n;
+    for (int pass = 0; pass < 4; ++pass) {
+        for (int i = tid; i < R * 256; i += 256) (&h[0][0])[i] = 0;
+        __syncthreads();
+        const int shift = 24 - 8 * pass;
+        uint32_t pre[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) pre[r] = r < R ? sst[r].prefix : 0xffffffffu;
+        for (int64_t i = tid; i < n; i += 256) {
+            const float v = xs[i];
+            if (positive_only && !(v > 0.0f)) continue;
+            const uint32_t key = f2key(v);
+            const unsigned bin = (key >> shift) & 255u;
+            if (pass == 0) {
+                atomicAdd(&h[0][bin], 1u);
+            } else {
+                const uint32_t hi = key >> (shift + 8);
+#pragma unroll
+                for (int r = 0; r < MAXR; ++r)
+                    if (r < R && hi == pre[r]) atomicAdd(&h[r][bin], 1u);
+            }
+        }
+        __syncthreads();
+        for (int r = wv; r < R; r += 4) {
+            const unsigned* hp = pass == 0 ? h[0] : h[r];
+            const uint4 c = make_uint4(hp[4 * lane], hp[4 * lane + 1], hp[4 * lane + 2], hp[4 * lane + 3]);
+            const SelState s2 = pick_wave(c, sst[r], pass, positive_only, qfrac ? qfrac[r] : 0.0f, lane);
+            if (lane == 0) sst[r] = s2;
+        }
+        __syncthreads();
+    }
+    if (mode == 0) {
+        if (tid < nq) out[(int64_t)tid * S + seg] = aten_lerp(key2f(sst[2 * tid].prefix), key2f(sst[2 * tid + 1].prefix), w[tid]);
+    } else {
+        if (tid < R) out[(int64_t)tid * S + seg] = sst[tid].remaining < 0 ? 0.0f : key2f(sst[tid].prefix);
+    }
+}
+
+// hist + state initialisation in one launch (a memset and k_sel_init before)
+__global__ __launch_bounds__(256) void k_sel_clear(unsigned* __restrict__ hist, int64_t words, SelState* st, const int64_t* ranks, int nsr, int R) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) hist[i] = 0u;
+    if (i < nsr) { st[i].prefix = 0; st[i].remaining = ranks ? ranks[i % R] : 0; }
+}
+
+// k_sel_hist with the pick folded in (single process): the last of a segment's blocks -- a ticket per segment -- descends the
+// segment's R states from the finished global histogram and clears it for the next pass.
+__global__ __launch_bounds__(256) void k_sel_hist_pick(const float* __restrict__ x, int64_t n, int R, int pass, SelState* st,
+                                                       unsigned* __restrict__ hist, int positive_only,
+                                                       const float* __restrict__ qfrac, unsigned int* tickets) {
+    __shared__ unsigned h[MAXR][256];
+    __shared__ uint32_t pre[MAXR];
+    __shared__ int is_last;
+    const int seg = blockIdx.y;
+    for (int i = threadIdx.x; i < R * 256; i += blockDim.x) (&h[0][0])[i] = 0;
+    if ((int)threadIdx.x < R) pre[threadIdx.x] = st[seg * R + threadIdx.x].prefix;
+    __syncthreads();
+    const int shift = 24 - 8 * pass;
+    const float* xs = x + (int64_t)seg * n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = xs[i];
+        if (positive_only && !(v > 0.0f)) continue;
+        const uint32_t key = f2key(v);
+        const unsigned bin = (key >> shift) & 255u;
+        if (pass == 0) {
+            atomicAdd(&h[0][bin], 1u);
+        } else {
+            const uint32_t hi = key >> (shift + 8);
+            for (int r = 0; r < R; ++r)
+                if (hi == pre[r]) atomicAdd(&h[r][bin], 1u);
+        }
+    }
+    __syncthreads();
+    unsigned* gh = hist + ((int64_t)seg * R) * 256;
+    for (int i = threadIdx.x; i < R * 256; i += blockDim.x) {
+        const unsigned c = pass == 0 ? h[0][i & 255] : (&h[0][0])[i];
+        if (c) __hip_atomic_fetch_add(gh + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __threadfence();                                       // this block's counts are visible device-wide before its ticket is drawn
+    fpcs::publish_wait();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = fpcs::ticket_last(tickets + seg, gridDim.x) ? 1 : 0;
+    __syncthreads();
+    if (!is_last) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = wv; r < R; r += 4) {
+        unsigned* hp = gh + r * 256 + 4 * lane;
+        uint4 c;
+        c.x = __hip_atomic_load(hp + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(hp + 3, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int i = seg * R + r;
+        const SelState s2 = pick_wave(c, st[i], pass, positive_only, qfrac ? qfrac[r] : 0.0f, lane);
+        if (lane == 0) st[i] = s2;
+    }
+}
+
 // quantile mode: out[j][col] = mean over the mbs chunk rows of lerp(v[2j], v[2j+1], w[j]);  R = 2*nq
 __global__ __launch_bounds__(256) void k_sel_quantile_out(const SelState* __restrict__ st, int R, int nq,
                                                           const float* __restrict__ w, int cols, int mbs,
@@ -145,22 +303,39 @@ __global__ __launch_bounds__(256) void k_sel_value_out(const SelState* __restric
     out[(int64_t)r * S + seg] = st[i].remaining < 0 ? 0.0f : key2f(st[i].prefix);
 }
 
+// A select that one launch finishes: a workgroup per segment (k_sel_one_block).  Taken when the segments alone fill the chip or the rows
+// are short; mbs == 1 only (the chunk mean runs over several segments).
+static bool one_block_ok(int64_t S, int64_t n, int mbs) {
+    static const int off = getenv("ADALOG_SEL_ONE_BLOCK") ? atoi(getenv("ADALOG_SEL_ONE_BLOCK")) : 1;
+    return off != 0 && mbs == 1 && (n <= 16384 || (S >= 256 && n <= 65536));
+}
+
 int run_select(const float* x, int64_t S, int64_t n, int R, const int64_t* d_ranks, const float* d_qfrac,
                int positive_only, SelState* st, unsigned* hist, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned) * S * R * 256, stream);
-    if (e != hipSuccess) { adalog_set_error("select/memset", e); return (int)e; }
     const int nsr = (int)(S * R);
-    hipLaunchKernelGGL(k_sel_init, dim3(cdiv(nsr, 256)), dim3(256), 0, stream, st, d_ranks, (int)S, R);
+    const int64_t words = (int64_t)nsr * 256;
     int64_t bps = (n + 256 * 16 - 1) / (256 * 16);
     if (bps > 512) bps = 512;
     if (bps < 1) bps = 1;
     while (bps * S > 65535LL * 16 && bps > 1) bps /= 2;
-    for (int pass = 0; pass < 4; ++pass) {
-        hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)bps, (unsigned)S), dim3(256), 0, stream, x, n, R, pass, st, hist,
-                           positive_only, 0, 1, 1);
-        hipLaunchKernelGGL(k_sel_pick, dim3(cdiv(nsr, 4)), dim3(256), 0, stream, st, hist, (int)S, R, pass, d_qfrac,
-                           positive_only);
+    unsigned int* tickets = adalog_ticket_pool_on((int)S, stream);     // S <= 65535 (checked by the callers)
+    static const int fused = getenv("ADALOG_SEL_FUSED") ? atoi(getenv("ADALOG_SEL_FUSED")) : 1;
+    if (!tickets || !fused) {                              // the separate launches (also the sharded form's building blocks)
+        hipError_t e = hipMemsetAsync(hist, 0, sizeof(unsigned) * words, stream);
+        if (e != hipSuccess) { adalog_set_error("select/memset", e); return (int)e; }
+        hipLaunchKernelGGL(k_sel_init, dim3(cdiv(nsr, 256)), dim3(256), 0, stream, st, d_ranks, (int)S, R);
+        for (int pass = 0; pass < 4; ++pass) {
+            hipLaunchKernelGGL(k_sel_hist, dim3((unsigned)bps, (unsigned)S), dim3(256), 0, stream, x, n, R, pass, st, hist,
+                               positive_only, 0, 1, 1);
+            hipLaunchKernelGGL(k_sel_pick, dim3(cdiv(nsr, 4)), dim3(256), 0, stream, st, hist, (int)S, R, pass, d_qfrac,
+                               positive_only);
+        }
+        return 0;
     }
+    hipLaunchKernelGGL(k_sel_clear, dim3(cdiv(words, 256)), dim3(256), 0, stream, hist, words, st, d_ranks, nsr, R);
+    for (int pass = 0; pass < 4; ++pass)
+        hipLaunchKernelGGL(k_sel_hist_pick, dim3((unsigned)bps, (unsigned)S), dim3(256), 0, stream, x, n, R, pass, st, hist,
+                           positive_only, d_qfrac, tickets);
     return 0;
 }
 
@@ -181,6 +356,11 @@ extern "C" int adalog_quantile_rows(const float* x, int64_t S, int64_t n, int nq
     const int R = 2 * nq;
     ADALOG_ARG_CHECK(workspace_bytes >= adalog_select_workspace_bytes(S, R), "quantile_rows: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (one_block_ok(S, n, mbs)) {
+        hipLaunchKernelGGL(k_sel_one_block, dim3((unsigned)S), dim3(256), 0, st, x, n, (int)S, R, ranks_lo_hi, nullptr, 0, 0, nq, weights, out);
+        ADALOG_LAUNCH_CHECK("adalog_quantile_rows");
+        return 0;
+    }
     unsigned* hist = (unsigned*)workspace;
     SelState* state = (SelState*)((char*)workspace + ((sizeof(unsigned) * S * R * 256 + 15) / 16) * 16);
     int rc = run_select(x, S, n, R, ranks_lo_hi, nullptr, 0, state, hist, st);
@@ -199,6 +379,11 @@ extern "C" int adalog_positive_percentile_rows(const float* x, int64_t S, int64_
     ADALOG_ARG_CHECK(S >= 1 && S <= 65535 && n >= 1 && nq >= 1 && nq <= MAXR, "positive_percentile_rows: bad sizes");
     ADALOG_ARG_CHECK(workspace_bytes >= adalog_select_workspace_bytes(S, nq), "positive_percentile_rows: workspace too small");
     hipStream_t st = (hipStream_t)stream;
+    if (one_block_ok(S, n, 1)) {
+        hipLaunchKernelGGL(k_sel_one_block, dim3((unsigned)S), dim3(256), 0, st, x, n, (int)S, nq, nullptr, qfrac, 1, 1, nq, nullptr, out);
+        ADALOG_LAUNCH_CHECK("adalog_positive_percentile_rows");
+        return 0;
+    }
     unsigned* hist = (unsigned*)workspace;
     SelState* state = (SelState*)((char*)workspace + ((sizeof(unsigned) * S * nq * 256 + 15) / 16) * 16);
     int rc = run_select(x, S, n, nq, nullptr, qfrac, 1, state, hist, st);

@@ -19,6 +19,7 @@
 // Exactness: the run boundaries are exact (same predicate as the reference); the sums are fp64 where the reference
 // rounds every (x - c) and every square to fp32 -- agreement ~1e-7 relative, inside the 1e-4 bar of the parity tests.
 #include "common.h"
+#include "fpcs_tail.h"
 
 #include <hipcub/hipcub.hpp>
 
@@ -129,10 +130,12 @@ __global__ __launch_bounds__(256) void k_sp_prefix(const float* __restrict__ sor
 template <int G>
 __global__ __launch_bounds__(256) void k_score_sorted(const float* __restrict__ sorted, const d2* __restrict__ prefix, int64_t S,
                                                       int64_t n, const float* __restrict__ scale, const float* __restrict__ zp,
-                                                      int P, float qmax, double norm, float* __restrict__ scores) {
+                                                      int P, float qmax, double norm, float* __restrict__ scores, int has_tail,
+                                                      fpcs::Tail tail, unsigned int* tickets) {
     constexpr int GPB = 256 / G;
     __shared__ int64_t bnd[GPB][G + 1];
     __shared__ double red[256];
+    __shared__ int last_col[GPB];
     const int gi = threadIdx.x / G, t = threadIdx.x % G;
     const int64_t pair = (int64_t)blockIdx.x * GPB + gi;               // = p * S + seg
     const bool live = pair < (int64_t)P * S;
@@ -173,7 +176,33 @@ __global__ __launch_bounds__(256) void k_score_sorted(const float* __restrict__ 
         if (t < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (live && t == 0) scores[pair] = (float)(-norm * red[threadIdx.x]);
+    if (t == 0) {
+        int lc = -1;
+        if (live) {
+            const float v = (float)(-norm * red[threadIdx.x]);
+            if (has_tail) {
+                // the FPCS step's tail in the same launch (fpcs_tail.h): a ticket per segment (= score column); the last of its P
+                // candidates to arrive has the block rank the column and write its next grid / commit its winner
+                fpcs::score_publish(scores + pair, v);
+                fpcs::publish_wait();
+                if (fpcs::ticket_last(tickets + seg, (unsigned)P)) lc = (int)seg;
+            } else {
+                scores[pair] = v;
+            }
+        }
+        last_col[gi] = lc;
+    }
+    if (!has_tail) return;
+    __syncthreads();
+    float* sc = reinterpret_cast<float*>(red);                 // 256 floats + 256 ints of the dead reduction buffer
+    int* top = reinterpret_cast<int*>(red) + 256;
+#pragma unroll 1
+    for (int g2 = 0; g2 < GPB; ++g2) {
+        const int col = last_col[g2];
+        if (col < 0) continue;
+        fpcs::column<256, false>(scores, P, (int)S, col, (int)threadIdx.x, tail, sc, top);
+        __syncthreads();
+    }
 }
 
 size_t sort_temp_bytes(int64_t S, int64_t n) {
@@ -224,9 +253,17 @@ extern "C" int adalog_sorted_prefix_build(const float* x, int64_t S, int64_t n, 
 }
 
 // scores[p][seg] = -norm * sum over the segment of (x - fq_{p,seg}(x))^2 ; scale / zp: [P][S] (candidate-major).
-extern "C" int adalog_score_self_sorted(const float* sorted, const double* prefix, int64_t S, int64_t n, const float* scale,
-                                        const float* zp, int P, int n_bits, double norm, float* scores, void* stream) {
+// `tail` (may be null): the FPCS step's ranking + next grid / commit inside the same launch (fpcs_tail.h); its grid is (scale, zp).
+extern "C" int adalog_score_self_sorted_tail(const float* sorted, const double* prefix, int64_t S, int64_t n, const float* scale,
+                                             const float* zp, int P, int n_bits, double norm, float* scores,
+                                             const adalog_fpcs_tail* tail, void* stream) {
     ADALOG_ARG_CHECK(sorted && prefix && scale && zp && scores && S >= 1 && n >= 1 && P >= 1, "score_self_sorted: bad arguments");
+    const char* why = fpcs::tail_problem(tail, P);
+    ADALOG_ARG_CHECK(why == nullptr, why);
+    ADALOG_ARG_CHECK(!tail || S <= 65536, "score_self_sorted: the fused tail takes <= 65536 segments");
+    unsigned int* tickets = tail ? adalog_ticket_pool_on((int)S, stream) : nullptr;
+    ADALOG_ARG_CHECK(!tail || tickets, "score_self_sorted: no ticket counters");
+    const fpcs::Tail tl = tail ? *tail : fpcs::Tail{};
     ADALOG_ARG_CHECK(n_bits >= 1 && n_bits <= 8, "score_self_sorted: 1..8 bits");
     const float qmax = (float)((1 << n_bits) - 1);
     const int G = 1 << n_bits;
@@ -236,7 +273,7 @@ extern "C" int adalog_score_self_sorted(const float* sorted, const double* prefi
     ADALOG_ARG_CHECK(blocks < ((int64_t)1 << 31), "score_self_sorted: grid too large");
     hipStream_t st = (hipStream_t)stream;
     adalog_note_kernel("k_score_sorted");
-#define LAUNCH_SS(GV) hipLaunchKernelGGL((k_score_sorted<GV>), dim3((unsigned)blocks), dim3(256), 0, st, sorted, (const d2*)prefix, S, n, scale, zp, P, qmax, norm, scores)
+#define LAUNCH_SS(GV) hipLaunchKernelGGL((k_score_sorted<GV>), dim3((unsigned)blocks), dim3(256), 0, st, sorted, (const d2*)prefix, S, n, scale, zp, P, qmax, norm, scores, tail ? 1 : 0, tl, tickets)
     switch (n_bits) {
         case 1: LAUNCH_SS(2); break;
         case 2: LAUNCH_SS(4); break;
@@ -250,4 +287,9 @@ extern "C" int adalog_score_self_sorted(const float* sorted, const double* prefi
 #undef LAUNCH_SS
     ADALOG_LAUNCH_CHECK("adalog_score_self_sorted");
     return 0;
+}
+
+extern "C" int adalog_score_self_sorted(const float* sorted, const double* prefix, int64_t S, int64_t n, const float* scale,
+                                        const float* zp, int P, int n_bits, double norm, float* scores, void* stream) {
+    return adalog_score_self_sorted_tail(sorted, prefix, S, n, scale, zp, P, n_bits, norm, scores, nullptr, stream);
 }

@@ -223,6 +223,47 @@ def _layout(M, n_cols, c_grid, G, gmod, ref_div, reduce_cols, dtype, Kp, k_valid
     return elems, mt.value, npad.value, mode.value
 
 
+class FpcsTail:
+    """The tail of one FPCS step (reference linear.py:483-523: top-k of the scores, then the next 16 x 8 grid around the survivors or
+    the committed winner) as ARGUMENTS (adalog_fpcs_tail, csrc/fpcs_tail.h), so that a kernel producing final scores runs it in its own
+    launch, or adalog_topk_next_tail / adalog_finish_topk_next_tail run it.  ``delta_in`` is read, ``delta_out`` written (they may be
+    the same tensor): the memoised grid spacing is never modified.  ``out`` (commit step only): write the winner straight into these
+    [cols] tensors -- the quantiser's own parameter storage -- instead of fresh ones."""
+    __slots__ = ("c", "scale", "zp", "third", "o_s", "o_z", "o_t", "new_cnt", "keep")
+
+    def __init__(self, scale, zp, third, k: int, new_cnt: int, lin, delta_in, delta_out, clamp_min, out=None):
+        scale = _f32c(scale, "scale")
+        cols = scale.shape[1]
+        rows = k * new_cnt if new_cnt > 0 else 1
+        dev = scale.device
+        self.scale, self.zp, self.third, self.new_cnt = scale, zp, third, new_cnt
+        if out is not None and new_cnt == 0:
+            o_s, o_z, o_t = out
+            for o_, src in ((o_s, scale), (o_z, zp), (o_t, third)):
+                if (o_ is None) != (src is None) or (o_ is not None and not (o_.is_contiguous() and o_.dtype == torch.float32
+                                                                             and o_.numel() == cols and o_.device == dev)):
+                    raise ValueError("FpcsTail: commit targets must be contiguous fp32 [cols] tensors matching the grid's planes")
+            self.o_s, self.o_z, self.o_t = o_s, o_z, o_t
+        else:
+            mk = lambda src: None if src is None else torch.empty((rows, cols), dtype=torch.float32, device=dev)
+            self.o_s, self.o_z, self.o_t = mk(scale), mk(zp), mk(third)
+        self.keep = (lin, delta_in, delta_out)
+        self.c = _lib.FpcsTail(int(k), int(new_cnt), int(clamp_min is not None), float(clamp_min if clamp_min is not None else 0.0),
+                               scale.data_ptr(), _ptr(zp), _ptr(third), _ptr(lin), _ptr(delta_in), _ptr(delta_out),
+                               self.o_s.data_ptr(), _ptr(self.o_z), _ptr(self.o_t))
+
+    def ref(self):
+        import ctypes
+        return ctypes.byref(self.c)
+
+    def result(self):
+        """what topk_next returns: the next grid [k * new_cnt, cols] planes, or the committed winner's [cols] planes"""
+        if self.new_cnt == 0:
+            f = lambda t: None if t is None else t.reshape(-1)
+            return f(self.o_s), f(self.o_z), f(self.o_t)
+        return self.o_s, self.o_z, self.o_t
+
+
 class PendingScores:
     """The partial sums a scoring kernel left behind, not yet reduced to scores: what ``gemm_score(..., defer=True)`` and
     ``score_act_gen(..., defer=True)`` return.  ``finish()`` gives the [C, cols] scores; on one GPU the FPCS driver hands the
@@ -249,34 +290,21 @@ class PendingScores:
         return scores
 
 
-def finish_topk_next(pend: PendingScores, scale, zp, third, k: int, new_cnt: int, lin, delta, clamp_min: Optional[float]):
+def finish_topk_next(pend: PendingScores, scale, zp, third, k: int, new_cnt: int, lin, delta, clamp_min: Optional[float], tail=None):
     """finish(pend) followed by topk_next(...) -- one launch where the partial layout allows it (csrc/gemm_finish.inc).  Same return
-    value as topk_next.  Single-GPU form: with several ranks the scores are all-reduced between the two steps."""
-    scale = _f32c(scale, "scale")
-    rows = k * new_cnt if new_cnt > 0 else 1
+    value as topk_next.  Single-GPU form: with several ranks the scores are all-reduced between the two steps.  ``tail``: a prepared
+    FpcsTail (then scale .. clamp_min are ignored)."""
+    if tail is None:
+        tail = FpcsTail(scale, zp, third, k, new_cnt, lin, delta, delta, clamp_min)
     cols = pend.cols
-    assert scale.shape[0] == pend.C and scale.shape[1] == cols
-    dev = scale.device
-    if _torch_ops.available():
-        scores, o_s, o_z, o_t = _top("finish_topk_next", pend.partial, pend.MT, pend.n_last, pend.Npad, pend.C, pend.G, pend.gmod,
-                                     pend.keep_h, pend.keep_n, pend.mode, pend.norm, int(k), scale, zp, third, int(new_cnt), lin, delta,
-                                     clamp_min is not None, float(clamp_min if clamp_min is not None else 0.0))
-        o_z, o_t = (None if zp is None else o_z), (None if third is None else o_t)
-    else:
-        mk = lambda src: None if src is None else torch.empty((rows, cols), dtype=torch.float32, device=dev)
-        o_s, o_z, o_t = mk(scale), mk(zp), mk(third)
-        scores = torch.empty((pend.C, cols), dtype=torch.float32, device=dev)
-        ws, nb = pend._ws()
-        rc = _lib.load().adalog_finish_topk_next(pend.partial.data_ptr(), scores.data_ptr(), pend.MT, pend.n_last, pend.Npad, pend.C,
-                                                pend.G, pend.gmod, int(pend.keep_h), int(pend.keep_n), pend.mode, pend.norm, _ptr(ws),
-                                                nb, int(k), scale.data_ptr(), _ptr(zp), _ptr(third), int(new_cnt), _ptr(lin),
-                                                _ptr(delta), int(clamp_min is not None),
-                                                float(clamp_min if clamp_min is not None else 0.0), o_s.data_ptr(), _ptr(o_z),
-                                                _ptr(o_t), _stream())
-        _lib.check(rc, "adalog_finish_topk_next")
-    if new_cnt == 0:
-        return o_s[0], (None if o_z is None else o_z[0]), (None if o_t is None else o_t[0])
-    return o_s, o_z, o_t
+    assert tail.scale.shape[0] == pend.C and tail.scale.shape[1] == cols
+    scores = torch.empty((pend.C, cols), dtype=torch.float32, device=tail.scale.device)
+    ws, nb = pend._ws()
+    rc = _lib.load().adalog_finish_topk_next_tail(pend.partial.data_ptr(), scores.data_ptr(), pend.MT, pend.n_last, pend.Npad, pend.C,
+                                                 pend.G, pend.gmod, int(pend.keep_h), int(pend.keep_n), pend.mode, pend.norm, _ptr(ws),
+                                                 nb, tail.ref(), _stream())
+    _lib.check(rc, "adalog_finish_topk_next")
+    return tail.result()
 
 
 def gemm_score(dtype: int, A, B, M: int, N: int, C: int, G: int, gmod: int, ref, sa: Strided, sb: Strided,
@@ -651,8 +679,9 @@ class GramState:
             GEMM_EVENTS.append((I8, self.T, self.K + 4 * self.O, self.K, 1, 1, ev0, ev1, "k_gram_build"))
         _lib.check(rc, "adalog_gram_build")
 
-    def score_w(self, w2, scale, zp, w_bits: int, norm: float):
-        """scores [P, O] (final: no partial sums) for the candidates (scale, zp) [P, O] of every output row of w2 [O, K]."""
+    def score_w(self, w2, scale, zp, w_bits: int, norm: float, tail=None):
+        """scores [P, O] (final: no partial sums) for the candidates (scale, zp) [P, O] of every output row of w2 [O, K].
+        ``tail`` (FpcsTail over this very grid): the kernel also ranks every row and writes its next grid / commits its winner."""
         lib = _lib.load()
         w2 = _f32c(w2, "weight")
         scale, zp = _f32c(scale, "scale"), _f32c(zp, "zp")
@@ -662,9 +691,10 @@ class GramState:
         if GEMM_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = lib.adalog_gram_score_w(w2.data_ptr(), self.O, self.K, w2.stride(0), scale.data_ptr(), zp.data_ptr(), P, int(w_bits),
-                                     self.ws.data_ptr(), self.T, self.a_bits, self.sa.data_ptr(), float(norm), scores.data_ptr(),
-                                     _stream())
+        assert tail is None or (tail.scale.data_ptr() == scale.data_ptr() and tail.zp is not None and tail.zp.data_ptr() == zp.data_ptr())
+        rc = lib.adalog_gram_score_w_tail(w2.data_ptr(), self.O, self.K, w2.stride(0), scale.data_ptr(), zp.data_ptr(), P, int(w_bits),
+                                          self.ws.data_ptr(), self.T, self.a_bits, self.sa.data_ptr(), float(norm), scores.data_ptr(),
+                                          None if tail is None else tail.ref(), _stream())
         if GEMM_EVENTS is not None:
             ev1.record()
             # flops as ISSUED (limbs * K^2 + the 32-row w.c panel per candidate row), not the token form's 2 T K O P: a roofline
@@ -745,19 +775,21 @@ class GramActState:
             GEMM_EVENTS.append((I8, 4 * self.T, self.K, self.O, 1, 1, ev0, ev1, "k_gram_act_build"))
         _lib.check(rc, "adalog_gram_act_build")
 
-    def score(self, scale, zp, norm: float):
-        """scores [P, 1] (final) for the per-tensor candidates (scale, zp) [P, 1]."""
+    def score(self, scale, zp, norm: float, tail=None):
+        """scores [P, 1] (final) for the per-tensor candidates (scale, zp) [P, 1].  ``tail`` (FpcsTail over this very grid): the
+        finish kernel's last block also ranks the candidates and writes the next grid / commits the winner."""
         lib = _lib.load()
         scale, zp = _f32c(scale, "scale").reshape(-1), _f32c(zp, "zp").reshape(-1)
+        assert tail is None or (tail.scale.data_ptr() == scale.data_ptr() and tail.zp is not None and tail.zp.data_ptr() == zp.data_ptr())
         P = scale.numel()
         assert P == self.P and zp.numel() == P
         scores = torch.empty((P, 1), dtype=torch.float32, device=scale.device)
         if GEMM_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        rc = lib.adalog_gram_act_score(self.prep.xt.data_ptr(), self.prep.sorted.data_ptr(), self.T, self.O, self.K, scale.data_ptr(),
-                                       zp.data_ptr(), P, self.a_bits, self.ws.data_ptr(), float(norm), self.qpart.data_ptr(),
-                                       scores.data_ptr(), _stream())
+        rc = lib.adalog_gram_act_score_tail(self.prep.xt.data_ptr(), self.prep.sorted.data_ptr(), self.T, self.O, self.K, scale.data_ptr(),
+                                            zp.data_ptr(), P, self.a_bits, self.ws.data_ptr(), float(norm), self.qpart.data_ptr(),
+                                            scores.data_ptr(), None if tail is None else tail.ref(), _stream())
         if GEMM_EVENTS is not None:
             ev1.record()
             # flops as ISSUED: the upper triangle of X_p^T X_p in 32 x 32 blocks, per candidate
@@ -797,28 +829,16 @@ def fpcs_next(scale, zp, third, idx, k: int, new_cnt: int, lin, delta, clamp_min
     return o_s, o_z, o_t
 
 
-def topk_next(scores, scale, zp, third, k: int, new_cnt: int, lin, delta, clamp_min: Optional[float]):
-    """topk(scores, k) followed by fpcs_next(...) in one launch; same return value as fpcs_next."""
-    scores, scale = _f32c(scores, "scores"), _f32c(scale, "scale")
+def topk_next(scores, scale, zp, third, k: int, new_cnt: int, lin, delta, clamp_min: Optional[float], tail=None):
+    """topk(scores, k) followed by fpcs_next(...) in one launch; same return value as fpcs_next.  ``tail``: a prepared FpcsTail."""
+    scores = _f32c(scores, "scores")
+    if tail is None:
+        tail = FpcsTail(scale, zp, third, k, new_cnt, lin, delta, delta, clamp_min)
     P, cols = scores.shape
-    rows = k * new_cnt if new_cnt > 0 else 1
-    if _torch_ops.available():
-        o_s, o_z, o_t = _top("topk_next", scores, scale, zp, third, int(k), int(new_cnt), lin, delta, clamp_min is not None,
-                             float(clamp_min if clamp_min is not None else 0.0))
-        o_z, o_t = (None if zp is None else o_z), (None if third is None else o_t)
-        if new_cnt == 0:
-            return o_s[0], (None if o_z is None else o_z[0]), (None if o_t is None else o_t[0])
-        return o_s, o_z, o_t
-    mk = lambda src: None if src is None else torch.empty((rows, cols), dtype=torch.float32, device=scale.device)
-    o_s, o_z, o_t = mk(scale), mk(zp), mk(third)
-    rc = _lib.load().adalog_topk_next(scores.data_ptr(), P, cols, int(k), scale.data_ptr(), _ptr(zp), _ptr(third),
-                                     int(new_cnt), _ptr(lin), _ptr(delta), int(clamp_min is not None),
-                                     float(clamp_min if clamp_min is not None else 0.0), o_s.data_ptr(), _ptr(o_z), _ptr(o_t),
-                                     None, _stream())
+    assert tail.scale.shape == (P, cols)
+    rc = _lib.load().adalog_topk_next_tail(scores.data_ptr(), P, cols, tail.ref(), None, _stream())
     _lib.check(rc, "adalog_topk_next")
-    if new_cnt == 0:
-        return o_s[0], (None if o_z is None else o_z[0]), (None if o_t is None else o_t[0])
-    return o_s, o_z, o_t
+    return tail.result()
 
 
 def candidate_grid(quant4, num_scale: int, num_zp: int, zp_min: int, n_bits: int, lin, clamp_min: Optional[float]):
@@ -906,12 +926,20 @@ def sorted_prefix_ok(S: int, n: int, n_bits: int) -> bool:
     return ws >= 0 and ws + 20 * int(S) * int(n) <= _SORTED_MAX_BYTES
 
 
-def score_self_sorted(sp: SortedPrefix, scale, zp, n_bits: int, norm: float):
-    """scores [P, S] = -norm * sum over each segment of (x - fq_p(x))^2 for the P candidates scale / zp [P, S]."""
+def score_self_sorted(sp: SortedPrefix, scale, zp, n_bits: int, norm: float, tail=None):
+    """scores [P, S] = -norm * sum over each segment of (x - fq_p(x))^2 for the P candidates scale / zp [P, S].  ``tail`` (FpcsTail
+    over this very grid): the launch also ranks every segment's candidates and writes its next grid / commits its winner."""
     scale, zp = _f32c(scale, "scale"), _f32c(zp, "zp")
     P = scale.shape[0]
     if scale.numel() != P * sp.S or zp.numel() != P * sp.S:
         raise ValueError("score_self_sorted: scale / zp must be [P, S]")
+    if tail is not None:
+        assert tail.scale.data_ptr() == scale.data_ptr() and tail.zp is not None and tail.zp.data_ptr() == zp.data_ptr()
+        scores = torch.empty((P, sp.S), dtype=torch.float32, device=scale.device)
+        rc = _lib.load().adalog_score_self_sorted_tail(sp.sorted.data_ptr(), sp.prefix.data_ptr(), sp.S, sp.n, scale.data_ptr(),
+                                                      zp.data_ptr(), P, int(n_bits), float(norm), scores.data_ptr(), tail.ref(), _stream())
+        _lib.check(rc, "adalog_score_self_sorted")
+        return scores
     if _torch_ops.available():
         return _top("score_self_sorted", sp.sorted, sp.prefix, scale, zp, int(n_bits), float(norm))
     scores = torch.empty((P, sp.S), dtype=torch.float32, device=scale.device)
@@ -931,13 +959,28 @@ def quantile_ranks(qs, n: int):
     return lohi, (pos - lo)
 
 
+_RANKS_DEV = {}
+
+
+def quantile_ranks_dev(qs, n: int, device):
+    """quantile_ranks on the device, kept per (qs, n, device): the percentile grids ask for the same four ranks of the same
+    row length every round of every module (2 host-to-device copies per call before: ~450 per deit_small calibration)"""
+    key = (tuple(qs), int(n), str(device))
+    hit = _RANKS_DEV.get(key)
+    if hit is None:
+        if len(_RANKS_DEV) > 512:
+            _RANKS_DEV.clear()
+        lohi, w = quantile_ranks(qs, n)
+        hit = _RANKS_DEV[key] = (lohi.to(device), w.to(device))
+    return hit
+
+
 def quantile_rows(x2, qs, mbs: int = 1):
     """torch.quantile(x2, qs, dim=-1) followed by the mean over groups of ``mbs`` rows -> [len(qs), S/mbs]."""
     x2 = _f32c(x2, "x")
     S, n = x2.shape
     nq = len(qs)
-    lohi, w = quantile_ranks(qs, n)
-    lohi, w = lohi.to(x2.device), w.to(x2.device)
+    lohi, w = quantile_ranks_dev(qs, n, x2.device)
     lib = _lib.load()
     ws_bytes = lib.adalog_select_workspace_bytes(S, 2 * nq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device)
@@ -952,7 +995,10 @@ def positive_percentile_rows(x2, qs):
     x2 = _f32c(x2, "x")
     S, n = x2.shape
     nq = len(qs)
-    qf = torch.tensor(qs, dtype=torch.float32).to(x2.device)
+    key = ("qf", tuple(qs), str(x2.device))
+    qf = _RANKS_DEV.get(key)
+    if qf is None:
+        qf = _RANKS_DEV[key] = torch.tensor(qs, dtype=torch.float32).to(x2.device)
     lib = _lib.load()
     ws_bytes = lib.adalog_select_workspace_bytes(S, nq)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x2.device)

@@ -186,10 +186,12 @@ class AsymmetricallyBatchingQuantConv2d(PTQSLBatchingQuantConv2d):
         ref = self.raw_out.permute(1, 0, 2, 3).reshape(1, self.out_channels, M).contiguous()      # [1, oc, tokens]
         scale, zp, delta = search.weight_grid(self._w2(), self.w_quantizer.n_bits, self.eq_n, conv=True)
         fn = lambda s, z, t: self._score_w(xp, ref, M, gh * gw, s, z, defer=True)
-        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
+        wq = self.w_quantizer
+        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None,
+                          commit_to=search.commit_targets(wq.scale, wq.zero_point, None))
         if res is not None:
-            self.w_quantizer.scale.data.copy_(res[0].view(-1, 1))
-            self.w_quantizer.zero_point.data.copy_(res[1].view(-1, 1))
+            search.commit_param(wq.scale, res[0])               # (no copy when the search's last kernel wrote them in place)
+            search.commit_param(wq.zero_point, res[1])
 
     def hyperparameter_searching(self):
         """conv.py:313-334 for the shipped configuration (qconv_a_bit = 8: the input is not quantised and the loop

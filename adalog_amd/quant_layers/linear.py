@@ -200,15 +200,15 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         self.__dict__.pop("_wp_cache", None)
 
     def _commit_w(self, scale, zp):
-        self.w_quantizer.scale.data.copy_(scale.view(self.n_V, self.crb_rows, 1))
-        self.w_quantizer.zero_point.data.copy_(zp.view(self.n_V, self.crb_rows, 1))
+        search.commit_param(self.w_quantizer.scale, scale)              # (no copy when the search's last kernel wrote them in place)
+        search.commit_param(self.w_quantizer.zero_point, zp)
         self.w_quantizer.inited = True
         self.w_quantizer._zp_on_grid = True          # zero point taken from an FPCS grid: inside [0, 2^bits - 1]
         self.invalidate_packed_weight()
 
     def _commit_a(self, scale, zp):
-        self.a_quantizer.scale.data.copy_(scale.view(self.a_quantizer.scale.shape))
-        self.a_quantizer.zero_point.data.copy_(zp.view(self.a_quantizer.zero_point.shape))
+        search.commit_param(self.a_quantizer.scale, scale)
+        search.commit_param(self.a_quantizer.zero_point, zp)
         self.a_quantizer.inited = True
         self.a_quantizer._zp_on_grid = True
 
@@ -330,16 +330,19 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
                                      row_bias=None if self.bias is None else self.bias.data, defer=defer and chunk >= P))
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
-    def _score_w_self(self, scale, zp):
-        """linear.py:296-318: scores [P, O] = -mean_i (W - fq_p(W))^2 from the sorted weight rows (csrc/sorted_score.hip)."""
+    def _score_w_self(self, scale, zp, tail=None):
+        """linear.py:296-318: scores [P, O] = -mean_i (W - fq_p(W))^2 from the sorted weight rows (csrc/sorted_score.hip).
+        ``tail``: the FPCS step's ranking / next grid / commit, run by the same launch (search.fpcs)."""
         be = backend.get()
         w2 = self._w2()
         if SORTED_SELF_SEARCH and be.sorted_prefix_ok(w2.shape[0], w2.shape[1], self.w_quantizer.n_bits):
             sp = search.memo_tensor_fn("spw", w2, (), lambda: be.sorted_prefix(w2))
+            if tail is not None:
+                return be.score_self_sorted(sp, scale, zp, self.w_quantizer.n_bits, 1.0 / w2.shape[1], tail=tail)
             return be.score_self_sorted(sp, scale, zp, self.w_quantizer.n_bits, 1.0 / w2.shape[1])
-        return be.score_w_self(w2, scale, zp, self.w_quantizer.n_bits)
+        return search.honour_tail(be.score_w_self(w2, scale, zp, self.w_quantizer.n_bits), tail)
 
-    def _score_a_self(self, scale, zp):
+    def _score_a_self(self, scale, zp, tail=None):
         """linear.py:320-353: scores [P, I | 1] = -sum_images mean_tokens (x - fq_p(x))^2.  The captured activation is sorted
         once per search (per channel: one segment per channel; per tensor: one segment), every step then costs 2^bits
         bisections per candidate instead of a pass over the tensor."""
@@ -352,8 +355,10 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if SORTED_SELF_SEARCH and be.sorted_prefix_ok(S, n, self.a_quantizer.n_bits):
             sp = search.memo_tensor_fn("spa", self.raw_input, (cw,),
                                        lambda: be.sorted_prefix(x2.t().contiguous() if cw else x2.reshape(1, -1)))
+            if tail is not None:
+                return be.score_self_sorted(sp, scale, zp, self.a_quantizer.n_bits, norm, tail=tail)
             return be.score_self_sorted(sp, scale, zp, self.a_quantizer.n_bits, norm)
-        return be.score_a_self(x2, scale, zp, cw, self.a_quantizer.n_bits, norm)
+        return search.honour_tail(be.score_a_self(x2, scale, zp, cw, self.a_quantizer.n_bits, norm), tail)
 
     # ------------------------------------------------------------------ FPCS (linear.py:483-523)
     def weight_fpcs(self, fpcs_width=16, steps=6, search_strategy="output"):
@@ -361,11 +366,18 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             return                                 # the activation quantiser is what this search saw last round: same winner
         scale, zp, delta = search.weight_grid(self._w2(), self.w_quantizer.n_bits, self.eq_n)
         if search_strategy == "self":
-            fn = lambda s, z, t: self._score_w_self(s, z)
+            fn = lambda s, z, t, tail=None: self._score_w_self(s, z, tail=tail)
+            fn.fused_tail = True
         else:
             score = self._w_scorer()
-            fn = lambda s, z, t: score(s, z, defer=True)
-        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
+            if getattr(score, "fused_tail", False):
+                fn = lambda s, z, t, tail=None: score(s, z, defer=True, tail=tail)
+                fn.fused_tail = True
+            else:
+                fn = lambda s, z, t: score(s, z, defer=True)
+        wq = self.w_quantizer
+        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None,
+                          commit_to=search.commit_targets(wq.scale, wq.zero_point, None))
         if res is not None:
             self._commit_w(res[0], res[1])
 
@@ -376,6 +388,10 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         gram = self._gram_state()
         if gram is not None:
             norm = 1.0 / self._tokens_per_image()
+            if getattr(backend.get(), "FpcsTail", None) is not None:
+                fn = lambda s, z, defer=False, tail=None: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm, tail=tail)
+                fn.fused_tail = True                     # the score kernel ranks its rows and writes the next grid itself
+                return fn
             return lambda s, z, defer=False: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm)
         fixed = self._pack_x_fixed()
         return lambda s, z, defer=False: self._score_w(fixed, s, z, defer=defer)
@@ -396,6 +412,10 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             st = be.GramActState(prep, self.raw_out.reshape(-1, self.out_features), None if self.bias is None else self.bias.data,
                                  self._w2(), wq.scale.data.view(-1), wq.zero_point.data.view(-1), wq.n_bits, aq.n_bits, self.eq_n)
             norm = 1.0 / (self._tokens_per_image() * self.out_features)
+            if getattr(be, "FpcsTail", None) is not None:
+                fn = lambda s, z, defer=False, tail=None: st.score(s, z, norm, tail=tail)
+                fn.fused_tail = True                     # the finish kernel's last block ranks and writes the next grid
+                return fn
             return lambda s, z, defer=False: st.score(s, z, norm)
         dt = self._int_dt(self.raw_input.numel() // self.in_features, prefer_fp8=self.in_features <= FP8_WEIGHT_SEARCH_MAX_K,
                           fixed=wq)
@@ -427,11 +447,17 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             return
         scale, zp, delta = search.activation_grid(self.raw_input, aq.n_bits, self.eq_n, aq.channel_wise)
         if search_strategy == "self":
-            fn = lambda s, z, t: self._score_a_self(s, z)
+            fn = lambda s, z, t, tail=None: self._score_a_self(s, z, tail=tail)
+            fn.fused_tail = True
         else:
             score = self._a_scorer()
-            fn = lambda s, z, t: score(s, z, defer=True)
-        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, 1e-4)
+            if getattr(score, "fused_tail", False):
+                fn = lambda s, z, t, tail=None: score(s, z, defer=True, tail=tail)
+                fn.fused_tail = True
+            else:
+                fn = lambda s, z, t: score(s, z, defer=True)
+        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, 1e-4,
+                          commit_to=search.commit_targets(aq.scale, aq.zero_point, None))
         if res is not None:
             self._commit_a(res[0], res[1])
 

@@ -248,8 +248,8 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         return out[0] if len(out) == 1 else torch.cat(out, 0)
 
     def _commit(self, quantizer, scale, zp):
-        quantizer.scale.data.copy_(scale.view(quantizer.scale.shape))
-        quantizer.zero_point.data.copy_(zp.view(quantizer.zero_point.shape))
+        search.commit_param(quantizer.scale, scale)             # (no copy when the search's last kernel wrote them in place)
+        search.commit_param(quantizer.zero_point, zp)
 
     def _fpcs(self, which, fpcs_width=16, steps=6, fixed=None, dt=I8, fixed_sa=None, sa_mul=1.0, checked=False):
         """matmul.py:243-262."""
@@ -260,9 +260,11 @@ class AsymmetricallyBatchingQuantMatMul(PTQSLBatchingQuantMatMul):
         if fixed is None:
             fixed = self._pack_fixed("B" if which == "A" else "A", dt)
         fn = lambda s, z, t: self._score(which, fixed, s, z, dt, fixed_sa, sa_mul, defer=True)
-        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None)
+        q = self.A_quantizer if which == "A" else self.B_quantizer
+        res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None,
+                          commit_to=search.commit_targets(q.scale, q.zero_point, None))
         if res is not None:
-            self._commit(self.A_quantizer if which == "A" else self.B_quantizer, res[0], res[1])
+            self._commit(q, res[0], res[1])
 
     def _init_from_grid(self, which):
         """matmul.py:266-271: parameters start at candidate [-2] of the percentile grid."""

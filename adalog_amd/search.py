@@ -108,10 +108,15 @@ def round_is_redundant(module, tag: str, *quantizers) -> bool:
 
 
 def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 16, eq_n: int = 128,
-         clamp_min: Optional[float] = None):
+         clamp_min: Optional[float] = None, commit_to=None):
     """Run the progressive search.  ``score_fn(scale, zp, third) -> scores [P, cols]`` (rank-local partial sums).
 
-    ``score_fn`` may return an ``ops.PendingScores`` (partial sums not yet reduced) instead of the scores.
+    ``score_fn`` may return an ``ops.PendingScores`` (partial sums not yet reduced) instead of the scores.  A ``score_fn`` with the
+    attribute ``fused_tail`` also takes ``tail=`` (an ``ops.FpcsTail``): its kernel then ranks the scores and writes the next grid /
+    commits the winner in the SAME launch (one GPU only: with several ranks the scores are all-reduced before the ranking).
+    ``delta`` (the grid spacing, memoised with the grid) is only read: the narrowed spacing goes to a buffer of this call.
+    ``commit_to``: (scale, zp | None, third | None) contiguous fp32 [cols] tensors -- the quantiser's own parameter storage -- that the
+    last step's kernel writes the winner into (no copy afterwards).
     Returns the committed (scale [cols], zp [cols] | None, third [cols] | None); with steps == 1 nothing is committed
     (the reference's loop never reaches its top-1 branch then) and None is returned.
     """
@@ -121,28 +126,82 @@ def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 1
     remain = steps
     first = True
     pending_t = getattr(be, "PendingScores", ())
-    while remain > 0:
-        res = score_fn(scale, zp, third)
-        last = (remain == 1) and not first
-        k = 1 if last else width
-        if isinstance(res, pending_t) and not parallel.is_dist() and (last or remain > 1):
-            # one GPU: the scoring kernel's partial sums are reduced, ranked and expanded into the next grid by ONE launch
-            # (ops.finish_topk_next); with several ranks the scores are all-reduced between the reduction and the ranking
-            if last:
-                return be.finish_topk_next(res, scale, zp, third, 1, 0, None, None, None)
-            scale, zp, third = be.finish_topk_next(res, scale, zp, third, k, new_cnt, lin, delta, clamp_min)
-            remain -= 1
-            first = False
-            continue
-        scores = parallel.all_reduce_sum(res.finish() if isinstance(res, pending_t) else res)
+    Tail = getattr(be, "FpcsTail", None)
+    one_gpu = Tail is not None and not parallel.is_dist()
+    fused = one_gpu and getattr(score_fn, "fused_tail", False)
+    d_in, d_buf = delta, None
+
+    def tail_for(last):
+        nonlocal d_buf
         if last:
-            return be.topk_next(scores, scale, zp, third, 1, 0, None, None, None)
-        if remain == 1:          # steps == 1: survivors are selected but never committed (linear.py:490-491)
+            return Tail(scale, zp, third, 1, 0, None, None, None, None, out=commit_to)
+        if d_buf is None:
+            d_buf = torch.empty_like(delta)
+        return Tail(scale, zp, third, width, new_cnt, lin, d_in, d_buf, clamp_min)
+
+    while remain > 0:
+        last = (remain == 1) and not first
+        if remain == 1 and first:    # steps == 1: survivors are selected but never committed (linear.py:490-491)
+            score_fn(scale, zp, third)
             return None
-        scale, zp, third = be.topk_next(scores, scale, zp, third, k, new_cnt, lin, delta, clamp_min)
+        if fused:
+            tail = tail_for(last)
+            score_fn(scale, zp, third, tail=tail)
+            res = None
+        else:
+            res = score_fn(scale, zp, third)
+            if one_gpu:
+                tail = tail_for(last)
+                if isinstance(res, pending_t):
+                    # the scoring kernel's partial sums are reduced, ranked and expanded into the next grid by ONE launch
+                    be.finish_topk_next(res, None, None, None, 0, 0, None, None, None, tail=tail)
+                else:
+                    be.topk_next(res, None, None, None, 0, 0, None, None, None, tail=tail)
+            else:
+                # several ranks (or a backend without tails): the scores are all-reduced between the reduction and the ranking
+                scores = parallel.all_reduce_sum(res.finish() if isinstance(res, pending_t) else res)
+                if last:
+                    return be.topk_next(scores, scale, zp, third, 1, 0, None, None, None)
+                if d_buf is None:
+                    d_buf = delta.clone()            # (topk_next narrows its delta in place: never the memoised one)
+                scale, zp, third = be.topk_next(scores, scale, zp, third, width, new_cnt, lin, d_buf, clamp_min)
+                remain -= 1
+                first = False
+                continue
+        if last:
+            return tail.result()
+        scale, zp, third = tail.result()
+        d_in = d_buf
         remain -= 1
         first = False
     return None
+
+
+def commit_param(param, value):
+    """param <- value, unless the search's last kernel already wrote the winner into the parameter's storage (fpcs commit_to)"""
+    if value.data_ptr() != param.data_ptr():
+        param.data.copy_(value.view(param.shape))
+
+
+def commit_targets(*params):
+    """the flat fp32 views of the parameters a search commits to (fpcs commit_to), None for a plane the search does not have"""
+    out = []
+    for p_ in params:
+        if p_ is None:
+            out.append(None)
+            continue
+        d = p_.data
+        if not (d.is_contiguous() and d.dtype == torch.float32):
+            return None
+        out.append(d.view(-1))
+    return tuple(out)
+
+
+def honour_tail(scores, tail):
+    """a scorer that was handed an FPCS tail but produced plain scores: rank / expand / commit them in one more launch"""
+    if tail is not None:
+        backend.get().topk_next(scores, None, None, None, 0, 0, None, None, None, tail=tail)
+    return scores
 
 
 def argbest(scores, k: int = 1):
@@ -223,15 +282,15 @@ def _memo(kind, x, extra, make):
     (1 + search_round times per operand).  Keyed by storage pointer + in-place version + shape: a re-parameterised
     weight or a new raw_input gives a new key.  The entry holds a reference to the tensor it was computed from, so its
     storage cannot be freed and handed to another tensor (same address, same version) while the entry lives.
-    ``delta`` is handed out as a copy (the FPCS driver narrows it in place).  Entries die with their tensor's search
-    (forget_grids)."""
+    ``delta`` is shared too: the FPCS driver reads it and narrows a buffer of its own.  Entries die with their tensor's
+    search (forget_grids)."""
     key = (kind, x.data_ptr(), x._version, tuple(x.shape), tuple(x.stride())) + tuple(extra)
     memo = _memo_dict()
     hit = memo.get(key)
     if hit is None:
         hit = memo[key] = (x, make())
     hit = hit[1]
-    return hit[0], hit[1], hit[2].clone()
+    return hit[0], hit[1], hit[2]          # (delta is read-only for its users: search.fpcs narrows a buffer of its own)
 
 
 def memo_tensor_fn(kind, x, extra, make):

@@ -216,6 +216,27 @@ int adalog_score_act_fused(const void* Wp, int M, int64_t Kp, const float* x, co
  *   quant4 = [4][cols] {Q_hi0, Q_hi1, Q_lo0, Q_lo1};  scale[(zi*num_scale+si)][col] = (dmin + lin[si]*(dmax-dmin))/(2L-1),
  *   zp = zp_min + zi, delta[col] = scale[1][col] - scale[0][col]. */
 int adalog_topk(const float* scores, int P, int cols, int k, int* idx, void* stream);
+/* The tail of one FPCS step as ARGUMENTS (round 6; csrc/fpcs_tail.h holds the device code): rank the P scores of every column, then
+ * write the next k x new_cnt grid around the survivors (new_cnt > 0) or commit the winner (new_cnt == 0, k == 1) -- reference
+ * linear.py:483-523.  Every kernel that produces FINAL scores takes it and runs it in its own launch (the last workgroup / wave to
+ * finish a column draws the column's ticket and ranks it): adalog_gram_score_w_tail, adalog_gram_act_score_tail,
+ * adalog_score_self_sorted_tail; adalog_topk_next_tail / adalog_finish_topk_next_tail are the stand-alone forms.
+ *   scale / zp / third: the grid that was scored, [P][cols] (zp, third may be null; the in / out planes must match);
+ *   lin: linspace(0, 1, new_cnt); delta_in [cols] is read, delta_out [cols] receives delta_in / (new_cnt - 0.5) (they may alias);
+ *   out_*: [k * new_cnt][cols], or [cols] for the committed winner -- which may be the quantiser's own parameter storage. */
+typedef struct adalog_fpcs_tail {
+    int32_t k, new_cnt, has_clamp;
+    float clamp_min;
+    const float* scale; const float* zp; const float* third;
+    const float* lin;
+    const float* delta_in; float* delta_out;
+    float* out_scale; float* out_zp; float* out_third;
+} adalog_fpcs_tail;
+int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream);
+/* adalog_finish_topk_next with the tail as a struct (delta_in / delta_out apart, commit into caller-owned storage) */
+int adalog_finish_topk_next_tail(const float* partial, float* scores, int MT, int N, int Npad, int C, int G, int gmod, int keep_h,
+                                 int keep_n, int cand_inner, double norm, void* workspace, int64_t workspace_bytes,
+                                 const adalog_fpcs_tail* tail, void* stream);
 /* adalog_topk_next = adalog_topk followed by adalog_fpcs_next in one launch (one workgroup per column); idx_out (optional)
  * receives the top-k indices [k][cols]. */
 int adalog_topk_next(const float* scores, int P, int cols, int k, const float* scale, const float* zp, const float* third,
@@ -276,6 +297,10 @@ int adalog_gram_build(const float* x, int T, int K, int64_t ldx, const float* sa
                       int O, const float* bias, void* workspace, int64_t workspace_bytes, void* stream);
 int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
                         const void* workspace, int T, int a_bits, const float* sa, double norm, float* scores, void* stream);
+/* ... and the FPCS step's tail in the same launch (tail may be null; its grid is (scale, zp); k <= 32) */
+int adalog_gram_score_w_tail(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
+                             const void* workspace, int T, int a_bits, const float* sa, double norm, float* scores,
+                             const adalog_fpcs_tail* tail, void* stream);
 
 /* ---- K8, Gram form   _search_best_a_scale scored from the candidates' Gram matrices   reference quant_layers/linear.py:394-430,505-523
  * The weight quantiser is fixed for the six scoring calls of an activation_fpcs call, and the score of the per-tensor candidate
@@ -305,6 +330,10 @@ int adalog_gram_act_build(const float* raw_out, int T, int O, const float* bias,
                           void* stream);
 int adalog_gram_act_score(const float* xt, const float* sorted, int T, int O, int K, const float* scale, const float* zp, int P, int a_bits,
                           const void* workspace, double norm, double* qpart, float* scores, void* stream);
+/* ... and the FPCS step's tail in the finish kernel's last block (tail may be null; its grid is (scale, zp) as [P][1]) */
+int adalog_gram_act_score_tail(const float* xt, const float* sorted, int T, int O, int K, const float* scale, const float* zp, int P,
+                               int a_bits, const void* workspace, double norm, double* qpart, float* scores,
+                               const adalog_fpcs_tail* tail, void* stream);
 
 /* ---- K9   _search_best_w_scale_self                                   reference linear.py:296-309
  * scores[p][row] = -mean_i (w[row][i] - fq_p(w[row][i]))^2,  w: [rows][I], scale/zp: [P][rows]. */
@@ -331,6 +360,10 @@ int adalog_sorted_prefix_build(const float* x, int64_t S, int64_t n, float* sort
                                int64_t workspace_bytes, void* stream);
 int adalog_score_self_sorted(const float* sorted, const double* prefix, int64_t S, int64_t n, const float* scale,
                              const float* zp, int P, int n_bits, double norm, float* scores, void* stream);
+/* ... and the FPCS step's tail in the same launch: a ticket per segment (tail may be null; its grid is (scale, zp); S <= 65536) */
+int adalog_score_self_sorted_tail(const float* sorted, const double* prefix, int64_t S, int64_t n, const float* scale,
+                                  const float* zp, int P, int n_bits, double norm, float* scores, const adalog_fpcs_tail* tail,
+                                  void* stream);
 
 /* ---- K5/K6  exact order statistics by radix select
  * adalog_quantile_rows: torch.quantile(x.view(S, n), q, dim=-1, interpolation='linear') for nq <= 4 quantiles, then the mean
