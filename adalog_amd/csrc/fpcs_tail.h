@@ -1,8 +1,14 @@
 // The tail of an FPCS step -- rank the P scores of a column, then write the next 16 x 8 candidate grid around the k survivors or
-// commit the winner (reference quant_layers/linear.py:483-523, matmul.py:243-262, conv.py:292-311) -- as DEVICE code that any kernel
-// producing final scores can run itself: the last workgroup (or wave) to finish a column draws the column's ticket and ranks it, so a
-// step is ONE launch (round 6: the Gram score kernels, the sorted self-MSE kernel and the Gram activation finish each handed their
-// scores to a separate k_topk_next launch -- 2 172 launches of ~11 us per deit_small calibration for microseconds of work).
+// commit the winner (reference quant_layers/linear.py:483-523, matmul.py:243-262, conv.py:292-311) -- as DEVICE code plus its
+// arguments as a C struct, shared by every kernel that ends a step: k_topk_next (stand-alone), the finish kernels of the token forms
+// (gemm_finish.inc: k_finish_tpo_topk / k_finish_wgacc_topk) and k_score_sorted_col (a workgroup per score column of the per-channel /
+// per-row self-MSE searches).  The struct carries what round 6 changed for ALL of them: the grid spacing is read from `delta_in` and
+// written to `delta_out` (the memoised spacing is never cloned), and the commit step writes the winner straight into the quantiser's
+// parameter storage (no copy_ launches afterwards).
+// What was measured and NOT kept (same-box A/Bs, profiles/r06_notes.md): running the tail inside k_gram_score (a ticket per output row)
+// and inside k_ga_finish / a one-workgroup k_score_sorted for the per-tensor searches -- on this multi-XCD part an agent-scope ticket
+// or score read is a ~2 us round trip, and one workgroup cannot issue a step's 2 176 divergent bisection loads as fast as eight can:
+// each lost to the separate 11 us k_topk_next launch.  score_publish / ticket_last below serve k_sel_hist_pick (select.hip).
 // Same deterministic order everywhere: score descending, candidate index ascending, NaN first (torch.topk with ties made
 // deterministic).
 #pragma once
@@ -81,14 +87,17 @@ __device__ __forceinline__ void emit(const int* top, int cols, int col, int gt, 
 // __syncthreads) or GT = 64 with WAVE = true (one wavefront: its lanes run in lockstep, the LDS traffic only needs to have landed).
 // `s` (>= P floats) and `top` (>= k ints) are LDS scratch of the group.  The scores are read at agent scope: other workgroups wrote
 // them and announced it through the column's ticket (score_publish / ticket_last below).
-template <int GT, bool WAVE>
+template <int GT, bool WAVE, bool COHERENT = true>
 __device__ __forceinline__ void column(const float* scores, int P, int cols, int col, int gt, const Tail& t, float* s, int* top) {
     auto sync = [&]() {
         if constexpr (WAVE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
         else __syncthreads();
     };
-    for (int p = gt; p < P; p += GT)
-        s[p] = __hip_atomic_load(scores + (int64_t)p * cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int p = gt; p < P; p += GT) {
+        // COHERENT: other workgroups of THIS launch wrote the scores (agent-scope loads); a stand-alone launch reads them plainly
+        if constexpr (COHERENT) s[p] = __hip_atomic_load(scores + (int64_t)p * cols + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else s[p] = scores[(int64_t)p * cols + col];
+    }
     const float d = t.new_cnt > 0 ? t.delta_in[col] : 0.0f;
     sync();
     for (int p = gt; p < P; p += GT) {

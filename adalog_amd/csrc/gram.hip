@@ -247,11 +247,7 @@ struct GramScoreArgs {
     float* scores;                             // [P][O]
     int nblk;                                  // O * P / 32
     long long* timeline;                       // lab only (tools/lab/gram_check.py): cycle stamps of wave 0 of each workgroup, else null
-    // the FPCS step's tail in the same launch (fpcs_tail.h): a ticket per output row; the wave that stores the last of a row's P / 32
-    // blocks ranks the row's P scores and writes its next grid / commits its winner (after its last pass: no other wave waits for it)
-    int has_tail; fpcs::Tail tail; unsigned int* tickets;
 };
-constexpr int GRAM_PEND = 63;                  // rows a wave may have waiting for their tail (the host checks the plan against it)
 
 // One pass of a wave over NB (<= CB) blocks of 32 candidates; every wave of the workgroup runs the same panel sequence (NB = 0: it
 // only helps moving the panels).  Two workgroups share a CU and run unsynchronised: one's row dots (VALU) issue under the other's MFMAs.
@@ -260,8 +256,7 @@ constexpr int GRAM_PEND = 63;                  // rows a wave may have waiting f
 // the K chunks [COOP NJ/4, (COOP + 1) NJ/4).  The row dot is linear in the accumulators, so each wave applies it to its partial
 // products and only the per-candidate sums (quad, lin) are added across the waves at the end.
 template <int NJ, int NB, bool BIG, bool TIE, int COOP = -1>
-__device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, int blk0, int w, int lane, float sa, int stamp_slot,
-                                          int* pend) {
+__device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, int blk0, int w, int lane, float sa, int stamp_slot) {
     constexpr bool CO = COOP >= 0;
     constexpr int QN = CO ? NJ / 4 : NJ;                   // K chunks this wave multiplies
     constexpr int J0 = CO ? COOP * (NJ / 4) : 0;           // ... starting here
@@ -493,20 +488,8 @@ __device__ __forceinline__ void gram_pass(const GramScoreArgs& p, uint8_t* lds, 
             const double tot = p.s0[o] - 2.0 * s * (lin[b] * p.cscl[o]) + s * s * q;
             const int blk = blk0 + b;
             const int cand = (blk - o * PB) * 32 + c;
-            if (h == 0) {
-                if (p.has_tail) fpcs::score_publish(p.scores + (int64_t)cand * p.O + o, (float)(-p.norm * tot));
-                else p.scores[(int64_t)cand * p.O + o] = (float)(-p.norm * tot);
-            }
+            if (h == 0) p.scores[(int64_t)cand * p.O + o] = (float)(-p.norm * tot);
         });
-        if (p.has_tail) {
-            fpcs::publish_wait();                           // this wave's scores are at the coherence point: draw the rows' tickets
-            if (lane == 0) {                                // rows this wave completed wait in its LDS list (pend[0] = how many)
-                static_for<NB>([&](auto bc) {
-                    const int o = orow[decltype(bc)::value];
-                    if (fpcs::ticket_last(p.tickets + o, (unsigned)PB)) { const int n = pend[0]; pend[1 + n] = o; pend[0] = n + 1; }
-                });
-            }
-        }
     }
     GRAM_STAMP(4);
 #undef GRAM_STAMP
@@ -521,11 +504,6 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
     const int nwg = gridDim.x;
     const int b_begin = (int)(((int64_t)p.nblk * blockIdx.x) / nwg), b_end = (int)(((int64_t)p.nblk * (blockIdx.x + 1)) / nwg);
     const float sa = p.sa[0];
-    __shared__ float tail_s_all[4][256];
-    __shared__ int tail_top_all[4][32];
-    __shared__ int pend_all[4][GRAM_PEND + 1];
-    int* pend = pend_all[w];
-    if (lane == 0) pend[0] = 0;
     int pass_no = 0;
     for (int pass0 = b_begin; pass0 < b_end; pass0 += 4 * CB, ++pass_no) {
         const int n = min(4 * CB, b_end - pass0);
@@ -537,10 +515,10 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
             if (n <= CB) {                                 // the thin tail: all four waves on the same n blocks, K split four ways
 #define GRAM_COOP(NBV)                                                                                            \
                 do {                                                                                              \
-                    if (w == 0) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 0>(p, lds, pass0, w, lane, sa, slot, pend);     \
-                    else if (w == 1) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 1>(p, lds, pass0, w, lane, sa, slot, pend); \
-                    else if (w == 2) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 2>(p, lds, pass0, w, lane, sa, slot, pend); \
-                    else gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 3>(p, lds, pass0, w, lane, sa, slot, pend);            \
+                    if (w == 0) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 0>(p, lds, pass0, w, lane, sa, slot);     \
+                    else if (w == 1) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 1>(p, lds, pass0, w, lane, sa, slot); \
+                    else if (w == 2) gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 2>(p, lds, pass0, w, lane, sa, slot); \
+                    else gram_pass<NJ, NBV, BIG, WGS_PER_CU == 2, 3>(p, lds, pass0, w, lane, sa, slot);            \
                 } while (0)
                 if (n == 1) GRAM_COOP(1);
                 else if (CB >= 2 && n == 2) GRAM_COOP((CB >= 2 ? 2 : 1));
@@ -552,20 +530,11 @@ __global__ __launch_bounds__(256, WGS_PER_CU) void k_gram_score(GramScoreArgs p)
         }
         const int nbw = n / 4 + (w < (n & 3) ? 1 : 0);     // this wave's blocks (wave-uniform)
         const int blk0 = pass0 + w * (n / 4) + min(w, n & 3);
-        if (nbw == CB) gram_pass<NJ, CB, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
-        else if (nbw == 0) gram_pass<NJ, 0, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
-        else if (nbw == 1) gram_pass<NJ, 1, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
-        else if (CB > 2 && nbw == 2) gram_pass<NJ, (CB > 2 ? 2 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
-        else if (CB > 3 && nbw == 3) gram_pass<NJ, (CB > 3 ? 3 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot, pend);
-    }
-    if (p.has_tail) {                                       // the rows this wave completed: rank, next grid / commit (fpcs_tail.h)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int npend = __builtin_amdgcn_readfirstlane(pend[0]);
-#pragma unroll 1
-        for (int i = 0; i < npend; ++i)
-            fpcs::column<64, true>(p.scores, p.P, p.O, __builtin_amdgcn_readfirstlane(pend[1 + i]), lane, p.tail, tail_s_all[w], tail_top_all[w]);
+        if (nbw == CB) gram_pass<NJ, CB, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (nbw == 0) gram_pass<NJ, 0, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (nbw == 1) gram_pass<NJ, 1, BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (CB > 2 && nbw == 2) gram_pass<NJ, (CB > 2 ? 2 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
+        else if (CB > 3 && nbw == 3) gram_pass<NJ, (CB > 3 ? 3 : 1), BIG, WGS_PER_CU == 2>(p, lds, blk0, w, lane, sa, slot);
     }
 #endif
 }
@@ -588,6 +557,73 @@ static int g_limbs(int64_t T, int a_bits) {
         cover = cover * 256.0 + 127.0;
     }
     return 8;
+}
+
+// ---- image-sharded build (several ranks hold disjoint token ranges): the integer sums are additive over tokens, so every rank forms
+// its own G and c as int64, the ranks all-reduce them (exact), and the limbs are cut from the GLOBAL sums.
+// gsum [K][K] = sum of the split partials (plain row-major)
+__global__ __launch_bounds__(256) void k_gram_sum_g(const int* __restrict__ part, int splits, int K, long long* __restrict__ gsum) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)K * K) return;
+    long long g = 0;
+    for (int z = 0; z < splits; ++z) g += (long long)part[(int64_t)z * K * K + idx];
+    gsum[idx] = g;
+}
+
+// csum [O][K] = the recombined limb products; s0 [O] = the chunks' shares in a fixed order
+__global__ __launch_bounds__(256) void k_gram_sum_c(const int* __restrict__ part, int splits, int O, int K, long long* __restrict__ csum,
+                                                    const double* __restrict__ s0p, int nchunk, double* __restrict__ s0) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < O) {
+        double t = 0.0;
+        for (int ch = 0; ch < nchunk; ++ch) t += s0p[idx * nchunk + ch];
+        s0[idx] = t;
+    }
+    if (idx >= (int64_t)O * K) return;
+    const int o = (int)(idx / K), k = (int)(idx % K);
+    long long c = 0;
+    for (int z = 0; z < splits; ++z)
+#pragma unroll
+        for (int l = 0; l < RLIMBS; ++l) c += ((long long)part[((int64_t)z * RLIMBS * O + (int64_t)l * O + o) * K + k]) << (8 * l);
+    csum[idx] = c;
+}
+
+// global sums -> the score kernel's operands: G limbs in fragment order (as k_gram_fin_g), c limbs (as k_gram_fin_c), S0, 2^-e
+__global__ __launch_bounds__(256) void k_gram_limbs_g(const long long* __restrict__ gsum, int K, int NL, int8_t* __restrict__ gfrag) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)K * K) return;
+    const int col = (int)(idx % K), slot = (int)(idx / K);
+    const int kt = slot >> 5, rp = slot & 31;
+    const int row = 32 * kt + 16 * ((rp >> 2) & 1) + 4 * (rp >> 3) + (rp & 3);
+    const int nj = K >> 5, jt = col >> 5, h = (col >> 4) & 1, e = col & 15;
+    long long rest = gsum[(int64_t)row * K + col];
+    for (int l = 0; l < NL; ++l) {
+        const int d = (int)(int8_t)(rest & 0xff);
+        gfrag[((((int64_t)l * nj + kt) * nj + jt) * 64 + (rp + 32 * h)) * 16 + e] = (int8_t)d;
+        rest = (rest - d) >> 8;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_gram_limbs_c(const long long* __restrict__ csum, int O, int K, int8_t* __restrict__ clim,
+                                                      const double* __restrict__ s0_in, const unsigned int* __restrict__ amax,
+                                                      double* __restrict__ s0, double* __restrict__ cscl) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < O) {
+        s0[idx] = s0_in[idx];
+        const float am = __uint_as_float(amax[idx]);
+        int e = 0;
+        if (am > 0.0f && am < 3.0e38f) e = RFIX_BITS - ilogbf(am);           // (the exponent k_gram_rfix used)
+        cscl[idx] = ldexp(1.0, -e);
+    }
+    if (idx >= (int64_t)O * K) return;
+    const int o = (int)(idx / K), k = (int)(idx % K);
+    long long rest = csum[idx];
+#pragma unroll
+    for (int l = 0; l < CLIMBS; ++l) {
+        const int d = (int)(int8_t)(rest & 0xff);
+        clim[((int64_t)o * CLIMBS + l) * K + k] = (int8_t)d;
+        rest = (rest - d) >> 8;
+    }
 }
 
 static int64_t al256(int64_t v) { return (v + 255) / 256 * 256; }
@@ -707,6 +743,71 @@ extern "C" int adalog_gram_build(const float* x, int T, int K, int64_t ldx, cons
     return 0;
 }
 
+/* ---- the same build for calibration images SHARDED over ranks, in three calls with the collectives between them:
+ *   adalog_gram_amax        amax[o] = bits of max_t |raw_out[t][o] - bias[o]| over THIS rank's tokens  -> all-reduce MAX (as int32)
+ *   adalog_gram_build_sums  with the GLOBAL amax: gsum [K][K], csum [O][K] (int64) and s0 [O] (fp64) of this rank's tokens
+ *                           -> all-reduce SUM of the three (integers: exact; s0: the same bits on every rank)
+ *   adalog_gram_build_from_sums  -> the workspace adalog_gram_score_w reads, for T = the GLOBAL token count (limbs of G sized for it)
+ * After that every rank scores the SAME final scores from the same state: an FPCS step needs no collective at all (six score
+ * all-reduces per weight_fpcs call before), and adalog_gram_ok is asked with the global token count. */
+extern "C" int adalog_gram_amax(const float* ref_t, int T, int O, const float* bias, unsigned int* amax, void* stream) {
+    ADALOG_ARG_CHECK(ref_t && amax && T >= 1 && O >= 1, "gram_amax: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const hipError_t me = hipMemsetAsync(amax, 0, (size_t)O * 4, st);
+    if (me != hipSuccess) { adalog_set_error("adalog_gram_amax (clear)", me); return (int)me; }
+    const int chunk = 8192, nchunk = (T + chunk - 1) / chunk;
+    hipLaunchKernelGGL(k_gram_rmax, dim3((unsigned)O, (unsigned)nchunk), dim3(256), 0, st, ref_t, T, chunk, bias, amax);
+    ADALOG_LAUNCH_CHECK("adalog_gram_amax");
+    return 0;
+}
+
+extern "C" int adalog_gram_build_sums(const float* x, int T, int K, int64_t ldx, const float* sa, const float* za, int a_bits,
+                                      const float* ref_t, int O, const float* bias, const unsigned int* amax, long long* gsum,
+                                      long long* csum, double* s0, void* ws, int64_t ws_bytes, void* stream) {
+    ADALOG_ARG_CHECK(x && sa && za && ref_t && amax && gsum && csum && s0 && ws, "gram_build_sums: null pointer");
+    const GramPlan g = gram_plan(T, O, K, a_bits);
+    ADALOG_ARG_CHECK(g.ok, "gram_build_sums: shape not supported");
+    ADALOG_ARG_CHECK(ws_bytes >= g.total, "gram_build_sums: workspace too small (adalog_gram_workspace_bytes of the LOCAL shape)");
+    ADALOG_ARG_CHECK(ldx >= K && ldx % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 255) == 0, "gram_build_sums: x rows / workspace must be aligned");
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* base = (uint8_t*)ws;
+    int8_t* xt = (int8_t*)(base + g.off_xt);
+    int8_t* rl = (int8_t*)(base + g.off_rl);
+    int* gpart = (int*)(base + g.off_gpart);
+    int* cpart = (int*)(base + g.off_cpart);
+    double* s0p = (double*)(base + g.off_s0p);
+    hipLaunchKernelGGL(k_gram_pack_xt, dim3((unsigned)(g.Tp / 64), (unsigned)((K + 63) / 64)), dim3(256), 0, st, x, T, K, ldx, sa, za,
+                       (float)((1 << a_bits) - 1), xt, g.Tp);
+    hipLaunchKernelGGL(k_gram_rfix, dim3((unsigned)O, (unsigned)g.r_nchunk), dim3(256), 0, st, ref_t, T, g.Tp, O, g.r_chunk, g.r_nchunk, bias,
+                       amax, rl, s0p, (double*)(base + g.off_cscl));
+    const unsigned tk = (unsigned)((K + 32 * MM_BJ - 1) / (32 * MM_BJ));
+    hipLaunchKernelGGL(k_i8mm, dim3((unsigned)((K + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sg_splits), dim3(256), 0, st,
+                       xt, xt, K, K, g.Tp, g.sg_steps, g.steps_total, gpart);
+    hipLaunchKernelGGL(k_i8mm, dim3((unsigned)((RLIMBS * O + 32 * MM_BI - 1) / (32 * MM_BI)), tk, (unsigned)g.sc_splits), dim3(256), 0,
+                       st, rl, xt, RLIMBS * O, K, g.Tp, g.sc_steps, g.steps_total, cpart);
+    hipLaunchKernelGGL(k_gram_sum_g, dim3((unsigned)(((int64_t)K * K + 255) / 256)), dim3(256), 0, st, gpart, g.sg_splits, K, gsum);
+    hipLaunchKernelGGL(k_gram_sum_c, dim3((unsigned)(((int64_t)O * K + 255) / 256)), dim3(256), 0, st, cpart, g.sc_splits, O, K, csum,
+                       s0p, g.r_nchunk, s0);
+    ADALOG_LAUNCH_CHECK("adalog_gram_build_sums");
+    return 0;
+}
+
+extern "C" int adalog_gram_build_from_sums(const long long* gsum, const long long* csum, const double* s0, const unsigned int* amax,
+                                           int T_total, int O, int K, int a_bits, void* ws, int64_t ws_bytes, void* stream) {
+    ADALOG_ARG_CHECK(gsum && csum && s0 && amax && ws, "gram_build_from_sums: null pointer");
+    const GramPlan g = gram_plan(T_total, O, K, a_bits);
+    ADALOG_ARG_CHECK(g.ok && nj_supported(g.NJ), "gram_build_from_sums: shape not supported (adalog_gram_supported)");
+    ADALOG_ARG_CHECK(ws_bytes >= g.total && ((uintptr_t)ws & 255) == 0, "gram_build_from_sums: workspace too small / misaligned");
+    hipStream_t st = (hipStream_t)stream;
+    uint8_t* base = (uint8_t*)ws;
+    hipLaunchKernelGGL(k_gram_limbs_g, dim3((unsigned)(((int64_t)K * K + 255) / 256)), dim3(256), 0, st, gsum, K, g.NL,
+                       (int8_t*)(base + g.off_gfrag));
+    hipLaunchKernelGGL(k_gram_limbs_c, dim3((unsigned)(((int64_t)O * K + 255) / 256)), dim3(256), 0, st, csum, O, K,
+                       (int8_t*)(base + g.off_clim), s0, amax, (double*)(base + g.off_s0), (double*)(base + g.off_cscl));
+    ADALOG_LAUNCH_CHECK("adalog_gram_build_from_sums");
+    return 0;
+}
+
 static long long* g_gram_timeline = nullptr;
 // lab only: cycle stamps [workgroup][pass < 2][8] of the next adalog_gram_score_w launches (null switches them off)
 extern "C" void adalog_gram_set_timeline(long long* buf) { g_gram_timeline = buf; }
@@ -715,17 +816,9 @@ static int device_cus_gram() { return adalog_device_cus(); }   // per device ord
 
 /* One FPCS step: scores [P][O] = -norm * sum_t (raw_out - b - q_a(x) . fq_p(W)^T)^2 for the P candidates (scale, zp) [P][O] of every
  * output row, from the workspace adalog_gram_build left.  W fp32 [O][ldw].  (T, O, K, a_bits) must be those of the build. */
-extern "C" int adalog_gram_score_w_tail(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
-                                        const void* ws, int T, int a_bits, const float* sa, double norm, float* scores,
-                                        const adalog_fpcs_tail* tail, void* stream) {
+extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
+                                   const void* ws, int T, int a_bits, const float* sa, double norm, float* scores, void* stream) {
     ADALOG_ARG_CHECK(W && scale && zp && ws && sa && scores, "gram_score_w: null pointer");
-    const char* why = fpcs::tail_problem(tail, P);
-    ADALOG_ARG_CHECK(why == nullptr, why);
-    ADALOG_ARG_CHECK(!tail || (tail->k <= 32 && O <= 65536), "gram_score_w: the fused tail takes k <= 32, O <= 65536");
-    // a wave lists the rows it completed (GRAM_PEND entries): at most one per block it stores, <= ceil(blocks per workgroup / 4) + 2 passes' worth
-    ADALOG_ARG_CHECK(!tail || ((int64_t)O * P / 32 + 255) / 256 / 4 + 8 <= GRAM_PEND, "gram_score_w: too many blocks per wave for the fused tail");
-    unsigned int* tickets = tail ? adalog_ticket_pool_on(O, stream) : nullptr;
-    ADALOG_ARG_CHECK(!tail || tickets, "gram_score_w: no ticket counters");
     ADALOG_ARG_CHECK(adalog_gram_supported(T, O, K, a_bits, w_bits, P), "gram_score_w: shape not supported (adalog_gram_supported)");
     ADALOG_ARG_CHECK(ldw >= K && ldw % 4 == 0 && ((uintptr_t)W & 15) == 0, "gram_score_w: weight rows must be 16-byte aligned");
     const GramPlan g = gram_plan(T, O, K, a_bits);
@@ -736,8 +829,6 @@ extern "C" int adalog_gram_score_w_tail(const float* W, int O, int K, int64_t ld
     a.gfrag = (const int8_t*)(base + g.off_gfrag); a.NL = g.NL; a.clim = (const int8_t*)(base + g.off_clim);
     a.s0 = (const double*)(base + g.off_s0); a.cscl = (const double*)(base + g.off_cscl);
     a.sa = sa; a.norm = norm; a.scores = scores;
-    a.has_tail = tail ? 1 : 0; a.tickets = tickets;
-    if (tail) a.tail = *tail;
     a.qmax = (float)((1 << w_bits) - 1);
     const float zone = 6e-7f * (float)(1 << w_bits);
     a.tie = 0.5f - (zone > 1e-5f ? zone : 1e-5f);
@@ -776,7 +867,19 @@ extern "C" int adalog_gram_score_w_tail(const float* W, int O, int K, int64_t ld
     return 0;
 }
 
-extern "C" int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
-                                   const void* ws, int T, int a_bits, const float* sa, double norm, float* scores, void* stream) {
-    return adalog_gram_score_w_tail(W, O, K, ldw, scale, zp, P, w_bits, ws, T, a_bits, sa, norm, scores, nullptr, stream);
+extern "C" int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream);
+
+// adalog_gram_score_w followed by the FPCS step's tail (`tail` may be null).  The tail is a SECOND launch here (adalog_topk_next_tail):
+// run inside k_gram_score -- a ticket per output row, the wave / workgroup storing a row's last block ranks it -- it cost 25 us per
+// launch (agent-scope ticket round trips of ~2 us per pass, then ~2 rows of tails at the end of every workgroup) against the 11 us of
+// the separate launch (round 6, same-box A/B 875 against 852 ms per calibration); a workgroup per complete row would unbalance the
+// 9-blocks-per-workgroup split.
+extern "C" int adalog_gram_score_w_tail(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
+                                        const void* ws, int T, int a_bits, const float* sa, double norm, float* scores,
+                                        const adalog_fpcs_tail* tail, void* stream) {
+    const char* why = fpcs::tail_problem(tail, P);
+    ADALOG_ARG_CHECK(why == nullptr, why);
+    const int rc = adalog_gram_score_w(W, O, K, ldw, scale, zp, P, w_bits, ws, T, a_bits, sa, norm, scores, stream);
+    if (rc || !tail) return rc;
+    return adalog_topk_next_tail(scores, P, O, tail, nullptr, stream);
 }

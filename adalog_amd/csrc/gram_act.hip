@@ -43,6 +43,8 @@
 
 #include <hipcub/hipcub.hpp>
 
+extern "C" int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream);
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -763,11 +765,10 @@ template <int G>
 __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sorted, const double* __restrict__ prefix, int64_t n,
                                                    const float* __restrict__ scale, const float* __restrict__ zp, int P, float qmax,
                                                    const double* __restrict__ qpart, int S, const double* __restrict__ s0, double norm,
-                                                   float* __restrict__ scores, int has_tail, fpcs::Tail tail, unsigned int* ticket) {
+                                                   float* __restrict__ scores) {
     constexpr int GPB = 256 / G;
     __shared__ int64_t bnd[GPB][G + 1];
     __shared__ double red[256];
-    __shared__ int is_last;
     const int gi = threadIdx.x / G, t = threadIdx.x % G;
     const int cand = blockIdx.x * GPB + gi;
     const bool live = cand < P;
@@ -813,20 +814,8 @@ __global__ __launch_bounds__(256) void k_ga_finish(const float* __restrict__ sor
     }
     if (live && t == 0) {
         const double sd = (double)s;
-        const float v = (float)(-norm * (s0v - 2.0 * sd * red[threadIdx.x] + sd * sd * quad));
-        if (has_tail) { fpcs::score_publish(scores + cand, v); fpcs::publish_wait(); }
-        else scores[cand] = v;
+        scores[cand] = (float)(-norm * (s0v - 2.0 * sd * red[threadIdx.x] + sd * sd * quad));
     }
-    if (!has_tail) return;
-    // the FPCS step's tail in the same launch (fpcs_tail.h): the last of the launch's blocks ranks the P scores of the one column
-    // and writes the next grid / the committed winner
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = fpcs::ticket_last(ticket, gridDim.x) ? 1 : 0;
-    __syncthreads();
-    if (!is_last) return;
-    float* sc = reinterpret_cast<float*>(red);                 // 256 floats + 256 ints of the dead reduction buffer
-    int* top = reinterpret_cast<int*>(red) + 256;
-    fpcs::column<256, false>(scores, P, 1, 0, (int)threadIdx.x, tail, sc, top);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -1008,8 +997,7 @@ extern "C" int adalog_gram_act_score_tail(const float* xt, const float* sorted, 
     ADALOG_ARG_CHECK(xt && sorted && scale && zp && ws && qpart && scores, "gram_act_score: null pointer");
     const char* why = fpcs::tail_problem(tail, P);
     ADALOG_ARG_CHECK(why == nullptr, why);
-    unsigned int* ticket = tail ? adalog_ticket_pool_on(1, stream) : nullptr;
-    ADALOG_ARG_CHECK(!tail || ticket, "gram_act_score: no ticket counter");
+
     ADALOG_ARG_CHECK(adalog_gram_act_supported(T, O, K, a_bits, a_bits, P), "gram_act_score: shape not supported (adalog_gram_act_supported)");
     const GaPlan g = ga_plan(T, O, K, P);
     const uint8_t* base = (const uint8_t*)ws;
@@ -1056,8 +1044,7 @@ extern "C" int adalog_gram_act_score_tail(const float* xt, const float* sorted, 
     const int G = 1 << a_bits;
     const int gpb = 256 / G;
     const unsigned blocks = (unsigned)((P + gpb - 1) / gpb);
-    const fpcs::Tail tl = tail ? *tail : fpcs::Tail{};
-#define GA_FIN(GV) hipLaunchKernelGGL((k_ga_finish<GV>), dim3(blocks), dim3(256), 0, st, sorted, prefix, g.n, scale, zp, P, a.qmax, qpart, g.QS, s0, norm, scores, tail ? 1 : 0, tl, ticket)
+#define GA_FIN(GV) hipLaunchKernelGGL((k_ga_finish<GV>), dim3(blocks), dim3(256), 0, st, sorted, prefix, g.n, scale, zp, P, a.qmax, qpart, g.QS, s0, norm, scores)
     switch (a_bits) {
         case 2: GA_FIN(4); break;
         case 3: GA_FIN(8); break;
@@ -1068,6 +1055,11 @@ extern "C" int adalog_gram_act_score_tail(const float* xt, const float* sorted, 
     }
 #undef GA_FIN
     ADALOG_LAUNCH_CHECK("adalog_gram_act_score");
+    // the FPCS step's tail: a second launch.  Both in-launch forms were measured and lost (round 6): the last of the finish kernel's
+    // eight workgroups ranking by ticket (26.9 us against 17.9 + 10.8: the agent-scope ticket and score reads are ~2 us round trips
+    // each), and ONE workgroup of 1 024 threads taking all 2 176 bisections (36.6 us: a single CU's address path serialises the
+    // divergent loads)
+    if (tail) return adalog_topk_next_tail(scores, P, 1, tail, nullptr, stream);
     return 0;
 }
 

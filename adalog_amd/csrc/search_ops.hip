@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_topk_next(const float* __restrict__ sco
     __shared__ float s[256];
     __shared__ int top[256];
     const int col = blockIdx.x;
-    fpcs::column<256, false>(scores, P, cols, col, (int)threadIdx.x, t, s, top);
+    fpcs::column<256, false, false>(scores, P, cols, col, (int)threadIdx.x, t, s, top);
     if (idx_out && (int)threadIdx.x < t.k) idx_out[(int64_t)threadIdx.x * cols + col] = top[threadIdx.x];
 }
 

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void k_sel_hist_pick(const float* __restrict__
         const unsigned c = pass == 0 ? h[0][i & 255] : (&h[0][0])[i];
         if (c) __hip_atomic_fetch_add(gh + i, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __threadfence();                                       // this block's counts are visible device-wide before its ticket is drawn
+    // (agent-scope atomics are performed at the coherence point: once they have returned -- vmcnt -- the counts are visible to the
+    // segment's last block; a __threadfence() here writes back the XCD's whole L2 and cost 35 us per pass)
     fpcs::publish_wait();
     __syncthreads();
     if (threadIdx.x == 0) is_last = fpcs::ticket_last(tickets + seg, gridDim.x) ? 1 : 0;

@@ -20,8 +20,11 @@
 // rounds every (x - c) and every square to fp32 -- agreement ~1e-7 relative, inside the 1e-4 bar of the parity tests.
 #include "common.h"
 #include "fpcs_tail.h"
+#include <stdlib.h>
 
 #include <hipcub/hipcub.hpp>
+
+extern "C" int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream);
 
 namespace {
 
@@ -130,12 +133,10 @@ __global__ __launch_bounds__(256) void k_sp_prefix(const float* __restrict__ sor
 template <int G>
 __global__ __launch_bounds__(256) void k_score_sorted(const float* __restrict__ sorted, const d2* __restrict__ prefix, int64_t S,
                                                       int64_t n, const float* __restrict__ scale, const float* __restrict__ zp,
-                                                      int P, float qmax, double norm, float* __restrict__ scores, int has_tail,
-                                                      fpcs::Tail tail, unsigned int* tickets) {
+                                                      int P, float qmax, double norm, float* __restrict__ scores) {
     constexpr int GPB = 256 / G;
     __shared__ int64_t bnd[GPB][G + 1];
     __shared__ double red[256];
-    __shared__ int last_col[GPB];
     const int gi = threadIdx.x / G, t = threadIdx.x % G;
     const int64_t pair = (int64_t)blockIdx.x * GPB + gi;               // = p * S + seg
     const bool live = pair < (int64_t)P * S;
@@ -176,32 +177,112 @@ __global__ __launch_bounds__(256) void k_score_sorted(const float* __restrict__ 
         if (t < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (t == 0) {
-        int lc = -1;
-        if (live) {
-            const float v = (float)(-norm * red[threadIdx.x]);
-            if (has_tail) {
-                // the FPCS step's tail in the same launch (fpcs_tail.h): a ticket per segment (= score column); the last of its P
-                // candidates to arrive has the block rank the column and write its next grid / commit its winner
-                fpcs::score_publish(scores + pair, v);
-                fpcs::publish_wait();
-                if (fpcs::ticket_last(tickets + seg, (unsigned)P)) lc = (int)seg;
-            } else {
-                scores[pair] = v;
+    if (live && t == 0) scores[pair] = (float)(-norm * red[threadIdx.x]);
+}
+
+// The same scores with the FPCS step's tail in the launch (round 6; fpcs_tail.h): ONE workgroup of 1024 threads per segment holds
+// all P candidates of its score column -- P x G (candidate, level) bisections, thread-strided -- so it ranks the column in LDS and
+// writes the column's next grid / commits its winner itself: no ticket, no second launch (k_topk_next before: 660 launches per
+// deit_small calibration).  Same arithmetic and the same fixed-order tree over a candidate's G run sums as k_score_sorted: the scores
+// are bit-identical.  LDS: bnd int32 [P][G + 1], acc double [P][G], scores float [P], top int [P].
+template <int G>
+__global__ __launch_bounds__(1024) void k_score_sorted_col(const float* __restrict__ sorted, const d2* __restrict__ prefix, int64_t S,
+                                                          int64_t n, const float* __restrict__ scale, const float* __restrict__ zp,
+                                                          int P, float qmax, double norm, float* __restrict__ scores, fpcs::Tail tail) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double* acc = reinterpret_cast<double*>(lds_raw);                   // [P][G]
+    int* bnd = reinterpret_cast<int*>(acc + (size_t)P * G);             // [P][G + 1]
+    float* sc = reinterpret_cast<float*>(bnd + (size_t)P * (G + 1));    // [P]
+    int* top = reinterpret_cast<int*>(sc + P);                          // [P]
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    const float* x = sorted + (int64_t)seg * n;
+    const d2* pf = prefix + (int64_t)seg * (n + 1);
+    const int ni = (int)n;
+    // boundaries: item (p, t), t = 0 .. G (t = G: the upper clamped run's start); a thread walks FOUR bisections in lockstep -- the
+    // launch is a chain of dependent far-memory round trips, so the items of a thread must overlap, not queue (one after the other
+    // they made this kernel slower than the eight-workgroup form plus a separate k_topk_next)
+    for (int base = 0; base < P * (G + 1); base += 4 * 1024) {
+        int lo[4], hi[4], idx[4];
+        float sv[4], tg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = base + u * 1024 + tid;
+            idx[u] = it < P * (G + 1) ? it : -1;
+            lo[u] = 0; hi[u] = idx[u] >= 0 ? ni : 0;
+            sv[u] = 1.0f; tg[u] = 0.0f;
+            if (idx[u] >= 0) {
+                const int p = it / (G + 1), t = it - p * (G + 1);
+                const float s = scale[(int64_t)p * S + seg], z = zp[(int64_t)p * S + seg];
+                const float klo = ceilf(-z), khi = floorf(qmax - z);
+                sv[u] = s;
+                tg[u] = t == G ? khi + 1.0f : fminf(klo + (float)t, khi + 1.0f);
             }
         }
-        last_col[gi] = lc;
+        for (int step = 0; step < 32; ++step) {
+            float xv[4];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool a = lo[u] < hi[u];
+                any |= a;
+                xv[u] = a ? x[(int)(((unsigned)lo[u] + (unsigned)hi[u]) >> 1)] : 0.0f;
+            }
+            if (!any) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (lo[u] < hi[u]) {
+                    const int mid = (int)(((unsigned)lo[u] + (unsigned)hi[u]) >> 1);
+                    if (rintf(xv[u] / sv[u]) >= tg[u]) hi[u] = mid; else lo[u] = mid + 1;     // first i with rne(x[i] / s) >= target
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (idx[u] >= 0) bnd[idx[u]] = lo[u];
     }
-    if (!has_tail) return;
     __syncthreads();
-    float* sc = reinterpret_cast<float*>(red);                 // 256 floats + 256 ints of the dead reduction buffer
-    int* top = reinterpret_cast<int*>(red) + 256;
-#pragma unroll 1
-    for (int g2 = 0; g2 < GPB; ++g2) {
-        const int col = last_col[g2];
-        if (col < 0) continue;
-        fpcs::column<256, false>(scores, P, (int)S, col, (int)threadIdx.x, tail, sc, top);
+    for (int it = tid; it < P * G; it += 1024) {
+        const int p = it / G, t = it - p * G;
+        const float s = scale[(int64_t)p * S + seg], z = zp[(int64_t)p * S + seg];
+        const float klo = ceilf(-z), khi = floorf(qmax - z);
+        const int* bp = bnd + p * (G + 1);
+        auto run = [&](int a, int b, float level) {
+            if (b <= a) return 0.0;
+            const float q = fminf(fmaxf(level + z, 0.0f), qmax);
+            const double c = (double)((q - z) * s);
+            const d2 pa = pf[a], pb = pf[b];
+            return (pb.y - pa.y) - 2.0 * c * (pb.x - pa.x) + (double)(b - a) * c * c;
+        };
+        double a = run(bp[t], bp[t + 1], klo + (float)t);
+        if (t == 0) a += run(0, bp[0], klo - 1.0f) + run(bp[G], ni, khi + 1.0f);
+        acc[it] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {                               // the fixed-order tree of k_score_sorted, per candidate
+        for (int it = tid; it < P * o; it += 1024) {
+            const int p = it / o, t = it - p * o;
+            acc[p * G + t] += acc[p * G + t + o];
+        }
         __syncthreads();
+    }
+    for (int p = tid; p < P; p += 1024) {
+        const float v = (float)(-norm * acc[p * G]);
+        sc[p] = v;
+        scores[(int64_t)p * S + seg] = v;
+    }
+    __syncthreads();
+    // rank + next grid / commit (fpcs_tail.h), the scores already in LDS
+    const float d = tail.new_cnt > 0 ? tail.delta_in[seg] : 0.0f;
+    for (int p = tid; p < P; p += 1024) {
+        const int r = fpcs::rank_of(sc, P, p);
+        if (r < tail.k) top[r] = p;
+    }
+    __syncthreads();
+    fpcs::emit(top, (int)S, seg, tid, 1024, d, tail);
+    if (tail.new_cnt > 0) {
+        __syncthreads();
+        if (tid == 0) tail.delta_out[seg] = d / ((float)tail.new_cnt - 0.5f);
     }
 }
 
@@ -258,22 +339,45 @@ extern "C" int adalog_score_self_sorted_tail(const float* sorted, const double* 
                                              const float* zp, int P, int n_bits, double norm, float* scores,
                                              const adalog_fpcs_tail* tail, void* stream) {
     ADALOG_ARG_CHECK(sorted && prefix && scale && zp && scores && S >= 1 && n >= 1 && P >= 1, "score_self_sorted: bad arguments");
+    ADALOG_ARG_CHECK(n_bits >= 1 && n_bits <= 8, "score_self_sorted: 1..8 bits");
     const char* why = fpcs::tail_problem(tail, P);
     ADALOG_ARG_CHECK(why == nullptr, why);
-    ADALOG_ARG_CHECK(!tail || S <= 65536, "score_self_sorted: the fused tail takes <= 65536 segments");
-    unsigned int* tickets = tail ? adalog_ticket_pool_on((int)S, stream) : nullptr;
-    ADALOG_ARG_CHECK(!tail || tickets, "score_self_sorted: no ticket counters");
-    const fpcs::Tail tl = tail ? *tail : fpcs::Tail{};
-    ADALOG_ARG_CHECK(n_bits >= 1 && n_bits <= 8, "score_self_sorted: 1..8 bits");
     const float qmax = (float)((1 << n_bits) - 1);
     const int G = 1 << n_bits;
+    hipStream_t st = (hipStream_t)stream;
+    adalog_note_kernel("k_score_sorted");
+    const size_t col_lds = (size_t)P * G * 8 + (size_t)P * (G + 1) * 4 + (size_t)P * 8;
+    // (a workgroup per column pays when the columns fill the chip: with ONE column -- the per-tensor searches -- the 2 176 bisections
+    // of a step sat on one CU, whose address path takes a fully divergent load at one line per clock: 51 us against 32 + 11 for the
+    // eight-workgroup form and a separate k_topk_next)
+    static const int col_min = getenv("ADALOG_SORTED_COL_MIN") ? atoi(getenv("ADALOG_SORTED_COL_MIN")) : 64;
+    if (tail && S >= col_min && G <= 64 && col_lds <= 150 * 1024 && S <= 65535 && n < ((int64_t)1 << 31)) {
+        // a workgroup per score column: scores, ranking and the next grid in one launch
+#define LAUNCH_SC(GV)                                                                                              \
+        do {                                                                                                       \
+            static unsigned long long attr_dev = 0;                                                                \
+            hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_score_sorted_col<GV>), 150 * 1024, &attr_dev); \
+            if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; }           \
+            hipLaunchKernelGGL((k_score_sorted_col<GV>), dim3((unsigned)S), dim3(1024), col_lds, st, sorted, (const d2*)prefix, S, n, \
+                               scale, zp, P, qmax, norm, scores, *tail);                                           \
+        } while (0)
+        switch (n_bits) {
+            case 1: LAUNCH_SC(2); break;
+            case 2: LAUNCH_SC(4); break;
+            case 3: LAUNCH_SC(8); break;
+            case 4: LAUNCH_SC(16); break;
+            case 5: LAUNCH_SC(32); break;
+            default: LAUNCH_SC(64); break;
+        }
+#undef LAUNCH_SC
+        ADALOG_LAUNCH_CHECK("adalog_score_self_sorted");
+        return 0;
+    }
     const int64_t pairs = (int64_t)P * S;
     const int gpb = 256 / G;
     const int64_t blocks = (pairs + gpb - 1) / gpb;
     ADALOG_ARG_CHECK(blocks < ((int64_t)1 << 31), "score_self_sorted: grid too large");
-    hipStream_t st = (hipStream_t)stream;
-    adalog_note_kernel("k_score_sorted");
-#define LAUNCH_SS(GV) hipLaunchKernelGGL((k_score_sorted<GV>), dim3((unsigned)blocks), dim3(256), 0, st, sorted, (const d2*)prefix, S, n, scale, zp, P, qmax, norm, scores, tail ? 1 : 0, tl, tickets)
+#define LAUNCH_SS(GV) hipLaunchKernelGGL((k_score_sorted<GV>), dim3((unsigned)blocks), dim3(256), 0, st, sorted, (const d2*)prefix, S, n, scale, zp, P, qmax, norm, scores)
     switch (n_bits) {
         case 1: LAUNCH_SS(2); break;
         case 2: LAUNCH_SS(4); break;
@@ -286,6 +390,7 @@ extern "C" int adalog_score_self_sorted_tail(const float* sorted, const double* 
     }
 #undef LAUNCH_SS
     ADALOG_LAUNCH_CHECK("adalog_score_self_sorted");
+    if (tail) return adalog_topk_next_tail(scores, P, (int)S, tail, nullptr, stream);     // (7 / 8 bit: the column does not fit one workgroup's LDS)
     return 0;
 }
 

@@ -648,26 +648,63 @@ def gram_ok(T: int, O: int, K: int, a_bits: int, w_bits: int, P: int) -> bool:
 
 class GramState:
     """G = X_int^T X_int, c = X_int^T (raw_out - bias), S0 = sum (raw_out - bias)^2 of one weight_fpcs call (csrc/gram.hip), built
-    once from the captured activation, the activation quantiser and raw_out; ``score_w`` then scores an FPCS step from it."""
-    __slots__ = ("ws", "T", "O", "K", "a_bits", "sa", "build_ms")
+    once from the captured activation, the activation quantiser and raw_out; ``score_w`` then scores an FPCS step from it.
+
+    Image-sharded ranks (adalog_amd.parallel): x2 / ref_t hold this rank's tokens.  G, c and S0 are sums over tokens, so the build
+    all-reduces them ONCE (adalog_gram_amax -> MAX, adalog_gram_build_sums -> SUM of int64 / fp64, adalog_gram_build_from_sums) and
+    every rank then scores the same FINAL scores from the same state: ``global_scores`` -- the six steps of the search need no
+    collective (the token-form kernels and the rank-local Gram state all-reduce [P, O] scores at every step)."""
+    __slots__ = ("ws", "T", "O", "K", "a_bits", "sa", "build_ms", "global_scores")
 
     def __init__(self, x2, sa, za, a_bits: int, ref_t, bias):
+        from . import parallel
         lib = _lib.load()
         x2, ref_t = _f32c(x2, "x"), _f32c(ref_t, "ref")
-        self.T, self.K = x2.shape
+        t_local, self.K = x2.shape
         self.O = ref_t.shape[-2]
-        assert ref_t.shape[-1] == self.T
+        assert ref_t.shape[-1] == t_local
         self.a_bits = int(a_bits)
         self.sa = _f32c(sa, "sa").reshape(-1)
         za = _f32c(za, "za").reshape(-1)
         assert self.sa.numel() == 1 and za.numel() == 1, "Gram form: per-tensor activation quantiser"
+        bias = None if bias is None else _f32c(bias, "bias")
+        self.global_scores = True
+        dev = x2.device
+        if parallel.is_dist():
+            # (equal shards: adalog_amd.parallel.shard_slice deals the images evenly, so the global token count is ws x local)
+            self.T = t_local * parallel.world_size()
+            amax = torch.empty(self.O, dtype=torch.int32, device=dev)
+            _lib.check(lib.adalog_gram_amax(ref_t.data_ptr(), t_local, self.O, _ptr(bias), amax.data_ptr(), _stream()), "adalog_gram_amax")
+            parallel.all_reduce_max(amax)                     # bits of non-negative floats: integer order = float order
+            nb_l = lib.adalog_gram_workspace_bytes(t_local, self.O, self.K, self.a_bits)
+            nb = lib.adalog_gram_workspace_bytes(self.T, self.O, self.K, self.a_bits)
+            if nb_l < 0 or nb < 0:
+                raise _lib.AdalogHipError("gram_build: shape not supported (gram_ok)")
+            tmp = _aligned_bytes(nb_l, dev)
+            gsum = torch.empty((self.K, self.K), dtype=torch.int64, device=dev)
+            csum = torch.empty((self.O, self.K), dtype=torch.int64, device=dev)
+            s0 = torch.empty(self.O, dtype=torch.float64, device=dev)
+            rc = lib.adalog_gram_build_sums(x2.data_ptr(), t_local, self.K, x2.stride(0), self.sa.data_ptr(), za.data_ptr(), self.a_bits,
+                                            ref_t.data_ptr(), self.O, _ptr(bias), amax.data_ptr(), gsum.data_ptr(), csum.data_ptr(),
+                                            s0.data_ptr(), tmp.data_ptr(), nb_l, _stream())
+            _lib.check(rc, "adalog_gram_build_sums")
+            parallel.all_reduce_sum(gsum)
+            parallel.all_reduce_sum(csum)
+            parallel.all_reduce_sum(s0)
+            self.ws = _aligned_bytes(nb, dev)
+            rc = lib.adalog_gram_build_from_sums(gsum.data_ptr(), csum.data_ptr(), s0.data_ptr(), amax.data_ptr(), self.T, self.O, self.K,
+                                                 self.a_bits, self.ws.data_ptr(), nb, _stream())
+            _lib.check(rc, "adalog_gram_build_from_sums")
+            return
+        # one rank: the sites an N-rank build would all-reduce (amax, G, c, S0)
+        parallel.note_planned(4 * self.O + 8 * self.K * self.K + 8 * self.O * self.K + 8 * self.O, count=4)
+        self.T = t_local
         nb = lib.adalog_gram_workspace_bytes(self.T, self.O, self.K, self.a_bits)
         if nb < 0:
             raise _lib.AdalogHipError("gram_build: shape not supported (gram_ok)")
         self.ws = torch.empty((nb + 255) // 8 + 32, dtype=torch.float64, device=x2.device)
         off = (-self.ws.data_ptr()) % 256                     # the kernels want a 256-byte aligned base
         self.ws = self.ws.view(torch.uint8)[off:off + nb]
-        bias = None if bias is None else _f32c(bias, "bias")
         if GEMM_EVENTS is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()

@@ -164,6 +164,15 @@ def _all_reduce(t: torch.Tensor, op) -> torch.Tensor:
     return t
 
 
+def note_planned(nbytes: int, count: int = 1):
+    """an all-reduce SITE that this (one-rank) run passed without issuing a collective -- e.g. an FPCS step whose scoring kernel ranked
+    its own scores, where an N-rank run all-reduces the [P, cols] scores first: keeps PLANNED what an N-GPU job would issue"""
+    if not getattr(_tls, "solo", False):
+        with _stats_lock:
+            PLANNED["collectives"] += int(count)
+            PLANNED["bytes"] += int(nbytes)
+
+
 def reset_stats():
     with _stats_lock:
         STATS["collectives"] = 0

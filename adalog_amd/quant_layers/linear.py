@@ -375,6 +375,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
                 fn.fused_tail = True
             else:
                 fn = lambda s, z, t: score(s, z, defer=True)
+            fn.global_scores = getattr(score, "global_scores", False)
         wq = self.w_quantizer
         res = search.fpcs(scale, zp, None, delta, fn, steps, fpcs_width, self.eq_n, None,
                           commit_to=search.commit_targets(wq.scale, wq.zero_point, None))
@@ -390,9 +391,12 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             norm = 1.0 / self._tokens_per_image()
             if getattr(backend.get(), "FpcsTail", None) is not None:
                 fn = lambda s, z, defer=False, tail=None: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm, tail=tail)
-                fn.fused_tail = True                     # the score kernel ranks its rows and writes the next grid itself
-                return fn
-            return lambda s, z, defer=False: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm)
+                fn.fused_tail = True                     # score_w runs the FPCS tail itself (same call)
+            else:
+                fn = lambda s, z, defer=False: gram.score_w(self._w2(), s, z, self.w_quantizer.n_bits, norm)
+            # under image sharding the state holds the all-reduced G, c, S0: the scores are final on every rank (search.fpcs)
+            fn.global_scores = bool(getattr(gram, "global_scores", False))
+            return fn
         fixed = self._pack_x_fixed()
         return lambda s, z, defer=False: self._score_w(fixed, s, z, defer=defer)
 
@@ -436,7 +440,11 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         if not getattr(aq, "_zp_on_grid", False):
             return None
         x2 = self._x2()
-        if not be.gram_ok(x2.shape[0], self.out_features, self.in_features, aq.n_bits, self.w_quantizer.n_bits, self.eq_n):
+        # (image-sharded ranks: the state is built from ALL ranks' tokens -- ops.GramState all-reduces G, c, S0 once -- so the form is
+        # priced on the global token count, not on this rank's share)
+        from .. import parallel
+        if not be.gram_ok(x2.shape[0] * parallel.world_size(), self.out_features, self.in_features, aq.n_bits,
+                          self.w_quantizer.n_bits, self.eq_n):
             return None
         return be.GramState(x2, aq.scale.data, aq.zero_point.data, aq.n_bits, self._ref2_t(),
                             None if self.bias is None else self.bias.data)

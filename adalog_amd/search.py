@@ -107,6 +107,10 @@ def round_is_redundant(module, tag: str, *quantizers) -> bool:
     return same
 
 
+# A/B switch: 0 = scorers that can run the FPCS tail in their own launch hand their scores to a separate k_topk_next instead
+FUSED_TAIL = __import__("os").environ.get("ADALOG_FUSED_TAIL", "1") != "0"
+
+
 def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 16, eq_n: int = 128,
          clamp_min: Optional[float] = None, commit_to=None):
     """Run the progressive search.  ``score_fn(scale, zp, third) -> scores [P, cols]`` (rank-local partial sums).
@@ -128,8 +132,12 @@ def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 1
     pending_t = getattr(be, "PendingScores", ())
     Tail = getattr(be, "FpcsTail", None)
     one_gpu = Tail is not None and not parallel.is_dist()
-    fused = one_gpu and getattr(score_fn, "fused_tail", False)
+    fused = one_gpu and FUSED_TAIL and getattr(score_fn, "fused_tail", False)
+    # a scorer whose state was all-reduced when it was built (the Gram form of the weight searches: G, c, S0) returns the GLOBAL
+    # scores on every rank: its steps need no collective; every other scorer's [P, cols] scores are rank-local partial sums
+    global_scores = getattr(score_fn, "global_scores", False)
     d_in, d_buf = delta, None
+    cols = scale.shape[1]
 
     def tail_for(last):
         nonlocal d_buf
@@ -144,6 +152,8 @@ def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 1
         if remain == 1 and first:    # steps == 1: survivors are selected but never committed (linear.py:490-491)
             score_fn(scale, zp, third)
             return None
+        if one_gpu and not global_scores:
+            parallel.note_planned(4 * scale.shape[0] * cols)       # (what an N-rank run all-reduces at this step)
         if fused:
             tail = tail_for(last)
             score_fn(scale, zp, third, tail=tail)
@@ -159,7 +169,9 @@ def fpcs(scale, zp, third, delta, score_fn: Callable, steps: int, width: int = 1
                     be.topk_next(res, None, None, None, 0, 0, None, None, None, tail=tail)
             else:
                 # several ranks (or a backend without tails): the scores are all-reduced between the reduction and the ranking
-                scores = parallel.all_reduce_sum(res.finish() if isinstance(res, pending_t) else res)
+                scores = res.finish() if isinstance(res, pending_t) else res
+                if not global_scores:
+                    scores = parallel.all_reduce_sum(scores)
                 if last:
                     return be.topk_next(scores, scale, zp, third, 1, 0, None, None, None)
                 if d_buf is None:

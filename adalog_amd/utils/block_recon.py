@@ -309,6 +309,18 @@ class BlockReconstructor(QuantCalibrator):
                 sched_block, sched_base = host.to(device, non_blocking=True), it
             sched_dev.copy_(sched_block[it - sched_base])
 
+        def fixed_rec_loss():
+            """the block's reconstruction loss as it stands (soft rounding targets, training-form quantisers: the forward values of an
+            iteration) on a FIXED set of its optimisation images -- what the iterations are meant to lower (block_recon.py:189-198)"""
+            n_eval = min(n_local, 2 * local_bs)
+            train_mm.reset_offers()
+            with torch.enable_grad():                        # the iteration's own forward path (contractions on csrc/brecq_gemm.hip)
+                pred = block(block.raw_input[:n_eval].to(device)).detach()
+            with torch.no_grad():
+                return float(loss_func.rec_term(pred, block.raw_out[:n_eval].to(device)))
+
+        report = os.environ.get("ADALOG_BRECQ_REPORT", "1") != "0" and n_local > 0
+        rec_before = fixed_rec_loss() if report else None
         try:
             for it in range(iters):
                 idx = next_indices(it)
@@ -383,6 +395,11 @@ class BlockReconstructor(QuantCalibrator):
             torch.backends.cuda.matmul.allow_tf32 = prev_tf32
             for prm in frozen:
                 prm.requires_grad_(True)
+        if report:
+            rec_after = fixed_rec_loss()
+            self.__dict__.setdefault('rec_report', {})[name] = (rec_before, rec_after)
+            logging.info('{}: reconstruction loss on its first {} images {:.6g} -> {:.6g} after {} iterations'.format(
+                name, min(n_local, 2 * local_bs), rec_before, rec_after, iters))
         for _, module in block.named_modules():
             if hasattr(module, 'w_quantizer'):
                 module.w_quantizer.soft_targets = False

@@ -297,7 +297,19 @@ int adalog_gram_build(const float* x, int T, int K, int64_t ldx, const float* sa
                       int O, const float* bias, void* workspace, int64_t workspace_bytes, void* stream);
 int adalog_gram_score_w(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
                         const void* workspace, int T, int a_bits, const float* sa, double norm, float* scores, void* stream);
-/* ... and the FPCS step's tail in the same launch (tail may be null; its grid is (scale, zp); k <= 32) */
+/* The build with the calibration images SHARDED over ranks (reference: scores are sums over images, linear.py:384), in
+ * three calls with the collectives between them:  adalog_gram_amax (this rank's column maxima, as float bits: all-reduce MAX as
+ * int32), adalog_gram_build_sums (with the GLOBAL amax: gsum [K][K] and csum [O][K] as int64, s0 [O] fp64, of this rank's tokens;
+ * workspace = adalog_gram_workspace_bytes of the LOCAL shape: all-reduce SUM of the three), adalog_gram_build_from_sums (-> the
+ * workspace adalog_gram_score_w reads, for T_total = the global token count).  Every rank then holds the same state and computes
+ * the same FINAL scores: an FPCS step of the search needs no collective. */
+int adalog_gram_amax(const float* ref_t, int T, int O, const float* bias, unsigned int* amax, void* stream);
+int adalog_gram_build_sums(const float* x, int T, int K, int64_t ldx, const float* sa, const float* za, int a_bits, const float* ref_t,
+                           int O, const float* bias, const unsigned int* amax, long long* gsum, long long* csum, double* s0,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+int adalog_gram_build_from_sums(const long long* gsum, const long long* csum, const double* s0, const unsigned int* amax, int T_total,
+                                int O, int K, int a_bits, void* workspace, int64_t workspace_bytes, void* stream);
+/* adalog_gram_score_w followed by the FPCS step's tail (tail may be null; its grid is (scale, zp)): two launches (csrc/gram.hip says why) */
 int adalog_gram_score_w_tail(const float* W, int O, int K, int64_t ldw, const float* scale, const float* zp, int P, int w_bits,
                              const void* workspace, int T, int a_bits, const float* sa, double norm, float* scores,
                              const adalog_fpcs_tail* tail, void* stream);

@@ -657,6 +657,7 @@ class GramState:
     scores[p][o] = -norm * (S0[o] - 2 sigma (w . c[o]) + sigma^2 (w^T G w)),  sigma = fl32(s_a * s_w[p][o])."""
 
     def __init__(self, x2, sa, za, a_bits, ref_t, bias):
+        from adalog_amd import parallel
         self.T, self.K = x2.shape
         self.O = ref_t.shape[-2]
         self.sa = sa.reshape(-1)[:1].clone()
@@ -664,12 +665,17 @@ class GramState:
         X = ((torch.round(x2 / self.sa) + z).clamp(0, 2 ** a_bits - 1) - z).to(torch.int64)        # [T, K]
         self.G = X.t() @ X
         rb = ref_t.reshape(self.O, self.T) - (bias.view(-1, 1) if bias is not None else 0.0)        # fp32 subtract
-        am = rb.abs().amax(1)
+        # image-sharded ranks (spec of ops.GramState's three-call build): the column maxima are all-reduced (MAX) before the
+        # fixed-point rounding, the integer sums G, c and S0 after it (SUM) -- every rank then holds the global state
+        am = parallel.all_reduce_max(rb.abs().amax(1).contiguous())
         e = torch.where(am > 0, 29 - torch.floor(torch.log2(am.double())), torch.zeros_like(am, dtype=torch.float64))
         self.e = e
         v = torch.round(rb.double() * torch.exp2(e).view(-1, 1)).to(torch.int64)                    # [O, T]
-        self.c = v @ X                                                                             # [O, K] int64
-        self.S0 = (v.double() ** 2).sum(1) * torch.exp2(-2 * e)
+        self.c = parallel.all_reduce_sum((v @ X).contiguous())                                       # [O, K] int64
+        self.G = parallel.all_reduce_sum(self.G.contiguous())
+        self.S0 = parallel.all_reduce_sum((v.double() ** 2).sum(1).contiguous()) * torch.exp2(-2 * e)
+        self.T = self.T * parallel.world_size()
+        self.global_scores = True
 
     def score_w(self, w2, scale, zp, w_bits, norm):
         O, K = w2.shape

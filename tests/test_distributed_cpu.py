@@ -100,6 +100,82 @@ def test_sharded_search_matches_single_process(kind, fixture):
             torch.testing.assert_close(r0[k], single[k], rtol=2e-3, atol=0, msg=lambda m: f"{k}: {m}")
 
 
+def _gram_w_case(seed=11, N=8, Tn=9, I=64, Oc=96, bits=4):
+    """a Linear layer with a FIXED per-tensor activation quantiser (an FPCS grid point), its captures, and the weight search's state"""
+    from adalog_amd import quant_layers as Q
+    from oracle import adalog_oracle as O
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Tn, I, generator=g)
+    x[..., : I // 8] *= 3.0
+    W = torch.randn(Oc, I, generator=g) * 0.05
+    b = torch.randn(Oc, generator=g) * 0.1
+    lay = Q.AsymmetricallyBatchingQuantLinear(I, Oc, True, "raw", bits, bits, calib_batch_size=N, search_round=1, eq_n=128, n_V=1,
+                                              fpcs=True, steps=6)
+    lay.weight.data.copy_(W); lay.bias.data.copy_(b)
+    sca, zpa = O.activation_candidates(x, bits, False)
+    aq = lay.a_quantizer
+    aq.scale.data.copy_(sca[:, 60].view(aq.scale.shape)); aq.zero_point.data.copy_(zpa[:, 60].float().view(aq.zero_point.shape))
+    aq.inited, aq._zp_on_grid = True, True
+    return lay, x
+
+
+def _gram_w_search(lay, x, lo, hi):
+    from adalog_amd import parallel, search
+    with torch.no_grad():
+        full_out = lay(x)
+        lay.raw_input, lay.raw_out = x[lo:hi].contiguous(), full_out[lo:hi].contiguous()
+        lay._initialize_calib_parameters()
+        search.forget_grids(); search.begin_rounds(lay)
+        parallel.reset_stats()
+        lay.weight_fpcs(steps=6, search_strategy="output")
+        st = parallel.collective_stats()
+    wq = lay.w_quantizer
+    return wq.scale.detach().clone(), wq.zero_point.detach().clone(), st
+
+
+def _gram_w_worker(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from adalog_amd import backend, parallel
+    from tests import cpu_backend
+    torch.set_num_threads(2)
+    backend.set_backend(cpu_backend)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    lay, x = _gram_w_case()
+    lo, hi = parallel.shard_slice(x.shape[0])
+    s_, z_, st = _gram_w_search(lay, x, lo, hi)
+    torch.save({"scale": s_, "zp": z_, "collectives": st["collectives"]}, os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gram_weight_search_with_the_state_all_reduced_once(world):
+    """The Gram form of the output-MSE weight search (reference quant_layers/linear.py:355-392, 483-503) under image sharding: G, c
+    and S0 are sums over tokens, so the build all-reduces them once (amax: MAX; G, c: int64 SUM, exact; S0: fp64 SUM) and every
+    rank then scores the same FINAL scores -- the six FPCS steps issue NO collective.  Checked on gloo with the integer
+    specification of the kernels (tests/cpu_backend.GramState): every rank commits bit-identical parameters, they EQUAL the
+    one-process search's (the state is the same integers), and the search issued exactly the build's four all-reduces (plus the
+    percentile grid's none: weights are replicated)."""
+    from adalog_amd import backend
+    from tests import cpu_backend
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gram_w_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        rs = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(world)]
+    for r in rs[1:]:
+        assert torch.equal(r["scale"], rs[0]["scale"]) and torch.equal(r["zp"], rs[0]["zp"])
+    assert all(r["collectives"] == 4 for r in rs), [r["collectives"] for r in rs]
+    backend.set_backend(cpu_backend)
+    try:
+        lay, x = _gram_w_case()
+        s1, z1, st1 = _gram_w_search(lay, x, 0, x.shape[0])
+    finally:
+        backend.set_backend(None)
+    assert torch.equal(rs[0]["scale"], s1) and torch.equal(rs[0]["zp"], z1)
+
+
 def test_shard_slice_and_gather_single_process():
     from adalog_amd import parallel
     assert parallel.world_size() == 1 and parallel.rank() == 0

@@ -64,3 +64,53 @@ def test_two_ranks_one_gpu_match_single_process(kind, fixture):
             assert (single[k] != r0[k]).float().mean().item() <= 0.1, k      # exact ties may resolve differently
         elif "scale" in k:
             torch.testing.assert_close(r0[k], single[k], rtol=2e-3, atol=0, msg=lambda m: f"{k}: {m}")
+
+
+def _gram_w_worker_dev(rank, world, port, outdir):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from adalog_amd import backend, ops, parallel
+    from tests.test_distributed_cpu import _gram_w_case, _gram_w_search
+    backend.set_backend(None)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    lay, x = _gram_w_case(N=32, Tn=197, I=384, Oc=384)               # deit_small attn.proj: adalog_gram_ok takes it (3 x 384 <= 6304 / 2)
+    lay.to(DEV)
+    x = x.to(DEV)
+    lo, hi = parallel.shard_slice(x.shape[0])
+    built = []
+    real = ops.GramState.__init__
+    ops.GramState.__init__ = lambda self, *a, **k: (built.append(1), real(self, *a, **k))[1]
+    s_, z_, st = _gram_w_search(lay, x, lo, hi)
+    torch.cuda.synchronize()
+    torch.save({"scale": s_.cpu(), "zp": z_.cpu(), "collectives": st["collectives"], "gram_builds": len(built)},
+               os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gram_weight_search_two_ranks_one_gpu_equals_single_process():
+    """The sharded Gram build with the REAL kernels (adalog_gram_amax / adalog_gram_build_sums / adalog_gram_build_from_sums, two ranks
+    sharing this box's GPU over gloo) at the deit_small attn.proj shape, which adalog_gram_ok accepts: both ranks commit bit-identical
+    weight parameters, they equal the one-process Gram search's (same integers in the state; S0 summed in fp64), the search took the
+    Gram route on every rank and issued four all-reduces -- the build's -- and none per FPCS step."""
+    from adalog_amd import backend
+    from tests.test_distributed_cpu import _gram_w_case, _gram_w_search
+    backend.set_backend(None)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_gram_w_worker_dev, args=(2, _free_port(), d), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
+    assert torch.equal(r0["scale"], r1["scale"]) and torch.equal(r0["zp"], r1["zp"])
+    assert r0["gram_builds"] == 1 and r1["gram_builds"] == 1, (r0["gram_builds"], r1["gram_builds"])
+    assert r0["collectives"] == 4 and r1["collectives"] == 4, (r0["collectives"], r1["collectives"])
+    lay, x = _gram_w_case(N=32, Tn=197, I=384, Oc=384)
+    lay.to(DEV)
+    s1, z1, _ = _gram_w_search(lay, x.to(DEV), 0, 32)
+    torch.cuda.synchronize()
+    assert (r0["zp"] == z1.cpu()).float().mean().item() >= 0.99
+    # (S0 is an fp64 sum taken in a different order: a score may round differently in its last fp32 bit and flip an exact tie)
+    same = (r0["scale"] == s1.cpu()).float().mean().item()
+    assert same >= 0.99, same
+    torch.testing.assert_close(r0["scale"], s1.cpu(), rtol=2e-3, atol=0)
