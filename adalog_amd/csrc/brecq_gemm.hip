@@ -72,6 +72,14 @@ __device__ __forceinline__ void split_pair(float a, float b, uint32_t& H, uint32
     v2bf l = {(__bf16)sa, (__bf16)sb};
     L = *reinterpret_cast<uint32_t*>(&l);
 }
+// two-term split (hi + mid: relative error 2^-16): the gradient contractions of a BRECQ iteration (round 6)
+__device__ __forceinline__ void split_pair2(float a, float b, uint32_t& H, uint32_t& Mi) {
+    v2bf h = {(__bf16)a, (__bf16)b};
+    H = *reinterpret_cast<uint32_t*>(&h);
+    const float ra = sub1(a, __uint_as_float(H << 16)), rb = sub1(b, __uint_as_float(H & 0xffff0000u));
+    v2bf m = {(__bf16)ra, (__bf16)rb};
+    Mi = *reinterpret_cast<uint32_t*>(&m);
+}
 // values that are exact in bf16 (small integers): one conversion, mid = lo = 0 (never read)
 __device__ __forceinline__ Frag3 cvt8(const float (&x)[8]) {
     Frag3 f;
@@ -114,7 +122,9 @@ __device__ __forceinline__ v16f mm(const uint4& a, const uint4& b, v16f c) {
 // C tile (64 RI) x (32 CJ WN), 2 WN waves as 2 x WN, wave tile (32 RI) x (32 CJ).  TA / TB: the operand is K-major in memory.
 // PA / PB = 1: the operand's values are exactly representable in bf16 (small integers: the integer part of a uniformly
 // fake-quantised activation, its scale handed over as alpha_dev) -- one conversion instead of the split, 3 products instead of
-// 6.  KT: K % 16 != 0 with a K-contiguous operand (the tail of the last step is zeroed in registers).
+// 6.  PA / PB = 2: a two-term split (hi + mid, 2^-16 relative) -- 3 products for two general operands (hi.hi, hi.mid, mid.hi),
+// 2 against an exact one: the gradient contractions (adalog_gemm_f32x3: exact = 2).
+// KT: K % 16 != 0 with a K-contiguous operand (the tail of the last step is zeroed in registers).
 // The MFMA's A operand is the N side: a lane then owns 4 consecutive n of one m in each accumulator quad -> 16-byte stores.
 template <int RI, int CJ, int WN, bool TA, bool TB, int PA, int PB, bool KT>
 __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(BqArgs p) {
@@ -268,7 +278,8 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
     // Jobs of step s, one per product group g = j RI + i:  g % RI == 0 -> n[j+1] of stage s;  the others, in order -> the carry
     // m0', m1', .., n0' of stage s + 1;  the groups left over issue this wave's DMA requests for stage s + BQ_NS - 1.
     constexpr int PBE = BP ? 3 : PB;
-    constexpr int NP = (PA == 3 && PBE == 3) ? 6 : (PA == 1 && PBE == 1) ? 1 : 3;     // MFMAs per product group
+    constexpr int NP = (PA == 3 && PBE == 3) ? 6 : (PA == 1 && PBE == 1) ? 1 : (PA == 2 && PBE == 2) ? 3
+                     : ((PA == 2 && PBE == 1) || (PA == 1 && PBE == 2)) ? 2 : 3;      // MFMAs per product group
     constexpr int NG = RI * CJ;
     constexpr int NCARRY = RI + 1;
     Frag3 mf[RI], nf[CJ], mfn[RI], nf0n;
@@ -310,7 +321,8 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
             v2bf h = {(__bf16)x[2 * pr], (__bf16)x[2 * pr + 1]};
             H = *reinterpret_cast<uint32_t*>(&h); Mi = H; L = H;
 #else
-            split_pair(x[2 * pr], x[2 * pr + 1], H, Mi, L);
+            if (planes == 2) split_pair2(x[2 * pr], x[2 * pr + 1], H, Mi);
+            else split_pair(x[2 * pr], x[2 * pr + 1], H, Mi, L);
 #endif
         }
         if (pr == 0) { f.hi.x = H; f.mid.x = Mi; f.lo.x = L; }
@@ -405,6 +417,12 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
                 if constexpr (PA == 3 && PBE == 3) {
                     c = u == 0 ? mm(n_.lo, m_.hi, c) : u == 1 ? mm(n_.hi, m_.lo, c) : u == 2 ? mm(n_.mid, m_.mid, c)
                       : u == 3 ? mm(n_.mid, m_.hi, c) : u == 4 ? mm(n_.hi, m_.mid, c) : mm(n_.hi, m_.hi, c);
+                } else if constexpr (PA == 2 && PBE == 2) {
+                    c = u == 0 ? mm(n_.mid, m_.hi, c) : u == 1 ? mm(n_.hi, m_.mid, c) : mm(n_.hi, m_.hi, c);
+                } else if constexpr (PA == 1 && PBE == 2) {
+                    c = u == 0 ? mm(n_.mid, m_.hi, c) : mm(n_.hi, m_.hi, c);
+                } else if constexpr (PA == 2 && PBE == 1) {
+                    c = u == 0 ? mm(n_.hi, m_.mid, c) : mm(n_.hi, m_.hi, c);
                 } else if constexpr (PA == 1 && PBE == 3) {
                     c = u == 0 ? mm(n_.lo, m_.hi, c) : u == 1 ? mm(n_.mid, m_.hi, c) : mm(n_.hi, m_.hi, c);
                 } else if constexpr (PA == 3 && PBE == 1) {
@@ -433,6 +451,7 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
                     if (c0) {                                 // 4 pair-splits spread over the group's MFMAs
                         if (NP >= 4) { if (u < 4) job_pair(c0, raw[g & 1], u); }
                         else if (NP == 3) { job_pair(c0, raw[g & 1], u); if (u == 2) job_pair(c0, raw[g & 1], 3); }
+                        else if (NP == 2) { job_pair(c0, raw[g & 1], 2 * u); job_pair(c0, raw[g & 1], 2 * u + 1); }
                         else { job_pair(c0, raw[g & 1], 0); job_pair(c0, raw[g & 1], 1); job_pair(c0, raw[g & 1], 2); job_pair(c0, raw[g & 1], 3); }
                     }
                     if (u == NP - 1) {
@@ -652,9 +671,24 @@ int bq_launch(const BqArgs& a, int transA, int transB, int pa, int pb, bool kt, 
         if (pa == 1) return kt ? bq_go<RI, CJ, WN, false, false, 1, 0, true>(a, wgs, st) : bq_go<RI, CJ, WN, false, false, 1, 0, false>(a, wgs, st);
         return kt ? bq_go<RI, CJ, WN, false, false, 3, 0, true>(a, wgs, st) : bq_go<RI, CJ, WN, false, false, 3, 0, false>(a, wgs, st);
     }
+    if (pa == 1 && pb == 2 && !transA && !transB && !kt) return bq_go<RI, CJ, WN, false, false, 1, 2, false>(a, wgs, st);
+    if (pa == 1 && pb == 2 && !transA && transB && !kt) return bq_go<RI, CJ, WN, false, true, 1, 2, false>(a, wgs, st);
     if (pa == 1 && pb == 3 && !transA && !transB && !kt) return bq_go<RI, CJ, WN, false, false, 1, 3, false>(a, wgs, st);
     if (pa == 1 && pb == 3 && !transA && transB && !kt) return bq_go<RI, CJ, WN, false, true, 1, 3, false>(a, wgs, st);
     if (pa == 3 && pb == 1 && transA && transB) return bq_go<RI, CJ, WN, true, true, 3, 1, false>(a, wgs, st);
+    // two-term operands (gradient contractions): every orientation for the general pair, the dL/dw form against an exact operand
+    if (pa == 2 && pb == 1 && transA && transB) return bq_go<RI, CJ, WN, true, true, 2, 1, false>(a, wgs, st);
+    if (pa == 2 && pb == 2) {
+        if (transA && transB) return bq_go<RI, CJ, WN, true, true, 2, 2, false>(a, wgs, st);
+        if (kt) {
+            if (transA) return bq_go<RI, CJ, WN, true, false, 2, 2, true>(a, wgs, st);
+            if (transB) return bq_go<RI, CJ, WN, false, true, 2, 2, true>(a, wgs, st);
+            return bq_go<RI, CJ, WN, false, false, 2, 2, true>(a, wgs, st);
+        }
+        if (transA) return bq_go<RI, CJ, WN, true, false, 2, 2, false>(a, wgs, st);
+        if (transB) return bq_go<RI, CJ, WN, false, true, 2, 2, false>(a, wgs, st);
+        return bq_go<RI, CJ, WN, false, false, 2, 2, false>(a, wgs, st);
+    }
     if (pa != 3 || pb != 3) return -3;
     if (transA && transB) return bq_go<RI, CJ, WN, true, true, 3, 3, false>(a, wgs, st);
     if (kt) {
@@ -669,10 +703,19 @@ int bq_launch(const BqArgs& a, int transA, int transB, int pa, int pb, bool kt, 
 
 }  // namespace
 
+// exact: 0 = general fp32 operand (three-term split), 1 = exactly representable in bf16, 2 = two-term split (2^-16 relative)
+static void bq_forms(int exactA, int exactB, int transA, int transB, int& pa, int& pb) {
+    pa = pb = 3;
+    if (exactA == 1 && exactB != 1 && !transA) { pa = 1; pb = exactB == 2 ? 2 : 3; return; }   // forward: A = x_int K-contiguous, B either orientation
+    if (exactB == 1 && exactA != 1 && transA && transB) { pb = 1; pa = exactA == 2 ? 2 : 3; return; }   // dL/dw: B = x_int, both K-major
+    if (exactA == 2 && exactB == 2) { pa = pb = 2; return; }
+    // (a two-term request next to a general operand, or an exact operand in an orientation without a dedicated form, runs as the
+    // general product: the split of an exact value is (x, 0, 0), the result the same or better)
+}
 static int bq_products(int exactA, int exactB, int transA, int transB) {
-    if (exactA && !exactB && !transA) return 3;              // forward: A = x_int K-contiguous, B either orientation
-    if (exactB && !exactA && transA && transB) return 3;
-    return 6;
+    int pa, pb;
+    bq_forms(exactA, exactB, transA, transB, pa, pb);
+    return (pa == 3 && pb == 3) ? 6 : ((pa == 2 && pb == 1) || (pa == 1 && pb == 2)) ? 2 : 3;
 }
 
 // Bytes of workspace adalog_gemm_f32x3 needs for this shape (0 when the product is not split along K).
@@ -689,7 +732,8 @@ static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_
                   int64_t sAo = 0, int64_t sBo = 0, int64_t sCo = 0) {
     // the integer forward form is built without the K-tail masking: with K % 16 != 0 it runs as a general product (same result)
     if (pa == 1 && pb == 3 && (K & (BQ_KS - 1)) != 0) pa = 3;
-    const int products = (pa == 3 && pb != 1) ? 6 : (pa == 1 && pb == 1) ? 1 : 3;
+    if (pa == 1 && pb == 2 && (K & (BQ_KS - 1)) != 0) pa = 2;
+    const int products = (pa == 3 && pb != 1) ? 6 : (pa == 1 && pb == 1) ? 1 : ((pa == 2 && pb == 1) || (pa == 1 && pb == 2)) ? 2 : 3;
     const BqPlan pl = bq_plan(M, N, K, G, allow_split, products, pb == 0);
     ADALOG_ARG_CHECK(pl.S == 1 || workspace, "gemm_f32x3: the split product needs its workspace");
     ADALOG_ARG_CHECK((((uintptr_t)workspace) & 15) == 0, "gemm_f32x3: workspace must be 16-byte aligned");
@@ -759,8 +803,8 @@ extern "C" int adalog_gemm_f32x3_g2(const float* A, int64_t lda, int transA, con
     ADALOG_ARG_CHECK(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, "gemm_f32x3: leading dimensions too small");
     ADALOG_ARG_CHECK((int64_t)(transA ? K : M) * lda * 4 < 0x7fffffffLL && (int64_t)(transB ? K : N) * ldb * 4 < 0x7fffffffLL,
                      "gemm_f32x3: an operand matrix exceeds 2 GiB");
-    const int products = bq_products(exactA, exactB, transA, transB);
-    const int pa = (products == 3 && exactA) ? 1 : 3, pb = (products == 3 && exactB) ? 1 : 3;
+    int pa, pb;
+    bq_forms(exactA, exactB, transA, transB, pa, pb);
     return bq_run(A, lda, transA, B, ldb, transB, 0, C, ldc, M, N, K, G, sAg, sBg, sCg, bias, alpha, alpha_dev, allow_split, pa, pb,
                   workspace, stream, Gi, sAo, sBo, sCo);
 }

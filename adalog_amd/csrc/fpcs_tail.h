@@ -1,14 +1,15 @@
 // The tail of an FPCS step -- rank the P scores of a column, then write the next 16 x 8 candidate grid around the k survivors or
 // commit the winner (reference quant_layers/linear.py:483-523, matmul.py:243-262, conv.py:292-311) -- as DEVICE code plus its
 // arguments as a C struct, shared by every kernel that ends a step: k_topk_next (stand-alone), the finish kernels of the token forms
-// (gemm_finish.inc: k_finish_tpo_topk / k_finish_wgacc_topk) and k_score_sorted_col (a workgroup per score column of the per-channel /
-// per-row self-MSE searches).  The struct carries what round 6 changed for ALL of them: the grid spacing is read from `delta_in` and
+// (gemm_finish.inc: k_finish_tpo_topk / k_finish_wgacc_topk).  The struct carries what round 6 changed for ALL of them: the grid spacing is read from `delta_in` and
 // written to `delta_out` (the memoised spacing is never cloned), and the commit step writes the winner straight into the quantiser's
 // parameter storage (no copy_ launches afterwards).
-// What was measured and NOT kept (same-box A/Bs, profiles/r06_notes.md): running the tail inside k_gram_score (a ticket per output row)
-// and inside k_ga_finish / a one-workgroup k_score_sorted for the per-tensor searches -- on this multi-XCD part an agent-scope ticket
-// or score read is a ~2 us round trip, and one workgroup cannot issue a step's 2 176 divergent bisection loads as fast as eight can:
-// each lost to the separate 11 us k_topk_next launch.  score_publish / ticket_last below serve k_sel_hist_pick (select.hip).
+// What was measured and NOT kept (same-box A/Bs, profiles/r06_notes.md): running the tail inside the kernels that produce final scores
+// -- k_gram_score (a ticket per output row), k_ga_finish and k_score_sorted (tickets; or one 1 024-thread workgroup per score column
+// ranking in LDS).  On this multi-XCD part an agent-scope ticket or score read is a ~2 us round trip, the last arrivals serialise
+// the columns' tails, and a workgroup per column cannot issue its 2 176 divergent bisection loads as fast as the spread-out form:
+// every variant lost to the separate 11 us k_topk_next launch.  Their `_tail` entry points run the two launches in one call.
+// score_publish / ticket_last below serve k_sel_hist_pick (select.hip).
 // Same deterministic order everywhere: score descending, candidate index ascending, NaN first (torch.topk with ties made
 // deterministic).
 #pragma once

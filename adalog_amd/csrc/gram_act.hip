@@ -41,8 +41,9 @@
 #include <type_traits>
 #include <utility>
 
-#include <hipcub/hipcub.hpp>
-
+extern "C" int64_t adalog_sort_workspace_bytes(int64_t S, int64_t n, int with_perm);
+extern "C" int adalog_sort_f32(const float* x, int64_t S, int64_t n, float* sorted, unsigned int* perm, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 extern "C" int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream);
 
 namespace {
@@ -191,10 +192,6 @@ __global__ __launch_bounds__(256) void k_ga_fin_c(const int* __restrict__ part, 
 }
 
 // ------------------------------------------------------------------------------------------------ prefix sums of C in sorted order
-__global__ void k_ga_iota(unsigned int* __restrict__ v, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (unsigned int)i;
-}
 
 // Cs[i] = C[perm[i]] (the one random pass over C) and the block sums of Cs
 __global__ __launch_bounds__(256) void k_ga_gather_sum(const double* __restrict__ C, const unsigned int* __restrict__ perm, int64_t n,
@@ -907,10 +904,7 @@ extern "C" int64_t adalog_gram_act_workspace_bytes(int T, int O, int K, int P) {
  * values, and the permutation that sorts them (perm[i] = flat index t K + k of the i-th smallest).  sort_ws: adalog_gram_act_sort_bytes. */
 extern "C" int64_t adalog_gram_act_sort_bytes(int64_t n) {
     if (n < 1 || n >= ((int64_t)1 << 31)) return -1;
-    size_t bytes = 0;
-    const float* k = nullptr; float* ko = nullptr; const unsigned int* v = nullptr; unsigned int* vo = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k, ko, v, vo, (int)n, 0, 32, (hipStream_t)0);
-    return (int64_t)al256((int64_t)bytes) + al256(n * 4);
+    return al256(adalog_sort_workspace_bytes(1, n, 1));                 // csrc/radix_sort.hip
 }
 
 extern "C" int adalog_gram_act_prepare(const float* x, int T, int K, int64_t ldx, float* xt, float* sorted, unsigned int* perm,
@@ -922,12 +916,9 @@ extern "C" int adalog_gram_act_prepare(const float* x, int T, int K, int64_t ldx
     const int64_t Tp = ((int64_t)T + 127) / 128 * 128;
     ADALOG_ARG_CHECK(K % 32 == 0, "gram_act_prepare: K must be a multiple of 32");
     hipLaunchKernelGGL(k_ga_fragorder, dim3((unsigned)(Tp / 32), (unsigned)(K / 32)), dim3(256), 0, st, x, T, K, ldx, xt, (int)(Tp / 32));
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, x, sorted, (const unsigned int*)nullptr, perm, (int)n, 0, 32, st);
-    unsigned int* iota = (unsigned int*)((uint8_t*)sort_ws + al256((int64_t)bytes));
-    hipLaunchKernelGGL(k_ga_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, iota, n);
-    const hipError_t e = hipcub::DeviceRadixSort::SortPairs(sort_ws, bytes, x, sorted, iota, perm, (int)n, 0, 32, st);
-    if (e != hipSuccess) { adalog_set_error("adalog_gram_act_prepare (sort)", e); return (int)e; }
+    // the values sorted, and the permutation that sorts them (flat indices t K + k): one segment of the hand-written radix sort
+    const int rc = adalog_sort_f32(x, 1, n, sorted, perm, sort_ws, sort_ws_bytes, stream);
+    if (rc) return rc;
     ADALOG_LAUNCH_CHECK("adalog_gram_act_prepare");
     return 0;
 }

@@ -8,7 +8,7 @@
 // and sat at its VALU floor (0.01 of the HBM roofline, 6.4 % of a calibration).  A uniform quantiser is a monotone step
 // function: for a candidate (s, z) the elements that land on level k form ONE contiguous run of the SORTED tensor.  So
 //   1. sort every segment once per captured tensor (per tensor: one segment; per channel / per weight row: one each) --
-//      a plain library radix sort (hipCUB), like rocBLAS for a plain GEMM;
+//      csrc/radix_sort.hip (hipCUB until round 5);
 //   2. exclusive prefix sums of x and x^2 along the sorted order, in fp64 (x^2 of an fp32 is exact in fp64);
 //   3. per (segment, candidate): one thread per level finds the first element of its run by bisection WITH THE EXACT
 //      PREDICATE rne(fl32(x / s)) >= k (IEEE divide, round-half-even: the reference's own op sequence, uniform.py:29) and
@@ -22,19 +22,15 @@
 #include "fpcs_tail.h"
 #include <stdlib.h>
 
-#include <hipcub/hipcub.hpp>
-
+extern "C" int64_t adalog_sort_workspace_bytes(int64_t S, int64_t n, int with_perm);
+extern "C" int adalog_sort_f32(const float* x, int64_t S, int64_t n, float* sorted, unsigned int* perm, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 extern "C" int adalog_topk_next_tail(const float* scores, int P, int cols, const adalog_fpcs_tail* tail, int* idx_out, void* stream);
 
 namespace {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 constexpr int PB = 1024;                 // elements per prefix block (256 threads x 4)
-
-__global__ void k_seg_offsets(int* __restrict__ offs, int64_t S, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i <= S) offs[i] = (int)(i * n);
-}
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -180,118 +176,9 @@ __global__ __launch_bounds__(256) void k_score_sorted(const float* __restrict__ 
     if (live && t == 0) scores[pair] = (float)(-norm * red[threadIdx.x]);
 }
 
-// The same scores with the FPCS step's tail in the launch (round 6; fpcs_tail.h): ONE workgroup of 1024 threads per segment holds
-// all P candidates of its score column -- P x G (candidate, level) bisections, thread-strided -- so it ranks the column in LDS and
-// writes the column's next grid / commits its winner itself: no ticket, no second launch (k_topk_next before: 660 launches per
-// deit_small calibration).  Same arithmetic and the same fixed-order tree over a candidate's G run sums as k_score_sorted: the scores
-// are bit-identical.  LDS: bnd int32 [P][G + 1], acc double [P][G], scores float [P], top int [P].
-template <int G>
-__global__ __launch_bounds__(1024) void k_score_sorted_col(const float* __restrict__ sorted, const d2* __restrict__ prefix, int64_t S,
-                                                          int64_t n, const float* __restrict__ scale, const float* __restrict__ zp,
-                                                          int P, float qmax, double norm, float* __restrict__ scores, fpcs::Tail tail) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    double* acc = reinterpret_cast<double*>(lds_raw);                   // [P][G]
-    int* bnd = reinterpret_cast<int*>(acc + (size_t)P * G);             // [P][G + 1]
-    float* sc = reinterpret_cast<float*>(bnd + (size_t)P * (G + 1));    // [P]
-    int* top = reinterpret_cast<int*>(sc + P);                          // [P]
-    const int seg = blockIdx.x, tid = threadIdx.x;
-    const float* x = sorted + (int64_t)seg * n;
-    const d2* pf = prefix + (int64_t)seg * (n + 1);
-    const int ni = (int)n;
-    // boundaries: item (p, t), t = 0 .. G (t = G: the upper clamped run's start); a thread walks FOUR bisections in lockstep -- the
-    // launch is a chain of dependent far-memory round trips, so the items of a thread must overlap, not queue (one after the other
-    // they made this kernel slower than the eight-workgroup form plus a separate k_topk_next)
-    for (int base = 0; base < P * (G + 1); base += 4 * 1024) {
-        int lo[4], hi[4], idx[4];
-        float sv[4], tg[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int it = base + u * 1024 + tid;
-            idx[u] = it < P * (G + 1) ? it : -1;
-            lo[u] = 0; hi[u] = idx[u] >= 0 ? ni : 0;
-            sv[u] = 1.0f; tg[u] = 0.0f;
-            if (idx[u] >= 0) {
-                const int p = it / (G + 1), t = it - p * (G + 1);
-                const float s = scale[(int64_t)p * S + seg], z = zp[(int64_t)p * S + seg];
-                const float klo = ceilf(-z), khi = floorf(qmax - z);
-                sv[u] = s;
-                tg[u] = t == G ? khi + 1.0f : fminf(klo + (float)t, khi + 1.0f);
-            }
-        }
-        for (int step = 0; step < 32; ++step) {
-            float xv[4];
-            bool any = false;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool a = lo[u] < hi[u];
-                any |= a;
-                xv[u] = a ? x[(int)(((unsigned)lo[u] + (unsigned)hi[u]) >> 1)] : 0.0f;
-            }
-            if (!any) break;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (lo[u] < hi[u]) {
-                    const int mid = (int)(((unsigned)lo[u] + (unsigned)hi[u]) >> 1);
-                    if (rintf(xv[u] / sv[u]) >= tg[u]) hi[u] = mid; else lo[u] = mid + 1;     // first i with rne(x[i] / s) >= target
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (idx[u] >= 0) bnd[idx[u]] = lo[u];
-    }
-    __syncthreads();
-    for (int it = tid; it < P * G; it += 1024) {
-        const int p = it / G, t = it - p * G;
-        const float s = scale[(int64_t)p * S + seg], z = zp[(int64_t)p * S + seg];
-        const float klo = ceilf(-z), khi = floorf(qmax - z);
-        const int* bp = bnd + p * (G + 1);
-        auto run = [&](int a, int b, float level) {
-            if (b <= a) return 0.0;
-            const float q = fminf(fmaxf(level + z, 0.0f), qmax);
-            const double c = (double)((q - z) * s);
-            const d2 pa = pf[a], pb = pf[b];
-            return (pb.y - pa.y) - 2.0 * c * (pb.x - pa.x) + (double)(b - a) * c * c;
-        };
-        double a = run(bp[t], bp[t + 1], klo + (float)t);
-        if (t == 0) a += run(0, bp[0], klo - 1.0f) + run(bp[G], ni, khi + 1.0f);
-        acc[it] = a;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {                               // the fixed-order tree of k_score_sorted, per candidate
-        for (int it = tid; it < P * o; it += 1024) {
-            const int p = it / o, t = it - p * o;
-            acc[p * G + t] += acc[p * G + t + o];
-        }
-        __syncthreads();
-    }
-    for (int p = tid; p < P; p += 1024) {
-        const float v = (float)(-norm * acc[p * G]);
-        sc[p] = v;
-        scores[(int64_t)p * S + seg] = v;
-    }
-    __syncthreads();
-    // rank + next grid / commit (fpcs_tail.h), the scores already in LDS
-    const float d = tail.new_cnt > 0 ? tail.delta_in[seg] : 0.0f;
-    for (int p = tid; p < P; p += 1024) {
-        const int r = fpcs::rank_of(sc, P, p);
-        if (r < tail.k) top[r] = p;
-    }
-    __syncthreads();
-    fpcs::emit(top, (int)S, seg, tid, 1024, d, tail);
-    if (tail.new_cnt > 0) {
-        __syncthreads();
-        if (tid == 0) tail.delta_out[seg] = d / ((float)tail.new_cnt - 0.5f);
-    }
-}
-
 size_t sort_temp_bytes(int64_t S, int64_t n) {
-    size_t bytes = 0;
-    const float* in = nullptr; float* out = nullptr; const int* offs = nullptr;
-    if (S == 1) (void)hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, in, out, (int)n, 0, 32, (hipStream_t)0);
-    else (void)hipcub::DeviceSegmentedRadixSort::SortKeys(nullptr, bytes, in, out, (int)(S * n), (int)S, offs, offs + 1, 0, 32, (hipStream_t)0);
-    return (bytes + 255) / 256 * 256;
+    const int64_t b = adalog_sort_workspace_bytes(S, n, 0);            // csrc/radix_sort.hip
+    return (size_t)((b < 256 ? 256 : b) + 255) / 256 * 256;
 }
 
 }  // namespace
@@ -316,14 +203,11 @@ extern "C" int adalog_sorted_prefix_build(const float* x, int64_t S, int64_t n, 
     uint8_t* ws = (uint8_t*)workspace;
     int* offs = (int*)(ws + tb);
     d2* bsum = (d2*)(ws + tb + ((S + 1) * 4 + 255) / 256 * 256);
-    hipError_t e;
-    if (S == 1) {
-        e = hipcub::DeviceRadixSort::SortKeys(ws, tb, x, sorted, (int)n, 0, 32, st);
-    } else {
-        hipLaunchKernelGGL(k_seg_offsets, dim3(cdiv(S + 1, 256)), dim3(256), 0, st, offs, S, n);
-        e = hipcub::DeviceSegmentedRadixSort::SortKeys(ws, tb, x, sorted, (int)(S * n), (int)S, offs, offs + 1, 0, 32, st);
+    ADALOG_ARG_CHECK(((uintptr_t)workspace & 255) == 0 || n <= 8192, "sorted_prefix_build: workspace must be 256-byte aligned");
+    {
+        const int rc = adalog_sort_f32(x, S, n, sorted, nullptr, ws, (int64_t)tb, stream);      // hand-written LSD radix sort, per segment
+        if (rc) return rc;
     }
-    if (e != hipSuccess) { adalog_set_error("adalog_sorted_prefix_build (sort)", e); return (int)e; }
     const int nb = cdiv(n, PB);
     ADALOG_ARG_CHECK(S <= 65535, "sorted_prefix_build: more than 65535 segments");
     hipLaunchKernelGGL(k_sp_blocksum, dim3(nb, (unsigned)S), dim3(256), 0, st, sorted, n, nb, bsum);
@@ -346,33 +230,6 @@ extern "C" int adalog_score_self_sorted_tail(const float* sorted, const double* 
     const int G = 1 << n_bits;
     hipStream_t st = (hipStream_t)stream;
     adalog_note_kernel("k_score_sorted");
-    const size_t col_lds = (size_t)P * G * 8 + (size_t)P * (G + 1) * 4 + (size_t)P * 8;
-    // (a workgroup per column pays when the columns fill the chip: with ONE column -- the per-tensor searches -- the 2 176 bisections
-    // of a step sat on one CU, whose address path takes a fully divergent load at one line per clock: 51 us against 32 + 11 for the
-    // eight-workgroup form and a separate k_topk_next)
-    static const int col_min = getenv("ADALOG_SORTED_COL_MIN") ? atoi(getenv("ADALOG_SORTED_COL_MIN")) : 64;
-    if (tail && S >= col_min && G <= 64 && col_lds <= 150 * 1024 && S <= 65535 && n < ((int64_t)1 << 31)) {
-        // a workgroup per score column: scores, ranking and the next grid in one launch
-#define LAUNCH_SC(GV)                                                                                              \
-        do {                                                                                                       \
-            static unsigned long long attr_dev = 0;                                                                \
-            hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_score_sorted_col<GV>), 150 * 1024, &attr_dev); \
-            if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; }           \
-            hipLaunchKernelGGL((k_score_sorted_col<GV>), dim3((unsigned)S), dim3(1024), col_lds, st, sorted, (const d2*)prefix, S, n, \
-                               scale, zp, P, qmax, norm, scores, *tail);                                           \
-        } while (0)
-        switch (n_bits) {
-            case 1: LAUNCH_SC(2); break;
-            case 2: LAUNCH_SC(4); break;
-            case 3: LAUNCH_SC(8); break;
-            case 4: LAUNCH_SC(16); break;
-            case 5: LAUNCH_SC(32); break;
-            default: LAUNCH_SC(64); break;
-        }
-#undef LAUNCH_SC
-        ADALOG_LAUNCH_CHECK("adalog_score_self_sorted");
-        return 0;
-    }
     const int64_t pairs = (int64_t)P * S;
     const int gpb = 256 / G;
     const int64_t blocks = (pairs + gpb - 1) / gpb;
@@ -390,7 +247,11 @@ extern "C" int adalog_score_self_sorted_tail(const float* sorted, const double* 
     }
 #undef LAUNCH_SS
     ADALOG_LAUNCH_CHECK("adalog_score_self_sorted");
-    if (tail) return adalog_topk_next_tail(scores, P, (int)S, tail, nullptr, stream);     // (7 / 8 bit: the column does not fit one workgroup's LDS)
+    // the FPCS step's tail: a second launch.  Measured and not kept (round 6, same-box A/Bs): a ticket per segment with the last
+    // arrival ranking it (126 us against 32 + 11: the last blocks serialise the columns' tails), and a workgroup of 1 024 threads per
+    // segment holding all P x G bisections and ranking in LDS (60 us against 40 + 11 for the per-channel searches, 51 against 16 + 11
+    // for the per-tensor ones, where one CU's address path serialises the divergent loads)
+    if (tail) return adalog_topk_next_tail(scores, P, (int)S, tail, nullptr, stream);
     return 0;
 }
 

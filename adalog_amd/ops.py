@@ -922,6 +922,25 @@ def score_a_self(x2, scale, zp, channel_wise: bool, n_bits: int, norm: float):
     return scores
 
 
+def sort_f32(x2, want_perm: bool = False):
+    """x2 [S, n] fp32 -> (sorted [S, n] ascending per segment, perm [S, n] int32 | None): the hand-written stable LSD radix sort of
+    csrc/radix_sort.hip (what SortedPrefix and GramActPrepared sort with).  perm[s, i] = index within segment s of its i-th smallest."""
+    x2 = _f32c(x2, "x")
+    if x2.dim() != 2:
+        raise ValueError("sort_f32: expected [S, n]")
+    S, n = x2.shape
+    lib = _lib.load()
+    nb = lib.adalog_sort_workspace_bytes(S, n, int(want_perm))
+    if nb < 0:
+        raise _lib.AdalogHipError("sort_f32: unsupported size")
+    ws = _aligned_bytes(nb, x2.device)
+    out = torch.empty_like(x2)
+    perm = torch.empty((S, n), dtype=torch.int32, device=x2.device) if want_perm else None
+    rc = lib.adalog_sort_f32(x2.data_ptr(), S, n, out.data_ptr(), _ptr(perm), ws.data_ptr(), nb, _stream())
+    _lib.check(rc, "adalog_sort_f32")
+    return out, perm
+
+
 class SortedPrefix:
     """A [S, n] tensor sorted per segment with fp64 prefix sums of x and x^2 along the sorted order (csrc/sorted_score.hip):
     what the self-MSE searches score their candidates from.  Built once per captured tensor, shared by the FPCS steps."""
@@ -1325,7 +1344,9 @@ def gemm_f32x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = 
     """alpha * alpha_dev[0] * a @ b^T (+ bias) for fp32 operands of either memory orientation, at fp32 accuracy on the bf16
     matrix cores (csrc/brecq_gemm.hip).  a: [..., M, K], b: [..., N, K] -> [..., M, N] (contiguous, or written into ``out``: any
     view whose last dim is contiguous and whose leading dims form at most two stride levels).
-    exact_a / exact_b: that operand holds integers exactly representable in bf16 (3 products instead of 6 where supported)."""
+    exact_a / exact_b: True / 1 = that operand holds integers exactly representable in bf16 (3 products instead of 6 where
+    supported); 2 = a two-term split of that operand is enough (hi + mid: 2^-16 relative -- the gradient contractions of a BRECQ
+    iteration: 3 products for two such operands, 2 against an exact one)."""
     if not gemm_f32x3_ok(a, b, bias, out):
         raise _lib.AdalogHipError(f"gemm_f32x3: unsupported operand layout {tuple(a.shape)}/{a.stride()} x {tuple(b.shape)}/{b.stride()}")
     la, lb = _mat_layout(a), _mat_layout(b)
@@ -1335,7 +1356,7 @@ def gemm_f32x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = 
     lo = _mat_layout(out)
     Gi, ((sa, sao), (sb, sbo), (sc, sco)) = _group_levels([la, lb, lo])
     lib = _lib.load()
-    sp, ea, eb = (1 if allow_split else 0), (1 if exact_a else 0), (1 if exact_b else 0)
+    sp, ea, eb = (1 if allow_split else 0), int(exact_a), int(exact_b)
     wsb = int(lib.adalog_gemm_f32x3_workspace_bytes(M, N, K, G, sp, ea, eb, la[0], lb[0]))
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device) if wsb else None
     rc = lib.adalog_gemm_f32x3_g2(a.data_ptr(), la[1], la[0], b.data_ptr(), lb[1], lb[0], out.data_ptr(), lo[1], M, N, K, G,

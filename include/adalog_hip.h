@@ -377,6 +377,15 @@ int adalog_score_self_sorted_tail(const float* sorted, const double* prefix, int
                                   const float* zp, int P, int n_bits, double norm, float* scores, const adalog_fpcs_tail* tail,
                                   void* stream);
 
+/* ---- stable LSD radix sort of fp32 keys, per segment (csrc/radix_sort.hip; hipCUB until round 5): what the sorted forms above and
+ * adalog_gram_act_prepare sort with.  x [S][n] contiguous -> sorted [S][n] (ascending per segment; -0 before +0), perm (may be null)
+ * [S][n]: perm[s][i] = index within segment s of its i-th smallest value, equal values in input order.  n <= 8192: one launch (a
+ * workgroup per segment, four passes in LDS, no workspace needed); longer segments: 12 launches over 8192-key tiles.  workspace:
+ * adalog_sort_workspace_bytes(S, n, perm != NULL) bytes, 256-byte aligned; S <= 65535, S n < 2^31; x and sorted must not overlap. */
+int64_t adalog_sort_workspace_bytes(int64_t S, int64_t n, int with_perm);
+int adalog_sort_f32(const float* x, int64_t S, int64_t n, float* sorted, unsigned int* perm, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
 /* ---- K5/K6  exact order statistics by radix select
  * adalog_quantile_rows: torch.quantile(x.view(S, n), q, dim=-1, interpolation='linear') for nq <= 4 quantiles, then the mean
  *   over each group of `mbs` consecutive rows (the reference's chunked quantile, linear.py:465-471, matmul.py:219-230).

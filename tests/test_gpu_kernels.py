@@ -1241,6 +1241,48 @@ def test_round_loss_multi_matches_per_tensor(ops):
     torch.testing.assert_close(loss_b, loss)
 
 
+# ------------------------------------------------------------------------------------------------ radix sort (csrc/radix_sort.hip)
+@pytest.mark.parametrize("S,n", [(1, 1), (1, 100), (3, 8192), (5, 8191), (384, 6304), (1152, 384), (1, 8193), (2, 100352), (1, 2420736),
+                                 (7, 20000)])
+def test_sort_f32_matches_a_stable_sort(ops, S, n):
+    """adalog_sort_f32 (the hand-written LSD radix sort that replaced hipCUB under the sorted self-MSE searches and the Gram
+    activation form): every segment ascending and equal to torch.sort's values bit for bit, the permutation the STABLE one (equal
+    values in input order).  Data with many duplicates, both signs, denormals, zeros and huge values; both the one-launch LDS form
+    (n <= 8192) and the tiled form."""
+    gen = g(9100 + S + n)
+    x = torch.randn(S, n, generator=gen)
+    x[:, ::3] = torch.round(x[:, ::3] * 4) / 4 + 0.0                # duplicates (+ 0.0: no -0.0, which the bit order puts before +0.0
+                                                                    # while torch.sort calls the two equal and keeps their input order)
+    if n > 16:
+        x[:, 5] = 0.0; x[:, 6] = 1e-42; x[:, 7] = -1e-42; x[:, 8] = 3e38; x[:, 9] = -3e38; x[:, 10] = 0.0
+    xd = x.to(DEV)
+    out, perm = ops.sort_f32(xd, want_perm=True)
+    ref, ridx = torch.sort(x, dim=1, stable=True)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(perm.cpu().long(), ridx)
+    out2, none = ops.sort_f32(xd, want_perm=False)
+    assert none is None and torch.equal(out2, out)
+
+
+def test_sorted_prefix_and_gram_act_prepare_use_no_library_sort(ops):
+    """The two call sites that sorted with hipCUB (rocPRIM kernels) until round 5 launch none now."""
+    from torch.profiler import ProfilerActivity, profile
+    gen = g(9200)
+    x = torch.randn(6304, 384, generator=gen).to(DEV)
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        sp1 = ops.sorted_prefix(x.view(1, -1))
+        sp2 = ops.sorted_prefix(x.t().contiguous())
+        prep = ops.GramActPrepared(x)
+        torch.cuda.synchronize()
+    names = [e.key for e in prof.key_averages()]
+    assert not any("rocprim" in n_ or "hipcub" in n_ for n_ in names), [n_ for n_ in names if "rocprim" in n_ or "hipcub" in n_]
+    assert any("k_rs_" in n_ for n_ in names), names
+    ref = torch.sort(x.view(-1).cpu())[0]
+    assert torch.equal(sp1.sorted.view(-1).cpu(), ref) and torch.equal(prep.sorted.cpu(), ref)
+    assert torch.equal(x.view(-1)[prep.perm.long()].cpu(), ref)
+    assert torch.equal(sp2.sorted.cpu(), torch.sort(x.t().cpu(), dim=1)[0])
+
+
 # ------------------------------------------------------------------------------------------------ K17b: BRECQ contractions
 def _last_kernel():
     from adalog_amd import _lib
@@ -1288,6 +1330,32 @@ def test_gemm_f32x3_integer_operand_and_planes(ops):
         gw = ops.gemm_f32x3(gy.t(), xi.t(), alpha_dev=sc, exact_b=True)
         refw = CB.gemm_f32x3(gy.cpu().t(), xi.cpu().t(), alpha_dev=sc.cpu()).double()
         assert rel_err(gw.cpu().double(), refw) <= 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 36, 40), (300, 260, 52), (197, 197, 64), (6304, 384, 384), (384, 1536, 6304)])
+def test_gemm_f32x3_two_term_operands(ops, M, N, K):
+    """exact = 2 (round 6: the gradient contractions of a BRECQ iteration): two bf16 terms per general operand -- three MFMA products
+    (hi.hi, hi.mid, mid.hi), two against an integer operand -- in every orientation, against the fp64 product.  The dropped terms
+    are 2^-16 relative per factor: the result stays within 6e-5 of the fp64 product (rms-normalised, like the three-term test's
+    2e-6) and is far more accurate than a plain bf16 product (4e-3)."""
+    gen = g(7150 + M + N + K)
+    for ta in (0, 1):
+        for tb in (0, 1):
+            a = (torch.randn(K, M, generator=gen).to(DEV).t() if ta else torch.randn(M, K, generator=gen).to(DEV))
+            b = (torch.randn(K, N, generator=gen).to(DEV).t() if tb else torch.randn(N, K, generator=gen).to(DEV))
+            assert ops.gemm_f32x3_ok(a, b, None)
+            out = ops.gemm_f32x3(a, b, exact_a=2, exact_b=2)
+            assert _last_kernel().startswith("bq_gemm<")
+            ref = CB.gemm_f32x3(a.cpu(), b.cpu()).double()
+            err = rel_err(out.cpu().double(), ref)
+            assert err <= 6e-5, (M, N, K, ta, tb, err)
+    # dL/dw against the integer activation: gy two-term, x_int exact (two products)
+    xi = torch.randint(-15, 16, (M, K), generator=gen).float().to(DEV)
+    gy = torch.randn(M, N, generator=gen).to(DEV)
+    sc = torch.tensor([0.37], device=DEV)
+    gw = ops.gemm_f32x3(gy.t(), xi.t(), alpha_dev=sc, exact_a=2, exact_b=True)
+    refw = CB.gemm_f32x3(gy.cpu().t(), xi.cpu().t(), alpha_dev=sc.cpu()).double()
+    assert rel_err(gw.cpu().double(), refw) <= 6e-5
 
 
 def test_gemm_f32x3_split_k_is_bit_reproducible(ops):

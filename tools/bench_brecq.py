@@ -24,6 +24,10 @@ def main():
     ap.add_argument("--iters", type=int, default=300)
     ap.add_argument("--images", type=int, default=128)
     ap.add_argument("--block", default="blocks.0")
+    ap.add_argument("--kernel-stats", default=None,
+                    help="write a BRECQ-ONLY per-kernel table (name, calls, total / average microseconds) of the reconstruct_single_block "
+                         "call to this CSV: the kernel activity records of torch.profiler (roctracer) around that call alone -- the "
+                         "calibration that precedes it is outside the window")
     args = ap.parse_args()
     import copy
     from adalog_amd.utils.block_recon import BlockReconstructor
@@ -59,10 +63,28 @@ def main():
             marks[it] = time.perf_counter()
     rec.iter_hook = hook
     torch.cuda.synchronize()
+    prof = None
+    if args.kernel_stats:
+        from torch.profiler import ProfilerActivity, profile
+        prof = profile(activities=[ProfilerActivity.CUDA])
+        prof.__enter__()
     t0 = time.perf_counter()
     rec.reconstruct_single_block(name, block, dev, quant_act=True, iters=args.iters)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        prof.__exit__(None, None, None)
+        rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)
+        tot = sum(e.device_time_total for e in rows) or 1.0
+        with open(args.kernel_stats, "w") as f:
+            f.write("Name,Calls,TotalDurationUs,AverageUs,Percentage,CallsPerIteration\n")
+            for e in rows:
+                if e.device_time_total <= 0:
+                    continue
+                f.write('"%s",%d,%.1f,%.2f,%.2f,%.2f\n' % (e.key.replace('"', "'"), e.count, e.device_time_total,
+                                                         e.device_time_total / max(e.count, 1), 100.0 * e.device_time_total / tot,
+                                                         e.count / args.iters))
+        print(f"kernel stats of the reconstruct_single_block call ({args.iters} iterations, profiler attached): {args.kernel_stats}")
     print(f"{args.model} W{args.bits}A{args.bits} {name}: {args.iters} iterations in {dt:.2f} s = {args.iters / dt:.1f} it/s "
           f"({dt / args.iters * 1e3:.2f} ms per iteration)")
     if len(marks) == 2:

@@ -1,6 +1,6 @@
 # round-6 lab: GPU tests touched by the FPCS-tail work, then a same-box A/B of ADALOG_FUSED_TAIL and a kernel-stats profile
 mkdir -p gpurun_out/r6d
-python -m pytest tests/test_gpu_kernels.py tests/test_gpu_traces.py tests/test_gpu_layers.py tests/test_gpu_e2e.py -x -q > gpurun_out/r6d/pytest.log 2>&1; tail -3 gpurun_out/r6d/pytest.log
+python -m pytest tests/test_gpu_kernels.py tests/test_gpu_traces.py tests/test_gpu_layers.py tests/test_gpu_distributed.py -x -q > gpurun_out/r6d/pytest.log 2>&1; tail -3 gpurun_out/r6d/pytest.log
 for i in 1 2; do for v in 1 0; do
   ADALOG_FUSED_TAIL=$v python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/r6d/b_${v}_$i.json 2>/dev/null
   python -c "
