@@ -517,6 +517,102 @@ __global__ __launch_bounds__(256) void k_pack_uniform_tab(PackArgs a) {
     }
 }
 
+// The same packer for ONE-BYTE outputs (fp8 / int8) with 16 consecutive k per thread: one 16-byte store per lane and candidate
+// (1 KiB per wave-store; the 4-byte stores of k_pack_uniform_tab wrote the fc2 weight candidates -- 75 MB of fp8 per launch -- at
+// 1.4 TB/s).  Needs K % 16 == 0 == Kp % 16, 16-byte aligned source rows and Kp / 16 >= 64 (a wave then spans at most two rows: the
+// row sums are reduced per row inside the wave).
+template <typename T>
+__global__ __launch_bounds__(256) void k_pack_uniform_tab16(PackArgs a) {
+    constexpr bool FP8OUT = std::is_same<T, fp8_t>::value;
+    static_assert(sizeof(T) == 1, "one-byte outputs");
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float4* s_tab = reinterpret_cast<float4*>(s_raw);                       // [rows of this block][C]
+    const int64_t nq = a.Kp >> 4;                                            // 16-element groups per row
+    const int64_t total = a.G * a.R * nq;
+    const int64_t q0 = (int64_t)blockIdx.x * 256;
+    const int64_t row0 = q0 / nq;
+    const int64_t rowN = min((q0 + 255) / nq, a.G * a.R - 1);
+    const int nrows = (int)(rowN - row0 + 1);
+    const int C = (int)a.C;
+    for (int e = threadIdx.x; e < nrows * C; e += 256) {
+        const int rl = e / C, c = e - rl * C;
+        const int64_t gr = row0 + rl, g = gr / a.R, r = gr - g * a.R;
+        const int64_t pidx = c * a.pc + (g % a.gmod) * a.pg + r * a.pr;
+        const float sc = a.scale[pidx], z = rintf(a.zp[pidx]);
+        s_tab[e] = make_float4(__builtin_amdgcn_rcpf(sc), sc, -z, a.qmax - z);
+    }
+    __syncthreads();
+    const int64_t idx = q0 + threadIdx.x;
+    const bool live = idx < total;
+    const int64_t gr = live ? idx / nq : row0, kq = live ? idx - gr * nq : 0;
+    const int64_t g = gr / a.R, r = gr - g * a.R;
+    const int64_t k0 = kq << 4;
+    float xv[16];
+    const bool in_k = live && k0 < a.K;                                      // (K % 16 == 0: a group is all valid or all padding)
+    if (in_k) {
+        const float4* xp = reinterpret_cast<const float4*>(a.x + g * a.sxg + r * a.sxr + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float4 v = xp[j]; xv[4 * j] = v.x; xv[4 * j + 1] = v.y; xv[4 * j + 2] = v.z; xv[4 * j + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) xv[e] = 0.0f;
+    }
+    const float4* tab = s_tab + (int)(gr - row0) * C;
+    for (int64_t c = blockIdx.y; c < a.C; c += gridDim.y) {
+        const float4 pr = tab[c];
+        float k[16], dm = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float t = xv[e] * pr.x; k[e] = rintf(t); dm = fmaxf(dm, fabsf(t - k[e])); }
+        if (__builtin_expect(dm > 0.4999f, 0)) {                             // tie zone (see k_pack_kfast): the IEEE quotient decides
+#pragma unroll
+            for (int e = 0; e < 16; ++e) k[e] = rintf(xv[e] / pr.y);
+        }
+        float v[16];
+        float fs = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            v[e] = in_k ? __builtin_amdgcn_fmed3f(k[e], pr.z, pr.w) : 0.0f;   // clamp(k + z, 0, qmax) - z
+            fs += v[e];                                                      // small integers: exact in fp32
+        }
+        if (live) {
+            const int64_t orow = a.c_inner ? (g * a.R + r) * a.C + c : (c * a.G + g) * a.R + r;
+            T* op = reinterpret_cast<T*>(a.out) + orow * a.Kp + k0;
+            uint4 o;
+            unsigned* ow = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (FP8OUT) {
+                    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * j], v[4 * j + 1], 0, false);
+                    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * j + 2], v[4 * j + 3], pk, true);
+                    ow[j] = (unsigned)pk;
+                } else {
+                    unsigned pk = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk = __builtin_amdgcn_cvt_pk_u8_f32(v[4 * j + e] + 128.0f, e, pk);
+                    ow[j] = pk ^ 0x80808080u;
+                }
+            }
+            *reinterpret_cast<uint4*>(op) = o;
+        }
+        if (a.rowsum) {
+            // a wave spans at most two rows (Kp / 16 >= 64): reduce each row's lanes, one atomic per (row, wave)
+            const int ridx = live ? (int)((c * a.G + g) * a.R + r) : -1;
+            const int first = __builtin_amdgcn_readfirstlane(ridx);
+            const bool mine = ridx == first;
+            int s1 = (live && mine) ? (int)fs : 0, s2 = (live && !mine) ? (int)fs : 0;
+#pragma unroll
+            for (int o2 = 32; o2 > 0; o2 >>= 1) { s1 += __shfl_xor(s1, o2); s2 += __shfl_xor(s2, o2); }
+            const unsigned long long other = __ballot(live && !mine);
+            if ((threadIdx.x & 63) == 0 && first >= 0 && s1 != 0) atomicAdd(a.rowsum + first, s1);
+            if (other) {
+                const int lane = threadIdx.x & 63, ol = __ffsll((long long)other) - 1;
+                const int r2 = __shfl(ridx, ol);
+                if (lane == ol && s2 != 0) atomicAdd(a.rowsum + r2, s2);
+            }
+        }
+    }
+}
+
 template <typename T, int KIND>
 int launch_pack(const PackArgs& a, hipStream_t st) {
     constexpr int EPT = Out<T>::EPT;
@@ -532,6 +628,23 @@ int launch_pack(const PackArgs& a, hipStream_t st) {
         if (KIND == KIND_UNIFORM && a.pr != 0 && use_tab && (a.Kp >> 2) >= 64 && a.C * TAB_ROWS * sizeof(float4) <= 64 * 1024 &&
             !getenv("ADALOG_PACK_GENERIC")) {
             // per-row parameters (weight candidates): parameters staged in LDS per block, exact grid (no grid-stride loop)
+            if constexpr (sizeof(T) == 1) {
+                // one-byte outputs, long aligned rows: 16 k per thread, 16-byte stores
+                static const int use16 = getenv("ADALOG_PACK_TAB16") ? atoi(getenv("ADALOG_PACK_TAB16")) : 1;
+                if (use16 && (a.K & 15) == 0 && (a.Kp & 15) == 0 && (a.Kp >> 4) >= 64 && (a.sxr & 3) == 0 && (a.sxg & 3) == 0 &&
+                    ((uintptr_t)a.x & 15) == 0 && ((uintptr_t)a.out & 15) == 0) {
+                    const int64_t t16 = a.G * a.R * (a.Kp >> 4);
+                    const int64_t bx16 = (t16 + 255) / 256;
+                    int64_t by16 = 1;
+                    while (bx16 * by16 < 1024 && by16 < a.C) by16 *= 2;
+                    // a block of 256 threads covers 256 * 16 k: at most 256 / (Kp / 16) + 2 <= TAB_ROWS rows
+                    if (bx16 < ((int64_t)1 << 31)) {
+                        hipLaunchKernelGGL((k_pack_uniform_tab16<T>), dim3((unsigned)bx16, (unsigned)by16), dim3(256),
+                                           (size_t)a.C * TAB_ROWS * sizeof(float4), st, a);
+                        return 0;
+                    }
+                }
+            }
             const int64_t bx = (total + 255) / 256;
             int64_t by = 1;
             while (bx * by < 1024 && by < a.C) by *= 2;

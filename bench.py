@@ -182,9 +182,10 @@ def hbm_kernels(ops, dev):
         ("k_uniform_rows (K1 uniform fake-quant, fp32 in/out)", 2 * nb, lambda j: ops.uniform_fake_quant(xs[j], sc1, zp1, 4)),
         ("k_adalog (K2/K3 shifted AdaLog fake-quant)", 2 * nb,
          lambda j: ops.log_fake_quant(xgs[j], sc1, q, t1, t2, 4, shift=shift, sub_shift=True)),
-        ("sorted_prefix build (K10 once per tensor: library radix sort + fp64 prefix sums; read 4 B, write 20 B per element)", 6 * nb,
+        ("sorted_prefix build (K10 once per tensor: hand-written LSD radix sort, 4 passes x (count, scatter) + fp64 prefix sums; read 4 B, "
+         "write 20 B per element)", 6 * nb,
          lambda j: ops.sorted_prefix(xs[j].view(1, -1))),
-        ("k_sel_hist/pick (K5 quantile, 4 radix passes)", 4 * nb, lambda j: ops.quantile_rows(xs[j].view(1, -1), [0.9, 1.0, 0.1, 0.0], 1)),
+        ("k_sel_hist_pick (K5 quantile, 4 radix passes, the pick folded into the counting kernel)", 4 * nb, lambda j: ops.quantile_rows(xs[j].view(1, -1), [0.9, 1.0, 0.1, 0.0], 1)),
         ("k_log2_shift (input of the fused search, once per layer)", 2 * nb, lambda j: ops.log2_shift(xgs[j], 0.17)),
         ("k_pack_uniform_tab (fc2 weight candidates: 128 x 384 x 1536 -> bf16 operand, write side)",
          Ws[0].numel() * 4 + Ws[0].numel() * P * 2,
@@ -268,8 +269,11 @@ def brecq_rate(model_name, bits, dev, iters=2000, depth=None):
                    f"{iters // 4 + 1}..{iters} (HIP-graph replay)",
             "setup_s_per_block": round(setup, 3), "block": name, "batch": 32,
             "sample_iters": iters, "blocks_in_model": nblk,
-            "contractions": ("csrc/brecq_gemm.hip (adalog_gemm_f32x3: fp32 operands as three bf16 terms, six MFMA products, fp32 "
-                             "accumulation; integer activation operands three products)" if train_mm.ENABLED else "rocBLAS fp32"),
+            "contractions": (("csrc/brecq_gemm.hip (adalog_gemm_f32x3 on the bf16 MFMA, fp32 accumulation; bf16 terms per general operand: "
+                              f"forward {3 if not train_mm.FWD_TERMS else 2}, gradients {3 if not train_mm.GRAD_TERMS else 2} "
+                              "(2 terms = 2^-16 relative: 3 products per pair of general operands, 2 against the integer activation; "
+                              "3 terms = 6 / 3 products, <= rocBLAS fp32 error); trained values within 1e-3 of the reference's own loop "
+                              "either way: tests/test_gpu_layers.py)") if train_mm.ENABLED else "rocBLAS fp32"),
             "multi_gpu": "block-parallel (blocks dealt to ranks, no collective inside an iteration); ADALOG_BRECQ_DP=batch = batch split",
             "extrapolated_s_per_block_20000_iters": round(setup + 20000 * dt_it, 1),
             "extrapolated_s_whole_model": round((setup + 20000 * dt_it) * nblk, 1)}

@@ -294,7 +294,8 @@ def issue_a(A, slot):
             A.e(f"s_mov_b32 m0, {t(6)}")
         else:
             A.e(f"s_add_i32 m0, {t(6)}, {q * 1024}")
-        A.e(f"buffer_load_dwordx4 v{V['DMA'] + q}, s[{S['rW']}:{S['rW'] + 3}], {t(7)} offen lds")
+        if not os.environ.get("FUSED_NODMA"):      # lab ablation: the weight ring is never refilled
+            A.e(f"buffer_load_dwordx4 v{V['DMA'] + q}, s[{S['rW']}:{S['rW'] + 3}], {t(7)} offen lds")
     cursor_step(A, "a", set_a_rows)
 
 
@@ -305,17 +306,24 @@ def gen_pair_ops(e, val0, first):
     ca, cc, chi = v('PAR', CA), v('PAR', CC), v('PAR', CHI)
     k, tt, x, dm = v('GT', 0), v('GT', 1), v('DX'), v('DM')
     ops = []
+    nogen, nolut, notie = os.environ.get("FUSED_NOGEN"), os.environ.get("FUSED_NOLUT"), os.environ.get("FUSED_NOTIE")
     for j in range(2):
+        if nogen:                                    # lab ablation: no generation at all (the B fragment keeps its last value)
+            continue
         ops += [
             f"v_fma_f32 {k}, {v('LV', e + j)}, {ca}, {cc}",
             f"v_med3_f32 {k}, {k}, 0, {chi}",
             f"v_add_f32 {tt}, 0x{MAGIC:08x}, {k}",
-            f"v_add_f32 {x}, 0x{(MAGIC ^ 0x80000000):08x}, {tt}",
-            f"v_sub_f32 {x}, {k}, {x}",
-            (f"v_max_f32 {dm}, abs({x}), abs({x})" if (first and j == 0) else f"v_max_f32 {dm}, abs({x}), {dm}"),
-            f"v_lshl_add_u32 {tt}, {tt}, 9, {v('LUTC')}",
-            ("ds", f"ds_read_b32 {v('VAL', val0 + j)}, {tt}", f"val{val0 + j}"),
         ]
+        if not notie:                                # lab ablation: without the near-tie tracking (3 VALU per element)
+            ops += [
+                f"v_add_f32 {x}, 0x{(MAGIC ^ 0x80000000):08x}, {tt}",
+                f"v_sub_f32 {x}, {k}, {x}",
+                (f"v_max_f32 {dm}, abs({x}), abs({x})" if (first and j == 0) else f"v_max_f32 {dm}, abs({x}), {dm}"),
+            ]
+        ops.append(f"v_lshl_add_u32 {tt}, {tt}, 9, {v('LUTC')}")
+        if not nolut:                                # lab ablation: without the LUT reads (VAL keeps its last value)
+            ops.append(("ds", f"ds_read_b32 {v('VAL', val0 + j)}, {tt}", f"val{val0 + j}"))
     return ops
 
 
@@ -403,6 +411,8 @@ def abuf(h, rb):
 
 
 def a_read(A, h, rb):
+    if os.environ.get("FUSED_NOAREAD"):              # lab ablation: the MFMAs run on whatever the A buffers hold (no LDS fragment reads)
+        return
     A.ds(f"ds_read_b128 {abuf(h, rb)}, {v('AS0' if h == 0 else 'AS1')} offset:{rb * 2048}", f"a{h}_{rb}")
 
 
@@ -425,7 +435,7 @@ def unit(A, h, bc, bn, xs_vgpr, eo, cold_blocks, first_fill_rb):
         if pi >= 2:
             # pair pi - 2 is packed right before this pair's LUT reads reuse its VAL registers: a full pair (and the MFMAs
             # in between) after its own reads were issued
-            ops.insert(7, pack_op(bn, pi - 2, 2 * (pi & 1)))
+            ops.insert(min(7, len(ops)), pack_op(bn, pi - 2, 2 * (pi & 1)))
         if pi == 0:
             ops.insert(0, ("waitfor", f"l{h}_0"))
         if pi == 2:
