@@ -630,6 +630,48 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                            sOc, sOg, order, reduce_cols, stream, nullptr);
 }
 
+// quant_forward of a uniformly quantised Linear layer / q.k^T product (reference quant_layers/linear.py:46-51, matmul.py:43-45) with
+// the A-side fake quantisation INSIDE the GEMM's loader (k_gemm_cand<.., GENA>):
+//   out[g][m][n] = sa[gh * sa_g] * sa_mul * sb[gh * sb_g + n * sb_n] * sum_k (q_a(x[g][m][k]) - z_a) * B[g][n][k] + bias[gh * bi_g + n * bi_n]
+// x fp32 [G][M][ldx] (groups sxg apart, K valid, K % 16 == 0), (a_scale, a_zp)[gh * a_pg] its per-tensor (a_pg = 0) / per-head
+// quantiser (gh = g % gmod), B the packed int8 operand [G][N][Kp] (adalog_pack_uniform).  Same result, bit for bit, as
+// adalog_pack_uniform(x) + adalog_gemm_score(out): the activation is read once as fp32 instead of written and re-read as int8, and
+// one launch per layer disappears.
+extern "C" int adalog_gemm_out_gen(const float* x, int64_t ldx, int64_t sxg, int K, const float* a_scale, const float* a_zp, int64_t a_pg,
+                                   int n_bits, const void* B, int64_t sBg, int M, int N, int64_t Kp, int G, int gmod, const float* sa,
+                                   int64_t sa_g, float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias,
+                                   int64_t bi_g, int64_t bi_n, float* out, int64_t ldo, int64_t sOg, void* stream) {
+    ADALOG_ARG_CHECK(x && a_scale && a_zp && B && sa && sb && out, "gemm_out_gen: null pointer");
+    ADALOG_ARG_CHECK(M >= 1 && N >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && K >= 16 && K % 16 == 0 && Kp >= K && Kp % BK2 == 0,
+                     "gemm_out_gen: K must be a multiple of 16, Kp a multiple of 128 covering it");
+    ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7 && ldx >= K && ldx % 4 == 0 && sxg % 4 == 0 && (((uintptr_t)x) & 15) == 0 &&
+                     (((uintptr_t)B) & 15) == 0, "gemm_out_gen: <= 7-bit quantiser, 16-byte aligned fp32 rows");
+    ADALOG_ARG_CHECK((int64_t)M * ldx < ((int64_t)1 << 31) && (int64_t)N * Kp < ((int64_t)1 << 31), "gemm_out_gen: operand exceeds 32-bit addressing");
+    GemmArgs p{};
+    p.A = nullptr; p.B = (const uint8_t*)B; p.sAc = 0; p.sAg = 0; p.sBc = 0; p.sBg = sBg;
+    p.M = M; p.N = N; p.Kb = Kp; p.KbA = Kp; p.Kvb = K; p.C = 1; p.G = G; p.gmod = gmod;
+    p.ref = nullptr; p.ldr = 0; p.sRg = 0; p.ref_cs = 1; p.ref_div = 1;
+    p.sa = sa; p.sa_c = 0; p.sa_g = sa_g; p.sa_mul = sa_mul;
+    p.sb = sb; p.sb_c = 0; p.sb_g = sb_g; p.sb_n = sb_n;
+    p.bias = bias; p.bi_c = 0; p.bi_g = bi_g; p.bi_n = bi_n;
+    p.out = out; p.ldo = ldo; p.sOc = 0; p.sOg = sOg;
+    p.order = 0; p.reduce_cols = 0;
+    p.gen_x = x; p.gen_ldx = ldx; p.gen_sg = sxg; p.gen_K = K; p.gen_scale = a_scale; p.gen_zp = a_zp; p.gen_sn = a_pg;
+    p.gen_qmax = (float)((1 << n_bits) - 1);
+    constexpr int TMV = 2;
+    p.MT = cdiv(M, 64 * TMV); p.NT = cdiv(N, BN2); p.Npad = p.NT * BN2;
+    const int64_t tiles = (int64_t)p.MT * p.NT * G;
+    ADALOG_ARG_CHECK(tiles < ((int64_t)1 << 31), "gemm_out_gen: grid too large");
+    const size_t shm = (size_t)(64 * TMV + BN2) * BK2 + (512 + 256) * sizeof(float);
+    static unsigned long long attr_dev = 0;
+    { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_cand<0, TMV, true, true>), (int)(72 * 1024), &attr_dev);
+      if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } }
+    adalog_note_kernel("k_gemm_cand_gen");
+    hipLaunchKernelGGL((k_gemm_cand<0, TMV, true, true>), dim3((unsigned)tiles), dim3(512), shm, (hipStream_t)stream, p);
+    ADALOG_LAUNCH_CHECK("adalog_gemm_out_gen");
+    return 0;
+}
+
 // Attention searches with uniform candidates (reference quant_layers/matmul.py:135-163 / 173-201), GEN form: scores of the
 // ref_div candidates (sb, zp)[c * sb_c + head * sb_g] of the operand x [G][N / ref_div][K = k_valid] (fp32, rows ldx apart, groups
 // sg apart) against the packed fixed operand A [G][M][Kp] -- what adalog_gemm_score computes from the packed candidate operand

@@ -501,6 +501,38 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
     return out
 
 
+def gemm_out_gen_ok(x3, Kp: int, n_bits: int) -> bool:
+    """gemm_out_gen takes this activation: fp32 [G, M, K], unit stride along K, rows and groups 16-byte aligned (a strided view such
+    as the class token x[:, 0] qualifies), K a multiple of 16 covered by the packed operand's Kp"""
+    return (x3.dim() == 3 and x3.dtype == torch.float32 and x3.is_cuda and x3.stride(2) == 1 and x3.stride(1) % 4 == 0
+            and x3.stride(0) % 4 == 0 and x3.stride(1) >= x3.shape[2] and x3.shape[-1] % 16 == 0 and x3.shape[-1] <= Kp
+            and 2 <= n_bits <= 7 and x3.data_ptr() % 16 == 0 and os.environ.get("ADALOG_QF_GEN", "1") != "0")
+
+
+def gemm_out_gen(x3, a_scale, a_zp, n_bits: int, B, N: int, gmod: int, sa: Strided, sb: Strided, bias: Optional[Strided],
+                 sa_mul: float = 1.0):
+    """Quantised forward with the A-side fake quantisation inside the GEMM's loader (adalog_gemm_out_gen, k_gemm_cand<GENA>):
+    out[g] = (q_a(x3[g]) . B[g]^T) * sa * sb[n] + bias[n] -> fp32 [G, M, N], q_a the per-tensor (one (scale, zp)) or per-head
+    ((scale, zp)[g % gmod]) uniform quantiser -- gemm_out(I8, pack_uniform(x3, ...), B, ...) without the pack launch and the int8
+    image of the activation (reference linear.py:46-51, matmul.py:43-45)."""
+    lib = _lib.load()
+    sa, sb = sa.checked(), sb.checked()
+    bias = None if bias is None else bias.checked()
+    G, M, K = x3.shape
+    Kp = B.shape[-1]
+    a_scale, a_zp = _f32c(a_scale, "a_scale").reshape(-1), _f32c(a_zp, "a_zp").reshape(-1)
+    assert a_scale.numel() == a_zp.numel() and a_scale.numel() in (1, gmod)
+    assert B.dtype == torch.int8 and B.is_contiguous() and B.shape[-2] == N
+    sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
+    out = torch.empty((G, M, N), dtype=torch.float32, device=x3.device)
+    rc = lib.adalog_gemm_out_gen(x3.data_ptr(), x3.stride(1), x3.stride(0), K, a_scale.data_ptr(), a_zp.data_ptr(), 0 if a_scale.numel() == 1 else 1,
+                                 int(n_bits), B.data_ptr(), sBg, M, N, Kp, G, gmod, sa.t.data_ptr(), sa.g, float(sa_mul),
+                                 sb.t.data_ptr(), sb.g, sb.n, None if bias is None else bias.t.data_ptr(),
+                                 0 if bias is None else bias.g, 0 if bias is None else bias.n, out.data_ptr(), N, M * N, _stream())
+    _lib.check(rc, "adalog_gemm_out_gen")
+    return out
+
+
 def log2_shift(x, shift: float):
     """log2(x + shift), correctly rounded, -inf where x + shift <= 0 (input of score_act_fused; once per layer)."""
     x = _f32c(x, "x")

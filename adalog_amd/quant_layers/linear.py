@@ -504,11 +504,15 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
             return super().quant_forward(x)
         lead = x.shape[:-1]
         x3 = x.reshape(1, -1, self.in_features)
-        xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
         wp = self._pack_w_cached()
-        out = be.gemm_out(I8, xp, wp, x3.shape[1], self.out_features, 1, 1, Strided(aq.scale.data.view(-1)),
-                          Strided(self.w_quantizer.scale.data.view(-1), n=1),
-                          None if self.bias is None else Strided(self.bias.data, n=1))
+        sa_, sb_ = Strided(aq.scale.data.view(-1)), Strided(self.w_quantizer.scale.data.view(-1), n=1)
+        bias_ = None if self.bias is None else Strided(self.bias.data, n=1)
+        if aq.scale.numel() == 1 and hasattr(be, "gemm_out_gen") and be.gemm_out_gen_ok(x3, wp.shape[-1], aq.n_bits):
+            # ONE launch for the layer: the activation is quantised in the GEMM's loader (k_gemm_cand<GENA>), the weight image is cached
+            out = be.gemm_out_gen(x3, aq.scale.data, aq.zero_point.data, aq.n_bits, wp, self.out_features, 1, sa_, sb_, bias_)
+            return out.view(*lead, self.out_features)
+        xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
+        out = be.gemm_out(I8, xp, wp, x3.shape[1], self.out_features, 1, 1, sa_, sb_, bias_)
         return out.view(*lead, self.out_features)
 
 

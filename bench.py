@@ -346,8 +346,9 @@ def quant_forward_rate(calibrated, images, dev, reps=5):
             "raw_ms_per_forward": round(ms_r, 3), "raw_images_per_s": round(n / ms_r * 1e3, 1),
             "kernels_by_layer_class": {k: sorted(v) for k, v in labels.items()},
             "output_rel_diff_vs_fp": round(rel, 4),
-            "note": "per layer: operand pack(s) + integer / bf16 MFMA product with the dequantising epilogue (packed weights cached across "
-                    "calls); raw = the FP32 model (rocBLAS)"}
+            "note": "uniformly quantised Linear layers (qkv / proj / fc1 / head): ONE launch, the activation quantised in the GEMM's loader "
+                    "(k_gemm_cand_gen, round 6); fc2 and the attention products: operand pack(s) + integer / bf16 MFMA product with the "
+                    "dequantising epilogue; packed weights cached across calls; raw = the FP32 model (rocBLAS)"}
 
 
 def _cpu_sample(threads, n_cand, min_seconds=0.0):

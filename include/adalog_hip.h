@@ -377,6 +377,17 @@ int adalog_score_self_sorted_tail(const float* sorted, const double* prefix, int
                                   const float* zp, int P, int n_bits, double norm, float* scores, const adalog_fpcs_tail* tail,
                                   void* stream);
 
+/* ---- K15 with the A-side fake quantisation in the GEMM's loader (round 6)      reference linear.py:46-51, matmul.py:43-45
+ *   out[g][m][n] = sa[gh * sa_g] * sa_mul * sb[gh * sb_g + n * sb_n] * sum_k (q_a(x[g][m][k]) - z_a) * B[g][n][k] + bias[gh * bi_g + n * bi_n]
+ * x: fp32 [G][M][ldx] (groups sxg elements apart; K valid, K % 16 == 0); (a_scale, a_zp)[gh * a_pg]: its uniform quantiser, per tensor
+ * (a_pg = 0) or per head (gh = g % gmod); B: packed int8 [G][N][Kp] (adalog_pack_uniform; sBg bytes between groups, 0 = shared);
+ * out fp32 [G][M][ldo] (groups sOg apart).  Bit for bit adalog_pack_uniform(x) + adalog_gemm_score(out = ...), in one launch and
+ * without the int8 image of the activation. */
+int adalog_gemm_out_gen(const float* x, int64_t ldx, int64_t sxg, int K, const float* a_scale, const float* a_zp, int64_t a_pg, int n_bits,
+                        const void* B, int64_t sBg, int M, int N, int64_t Kp, int G, int gmod, const float* sa, int64_t sa_g,
+                        float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_g, int64_t bi_n,
+                        float* out, int64_t ldo, int64_t sOg, void* stream);
+
 /* ---- stable LSD radix sort of fp32 keys, per segment (csrc/radix_sort.hip; hipCUB until round 5): what the sorted forms above and
  * adalog_gram_act_prepare sort with.  x [S][n] contiguous -> sorted [S][n] (ascending per segment; -0 before +0), perm (may be null)
  * [S][n]: perm[s][i] = index within segment s of its i-th smallest value, equal values in input order.  n <= 8192: one launch (a

@@ -1825,3 +1825,41 @@ def test_gram_act_score_matches_fp64_and_token_form(ops, bits, T, O, K, tok):
         want = ops.score_act_gen(dt, wp, d(x), d(sc).view(P, 1), d(zp).view(P, 1), bits, d(ref), d(sw), None if b is None else d(b), norm)
         assert rel_err(got.cpu(), want.cpu()) <= 3e-6
     assert torch.equal(got, st.score(d(sc).view(P, 1), d(zp).view(P, 1), norm))     # bit-reproducible
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+@pytest.mark.parametrize("M,N,K", [(6304, 1152, 384), (197, 96, 48), (32, 1000, 384), (1000, 1536, 1536), (130, 64, 16)])
+def test_gemm_out_gen_equals_pack_then_gemm(ops, bits, M, N, K):
+    """quant_forward of a uniformly quantised Linear in ONE launch (adalog_gemm_out_gen: the activation is quantised in the GEMM's
+    loader) against the two-launch route it replaces (pack_uniform + gemm_out): the same int8 codes reach the same int32 dot products
+    and the same epilogue, so the fp32 outputs are equal BIT FOR BIT -- including elements that sit exactly on a rounding tie
+    (x / scale + zp = n + 0.5 by construction) and values far outside the clamp range; and the codes equal the oracle's."""
+    gen = g(7000 + bits * 13 + M)
+    scale = torch.tensor([0.0371]); zp = torch.tensor([float(2 ** (bits - 1) - 1)])
+    x = torch.randn(1, M, K, generator=gen) * 0.3
+    ties = torch.randint(0, 2 ** bits, (M, K), generator=gen).float()
+    tie_mask = torch.rand(M, K, generator=gen) < 0.05
+    x[0][tie_mask] = ((ties + 0.5 - zp) * scale)[tie_mask]
+    x[0][torch.rand(M, K, generator=gen) < 0.01] = 1e6
+    x[0][torch.rand(M, K, generator=gen) < 0.01] = -1e6
+    w = torch.randint(-(2 ** (bits - 1)), 2 ** (bits - 1), (1, 1, N, K), generator=gen).to(torch.int8)
+    Kp = CB.pad_k(K, CB.I8)
+    wp = torch.zeros(1, 1, N, Kp, dtype=torch.int8); wp[..., :K] = w
+    sb = torch.rand(N, generator=gen) * 0.01 + 0.001
+    bias = torch.randn(N, generator=gen)
+    xd, wd = x.to(DEV), wp.to(DEV)
+    sa_, sb_, bi_ = ops.Strided(scale.to(DEV)), ops.Strided(sb.to(DEV), n=1), ops.Strided(bias.to(DEV), n=1)
+    assert ops.gemm_out_gen_ok(xd, Kp, bits)
+    got = ops.gemm_out_gen(xd, scale.to(DEV), zp.to(DEV), bits, wd, N, 1, sa_, sb_, bi_)
+    xp = ops.pack_uniform(xd, scale.to(DEV), zp.to(DEV), 1, 0, 1, 0, 0, bits, ops.I8)
+    want = ops.gemm_out(ops.I8, xp, wd, M, N, 1, 1, sa_, sb_, bi_)
+    assert got.shape == want.shape == (1, M, N)
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    # a row-strided view (the class token x[:, 0] in front of the head) is read in place
+    wide = torch.zeros(M, 3, K, device=DEV); wide[:, 0] = xd[0]
+    view = wide[:, 0].unsqueeze(0)
+    assert not view.is_contiguous() and ops.gemm_out_gen_ok(view, Kp, bits)
+    assert torch.equal(ops.gemm_out_gen(view, scale.to(DEV), zp.to(DEV), bits, wd, N, 1, sa_, sb_, bi_), want)
+    # the packed codes are the oracle's: round-half-even of x / scale + zp, clamped, minus the zero point
+    _, q = O.uniform_fake_quant(x[0], scale, zp, bits)
+    assert torch.equal(xp[0, 0, :, :K].cpu().float(), q - zp)
