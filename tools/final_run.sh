@@ -2,7 +2,7 @@
 # End-of-round validation on the GPU box (run from the repo root, e.g. gpurun -- 'bash tools/final_run.sh'):
 # the -m gpu test suite, the default bench line, a rocprofv3 kernel-stats pass, the PMC traffic passes, the 2-rank gloo
 # launch path, and one calibration each of the other model families / bit widths.  Everything lands under
-# gpurun_out/final/; the summaries that are kept go to profiles/r05_* (tools/collect_profiles.sh r05).
+# gpurun_out/final/; the summaries that are kept go to profiles/r06_* (tools/collect_profiles.sh r06).
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
 mkdir -p gpurun_out/final
 rm -f gpurun_out/trace_parity.jsonl gpurun_out/fullshape_parity.jsonl gpurun_out/golden_forward_parity.jsonl gpurun_out/wrapper_flow_parity.jsonl gpurun_out/brecq_traj_parity.jsonl
@@ -26,8 +26,9 @@ for m in vit_base swin_base; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_$m -o p -- python3 bench.py --model $m --steps 1 --warmup 1 --no-cpu-baseline --schedule product --no-rerun-all > gpurun_out/final/prof_$m.log 2>&1
   rm -f gpurun_out/final/prof_$m/p_kernel_trace.csv gpurun_out/final/prof_$m/*/p_kernel_trace.csv
 done
-# BRECQ: kernel statistics of 300 iterations on a deit_small block (graph replay) and the products of an iteration one by one
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_brecq -o p -- python3 tools/bench_brecq.py --iters 300 > gpurun_out/final/prof_brecq.log 2>&1
-rm -f gpurun_out/final/prof_brecq/p_kernel_trace.csv gpurun_out/final/prof_brecq/*/p_kernel_trace.csv
-timeout 300 python tools/lab/bq_gemm_bench.py --out gpurun_out/final/bq_gemm_bench.json > gpurun_out/final/bq_gemm_bench.log 2>&1; tail -2 gpurun_out/final/bq_gemm_bench.log
-timeout 300 python tools/lab/bq_gemm_bench.py --model vit_base --out gpurun_out/final/bq_gemm_bench_vit_base.json > gpurun_out/final/bq_gemm_bench_vit_base.log 2>&1; tail -1 gpurun_out/final/bq_gemm_bench_vit_base.log
+# BRECQ: kernel statistics of the reconstruct_single_block call alone (300 iterations, graph replay; torch.profiler around the call:
+# rocprofv3 around the whole script would mix in the FP model's forward and the block's calibration), then the products one by one
+timeout 400 python tools/bench_brecq.py --iters 300 --kernel-stats gpurun_out/final/kernel_stats_brecq_deit_small_block.csv > gpurun_out/final/prof_brecq.log 2>&1; tail -2 gpurun_out/final/prof_brecq.log
+timeout 400 python tools/bench_brecq.py --model vit_base --iters 300 --kernel-stats gpurun_out/final/kernel_stats_brecq_vit_base_block.csv > gpurun_out/final/prof_brecq_vit_base.log 2>&1; tail -2 gpurun_out/final/prof_brecq_vit_base.log
+timeout 300 python tools/lab/bq_gemm_bench.py --terms 2 --int-act --out gpurun_out/final/bq_gemm_bench.json > gpurun_out/final/bq_gemm_bench.log 2>&1; tail -2 gpurun_out/final/bq_gemm_bench.log
+timeout 300 python tools/lab/bq_gemm_bench.py --model vit_base --terms 2 --int-act --out gpurun_out/final/bq_gemm_bench_vit_base.json > gpurun_out/final/bq_gemm_bench_vit_base.log 2>&1; tail -1 gpurun_out/final/bq_gemm_bench_vit_base.log

@@ -4,7 +4,7 @@
 import csv
 import sys
 
-r = sys.argv[1] if len(sys.argv) > 1 else "r05"
+r = sys.argv[1] if len(sys.argv) > 1 else "r06"
 GROUPS = [
     ("`k_act_fused_asm` (fc2 activation search)", ["k_act_fused_asm"]),
     ("`k_ga_quad` + build + finish (Gram form: qkv / proj / fc1 activation searches)", ["k_ga_"]),
@@ -16,7 +16,7 @@ GROUPS = [
     ("`k_gemm_grpw<GEN>` / `k_gemm_grpk8` / `k_gemm_avq` (attention)", ["k_gemm_grp", "k_gemm_avq", "k_gemm_win"]),
     ("operand packs", ["k_pack"]),
     ("finish + top-k", ["k_finish", "k_topk", "k_fused_finish"]),
-    ("`k_score_sorted` + sort + prefix", ["k_score_sorted", "k_sp_", "rocprim", "k_seg_offsets"]),
+    ("`k_score_sorted` + sort + prefix", ["k_score_sorted", "k_sp_", "rocprim", "k_seg_offsets", "k_rs_"]),
     ("radix select + candidate grids", ["k_sel_", "k_candidate_grid"]),
 ]
 
@@ -42,3 +42,8 @@ for name, keys in GROUPS:
     print(f"| {name} | {cp:.0f} / {cr:.0f} | {mp:.0f} / {mr:.0f} |")
 print(f"| everything else (FP forward passes, copies, fills, small kernels) | | {tp / 3e6 - seen_p:.0f} / {tr / 3e6 - seen_r:.0f} |")
 print(f"| **GPU time per calibration** | | **{tp / 3e6:.0f} / {tr / 3e6:.0f}** |")
+SCORING = ["k_act_fused_asm", "k_ga_quad", "k_ga_rect", "k_gram_score", "k_gemm_"]
+for label, rows in (("default", prod), ("reference", ref)):
+    rest = [x for x in rows if not any(k in x["Name"] for k in SCORING)]
+    print(f"{label} schedule: {sum(int(x['Calls']) for x in rows) / 3:.0f} launches per calibration; outside the scoring kernels "
+          f"{sum(int(x['Calls']) for x in rest) / 3:.0f} launches, {sum(float(x['TotalDurationNs']) for x in rest) / 3e6:.0f} ms")
