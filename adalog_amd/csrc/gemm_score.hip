@@ -57,6 +57,19 @@ static int device_cus() {
 }
 
 // ---- tile selection shared by launch, layout query and finish
+// quant_forward (store form): the products of a forward pass are small -- fc2 of deit_small is 25 x 2 tiles of 256 x 256 on 256 CUs.
+// Largest row tile that still gives every CU its two workgroups; 64-row tiles otherwise.  Measured per product of a deit_small
+// forward (32 images, us per launch at 256- / 128- / 64-row tiles): fc2 66 / 39 / 26, softmax.v 29 / 28 / 16, proj - / 22 / 13,
+// fc1 - / 31 / 21, qkv - / 20 / 17, q.k^T 13 / 15 / 12 (profiles/r06_notes.md).
+static int pick_tm_out(int M, int64_t col_tiles_x_groups) {
+    if (const char* e = getenv("ADALOG_GEMM_TM")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) return v; }
+    const int64_t want = 2 * (int64_t)device_cus();
+    const int tms[3] = {4, 2, 1};
+    for (int i = 0; i < 3; ++i)
+        if ((int64_t)cdiv(M, 64 * tms[i]) * col_tiles_x_groups >= want) return tms[i];
+    return 1;
+}
+
 static int pick_tm(int M, bool scoring) {
     // largest row tile whose padding waste stays within 10 % of the best achievable.  The scoring epilogue keeps more
     // state than the store epilogue: with TM = 4 (128 accumulator VGPRs) it spills, so scoring launches use TM <= 2.
@@ -100,7 +113,7 @@ static Layout layout_of(int M, int N, int C, int G, int gmod, int ref_div, int r
     static const int use_wgacc = getenv("ADALOG_GEMM_WGACC") ? atoi(getenv("ADALOG_GEMM_WGACC")) : 1;
     Layout L{};
     L.big = (C == 1);
-    L.tm = L.big ? pick_tm(M, scoring) : 2;
+    L.tm = L.big ? (scoring ? pick_tm(M, scoring) : pick_tm_out(M, (int64_t)cdiv(N, 256) * G)) : 2;
     const bool cand_cols = L.big && scoring && ref_transposed && (ref_div == 64 || ref_div == 128 || ref_div == 256);
     if (cand_cols && use_stream) {
         L.wide = pick_wide(M, kvalid_bytes);
@@ -256,6 +269,8 @@ extern "C" int adalog_gemm_mixed_ok(int M, int N, int G, int gmod, int ref_div, 
 // GEN form of the attention searches (adalog_gemm_score_gen): the candidate operand B is not read but generated in the kernel
 // from the fp32 tensor x [G][N / ref_div][K] with the candidates' (sb, zp) pairs
 struct MmGen { const float* x; int64_t ldx, sg; const float* zp; int n_bits; };
+// extras of the STORE epilogue (GemmArgs: addend, out_gi, sOo)
+struct MmOutEx { const float* addend; int out_gi; int64_t sOo; };
 
 static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc, int64_t sAg, int64_t sBc,
                            int64_t sBg, int M, int N, int64_t Kp, int64_t k_valid, int C, int G, int gmod, const float* ref,
@@ -263,8 +278,11 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
                            int64_t sa_g, float sa_mul, const float* sb, int64_t sb_c, int64_t sb_g, int64_t sb_n,
                            const float* bias, int64_t bi_c, int64_t bi_g, int64_t bi_n, const float* row_scale,
                            const float* row_bias, float* partial, int64_t partial_elems, float* out, int64_t ldo,
-                           int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream, const MmGen* gen) {
+                           int64_t sOc, int64_t sOg, int order, int reduce_cols, void* stream, const MmGen* gen,
+                           const MmOutEx* ox = nullptr) {
     ADALOG_ARG_CHECK(A && (B || gen) && sa && sb, "gemm_score: null operand/scale pointer");
+    ADALOG_ARG_CHECK(!ox || (out && C == 1 && !row_scale && (ox->out_gi == 0 || (ox->out_gi > 0 && G % ox->out_gi == 0))),
+                     "gemm_out_ex: the epilogue extras need out, C == 1 and an inner group count that divides G");
     ADALOG_ARG_CHECK(!gen || ((dtype == 0 || dtype == 3) && gen->x && gen->zp && k_valid > 0 && k_valid % 16 == 0 && k_valid <= 64 &&
                               gen->ldx % 4 == 0 && gen->sg % 4 == 0 && (((uintptr_t)gen->x) & 15) == 0),
                      "gemm_score_gen: int8 / fp8 candidates of K = 16, 32, 48 or 64 from a 16-byte aligned fp32 tensor");
@@ -396,6 +414,7 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
     p.MT = L.MT; p.NT = L.NT; p.Npad = L.Npad;
     p.order = order; p.reduce_cols = reduce_cols && ref_div == 1; p.timeline = g_timeline;
     p.partial = partial; p.out = out; p.ldo = ldo; p.sOc = sOc; p.sOg = sOg;
+    if (ox) { p.addend = ox->addend; p.out_gi = ox->out_gi; p.sOo = ox->sOo; }
     if (partial) ADALOG_ARG_CHECK(partial_elems >= L.elems, "gemm_score: partial buffer too small");
     if (L.acc) { ADALOG_ARG_CHECK(((uintptr_t)partial & 7) == 0, "gemm_score: accumulator buffer must be 8-byte aligned"); p.wg_acc = (double*)partial; }
     if (gen) {
@@ -598,7 +617,21 @@ static int gemm_score_impl(int dtype, const void* A, const void* B, int64_t sAc,
         do {                                                                                                      \
             if (dtype == 0) LAUNCH_BIG_TM(0, ST); else if (dtype == 1) LAUNCH_BIG_TM(1, ST); else LAUNCH_BIG_TM(2, ST); \
         } while (0)
-        if (out) LAUNCH_BIG_DT(true); else LAUNCH_BIG_DT(false);
+        if (out && ox) {
+            // the STORE form with the epilogue extras (int8 / bf16 operands)
+#define LAUNCH_ADD(DT, TMV)                                                                                       \
+        do {                                                                                                      \
+            static unsigned long long attr_dev = 0;                                                               \
+            { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_cand<DT, TMV, true, false, true>), (int)(72 * 1024), &attr_dev); \
+              if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } }     \
+            adalog_note_kernel("k_gemm_cand_ex");                                                                 \
+            hipLaunchKernelGGL((k_gemm_cand<DT, TMV, true, false, true>), grid, dim3(512), shm, st, p);           \
+        } while (0)
+            ADALOG_ARG_CHECK(dtype == 0 || dtype == 1, "gemm_out_ex: int8 or bf16 operands");
+            if (dtype == 0) { if (L.tm == 4) LAUNCH_ADD(0, 4); else if (L.tm == 2) LAUNCH_ADD(0, 2); else LAUNCH_ADD(0, 1); }
+            else { if (L.tm == 4) LAUNCH_ADD(1, 4); else if (L.tm == 2) LAUNCH_ADD(1, 2); else LAUNCH_ADD(1, 1); }
+#undef LAUNCH_ADD
+        } else if (out) LAUNCH_BIG_DT(true); else LAUNCH_BIG_DT(false);
 #undef LAUNCH_BIG_DT
 #undef LAUNCH_BIG_TM
 #undef LAUNCH_BIG
@@ -630,6 +663,23 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
                            sOc, sOg, order, reduce_cols, stream, nullptr);
 }
 
+// quant_forward product from packed operands with the epilogue extras (reference quant_layers/linear.py:46-51, matmul.py:43-45,
+// utils/wrap_net.py:30-31):  out[g][m][n] = sa[gh * sa_g] * sa_mul * sb[gh * sb_g + n * sb_n] * (A[g] . B[g]^T)[m][n]
+//                                            + bias[gh * bi_g + n * bi_n] + addend[g][m][n]
+// A [G][M][Kp], B [G][N][Kp] packed int8 (dtype 0) / bf16 (1) operands (group strides in elements; 0 = shared), gh = g % gmod.
+// addend (may be null): the residual stream, indexed like out.  out_gi > 0: two-level output groups -- group g is written at
+// (g % out_gi) * sOg + (g / out_gi) * sOo, e.g. softmax . v with out_gi = H, sOg = D, sOo = N * H * D, ldo = H * D writes
+// [B][N][H][D] storage, so that the transpose(1, 2).reshape(B, N, C) in front of the projection layer is a view.
+extern "C" int adalog_gemm_out_ex(int dtype, const void* A, const void* B, int64_t sAg, int64_t sBg, int M, int N, int64_t Kp, int G,
+                                  int gmod, const float* sa, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n,
+                                  const float* bias, int64_t bi_g, int64_t bi_n, const float* addend, float* out, int64_t ldo,
+                                  int64_t sOg, int out_gi, int64_t sOo, void* stream) {
+    ADALOG_ARG_CHECK(out && (dtype == 0 || dtype == 1), "gemm_out_ex: int8 or bf16 operands, out required");
+    const MmOutEx ox{addend, out_gi, sOo};
+    return gemm_score_impl(dtype, A, B, 0, sAg, 0, sBg, M, N, Kp, 0, 1, G, gmod, nullptr, 0, 0, 1, 1, sa, 0, sa_g, sa_mul, sb, 0, sb_g, sb_n,
+                           bias, 0, bi_g, bi_n, nullptr, nullptr, nullptr, 0, out, ldo, 0, sOg, 0, 0, stream, nullptr, &ox);
+}
+
 // quant_forward of a uniformly quantised Linear layer / q.k^T product (reference quant_layers/linear.py:46-51, matmul.py:43-45) with
 // the A-side fake quantisation INSIDE the GEMM's loader (k_gemm_cand<.., GENA>):
 //   out[g][m][n] = sa[gh * sa_g] * sa_mul * sb[gh * sb_g + n * sb_n] * sum_k (q_a(x[g][m][k]) - z_a) * B[g][n][k] + bias[gh * bi_g + n * bi_n]
@@ -637,10 +687,22 @@ extern "C" int adalog_gemm_score(int dtype, const void* A, const void* B, int64_
 // quantiser (gh = g % gmod), B the packed int8 operand [G][N][Kp] (adalog_pack_uniform).  Same result, bit for bit, as
 // adalog_pack_uniform(x) + adalog_gemm_score(out): the activation is read once as fp32 instead of written and re-read as int8, and
 // one launch per layer disappears.
+extern "C" int adalog_gemm_out_gen_ex(const float* x, int64_t ldx, int64_t sxg, int K, const float* a_scale, const float* a_zp, int64_t a_pg,
+                                      int n_bits, const void* B, int64_t sBg, int M, int N, int64_t Kp, int G, int gmod, const float* sa,
+                                      int64_t sa_g, float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias,
+                                      int64_t bi_g, int64_t bi_n, const float* addend, float* out, int64_t ldo, int64_t sOg, void* stream);
 extern "C" int adalog_gemm_out_gen(const float* x, int64_t ldx, int64_t sxg, int K, const float* a_scale, const float* a_zp, int64_t a_pg,
                                    int n_bits, const void* B, int64_t sBg, int M, int N, int64_t Kp, int G, int gmod, const float* sa,
                                    int64_t sa_g, float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias,
                                    int64_t bi_g, int64_t bi_n, float* out, int64_t ldo, int64_t sOg, void* stream) {
+    return adalog_gemm_out_gen_ex(x, ldx, sxg, K, a_scale, a_zp, a_pg, n_bits, B, sBg, M, N, Kp, G, gmod, sa, sa_g, sa_mul, sb, sb_g, sb_n,
+                                  bias, bi_g, bi_n, nullptr, out, ldo, sOg, stream);
+}
+// ... + addend[g][m][n] (same strides as out): the residual stream added in the epilogue (x + proj(...) of a transformer block)
+extern "C" int adalog_gemm_out_gen_ex(const float* x, int64_t ldx, int64_t sxg, int K, const float* a_scale, const float* a_zp, int64_t a_pg,
+                                      int n_bits, const void* B, int64_t sBg, int M, int N, int64_t Kp, int G, int gmod, const float* sa,
+                                      int64_t sa_g, float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias,
+                                      int64_t bi_g, int64_t bi_n, const float* addend, float* out, int64_t ldo, int64_t sOg, void* stream) {
     ADALOG_ARG_CHECK(x && a_scale && a_zp && B && sa && sb && out, "gemm_out_gen: null pointer");
     ADALOG_ARG_CHECK(M >= 1 && N >= 1 && G >= 1 && gmod >= 1 && G % gmod == 0 && K >= 16 && K % 16 == 0 && Kp >= K && Kp % BK2 == 0,
                      "gemm_out_gen: K must be a multiple of 16, Kp a multiple of 128 covering it");
@@ -654,20 +716,28 @@ extern "C" int adalog_gemm_out_gen(const float* x, int64_t ldx, int64_t sxg, int
     p.sa = sa; p.sa_c = 0; p.sa_g = sa_g; p.sa_mul = sa_mul;
     p.sb = sb; p.sb_c = 0; p.sb_g = sb_g; p.sb_n = sb_n;
     p.bias = bias; p.bi_c = 0; p.bi_g = bi_g; p.bi_n = bi_n;
-    p.out = out; p.ldo = ldo; p.sOc = 0; p.sOg = sOg;
+    p.out = out; p.ldo = ldo; p.sOc = 0; p.sOg = sOg; p.addend = addend;
     p.order = 0; p.reduce_cols = 0;
     p.gen_x = x; p.gen_ldx = ldx; p.gen_sg = sxg; p.gen_K = K; p.gen_scale = a_scale; p.gen_zp = a_zp; p.gen_sn = a_pg;
     p.gen_qmax = (float)((1 << n_bits) - 1);
-    constexpr int TMV = 2;
-    p.MT = cdiv(M, 64 * TMV); p.NT = cdiv(N, BN2); p.Npad = p.NT * BN2;
+    // 128-row tiles while they give every CU one, else 64-row tiles (attn.proj of deit_small: 50 x 2 -> 99 x 2 tiles)
+    int tmv = pick_tm_out(M, (int64_t)cdiv(N, BN2) * G);
+    if (tmv > 2) tmv = 2;
+    p.MT = cdiv(M, 64 * tmv); p.NT = cdiv(N, BN2); p.Npad = p.NT * BN2;
     const int64_t tiles = (int64_t)p.MT * p.NT * G;
     ADALOG_ARG_CHECK(tiles < ((int64_t)1 << 31), "gemm_out_gen: grid too large");
-    const size_t shm = (size_t)(64 * TMV + BN2) * BK2 + (512 + 256) * sizeof(float);
-    static unsigned long long attr_dev = 0;
-    { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_cand<0, TMV, true, true>), (int)(72 * 1024), &attr_dev);
-      if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } }
-    adalog_note_kernel("k_gemm_cand_gen");
-    hipLaunchKernelGGL((k_gemm_cand<0, TMV, true, true>), dim3((unsigned)tiles), dim3(512), shm, (hipStream_t)stream, p);
+    const size_t shm = (size_t)(64 * tmv + BN2) * BK2 + (512 + 256) * sizeof(float);
+#define LAUNCH_GENA(TMV, ADDV, LABEL)                                                                             \
+    do {                                                                                                          \
+        static unsigned long long attr_dev = 0;                                                                   \
+        { hipError_t ea__ = adalog_max_lds(reinterpret_cast<const void*>(&k_gemm_cand<0, TMV, true, true, ADDV>), (int)(72 * 1024), &attr_dev); \
+          if (ea__ != hipSuccess) { adalog_set_error("hipFuncSetAttribute", ea__); return (int)ea__; } }         \
+        adalog_note_kernel(LABEL);                                                                                \
+        hipLaunchKernelGGL((k_gemm_cand<0, TMV, true, true, ADDV>), dim3((unsigned)tiles), dim3(512), shm, (hipStream_t)stream, p); \
+    } while (0)
+    if (addend) { if (tmv == 2) LAUNCH_GENA(2, true, "k_gemm_cand_gen_ex"); else LAUNCH_GENA(1, true, "k_gemm_cand_gen_ex"); }
+    else { if (tmv == 2) LAUNCH_GENA(2, false, "k_gemm_cand_gen"); else LAUNCH_GENA(1, false, "k_gemm_cand_gen"); }
+#undef LAUNCH_GENA
     ADALOG_LAUNCH_CHECK("adalog_gemm_out_gen");
     return 0;
 }

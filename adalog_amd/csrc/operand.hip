@@ -35,7 +35,11 @@ struct PackArgs {
     int64_t Kp;
     int32_t* rowsum;      // optional [C][G][R] sum_k (q - z)
     int c_inner;          // 0: out[c][g][r][Kp]   1: out[g][r][c][Kp] (candidates innermost: GEMM columns = (row, candidate))
+    int pre;              // adalog, fast kernel: 1 = the operand is GELU(x) (erf form, ATen's expression): quant_forward of fc2 reads fc1's output
 };
+
+// x * 0.5 * (1 + erf(x / sqrt 2)) as ATen's GeluCUDAKernelImpl evaluates it in fp32 ("none" approximation)
+__device__ __forceinline__ float gelu_erf(float x) { return (x * 0.5f) * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 struct fp8_t { uint8_t b; };   // e4m3 byte as the hardware converts it (v_cvt_pk_fp8_f32); integers up to 16 are exact
 
@@ -306,11 +310,17 @@ __global__ __launch_bounds__(256) void k_pack_adalog_fast(PackArgs a) {
             const float* xp = a.x + g * a.sxg + r * a.sxr + k0;
             if (nlive == 4 && ((uintptr_t)xp & 15) == 0) {
                 const float4 v = *reinterpret_cast<const float4*>(xp);
-                xv[0] = v.x + sh; xv[1] = v.y + sh; xv[2] = v.z + sh; xv[3] = v.w + sh;
+                xv[0] = v.x; xv[1] = v.y; xv[2] = v.z; xv[3] = v.w;
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (e < nlive) xv[e] = xp[e] + sh;
+                for (int e = 0; e < 4; ++e) if (e < nlive) xv[e] = xp[e];
             }
+            if (a.pre == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = gelu_erf(xv[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (e < nlive) xv[e] += sh;
         }
         float lx[4];
 #pragma unroll
@@ -613,6 +623,136 @@ __global__ __launch_bounds__(256) void k_pack_uniform_tab16(PackArgs a) {
     }
 }
 
+// quant_forward of softmax . v (reference utils/wrap_net.py:26-30 + quant_layers/matmul.py:43-45): (scores * scale).softmax(-1) and the
+// AdaLog quantisation of the probabilities in ONE pass -- the probabilities are never written; the output is the packed bf16
+// operand of the product (what k_pack_adalog_fast writes for C = 1).  A wavefront owns a row of S <= 256 scores.  The arithmetic is
+// ATen's softmax_warp_forward, operation for operation (element k = lane + 64 it; max; e = exp(x - max) summed per lane in `it`
+// order, then the xor butterfly 32, 16, .., 1; e / sum), so that the composed route (torch softmax, then the packer) and this
+// kernel quantise the same fp32 probabilities.
+struct SoftmaxPackArgs {
+    const float* x; int64_t rows; int S; float mul;      // scores [rows][S] (contiguous), multiplied by `mul` first
+    const float* scale; const float* qv; const float* mant; int levels2;   // the AdaLog quantiser: device scalars (scale, q), 37 numerators
+    unsigned short* out; int64_t Kp;                     // bf16 bits [rows][Kp], zero beyond S
+};
+__global__ __launch_bounds__(256) void k_softmax_adalog_pack(SoftmaxPackArgs a) {
+    __shared__ unsigned short s_lut[258];
+    const int lw = a.levels2 + 2;
+    const float qf = a.qv[0], sc = a.scale[0];
+    for (int k = threadIdx.x; k < lw; k += blockDim.x) {
+        const int kqv = k * (int)qf;
+        const int t = kqv / ADALOG_R, j = kqv - t * ADALOG_R;
+        const float v = (k >= a.levels2 || t > 100) ? 0.0f : ldexpf(a.mant[j], -t);
+        s_lut[k] = (unsigned short)(__float_as_uint(v) >> 16);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* xr = a.x + row * a.S;
+    float el[4];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = lane + 64 * it;
+        el[it] = k < a.S ? xr[k] * a.mul : -__builtin_inff();
+    }
+    mx = el[0];
+#pragma unroll
+    for (int it = 1; it < 4; ++it) mx = mx < el[it] ? el[it] : mx;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float b = __shfl_xor(mx, o); mx = mx < b ? b : mx; }
+    float sum = 0.0f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) { el[it] = expf(el[it] - mx); sum += el[it]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum = sum + __shfl_xor(sum, o);
+    const float inv_s = __builtin_amdgcn_rcpf(sc), rq37 = 37.0f / qf;
+    unsigned short* orow = a.out + row * a.Kp;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int k = lane + 64 * it;
+        if (k >= a.Kp) break;
+        unsigned short hv = 0;
+        if (k < a.S) {
+            const float pr = el[it] / sum;
+            float kk = adalog_k_fast(pr, sc, inv_s, qf, rq37, true);
+            kk = (kk == kk) ? fminf(fmaxf(kk, 0.0f), (float)(a.levels2 + 1)) : (float)(a.levels2 + 1);
+            hv = s_lut[(int)kk];
+        }
+        orow[k] = hv;
+    }
+}
+
+// quant_forward of an attention block (reference utils/wrap_net.py:19-31 + quant_layers/matmul.py:43-45): the qkv projection's output
+// [B][N][3][H][64] is split into heads, passed through the three per-head uniform input quantisers (q and k of q . k^T, v of
+// softmax . v) and written as the packed operands of the two products in ONE pass -- no permuted fp32 copies of q / k / v, no three
+// packer launches:  qp, kp int8 [B*H][N][128] (64 codes q - z, 64 zero bytes), vp bf16 [B*H][64][Np] (v transposed: a row per
+// channel, a column per token, zero beyond N).  Codes as adalog_pack_uniform writes them: clamp(rne(x / s) + rne(z), 0, qmax) - rne(z).
+struct AttnSplitArgs {
+    const float* qkv; int B, N, H;
+    const float* qs; const float* qz; const float* ks; const float* kz; const float* vs; const float* vz;    // [H] each (pg = 1) or [1] (pg = 0)
+    int pg; float q_qmax, k_qmax, v_qmax;
+    int8_t* qp; int8_t* kp; unsigned short* vp; int64_t Np;
+};
+__global__ __launch_bounds__(256) void k_attn_split_pack(AttnSplitArgs a) {
+    __shared__ unsigned short vt[64][72];                       // [channel][token of the tile], rows padded against bank conflicts
+    const int h = blockIdx.y, b = blockIdx.z, n0 = blockIdx.x * 64;
+    const int t = threadIdx.x, row = t >> 2, qt = t & 3;       // token of the tile, 16-channel quarter
+    const int n = n0 + row;
+    const int HD = a.H * 64;
+    const int64_t g = (int64_t)b * a.H + h;
+    const int pi = a.pg ? h : 0;
+    const bool live = n < a.N;
+    const float* src = a.qkv + ((int64_t)b * a.N + (live ? n : 0)) * (3 * HD) + h * 64 + qt * 16;
+    auto load16 = [&](const float* p_, float (&x)[16]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 v = *reinterpret_cast<const float4*>(p_ + 4 * j);
+            x[4 * j] = v.x; x[4 * j + 1] = v.y; x[4 * j + 2] = v.z; x[4 * j + 3] = v.w;
+        }
+    };
+    auto codes = [&](const float (&x)[16], float s, float z, float qmax, float (&c)[16]) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = fminf(fmaxf(rintf(x[e] / s) + z, 0.0f), qmax) - z;
+    };
+    float x[16], c[16];
+    // q and k: one 16-byte store of codes and one of padding per thread and operand
+    for (int which = 0; which < 2; ++which) {
+        const float s = which ? a.ks[pi] : a.qs[pi], z = rintf(which ? a.kz[pi] : a.qz[pi]), qmax = which ? a.k_qmax : a.q_qmax;
+        if (live) {
+            load16(src + which * HD, x);
+            codes(x, s, z, qmax, c);
+            uint4 o;
+            unsigned* ow = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk |= ((unsigned)(int)c[4 * j + e] & 0xffu) << (8 * e);
+                ow[j] = pk;
+            }
+            int8_t* dst = (which ? a.kp : a.qp) + (g * a.N + n) * 128 + qt * 16;
+            *reinterpret_cast<uint4*>(dst) = o;
+            *reinterpret_cast<uint4*>(dst + 64) = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // v: quantise, transpose through LDS, rows of 64 tokens (128 bytes) out
+    {
+        const float s = a.vs[pi], z = rintf(a.vz[pi]);
+        if (live) { load16(src + 2 * HD, x); codes(x, s, z, a.v_qmax, c); }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) vt[qt * 16 + e][row] = live ? (unsigned short)(__float_as_uint(c[e]) >> 16) : (unsigned short)0;   // small integers: exact in bf16
+        __syncthreads();
+        const int ch = t >> 2, tq = t & 3;                       // channel, 16-token quarter
+        if (n0 + tq * 16 < a.Np) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(&vt[ch][tq * 16]), hi = *reinterpret_cast<const uint4*>(&vt[ch][tq * 16 + 8]);
+            unsigned short* dst = a.vp + (g * 64 + ch) * a.Np + n0 + tq * 16;
+            *reinterpret_cast<uint4*>(dst) = lo;
+            *reinterpret_cast<uint4*>(dst + 8) = hi;
+        }
+    }
+}
+
 template <typename T, int KIND>
 int launch_pack(const PackArgs& a, hipStream_t st) {
     constexpr int EPT = Out<T>::EPT;
@@ -736,10 +876,25 @@ extern "C" int adalog_pack_uniform(const float* x, int64_t G, int64_t R, int64_t
     return 0;
 }
 
+extern "C" int adalog_pack_adalog_bf16_pre(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr,
+                                           int64_t sxk, const float* scale, const float* qv, int64_t C, int64_t pc,
+                                           int64_t gmod, int64_t pg, int n_bits, const float* mant37, const float* shift,
+                                           int clamp_u, void* out, int64_t Kp, int c_inner, int pre, void* stream);
 extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr,
                                        int64_t sxk, const float* scale, const float* qv, int64_t C, int64_t pc,
                                        int64_t gmod, int64_t pg, int n_bits, const float* mant37, const float* shift,
                                        int clamp_u, void* out, int64_t Kp, int c_inner, void* stream) {
+    return adalog_pack_adalog_bf16_pre(x, G, R, K, sxg, sxr, sxk, scale, qv, C, pc, gmod, pg, n_bits, mant37, shift, clamp_u, out, Kp,
+                                       c_inner, 0, stream);
+}
+// pre = 1: the operand is GELU(x) -- the activation function between fc1 and fc2 (reference timm Mlp / quant_layers/linear.py:770-796
+// quant_forward) applied in the packer's loader, so that quant_forward of the MLP runs no separate GELU pass.  Per-tensor scale, unit
+// stride along K only (the fast kernel); anything else is refused.
+extern "C" int adalog_pack_adalog_bf16_pre(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr,
+                                           int64_t sxk, const float* scale, const float* qv, int64_t C, int64_t pc,
+                                           int64_t gmod, int64_t pg, int n_bits, const float* mant37, const float* shift,
+                                           int clamp_u, void* out, int64_t Kp, int c_inner, int pre, void* stream) {
+    ADALOG_ARG_CHECK(pre == 0 || (pre == 1 && pg == 0 && sxk == 1 && !getenv("ADALOG_PACK_GENERIC")), "pack_adalog: the GELU prologue needs a per-tensor scale and unit K stride");
     ADALOG_ARG_CHECK(x && scale && qv && mant37 && out, "pack_adalog: null pointer");
     ADALOG_ARG_CHECK(G >= 1 && R >= 1 && K >= 1 && C >= 1 && C <= 65535 && gmod >= 1, "pack_adalog: bad sizes");
     ADALOG_ARG_CHECK(Kp >= K && (Kp * 2) % 64 == 0, "pack_adalog: Kp must cover K and be a multiple of 32 elements");
@@ -748,7 +903,8 @@ extern "C" int adalog_pack_adalog_bf16(const float* x, int64_t G, int64_t R, int
     a.x = x; a.G = G; a.R = R; a.K = K; a.sxg = sxg; a.sxr = sxr; a.sxk = sxk;
     a.scale = scale; a.qv = qv; a.C = C; a.pc = pc; a.gmod = gmod; a.pg = pg; a.pr = 0;
     a.levels2 = 1 << n_bits; a.mant = mant37; a.shift = shift; a.clamp_u = clamp_u; a.out = out; a.Kp = Kp;
-    a.c_inner = c_inner;
+    a.c_inner = c_inner; a.pre = pre;
+    ADALOG_ARG_CHECK(pre == 0 || (size_t)C * (sizeof(float4) + (size_t)(a.levels2 + 2) * sizeof(unsigned short)) <= 64 * 1024, "pack_adalog: the GELU prologue runs on the fast kernel only");
     launch_pack<__hip_bfloat16, KIND_ADALOG>(a, (hipStream_t)stream);
     ADALOG_LAUNCH_CHECK("adalog_pack_adalog_bf16");
     return 0;
@@ -806,5 +962,41 @@ extern "C" int adalog_pack_split3_bf16(const float* x, int64_t G, int64_t R, int
     hipLaunchKernelGGL(k_pack_split3, dim3(bx, (unsigned)(R < 65535 ? R : 65535), (unsigned)G), dim3(256), 0, (hipStream_t)stream, x, R, K, sxg, sxr, sxk,
                        (uint16_t*)out, Kt);
     ADALOG_LAUNCH_CHECK("adalog_pack_split3_bf16");
+    return 0;
+}
+
+// (x * mul).softmax(-1) quantised by the post-softmax AdaLog quantiser (per-tensor scale, log base 2^(-q/37), u clamped to
+// [1e-15, 1]: reference quant_layers/matmul.py:337-343 with the searched q) straight into the bf16 operand image [rows][Kp] of
+// the softmax . v product.  x: fp32 [rows][S] contiguous, S <= 256; Kp: a multiple of 32 elements covering S, <= 256.
+extern "C" int adalog_softmax_adalog_pack_bf16(const float* x, int64_t rows, int S, float mul, const float* scale, const float* qv,
+                                               int n_bits, const float* mant37, void* out, int64_t Kp, void* stream) {
+    if (rows == 0) return 0;
+    ADALOG_ARG_CHECK(x && scale && qv && mant37 && out && rows > 0, "softmax_adalog_pack: null pointer");
+    ADALOG_ARG_CHECK(S >= 1 && S <= 256 && Kp >= S && Kp <= 256 && (Kp * 2) % 64 == 0, "softmax_adalog_pack: 1 <= S <= Kp <= 256, Kp a multiple of 32");
+    ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "softmax_adalog_pack: n_bits must be in [2,7]");
+    SoftmaxPackArgs a{x, rows, S, mul, scale, qv, mant37, 1 << n_bits, reinterpret_cast<unsigned short*>(out), Kp};
+    adalog_note_kernel("k_softmax_adalog_pack");
+    hipLaunchKernelGGL(k_softmax_adalog_pack, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    ADALOG_LAUNCH_CHECK("adalog_softmax_adalog_pack_bf16");
+    return 0;
+}
+
+// The three operand packs of an attention block's quant_forward in one launch (k_attn_split_pack): qkv fp32 [B][N][3][H][64]
+// (contiguous, 16-byte aligned); (scale, zero point) of the three uniform quantisers per head (pg = 1: [H]) or per tensor (pg = 0);
+// qp, kp int8 [B*H][N][128]; vp bf16 [B*H][64][Np], Np a multiple of 64 covering N.  Head dimension 64 only.
+extern "C" int adalog_attn_split_pack(const float* qkv, int B, int N, int H, const float* q_scale, const float* q_zp, int q_bits,
+                                      const float* k_scale, const float* k_zp, int k_bits, const float* v_scale, const float* v_zp,
+                                      int v_bits, int pg, void* qp, void* kp, void* vp, int64_t Np, void* stream) {
+    if (B == 0 || N == 0) return 0;
+    ADALOG_ARG_CHECK(qkv && q_scale && q_zp && k_scale && k_zp && v_scale && v_zp && qp && kp && vp, "attn_split_pack: null pointer");
+    ADALOG_ARG_CHECK(B >= 1 && N >= 1 && H >= 1 && H <= 65535 && B <= 65535 && Np >= N && Np % 64 == 0, "attn_split_pack: bad sizes (Np: a multiple of 64 covering N)");
+    ADALOG_ARG_CHECK(q_bits >= 2 && q_bits <= 7 && k_bits >= 2 && k_bits <= 7 && v_bits >= 2 && v_bits <= 7, "attn_split_pack: n_bits must be in [2,7]");
+    ADALOG_ARG_CHECK(((((uintptr_t)qkv) | ((uintptr_t)qp) | ((uintptr_t)kp) | ((uintptr_t)vp)) & 15) == 0, "attn_split_pack: 16-byte aligned buffers");
+    AttnSplitArgs a{qkv, B, N, H, q_scale, q_zp, k_scale, k_zp, v_scale, v_zp, pg ? 1 : 0, (float)((1 << q_bits) - 1), (float)((1 << k_bits) - 1),
+                    (float)((1 << v_bits) - 1), reinterpret_cast<int8_t*>(qp), reinterpret_cast<int8_t*>(kp),
+                    reinterpret_cast<unsigned short*>(vp), Np};
+    adalog_note_kernel("k_attn_split_pack");
+    hipLaunchKernelGGL(k_attn_split_pack, dim3((unsigned)(Np / 64), (unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, a);
+    ADALOG_LAUNCH_CHECK("adalog_attn_split_pack");
     return 0;
 }

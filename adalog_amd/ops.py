@@ -157,9 +157,19 @@ def pack_uniform(x3, scale, zero_point, C: int, pc: int, gmod: int, pg: int, pr:
 
 
 def pack_adalog(x3, scale, qv, C: int, pc: int, gmod: int, pg: int, n_bits: int, mant37, shift=None,
-                clamp_u: bool = True, c_inner: bool = False, k_align: int = 128):
+                clamp_u: bool = True, c_inner: bool = False, k_align: int = 128, pre_gelu: bool = False):
+    """``pre_gelu``: the operand is GELU(x3) (erf form) -- applied in the packer's loader (adalog_pack_adalog_bf16_pre)."""
     G, R, K, sg, sr, sk = _view3(x3)
     Kp = pad_k(K, BF16, k_align)
+    if pre_gelu:
+        out = torch.empty((1, G, R * C, Kp) if c_inner else (C, G, R, Kp), dtype=torch.bfloat16, device=x3.device)
+        rc = _lib.load().adalog_pack_adalog_bf16_pre(x3.data_ptr(), G, R, K, sg, sr, sk, _ptr(_f32c(scale, "scale")),
+                                                    _ptr(_f32c(qv, "qv")), C, pc, gmod, pg, int(n_bits), _ptr(_f32c(mant37, "mant37")),
+                                                    _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(clamp_u)),
+                                                    out.data_ptr(), Kp, int(bool(c_inner)), 1, _stream())
+        _lib.check(rc, "adalog_pack_adalog_bf16_pre")
+        out.k_valid = K
+        return out
     if _torch_ops.available():
         out = _top("pack_adalog", x3, _f32c(scale, "scale"), _f32c(qv, "qv"), int(C), int(pc), int(gmod), int(pg), int(n_bits),
                    _f32c(mant37, "mant37"), None if shift is None else _f32c(shift, "shift"), bool(clamp_u), int(Kp), bool(c_inner))
@@ -481,8 +491,11 @@ def gemm_score_avq(A, src3, q_all, lut, n_bits: int, M: int, N: int, P: int, G: 
 
 
 def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, sb: Strided, bias: Optional[Strided],
-             sa_mul: float = 1.0):
-    """Quantised forward: out[g] = (A[g] . B[g]^T) * sa * sb[n] + bias[n]   -> fp32 [G, M, N]."""
+             sa_mul: float = 1.0, addend=None, heads_last: int = 0):
+    """Quantised forward: out[g] = (A[g] . B[g]^T) * sa * sb[n] + bias[n] (+ addend[g])   -> fp32 [G, M, N].
+    ``addend``: fp32 [G, M, N] contiguous, added in the epilogue (the residual stream).  ``heads_last`` = H > 0 (G = B * H): the
+    result is written as [B, M, H, N] storage -- returned in that shape -- so that the transpose(1, 2).reshape(B, M, H * N) after
+    softmax . v is a view (adalog_gemm_out_ex: two-level output groups)."""
     lib = _lib.load()
     sa, sb = sa.checked(), sb.checked()
     bias = None if bias is None else bias.checked()
@@ -490,6 +503,24 @@ def gemm_out(dtype: int, A, B, M: int, N: int, G: int, gmod: int, sa: Strided, s
     assert B.shape[-1] == Kp and A.dtype == _TORCH_DT[dtype] and B.dtype == _TORCH_DT[dtype]
     sAg = 0 if A.shape[1] == 1 and G > 1 else A.stride(1)
     sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
+    if addend is not None or heads_last:
+        assert dtype in (I8, BF16) and sa.c == 0 and sb.c == 0 and (bias is None or bias.c == 0)
+        H = int(heads_last)
+        if H:
+            assert G % H == 0 and addend is None
+            out = torch.empty((G // H, M, H, N), dtype=torch.float32, device=A.device)
+            ldo, sOg, gi, sOo = H * N, N, H, M * H * N
+        else:
+            addend = _f32c(addend, "addend")
+            assert addend.numel() == G * M * N
+            out = torch.empty((G, M, N), dtype=torch.float32, device=A.device)
+            ldo, sOg, gi, sOo = N, M * N, 0, 0
+        rc = lib.adalog_gemm_out_ex(dtype, A.data_ptr(), B.data_ptr(), sAg, sBg, M, N, Kp, G, gmod, sa.t.data_ptr(), sa.g, float(sa_mul),
+                                    sb.t.data_ptr(), sb.g, sb.n, None if bias is None else bias.t.data_ptr(),
+                                    0 if bias is None else bias.g, 0 if bias is None else bias.n, _ptr(addend), out.data_ptr(),
+                                    ldo, sOg, gi, sOo, _stream())
+        _lib.check(rc, "adalog_gemm_out_ex")
+        return out
     out = torch.empty((G, M, N), dtype=torch.float32, device=A.device)
     rc = lib.adalog_gemm_score(dtype, A.data_ptr(), B.data_ptr(), 0, sAg, 0, sBg, M, N, Kp, 0, 1, G, gmod, None, 0, 0, 1, 1,
                                sa.t.data_ptr(), sa.c, sa.g, float(sa_mul), sb.t.data_ptr(), sb.c, sb.g, sb.n,
@@ -510,7 +541,7 @@ def gemm_out_gen_ok(x3, Kp: int, n_bits: int) -> bool:
 
 
 def gemm_out_gen(x3, a_scale, a_zp, n_bits: int, B, N: int, gmod: int, sa: Strided, sb: Strided, bias: Optional[Strided],
-                 sa_mul: float = 1.0):
+                 sa_mul: float = 1.0, addend=None):
     """Quantised forward with the A-side fake quantisation inside the GEMM's loader (adalog_gemm_out_gen, k_gemm_cand<GENA>):
     out[g] = (q_a(x3[g]) . B[g]^T) * sa * sb[n] + bias[n] -> fp32 [G, M, N], q_a the per-tensor (one (scale, zp)) or per-head
     ((scale, zp)[g % gmod]) uniform quantiser -- gemm_out(I8, pack_uniform(x3, ...), B, ...) without the pack launch and the int8
@@ -525,12 +556,60 @@ def gemm_out_gen(x3, a_scale, a_zp, n_bits: int, B, N: int, gmod: int, sa: Strid
     assert B.dtype == torch.int8 and B.is_contiguous() and B.shape[-2] == N
     sBg = 0 if B.shape[1] == 1 and G > 1 else B.stride(1)
     out = torch.empty((G, M, N), dtype=torch.float32, device=x3.device)
-    rc = lib.adalog_gemm_out_gen(x3.data_ptr(), x3.stride(1), x3.stride(0), K, a_scale.data_ptr(), a_zp.data_ptr(), 0 if a_scale.numel() == 1 else 1,
-                                 int(n_bits), B.data_ptr(), sBg, M, N, Kp, G, gmod, sa.t.data_ptr(), sa.g, float(sa_mul),
-                                 sb.t.data_ptr(), sb.g, sb.n, None if bias is None else bias.t.data_ptr(),
-                                 0 if bias is None else bias.g, 0 if bias is None else bias.n, out.data_ptr(), N, M * N, _stream())
-    _lib.check(rc, "adalog_gemm_out_gen")
+    if addend is not None:                               # the residual stream, added in the epilogue
+        addend = _f32c(addend, "addend")
+        assert addend.numel() == G * M * N
+    rc = lib.adalog_gemm_out_gen_ex(x3.data_ptr(), x3.stride(1), x3.stride(0), K, a_scale.data_ptr(), a_zp.data_ptr(),
+                                    0 if a_scale.numel() == 1 else 1, int(n_bits), B.data_ptr(), sBg, M, N, Kp, G, gmod,
+                                    sa.t.data_ptr(), sa.g, float(sa_mul), sb.t.data_ptr(), sb.g, sb.n,
+                                    None if bias is None else bias.t.data_ptr(), 0 if bias is None else bias.g,
+                                    0 if bias is None else bias.n, _ptr(addend), out.data_ptr(), N, M * N, _stream())
+    _lib.check(rc, "adalog_gemm_out_gen_ex")
     return out
+
+
+def softmax_adalog_pack(x3, mul: float, scale, qv, n_bits: int, mant37):
+    """(x3 * mul).softmax(-1) through the post-softmax AdaLog quantiser, as the packed bf16 operand [1, G, R, Kp] of softmax . v
+    (adalog_softmax_adalog_pack_bf16: one pass, the probabilities are never stored).  x3: fp32 [G, R, S] contiguous, S <= 256."""
+    x3 = _f32c(x3, "scores")
+    G, R, S = x3.shape
+    Kp = pad_k(S, BF16)
+    out = torch.empty((1, G, R, Kp), dtype=torch.bfloat16, device=x3.device)
+    rc = _lib.load().adalog_softmax_adalog_pack_bf16(x3.data_ptr(), G * R, S, float(mul), _ptr(_f32c(scale, "scale")),
+                                                    _ptr(_f32c(qv, "qv")), int(n_bits), _ptr(_f32c(mant37, "mant37")),
+                                                    out.data_ptr(), Kp, _stream())
+    _lib.check(rc, "adalog_softmax_adalog_pack_bf16")
+    out.k_valid = S
+    return out
+
+
+def softmax_adalog_pack_ok(S: int) -> bool:
+    return S <= 256 and pad_k(S, BF16) <= 256
+
+
+def attn_split_pack(qkv, H: int, q_par, k_par, v_par, per_head: bool):
+    """qkv fp32 [B, N, 3*H*64] (the qkv projection's output) -> (qp, kp, vp): the packed operands of q . k^T (int8 [1, B*H, N, 128])
+    and of softmax . v's second operand (bf16 [1, B*H, 64, Np], v transposed) through the three uniform input quantisers
+    ((scale, zero_point, n_bits) each; per head or per tensor) in one launch (adalog_attn_split_pack)."""
+    qkv = _f32c(qkv, "qkv")
+    B, N, C3 = qkv.shape
+    assert C3 == 3 * H * 64
+    Np = ((N + 63) // 64) * 64
+    qp = torch.empty((1, B * H, N, 128), dtype=torch.int8, device=qkv.device)
+    kp = torch.empty((1, B * H, N, 128), dtype=torch.int8, device=qkv.device)
+    vp = torch.empty((1, B * H, 64, Np), dtype=torch.bfloat16, device=qkv.device)
+    par = []
+    for s_, z_, b_ in (q_par, k_par, v_par):
+        s_, z_ = _f32c(s_, "scale").reshape(-1), _f32c(z_, "zero_point").reshape(-1)
+        assert s_.numel() == z_.numel() == (H if per_head else 1)
+        par += [s_, z_, int(b_)]
+    rc = _lib.load().adalog_attn_split_pack(qkv.data_ptr(), B, N, H, par[0].data_ptr(), par[1].data_ptr(), par[2], par[3].data_ptr(),
+                                           par[4].data_ptr(), par[5], par[6].data_ptr(), par[7].data_ptr(), par[8],
+                                           1 if per_head else 0, qp.data_ptr(), kp.data_ptr(), vp.data_ptr(), Np, _stream())
+    _lib.check(rc, "adalog_attn_split_pack")
+    qp.k_valid = kp.k_valid = 64
+    vp.k_valid = N
+    return qp, kp, vp
 
 
 def log2_shift(x, shift: float):

@@ -493,27 +493,36 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         return None
 
     # ------------------------------------------------------------------ quantised forward (linear.py:46-51), fused
-    def quant_forward(self, x):
+    def quant_forward(self, x, addend=None):
+        """``addend`` (optional, the shape of the output): added to the result -- in the GEMM's epilogue on the fused routes (the
+        residual stream of a transformer block: x + proj(...), utils/models.py)."""
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
         if torch.is_grad_enabled() and (self.w_quantizer.training_mode or self.a_quantizer.training_mode
                                         or not isinstance(self.w_quantizer, UniformQuantizer)):
-            return super().quant_forward(x)                    # BRECQ: differentiable fake-quant + GEMM
+            out = super().quant_forward(x)                     # BRECQ: differentiable fake-quant + GEMM
+            return out if addend is None else addend + out
         be = backend.get()
         aq = self.a_quantizer
         if not isinstance(self.w_quantizer, UniformQuantizer) or aq.n_bits > 7 or self.w_quantizer.n_bits > 7:
-            return super().quant_forward(x)
+            out = super().quant_forward(x)
+            return out if addend is None else addend + out
         lead = x.shape[:-1]
         x3 = x.reshape(1, -1, self.in_features)
         wp = self._pack_w_cached()
         sa_, sb_ = Strided(aq.scale.data.view(-1)), Strided(self.w_quantizer.scale.data.view(-1), n=1)
         bias_ = None if self.bias is None else Strided(self.bias.data, n=1)
+        fused_add = addend is not None and hasattr(be, "softmax_adalog_pack") and addend.shape == lead + (self.out_features,)
+        add_ = addend.reshape(1, -1, self.out_features) if fused_add else None
         if aq.scale.numel() == 1 and hasattr(be, "gemm_out_gen") and be.gemm_out_gen_ok(x3, wp.shape[-1], aq.n_bits):
             # ONE launch for the layer: the activation is quantised in the GEMM's loader (k_gemm_cand<GENA>), the weight image is cached
-            out = be.gemm_out_gen(x3, aq.scale.data, aq.zero_point.data, aq.n_bits, wp, self.out_features, 1, sa_, sb_, bias_)
-            return out.view(*lead, self.out_features)
-        xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
-        out = be.gemm_out(I8, xp, wp, x3.shape[1], self.out_features, 1, 1, sa_, sb_, bias_)
-        return out.view(*lead, self.out_features)
+            out = be.gemm_out_gen(x3, aq.scale.data, aq.zero_point.data, aq.n_bits, wp, self.out_features, 1, sa_, sb_, bias_,
+                                  **({"addend": add_} if fused_add else {}))
+        else:
+            xp = be.pack_uniform(x3, aq.scale.data.view(-1), aq.zero_point.data.view(-1), 1, 0, 1, 0, 0, aq.n_bits, I8)
+            out = be.gemm_out(I8, xp, wp, x3.shape[1], self.out_features, 1, 1, sa_, sb_, bias_,
+                              **({"addend": add_} if fused_add else {}))
+        out = out.view(*lead, self.out_features)
+        return out if (addend is None or fused_add) else addend + out
 
 
 class AsymmetricallyChannelWiseBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
@@ -538,10 +547,11 @@ class AsymmetricallyChannelWiseBatchingQuantLinear(AsymmetricallyBatchingQuantLi
     def prev_layer(self):
         return self._prev_layer
 
-    def quant_forward(self, x):
+    def quant_forward(self, x, addend=None):
         if self.a_quantizer.channel_wise:            # only between search and reparam; plain composition
-            return MinMaxQuantLinear.quant_forward(self, x)
-        return super().quant_forward(x)
+            out = MinMaxQuantLinear.quant_forward(self, x)
+            return out if addend is None else addend + out
+        return super().quant_forward(x, addend)
 
     def hyperparameter_searching(self):
         """linear.py:585-594: per-channel activation FPCS against the activation's own MSE."""
@@ -767,12 +777,21 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         self.bias.data.copy_(fold)
         aq.mark_bias_reparamed()
 
-    def quant_forward(self, x):
+    def fused_ok(self):
+        """quant_forward takes the fused route (packer + bf16 MFMA product): the callers that hand over fc1's output with
+        ``pre_gelu`` (utils/models.py: Mlp) ask first."""
+        return (self.calibrated and isinstance(self.w_quantizer, UniformQuantizer) and not self.a_quantizer.training_mode
+                and not (torch.is_grad_enabled() and self.w_quantizer.training_mode) and hasattr(backend.get(), "softmax_adalog_pack"))
+
+    def quant_forward(self, x, addend=None, pre_gelu=False):
+        """``pre_gelu``: x is fc1's output and the layer's input is GELU(x) -- applied in the packer's loader (one pass less over the
+        widest activation of the block); ``addend``: added to the result in the GEMM's epilogue (the residual stream)."""
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
         aq = self.a_quantizer
         if (torch.is_grad_enabled() and (self.w_quantizer.training_mode or aq.training_mode)) \
                 or not isinstance(self.w_quantizer, UniformQuantizer) or aq.training_mode:
-            return MinMaxQuantLinear.quant_forward(self, x)
+            out = MinMaxQuantLinear.quant_forward(self, torch.nn.functional.gelu(x) if pre_gelu else x)
+            return out if addend is None else addend + out
         be = backend.get()
         dev = x.device
         lead = x.shape[:-1]
@@ -780,8 +799,10 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         if self._q_host is None:
             self._q_host = int(aq.q.item())
         qv = search.const_tensor([float(self._q_host)], dev)
+        if pre_gelu and not (hasattr(be, "softmax_adalog_pack") and x3.stride(-1) == 1):
+            x3, pre_gelu = torch.nn.functional.gelu(x3), False
         xp = be.pack_adalog(x3, aq.scale.data.view(-1), qv, 1, 0, 1, 0, aq.n_bits, self._mant37(dev),
-                            shift=aq.shift.data, clamp_u=True)
+                            shift=aq.shift.data, clamp_u=True, **({"pre_gelu": True} if pre_gelu else {}))
         _, sub = aq._shift_args()
         if sub:
             wp, rowsum = self._pack_w_cached(BF16, want_rowsum=True)
@@ -790,10 +811,13 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         else:
             wp = self._pack_w_cached(BF16)
             bias = None if self.bias is None else self.bias.data
+        fused_add = addend is not None and hasattr(be, "softmax_adalog_pack") and addend.shape == lead + (self.out_features,)
         out = be.gemm_out(BF16, xp, wp, x3.shape[1], self.out_features, 1, 1, Strided(aq.scale.data.view(-1)),
                           Strided(self.w_quantizer.scale.data.view(-1), n=1),
-                          None if bias is None else Strided(bias, n=1), sa_mul=self._ts32())
-        return out.view(*lead, self.out_features)
+                          None if bias is None else Strided(bias, n=1), sa_mul=self._ts32(),
+                          **({"addend": addend.reshape(1, -1, self.out_features)} if fused_add else {}))
+        out = out.view(*lead, self.out_features)
+        return out if (addend is None or fused_add) else addend + out
 
     def _load_from_state_dict(self, *a, **k):
         super()._load_from_state_dict(*a, **k)

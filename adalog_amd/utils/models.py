@@ -20,7 +20,21 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
+from .. import backend as _backend
+from .. import search as _search
 from .. import train_mm
+
+# quant_forward of a ViT / DeiT block on the fused route (Attention._fused_quant_forward, Mlp.forward): 0 = module by module
+QF_FUSED = os.environ.get("ADALOG_QF_FUSED", "1") != "0"
+
+
+def _plain_quant_forward(m):
+    """m is one of the package's quantised modules, calibrated, in quant_forward mode, and nobody listens on its forward (the
+    calibrator's capture hooks need the module-by-module route)."""
+    return (getattr(m, "mode", None) == "quant_forward" and getattr(m, "calibrated", False)
+            and not m._forward_hooks and not m._forward_pre_hooks)
 
 
 class MatMul(nn.Module):
@@ -40,8 +54,16 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features or in_features)
         self.drop2 = nn.Identity()
 
-    def forward(self, x):
-        return self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
+    def forward(self, x, residual=None):
+        """``residual`` (utils/models.py: Block): returned added to the result -- inside fc2's launch on the fused route."""
+        fc2 = self.fc2
+        if (QF_FUSED and not torch.is_grad_enabled() and x.is_cuda and _plain_quant_forward(fc2) and hasattr(fc2, "fused_ok")
+                and fc2.fused_ok() and isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none"
+                and all(isinstance(m, nn.Identity) for m in (self.drop1, self.norm, self.drop2))):
+            # quant_forward: GELU runs in the loader of fc2's operand packer, the residual is added in fc2's epilogue
+            return fc2.quant_forward(self.fc1(x), addend=residual, pre_gelu=True)
+        out = self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
+        return out if residual is None else residual + out
 
 
 class Attention(nn.Module):
@@ -62,7 +84,60 @@ class Attention(nn.Module):
         self.matmul1 = MatMul()
         self.matmul2 = MatMul()
 
-    def forward(self, x):
+    def _fused_quant_forward_ok(self, x):
+        """quant_forward of the whole block on the fused route (below): every quantised module of the block is in plain
+        quant_forward mode with the input quantisers the packers implement, head dimension 64, <= 256 tokens."""
+        from ..quant_layers.matmul import AsymmetricallyBatchingQuantMatMul, PostSoftmaxAsymmetricallyBatchingQuantMatMul
+        from ..quantizers.uniform import UniformQuantizer
+        m1, m2 = self.matmul1, self.matmul2
+        if not (QF_FUSED and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and self.head_dim == 64
+                and x.shape[1] <= 256 and isinstance(self.q_norm, nn.Identity) and isinstance(self.k_norm, nn.Identity)
+                and isinstance(self.attn_drop, nn.Identity) and isinstance(self.proj_drop, nn.Identity)):
+            return False
+        if not (type(m1) is AsymmetricallyBatchingQuantMatMul and type(m2) is PostSoftmaxAsymmetricallyBatchingQuantMatMul
+                and all(_plain_quant_forward(m) for m in (self.qkv, self.proj, m1, m2))):
+            return False
+        qs = (m1.A_quantizer, m1.B_quantizer, m2.B_quantizer)
+        return (all(isinstance(q, UniformQuantizer) and 2 <= q.n_bits <= 7 and not q.training_mode for q in qs)
+                and not m2.A_quantizer.training_mode and m1._heads() == m2._heads() and m2.A_quantizer.scale.numel() == 1
+                and hasattr(_backend.get(), "attn_split_pack"))
+
+    def _fused_quant_forward(self, x, residual):
+        """The attention block in quant_forward mode (reference utils/wrap_net.py:19-32 with every product in quant_forward,
+        quant_layers/matmul.py:43-45) as five launches after the qkv projection: split + three input quantisers + operand packs;
+        q . k^T (int8 MFMA); scale + softmax + AdaLog quantiser + pack; softmax . v (bf16 MFMA) written as [B, N, H, D]; the
+        projection with the residual stream added in its epilogue."""
+        from ..ops import BF16, I8, Strided
+        be = _backend.get()
+        B, N, C = x.shape
+        H = self.num_heads
+        m1, m2 = self.matmul1, self.matmul2
+        qkv = self.qkv(x)
+        hm = m1._heads()
+        pg = 1 if hm > 1 else 0
+        sA, zA = m1._q_params(m1.A_quantizer)
+        sB, zB = m1._q_params(m1.B_quantizer)
+        sV, zV = m2._q_params(m2.B_quantizer)
+        qp, kp, vp = be.attn_split_pack(qkv, H, (sA, zA, m1.A_quantizer.n_bits), (sB, zB, m1.B_quantizer.n_bits),
+                                        (sV, zV, m2.B_quantizer.n_bits), hm > 1)
+        scores = be.gemm_out(I8, qp, kp, N, N, B * H, hm, Strided(sA, g=pg), Strided(sB, g=pg), None)
+        if m2._q_host is None:
+            m2._q_host = int(m2.A_quantizer.q.item())
+        qv = _search.const_tensor([float(m2._q_host)], x.device)
+        a_scale = m2.A_quantizer.scale.data.view(-1)
+        ap = be.softmax_adalog_pack(scores, self.scale, a_scale, qv, m2.A_quantizer.n_bits, m2._mant37(x.device))
+        out = be.gemm_out(BF16, ap, vp, N, self.head_dim, B * H, hm, Strided(a_scale), Strided(sV, g=pg), None, sa_mul=m2._ts32(),
+                          heads_last=H)
+        return self.proj.quant_forward(out.view(B, N, C), addend=residual)
+
+    def forward(self, x, residual=None):
+        """``residual`` (Block): returned added to the result -- inside the projection's launch on the fused route."""
+        if self._fused_quant_forward_ok(x):
+            return self._fused_quant_forward(x, residual)
+        out = self._forward(x)
+        return out if residual is None else residual + out
+
+    def _forward(self, x):
         B, N, C = x.shape
         x = self.qkv(x)
         fused = None
@@ -98,6 +173,9 @@ class Block(nn.Module):
         self.drop_path2 = nn.Identity()
 
     def forward(self, x):
+        if all(isinstance(m, nn.Identity) for m in (self.ls1, self.ls2, self.drop_path1, self.drop_path2)):
+            x = self.attn(self.norm1(x), residual=x)       # x + attn(...): the sum is taken by the branch (in its last launch when fused)
+            return self.mlp(self.norm2(x), residual=x)
         x = x + self.drop_path1(self.ls1(self.attn(self.norm1(x))))
         x = x + self.drop_path2(self.ls2(self.mlp(self.norm2(x))))
         return x

@@ -316,10 +316,22 @@ def quant_forward_rate(calibrated, images, dev, reps=5):
             return hook
         for m in model.modules():
             if hasattr(m, "mode"):
+                m.mode = "quant_forward"
                 hooks.append(m.register_forward_hook(mk(type(m).__name__)))
-    ms_q, out_q = run("quant_forward")
+        with torch.no_grad():                                      # (listeners on the modules' forward select the module-by-module route)
+            out_mod = model(images)
     for h in hooks:
         h.remove()
+    ms_q, out_q = run("quant_forward")                             # no listeners: the fused block route (utils/models.py)
+    launches = None
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with torch.no_grad(), profile(activities=[ProfilerActivity.CUDA]) as prof:
+            model(images)
+            torch.cuda.synchronize()
+        launches = int(sum(e.count for e in prof.key_averages() if "DeviceType.CUDA" in str(getattr(e, "device_type", ""))))
+    except Exception:                                              # the count is a report item only
+        launches = None
     ms_r, out_r = run("raw")
     # the same quant_forward as a captured HIP graph (what validate() replays per batch shape: utils/graph_forward.py)
     from adalog_amd.utils.graph_forward import GraphedForward
@@ -344,11 +356,15 @@ def quant_forward_rate(calibrated, images, dev, reps=5):
             "eager_ms_per_forward": round(ms_q, 3), "eager_images_per_s": round(n / ms_q * 1e3, 1),
             "graph_output_equals_eager": graph_equal,
             "raw_ms_per_forward": round(ms_r, 3), "raw_images_per_s": round(n / ms_r * 1e3, 1),
+            "launches_per_forward": launches,
+            "fused_vs_module_route_rel_diff": float((out_q - out_mod).norm() / out_mod.norm()),
             "kernels_by_layer_class": {k: sorted(v) for k, v in labels.items()},
             "output_rel_diff_vs_fp": round(rel, 4),
-            "note": "uniformly quantised Linear layers (qkv / proj / fc1 / head): ONE launch, the activation quantised in the GEMM's loader "
-                    "(k_gemm_cand_gen, round 6); fc2 and the attention products: operand pack(s) + integer / bf16 MFMA product with the "
-                    "dequantising epilogue; packed weights cached across calls; raw = the FP32 model (rocBLAS)"}
+            "note": "timed: the fused block route (utils/models.py, round 6) -- per transformer block qkv / proj / fc1 in ONE launch each "
+                    "(activation quantised in the GEMM's loader, residual added in proj's and fc2's epilogue), q / k / v split + "
+                    "quantised + packed in one launch, scale + softmax + AdaLog quantiser + pack in one launch, softmax.v written as "
+                    "[B,N,H,D], GELU inside fc2's operand packer; kernels_by_layer_class: the module-by-module route (a forward with "
+                    "listeners on every module), kept for callers that hook modules; packed weights cached; raw = the FP32 model (rocBLAS)"}
 
 
 def _cpu_sample(threads, n_cand, min_seconds=0.0):

@@ -388,6 +388,40 @@ int adalog_gemm_out_gen(const float* x, int64_t ldx, int64_t sxg, int K, const f
                         float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_g, int64_t bi_n,
                         float* out, int64_t ldo, int64_t sOg, void* stream);
 
+/* ... + addend[g][m][n] (may be null; indexed like out): the residual stream of a transformer block added in the epilogue */
+int adalog_gemm_out_gen_ex(const float* x, int64_t ldx, int64_t sxg, int K, const float* a_scale, const float* a_zp, int64_t a_pg, int n_bits,
+                           const void* B, int64_t sBg, int M, int N, int64_t Kp, int G, int gmod, const float* sa, int64_t sa_g,
+                           float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias, int64_t bi_g, int64_t bi_n,
+                           const float* addend, float* out, int64_t ldo, int64_t sOg, void* stream);
+/* K15 from packed operands (dtype 0 = int8, 1 = bf16; A [G][M][Kp], B [G][N][Kp], group strides in elements, 0 = shared) with the
+ * same epilogue extras:  out = sa * sa_mul * sb[n] * (A . B^T) + bias[n] + addend.  out_gi > 0: two-level output groups, group g
+ * written at (g % out_gi) * sOg + (g / out_gi) * sOo -- softmax . v with out_gi = H, sOg = D, sOo = N * H * D, ldo = H * D writes
+ * [B][N][H][D] storage: the transpose(1, 2).reshape(B, N, C) of reference utils/wrap_net.py:31 becomes a view. */
+int adalog_gemm_out_ex(int dtype, const void* A, const void* B, int64_t sAg, int64_t sBg, int M, int N, int64_t Kp, int G, int gmod,
+                       const float* sa, int64_t sa_g, float sa_mul, const float* sb, int64_t sb_g, int64_t sb_n, const float* bias,
+                       int64_t bi_g, int64_t bi_n, const float* addend, float* out, int64_t ldo, int64_t sOg, int out_gi, int64_t sOo,
+                       void* stream);
+
+/* ---- quant_forward prologues of a transformer block (round 6): the passes between two products folded into the packers
+ * adalog_pack_adalog_bf16_pre: adalog_pack_adalog_bf16 of GELU(x) (pre = 1: x * 0.5 * (1 + erf(x / sqrt 2)), ATen's fp32 expression) --
+ *   the activation between fc1 and fc2 (timm Mlp; reference linear.py:770-796 reads GELU's output).  Per-tensor scale, sxk = 1.
+ * adalog_softmax_adalog_pack_bf16: (x * mul).softmax(-1) (reference utils/wrap_net.py:26-27), quantised by the post-softmax AdaLog
+ *   quantiser (matmul.py:337-343: per-tensor scale, log base 2^(-q/37), u clamped to [1e-15, 1]) into the bf16 operand [rows][Kp]
+ *   of softmax . v; the probabilities are never stored.  x fp32 [rows][S] contiguous, S <= Kp <= 256.  ATen's softmax arithmetic,
+ *   operation for operation.
+ * adalog_attn_split_pack: qkv fp32 [B][N][3][H][64] -> the packed operands of both attention products through their three per-head
+ *   (pg = 1) or per-tensor (pg = 0) uniform quantisers: qp, kp int8 [B*H][N][128]; vp bf16 [B*H][64][Np] (v transposed, zero beyond
+ *   N; Np a multiple of 64).  Replaces the split / permute copies of wrap_net.py:20-22 and three adalog_pack_uniform launches. */
+int adalog_pack_adalog_bf16_pre(const float* x, int64_t G, int64_t R, int64_t K, int64_t sxg, int64_t sxr, int64_t sxk,
+                                const float* scale, const float* qv, int64_t C, int64_t pc, int64_t gmod, int64_t pg,
+                                int n_bits, const float* mant37, const float* shift, int clamp_u, void* out, int64_t Kp,
+                                int c_inner, int pre, void* stream);
+int adalog_softmax_adalog_pack_bf16(const float* x, int64_t rows, int S, float mul, const float* scale, const float* qv, int n_bits,
+                                    const float* mant37, void* out, int64_t Kp, void* stream);
+int adalog_attn_split_pack(const float* qkv, int B, int N, int H, const float* q_scale, const float* q_zp, int q_bits,
+                           const float* k_scale, const float* k_zp, int k_bits, const float* v_scale, const float* v_zp, int v_bits,
+                           int pg, void* qp, void* kp, void* vp, int64_t Np, void* stream);
+
 /* ---- stable LSD radix sort of fp32 keys, per segment (csrc/radix_sort.hip; hipCUB until round 5): what the sorted forms above and
  * adalog_gram_act_prepare sort with.  x [S][n] contiguous -> sorted [S][n] (ascending per segment; -0 before +0), perm (may be null)
  * [S][n]: perm[s][i] = index within segment s of its i-th smallest value, equal values in input order.  n <= 8192: one launch (a

@@ -437,3 +437,51 @@ def test_cli_deit_base_w3a3_calibrate_and_optimize(tmp_path):
     assert len(fid) == 2 and all(q == q and q > MIN_SQNR_DB[3] for _, q in fid), fid
     assert fid[0][1] >= MIN_SQNR_RUN["deit_base_w3"], fid                     # the calibrated model
     _assert_reconstruction_lowers_the_loss(r.stdout + r.stderr, 14)
+
+
+@pytest.mark.parametrize("bits", [4, 6])
+def test_fused_block_quant_forward_matches_the_module_route(bits):
+    """quant_forward of a calibrated deit_tiny on the fused block route (utils/models.py: Attention._fused_quant_forward, Mlp.forward
+    -- q / k / v split-quantise-pack in one launch, softmax + AdaLog quantiser + pack in one launch, softmax.v written heads-last, GELU
+    inside fc2's packer, residuals in the projections' epilogues) against the module-by-module route (every quantised module's own
+    quant_forward, torch softmax / GELU / adds between them; ADALOG_QF_FUSED=0).  Every fused piece is bit-identical to what it
+    replaces (tests/test_gpu_kernels.py), so the logits must agree to fp32 rounding of the few re-associated adds -- and the fused
+    route must launch far fewer kernels."""
+    from torch.profiler import ProfilerActivity, profile
+    from adalog_amd.utils import models as M
+    from adalog_amd.utils.calibrator import QuantCalibrator
+    from adalog_amd.utils.models import create_model
+    from adalog_amd.utils.wrap_net import wrap_modules_in_net, wrap_reparamed_modules_in_net
+    torch.manual_seed(5)
+    model = wrap_modules_in_net(create_model("deit_tiny").eval(), _cfg(bits), reparam=True).to(DEV)
+    x = torch.randn(8, 3, 224, 224, generator=torch.Generator().manual_seed(5)).to(DEV)
+    QuantCalibrator(model, [(x, None)], capture="block").batching_quant_calib()
+    model = wrap_reparamed_modules_in_net(model).to(DEV).eval()
+    for m in model.modules():
+        if hasattr(m, "reparam_bias"):
+            m.reparam_bias()
+        if hasattr(m, "mode"):
+            m.mode = "quant_forward"
+
+    def run(fused):
+        M.QF_FUSED = fused
+        with torch.no_grad():
+            model(x)
+            torch.cuda.synchronize()
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                y = model(x)
+                torch.cuda.synchronize()
+        n = sum(e.count for e in prof.key_averages() if "DeviceType.CUDA" in str(getattr(e, "device_type", "")))
+        return y, n
+    try:
+        y_mod, n_mod = run(False)
+        y_fused, n_fused = run(True)
+    finally:
+        M.QF_FUSED = True
+    rel = ((y_fused - y_mod).norm() / y_mod.norm()).item()
+    assert torch.isfinite(y_fused).all() and rel <= 1e-5, rel
+    assert n_fused <= 0.72 * n_mod, (n_fused, n_mod)
+    y2 = None
+    with torch.no_grad():
+        y2 = model(x)
+    assert torch.equal(y2, y_fused)                                    # deterministic

@@ -1863,3 +1863,98 @@ def test_gemm_out_gen_equals_pack_then_gemm(ops, bits, M, N, K):
     # the packed codes are the oracle's: round-half-even of x / scale + zp, clamped, minus the zero point
     _, q = O.uniform_fake_quant(x[0], scale, zp, bits)
     assert torch.equal(xp[0, 0, :, :K].cpu().float(), q - zp)
+
+
+# ------------------------------------------------------------------------------------------------ quant_forward prologues (round 6)
+def _adalog_pack_params(bits, q=23.0):
+    L = 2 ** (bits - 1)
+    mant = torch.tensor([float(round(2 ** (-j / 37) * (4 * L - 2))) for j in range(37)])
+    return mant.to(DEV), torch.tensor([q]).to(DEV)
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+@pytest.mark.parametrize("G,R,S", [(12, 197, 197), (5, 64, 49), (3, 256, 256), (2, 7, 130)])
+def test_softmax_adalog_pack_equals_softmax_then_pack(ops, bits, G, R, S):
+    """(scores * scale).softmax(-1) -> post-softmax AdaLog quantiser -> bf16 operand in ONE launch (adalog_softmax_adalog_pack_bf16)
+    against torch's softmax followed by the packer: the kernel restates ATen's softmax arithmetic operation for operation, so the
+    packed operands must be equal bit for bit (a probability differing in its last bit could flip a code)."""
+    gen = g(9100 + bits + S)
+    x = (torch.randn(G, R, S, generator=gen) * 6).to(DEV)
+    x[0, 0] = 0.0                                                     # a uniform row
+    x[0, 1, :3] = torch.tensor([80.0, -80.0, 79.5])                   # saturating exponents
+    mant, qv = _adalog_pack_params(bits)
+    scale = torch.ones(1, device=DEV)
+    mul = 0.125
+    want = ops.pack_adalog((x * mul).softmax(dim=-1), scale, qv, 1, 0, 1, 0, bits, mant, shift=None, clamp_u=True)
+    got = ops.softmax_adalog_pack(x, mul, scale, qv, bits, mant)
+    assert got.shape == want.shape and got.dtype == torch.bfloat16
+    same = (got.view(torch.int16) == want.view(torch.int16)).float().mean().item()
+    assert same == 1.0, same
+    assert (got[..., S:] == 0).all()
+
+
+@pytest.mark.parametrize("bits", [3, 4, 6])
+def test_pack_adalog_with_the_gelu_prologue(ops, bits):
+    """fc2's operand packer reading fc1's output (pre_gelu): equal, bit for bit, to torch GELU followed by the packer."""
+    gen = g(9200 + bits)
+    x = (torch.randn(1, 1000, 1536, generator=gen) * 1.5).to(DEV)
+    x[0, 0, :8] = torch.tensor([0.0, -0.0, 1e-8, -1e-8, 12.0, -12.0, 3.0, -0.75])
+    mant, qv = _adalog_pack_params(bits, q=31.0)
+    scale = torch.tensor([2.1], device=DEV)
+    shift = torch.tensor([0.16997124254703522], device=DEV)
+    want = ops.pack_adalog(torch.nn.functional.gelu(x), scale, qv, 1, 0, 1, 0, bits, mant, shift=shift, clamp_u=True)
+    got = ops.pack_adalog(x, scale, qv, 1, 0, 1, 0, bits, mant, shift=shift, clamp_u=True, pre_gelu=True)
+    same = (got.view(torch.int16) == want.view(torch.int16)).float().mean().item()
+    assert same == 1.0, same
+
+
+@pytest.mark.parametrize("B,N,H,per_head", [(4, 197, 6, True), (2, 64, 3, True), (3, 130, 12, False), (1, 1, 2, True)])
+def test_attn_split_pack_equals_three_packs(ops, B, N, H, per_head):
+    """q / k / v of an attention block split, quantised and packed in one launch (adalog_attn_split_pack) against the permuted views
+    through adalog_pack_uniform: identical bytes, padding included."""
+    gen = g(9300 + N)
+    D = 64
+    qkv = (torch.randn(B, N, 3 * H * D, generator=gen) * 1.3).to(DEV)
+    n = H if per_head else 1
+    par = []
+    for bits in (4, 3, 6):
+        s_ = (torch.rand(n, generator=gen) * 0.2 + 0.05).to(DEV)
+        z_ = torch.randint(0, 2 ** bits, (n,), generator=gen).float().to(DEV)
+        par.append((s_, z_, bits))
+    qp, kp, vp = ops.attn_split_pack(qkv, H, par[0], par[1], par[2], per_head)
+    q, k, v = qkv.reshape(B, N, 3, H, D).permute(2, 0, 3, 1, 4).unbind(0)            # [B, H, N, D] views (wrap_net.py:20-22)
+    pg = 1 if per_head else 0
+    gm = H if per_head else 1
+    want_q = ops.pack_uniform(q.reshape(B * H, N, D), par[0][0], par[0][1], 1, 0, gm, pg, 0, par[0][2], ops.I8)
+    want_k = ops.pack_uniform(k.reshape(B * H, N, D), par[1][0], par[1][1], 1, 0, gm, pg, 0, par[1][2], ops.I8)
+    vt = v.transpose(-2, -1).reshape(B * H, D, N)
+    want_v = ops.pack_uniform(vt, par[2][0], par[2][1], 1, 0, gm, pg, 0, par[2][2], ops.BF16)
+    assert qp.shape == want_q.shape and torch.equal(qp, want_q)
+    assert torch.equal(kp, want_k)
+    # (values, not bit patterns: the general packer clamps q - z directly and keeps the sign of a -0.0 quotient; zero is zero to the MFMA)
+    assert vp.shape == want_v.shape and torch.equal(vp.float(), want_v.float())
+
+
+@pytest.mark.parametrize("dt", ["i8", "bf16"])
+def test_gemm_out_addend_and_heads_last(ops, dt):
+    """The epilogue extras of the quant_forward product (adalog_gemm_out_ex): the residual added in the epilogue equals out + addend
+    bit for bit; the heads-last store equals the permuted copy of the plain product."""
+    gen = g(9400)
+    B, H, M, N, K = 3, 6, 197, 64, 197
+    dto = ops.I8 if dt == "i8" else ops.BF16
+    tdt = torch.int8 if dt == "i8" else torch.bfloat16
+    Kp = CB.pad_k(K, CB.I8 if dt == "i8" else CB.BF16)
+    A = torch.zeros(1, B * H, M, Kp, dtype=tdt); Bm = torch.zeros(1, B * H, N, Kp, dtype=tdt)
+    A[..., :K] = torch.randint(-7, 8, (1, B * H, M, K), generator=gen).to(tdt)
+    Bm[..., :K] = torch.randint(-7, 8, (1, B * H, N, K), generator=gen).to(tdt)
+    sa = (torch.rand(H, generator=gen) * 0.1 + 0.01).to(DEV); sb = (torch.rand(H, generator=gen) * 0.1 + 0.01).to(DEV)
+    Ad, Bd = A.to(DEV), Bm.to(DEV)
+    plain = ops.gemm_out(dto, Ad, Bd, M, N, B * H, H, ops.Strided(sa, g=1), ops.Strided(sb, g=1), None)
+    hl = ops.gemm_out(dto, Ad, Bd, M, N, B * H, H, ops.Strided(sa, g=1), ops.Strided(sb, g=1), None, heads_last=H)
+    assert hl.shape == (B, M, H, N)
+    assert torch.equal(hl, plain.view(B, H, M, N).permute(0, 2, 1, 3).contiguous())
+    add = torch.randn(B * H, M, N, generator=gen).to(DEV)
+    bias = torch.randn(N, generator=gen).to(DEV)
+    base = ops.gemm_out(dto, Ad, Bd, M, N, B * H, H, ops.Strided(sa, g=1), ops.Strided(sb, g=1), ops.Strided(bias, n=1))
+    got = ops.gemm_out(dto, Ad, Bd, M, N, B * H, H, ops.Strided(sa, g=1), ops.Strided(sb, g=1), ops.Strided(bias, n=1), addend=add)
+    assert torch.equal(got, base + add)

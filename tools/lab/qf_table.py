@@ -7,8 +7,12 @@ dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows
 mark = [i for i, n in enumerate(names) if "triu_tril" in n]      # qf_prof.py launches it right before the measured passes
 lo = mark[-1] + 1 if mark else 0
 agg, tot = collections.OrderedDict(), 0.0
-for n, d in zip(names[lo:], dur[lo:]):
+BY_GRID = len(sys.argv) > 3
+grids = [r.get("Grid_Size", r.get("Grid_Size_X", "?")) for r in rows]
+for i, (n, d) in enumerate(zip(names[lo:], dur[lo:])):
     k = n.replace("(anonymous namespace)::", "").replace("at::native::", "").split("(")[0][:100]
+    if BY_GRID and "k_gemm_cand" in k:
+        k += f" grid={grids[lo + i]}"
     a = agg.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += d; tot += d
 print("markers", len(mark), "GPU us per forward", round(tot / N, 1))
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
