@@ -634,6 +634,7 @@ struct SoftmaxPackArgs {
     const float* scale; const float* qv; const float* mant; int levels2;   // the AdaLog quantiser: device scalars (scale, q), 37 numerators
     unsigned short* out; int64_t Kp;                     // bf16 bits [rows][Kp], zero beyond S
 };
+constexpr int SM_ROWS = 4;
 __global__ __launch_bounds__(256) void k_softmax_adalog_pack(SoftmaxPackArgs a) {
     __shared__ unsigned short s_lut[258];
     const int lw = a.levels2 + 2;
@@ -646,40 +647,51 @@ __global__ __launch_bounds__(256) void k_softmax_adalog_pack(SoftmaxPackArgs a) 
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
-    const float* xr = a.x + row * a.S;
-    float el[4];
-    float mx = -__builtin_inff();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int k = lane + 64 * it;
-        el[it] = k < a.S ? xr[k] * a.mul : -__builtin_inff();
-    }
-    mx = el[0];
-#pragma unroll
-    for (int it = 1; it < 4; ++it) mx = mx < el[it] ? el[it] : mx;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const float b = __shfl_xor(mx, o); mx = mx < b ? b : mx; }
-    float sum = 0.0f;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) { el[it] = expf(el[it] - mx); sum += el[it]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum = sum + __shfl_xor(sum, o);
     const float inv_s = __builtin_amdgcn_rcpf(sc), rq37 = 37.0f / qf;
-    unsigned short* orow = a.out + row * a.Kp;
+    // a wavefront takes SM_ROWS consecutive rows (the table above is built once per 4 SM_ROWS rows); their loads are issued together
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * SM_ROWS;
+    float raw[SM_ROWS][4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int k = lane + 64 * it;
-        if (k >= a.Kp) break;
-        unsigned short hv = 0;
-        if (k < a.S) {
-            const float pr = el[it] / sum;
-            float kk = adalog_k_fast(pr, sc, inv_s, qf, rq37, true);
-            kk = (kk == kk) ? fminf(fmaxf(kk, 0.0f), (float)(a.levels2 + 1)) : (float)(a.levels2 + 1);
-            hv = s_lut[(int)kk];
+    for (int rr = 0; rr < SM_ROWS; ++rr) {
+        const bool rv = row0 + rr < a.rows;
+        const float* xr = a.x + (rv ? row0 + rr : 0) * a.S;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int k = lane + 64 * it;
+            raw[rr][it] = (rv && k < a.S) ? xr[k] : 0.0f;
         }
-        orow[k] = hv;
+    }
+#pragma unroll
+    for (int rr = 0; rr < SM_ROWS; ++rr) {
+        const int64_t row = row0 + rr;
+        if (row >= a.rows) return;
+        float el[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) el[it] = lane + 64 * it < a.S ? raw[rr][it] * a.mul : -__builtin_inff();
+        float mx = el[0];
+#pragma unroll
+        for (int it = 1; it < 4; ++it) mx = mx < el[it] ? el[it] : mx;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const float b = __shfl_xor(mx, o); mx = mx < b ? b : mx; }
+        float sum = 0.0f;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { el[it] = expf(el[it] - mx); sum += el[it]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum = sum + __shfl_xor(sum, o);
+        unsigned short* orow = a.out + row * a.Kp;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int k = lane + 64 * it;
+            if (k >= a.Kp) break;
+            unsigned short hv = 0;
+            if (k < a.S) {
+                const float pr = el[it] / sum;
+                float kk = adalog_k_fast(pr, sc, inv_s, qf, rq37, true);
+                kk = (kk == kk) ? fminf(fmaxf(kk, 0.0f), (float)(a.levels2 + 1)) : (float)(a.levels2 + 1);
+                hv = s_lut[(int)kk];
+            }
+            orow[k] = hv;
+        }
     }
 }
 
@@ -976,7 +988,7 @@ extern "C" int adalog_softmax_adalog_pack_bf16(const float* x, int64_t rows, int
     ADALOG_ARG_CHECK(n_bits >= 2 && n_bits <= 7, "softmax_adalog_pack: n_bits must be in [2,7]");
     SoftmaxPackArgs a{x, rows, S, mul, scale, qv, mant37, 1 << n_bits, reinterpret_cast<unsigned short*>(out), Kp};
     adalog_note_kernel("k_softmax_adalog_pack");
-    hipLaunchKernelGGL(k_softmax_adalog_pack, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_softmax_adalog_pack, dim3((unsigned)((rows + 4 * SM_ROWS - 1) / (4 * SM_ROWS))), dim3(256), 0, (hipStream_t)stream, a);
     ADALOG_LAUNCH_CHECK("adalog_softmax_adalog_pack_bf16");
     return 0;
 }
