@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
                                                     const float* __restrict__ scale, const int64_t* __restrict__ q,
                                                     int levels2, const float* __restrict__ shift, int sub_shift,
                                                     float* __restrict__ part_s, unsigned int* counter,
-                                                    float* __restrict__ gscale) {
+                                                    float* __restrict__ gscale, int pre) {
     __shared__ float sm[4];
     __shared__ double smd[4];
     const float s = scale[0], qf = (float)q[0];
@@ -180,6 +180,14 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
     // k is the forward's bin (same exact-with-fallback evaluation); the gradient factors use reciprocals: they are smooth
     // in their inputs, so a last-ulp difference from the IEEE quotients moves the gradient by ~1e-7 relative.
     auto one = [&](float xv, float g, float& gxo) {
+        // pre: the quantiser saw GELU(xv); d GELU / dx = cdf + x * pdf as ATen's GeluBackward evaluates it
+        float dg = 1.0f;
+        if (pre) {
+            const float cdf = 0.5f * (1.0f + erff(xv * 0.70710678118654752440f));
+            const float pdf = expf(-0.5f * xv * xv) * 0.39894228040143267794f;
+            dg = cdf + xv * pdf;
+            xv = (xv * 0.5f) * (1.0f + erff(xv * 0.70710678118654752440f));
+        }
         const float xs = shift ? xv + sh : xv;
         const float ur = xs / s;
         const bool iu = (ur >= 1e-15f) && (ur <= 1.0f);
@@ -189,7 +197,7 @@ __global__ __launch_bounds__(256) void k_adalog_bwd(const float* __restrict__ gy
         // y before the "- shift", recomputed from k (adding the shift back to the stored output would cancel small y)
         const float yv = (k <= kmax) ? __builtin_amdgcn_exp2f(-fminf(fmaxf(k, 0.0f), kmax) * q37) * s : 0.0f;
         const float dydx = (iu && ik) ? yv * __builtin_amdgcn_rcpf(u * s) : 0.0f;
-        gxo = g * dydx;
+        gxo = g * dydx * dg;
         as += g * inv_s * (yv - dydx * xs);
     };
     // four elements per thread and turn (16-byte loads; x, gy, gx come from the allocator: 16-byte aligned)
@@ -360,8 +368,8 @@ __global__ __launch_bounds__(256) void k_round_loss_multi(RoundLossMulti a, floa
 // One Adam step (torch.optim.Adam defaults: no weight decay, no amsgrad) for up to ADAM_MAX tensors in ONE launch.  The
 // reference's two optimisers (utils/block_recon.py:108-109) step ~10 tensors per iteration; torch's fused multi-tensor kernel
 // gives a 65 536-element chunk to a block, i.e. ~40 blocks for a block's 2.4 M trained values (52 us); here every block takes
-// 1024 elements.  step_dev holds the number of steps taken so far (the kernel uses step_dev[0] + 1; k_adam_count advances it
-// afterwards, so a captured HIP graph keeps counting); lr_dev (optional) overrides lr: the cosine schedule writes it on the host.
+// 1024 elements.  step_dev holds the number of steps taken so far (the kernel uses step_dev[0] + 1 and its last workgroup to
+// arrive stores that back, so a captured HIP graph keeps counting); lr_dev (optional) overrides lr: the cosine schedule writes it on the host.
 constexpr int ADAM_MAX = 16;
 struct AdamMulti {
     float* param[ADAM_MAX];
@@ -374,7 +382,7 @@ struct AdamMulti {
 };
 
 __global__ __launch_bounds__(256) void k_adam_multi(AdamMulti a, float lr, const float* __restrict__ lr_dev, float beta1, float beta2,
-                                                    float eps, const float* __restrict__ step_dev) {
+                                                    float eps, float* step_dev, unsigned int* ticket) {
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
     if (lr_dev) lr = lr_dev[0];
@@ -399,8 +407,10 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamMulti a, float lr, const
             pp[i] = pp[i] - step_size * (m_ / denom);                         // param.addcdiv_(exp_avg, denom, value=-step_size)
         }
     }
+    // the step counter advances in this launch: every workgroup has read it by the time the last one arrives (round 6; a one-thread
+    // k_adam_count launch per optimiser and iteration before)
+    if (last_block_arrives(ticket, gridDim.x) && threadIdx.x == 0) step_dev[0] = step;
 }
-__global__ void k_adam_count(float* step_dev) { step_dev[0] += 1.0f; }
 
 // The whole update of AdaRound's alpha in one launch (a captured BRECQ iteration, one GPU): the gradient through the soft-rounded
 // weights (k_adaround's backward form, from dL/dw_sim), the gradient of the rounding regulariser (k_round_loss_multi's, times its
@@ -423,9 +433,10 @@ struct AlphaStepMulti {
 };
 
 __global__ __launch_bounds__(256) void k_alpha_step_multi(AlphaStepMulti a, float lr, const float* __restrict__ lr_dev, float beta1,
-                                                          float beta2, float eps, const float* __restrict__ step_dev, float b,
+                                                          float beta2, float eps, float* step_dev, float b,
                                                           const float* __restrict__ b_dev, float weight,
-                                                          const float* __restrict__ gmul, const float* __restrict__ gate, int epb) {
+                                                          const float* __restrict__ gmul, const float* __restrict__ gate, int epb,
+                                                          unsigned int* ticket) {
     int t = 0;
     while (t + 1 < a.count && (int)blockIdx.x >= a.first_block[t + 1]) ++t;
     if (lr_dev) lr = lr_dev[0];
@@ -473,6 +484,7 @@ __global__ __launch_bounds__(256) void k_alpha_step_multi(AlphaStepMulti a, floa
             al[i] = av - step_size * (m_ / denom);
         }
     }
+    if (last_block_arrives(ticket, gridDim.x) && threadIdx.x == 0) step_dev[0] = step;     // (as in k_adam_multi)
 }
 
 // reconstruction loss  scale * sum_i (pred_i - tgt_i)^2  (block_recon.py:186-199 with p = 2) and its gradient
@@ -1006,9 +1018,18 @@ extern "C" int adalog_uniform_fq_backward(const float* gy, const float* x, float
 }
 
 // gscale: [1] optional; workspace: 1024 floats
+extern "C" int adalog_log_fq_backward_pre(const float* gy, const float* x, const float* y, float* gx, int64_t n,
+                                          const float* scale, const int64_t* q, int n_bits, const float* shift, int sub_shift,
+                                          float* gscale, float* workspace, int pre, void* stream);
 extern "C" int adalog_log_fq_backward(const float* gy, const float* x, const float* y, float* gx, int64_t n,
                                       const float* scale, const int64_t* q, int n_bits, const float* shift, int sub_shift,
                                       float* gscale, float* workspace, void* stream) {
+    return adalog_log_fq_backward_pre(gy, x, y, gx, n, scale, q, n_bits, shift, sub_shift, gscale, workspace, 0, stream);
+}
+// pre = 1: backward of adalog_log_fake_quant_f32_pre -- x is the GELU's INPUT; gx = dL/dx through the quantiser (STE) and the GELU
+extern "C" int adalog_log_fq_backward_pre(const float* gy, const float* x, const float* y, float* gx, int64_t n,
+                                          const float* scale, const int64_t* q, int n_bits, const float* shift, int sub_shift,
+                                          float* gscale, float* workspace, int pre, void* stream) {
     if (n == 0) return 0;
     ADALOG_ARG_CHECK(gy && x && y && scale && q, "log_fq_backward: bad arguments");
     ADALOG_ARG_CHECK(!gscale || workspace, "log_fq_backward: the scale gradient needs a workspace");
@@ -1017,7 +1038,7 @@ extern "C" int adalog_log_fq_backward(const float* gy, const float* x, const flo
     unsigned int* ticket = gscale ? ticket_wide(stream) : nullptr;
     ADALOG_ARG_CHECK(!gscale || ticket, "log_fq_backward: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_adalog_bwd, dim3(nb), dim3(256), 0, st, gy, x, y, gx, n, scale, q, 1 << n_bits, shift, sub_shift,
-                       gscale ? workspace : nullptr, ticket, gscale);
+                       gscale ? workspace : nullptr, ticket, gscale, pre ? 1 : 0);
     ADALOG_LAUNCH_CHECK("adalog_log_fq_backward");
     return 0;
 }
@@ -1145,9 +1166,10 @@ extern "C" int adalog_alpha_step_multi(float* const* alphas, const float* const*
     a.first_block[count] = blocks;
     a.count = count;
     hipStream_t st = (hipStream_t)stream;
+    unsigned int* ticket = ticket_wide(stream);
+    ADALOG_ARG_CHECK(ticket, "alpha_step_multi: cannot allocate the ticket counters");
     hipLaunchKernelGGL(k_alpha_step_multi, dim3(blocks), dim3(256), 0, st, a, lr, lr_dev, beta1, beta2, eps, step_dev, b, b_dev, weight,
-                       gmul, gate, epb);
-    hipLaunchKernelGGL(k_adam_count, dim3(1), dim3(1), 0, st, step_dev);
+                       gmul, gate, epb, ticket);
     ADALOG_LAUNCH_CHECK("adalog_alpha_step_multi");
     return 0;
 }
@@ -1170,8 +1192,9 @@ extern "C" int adalog_adam_multi(float* const* params, const float* const* grads
     a.first_block[count] = blocks;
     a.count = count;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, st, a, lr, lr_dev, beta1, beta2, eps, step_dev);
-    hipLaunchKernelGGL(k_adam_count, dim3(1), dim3(1), 0, st, step_dev);
+    unsigned int* ticket = ticket_wide(stream);
+    ADALOG_ARG_CHECK(ticket, "adam_multi: cannot allocate the ticket counters");
+    hipLaunchKernelGGL(k_adam_multi, dim3(blocks), dim3(256), 0, st, a, lr, lr_dev, beta1, beta2, eps, step_dev, ticket);
     ADALOG_LAUNCH_CHECK("adalog_adam_multi");
     return 0;
 }

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_adalog(const float* __restrict__ x, flo
                                                 const float* __restrict__ scale, const int64_t* __restrict__ q,
                                                 const float* __restrict__ t1, const float* __restrict__ t2,
                                                 int levels2, const float* __restrict__ shift, int sub_shift,
-                                                int train_form) {
+                                                int train_form, int pre) {
     __shared__ float lut[256];
     const float s = scale[0];
     const float qf = (float)q[0];
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_adalog(const float* __restrict__ x, flo
     // adalog_k(clamp(xs / s), q)): the two IEEE divisions per element kept this kernel at 0.45 of the HBM rate (round 5)
     const float inv_s = 1.0f / s, rq37 = 37.0f / qf;
     auto one = [&](float v, float& out, uint8_t& b) {
+        if (pre) v = (v * 0.5f) * (1.0f + erff(v * 0.70710678118654752440f));   // GELU (ATen's fp32 expression): fc2 reads fc1's output
         float xs = shift ? v + sh : v;
         float k = adalog_k_fast(xs, s, inv_s, qf, rq37, true);
         bool keep = k < (float)levels2;
@@ -162,9 +163,19 @@ extern "C" int adalog_uniform_fake_quant_f32(const float* x, float* y, uint8_t* 
     return 0;
 }
 
+extern "C" int adalog_log_fake_quant_f32_pre(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale,
+                                             const int64_t* q, const float* table1, const float* table2, int n_bits,
+                                             const float* shift, int sub_shift, int train_form, int pre, void* stream);
 extern "C" int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale,
                                          const int64_t* q, const float* table1, const float* table2, int n_bits,
                                          const float* shift, int sub_shift, int train_form, void* stream) {
+    return adalog_log_fake_quant_f32_pre(x, y, bins, n, scale, q, table1, table2, n_bits, shift, sub_shift, train_form, 0, stream);
+}
+// pre = 1: the quantiser's input is GELU(x) (erf form), applied on the fly: a BRECQ iteration's fc2 input quantiser reads fc1's output
+// (the GELU pass and its stored result disappear; adalog_log_fq_backward_pre is the matching backward)
+extern "C" int adalog_log_fake_quant_f32_pre(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale,
+                                             const int64_t* q, const float* table1, const float* table2, int n_bits,
+                                             const float* shift, int sub_shift, int train_form, int pre, void* stream) {
     if (n == 0) return 0;
     ADALOG_ARG_CHECK(x && scale && q && n >= 0, "log_fake_quant: bad arguments");
     ADALOG_ARG_CHECK(train_form || (table1 && table2), "log_fake_quant: eval form needs table1/table2");
@@ -175,10 +186,10 @@ extern "C" int adalog_log_fake_quant_f32(const float* x, float* y, uint8_t* bins
     const bool vec = (n % 4 == 0) && aligned16(x) && (!y || aligned16(y)) && (!bins || ((uintptr_t)bins & 3) == 0);
     if (vec)
         hipLaunchKernelGGL(k_adalog<true>, dim3(grid_for(n / 4)), dim3(256), 0, st, x, y, bins, n, scale, q, table1,
-                           table2, levels2, shift, sub_shift, train_form);
+                           table2, levels2, shift, sub_shift, train_form, pre ? 1 : 0);
     else
         hipLaunchKernelGGL(k_adalog<false>, dim3(grid_for(n)), dim3(256), 0, st, x, y, bins, n, scale, q, table1, table2,
-                           levels2, shift, sub_shift, train_form);
+                           levels2, shift, sub_shift, train_form, pre ? 1 : 0);
     ADALOG_LAUNCH_CHECK("adalog_log_fake_quant_f32");
     return 0;
 }

@@ -104,24 +104,25 @@ def uniform_fake_quant(x, scale, zero_point, n_bits: int, sym: bool = False, wan
 
 
 def log_fake_quant(x, scale, q, table1, table2, n_bits: int, shift=None, sub_shift: bool = False,
-                   train_form: bool = False, want_bins: bool = False, want_y: bool = True):
+                   train_form: bool = False, want_bins: bool = False, want_y: bool = True, pre_gelu: bool = False):
+    """``pre_gelu``: the quantiser's input is GELU(x) (erf form), applied in the kernel (adalog_log_fake_quant_f32_pre)."""
     x = _f32c(x, "x")
     scale = _f32c(scale, "scale")
     if scale.numel() != 1:
         raise ValueError("AdaLog quantisers are per-tensor (scale must have one element)")
     if q.dtype != torch.int64 or not q.is_cuda:
         raise TypeError("q must be an int64 tensor on the device (the quantiser's buffer)")
-    if want_y and not want_bins and not train_form and _torch_ops.available():
+    if want_y and not want_bins and not train_form and not pre_gelu and _torch_ops.available():
         return _top("log_fake_quant", x, scale, q, _f32c(table1, "table1"), _f32c(table2, "table2"), int(n_bits),
                     None if shift is None else _f32c(shift, "shift"), bool(sub_shift))
     y = torch.empty_like(x) if want_y else None
     bins = torch.empty(x.shape, dtype=torch.uint8, device=x.device) if want_bins else None
     lib = _lib.load()
-    rc = lib.adalog_log_fake_quant_f32(_ptr(x), _ptr(y), _ptr(bins), x.numel(), _ptr(scale), _ptr(q),
-                                       _ptr(None if train_form else _f32c(table1, "table1")),
-                                       _ptr(None if train_form else _f32c(table2, "table2")), int(n_bits),
-                                       _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(sub_shift)),
-                                       int(bool(train_form)), _stream())
+    rc = lib.adalog_log_fake_quant_f32_pre(_ptr(x), _ptr(y), _ptr(bins), x.numel(), _ptr(scale), _ptr(q),
+                                           _ptr(None if train_form else _f32c(table1, "table1")),
+                                           _ptr(None if train_form else _f32c(table2, "table2")), int(n_bits),
+                                           _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(sub_shift)),
+                                           int(bool(train_form)), int(bool(pre_gelu)), _stream())
     _lib.check(rc, "adalog_log_fake_quant_f32")
     return (y, bins) if want_bins else y
 
@@ -1280,15 +1281,16 @@ def uniform_fake_quant_backward(gy, x, scale, zero_point, n_bits: int, sym: bool
     return gx, gs, gz
 
 
-def log_fake_quant_backward(gy, x, y, scale, q, n_bits: int, shift, sub_shift: bool):
+def log_fake_quant_backward(gy, x, y, scale, q, n_bits: int, shift, sub_shift: bool, pre_gelu: bool = False):
+    """``pre_gelu``: backward of log_fake_quant(pre_gelu=True) -- x is the GELU's input, gx includes the GELU's derivative."""
     gy, x, y, scale = _f32c(gy, "gy"), _f32c(x, "x"), _f32c(y, "y"), _f32c(scale, "scale")
     gx = torch.empty_like(x)
     gs = torch.empty_like(scale)
     ws = torch.empty(1024, dtype=torch.float32, device=x.device)
-    rc = _lib.load().adalog_log_fq_backward(gy.data_ptr(), x.data_ptr(), y.data_ptr(), gx.data_ptr(), x.numel(),
-                                           scale.data_ptr(), q.data_ptr(), int(n_bits),
-                                           _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(sub_shift)),
-                                           gs.data_ptr(), ws.data_ptr(), _stream())
+    rc = _lib.load().adalog_log_fq_backward_pre(gy.data_ptr(), x.data_ptr(), y.data_ptr(), gx.data_ptr(), x.numel(),
+                                               scale.data_ptr(), q.data_ptr(), int(n_bits),
+                                               _ptr(None if shift is None else _f32c(shift, "shift")), int(bool(sub_shift)),
+                                               gs.data_ptr(), ws.data_ptr(), int(bool(pre_gelu)), _stream())
     _lib.check(rc, "adalog_log_fq_backward")
     return gx, gs
 

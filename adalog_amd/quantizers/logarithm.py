@@ -21,19 +21,23 @@ class _AdaLogSTE(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, scale, q, n_bits, shift, sub_shift):
+    def forward(ctx, x, scale, q, n_bits, shift, sub_shift, pre_gelu=False):
+        """``pre_gelu``: the quantiser's input is GELU(x) -- x is fc1's output; the activation function and its derivative run inside
+        the two kernels (no GELU pass, no stored GELU output: utils/models.py Mlp.forward inside a BRECQ iteration)."""
         be = backend.get()
-        y = be.log_fake_quant(x, scale, q, None, None, n_bits, shift=shift, sub_shift=sub_shift, train_form=True)
+        kw = {"pre_gelu": True} if pre_gelu else {}
+        y = be.log_fake_quant(x, scale, q, None, None, n_bits, shift=shift, sub_shift=sub_shift, train_form=True, **kw)
         ctx.save_for_backward(x, scale, q, shift, y)
-        ctx.n_bits, ctx.sub_shift = n_bits, sub_shift
+        ctx.n_bits, ctx.sub_shift, ctx.pre_gelu = n_bits, sub_shift, bool(pre_gelu)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, scale, q, shift, y = ctx.saved_tensors
         be = backend.get()
-        gx, gs = be.log_fake_quant_backward(gy, x, y, scale, q, ctx.n_bits, shift, ctx.sub_shift)
-        return gx, gs, None, None, None, None
+        kw = {"pre_gelu": True} if ctx.pre_gelu else {}
+        gx, gs = be.log_fake_quant_backward(gy, x, y, scale, q, ctx.n_bits, shift, ctx.sub_shift, **kw)
+        return gx, gs, None, None, None, None, None
 
 
 class AdaLogQuantizer(nn.Module):
@@ -76,16 +80,25 @@ class AdaLogQuantizer(nn.Module):
     def _shift_args(self):
         return None, False
 
-    def forward(self, x):
+    def forward(self, x, pre_gelu=False):
+        """``pre_gelu`` (training form on the GPU only; callers ask ``fused_gelu_ok`` first): quantise GELU(x)."""
         if self.n_bits == 32:
-            return x
+            return torch.nn.functional.gelu(x) if pre_gelu else x
         assert self.inited
         shift, sub = self._shift_args()
         if self.training_mode and torch.is_grad_enabled():
-            return _AdaLogSTE.apply(x, self.scale, self.q, self.n_bits, shift, sub)
+            if pre_gelu and not self.fused_gelu_ok(x):
+                x, pre_gelu = torch.nn.functional.gelu(x), False
+            return _AdaLogSTE.apply(x, self.scale, self.q, self.n_bits, shift, sub, pre_gelu)
+        if pre_gelu:
+            x = torch.nn.functional.gelu(x)
         return backend.get().log_fake_quant(x, self.scale.data, self.q, self.table1, self.table2, self.n_bits,
                                             shift=None if shift is None else shift.data, sub_shift=sub,
                                             train_form=self.training_mode)
+
+    def fused_gelu_ok(self, x):
+        be = backend.get()
+        return bool(x.is_cuda and x.dtype == torch.float32 and hasattr(be, "softmax_adalog_pack") and self.n_bits != 32)
 
     def bins(self, x):
         """Integer bin index k (uint8; 255 marks the masked 'below the last bin' code)."""

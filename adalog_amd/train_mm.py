@@ -162,9 +162,12 @@ def linear(x_sim, w_sim, bias):
     return _LinearFn.apply(x2.contiguous(), w_sim.contiguous(), bias).view(*lead, w_sim.shape[0])
 
 
-def quant_linear(x, a_quantizer, w_sim, bias):
-    """F.linear(a_quantizer(x), w_sim, bias) for a BRECQ iteration; fuses a per-tensor asymmetric uniform activation quantiser."""
+def quant_linear(x, a_quantizer, w_sim, bias, pre_gelu=False):
+    """F.linear(a_quantizer(x), w_sim, bias) for a BRECQ iteration; fuses a per-tensor asymmetric uniform activation quantiser.
+    ``pre_gelu``: the quantiser's input is GELU(x), applied by the quantiser itself (AdaLogQuantizer.forward)."""
     from .quantizers.uniform import UniformQuantizer
+    if pre_gelu:
+        return linear(a_quantizer(x, pre_gelu=True), w_sim, bias)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     aq = a_quantizer

@@ -62,6 +62,13 @@ class Mlp(nn.Module):
                 and all(isinstance(m, nn.Identity) for m in (self.drop1, self.norm, self.drop2))):
             # quant_forward: GELU runs in the loader of fc2's operand packer, the residual is added in fc2's epilogue
             return fc2.quant_forward(self.fc1(x), addend=residual, pre_gelu=True)
+        if (QF_FUSED and train_mm.ENABLED and torch.is_grad_enabled() and x.is_cuda and _plain_quant_forward(fc2)
+                and getattr(getattr(fc2, "a_quantizer", None), "training_mode", False) and hasattr(fc2.a_quantizer, "fused_gelu_ok")
+                and isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none"
+                and all(isinstance(m, nn.Identity) for m in (self.drop1, self.norm, self.drop2))):
+            # a BRECQ iteration: GELU and its derivative run inside the kernels of fc2's input quantiser (no GELU pass either way)
+            out = fc2.quant_forward(self.fc1(x), pre_gelu=True)
+            return out if residual is None else residual + out
         out = self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
         return out if residual is None else residual + out
 

@@ -416,6 +416,14 @@ int adalog_pack_adalog_bf16_pre(const float* x, int64_t G, int64_t R, int64_t K,
                                 const float* scale, const float* qv, int64_t C, int64_t pc, int64_t gmod, int64_t pg,
                                 int n_bits, const float* mant37, const float* shift, int clamp_u, void* out, int64_t Kp,
                                 int c_inner, int pre, void* stream);
+/* the same prologue in the training-form quantiser of a BRECQ iteration (block_recon.py:116-121 through fc2's input quantiser,
+ * logarithm.py:88-92): y = q(GELU(x)) and its backward (x = the GELU's input; gx through the STE and the GELU's derivative) */
+int adalog_log_fake_quant_f32_pre(const float* x, float* y, uint8_t* bins, int64_t n, const float* scale, const int64_t* q,
+                                  const float* table1, const float* table2, int n_bits, const float* shift, int sub_shift,
+                                  int train_form, int pre, void* stream);
+int adalog_log_fq_backward_pre(const float* gy, const float* x, const float* y, float* gx, int64_t n, const float* scale,
+                               const int64_t* q, int n_bits, const float* shift, int sub_shift, float* gscale, float* workspace,
+                               int pre, void* stream);
 int adalog_softmax_adalog_pack_bf16(const float* x, int64_t rows, int S, float mul, const float* scale, const float* qv, int n_bits,
                                     const float* mant37, void* out, int64_t Kp, void* stream);
 int adalog_attn_split_pack(const float* qkv, int B, int N, int H, const float* q_scale, const float* q_zp, int q_bits,

@@ -1958,3 +1958,49 @@ def test_gemm_out_addend_and_heads_last(ops, dt):
     base = ops.gemm_out(dto, Ad, Bd, M, N, B * H, H, ops.Strided(sa, g=1), ops.Strided(sb, g=1), ops.Strided(bias, n=1))
     got = ops.gemm_out(dto, Ad, Bd, M, N, B * H, H, ops.Strided(sa, g=1), ops.Strided(sb, g=1), ops.Strided(bias, n=1), addend=add)
     assert torch.equal(got, base + add)
+
+
+@pytest.mark.parametrize("q", [23, 61])
+def test_adalog_training_form_with_the_gelu_prologue(ops, q):
+    """fc2's input quantiser inside a BRECQ iteration reading fc1's output (pre_gelu): the forward equals the quantiser applied to
+    torch's GELU bit for bit; the backward equals autograd's route (STE quantiser backward, then GeluBackward) -- dL/dx to fp32
+    rounding of one product, the scale gradient unchanged."""
+    gen = g(9500 + q)
+    bits = 4
+    x = (1.7 * torch.randn(6, 197, 256, generator=gen)).to(DEV)
+    x[0, 0, :6] = torch.tensor([0.0, -0.0, 9.0, -9.0, 1e-6, -3.0])
+    s = torch.tensor([2.3], device=DEV); sh = torch.tensor([O.GELU_SHIFT], device=DEV); qd = torch.tensor([q], device=DEV)
+    gy = torch.randn(x.shape, generator=gen).to(DEV)
+    for sub in (True, False):
+        xg = x.clone().requires_grad_(True)
+        gel = torch.nn.functional.gelu(xg)
+        y_ref = ops.log_fake_quant(gel.detach(), s, qd, None, None, bits, shift=sh, sub_shift=sub, train_form=True)
+        y = ops.log_fake_quant(x, s, qd, None, None, bits, shift=sh, sub_shift=sub, train_form=True, pre_gelu=True)
+        assert torch.equal(y, y_ref)
+        g_gel, gs_ref = ops.log_fake_quant_backward(gy, gel.detach(), y_ref, s, qd, bits, sh, sub)
+        gel.backward(g_gel)
+        gx, gs = ops.log_fake_quant_backward(gy, x, y, s, qd, bits, sh, sub, pre_gelu=True)
+        # (where the GELU's derivative cdf + x * pdf cancels -- x around -0.75 -- its last bits depend on the order of two roundings)
+        torch.testing.assert_close(gx, xg.grad, rtol=1e-4, atol=1e-7)
+        torch.testing.assert_close(gs, gs_ref, rtol=1e-6, atol=1e-7)
+
+
+def test_adam_multi_matches_torch_adam_and_counts_its_steps(ops):
+    """adalog_adam_multi over several tensors for several steps against torch.optim.Adam (defaults), and the device step counter it
+    advances itself (the last workgroup to arrive stores step + 1: no separate counting launch)."""
+    gen = g(9600)
+    shapes = [(3,), (1000,), (384, 384), (5000,)]
+    ps = [torch.randn(*s_, generator=gen).to(DEV) for s_ in shapes]
+    ref = [p_.clone().requires_grad_(True) for p_ in ps]
+    opt = torch.optim.Adam(ref, lr=1e-3)
+    m = [torch.zeros_like(p_) for p_ in ps]; v = [torch.zeros_like(p_) for p_ in ps]
+    step = torch.zeros(1, device=DEV)
+    for it in range(5):
+        gs = [torch.randn(*s_, generator=gen).to(DEV) for s_ in shapes]
+        for r_, g_ in zip(ref, gs):
+            r_.grad = g_.clone()
+        opt.step()
+        ops.adam_multi(ps, gs, m, v, step, 1e-3, 0.9, 0.999, 1e-8)
+        assert step.item() == it + 1
+    for p_, r_ in zip(ps, ref):
+        torch.testing.assert_close(p_, r_.detach(), rtol=2e-6, atol=1e-7)

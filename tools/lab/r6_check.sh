@@ -1,9 +1,5 @@
-# round-6 lab: softmax pack kernel after the rows-per-wave change
-cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-mkdir -p gpurun_out/r6m gpurun_out/r6n
-python -m pytest tests/test_gpu_kernels.py -x -q -k "softmax_adalog" > gpurun_out/r6n/pytest1.log 2>&1; tail -3 gpurun_out/r6n/pytest1.log
-rm -rf gpurun_out/r6m/qf
-QF_REPS=20 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r6m/qf -o p -- python3 tools/lab/qf_prof.py > gpurun_out/r6m/qf.log 2>&1
-f=$(ls gpurun_out/r6m/qf/*/p_kernel_trace.csv gpurun_out/r6m/qf/p_kernel_trace.csv 2>/dev/null | head -1)
-python tools/lab/qf_table.py $f 20 | tee gpurun_out/r6m/qf_table_fused.txt
-rm -f $f
+# round-6 lab: BRECQ with GELU inside the fc2 input quantiser's kernels and the step counter folded into the Adam kernels
+mkdir -p gpurun_out/r6o
+python -m pytest tests/test_gpu_kernels.py -x -q -k "adalog or adam or brecq or gelu" > gpurun_out/r6o/pytest1.log 2>&1; tail -3 gpurun_out/r6o/pytest1.log
+python -m pytest tests/test_gpu_layers.py -x -q > gpurun_out/r6o/pytest2.log 2>&1; tail -3 gpurun_out/r6o/pytest2.log
+for m in deit_small vit_base; do for v in 1 0 1 0; do echo "QF_FUSED=$v $m"; ADALOG_QF_FUSED=$v python tools/bench_brecq.py --model $m --iters 600 2>&1 | grep -v amdgpu.ids | tail -1; done; done
