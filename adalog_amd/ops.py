@@ -569,6 +569,12 @@ def gemm_out_gen(x3, a_scale, a_zp, n_bits: int, B, N: int, gmod: int, sa: Strid
     return out
 
 
+# Capability flag read by the layers (getattr(backend.get(), "QF_EXTRAS", False)): this backend has the quant_forward extras of round 6
+# -- epilogue addend / heads-last store (gemm_out, gemm_out_gen), the GELU prologue of the AdaLog packer and of the training-form
+# quantiser, softmax_adalog_pack, attn_split_pack.  The CPU specification backend of the tests does not: the layers then compose.
+QF_EXTRAS = True
+
+
 def softmax_adalog_pack(x3, mul: float, scale, qv, n_bits: int, mant37):
     """(x3 * mul).softmax(-1) through the post-softmax AdaLog quantiser, as the packed bf16 operand [1, G, R, Kp] of softmax . v
     (adalog_softmax_adalog_pack_bf16: one pass, the probabilities are never stored).  x3: fp32 [G, R, S] contiguous, S <= 256."""

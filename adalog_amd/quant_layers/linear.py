@@ -515,7 +515,7 @@ class AsymmetricallyBatchingQuantLinear(PTQSLBatchingQuantLinear):
         wp = self._pack_w_cached()
         sa_, sb_ = Strided(aq.scale.data.view(-1)), Strided(self.w_quantizer.scale.data.view(-1), n=1)
         bias_ = None if self.bias is None else Strided(self.bias.data, n=1)
-        fused_add = addend is not None and hasattr(be, "softmax_adalog_pack") and addend.shape == lead + (self.out_features,)
+        fused_add = addend is not None and getattr(be, "QF_EXTRAS", False) and addend.shape == lead + (self.out_features,)
         add_ = addend.reshape(1, -1, self.out_features) if fused_add else None
         if aq.scale.numel() == 1 and hasattr(be, "gemm_out_gen") and be.gemm_out_gen_ok(x3, wp.shape[-1], aq.n_bits):
             # ONE launch for the layer: the activation is quantised in the GEMM's loader (k_gemm_cand<GENA>), the weight image is cached
@@ -785,7 +785,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         """quant_forward takes the fused route (packer + bf16 MFMA product): the callers that hand over fc1's output with
         ``pre_gelu`` (utils/models.py: Mlp) ask first."""
         return (self.calibrated and isinstance(self.w_quantizer, UniformQuantizer) and not self.a_quantizer.training_mode
-                and not (torch.is_grad_enabled() and self.w_quantizer.training_mode) and hasattr(backend.get(), "softmax_adalog_pack"))
+                and not (torch.is_grad_enabled() and self.w_quantizer.training_mode) and getattr(backend.get(), "QF_EXTRAS", False))
 
     def quant_forward(self, x, addend=None, pre_gelu=False):
         """``pre_gelu``: x is fc1's output and the layer's input is GELU(x) -- applied in the packer's loader (one pass less over the
@@ -803,7 +803,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         if self._q_host is None:
             self._q_host = int(aq.q.item())
         qv = search.const_tensor([float(self._q_host)], dev)
-        if pre_gelu and not (hasattr(be, "softmax_adalog_pack") and x3.stride(-1) == 1):
+        if pre_gelu and not (getattr(be, "QF_EXTRAS", False) and x3.stride(-1) == 1):
             x3, pre_gelu = torch.nn.functional.gelu(x3), False
         xp = be.pack_adalog(x3, aq.scale.data.view(-1), qv, 1, 0, 1, 0, aq.n_bits, self._mant37(dev),
                             shift=aq.shift.data, clamp_u=True, **({"pre_gelu": True} if pre_gelu else {}))
@@ -815,7 +815,7 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         else:
             wp = self._pack_w_cached(BF16)
             bias = None if self.bias is None else self.bias.data
-        fused_add = addend is not None and hasattr(be, "softmax_adalog_pack") and addend.shape == lead + (self.out_features,)
+        fused_add = addend is not None and getattr(be, "QF_EXTRAS", False) and addend.shape == lead + (self.out_features,)
         out = be.gemm_out(BF16, xp, wp, x3.shape[1], self.out_features, 1, 1, Strided(aq.scale.data.view(-1)),
                           Strided(self.w_quantizer.scale.data.view(-1), n=1),
                           None if bias is None else Strided(bias, n=1), sa_mul=self._ts32(),

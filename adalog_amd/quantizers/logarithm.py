@@ -98,7 +98,7 @@ class AdaLogQuantizer(nn.Module):
 
     def fused_gelu_ok(self, x):
         be = backend.get()
-        return bool(x.is_cuda and x.dtype == torch.float32 and hasattr(be, "softmax_adalog_pack") and self.n_bits != 32)
+        return bool(x.is_cuda and x.dtype == torch.float32 and getattr(be, "QF_EXTRAS", False) and self.n_bits != 32)
 
     def bins(self, x):
         """Integer bin index k (uint8; 255 marks the masked 'below the last bin' code)."""

@@ -107,7 +107,7 @@ class Attention(nn.Module):
         qs = (m1.A_quantizer, m1.B_quantizer, m2.B_quantizer)
         return (all(isinstance(q, UniformQuantizer) and 2 <= q.n_bits <= 7 and not q.training_mode for q in qs)
                 and not m2.A_quantizer.training_mode and m1._heads() == m2._heads() and m2.A_quantizer.scale.numel() == 1
-                and hasattr(_backend.get(), "attn_split_pack"))
+                and getattr(_backend.get(), "QF_EXTRAS", False))
 
     def _fused_quant_forward(self, x, residual):
         """The attention block in quant_forward mode (reference utils/wrap_net.py:19-32 with every product in quant_forward,
