@@ -485,3 +485,93 @@ def test_fused_block_quant_forward_matches_the_module_route(bits):
     with torch.no_grad():
         y2 = model(x)
     assert torch.equal(y2, y_fused)                                    # deterministic
+
+
+def _minmax_params(t, bits, per=None):
+    """(scale, zero_point) of an asymmetric uniform quantiser from the tensor's range; per: dims to KEEP (None = per tensor)."""
+    if per is None:
+        mn, mx = t.min(), t.max()
+    else:
+        red = [d for d in range(t.dim()) if d not in per]
+        mn, mx = t.amin(dim=red, keepdim=True), t.amax(dim=red, keepdim=True)
+    s = (mx - mn).clamp_min(1e-6) / (2 ** bits - 1)
+    return s, torch.round(-mn / s).clamp(0, 2 ** bits - 1)
+
+
+def _arm(q, s, z=None):
+    q.scale.data.copy_(s.reshape(q.scale.shape))
+    if z is not None:
+        q.zero_point.data.copy_(z.reshape(q.zero_point.shape))
+    q.inited = True
+    q._zp_on_grid = True
+
+
+@pytest.mark.parametrize("bits", [4, 6])
+@pytest.mark.parametrize("cls", ["linear", "linear_channelwise", "postgelu", "postgelu_bias_reparamed", "matmul", "postsoftmax", "conv"])
+def test_quant_forward_matches_composed_at_full_shape(cls, bits):
+    """quant_forward of each of the six concrete layer classes at deit_small's shapes (32 images) on the product route (operand
+    generation / packs + integer or bf16 MFMA product with the dequantising epilogue) against the composed route of the base class
+    (fake-quantise both operands, then the fp32 product: reference linear.py:46-51, matmul.py:43-45, conv.py:60-65) -- the same
+    quantised operands, so the results agree to fp32 accumulation order (1e-5 of the output's range)."""
+    from adalog_amd import quant_layers as Q
+    g = torch.Generator().manual_seed(77 + bits)
+    N, T, D, H = 32, 197, 384, 6
+
+    def close(a, b):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert ((a - b).abs().max() / b.abs().max()).item() <= 1e-5, ((a - b).abs().max() / b.abs().max()).item()
+
+    with torch.no_grad():
+        if cls in ("linear", "linear_channelwise"):
+            C = Q.AsymmetricallyBatchingQuantLinear if cls == "linear" else Q.AsymmetricallyChannelWiseBatchingQuantLinear
+            lay = C(D, 3 * D, True, "quant_forward", bits, bits, n_V=3 if cls != "linear" else 1, fpcs=True).to(DEV)
+            x = torch.randn(N, T, D, generator=g).to(DEV) * (0.5 + torch.rand(D, generator=g).to(DEV))
+            ws, wz = _minmax_params(lay.weight.data.view(lay.n_V, lay.crb_rows, D), bits, per=(0, 1))
+            _arm(lay.w_quantizer, ws, wz)
+            a_s, a_z = _minmax_params(x, bits, per=(2,) if cls != "linear" else None)
+            _arm(lay.a_quantizer, a_s, a_z)
+            lay.calibrated = True
+            close(lay(x), Q.MinMaxQuantLinear.quant_forward(lay, x))
+        elif cls.startswith("postgelu"):
+            lay = Q.PostGeluLogBasedBatchingQuantLinear(4 * D, D, True, "quant_forward", bits, bits, n_V=1, quantizer="adalog", fpcs=True).to(DEV)
+            x = torch.nn.functional.gelu(2.0 * torch.randn(N, T, 4 * D, generator=g)).to(DEV)
+            ws, wz = _minmax_params(lay.weight.data.view(1, D, 4 * D), bits, per=(0, 1))
+            _arm(lay.w_quantizer, ws, wz)
+            aq = lay.a_quantizer
+            aq.shift.data.fill_(0.16997124254703522)
+            aq.scale.data.fill_((x.max().item() + 0.17) * 0.9)
+            aq.q.fill_(41)
+            aq.update_table(41)
+            aq.inited = True
+            lay._q_host = None                                   # (the layer's host mirror of q, as after load_state_dict)
+            lay.calibrated = True
+            if cls.endswith("reparamed"):
+                lay.reparam_bias()
+            close(lay(x), Q.MinMaxQuantLinear.quant_forward(lay, x))
+            h = (2.0 * torch.randn(N, T, 4 * D, generator=g)).to(DEV)              # fc1's output: GELU inside the packer
+            close(lay.quant_forward(h, pre_gelu=True), Q.MinMaxQuantLinear.quant_forward(lay, torch.nn.functional.gelu(h)))
+        elif cls in ("matmul", "postsoftmax"):
+            if cls == "matmul":
+                lay = Q.AsymmetricallyBatchingQuantMatMul(bits, bits, "quant_forward", head_channel_wise=True, num_heads=H, fpcs=True).to(DEV)
+                A = (torch.randn(N, H, T, 64, generator=g) * (0.5 + torch.rand(1, H, 1, 1, generator=g))).to(DEV)
+                B = (torch.randn(N, H, T, 64, generator=g) * (0.5 + torch.rand(1, H, 1, 1, generator=g))).to(DEV).transpose(-2, -1)
+                _arm(lay.A_quantizer, *_minmax_params(A, bits, per=(1,)))
+            else:
+                lay = Q.PostSoftmaxAsymmetricallyBatchingQuantMatMul(bits, bits, "quant_forward", head_channel_wise=True, num_heads=H,
+                                                                     fpcs=True, quantizer="adalog").to(DEV)
+                A = (torch.randn(N, H, T, T, generator=g) * 3).softmax(-1).to(DEV)
+                B = (torch.randn(N, H, T, 64, generator=g) * (0.5 + torch.rand(1, H, 1, 1, generator=g))).to(DEV)
+                lay.A_quantizer.q.fill_(29)
+                lay.A_quantizer.update_table(29)
+                lay._q_host = None
+            _arm(lay.B_quantizer, *_minmax_params(B, bits, per=(1,)))
+            lay.calibrated = True
+            close(lay(A, B), Q.MinMaxQuantMatMul.quant_forward(lay, A, B))
+        else:
+            lay = Q.AsymmetricallyBatchingQuantConv2d(3, D, 16, 16, mode="quant_forward", w_bit=bits, a_bit=8, fpcs=True).to(DEV)
+            x = torch.randn(N, 3, 224, 224, generator=g).to(DEV)
+            _arm(lay.w_quantizer, *_minmax_params(lay.weight.data.view(D, -1), bits, per=(0,)))
+            lay.a_quantizer.scale.data.fill_(x.abs().max().item() / 127)
+            lay.a_quantizer.inited = True
+            lay.calibrated = True
+            close(lay(x), Q.MinMaxQuantConv2d.quant_forward(lay, x))
