@@ -1860,6 +1860,9 @@ def test_gemm_out_gen_equals_pack_then_gemm(ops, bits, M, N, K):
     view = wide[:, 0].unsqueeze(0)
     assert not view.is_contiguous() and ops.gemm_out_gen_ok(view, Kp, bits)
     assert torch.equal(ops.gemm_out_gen(view, scale.to(DEV), zp.to(DEV), bits, wd, N, 1, sa_, sb_, bi_), want)
+    # the residual stream added in the epilogue (adalog_gemm_out_gen_ex): bit for bit the separate add
+    add = torch.randn(1, M, N, generator=gen).to(DEV)
+    assert torch.equal(ops.gemm_out_gen(xd, scale.to(DEV), zp.to(DEV), bits, wd, N, 1, sa_, sb_, bi_, addend=add), want + add)
     # the packed codes are the oracle's: round-half-even of x / scale + zp, clamped, minus the zero point
     _, q = O.uniform_fake_quant(x[0], scale, zp, bits)
     assert torch.equal(xp[0, 0, :, :K].cpu().float(), q - zp)

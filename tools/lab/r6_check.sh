@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r6q
-python -m pytest tests/test_gpu_e2e.py -x -q -k "full_shape" > gpurun_out/r6q/pytest1.log 2>&1; tail -25 gpurun_out/r6q/pytest1.log
+python -m pytest tests/test_gpu_kernels.py -x -q -k "gemm_out_gen" > gpurun_out/r6q/pytest1.log 2>&1; tail -3 gpurun_out/r6q/pytest1.log
