@@ -66,6 +66,7 @@ SIGNATURES = {
     "adalog_pack_adalog_bf16_pre": (i32, [p, i64, i64, i64, i64, i64, i64, p, p, i64, i64, i64, i64, i32, p, p, i32, p, i64, i32, i32, p]),
     "adalog_log_fake_quant_f32_pre": (i32, [p, p, p, i64, p, p, p, p, i32, p, i32, i32, i32, p]),
     "adalog_log_fq_backward_pre": (i32, [p, p, p, p, i64, p, p, i32, p, i32, p, p, i32, p]),
+    "adalog_brecq_prepare": (i32, [p, p, p, p, p, i64, i64, i64, p, p, i32, p]),
     "adalog_softmax_adalog_pack_bf16": (i32, [p, i64, i32, f32, p, p, i32, p, p, i64, p]),
     "adalog_attn_split_pack": (i32, [p, i32, i32, i32, p, p, i32, p, p, i32, p, p, i32, i32, p, p, p, i64, p]),
     "adalog_gemm_out_gen": (i32, [p, i64, i64, i32, p, p, i64, i32, p, i64, i32, i32, i64, i32, i32, p, i64, f32, p, i64, i64, p, i64, i64,

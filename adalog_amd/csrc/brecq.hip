@@ -521,6 +521,27 @@ __global__ __launch_bounds__(256) void k_rec_loss_bwd(const float* __restrict__ 
         gpred[i] = (pred[i] - tgt[i]) * f;
 }
 
+// What precedes a captured BRECQ iteration's replay (utils/block_recon.py:114-117: cur_inp, cur_out = block.raw_input[idx], raw_out[idx];
+// the iteration's b / gate / learning rate) as ONE launch: the mini-batch rows of the block's stored inputs and outputs gathered into
+// the graph's static tensors and the iteration's schedule row copied into its device scalars -- two index_select launches and a
+// device-to-device copy before.  rows of rin4 / rout4 float4 each; idx: int64 [bs].
+__global__ __launch_bounds__(256) void k_brecq_prepare(const float4* __restrict__ src_in, const float4* __restrict__ src_out,
+                                                       const int64_t* __restrict__ idx, float4* __restrict__ dst_in,
+                                                       float4* __restrict__ dst_out, int64_t bs, int64_t rin4, int64_t rout4,
+                                                       const float* __restrict__ sched_row, float* __restrict__ sched_dev, int n_sched) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_sched) sched_dev[threadIdx.x] = sched_row[threadIdx.x];
+    const int64_t n_in = bs * rin4, total = n_in + bs * rout4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n_in) {
+            const int64_t b = i / rin4, e = i - b * rin4;
+            dst_in[i] = src_in[idx[b] * rin4 + e];
+        } else {
+            const int64_t j = i - n_in, b = j / rout4, e = j - b * rout4;
+            dst_out[j] = src_out[idx[b] * rout4 + e];
+        }
+    }
+}
+
 // q - z of the per-tensor asymmetric quantiser, as fp32: the exact integer operand of the training-mode GEMM
 // (brecq_gemm.hip), whose epilogue multiplies by the trained scale -- (q - z) * s is the fake-quantised activation.
 __global__ __launch_bounds__(256) void k_uniform_int(const float* __restrict__ x, float* __restrict__ y, int64_t n,
@@ -1101,6 +1122,25 @@ extern "C" int adalog_rec_loss_backward(const float* pred, const float* tgt, int
     hipLaunchKernelGGL(k_rec_loss_bwd, dim3(grid1(n, 4096)), dim3(256), 0, (hipStream_t)stream, pred, tgt, n, 2.0f * scale, gmul,
                        gpred);
     ADALOG_LAUNCH_CHECK("adalog_rec_loss_backward");
+    return 0;
+}
+
+// dst_in[b] = src_in[idx[b]], dst_out[b] = src_out[idx[b]] (rows of row_in / row_out floats, multiples of 4, 16-byte aligned tensors),
+// and sched_dev[0..n_sched) = sched_row[0..n_sched) (n_sched <= 8; sched_row may be null with n_sched = 0), in one launch.
+extern "C" int adalog_brecq_prepare(const float* src_in, const float* src_out, const int64_t* idx, float* dst_in, float* dst_out,
+                                    int64_t bs, int64_t row_in, int64_t row_out, const float* sched_row, float* sched_dev, int n_sched,
+                                    void* stream) {
+    ADALOG_ARG_CHECK(src_in && src_out && idx && dst_in && dst_out && bs >= 1 && row_in >= 4 && row_out >= 4 && row_in % 4 == 0 &&
+                     row_out % 4 == 0, "brecq_prepare: rows must be multiples of 4 floats");
+    ADALOG_ARG_CHECK(((((uintptr_t)src_in) | ((uintptr_t)src_out) | ((uintptr_t)dst_in) | ((uintptr_t)dst_out)) & 15) == 0,
+                     "brecq_prepare: 16-byte aligned tensors");
+    ADALOG_ARG_CHECK(n_sched >= 0 && n_sched <= 8 && (n_sched == 0 || (sched_row && sched_dev)), "brecq_prepare: bad schedule row");
+    const int64_t total = bs * (row_in / 4 + row_out / 4);
+    hipLaunchKernelGGL(k_brecq_prepare, dim3(grid1(total, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(src_in), reinterpret_cast<const float4*>(src_out), idx,
+                       reinterpret_cast<float4*>(dst_in), reinterpret_cast<float4*>(dst_out), bs, row_in / 4, row_out / 4, sched_row,
+                       sched_dev, n_sched);
+    ADALOG_LAUNCH_CHECK("adalog_brecq_prepare");
     return 0;
 }
 

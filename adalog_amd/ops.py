@@ -1607,6 +1607,27 @@ def scaled_softmax_backward(gy: torch.Tensor, y: torch.Tensor, scale: float) -> 
     return gx
 
 
+def brecq_prepare(src_in, src_out, idx, dst_in, dst_out, sched_row=None, sched_dev=None):
+    """dst_in.copy_(src_in[idx]); dst_out.copy_(src_out[idx]); sched_dev.copy_(sched_row) in one launch (adalog_brecq_prepare): what a
+    BRECQ iteration does before its graph is replayed.  False when the tensors do not qualify (the caller takes the three steps)."""
+    ts = (src_in, src_out, dst_in, dst_out)
+    if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.data_ptr() % 16 == 0 for t in ts):
+        return False
+    bs = idx.numel()
+    row_in, row_out = src_in[0].numel(), src_out[0].numel()
+    if (idx.dtype != torch.int64 or not idx.is_cuda or not idx.is_contiguous() or row_in % 4 or row_out % 4 or dst_in.numel() != bs * row_in
+            or dst_out.numel() != bs * row_out):
+        return False
+    ns = 0 if sched_row is None else sched_row.numel()
+    if ns and not (ns <= 8 and sched_row.is_cuda and sched_row.dtype == torch.float32 and sched_row.is_contiguous()
+                   and sched_dev is not None and sched_dev.numel() >= ns and sched_dev.is_contiguous()):
+        return False
+    rc = _lib.load().adalog_brecq_prepare(src_in.data_ptr(), src_out.data_ptr(), idx.data_ptr(), dst_in.data_ptr(), dst_out.data_ptr(), bs,
+                                         row_in, row_out, _ptr(sched_row if ns else None), _ptr(sched_dev if ns else None), ns, _stream())
+    _lib.check(rc, "adalog_brecq_prepare")
+    return True
+
+
 def merge_heads(parts, B: int, N: int, H: int, D: int) -> torch.Tensor:
     """The P <= 4 tensors [B, H, N, D] (None = zeros) -> [B, N, P*H*D]: the gradient of permute_heads from its parts' gradients."""
     P = len(parts)

@@ -25,6 +25,9 @@ from ..quantizers import adaround as adaround_mod
 from .calibrator import QuantCalibrator
 from . import models as M
 
+# gather of the mini-batch (inputs, outputs) and the iteration's schedule row in ONE launch before a graph replay (adalog_brecq_prepare)
+PREPARE_FUSED = os.environ.get("ADALOG_BRECQ_PREPARE", "1") != "0"
+
 
 class HipAdam(torch.optim.Optimizer):
     """torch.optim.Adam with its default options (what reference utils/block_recon.py:108-109 constructs), stepping ALL tensors
@@ -293,8 +296,9 @@ class BlockReconstructor(QuantCalibrator):
 
         sched_block, sched_base = None, 0
 
-        def next_schedule(it):
-            """Row `it` of the schedule table -> sched_dev (b of iteration it, its gate, the learning rate it steps with)."""
+        def next_schedule(it, copy=True):
+            """Row `it` of the schedule table -> sched_dev (b of iteration it, its gate, the learning rate it steps with); returned (and
+            not copied) with ``copy=False``: the replay path hands it to adalog_brecq_prepare together with the mini-batch gather."""
             nonlocal sched_block, sched_base
             if sched_block is None or it >= sched_base + sched_block.shape[0]:
                 cnt = min(IDX_AHEAD, iters - it)
@@ -307,7 +311,9 @@ class BlockReconstructor(QuantCalibrator):
                     twin.step()                              # (block_recon.py:124-125: the scheduler steps after the optimiser)
                 host = torch.tensor(rows, dtype=torch.float32).pin_memory()
                 sched_block, sched_base = host.to(device, non_blocking=True), it
-            sched_dev.copy_(sched_block[it - sched_base])
+            if copy:
+                sched_dev.copy_(sched_block[it - sched_base])
+            return sched_block[it - sched_base]
 
         def fixed_rec_loss():
             """the block's reconstruction loss as it stands (soft rounding targets, training-form quantisers: the forward values of an
@@ -324,8 +330,10 @@ class BlockReconstructor(QuantCalibrator):
         try:
             for it in range(iters):
                 idx = next_indices(it)
+                replaying = use_graph and graph is not None and it >= 3
+                sched_row = None
                 if table_mode:
-                    next_schedule(it)
+                    sched_row = next_schedule(it, copy=not replaying)
                 if not use_graph or it < 3:                  # eager (and the warm-up iterations before the capture)
                     eager_step(block.raw_input[idx].to(device), block.raw_out[idx].to(device))
                     if iter_hook is not None:
@@ -339,12 +347,19 @@ class BlockReconstructor(QuantCalibrator):
                         b_dev = torch.zeros(1, dtype=torch.float32, device=device)
                         rw_dev = torch.zeros(1, dtype=torch.float32, device=device)
                 else:
-                    if block.raw_input.device == static_inp.device:
-                        torch.index_select(block.raw_input, 0, idx, out=static_inp)
-                        torch.index_select(block.raw_out, 0, idx, out=static_out)
-                    else:                                        # keep_gpu=False: block data lives on the host
-                        static_inp.copy_(block.raw_input[idx])
-                        static_out.copy_(block.raw_out[idx])
+                    be_ = backend.get() if device.type == 'cuda' else None
+                    one = (PREPARE_FUSED and be_ is not None and hasattr(be_, "brecq_prepare")
+                           and block.raw_input.device == static_inp.device
+                           and be_.brecq_prepare(block.raw_input, block.raw_out, idx, static_inp, static_out, sched_row, sched_dev))
+                    if not one:                                  # (gather + gather + schedule copy as separate launches)
+                        if sched_row is not None:
+                            sched_dev.copy_(sched_row)
+                        if block.raw_input.device == static_inp.device:
+                            torch.index_select(block.raw_input, 0, idx, out=static_inp)
+                            torch.index_select(block.raw_out, 0, idx, out=static_out)
+                        else:                                    # keep_gpu=False: block data lives on the host
+                            static_inp.copy_(block.raw_input[idx])
+                            static_out.copy_(block.raw_out[idx])
                 active = loss_func.advance()                 # iteration counter, b of this iteration
                 if not table_mode:
                     b_dev.fill_(float(loss_func.b))

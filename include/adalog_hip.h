@@ -424,6 +424,10 @@ int adalog_log_fake_quant_f32_pre(const float* x, float* y, uint8_t* bins, int64
 int adalog_log_fq_backward_pre(const float* gy, const float* x, const float* y, float* gx, int64_t n, const float* scale,
                                const int64_t* q, int n_bits, const float* shift, int sub_shift, float* gscale, float* workspace,
                                int pre, void* stream);
+/* what precedes a captured BRECQ iteration's replay (block_recon.py:114-117) in one launch: dst_in[b] = src_in[idx[b]],
+ * dst_out[b] = src_out[idx[b]] (rows of row_in / row_out floats, multiples of 4), sched_dev[0..n_sched) = sched_row[0..n_sched) */
+int adalog_brecq_prepare(const float* src_in, const float* src_out, const int64_t* idx, float* dst_in, float* dst_out, int64_t bs,
+                         int64_t row_in, int64_t row_out, const float* sched_row, float* sched_dev, int n_sched, void* stream);
 int adalog_softmax_adalog_pack_bf16(const float* x, int64_t rows, int S, float mul, const float* scale, const float* qv, int n_bits,
                                     const float* mant37, void* out, int64_t Kp, void* stream);
 int adalog_attn_split_pack(const float* qkv, int B, int N, int H, const float* q_scale, const float* q_zp, int q_bits,

@@ -2007,3 +2007,16 @@ def test_adam_multi_matches_torch_adam_and_counts_its_steps(ops):
         assert step.item() == it + 1
     for p_, r_ in zip(ps, ref):
         torch.testing.assert_close(p_, r_.detach(), rtol=2e-6, atol=1e-7)
+
+
+def test_brecq_prepare_equals_two_gathers_and_a_copy(ops):
+    """adalog_brecq_prepare: the mini-batch rows of a block's stored inputs / outputs and the iteration's schedule row in one launch."""
+    gen = g(9800)
+    src_in = torch.randn(50, 197, 384, generator=gen).to(DEV); src_out = torch.randn(50, 197, 96, generator=gen).to(DEV)
+    idx = torch.randperm(50, generator=gen)[:32].to(DEV)
+    dst_in = torch.empty(32, 197, 384, device=DEV); dst_out = torch.empty(32, 197, 96, device=DEV)
+    table = torch.randn(7, 3, generator=gen).to(DEV); sched = torch.zeros(3, device=DEV)
+    assert ops.brecq_prepare(src_in, src_out, idx, dst_in, dst_out, table[4], sched)
+    assert torch.equal(dst_in, src_in[idx]) and torch.equal(dst_out, src_out[idx]) and torch.equal(sched, table[4])
+    assert ops.brecq_prepare(src_in, src_out, idx, dst_in, dst_out)                        # no schedule row
+    assert not ops.brecq_prepare(src_in[:, :, :3], src_out, idx, dst_in, dst_out)          # (a view that does not qualify: the caller composes)
