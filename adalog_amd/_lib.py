@@ -128,6 +128,7 @@ SIGNATURES = {
     "adalog_gemm_f32x3_planes_workspace_bytes": (i64, [i32, i32, i32, i32, i32, i32]),
     "adalog_gemm_f32x3_planes": (i32, [p, i64, p, i64, p, i64, i32, i32, i32, i32, i64, i64, p, f32, p, i32, i32, p, p]),
     "adalog_gemm_f32x3": (i32, [p, i64, i32, p, i64, i32, p, i64, i32, i32, i32, i32, i64, i64, i64, p, f32, p, i32, i32, i32, p, p]),
+    "adalog_gemm_f32x3_add": (i32, [p, i64, i32, p, i64, i32, p, i64, i32, i32, i32, i32, i64, i64, i64, p, f32, p, i32, i32, i32, p, p, p]),
     "adalog_gemm_f32x3_g2": (i32, [p, i64, i32, p, i64, i32, p, i64, i32, i32, i32, i32, i64, i64, i64, i32, i64, i64, i64, p, f32, p,
                              i32, i32, i32, p, p]),
     "adalog_shift_fold": (i32, [p, p, p, p, i32, i32, p, p]),

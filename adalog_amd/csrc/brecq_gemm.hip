@@ -543,7 +543,9 @@ __global__ __launch_bounds__(128 * WN, (RI * CJ >= 8 ? 1 : 2)) void k_bq_gemm(Bq
 // C[g][m][n] = alpha * sum_s part[s][g][m][n] + bias[n]   (fixed order: bit-reproducible)
 __global__ __launch_bounds__(256) void k_bq_reduce(const float* __restrict__ part, int S, int64_t gmn, int M, int N,
                                                    float* __restrict__ C, int64_t ldc, int64_t sCg, int Gi, int64_t sCo,
-                                                   const float* __restrict__ bias, float alpha, const float* __restrict__ alpha_dev) {
+                                                   const float* __restrict__ bias, float alpha, const float* __restrict__ alpha_dev,
+                                                   const float* __restrict__ addend) {
+    // addend (optional): laid out like C, added last -- the residual stream of a transformer block (x + fc2(...)) rides in this pass
     const float a = alpha * (alpha_dev ? alpha_dev[0] : 1.0f);
     if (((N | (int)ldc | (int)(sCg | sCo)) & 3) != 0) {          // element form (N, ldc or the group stride not a multiple of 4)
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < gmn; e += (int64_t)gridDim.x * 256) {
@@ -551,7 +553,9 @@ __global__ __launch_bounds__(256) void k_bq_reduce(const float* __restrict__ par
             for (int s = 1; s < S; ++s) acc += part[(int64_t)s * gmn + e];
             const int64_t g = e / ((int64_t)M * N), r = e - g * (int64_t)M * N;
             const int m = (int)(r / N), n = (int)(r - (int64_t)m * N);
-            C[(g % Gi) * sCg + (g / Gi) * sCo + (int64_t)m * ldc + n] = acc * a + (bias ? bias[n] : 0.0f);
+            const int64_t o = (g % Gi) * sCg + (g / Gi) * sCo + (int64_t)m * ldc + n;
+            const float v = acc * a + (bias ? bias[n] : 0.0f);
+            C[o] = addend ? v + addend[o] : v;
         }
         return;
     }
@@ -570,7 +574,23 @@ __global__ __launch_bounds__(256) void k_bq_reduce(const float* __restrict__ par
             const float4 b = *reinterpret_cast<const float4*>(bias + n);
             acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
         }
-        *reinterpret_cast<float4*>(C + (g % Gi) * sCg + (g / Gi) * sCo + (int64_t)m * ldc + n) = acc;
+        const int64_t o = (g % Gi) * sCg + (g / Gi) * sCo + (int64_t)m * ldc + n;
+        if (addend) {
+            const float4 r = *reinterpret_cast<const float4*>(addend + o);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        *reinterpret_cast<float4*>(C + o) = acc;
+    }
+}
+
+// C += addend over the same [G][M][N] layout: the products that are NOT split along K take the residual in a pass of their own
+__global__ __launch_bounds__(256) void k_bq_addend(float* __restrict__ C, const float* __restrict__ addend, int64_t gmn, int M, int N,
+                                                   int64_t ldc, int64_t sCg, int Gi, int64_t sCo) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < gmn; e += (int64_t)gridDim.x * 256) {
+        const int64_t g = e / ((int64_t)M * N), r = e - g * (int64_t)M * N;
+        const int m = (int)(r / N), n = (int)(r - (int64_t)m * N);
+        const int64_t o = (g % Gi) * sCg + (g / Gi) * sCo + (int64_t)m * ldc + n;
+        C[o] += addend[o];
     }
 }
 
@@ -729,7 +749,7 @@ extern "C" int64_t adalog_gemm_f32x3_workspace_bytes(int M, int N, int K, int G,
 static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_t ldb, int transB, int64_t bplane, float* C,
                   int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, const float* bias, float alpha,
                   const float* alpha_dev, int allow_split, int pa, int pb, float* workspace, void* stream, int Gi = 0,
-                  int64_t sAo = 0, int64_t sBo = 0, int64_t sCo = 0) {
+                  int64_t sAo = 0, int64_t sBo = 0, int64_t sCo = 0, const float* addend = nullptr) {
     // the integer forward form is built without the K-tail masking: with K % 16 != 0 it runs as a general product (same result)
     if (pa == 1 && pb == 3 && (K & (BQ_KS - 1)) != 0) pa = 3;
     if (pa == 1 && pb == 2 && (K & (BQ_KS - 1)) != 0) pa = 2;
@@ -761,8 +781,15 @@ static int bq_run(const float* A, int64_t lda, int transA, const void* B, int64_
         const int64_t gmn = (int64_t)G * M * N;
         int blocks = (int)((gmn / 4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_bq_reduce, dim3(blocks), dim3(256), 0, st, workspace, pl.S, gmn, M, N, C, ldc, sCg, a.Gi, sCo, bias, alpha, alpha_dev);
+        hipLaunchKernelGGL(k_bq_reduce, dim3(blocks), dim3(256), 0, st, workspace, pl.S, gmn, M, N, C, ldc, sCg, a.Gi, sCo, bias, alpha, alpha_dev,
+                           addend);
         ADALOG_LAUNCH_CHECK("adalog_gemm_f32x3/reduce");
+    } else if (addend) {
+        const int64_t gmn = (int64_t)G * M * N;
+        int blocks = (int)((gmn + 1023) / 1024);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(k_bq_addend, dim3(blocks), dim3(256), 0, st, C, addend, gmn, M, N, ldc, sCg, a.Gi, sCo);
+        ADALOG_LAUNCH_CHECK("adalog_gemm_f32x3/addend");
     }
     return 0;
 }
@@ -782,6 +809,24 @@ extern "C" int adalog_gemm_f32x3_g2(const float* A, int64_t lda, int transA, con
                                     int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, int Gi,
                                     int64_t sAo, int64_t sBo, int64_t sCo, const float* bias, float alpha, const float* alpha_dev,
                                     int allow_split, int exactA, int exactB, float* workspace, void* stream);
+// ... + addend[g][m][n] (laid out like C; may be null): added in the split product's reduction pass (no extra launch) or, for a product
+// that is not split, by a pass of its own -- x + fc2(...) of a transformer block inside a BRECQ iteration.
+extern "C" int adalog_gemm_f32x3_add(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
+                                     int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg,
+                                     const float* bias, float alpha, const float* alpha_dev, int allow_split, int exactA, int exactB,
+                                     const float* addend, float* workspace, void* stream) {
+    if (M == 0 || N == 0 || G == 0) return 0;
+    ADALOG_ARG_CHECK(A && B && C && M > 0 && N > 0 && K > 0 && G > 0, "gemm_f32x3_add: bad arguments");
+    ADALOG_ARG_CHECK((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)addend) & 15) == 0, "gemm_f32x3_add: operands must be 16-byte aligned");
+    ADALOG_ARG_CHECK(!bias || (N & 15) == 0, "gemm_f32x3_add: a fused bias needs N to be a multiple of 16");
+    ADALOG_ARG_CHECK(lda >= (transA ? M : K) && ldb >= (transB ? N : K) && ldc >= N, "gemm_f32x3_add: leading dimensions too small");
+    ADALOG_ARG_CHECK((int64_t)(transA ? K : M) * lda * 4 < 0x7fffffffLL && (int64_t)(transB ? K : N) * ldb * 4 < 0x7fffffffLL,
+                     "gemm_f32x3_add: an operand matrix exceeds 2 GiB");
+    int pa, pb;
+    bq_forms(exactA, exactB, transA, transB, pa, pb);
+    return bq_run(A, lda, transA, B, ldb, transB, 0, C, ldc, M, N, K, G, sAg, sBg, sCg, bias, alpha, alpha_dev, allow_split, pa, pb,
+                  workspace, stream, 0, 0, 0, 0, addend);
+}
 extern "C" int adalog_gemm_f32x3(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C,
                                  int64_t ldc, int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg,
                                  const float* bias, float alpha, const float* alpha_dev, int allow_split, int exactA, int exactB,

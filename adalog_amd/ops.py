@@ -1459,7 +1459,7 @@ def gemm_f32x3_ok(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor]
 
 def gemm_f32x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None, alpha: float = 1.0,
                allow_split: bool = True, alpha_dev: Optional[torch.Tensor] = None, exact_a: bool = False,
-               exact_b: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               exact_b: bool = False, out: Optional[torch.Tensor] = None, addend: Optional[torch.Tensor] = None) -> torch.Tensor:
     """alpha * alpha_dev[0] * a @ b^T (+ bias) for fp32 operands of either memory orientation, at fp32 accuracy on the bf16
     matrix cores (csrc/brecq_gemm.hip).  a: [..., M, K], b: [..., N, K] -> [..., M, N] (contiguous, or written into ``out``: any
     view whose last dim is contiguous and whose leading dims form at most two stride levels).
@@ -1478,6 +1478,16 @@ def gemm_f32x3(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = 
     sp, ea, eb = (1 if allow_split else 0), int(exact_a), int(exact_b)
     wsb = int(lib.adalog_gemm_f32x3_workspace_bytes(M, N, K, G, sp, ea, eb, la[0], lb[0]))
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=a.device) if wsb else None
+    if addend is not None:
+        # ``addend`` (fp32, the shape of the result, contiguous): added to the product -- inside the split product's reduction pass
+        # (adalog_gemm_f32x3_add); one level of groups, contiguous result
+        addend = _f32c(addend, "addend")
+        if Gi != G or addend.numel() != out.numel() or not out.is_contiguous() or addend.data_ptr() % 16:
+            raise _lib.AdalogHipError("gemm_f32x3: addend needs a contiguous result of one group level")
+        rc = lib.adalog_gemm_f32x3_add(a.data_ptr(), la[1], la[0], b.data_ptr(), lb[1], lb[0], out.data_ptr(), lo[1], M, N, K, G, sa, sb, sc,
+                                       _ptr(bias), float(alpha), _ptr(alpha_dev), sp, ea, eb, addend.data_ptr(), _ptr(ws), _stream())
+        _lib.check(rc, "adalog_gemm_f32x3_add")
+        return out
     rc = lib.adalog_gemm_f32x3_g2(a.data_ptr(), la[1], la[0], b.data_ptr(), lb[1], lb[0], out.data_ptr(), lo[1], M, N, K, G,
                                   sa, sb, sc, Gi, sao, sbo, sco, _ptr(bias), float(alpha), _ptr(alpha_dev), sp, ea, eb, _ptr(ws),
                                   _stream())

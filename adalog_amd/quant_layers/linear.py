@@ -80,16 +80,17 @@ class MinMaxQuantLinear(nn.Linear):
     def quant_input(self, x):
         return self.a_quantizer(x)
 
-    def quant_forward(self, x, pre_gelu=False):
+    def quant_forward(self, x, pre_gelu=False, addend=None):
         """``pre_gelu``: the layer's input is GELU(x) -- handed to an activation quantiser that applies it in its own kernels
-        (AdaLogQuantizer.forward), else applied here."""
+        (AdaLogQuantizer.forward), else applied here.  ``addend``: added to the result (inside the product where that is free)."""
         assert self.calibrated, f"Module should be calibrated before run quant_forward for {self}"
         if pre_gelu and not hasattr(self.a_quantizer, "fused_gelu_ok"):
             x, pre_gelu = F.gelu(x), False
         w_sim, bias_sim = self.quant_weight_bias()
         if w_sim.requires_grad:                          # a BRECQ iteration: the contractions run on csrc/brecq_gemm.hip
-            return train_mm.quant_linear(x, self.a_quantizer, w_sim, bias_sim, pre_gelu=pre_gelu)
-        return F.linear(self.a_quantizer(x, pre_gelu=True) if pre_gelu else self.quant_input(x), w_sim, bias_sim)
+            return train_mm.quant_linear(x, self.a_quantizer, w_sim, bias_sim, pre_gelu=pre_gelu, addend=addend)
+        out = F.linear(self.a_quantizer(x, pre_gelu=True) if pre_gelu else self.quant_input(x), w_sim, bias_sim)
+        return out if addend is None else addend + out
 
     def debug_only_quant_weight(self, x):
         w_sim, bias_sim = self.quant_weight_bias()
@@ -794,8 +795,8 @@ class PostGeluLogBasedBatchingQuantLinear(AsymmetricallyBatchingQuantLinear):
         aq = self.a_quantizer
         if (torch.is_grad_enabled() and (self.w_quantizer.training_mode or aq.training_mode)) \
                 or not isinstance(self.w_quantizer, UniformQuantizer) or aq.training_mode:
-            out = MinMaxQuantLinear.quant_forward(self, x, pre_gelu=pre_gelu)      # (a BRECQ iteration: GELU inside the quantiser's kernels)
-            return out if addend is None else addend + out
+            # (a BRECQ iteration: GELU inside the quantiser's kernels, the residual inside the product's reduction pass)
+            return MinMaxQuantLinear.quant_forward(self, x, pre_gelu=pre_gelu, addend=addend)
         be = backend.get()
         dev = x.device
         lead = x.shape[:-1]

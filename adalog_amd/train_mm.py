@@ -33,6 +33,7 @@ HEADS_LAST = os.environ.get("ADALOG_BRECQ_HEADS_LAST", "1") != "0"        # soft
 W_KMAJOR = os.environ.get("ADALOG_BRECQ_WT", "1") != "0"
 QKV_FUSED = os.environ.get("ADALOG_BRECQ_QKV_QUANT", "1") != "0"          # q / k / v split + their three quantisers as one pass
 FUSED_SOFTMAX = os.environ.get("ADALOG_BRECQ_SOFTMAX", "1") != "0"         # attn * scale + softmax as one pass each way
+ADDEND_FUSED = os.environ.get("ADALOG_BRECQ_ADDEND", "1") != "0"           # the residual behind fc2 added inside the product's reduction pass
 INT_ACT = os.environ.get("ADALOG_BRECQ_INT_ACT", "1") != "0"            # integer activation operand (0: s_a * x_int as fp32)
 # bf16 terms per general operand of the GRADIENT contractions (dL/dx, dL/dw, the attention products' backward): 2 = hi + mid (2^-16
 # relative: three MFMA products instead of six, two instead of three against the integer activation); 3 = the forward's three-term
@@ -99,11 +100,17 @@ class _LinearFn(torch.autograd.Function):
     """y = x2 @ w2^T + bias with general fp32 operands (x2 [M, K], w2 [N, K])."""
 
     @staticmethod
-    def forward(ctx, x2, w2, bias):
+    def forward(ctx, x2, w2, bias, addend=None):
+        """``addend`` [M, N] (optional): added to the product -- in the reduction pass of a K-split product (the residual stream of a
+        transformer block behind fc2: no separate add launch)."""
         be = backend.get()
         ctx.save_for_backward(x2, w2)
+        ctx.has_addend = addend is not None
         if WEIGHT_PLANES:
-            return be.gemm_f32x3_planes(x2, _planes(be, w2), x2.shape[1], bias)
+            out = be.gemm_f32x3_planes(x2, _planes(be, w2), x2.shape[1], bias)
+            return out if addend is None else out + addend
+        if addend is not None:
+            return be.gemm_f32x3(x2, _kmajor(w2), bias, exact_a=FWD_TERMS, exact_b=FWD_TERMS, addend=addend)
         return be.gemm_f32x3(x2, _kmajor(w2), bias, exact_a=FWD_TERMS, exact_b=FWD_TERMS)
 
     @staticmethod
@@ -118,7 +125,7 @@ class _LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = be.gemm_f32x3(gy.t(), x2.t(), exact_a=GRAD_TERMS, exact_b=GRAD_TERMS)
         gb = gy.sum(0) if ctx.needs_input_grad[2] else None
-        return gx, gw, gb
+        return gx, gw, gb, (gy if ctx.has_addend and ctx.needs_input_grad[3] else None)
 
 
 class _QuantLinearFn(torch.autograd.Function):
@@ -153,30 +160,37 @@ class _QuantLinearFn(torch.autograd.Function):
         return gx, gs, None, gw, gb, None
 
 
-def linear(x_sim, w_sim, bias):
-    """F.linear(x_sim, w_sim, bias) for a BRECQ iteration."""
+def linear(x_sim, w_sim, bias, addend=None):
+    """F.linear(x_sim, w_sim, bias) (+ addend, the shape of the result) for a BRECQ iteration."""
     lead = x_sim.shape[:-1]
     x2 = x_sim.reshape(-1, x_sim.shape[-1])
     if not (torch.is_grad_enabled() and _usable(x2, w_sim, bias)):
-        return F.linear(x_sim, w_sim, bias)
-    return _LinearFn.apply(x2.contiguous(), w_sim.contiguous(), bias).view(*lead, w_sim.shape[0])
+        out = F.linear(x_sim, w_sim, bias)
+        return out if addend is None else addend + out
+    if addend is not None and ADDEND_FUSED and addend.shape == lead + (w_sim.shape[0],) and addend.dtype == torch.float32:
+        a2 = addend.reshape(-1, w_sim.shape[0]).contiguous()
+        if a2.data_ptr() % 16 == 0:
+            return _LinearFn.apply(x2.contiguous(), w_sim.contiguous(), bias, a2).view(*lead, w_sim.shape[0])
+    out = _LinearFn.apply(x2.contiguous(), w_sim.contiguous(), bias).view(*lead, w_sim.shape[0])
+    return out if addend is None else addend + out
 
 
-def quant_linear(x, a_quantizer, w_sim, bias, pre_gelu=False):
-    """F.linear(a_quantizer(x), w_sim, bias) for a BRECQ iteration; fuses a per-tensor asymmetric uniform activation quantiser.
-    ``pre_gelu``: the quantiser's input is GELU(x), applied by the quantiser itself (AdaLogQuantizer.forward)."""
+def quant_linear(x, a_quantizer, w_sim, bias, pre_gelu=False, addend=None):
+    """F.linear(a_quantizer(x), w_sim, bias) (+ addend) for a BRECQ iteration; fuses a per-tensor asymmetric uniform activation
+    quantiser.  ``pre_gelu``: the quantiser's input is GELU(x), applied by the quantiser itself (AdaLogQuantizer.forward)."""
     from .quantizers.uniform import UniformQuantizer
     if pre_gelu:
-        return linear(a_quantizer(x, pre_gelu=True), w_sim, bias)
+        return linear(a_quantizer(x, pre_gelu=True), w_sim, bias, addend)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     aq = a_quantizer
     fused = (INT_ACT and type(aq) is UniformQuantizer and aq.training_mode and not aq.sym and aq.n_bits < 8
              and aq.scale.numel() == 1 and torch.is_grad_enabled() and _usable(x2, w_sim, bias))
     if not fused:
-        return linear(aq(x), w_sim, bias)
+        return linear(aq(x), w_sim, bias, addend)
     out = _QuantLinearFn.apply(x2.contiguous(), aq.scale.view(1), aq.zero_point.view(1), w_sim.contiguous(), bias, aq.n_bits)
-    return out.view(*lead, w_sim.shape[0])
+    out = out.view(*lead, w_sim.shape[0])
+    return out if addend is None else addend + out
 
 
 class _SplitHeadsFn(torch.autograd.Function):

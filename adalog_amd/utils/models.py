@@ -67,8 +67,7 @@ class Mlp(nn.Module):
                 and isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none"
                 and all(isinstance(m, nn.Identity) for m in (self.drop1, self.norm, self.drop2))):
             # a BRECQ iteration: GELU and its derivative run inside the kernels of fc2's input quantiser (no GELU pass either way)
-            out = fc2.quant_forward(self.fc1(x), pre_gelu=True)
-            return out if residual is None else residual + out
+            return fc2.quant_forward(self.fc1(x), addend=residual, pre_gelu=True)
         out = self.drop2(self.fc2(self.norm(self.drop1(self.act(self.fc1(x))))))
         return out if residual is None else residual + out
 

@@ -598,6 +598,12 @@ int64_t adalog_gemm_f32x3_workspace_bytes(int M, int N, int K, int G, int allow_
 int adalog_gemm_f32x3(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C, int64_t ldc,
                       int M, int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, const float* bias, float alpha,
                       const float* alpha_dev, int allow_split, int exactA, int exactB, float* workspace, void* stream);
+/* ... + addend[g][m][n] (laid out like C, may be null): added in the split product's reduction pass, or by a pass of its own when the
+ * product is not split -- the residual stream (x + fc2(...)) inside a BRECQ iteration */
+int adalog_gemm_f32x3_add(const float* A, int64_t lda, int transA, const float* B, int64_t ldb, int transB, float* C, int64_t ldc, int M,
+                          int N, int K, int G, int64_t sAg, int64_t sBg, int64_t sCg, const float* bias, float alpha,
+                          const float* alpha_dev, int allow_split, int exactA, int exactB, const float* addend, float* workspace,
+                          void* stream);
 /* The same product over TWO-LEVEL groups: group g = go * Gi + gi sits at gi * s?g + go * s?o in each operand (a [B][H] batch whose
  *   strides do not collapse into one: q / k / v read in place from the qkv output, or softmax.v writing [B][N][H][D] directly, so
  *   that the transpose(1, 2).reshape of reference utils/wrap_net.py:31 is a view).  Gi <= 0 or >= G: one level. */

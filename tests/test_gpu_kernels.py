@@ -2020,3 +2020,17 @@ def test_brecq_prepare_equals_two_gathers_and_a_copy(ops):
     assert torch.equal(dst_in, src_in[idx]) and torch.equal(dst_out, src_out[idx]) and torch.equal(sched, table[4])
     assert ops.brecq_prepare(src_in, src_out, idx, dst_in, dst_out)                        # no schedule row
     assert not ops.brecq_prepare(src_in[:, :, :3], src_out, idx, dst_in, dst_out)          # (a view that does not qualify: the caller composes)
+
+
+@pytest.mark.parametrize("M,N,K", [(6304, 384, 1536), (6304, 384, 384), (130, 64, 96)])
+def test_gemm_f32x3_addend_rides_in_the_reduction_pass(ops, M, N, K):
+    """adalog_gemm_f32x3_add: the product plus an addend laid out like the result -- bit for bit `product + addend`, whether the
+    product is split along K (the addend is added by the reduction pass: fc2's forward inside a BRECQ iteration) or not."""
+    gen = g(9900 + K)
+    a = torch.randn(M, K, generator=gen).to(DEV); b = (torch.randn(N, K, generator=gen) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=gen).to(DEV) if N % 16 == 0 else None
+    add = torch.randn(M, N, generator=gen).to(DEV)
+    for ea in (0, 2):
+        want = ops.gemm_f32x3(a, b, bias, exact_a=ea, exact_b=ea) + add
+        got = ops.gemm_f32x3(a, b, bias, exact_a=ea, exact_b=ea, addend=add)
+        assert torch.equal(got, want)
