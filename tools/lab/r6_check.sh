@@ -1,4 +1,4 @@
-mkdir -p gpurun_out/r6r
-python -m pytest tests/test_gpu_kernels.py -x -q -k "gemm_f32x3" > gpurun_out/r6r/pytest1.log 2>&1; tail -3 gpurun_out/r6r/pytest1.log
-python -m pytest tests/test_gpu_layers.py -x -q > gpurun_out/r6r/pytest2.log 2>&1; tail -3 gpurun_out/r6r/pytest2.log
-for m in deit_small vit_base; do for v in 1 0 1 0; do echo "ADDEND=$v $m"; ADALOG_BRECQ_ADDEND=$v python tools/bench_brecq.py --model $m --iters 600 2>&1 | grep -v amdgpu.ids | tail -1; done; done
+# final tree: whole GPU suite + the default bench line
+mkdir -p gpurun_out/final
+(time timeout 2400 python -m pytest tests -m gpu -q) > gpurun_out/final/pytest_gpu.log 2>&1; tail -4 gpurun_out/final/pytest_gpu.log
+timeout 900 python bench.py > gpurun_out/final/bench.json 2> gpurun_out/final/bench.err; head -c 300 gpurun_out/final/bench.json; echo
