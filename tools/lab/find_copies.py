@@ -40,6 +40,16 @@ for rep in range(2):
     class Spy(TorchFunctionMode):
         def __torch_function__(self, func, types, args=(), kwargs=None):
             name = getattr(func, "__name__", str(func))
+            big = None
+            if os.environ.get("BIG_COPIES") and name in ("contiguous", "clone", "copy_", "reshape", "to", "flatten", "view_as", "t", "float"):
+                for a in args[:2]:
+                    if torch.is_tensor(a) and a.is_cuda and a.numel() >= 200_000 and not a.is_contiguous():
+                        big = (tuple(a.shape), tuple(a.stride()))
+                        break
+            if big is not None and name in ("contiguous", "clone", "reshape", "copy_", "flatten"):
+                fr = [f for f in traceback.extract_stack()[:-1] if "adalog_amd" in f.filename]
+                where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-3:][::-1]) if fr else "?"
+                cnt[("BIG " + name + " " + str(big), where)] += 1
             if name in WATCH:
                 fr = [f for f in traceback.extract_stack()[:-1] if "adalog_amd" in f.filename]
                 where = " <- ".join(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-3:][::-1]) if fr else "?"
